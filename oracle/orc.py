@@ -1,0 +1,164 @@
+"""ctypes binding of the C oracle (oracle/secp256k1_oracle.c).  TEST INFRASTRUCTURE ONLY:
+import from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, nowhere else."""
+import ctypes
+import os
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "liblnamd_oracle.so")
+_OSSL = os.path.join(_DIR, "libossl_xcheck.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_DIR, f) for f in ("secp256k1_oracle.c", "secp256k1_oracle.h", "openssl_xcheck.c", "Makefile")]
+    stale = force or not (os.path.exists(_LIB) and os.path.exists(_OSSL))
+    if not stale:
+        t = min(os.path.getmtime(_LIB), os.path.getmtime(_OSSL))
+        stale = any(os.path.getmtime(s) > t for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _DIR, "-s"])
+
+
+_lib = None
+_ossl = None
+_u8p = ctypes.c_char_p
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB)
+        L.orc_init.restype = None
+        for name, args in {
+            "orc_pubkey_parse": [_u8p, ctypes.c_size_t, _u8p],
+            "orc_sig_parse_compact": [_u8p],
+            "orc_sig_parse_der": [_u8p, ctypes.c_size_t, _u8p],
+            "orc_signature_from_der": [_u8p, ctypes.c_size_t, _u8p, ctypes.POINTER(ctypes.c_int)],
+            "orc_ecdsa_verify": [_u8p, _u8p, _u8p, ctypes.c_size_t],
+            "orc_schnorr_verify": [_u8p, _u8p, _u8p],
+            "orc_sigcheck_channel_announcement": [_u8p, ctypes.c_size_t],
+            "orc_sigcheck_channel_update": [_u8p, ctypes.c_size_t, _u8p],
+            "orc_sigcheck_node_announcement": [_u8p, ctypes.c_size_t],
+            "orc_pubkey_create": [_u8p, _u8p],
+            "orc_ecdsa_sign": [_u8p, _u8p, _u8p, _u8p],
+            "orc_schnorr_sign": [_u8p, _u8p, _u8p, _u8p],
+        }.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = ctypes.c_int
+        for name in ("orc_sha256", "orc_sha256d"):
+            f = getattr(L, name)
+            f.argtypes = [_u8p, ctypes.c_size_t, _u8p]
+            f.restype = None
+        L.orc_ecdsa_verify_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        L.orc_ecdsa_verify_batch.restype = None
+        L.orc_schnorr_verify_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_int]
+        L.orc_schnorr_verify_batch.restype = None
+        L.orc_init()
+        _lib = L
+    return _lib
+
+
+def ossl():
+    global _ossl
+    if _ossl is None:
+        build()
+        L = ctypes.CDLL(_OSSL)
+        L.ossl_ecdsa_verify.argtypes = [_u8p, _u8p, _u8p, ctypes.c_size_t]
+        L.ossl_ecdsa_verify.restype = ctypes.c_int
+        _ossl = L
+    return _ossl
+
+
+def sha256(b):
+    out = ctypes.create_string_buffer(32)
+    lib().orc_sha256(bytes(b), len(b), out)
+    return out.raw
+
+
+def sha256d(b):
+    out = ctypes.create_string_buffer(32)
+    lib().orc_sha256d(bytes(b), len(b), out)
+    return out.raw
+
+
+def pubkey_parse(pub):
+    out = ctypes.create_string_buffer(64)
+    return out.raw if lib().orc_pubkey_parse(bytes(pub), len(pub), out) else None
+
+
+def sig_parse_compact(sig64):
+    return bool(lib().orc_sig_parse_compact(bytes(sig64)))
+
+
+def sig_parse_der(der):
+    out = ctypes.create_string_buffer(64)
+    return out.raw if lib().orc_sig_parse_der(bytes(der), len(der), out) else None
+
+
+def signature_from_der(der):
+    out = ctypes.create_string_buffer(64)
+    t = ctypes.c_int(0)
+    if not lib().orc_signature_from_der(bytes(der), len(der), out, ctypes.byref(t)):
+        return None
+    return out.raw, t.value
+
+
+def ecdsa_verify(hash32, sig64, pub):
+    return bool(lib().orc_ecdsa_verify(bytes(hash32), bytes(sig64), bytes(pub), len(pub)))
+
+
+def schnorr_verify(msg32, xonly32, sig64):
+    return bool(lib().orc_schnorr_verify(bytes(msg32), bytes(xonly32), bytes(sig64)))
+
+
+def sigcheck_channel_announcement(msg):
+    return lib().orc_sigcheck_channel_announcement(bytes(msg), len(msg))
+
+
+def sigcheck_channel_update(msg, node_id33):
+    return lib().orc_sigcheck_channel_update(bytes(msg), len(msg), bytes(node_id33))
+
+
+def sigcheck_node_announcement(msg):
+    return lib().orc_sigcheck_node_announcement(bytes(msg), len(msg))
+
+
+def pubkey_create(seckey32):
+    out = ctypes.create_string_buffer(65)
+    return out.raw if lib().orc_pubkey_create(bytes(seckey32), out) else None
+
+
+def ecdsa_sign(hash32, seckey32, nonce32):
+    out = ctypes.create_string_buffer(64)
+    return out.raw if lib().orc_ecdsa_sign(bytes(hash32), bytes(seckey32), bytes(nonce32), out) else None
+
+
+def schnorr_sign(msg32, seckey32, aux32=b"\x00" * 32):
+    out = ctypes.create_string_buffer(64)
+    return out.raw if lib().orc_schnorr_sign(bytes(msg32), bytes(seckey32), bytes(aux32), out) else None
+
+
+def ecdsa_verify_batch(hashes, sigs, pubs, publen, nthreads=1):
+    """numpy uint8 arrays [n,32], [n,64], [n,publen] (C-contiguous) -> uint8 [n]"""
+    import numpy as np
+    n = hashes.shape[0]
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_ecdsa_verify_batch(n, hashes.ctypes.data, sigs.ctypes.data, pubs.ctypes.data, publen,
+                                 out.ctypes.data, nthreads)
+    return out
+
+
+def schnorr_verify_batch(msgs, xonly, sigs, nthreads=1):
+    import numpy as np
+    n = msgs.shape[0]
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_schnorr_verify_batch(n, msgs.ctypes.data, xonly.ctypes.data, sigs.ctypes.data, out.ctypes.data, nthreads)
+    return out
+
+
+def ossl_ecdsa_verify(hash32, sig64, pub):
+    return ossl().ossl_ecdsa_verify(bytes(hash32), bytes(sig64), bytes(pub), len(pub))

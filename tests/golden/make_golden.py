@@ -1,0 +1,450 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/kat.json.
+
+Sources
+  * literal vectors held by the reference's own tests for this path (provenance = file:line
+    under /root/reference, Core Lightning v26.06.6) -- copied as hex, verdicts asserted by
+    the reference where it asserts them, derived with oracle/pyref.py otherwise;
+  * BIP-340 official test vectors 0-14 (not in the reference tree, no network: recalled
+    offline; 0-3 self-authenticate by re-signing with the published secret keys, 4/6/8/9/10
+    by the property their CSV comment documents -- all checked below);
+  * edge-case classes SURVEY.md 8(c) lists as unpinned in-tree, synthesised with the
+    spec-level big-int model oracle/pyref.py from a fixed seed.
+
+Expected verdicts in the JSON are pyref's (and, where the reference asserts one, the
+reference's).  Run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import pyref as R  # noqa: E402
+
+P, N, G = R.P, R.N, R.G
+
+
+class Rng:
+    """deterministic byte stream (SHA-256 counter mode) so the file is reproducible"""
+
+    def __init__(self, seed):
+        self.seed = seed.encode()
+        self.ctr = 0
+
+    def bytes(self, n):
+        out = b""
+        while len(out) < n:
+            out += hashlib.sha256(self.seed + self.ctr.to_bytes(8, "big")).digest()
+            self.ctr += 1
+        return out[:n]
+
+    def scalar(self):
+        while True:
+            v = int.from_bytes(self.bytes(32), "big")
+            if 1 <= v < N:
+                return v
+
+    def below(self, n):
+        return int.from_bytes(self.bytes(40), "big") % n
+
+
+def b32(v):
+    return v.to_bytes(32, "big")
+
+
+# ------------------------------------------------------------------------------------ in-tree KATs
+KAT_G_MSG = (
+    "010011effc9ed10fceccfae5f9e3fef20d983b06eed030e968fd8d1e6c5905e18f9f2df6a43f00d7c0ddf52e0467ab1e32394051b72ea6343fb008a4117c265f3d7b"
+    "732bab7df4ee404ac926aef6610f4eb33e31baabfd9afdbf897c8a80057efa1468362b4d2cc0a5482013e1058c8205717f85c3bc82c3ea89f17cfeac21e2cb2a"
+    "c65b429f79b24fbd51094bee5e080d4c7cfc28a584e279075643054a48b2972f0b72becfd57e03297bf0102b09329982e0ac839dc120959c07456431d3c8fd14"
+    "30ffe2cc2710e9600e602779c9cf5f91e95874ef4bcf9f0bdda2ce2be97bba562848a2717acdb8dec30bd5073f2f853776cc98f0b6cddc2dcfb57aa69fa7c434"
+    "00030800006fe28c0ab6f1b372c1a6a246ae63f74f931e8365e15a089c68d619000000000009984d00063a0001"
+    "0254ff808f53b2f8c45e74b70430f336c6c76ba2f4af289f48d6086ae6e60462d303baa70886d9200af0ffbd3f9e18d96008331c858456b16e3a9b41e735c6208fef"
+    "03c8731bbac446b7d11b7f5a1861c7d2c87ccf429780c74463de3428dceeb73ad702b3e55c7a1a6cdf17a83a801f7f8f698e4980323e2584f27a643a1b0519ebf8c7")
+
+KAT_O = dict(
+    tx="0200000001e1ebca08cf1c301ac563580a1126d5c8fcb0e5e2043230b852c726553caf1e1d0000000000000000000160ae0a0000000000"
+       "22002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d61927436041796d000000",
+    der="30450221009b2e0eef267b94c3899fb0dc7375012e2cee4c10348a068fe78d1b82b4b14036022077c3fad3adac2ddf33f415e45f0daf66"
+        "58b7a0b09647de4443938ae2dbafe2b901",
+    wscript="76a914a8c40c334351dbe8e5908544f1c98fbcfb8719fc8763ac6721038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de05"
+            "4432eb7f7c820120876475527c2103cf8e2f193a6aed60db80af75f3c8d59c2de735b299b7c7083527be9bd23b77a852ae67a914b8bcd51e"
+            "fa35be1e50ae2d5f72f4500acb005c9c88ac6868",
+    key="038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f",
+    input_sat=700000, fee_ok=165750)
+
+KAT_B11 = dict(
+    sig="269fa68a6051f26991ab50eb851494d1a4b9c616aeee892ff50a144af471554a3057b2fee45910e267c4ef6067da10016cf5519237b3ca1c1c2014cc1d6f69a6",
+    data="6c6e626332306d0b25fe64500d04444444444444444444444444444444444444444444444444444444444444444021a00008101820283038404800081018202830"
+         "3840480008101820283038404808105c343925b6f67e2c340036ed12093dd44e0368df1b6ea26c53dbe4811f58fd5db8c10486a10adac43daa9c8a5a68e09ea10"
+         "692b82226ee190e572db9b90e17a410484ab4050280704000",
+    key="03e7156ae33b0a208d0744199163177e909e80176e55d97a2f221ede0f934dd9ad")
+
+BIP340 = [  # (index, seckey|None, pubkey, aux|None, msg, sig, expected, comment)
+    (0, "0000000000000000000000000000000000000000000000000000000000000003", "F9308A019258C31049344F85F89D5229B531C845836F99B08601F113BCE036F9", "00" * 32, "00" * 32,
+     "E907831F80848D1069A5371B402410364BDF1C5F8307B0084C55F1CE2DCA821525F66A4A85EA8B71E482A74F382D2CE5EBEEE8FDB2172F477DF4900D310536C0", True, ""),
+    (1, "B7E151628AED2A6ABF7158809CF4F3C762E7160F38B4DA56A784D9045190CFEF", "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", "00" * 31 + "01",
+     "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "6896BD60EEAE296DB48A229FF71DFE071BDE413E6D43F917DC8DCF8C78DE33418906D11AC976ABCCB20B091292BFF4EA897EFCB639EA871CFA95F6DE339E4B0A", True, ""),
+    (2, "C90FDAA22168C234C4C6628B80DC1CD129024E088A67CC74020BBEA63B14E5C9", "DD308AFEC5777E13121FA72B9CC1B7CC0139715309B086C960E18FD969774EB8",
+     "C87AA53824B4D7AE2EB035A2B5BBBCCC080E76CDC6D1692C4B0B62D798E6D906", "7E2D58D8B3BCDF1ABADEC7829054F90DDA9805AAB56C77333024B9D0A508B75C",
+     "5831AAEED7B44BB74E5EAB94BA9D4294C49BCF2A60728D8B4C200F50DD313C1BAB745879A5AD954A72C45A91C3A51D3C7ADEA98D82F8481E0E1E03674A6F3FB7", True, ""),
+    (3, "0B432B2677937381AEF05BB02A66ECD012773062CF3FA2549E44F58ED2401710", "25D1DFF95105F5253C4022F628A996AD3A0D95FBF21D468A1B33F8C160D8F517", "FF" * 32, "FF" * 32,
+     "7EB0509757E246F19449885651611CB965ECC1A187DD51B64FDA1EDC9637D5EC97582B9CB13DB3933705B32BA982AF5AF25FD78881EBB32771FC5922EFC66EA3", True,
+     "test fails if msg is reduced modulo p or n"),
+    (4, None, "D69C3509BB99E412E68B0FE8544E72837DFA30746D8BE2AA65975F29D22DC7B9", None, "4DF3C3F68FCC83B27E9D42C90431A72499F17875C81A599B566C9889B9696703",
+     "00000000000000000000003B78CE563F89A0ED9414F5AA28AD0D96D6795F9C6376AFB1548AF603B3EB45C9F8207DEE1060CB71C04E80F593060B07D28308D7F4", True, ""),
+    (5, None, "EEFDEA4CDB677750A420FEE807EACF21EB9898AE79B9768766E4FAA04A2D4A34", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "6CFF5C3BA86C69EA4B7376F31A9BCB4F74C1976089B2D9963DA2E5543E17776969E89B4C5564D00349106B8497785DD7D1D713A8AE82B32FA79D5F7FC407D39B", False, "public key not on the curve"),
+    (6, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "FFF97BD5755EEEA420453A14355235D382F6472F8568A18B2F057A14602975563CC27944640AC607CD107AE10923D9EF7A73C643E166BE5EBEAFA34B1AC553E2", False, "has_even_y(R) is false"),
+    (7, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "1FA62E331EDBC21C394792D2AB1100A7B432B013DF3F6FF4F99FCB33E0E1515F28890B3EDB6E7189B630448B515CE4F8622A954CFE545735AAEA5134FCCDB2BD", False, "negated message"),
+    (8, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "6CFF5C3BA86C69EA4B7376F31A9BCB4F74C1976089B2D9963DA2E5543E177769961764B3AA9B2FFCB6EF947B6887A226E8D7C93E00C5ED0C1834FF0D0C2E6DA6", False, "negated s value"),
+    (9, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "0000000000000000000000000000000000000000000000000000000000000000123DDA8328AF9C23A94C1FEECFD123BA4FB73476F0D594DCB65C6425BD186051", False,
+     "sG - eP is infinite (x(inf) taken as 0)"),
+    (10, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "00000000000000000000000000000000000000000000000000000000000000017615FBAF5AE28864013C099742DEADB4DBA87F11AC6754F93780D5A1837CF197", False,
+     "sG - eP is infinite (x(inf) taken as 1)"),
+    (11, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "4A298DACAE57395A15D0795DDBFD1DCB564DA82B0F269BC70A74F8220429BA1D69E89B4C5564D00349106B8497785DD7D1D713A8AE82B32FA79D5F7FC407D39B", False,
+     "sig[0:32] is not an X coordinate on the curve"),
+    (12, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F69E89B4C5564D00349106B8497785DD7D1D713A8AE82B32FA79D5F7FC407D39B", False, "sig[0:32] is equal to field size"),
+    (13, None, "DFF1D77F2A671C5F36183726DB2341BE58FEAE1DA2DECED843240F7B502BA659", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "6CFF5C3BA86C69EA4B7376F31A9BCB4F74C1976089B2D9963DA2E5543E177769FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141", False, "sig[32:64] is equal to curve order"),
+    (14, None, "FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC30", None, "243F6A8885A308D313198A2E03707344A4093822299F31D0082EFA98EC4E6C89",
+     "6CFF5C3BA86C69EA4B7376F31A9BCB4F74C1976089B2D9963DA2E5543E17776969E89B4C5564D00349106B8497785DD7D1D713A8AE82B32FA79D5F7FC407D39B", False,
+     "public key is not a valid X coordinate because it exceeds the field size"),
+]
+
+
+def ecdsa_row(name, h, sig, pub, src, expect=None):
+    got = R.ecdsa_verify(h, sig, pub)
+    if expect is not None:
+        assert got == expect, name
+    return dict(name=name, hash=h.hex(), sig=sig.hex(), pub=pub.hex(), expect=got, source=src)
+
+
+def main():
+    out = dict(ecdsa=[], schnorr=[], gossip=[], der=[], sha256d=[], bip143=[], pubkey=[])
+
+    # ---- KAT-G: gossipd/test/run-check_channel_announcement.c:62-108
+    msg = bytes.fromhex(KAT_G_MSG)
+    stripped = msg[:258] + b"\x00\x00" + msg[263:]
+    for label, m, first_bad, refassert in (("orig", msg, 1, "Bad node_signature_1 asserted at :84-85"),
+                                           ("features-stripped", stripped, 2, "Bad node_signature_2 asserted at :107-108")):
+        assert R.sigcheck_channel_announcement(m) == first_bad
+        out["gossip"].append(dict(name="KAT-G/" + label, kind="channel_announcement", msg=m.hex(), expect=first_bad,
+                                  source="gossipd/test/run-check_channel_announcement.c:62 (%s)" % refassert))
+        flen = int.from_bytes(m[258:260], "big")
+        koff = 260 + flen + 40
+        h = R.sha256d(m[258:])
+        out["sha256d"].append(dict(data=m[258:].hex(), expect=h.hex(), source="KAT-G/" + label))
+        for i, nm in enumerate(("node_signature_1", "node_signature_2", "bitcoin_signature_1", "bitcoin_signature_2")):
+            out["ecdsa"].append(ecdsa_row("KAT-G/%s/%s" % (label, nm), h, m[2 + 64 * i:66 + 64 * i], m[koff + 33 * i:koff + 33 * i + 33],
+                                          "gossipd/test/run-check_channel_announcement.c:62"))
+    assert out["sha256d"][0]["expect"] == "bb92b8f45b48e65ad2f2cfff2242fa921b4cf46f709a372ca7788537e89d9de1"  # quoted at :8
+
+    # ---- KAT-O: onchaind/test/run-grind_feerate.c:120-150
+    tx = bytes.fromhex(KAT_O["tx"])
+    txid, vout, seq = tx[5:37], int.from_bytes(tx[37:41], "little"), int.from_bytes(tx[42:46], "little")
+    spk, lock = tx[56:90], int.from_bytes(tx[-4:], "little")
+    der = bytes.fromhex(KAT_O["der"])
+    (r, s), sht = R.signature_from_der(der)
+    sig64 = b32(r) + b32(s)
+    out["der"].append(dict(name="KAT-O", der=der.hex(), expect_sig=sig64.hex(), expect_sighash=sht,
+                           source="onchaind/test/run-grind_feerate.c:125"))
+    wscript, key = bytes.fromhex(KAT_O["wscript"]), bytes.fromhex(KAT_O["key"])
+    for fee in (165750, 165749, 165751, 0, 250000):
+        h, pre = R.bip143_sighash(2, [(txid, vout, seq)], [(KAT_O["input_sat"] - fee, spk)], lock, 0, wscript, KAT_O["input_sat"], sht)
+        exp = fee == KAT_O["fee_ok"]  # reference: exactly one fee matches (:147-150)
+        out["ecdsa"].append(ecdsa_row("KAT-O/fee=%d" % fee, h, sig64, key, "onchaind/test/run-grind_feerate.c:120-150", exp))
+        out["bip143"].append(dict(name="KAT-O/fee=%d" % fee, preimage=pre.hex(), expect=h.hex()))
+
+    # ---- KAT-B11: common/test/run-bolt11.c:465-467,310
+    h = R.sha256(bytes.fromhex(KAT_B11["data"]))
+    assert h.hex() == "116fdb0f18352c886deb263f6466eb40e5e6518b80231a1f9df86088bfa48043"
+    out["ecdsa"].append(ecdsa_row("KAT-B11", h, bytes.fromhex(KAT_B11["sig"]), bytes.fromhex(KAT_B11["key"]),
+                                  "common/test/run-bolt11.c:465-467,310", True))
+
+    # ---- BIP-340 vectors
+    for idx, sk, pk, aux, m, sg, exp, comment in BIP340:
+        pkb, mb, sgb = bytes.fromhex(pk), bytes.fromhex(m), bytes.fromhex(sg)
+        assert R.schnorr_verify(mb, pkb, sgb) == exp, idx
+        auth = "property"
+        if sk:
+            assert R.pubkey_create(int(sk, 16))[0] == int(pk, 16) and R.schnorr_sign(mb, int(sk, 16), bytes.fromhex(aux)) == sgb
+            auth = "re-signed with published seckey"
+        out["schnorr"].append(dict(name="BIP340/%d" % idx, msg=m.lower(), pk=pk.lower(), sig=sg.lower(), expect=exp,
+                                   source="BIP-340 test-vectors.csv #%d (%s; %s)" % (idx, comment or "valid", auth)))
+
+    # ---- synthesised ECDSA edge classes
+    rng = Rng("lightning_amd/golden/ecdsa/v1")
+    for t in range(24):
+        d, k = rng.scalar(), rng.scalar()
+        Q = R.pubkey_create(d)
+        h = rng.bytes(32)
+        sig = R.ecdsa_sign(h, d, k)
+        r, s = int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big")
+        pub65, pub33 = R.ser65(Q), R.ser33(Q)
+        src = "synth seed ecdsa/v1 #%d" % t
+        out["ecdsa"].append(ecdsa_row("valid65/%d" % t, h, sig, pub65, src, True))
+        out["ecdsa"].append(ecdsa_row("valid33/%d" % t, h, sig, pub33, src, True))
+        out["ecdsa"].append(ecdsa_row("highS/%d" % t, h, b32(r) + b32(N - s), pub65, src, False))
+        hb = bytearray(h); hb[rng.below(32)] ^= 1 << rng.below(8)
+        out["ecdsa"].append(ecdsa_row("fliphash/%d" % t, bytes(hb), sig, pub65, src, False))
+        sb = bytearray(sig); sb[rng.below(64)] ^= 1 << rng.below(8)
+        out["ecdsa"].append(ecdsa_row("flipsig/%d" % t, h, bytes(sb), pub33, src))
+        out["ecdsa"].append(ecdsa_row("wrongkey/%d" % t, h, sig, R.ser33(R.pubkey_create(rng.scalar())), src, False))
+        out["ecdsa"].append(ecdsa_row("wrongparity/%d" % t, h, sig, bytes([pub33[0] ^ 1]) + pub33[1:], src, False))
+        if t < 4:
+            out["ecdsa"].append(ecdsa_row("r=0/%d" % t, h, b32(0) + b32(s), pub65, src, False))
+            out["ecdsa"].append(ecdsa_row("s=0/%d" % t, h, b32(r) + b32(0), pub65, src, False))
+            out["ecdsa"].append(ecdsa_row("r=n/%d" % t, h, b32(N) + b32(s), pub65, src, False))
+            out["ecdsa"].append(ecdsa_row("s=n/%d" % t, h, b32(r) + b32(N), pub65, src, False))
+            out["ecdsa"].append(ecdsa_row("r=n+r/%d" % t, h, b32(N + (r % (2**256 - N))) + b32(s), pub65, src, False))
+            out["ecdsa"].append(ecdsa_row("s=2^256-1/%d" % t, h, b32(r) + b"\xff" * 32, pub65, src, False))
+            out["ecdsa"].append(ecdsa_row("prefix05/%d" % t, h, sig, b"\x05" + pub33[1:], src, False))
+            out["ecdsa"].append(ecdsa_row("prefix04len33/%d" % t, h, sig, b"\x04" + pub33[1:], src, False))
+            out["ecdsa"].append(ecdsa_row("hybrid-ok/%d" % t, h, sig, bytes([6 + (Q[1] & 1)]) + pub65[1:], src, True))
+            out["ecdsa"].append(ecdsa_row("hybrid-badparity/%d" % t, h, sig, bytes([7 - (Q[1] & 1)]) + pub65[1:], src, False))
+            yb = bytearray(pub65); yb[64] ^= 1
+            out["ecdsa"].append(ecdsa_row("offcurve65/%d" % t, h, sig, bytes(yb), src, False))
+            out["ecdsa"].append(ecdsa_row("x>=p/%d" % t, h, sig, b"\x02" + b32(P + t), src, False))
+            out["ecdsa"].append(ecdsa_row("y>=p/%d" % t, h, sig, b"\x04" + pub65[1:33] + b32(P + 1), src, False))
+            # x with no square root
+            x = Q[0]
+            while R.lift_x(x) is not None:
+                x += 1
+            out["ecdsa"].append(ecdsa_row("nosqrt/%d" % t, h, sig, b"\x02" + b32(x), src, False))
+            # hash >= n: z is reduced mod n, so hash and hash+n verify alike
+            z = rng.below(2**256 - N)
+            hs = b32(z)
+            sg2 = R.ecdsa_sign(hs, d, k)
+            out["ecdsa"].append(ecdsa_row("hash<2^256-n/%d" % t, hs, sg2, pub65, src, True))
+            out["ecdsa"].append(ecdsa_row("hash+n/%d" % t, b32(z + N), sg2, pub65, src, True))
+            out["ecdsa"].append(ecdsa_row("hash=0/%d" % t, b32(0), R.ecdsa_sign(b32(0), d, k), pub33, src, True))
+            out["ecdsa"].append(ecdsa_row("hash=n/%d" % t, b32(N), R.ecdsa_sign(b32(0), d, k), pub33, src, True))
+            # R = infinity: u1*G + u2*Q = 0  <=>  z = -r*d
+            out["ecdsa"].append(ecdsa_row("R=inf/%d" % t, b32((-r * d) % N), sig, pub65, src, False))
+            # u1*G == u2*Q (doubling inside the final add): z = r*d, R = 2*u1*G, r must be x(R)
+            kk = rng.scalar()
+            rr = R.pmul(kk, G)[0] % N
+            ss = 2 * rr * d * pow(kk, -1, N) % N
+            if ss > R.HALF_N:
+                ss = N - ss
+            out["ecdsa"].append(ecdsa_row("u1G==u2Q/%d" % t, b32(rr * d % N), b32(rr) + b32(ss), pub65, src, True))
+    # special public keys: G, -G, lambda*G, small multiples (exercise degenerate adds inside table/ladder code)
+    LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    assert pow(LAM, 3, N) == 1 and LAM != 1
+    for nm, d in (("Q=G", 1), ("Q=-G", N - 1), ("Q=2G", 2), ("Q=lamG", LAM), ("Q=lam2G", LAM * LAM % N), ("Q=-lamG", N - LAM),
+                  ("Q=3G", 3), ("Q=(n-1)/2 G", (N - 1) // 2), ("Q=2^128 G", 1 << 128), ("Q=(2^128-1)G", (1 << 128) - 1)):
+        Q = R.pubkey_create(d)
+        for t in range(3):
+            k = rng.scalar()
+            h = rng.bytes(32)
+            sig = R.ecdsa_sign(h, d, k)
+            out["ecdsa"].append(ecdsa_row("%s/%d" % (nm, t), h, sig, R.ser33(Q), "synth special key", True))
+            hb = bytearray(h); hb[0] ^= 1
+            out["ecdsa"].append(ecdsa_row("%s/bad%d" % (nm, t), bytes(hb), sig, R.ser65(Q), "synth special key", False))
+    # small / structured scalars through the key-less construction: pick u1,u2, R = u1 G + u2 Q, s = r/u2, z = u1 s
+    Q = R.pubkey_create(rng.scalar())
+    for nm, u1, u2 in (("u1=0", 0, 5), ("u1=1,u2=1", 1, 1), ("u2=1", rng.scalar(), 1), ("u1=n-1", N - 1, rng.scalar()),
+                       ("u2=n-1", rng.scalar(), N - 1), ("u2=2^128", rng.scalar(), 1 << 128), ("u2=lam", rng.scalar(), LAM),
+                       ("u1=2^255", 1 << 255, rng.scalar()), ("u2=16", rng.scalar(), 16), ("u2=2^129-1", 7, (1 << 129) - 1)):
+        Rp = R.padd(R.pmul(u1, G), R.pmul(u2, Q))
+        r = Rp[0] % N
+        s = r * pow(u2, -1, N) % N
+        z = u1 * s % N
+        if s > R.HALF_N:
+            s = N - s
+            z = (N - z) % N  # (z, s) -> (-z, -s) keeps u1 = z/s, u2 = r/s ... u2 flips: re-derive
+            # with s negated: u1' = z'/s' = u1, u2' = r/s' = -u2 -> not the same point; instead negate Q
+            Qn = R.pneg(Q)
+            out["ecdsa"].append(ecdsa_row("keyless/%s" % nm, b32(z), b32(r) + b32(s), R.ser33(Qn), "synth key-less", True))
+        else:
+            out["ecdsa"].append(ecdsa_row("keyless/%s" % nm, b32(z), b32(r) + b32(s), R.ser33(Q), "synth key-less", True))
+    # x(R) >= n: accept needs the r + n < p second candidate.  Build R from a chosen x in [n, p).
+    x = N
+    made = 0
+    while made < 3:
+        x += 1
+        Rp = R.lift_x(x)
+        if Rp is None:
+            continue
+        u1, u2 = rng.scalar(), rng.scalar()
+        Qk = R.pmul(pow(u2, -1, N), R.padd(Rp, R.pneg(R.pmul(u1, G))))
+        r = x - N
+        s = r * pow(u2, -1, N) % N
+        z = u1 * s % N
+        if s > R.HALF_N:
+            s, Qk = N - s, R.pneg(Qk)
+            z = (N - z) % N
+        out["ecdsa"].append(ecdsa_row("x(R)=r+n/%d" % made, b32(z), b32(r) + b32(s), R.ser65(Qk), "synth key-less, x(R) in [n,p)", True))
+        # same r but a point whose x really is r (< n) must not be confused: flip a hash bit -> reject
+        out["ecdsa"].append(ecdsa_row("x(R)=r+n/bad%d" % made, b32(z ^ 1), b32(r) + b32(s), R.ser65(Qk), "synth key-less", False))
+        made += 1
+
+    # ---- synthesised Schnorr edge classes
+    rng = Rng("lightning_amd/golden/schnorr/v1")
+    for t in range(24):
+        d = rng.scalar()
+        m, aux = rng.bytes(32), rng.bytes(32)
+        px = b32(R.pubkey_create(d)[0])
+        sg = R.schnorr_sign(m, d, aux)
+        src = "synth seed schnorr/v1 #%d" % t
+
+        def row(nm, mm, pp, ss, exp=None):
+            got = R.schnorr_verify(mm, pp, ss)
+            if exp is not None:
+                assert got == exp, nm
+            out["schnorr"].append(dict(name="%s/%d" % (nm, t), msg=mm.hex(), pk=pp.hex(), sig=ss.hex(), expect=got, source=src))
+        row("valid", m, px, sg, True)
+        mb = bytearray(m); mb[rng.below(32)] ^= 1 << rng.below(8)
+        row("flipmsg", bytes(mb), px, sg, False)
+        sb = bytearray(sg); sb[rng.below(64)] ^= 1 << rng.below(8)
+        row("flipsig", m, px, bytes(sb))
+        s = int.from_bytes(sg[32:], "big")
+        row("negs", m, px, sg[:32] + b32(N - s), False)
+        row("wrongkey", m, b32(R.pubkey_create(rng.scalar())[0]), sg, False)
+        if t < 4:
+            row("r>=p", m, px, b32(P + t) + sg[32:], False)
+            row("s>=n", m, px, sg[:32] + b32(N + t), False)
+            row("s=0", m, px, sg[:32] + b32(0))
+            row("pk>=p", m, b32(P + 1 + t), sg, False)
+            x = int.from_bytes(px, "big")
+            while R.lift_x(x) is not None:
+                x += 1
+            row("pk-nolift", m, b32(x), sg, False)
+            row("pk=0", m, b32(0), sg, False)
+            # R = infinity: s*G = e*P with P = d'G (even-y normalised d') -> s = e*d' where e depends on r: pick r, solve s
+            dd = d if R.pubkey_create(d)[1] % 2 == 0 else N - d
+            rx = b32(R.pubkey_create(rng.scalar())[0])
+            e = int.from_bytes(R.tagged_hash("BIP0340/challenge", rx + px + m), "big") % N
+            row("R=inf", m, px, rx + b32(e * dd % N), False)
+            # odd-y R: sign with the un-negated nonce
+            k0 = rng.scalar()
+            Rp = R.pmul(k0, G)
+            if Rp[1] % 2 == 0:
+                k0 = N - k0
+            e = int.from_bytes(R.tagged_hash("BIP0340/challenge", b32(Rp[0]) + px + m), "big") % N
+            row("oddR", m, px, b32(Rp[0]) + b32((k0 + e * dd) % N), False)
+
+    # ---- pubkey parse table (secp256k1_ec_pubkey_parse semantics)
+    rng = Rng("lightning_amd/golden/pubkey/v1")
+    for t in range(8):
+        Q = R.pubkey_create(rng.scalar())
+        for pub in (R.ser33(Q), R.ser65(Q), bytes([6 + (Q[1] & 1)]) + R.ser65(Q)[1:], bytes([7 - (Q[1] & 1)]) + R.ser65(Q)[1:],
+                    b"\x00" + R.ser33(Q)[1:], b"\x02" + b32(P - 1 - t), b"\x03" + b32(t), b"\x04" + b32(Q[0]) + b32(P - Q[1]),
+                    b"\x04" + b32(Q[0]) + b32((Q[1] + 1) % P)):
+            pt = R.pubkey_parse(pub)
+            out["pubkey"].append(dict(pub=pub.hex(), expect=None if pt is None else (b32(pt[0]) + b32(pt[1])).hex()))
+
+    # ---- DER parse table (secp256k1_ecdsa_signature_parse_der semantics)
+    rng = Rng("lightning_amd/golden/der/v1")
+
+    def der_int(v, pad=0):
+        b = v.to_bytes((v.bit_length() + 7) // 8 or 1, "big")
+        if b[0] & 0x80:
+            b = b"\x00" + b
+        b = b"\x00" * pad + b
+        return b"\x02" + bytes([len(b)]) + b
+
+    def der_sig(r, s, **kw):
+        body = der_int(r, kw.get("rpad", 0)) + der_int(s, kw.get("spad", 0))
+        return b"\x30" + bytes([len(body)]) + body
+    cases = []
+    for t in range(6):
+        r, s = rng.scalar(), rng.scalar() >> (8 * t)
+        cases.append(("ok/%d" % t, der_sig(r, s)))
+        cases.append(("rpad/%d" % t, der_sig(r, s, rpad=1)))
+        cases.append(("trailing/%d" % t, der_sig(r, s) + b"\x00"))
+        good = der_sig(r, s)
+        cases.append(("badlen/%d" % t, good[:1] + bytes([good[1] + 1]) + good[2:]))
+        cases.append(("truncated/%d" % t, good[:-1]))
+        cases.append(("tag31/%d" % t, b"\x31" + good[1:]))
+        cases.append(("longform/%d" % t, b"\x30\x81" + good[1:]))
+    cases.append(("r>=n", der_sig(N + 5, 7)))
+    cases.append(("s=33bytes", der_sig(5, 1 << 256)))
+    cases.append(("negative-r", b"\x30\x06\x02\x01\x80\x02\x01\x01"))
+    cases.append(("zero-len-int", b"\x30\x05\x02\x00\x02\x01\x01"))
+    cases.append(("r=0", b"\x30\x06\x02\x01\x00\x02\x01\x01"))
+    cases.append(("ff-pad", b"\x30\x07\x02\x02\xff\x80\x02\x01\x01"))
+    cases.append(("empty", b""))
+    cases.append(("only-seq", b"\x30\x00"))
+    for nm, der in cases:
+        rs = R.sig_parse_der(der)
+        out["der"].append(dict(name="synth/" + nm, der=der.hex(), expect_sig=None if rs is None else (b32(rs[0]) + b32(rs[1])).hex(),
+                               expect_sighash=None, source="synth der/v1"))
+    for nm, der in (("with-sighash-all", der_sig(5, 7) + b"\x01"), ("with-sighash-single-acp", der_sig(5, 7) + b"\x83"),
+                    ("bad-sighash-none", der_sig(5, 7) + b"\x02"), ("bad-sighash-0", der_sig(5, 7) + b"\x00")):
+        res = R.signature_from_der(der)
+        out["der"].append(dict(name="sigfromder/" + nm, der=der.hex(), full=True,
+                               expect_sig=None if res is None else (b32(res[0][0]) + b32(res[0][1])).hex(),
+                               expect_sighash=None if res is None else res[1], source="bitcoin/signature.c:310-323 semantics"))
+
+    # ---- synthesised gossip messages (wire layout: wire/peer_wire.csv:344-381; built like devtools/mkgossip.c:131-147,235-322)
+    rng = Rng("lightning_amd/golden/gossip/v1")
+    chain = bytes.fromhex("6fe28c0ab6f1b372c1a6a246ae63f74f931e8365e15a089c68d6190000000000")
+    for t in range(6):
+        ds = [rng.scalar() for _ in range(4)]
+        keys = [R.ser33(R.pubkey_create(d)) for d in ds]
+        if keys[0] > keys[1]:
+            keys[0], keys[1], ds[0], ds[1] = keys[1], keys[0], ds[1], ds[0]
+        feat = rng.bytes(t % 3)
+        tail = len(feat).to_bytes(2, "big") + feat + chain + rng.bytes(8) + b"".join(keys)
+        h = R.sha256d(tail)
+        sigs = [R.ecdsa_sign(h, d, rng.scalar()) for d in ds]
+        m = b"\x01\x00" + b"".join(sigs) + tail
+        assert R.sigcheck_channel_announcement(m) == 0
+        out["gossip"].append(dict(name="cann/ok/%d" % t, kind="channel_announcement", msg=m.hex(), expect=0, source="synth gossip/v1"))
+        for bad in range(4):
+            mb = bytearray(m)
+            mb[2 + 64 * bad + 40] ^= 0x10
+            exp = R.sigcheck_channel_announcement(bytes(mb))
+            assert exp == bad + 1
+            out["gossip"].append(dict(name="cann/bad%d/%d" % (bad + 1, t), kind="channel_announcement", msg=bytes(mb).hex(), expect=exp,
+                                      source="synth gossip/v1"))
+        mb = bytearray(m); mb[len(m) - 1] ^= 1  # corrupt bitcoin_key_2 -> all four hashes change, key may stop parsing
+        out["gossip"].append(dict(name="cann/tailflip/%d" % t, kind="channel_announcement", msg=bytes(mb).hex(),
+                                  expect=R.sigcheck_channel_announcement(bytes(mb)), source="synth gossip/v1"))
+        # channel_update: 138 bytes (2 type + 64 sig + 72 signed)
+        body = chain + rng.bytes(8) + rng.bytes(4) + b"\x01" + bytes([t & 1]) + rng.bytes(2 + 8 + 4 + 4 + 8)
+        assert len(body) == 72
+        sg = R.ecdsa_sign(R.sha256d(body), ds[t & 1], rng.scalar())
+        mu = b"\x01\x02" + sg + body
+        assert R.sigcheck_channel_update(mu, keys[t & 1]) == 0
+        out["gossip"].append(dict(name="cupd/ok/%d" % t, kind="channel_update", msg=mu.hex(), node_id=keys[t & 1].hex(), expect=0, source="synth gossip/v1"))
+        out["gossip"].append(dict(name="cupd/wrongnode/%d" % t, kind="channel_update", msg=mu.hex(), node_id=keys[1 - (t & 1)].hex(), expect=1, source="synth gossip/v1"))
+        mb = bytearray(mu); mb[-1] ^= 0x01  # tests/test_gossip.py:1990-2002 flips the last nibble
+        out["gossip"].append(dict(name="cupd/lastnibble/%d" % t, kind="channel_update", msg=bytes(mb).hex(), node_id=keys[t & 1].hex(), expect=1,
+                                  source="synth gossip/v1 (shape of tests/test_gossip.py:1990-2002)"))
+        # node_announcement
+        feat = rng.bytes(t % 4)
+        addrs = rng.bytes(7 * (t % 3))
+        body = len(feat).to_bytes(2, "big") + feat + rng.bytes(4) + keys[0] + rng.bytes(3) + rng.bytes(32) + len(addrs).to_bytes(2, "big") + addrs
+        sg = R.ecdsa_sign(R.sha256d(body), ds[0], rng.scalar())
+        mn = b"\x01\x01" + sg + body
+        assert R.sigcheck_node_announcement(mn) == 0
+        out["gossip"].append(dict(name="nann/ok/%d" % t, kind="node_announcement", msg=mn.hex(), expect=0, source="synth gossip/v1"))
+        mb = bytearray(mn); mb[70 + len(feat)] ^= 0x80
+        out["gossip"].append(dict(name="nann/bad/%d" % t, kind="node_announcement", msg=bytes(mb).hex(), expect=R.sigcheck_node_announcement(bytes(mb)),
+                                  source="synth gossip/v1"))
+    # malformed: sig with r >= n must be a parse failure (-1), not "Bad signature"
+    mb = bytearray(bytes.fromhex(out["gossip"][2]["msg"])); mb[2:34] = b"\xff" * 32
+    out["gossip"].append(dict(name="cann/malformed-r>=n", kind="channel_announcement", msg=bytes(mb).hex(),
+                              expect=R.sigcheck_channel_announcement(bytes(mb)), source="wire/fromwire.c:196-198"))
+
+    path = os.path.join(HERE, "kat.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print({k: len(v) for k, v in out.items()}, "->", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
