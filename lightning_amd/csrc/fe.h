@@ -1,0 +1,343 @@
+// secp256k1 base field, p = 2^256 - 2^32 - 977, for one signature per wavefront lane.
+//
+// Representation: 9 limbs of 29 bits in u32 registers, LAZY: limbs may exceed 29 bits.
+// A value of "magnitude" m has limbs[0..7] <= m*LIM29 and limb[8] <= m*LIM24 (m <= 7 so
+// nothing overflows a u32).  Why this shape (measured, profiles/r01_microbench_valu_rates.txt):
+// on gfx950 v_mad_u64_u32 runs at the same half rate as v_add_co/v_addc (and carry chains
+// additionally pay the VALU-writes-VCC -> VALU-reads-VCC 2-wait-state hazard), so the cheap
+// resource is the 64-bit accumulate inside the multiplier, not the adder.  29-bit limbs let a
+// whole product column (<= 9 partial products of <= 2^58..2^61) accumulate in one 64-bit
+// register with no carry handling at all: 81 mads per multiply (45 per square), additions are
+// 9 independent v_add_u32, and carries are resolved once per multiply.
+//
+// Replaces (together with scalar.h/group.h): the field layer of libsecp256k1 that
+// bitcoin/signature.c:188,425 reaches through secp256k1_ecdsa_verify / schnorrsig_verify.
+#pragma once
+#include "lamd_common.h"
+
+namespace lamd {
+
+struct fe {
+  u32 n[9];
+#if defined(LAMD_CHECK_MAG)
+  int mag;
+#endif
+};
+
+constexpr u32 FE_M29 = 0x1FFFFFFFu;
+constexpr u32 FE_M24 = 0x00FFFFFFu;
+constexpr u32 FE_LIM29 = (1u << 29) + (1u << 13);
+constexpr u32 FE_LIM24 = (1u << 24) + (1u << 13);
+// p in 29-bit limbs
+constexpr u32 FE_P0 = 0x1FFFFC2Fu, FE_P1 = 0x1FFFFFF7u, FE_PM = 0x1FFFFFFFu, FE_P8 = 0x00FFFFFFu;
+// 2^261 mod p = 2^37 + 31264 = 31264 + 256 * 2^29
+constexpr u32 FE_R0 = 31264u;
+constexpr int FE_R1_SHIFT = 8;
+
+#if defined(LAMD_CHECK_MAG)
+#define FE_SETMAG(r, m) ((r).mag = (m))
+#define FE_MAG(a) ((a).mag)
+LAMD_HD void fe_verify(const fe &a) {
+  LAMD_ASSERT(a.mag >= 0 && a.mag <= 7);
+  for (int i = 0; i < 8; i++) LAMD_ASSERT((u64)a.n[i] <= (u64)a.mag * FE_LIM29);
+  LAMD_ASSERT((u64)a.n[8] <= (u64)a.mag * FE_LIM24);
+}
+#else
+#define FE_SETMAG(r, m) ((void)0)
+#define FE_MAG(a) 0
+LAMD_HD void fe_verify(const fe &) {}
+#endif
+
+LAMD_HD fe fe_zero() {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = 0;
+  FE_SETMAG(r, 0);
+  return r;
+}
+LAMD_HD fe fe_set_int(u32 v) {  // v < 2^29
+  fe r = fe_zero();
+  r.n[0] = v;
+  FE_SETMAG(r, 1);
+  return r;
+}
+
+// r = a + b (lazy)
+LAMD_HD fe fe_add(const fe &a, const fe &b) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = a.n[i] + b.n[i];
+  FE_SETMAG(r, FE_MAG(a) + FE_MAG(b));
+  fe_verify(r);
+  return r;
+}
+// r = -a for a of magnitude <= m: (m+1)*p - a, limb-wise non-negative; magnitude m+1
+LAMD_HD fe fe_neg(const fe &a, int m) {
+  LAMD_ASSERT(FE_MAG(a) <= m && m + 1 <= 7);
+  fe r;
+  const u32 k = (u32)(m + 1);
+  r.n[0] = k * FE_P0 - a.n[0];
+  r.n[1] = k * FE_P1 - a.n[1];
+#pragma unroll
+  for (int i = 2; i < 8; i++) r.n[i] = k * FE_PM - a.n[i];
+  r.n[8] = k * FE_P8 - a.n[8];
+  FE_SETMAG(r, m + 1);
+  fe_verify(r);
+  return r;
+}
+// r = a - b, b of magnitude <= mb; magnitude mag(a) + mb + 1
+LAMD_HD fe fe_sub(const fe &a, const fe &b, int mb) { return fe_add(a, fe_neg(b, mb)); }
+
+LAMD_HD fe fe_mul_int(const fe &a, u32 k) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = a.n[i] * k;
+  FE_SETMAG(r, FE_MAG(a) * (int)k);
+  fe_verify(r);
+  return r;
+}
+
+// Magnitude -> 1 with fully parallel (non-rippling) carries: every limb keeps its low bits and
+// receives its neighbour's overflow (<= 7), the 2^256 overflow of the top limb folds back
+// through 2^256 = 2^32 + 977 (mod p).  ~30 independent VALU ops, no carry chain.
+LAMD_HD fe fe_norm_weak(const fe &a) {
+  fe r;
+  const u32 e = a.n[8] >> 24;
+  r.n[0] = (a.n[0] & FE_M29) + e * 977u;
+  r.n[1] = (a.n[1] & FE_M29) + (a.n[0] >> 29) + (e << 3);
+#pragma unroll
+  for (int i = 2; i < 8; i++) r.n[i] = (a.n[i] & FE_M29) + (a.n[i - 1] >> 29);
+  r.n[8] = (a.n[8] & FE_M24) + (a.n[7] >> 29);
+  FE_SETMAG(r, 1);
+  fe_verify(r);
+  return r;
+}
+
+// Exact carry propagation: limbs[0..7] < 2^29, limb[8] <= 2^24 (bit 24 may be set once);
+// value < 2^256 + 2^41.  Input any magnitude <= 7.
+LAMD_HD fe fe_carry(const fe &a) {
+  fe r;
+  u32 e = a.n[8] >> 24;
+  u32 t = a.n[0] + e * 977u;  // < 2^32
+  r.n[0] = t & FE_M29;
+  u32 c = t >> 29;
+  t = a.n[1] + (e << 3) + c;
+  r.n[1] = t & FE_M29;
+  c = t >> 29;
+#pragma unroll
+  for (int i = 2; i < 8; i++) {
+    t = a.n[i] + c;
+    r.n[i] = t & FE_M29;
+    c = t >> 29;
+  }
+  r.n[8] = (a.n[8] & FE_M24) + c;
+  FE_SETMAG(r, 1);
+  return r;
+}
+
+// canonical representative in [0, p)
+LAMD_HD fe fe_normalize(const fe &a) {
+  fe r = fe_carry(fe_carry(a));  // second pass clears a possible bit 24; now value < 2^256
+  // t = r + (2^32 + 977); if that reaches 2^256 then r >= p and the answer is t - 2^256
+  fe t;
+  u32 v = r.n[0] + 977u;
+  t.n[0] = v & FE_M29;
+  u32 c = v >> 29;
+  v = r.n[1] + 8u + c;
+  t.n[1] = v & FE_M29;
+  c = v >> 29;
+#pragma unroll
+  for (int i = 2; i < 8; i++) {
+    v = r.n[i] + c;
+    t.n[i] = v & FE_M29;
+    c = v >> 29;
+  }
+  v = r.n[8] + c;
+  t.n[8] = v & FE_M24;
+  const bool ge = (v >> 24) != 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = ge ? t.n[i] : r.n[i];
+  FE_SETMAG(r, 1);
+  return r;
+}
+
+// does a (any magnitude <= 7) represent 0 mod p?
+LAMD_HD bool fe_is_zero(const fe &a) {
+  const fe r = fe_carry(a);  // value in [0, 2^256 + 2^41): zero iff 0 or p
+  u32 z0 = r.n[0] | r.n[1] | r.n[8];
+  u32 z1 = (r.n[0] ^ FE_P0) | (r.n[1] ^ FE_P1) | (r.n[8] ^ FE_P8);
+#pragma unroll
+  for (int i = 2; i < 8; i++) {
+    z0 |= r.n[i];
+    z1 |= r.n[i] ^ FE_PM;
+  }
+  return (z0 == 0) | (z1 == 0);
+}
+LAMD_HD bool fe_equal(const fe &a, const fe &b, int mb) { return fe_is_zero(fe_sub(a, b, mb)); }
+LAMD_HD bool fe_is_odd_canonical(const fe &a) { return a.n[0] & 1; }  // a already fe_normalize()d
+
+LAMD_HD fe fe_select(bool take_a, const fe &a, const fe &b) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = take_a ? a.n[i] : b.n[i];
+  FE_SETMAG(r, FE_MAG(a) > FE_MAG(b) ? FE_MAG(a) : FE_MAG(b));
+  return r;
+}
+
+// ---- shared reduction: 17 product columns (+ c[17] = 0 on entry) -> magnitude-1 field element
+LAMD_HD fe fe_reduce_columns(u64 c[18]) {
+  // 1. split the high half into 29-bit limbs
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    c[k + 1] += c[k] >> 29;
+    c[k] &= FE_M29;
+  }
+  // 2. fold limb k (weight 2^(29k), k >= 9) onto limbs k-9, k-8 with 2^261 = 31264 + 256*2^29 (mod p)
+  c[8] += c[17] * (u64)FE_R0;     // c[17] <= 2^35
+  c[9] += c[17] << FE_R1_SHIFT;                                       // c[9] <= 2^29 + 2^43
+  c[0] += c[9] * FE_R0;                                               // <= 2^59
+  c[1] += c[9] << FE_R1_SHIFT;
+#pragma unroll
+  for (int k = 10; k < 17; k++) {
+    c[k - 9] += (u64)(u32)c[k] * FE_R0;
+    c[k - 8] += c[k] << FE_R1_SHIFT;
+  }
+  // 3. carry the low half
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    c[k + 1] += c[k] >> 29;
+    c[k] &= FE_M29;
+  }
+  // 4. bits >= 256 of the top limb: 2^256 = 2^32 + 977 = 977 + 8*2^29
+  const u64 e = c[8] >> 24;  // <= 2^40
+  c[8] &= FE_M24;
+  c[0] += e * 977u;
+  c[1] += e << 3;
+  c[1] += c[0] >> 29; c[0] &= FE_M29;
+  c[2] += c[1] >> 29; c[1] &= FE_M29;
+  c[3] += c[2] >> 29; c[2] &= FE_M29;
+  fe r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.n[k] = (u32)c[k];
+  FE_SETMAG(r, 1);
+  fe_verify(r);
+  return r;
+}
+
+// r = a*b; requires mag(a)*mag(b) <= 7
+LAMD_HD fe fe_mul(const fe &a, const fe &b) {
+  LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7);
+  u64 c[18];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j < 0 || j > 8) continue;
+      s += (u64)a.n[i] * b.n[j];
+    }
+    c[k] = s;
+  }
+  c[17] = 0;
+  return fe_reduce_columns(c);
+}
+
+// r = a^2; requires mag(a) <= 2
+LAMD_HD fe fe_sqr(const fe &a) {
+  LAMD_ASSERT(FE_MAG(a) <= 2);
+  u32 d[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
+  u64 c[18];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 s = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j < 0 || j > 8 || i > j) continue;
+      s += (i == j) ? (u64)a.n[i] * a.n[i] : (u64)d[i] * a.n[j];
+    }
+    c[k] = s;
+  }
+  c[17] = 0;
+  return fe_reduce_columns(c);
+}
+
+LAMD_HD fe fe_sqr_n(fe a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; i++) a = fe_sqr(a);
+  return a;
+}
+
+// a^(2^223 - 1) and a^(2^22-1), a^(2^2-1): shared prefix of the inversion and square-root chains
+struct fe_chain { fe x2, x22, x223; };
+LAMD_HD fe_chain fe_pow_chain(const fe &a) {  // a magnitude 1
+  fe_chain o;
+  const fe x2 = fe_mul(fe_sqr(a), a);
+  const fe x3 = fe_mul(fe_sqr(x2), a);
+  const fe x6 = fe_mul(fe_sqr_n(x3, 3), x3);
+  const fe x9 = fe_mul(fe_sqr_n(x6, 3), x3);
+  const fe x11 = fe_mul(fe_sqr_n(x9, 2), x2);
+  const fe x22 = fe_mul(fe_sqr_n(x11, 11), x11);
+  const fe x44 = fe_mul(fe_sqr_n(x22, 22), x22);
+  const fe x88 = fe_mul(fe_sqr_n(x44, 44), x44);
+  const fe x176 = fe_mul(fe_sqr_n(x88, 88), x88);
+  const fe x220 = fe_mul(fe_sqr_n(x176, 44), x44);
+  o.x223 = fe_mul(fe_sqr_n(x220, 3), x3);
+  o.x2 = x2;
+  o.x22 = x22;
+  return o;
+}
+// a^(p-2): 255 squarings + 15 multiplications
+LAMD_HD fe fe_inv(const fe &a) {
+  const fe_chain ch = fe_pow_chain(a);
+  fe t = fe_mul(fe_sqr_n(ch.x223, 23), ch.x22);
+  t = fe_mul(fe_sqr_n(t, 5), a);
+  t = fe_mul(fe_sqr_n(t, 3), ch.x2);
+  t = fe_mul(fe_sqr_n(t, 2), a);
+  return t;
+}
+// candidate square root a^((p+1)/4) (p = 3 mod 4); caller checks r^2 == a
+LAMD_HD fe fe_sqrt_candidate(const fe &a) {
+  const fe_chain ch = fe_pow_chain(a);
+  fe t = fe_mul(fe_sqr_n(ch.x223, 23), ch.x22);
+  t = fe_mul(fe_sqr_n(t, 6), ch.x2);
+  return fe_sqr_n(t, 2);
+}
+
+// ---- conversions.  w[0..7]: 256-bit value as little-endian 32-bit words.
+LAMD_HD fe fe_from_words(const u32 w[8]) {
+  fe r;
+  r.n[0] = w[0] & FE_M29;
+  r.n[1] = ((w[0] >> 29) | (w[1] << 3)) & FE_M29;
+  r.n[2] = ((w[1] >> 26) | (w[2] << 6)) & FE_M29;
+  r.n[3] = ((w[2] >> 23) | (w[3] << 9)) & FE_M29;
+  r.n[4] = ((w[3] >> 20) | (w[4] << 12)) & FE_M29;
+  r.n[5] = ((w[4] >> 17) | (w[5] << 15)) & FE_M29;
+  r.n[6] = ((w[5] >> 14) | (w[6] << 18)) & FE_M29;
+  r.n[7] = ((w[6] >> 11) | (w[7] << 21)) & FE_M29;
+  r.n[8] = w[7] >> 8;
+  FE_SETMAG(r, 1);
+  return r;
+}
+// a must be canonical (fe_normalize) or at least exactly carried with value < 2^256
+LAMD_HD void fe_to_words(u32 w[8], const fe &a) {
+  w[0] = a.n[0] | (a.n[1] << 29);
+  w[1] = (a.n[1] >> 3) | (a.n[2] << 26);
+  w[2] = (a.n[2] >> 6) | (a.n[3] << 23);
+  w[3] = (a.n[3] >> 9) | (a.n[4] << 20);
+  w[4] = (a.n[4] >> 12) | (a.n[5] << 17);
+  w[5] = (a.n[5] >> 15) | (a.n[6] << 14);
+  w[6] = (a.n[6] >> 18) | (a.n[7] << 11);
+  w[7] = (a.n[7] >> 21) | (a.n[8] << 8);
+}
+// is the 256-bit integer in w >= p ?  (p = FFFFFFFF x6 | FFFFFFFE | FFFFFC2F)
+LAMD_HD bool words_ge_p(const u32 w[8]) {
+  const u32 all1 = w[7] & w[6] & w[5] & w[4] & w[3] & w[2];
+  const bool low_ge = (w[1] == 0xFFFFFFFFu) | ((w[1] == 0xFFFFFFFEu) & (w[0] >= 0xFFFFFC2Fu));
+  return (all1 == 0xFFFFFFFFu) & low_ge;
+}
+
+}  // namespace lamd

@@ -1,0 +1,133 @@
+// secp256k1 group law (y^2 = x^3 + 7) on top of fe.h, shaped for one signature per lane:
+// branch-free main paths, magnitudes tracked so that every fe_mul/fe_sqr operand stays inside
+// the 64-bit column budget, and the (adversarially reachable) degenerate cases of an addition
+// -- P + P, P + (-P), infinity -- taken on a cold, wave-rarely-entered path.
+//
+// Semantics replaced: libsecp256k1's group/ecmult layer as reached from
+// bitcoin/signature.c:188 (secp256k1_ecdsa_verify) and :425 (secp256k1_schnorrsig_verify).
+#pragma once
+#include "fe.h"
+
+namespace lamd {
+
+struct ge {  // affine, magnitude-1 coordinates
+  fe x, y;
+};
+struct gej {  // Jacobian: x, y magnitude 1, z magnitude <= 2
+  fe x, y, z;
+  bool inf;
+};
+
+LAMD_HD gej gej_infinity() {
+  gej r;
+  r.x = fe_zero(); r.y = fe_zero(); r.z = fe_zero();
+  FE_SETMAG(r.x, 1); FE_SETMAG(r.y, 1); FE_SETMAG(r.z, 1);
+  r.inf = true;
+  return r;
+}
+LAMD_HD gej gej_from_ge(const ge &a) {
+  gej r;
+  r.x = a.x; r.y = a.y; r.z = fe_set_int(1); r.inf = false;
+  return r;
+}
+
+// y^2 == x^3 + 7 ?
+LAMD_HD bool ge_on_curve(const ge &a) {
+  const fe y2 = fe_sqr(a.y);
+  const fe x3 = fe_mul(fe_sqr(a.x), a.x);
+  return fe_equal(fe_add(x3, fe_set_int(7)), y2, 1);
+}
+
+// 3M + 4S.  secp256k1 has no point of order 2, so y = 0 cannot occur for a curve point.
+LAMD_HD gej gej_double(const gej &a) {
+  gej r;
+  const fe yy = fe_sqr(a.y);
+  const fe u = fe_mul_int(yy, 2);                 // 2Y^2        (2)
+  const fe uu = fe_sqr(u);                         // 4Y^4        (1)
+  const fe w = fe_mul(a.x, u);                     // 2XY^2       (1)
+  const fe m = fe_norm_weak(fe_mul_int(fe_sqr(a.x), 3));  // 3X^2  (1)
+  const fe mm = fe_sqr(m);
+  r.x = fe_norm_weak(fe_add(mm, fe_neg(fe_mul_int(w, 4), 4)));               // M^2 - 8XY^2
+  const fe t = fe_add(fe_mul_int(w, 2), fe_neg(r.x, 1));                      // 4XY^2 - X3  (4)
+  r.y = fe_norm_weak(fe_add(fe_mul(m, t), fe_neg(fe_mul_int(uu, 2), 2)));   // M*t - 8Y^4
+  r.z = fe_mul_int(fe_mul(a.y, a.z), 2);                                      // 2YZ         (2)
+  r.inf = a.inf;
+  return r;
+}
+
+// Result of the generic part of a mixed addition, plus what the caller must do if degenerate.
+enum { ADD_OK = 0, ADD_DOUBLE = 1, ADD_INFINITY = 2 };
+
+// r = a + b for Jacobian a (not infinity) and affine b, assuming a != +-b; 8M + 3S.
+// *status reports the degenerate cases (r is then garbage); *h_out = H with Z3 = Z1*H.
+LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, int *status, fe *h_out) {
+  gej r;
+  const fe zz = fe_sqr(a.z);
+  const fe u2 = fe_mul(b.x, zz);
+  const fe s2 = fe_mul(b.y, fe_mul(a.z, zz));
+  const fe h = fe_norm_weak(fe_add(u2, fe_neg(a.x, 1)));
+  const fe rr = fe_norm_weak(fe_add(s2, fe_neg(a.y, 1)));
+  const bool hz = fe_is_zero(h);
+  const bool rz = fe_is_zero(rr);
+  *status = hz ? (rz ? ADD_DOUBLE : ADD_INFINITY) : ADD_OK;
+  const fe hh = fe_sqr(h);
+  const fe hhh = fe_mul(h, hh);
+  const fe v = fe_mul(a.x, hh);
+  r.x = fe_norm_weak(fe_add(fe_sqr(rr), fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3)));
+  const fe t = fe_add(v, fe_neg(r.x, 1));  // (3)
+  r.y = fe_norm_weak(fe_add(fe_mul(rr, t), fe_neg(fe_mul(a.y, hhh), 1)));
+  r.z = fe_mul(a.z, h);
+  r.inf = false;
+  *h_out = h;
+  return r;
+}
+
+LAMD_HD gej gej_select(bool take_a, const gej &a, const gej &b) {
+  gej r;
+  r.x = fe_select(take_a, a.x, b.x);
+  r.y = fe_select(take_a, a.y, b.y);
+  r.z = fe_select(take_a, a.z, b.z);
+  r.inf = take_a ? a.inf : b.inf;
+  return r;
+}
+
+// Complete mixed addition with a lane predicate: r = skip ? a : a + b.  The degenerate outcomes
+// are handled under a divergent branch that is never taken on honest inputs.
+LAMD_HD gej gej_add_ge(const gej &a, const ge &b, bool skip) {
+  int st;
+  fe h;
+  gej r = gej_add_ge_core(a, b, &st, &h);
+  if (__builtin_expect(!skip && !a.inf && st != ADD_OK, 0)) {
+    if (st == ADD_DOUBLE) {
+      r = gej_double(gej_from_ge(b));
+    } else {
+      r = gej_infinity();
+    }
+  }
+  const gej bj = gej_from_ge(b);
+  r = gej_select(a.inf, bj, r);  // infinity + b = b
+  return gej_select(skip, a, r);
+}
+
+LAMD_HD ge ge_neg_if(const ge &a, bool neg) {
+  ge r;
+  r.x = a.x;
+  r.y = fe_select(neg, fe_norm_weak(fe_neg(a.y, 1)), a.y);
+  return r;
+}
+
+// ---- 64-byte packed affine points (canonical 8x32-bit little-endian words per coordinate)
+LAMD_HD ge ge_from_words(const u32 xw[8], const u32 yw[8]) {
+  ge r;
+  r.x = fe_from_words(xw);
+  r.y = fe_from_words(yw);
+  return r;
+}
+
+// secp256k1 generator
+#define LAMD_GX {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu}
+#define LAMD_GY {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u}
+// beta: cube root of unity mod p with lambda*(x, y) = (beta*x, y)
+#define LAMD_BETA {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu}
+
+}  // namespace lamd

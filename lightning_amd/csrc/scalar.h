@@ -1,0 +1,288 @@
+// Scalars modulo the secp256k1 group order n, 8 x 32-bit saturated limbs (little-endian words).
+// Only the per-signature preparation uses these (s^-1, u1 = z*s^-1, u2 = r*s^-1, the BIP-340
+// challenge reduction and the GLV split) -- a few percent of a verification once the inversion
+// is batched (Montgomery's trick across the signatures one thread owns), so this code favours
+// being obviously right over being fast.
+//
+// Semantics replaced: libsecp256k1's scalar layer as reached from bitcoin/signature.c:188,425.
+#pragma once
+#include "lamd_common.h"
+
+namespace lamd {
+
+struct sc { u32 w[8]; };  // value in [0, n)
+
+// n = FFFFFFFF FFFFFFFF FFFFFFFF FFFFFFFE BAAEDCE6 AF48A03B BFD25E8C D0364141
+#define LAMD_SC_N {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}
+// (n-1)/2
+#define LAMD_SC_HALF {0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu}
+// 2^256 - n (129 bits)
+#define LAMD_SC_NC {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u}
+
+LAMD_HD bool sc_is_zero(const sc &a) {
+  u32 z = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) z |= a.w[i];
+  return z == 0;
+}
+// a >= b on raw 256-bit words
+LAMD_HD bool words_ge(const u32 a[8], const u32 b[8]) {
+  bool ge = true;  // equal so far
+#pragma unroll
+  for (int i = 0; i < 8; i++) ge = (a[i] > b[i]) | ((a[i] == b[i]) & ge);  // low word first, high word decides last
+  return ge;
+}
+LAMD_HD bool words_ge_n(const u32 a[8]) {
+  const u32 n[8] = LAMD_SC_N;
+  return words_ge(a, n);
+}
+// s > (n-1)/2 ?  (BOLT #2 / BIP-62 low-S rule enforced by secp256k1_ecdsa_verify)
+LAMD_HD bool sc_is_high(const sc &a) {
+  const u32 h[8] = LAMD_SC_HALF;
+  return !words_ge(h, a.w);
+}
+// r = a - n (mod 2^256); only meaningful when a >= n
+LAMD_HD void words_sub_n(u32 r[8], const u32 a[8]) {
+  const u32 nc[5] = LAMD_SC_NC;  // a - n = a + (2^256 - n) mod 2^256
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    c += (u64)a[i] + (i < 5 ? nc[i] : 0u);
+    r[i] = (u32)c;
+    c >>= 32;
+  }
+}
+// reduce a 256-bit integer once (it is < 2n because n > 2^255)
+LAMD_HD sc sc_from_words(const u32 a[8], bool *overflow) {
+  sc r;
+  u32 t[8];
+  words_sub_n(t, a);
+  const bool ge = words_ge_n(a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = ge ? t[i] : a[i];
+  if (overflow) *overflow = ge;
+  return r;
+}
+LAMD_HD sc sc_neg(const sc &a) {
+  const u32 n[8] = LAMD_SC_N;
+  sc r;
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const u64 t = (u64)n[i] - a.w[i] - borrow;
+    r.w[i] = (u32)t;
+    borrow = (t >> 32) & 1;
+  }
+  const bool z = sc_is_zero(a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = z ? 0u : r.w[i];
+  return r;
+}
+
+// out[0..HL+5] = lo[0..7] + hi[0..HL-1] * (2^256 - n); the caller knows how many words can be non-zero
+template <int HL>
+LAMD_HD void sc_fold(u32 *out, const u32 *lo, const u32 *hi) {
+  const u32 nc[5] = LAMD_SC_NC;
+  constexpr int OL = (HL + 5 > 8 ? HL + 5 : 8) + 1;
+#pragma unroll
+  for (int i = 0; i < OL; i++) out[i] = i < 8 ? lo[i] : 0u;
+#pragma unroll
+  for (int i = 0; i < HL; i++) {
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const u64 t = (u64)hi[i] * nc[j] + out[i + j] + carry;
+      out[i + j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+    // ripple the row's carry
+#pragma unroll
+    for (int j = i + 5; j < OL; j++) {
+      const u64 t = (u64)out[j] + carry;
+      out[j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+  }
+}
+
+// 512-bit t -> t mod n
+LAMD_HD sc sc_reduce512(const u32 t[16]) {
+  u32 a[14];           // lo + hi*NC: < 2^256 + 2^385 -> 13 words (+1 spare)
+  sc_fold<8>(a, t, t + 8);
+  u32 b[11];           // a[0..7] + a[8..12]*NC: < 2^256 + 2^(130+129) -> 9 words
+  sc_fold<5>(b, a, a + 8);
+  u32 c[9];            // b[0..7] + b[8]*NC with b[8] < 2^4: < 2^256 + 2^133 -> bit 256 at most
+  sc_fold<1>(c, b, b + 8);
+  // c[8] in {0,1}: subtract n once if c >= n (c < 2n since c < 2^256 + 2^133 < 2n)
+  u32 d[8];
+  words_sub_n(d, c);
+  const bool ge = (c[8] != 0) | words_ge_n(c);
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = ge ? d[i] : c[i];
+  return r;
+}
+
+LAMD_HD sc sc_mul(const sc &a, const sc &b) {
+  u32 t[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u64 v = (u64)a.w[i] * b.w[j] + t[i + j] + carry;
+      t[i + j] = (u32)v;
+      carry = (u32)(v >> 32);
+    }
+    t[i + 8] = carry;
+  }
+  return sc_reduce512(t);
+}
+LAMD_HD sc sc_sqr_n(sc a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; i++) a = sc_mul(a, a);
+  return a;
+}
+
+// a^(n-2).  n-2 = (2^127 - 1) << 129 | 0 << 128 | 0xBAAEDCE6AF48A03BBFD25E8CD036413F
+LAMD_HD sc sc_inv(const sc &a) {
+  const sc x2 = sc_mul(sc_sqr_n(a, 1), a);
+  const sc x4 = sc_mul(sc_sqr_n(x2, 2), x2);
+  const sc x8 = sc_mul(sc_sqr_n(x4, 4), x4);
+  const sc x16 = sc_mul(sc_sqr_n(x8, 8), x8);
+  const sc x32 = sc_mul(sc_sqr_n(x16, 16), x16);
+  const sc x64 = sc_mul(sc_sqr_n(x32, 32), x32);
+  sc t = sc_mul(sc_sqr_n(x64, 32), x32);
+  t = sc_mul(sc_sqr_n(t, 16), x16);
+  t = sc_mul(sc_sqr_n(t, 8), x8);
+  t = sc_mul(sc_sqr_n(t, 4), x4);
+  t = sc_mul(sc_sqr_n(t, 2), x2);
+  t = sc_mul(sc_sqr_n(t, 1), a);  // a^(2^127 - 1)
+  t = sc_sqr_n(t, 1);             // bit 128 of n-2 is 0
+  const u32 low[4] = {0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u};
+#pragma unroll 1
+  for (int i = 127; i >= 0; i--) {
+    t = sc_mul(t, t);
+    if ((low[i >> 5] >> (i & 31)) & 1) t = sc_mul(t, a);
+  }
+  return t;
+}
+
+// ---- GLV endomorphism split: k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128.
+// Lattice basis (a1, b1), (a2, b2) of {(x, y): x + y*lambda = 0 mod n}; g1 = round(2^384*b2/n),
+// g2 = round(2^384*(-b1)/n); c1 = round(k*g1 / 2^384), c2 = round(k*g2 / 2^384);
+// k1 = k - c1*a1 - c2*a2, k2 = c1*(-b1) - c2*b2 as exact (small) integers.
+// Constants re-derived and the 128-bit bound checked in tests (tests/test_devmath_host.py).
+struct glv_half {
+  u32 mag[4];  // |k_i| + 0x8888...8 (low 128 bits): window j, digit = nibble_j - 8 in [-8, 7]
+  u32 top;     // carry out of that addition: digit 32 in {0, 1}
+  u32 neg;     // 1 if k_i < 0
+};
+
+LAMD_HD void mul_words_lo(u32 *out, int outl, const u32 *a, int al, const u32 *b, int bl) {
+  for (int i = 0; i < outl; i++) out[i] = 0;
+  for (int i = 0; i < al; i++) {
+    u32 carry = 0;
+    for (int j = 0; j < bl && i + j < outl; j++) {
+      const u64 t = (u64)a[i] * b[j] + out[i + j] + carry;
+      out[i + j] = (u32)t;
+      carry = (u32)(t >> 32);
+    }
+    if (i + bl < outl) out[i + bl] = carry;
+  }
+}
+
+// round(k * g / 2^384) for a 256-bit g: top 128 bits of the 512-bit product, rounded
+LAMD_HD void glv_mulshift384(u32 c[4], const sc &k, const u32 g[8]) {
+  u32 t[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    u32 carry = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u64 v = (u64)k.w[i] * g[j] + t[i + j] + carry;
+      t[i + j] = (u32)v;
+      carry = (u32)(v >> 32);
+    }
+    t[i + 8] = carry;
+  }
+  // + 2^383 then >> 384: add bit 31 of word 11 into words 12..15
+  u64 cy = (t[11] >> 31) & 1;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    cy += t[12 + i];
+    c[i] = (u32)cy;
+    cy >>= 32;
+  }
+}
+
+LAMD_HD glv_half glv_finish(const u32 v[6]) {
+  // v: signed 192-bit two's complement, |v| < 2^128
+  glv_half h;
+  const u32 neg = v[5] >> 31;
+  u32 m[4];
+  u64 c = neg;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u64)(neg ? ~v[i] : v[i]);
+    m[i] = (u32)c;
+    c >>= 32;
+  }
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    c += (u64)m[i] + 0x88888888u;
+    h.mag[i] = (u32)c;
+    c >>= 32;
+  }
+  h.top = (u32)c;
+  h.neg = neg;
+  return h;
+}
+
+LAMD_HD void glv_split(glv_half *h1, glv_half *h2, const sc &k) {
+  const u32 g1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+  const u32 g2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+  const u32 a1[4] = {0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};          // a1 = b2
+  const u32 mb1[4] = {0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};         // -b1
+  const u32 a2[5] = {0x9D44CFD8u, 0x57C1108Du, 0xA8E2F3F6u, 0x14CA50F7u, 1u};
+  u32 c1[4], c2[4];
+  glv_mulshift384(c1, k, g1);
+  glv_mulshift384(c2, k, g2);
+  u32 p1[6], p2[6], q1[6], q2[6];
+  mul_words_lo(p1, 6, c1, 4, a1, 4);   // c1*a1
+  mul_words_lo(p2, 6, c2, 4, a2, 5);   // c2*a2
+  mul_words_lo(q1, 6, c1, 4, mb1, 4);  // c1*(-b1)
+  mul_words_lo(q2, 6, c2, 4, a1, 4);   // c2*b2
+  u32 k1[6], k2[6];
+  // k1 = k - p1 - p2 (mod 2^192), k2 = q1 - q2 (mod 2^192)
+  u64 b = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const u64 t = (u64)k.w[i] - p1[i] - b;
+    k1[i] = (u32)t;
+    b = (t >> 32) & 1;
+  }
+  b = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const u64 t = (u64)k1[i] - p2[i] - b;
+    k1[i] = (u32)t;
+    b = (t >> 32) & 1;
+  }
+  b = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const u64 t = (u64)q1[i] - q2[i] - b;
+    k2[i] = (u32)t;
+    b = (t >> 32) & 1;
+  }
+  *h1 = glv_finish(k1);
+  *h2 = glv_finish(k2);
+}
+
+}  // namespace lamd

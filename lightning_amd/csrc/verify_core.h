@@ -1,0 +1,362 @@
+// Per-signature verification logic, written once as host+device inline functions so that the
+// kernels in kernels.hip and the CPU test harness (tests/devmath_host.cpp) run the same code.
+//
+// Pipeline (one signature per lane everywhere):
+//   prep     ECDSA : parse r,s (range, low-S), z = hash mod n, s^-1 by Montgomery batch inversion
+//                    over the signatures a thread owns, u1 = z/s, u2 = r/s, GLV-split u2
+//            BIP340: r < p, s < n, e = H_challenge(r||pk||m) mod n, u1 = s, GLV-split (-e)
+//   keys     SEC1 33/65-byte or x-only 32-byte public key -> validated affine point
+//   ecmult   R = u1*G + u2*Q: per-lane 8-entry table of Q (shared-Z / isomorphic-curve trick so
+//            the ladder only does mixed additions), 33 signed 4-bit windows x 2 half-scalars,
+//            then 16 lookups in the 16-bit-window table of G; final x (and y-parity) check
+//
+// Reference semantics: secp256k1_ecdsa_verify / secp256k1_schnorrsig_verify /
+// secp256k1_ec_pubkey_parse / secp256k1_xonly_pubkey_parse as called from
+// bitcoin/signature.c:188,422,425, common/node_id.c:24, bitcoin/pubkey.c:19.
+#pragma once
+#include "group.h"
+#include "scalar.h"
+#include "sha256.h"
+
+namespace lamd {
+
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1 };
+
+// ---- per-signature record produced by prep, consumed by ecmult (80 bytes, 16-byte aligned)
+struct prep_rec {
+  u32 u1[8];   // scalar for G (little-endian words)
+  u32 k1[4];   // |k1| + 0x88..8  (see glv_half)
+  u32 k2[4];
+  u32 flags;   // PREP_*
+  u32 pad[3];
+};
+enum { PREP_VALID = 1, PREP_K1NEG = 2, PREP_K2NEG = 4, PREP_K1TOP = 8, PREP_K2TOP = 16 };
+
+// scratch slot owned by one ecmult lane (u32 words)
+constexpr int SLOT_WORDS = 256;        // 1 KiB
+constexpr int SLOT_ENTRY_WORDS = 24;   // x[8] | beta*x[8] | y[8]
+constexpr int SLOT_H_OFF = 8 * SLOT_ENTRY_WORDS;  // 6 x 8 words of H_2..H_7
+
+// Static table of G: window w, digit d -> d * 2^(BITS*w) * G as 64-byte affine words (d = 0 unused).
+// 16-bit windows (64 MiB, lives in HBM / Infinity Cache) make u1*G sixteen mixed additions.
+// The CPU test harness builds the same code with 8-bit windows to keep its table small.
+#ifndef LAMD_GTABLE_WINDOW_BITS
+#define LAMD_GTABLE_WINDOW_BITS 16
+#endif
+constexpr int GTABLE_WINDOW_BITS = LAMD_GTABLE_WINDOW_BITS;
+constexpr int GTABLE_WINDOWS = 256 / GTABLE_WINDOW_BITS;
+constexpr size_t GTABLE_ENTRIES = (size_t)GTABLE_WINDOWS << GTABLE_WINDOW_BITS;
+constexpr size_t GTABLE_BYTES = GTABLE_ENTRIES * 64;
+
+// ---- byte loads: 32 big-endian bytes -> 8 little-endian words (w[0] least significant)
+LAMD_HD u32 load_be32(const u8 *p) {
+  return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+}
+LAMD_HD void load_words_be(u32 w[8], const u8 *p) {
+  if ((((uintptr_t)p) & 3) == 0) {
+    const u32 *q = (const u32 *)p;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[7 - i] = __builtin_bswap32(q[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[7 - i] = load_be32(p + 4 * i);
+  }
+}
+
+// ---- public keys.  len: 33 / 65 (SEC1) or 32 (BIP-340 x-only, lifted to even y).
+// Writes canonical affine words; returns validity.
+LAMD_HD bool parse_pubkey(const u8 *p, int len, u32 qx[8], u32 qy[8]) {
+  bool ok = true;
+  u32 prefix = 2;
+  const u8 *xp = p;
+  if (len != 32) {
+    prefix = p[0];
+    xp = p + 1;
+  }
+  load_words_be(qx, xp);
+  ok &= !words_ge_p(qx);
+  const fe x = fe_from_words(qx);
+  const fe rhs = fe_add(fe_mul(fe_sqr(x), x), fe_set_int(7));  // x^3 + 7  (2)
+  if (len == 65) {
+    load_words_be(qy, p + 33);
+    ok &= !words_ge_p(qy);
+    ok &= (prefix == 4) | (prefix == 6) | (prefix == 7);
+    ok &= (prefix == 4) | ((qy[0] & 1) == (prefix & 1));  // hybrid: parity byte must match
+    const fe y = fe_from_words(qy);
+    ok &= fe_equal(rhs, fe_sqr(y), 1);
+  } else {
+    ok &= (prefix == 2) | (prefix == 3);
+    const fe rn = fe_norm_weak(rhs);
+    fe y = fe_sqrt_candidate(rn);
+    ok &= fe_equal(rn, fe_sqr(y), 1);
+    y = fe_normalize(y);
+    const bool flip = (y.n[0] & 1) != (prefix & 1);
+    y = fe_select(flip, fe_normalize(fe_neg(y, 1)), y);
+    fe_to_words(qy, y);
+  }
+  return ok;
+}
+
+// ---- ECDSA preparation for the signatures i = first, first+stride, ... < n owned by one thread
+// recs[i].u1 doubles as the prefix-product store between the two passes.
+LAMD_HD void ecdsa_load_rs(const u8 *sig64, sc *r, sc *s, bool *ok) {
+  u32 rw[8], sw[8];
+  load_words_be(rw, sig64);
+  load_words_be(sw, sig64 + 32);
+  bool v = !words_ge_n(rw) & !words_ge_n(sw);  // secp256k1_ecdsa_signature_parse_compact
+#pragma unroll
+  for (int i = 0; i < 8; i++) { r->w[i] = rw[i]; s->w[i] = sw[i]; }
+  v &= !sc_is_zero(*r) & !sc_is_zero(*s);      // secp256k1_ecdsa_verify: r, s in [1, n-1]
+  v &= !sc_is_high(*s);                        // ... and low-S
+  *ok = v;
+}
+
+LAMD_HD void ecdsa_prep_thread(size_t first, size_t stride, size_t n, const u8 *hash32, const u8 *sig64,
+                               prep_rec *recs) {
+  sc acc;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc.w[i] = (i == 0);
+  size_t last = first;
+  bool any = false;
+#pragma unroll 1
+  for (size_t i = first; i < n; i += stride) {
+    sc r, s;
+    bool ok;
+    ecdsa_load_rs(sig64 + 64 * i, &r, &s, &ok);
+#pragma unroll
+    for (int k = 0; k < 8; k++) recs[i].u1[k] = acc.w[k];  // product of the valid s before i
+    if (ok) acc = sc_mul(acc, s);
+    last = i;
+    any = true;
+  }
+  if (!any) return;
+  sc inv = sc_inv(acc);
+#pragma unroll 1
+  for (size_t i = last;; i -= stride) {
+    sc r, s, prefix;
+    bool ok;
+    ecdsa_load_rs(sig64 + 64 * i, &r, &s, &ok);
+#pragma unroll
+    for (int k = 0; k < 8; k++) prefix.w[k] = recs[i].u1[k];
+    prep_rec out;
+#pragma unroll
+    for (int k = 0; k < 8; k++) out.u1[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { out.k1[k] = 0x88888888u; out.k2[k] = 0x88888888u; }
+    out.flags = 0;
+    out.pad[0] = out.pad[1] = out.pad[2] = 0;
+    if (ok) {
+      const sc w = sc_mul(inv, prefix);  // s_i^-1
+      inv = sc_mul(inv, s);
+      u32 zw[8];
+      load_words_be(zw, hash32 + 32 * i);
+      const sc z = sc_from_words(zw, nullptr);
+      const sc u1 = sc_mul(z, w);
+      const sc u2 = sc_mul(r, w);
+      glv_half h1, h2;
+      glv_split(&h1, &h2, u2);
+#pragma unroll
+      for (int k = 0; k < 8; k++) out.u1[k] = u1.w[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { out.k1[k] = h1.mag[k]; out.k2[k] = h2.mag[k]; }
+      out.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) |
+                  (h2.top ? PREP_K2TOP : 0);
+    }
+    recs[i] = out;
+    if (i == first) break;
+  }
+}
+
+// ---- BIP-340 preparation, one signature
+LAMD_HD void schnorr_prep_one(const u8 *msg32, const u8 *pk32, const u8 *sig64, prep_rec *rec) {
+  u32 rw[8], sw[8];
+  load_words_be(rw, sig64);
+  load_words_be(sw, sig64 + 32);
+  bool ok = !words_ge_p(rw) & !words_ge_n(sw);
+  u32 rb[8], pb[8], mb[8], eh[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) rb[i] = rw[7 - i];
+  u32 t[8];
+  load_words_be(t, pk32);
+#pragma unroll
+  for (int i = 0; i < 8; i++) pb[i] = t[7 - i];
+  load_words_be(t, msg32);
+#pragma unroll
+  for (int i = 0; i < 8; i++) mb[i] = t[7 - i];
+  bip340_challenge(eh, rb, pb, mb);
+  u32 ew[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) ew[i] = eh[7 - i];
+  const sc e = sc_from_words(ew, nullptr);
+  const sc ne = sc_neg(e);
+  glv_half h1, h2;
+  glv_split(&h1, &h2, ne);
+  prep_rec out;
+#pragma unroll
+  for (int k = 0; k < 8; k++) out.u1[k] = sw[k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { out.k1[k] = h1.mag[k]; out.k2[k] = h2.mag[k]; }
+  out.flags = (ok ? PREP_VALID : 0) | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) |
+              (h2.top ? PREP_K2TOP : 0);
+  out.pad[0] = out.pad[1] = out.pad[2] = 0;
+  *rec = out;
+}
+
+// ---- table slot helpers
+LAMD_HD void slot_store_fe(u32 *dst, const fe &a) {
+  u32 w[8];
+  fe_to_words(w, fe_normalize(a));
+#pragma unroll
+  for (int i = 0; i < 8; i++) dst[i] = w[i];
+}
+LAMD_HD fe slot_load_fe(const u32 *src) {
+  u32 w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = src[i];
+  return fe_from_words(w);
+}
+
+// Build the lane's table of 1Q..8Q brought to one shared Z (returned): entry e = (e+1)*Q as an
+// affine point of the isomorphic curve y^2 = x^3 + 7*Zg^6, stored as x | beta*x | y.
+LAMD_HD fe build_q_table(u32 *slot, const ge &q) {
+  gej p = gej_from_ge(q);
+  slot_store_fe(slot + 0, p.x);
+  slot_store_fe(slot + 16, p.y);
+  p = gej_double(p);
+  slot_store_fe(slot + SLOT_ENTRY_WORDS + 0, p.x);
+  slot_store_fe(slot + SLOT_ENTRY_WORDS + 16, p.y);
+#pragma unroll 1
+  for (int i = 2; i < 8; i++) {  // entry i = (i+1)Q = entry(i-1) + Q
+    int st;
+    fe h;
+    p = gej_add_ge_core(p, q, &st, &h);  // (i)Q = +-Q is impossible for i in 2..8: no degenerate case
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, p.x);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, p.y);
+    slot_store_fe(slot + SLOT_H_OFF + (i - 2) * 8, h);
+  }
+  const fe zg = fe_norm_weak(p.z);
+  const u32 betaw[8] = LAMD_BETA;
+  const fe beta = fe_from_words(betaw);
+  // entry 7 already has Z = Zg
+  {
+    const fe x = slot_load_fe(slot + 7 * SLOT_ENTRY_WORDS);
+    slot_store_fe(slot + 7 * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
+  }
+  fe rho = fe_set_int(1);
+#pragma unroll 1
+  for (int i = 6; i >= 0; i--) {
+    // rho = Zg / Z_entry(i): entry i+1 = entry i + Q had Z_{i+1} = Z_i * H (H stored at index i-1 for i >= 1),
+    // and entry 1 = 2Q has Z = Z_2, entry 0 = Q has Z = 1 so its ratio is Zg itself.
+    if (i >= 1) rho = fe_mul(rho, slot_load_fe(slot + SLOT_H_OFF + (i - 1) * 8));
+    else rho = zg;
+    const fe r2 = fe_sqr(rho);
+    const fe r3 = fe_mul(r2, rho);
+    const fe x = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + 0), r2);
+    const fe y = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + 16), r3);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, x);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, y);
+  }
+  return zg;
+}
+
+LAMD_HD int glv_digit(const u32 mag[4], u32 top, int i) {
+  // window i of the biased magnitude; i == 32 is the carry bit
+  if (i == 32) return (int)top;
+  return (int)((mag[i >> 3] >> ((i & 7) * 4)) & 15u) - 8;
+}
+
+// R = u1*G + (k1 + k2*lambda)*Q for a prepared record; returns R (Jacobian on the real curve)
+LAMD_HD gej ecmult_lane(const prep_rec &rec, const ge &q, u32 *slot, const u32 *gtable) {
+  const fe zg = build_q_table(slot, q);
+  const bool n1 = rec.flags & PREP_K1NEG, n2 = rec.flags & PREP_K2NEG;
+  const u32 t1 = (rec.flags & PREP_K1TOP) ? 1u : 0u, t2 = (rec.flags & PREP_K2TOP) ? 1u : 0u;
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int i = 32; i >= 0; i--) {
+    if (i != 32) {
+#pragma unroll 1
+      for (int j = 0; j < 4; j++) acc = gej_double(acc);
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      int d = half ? glv_digit(rec.k2, t2, i) : glv_digit(rec.k1, t1, i);
+      if (half ? n2 : n1) d = -d;
+      const bool skip = d == 0;
+      const int a = d < 0 ? -d : d;
+      const u32 *e = slot + (skip ? 0 : a - 1) * SLOT_ENTRY_WORDS;
+      ge pt;
+      pt.x = slot_load_fe(e + (half ? 8 : 0));
+      pt.y = slot_load_fe(e + 16);
+      pt = ge_neg_if(pt, d < 0);
+      acc = gej_add_ge(acc, pt, skip);
+    }
+  }
+  // back from the isomorphic curve: (X, Y, Z) -> (X, Y, Z*Zg)
+  acc.z = fe_mul(acc.z, zg);
+  // + u1*G from the 16-bit-window table
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);
+    const bool skip = d == 0;
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    ge pt;
+    pt.x = slot_load_fe(e);
+    pt.y = slot_load_fe(e + 8);
+    acc = gej_add_ge(acc, pt, skip);
+  }
+  return acc;
+}
+
+// One entry of the static G table: out = d * B (B = 2^(BITS*w) * G given as affine words), d >= 1.
+LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
+  const ge b = ge_from_words(base, base + 8);
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int bit = GTABLE_WINDOW_BITS - 1; bit >= 0; bit--) {
+    acc = gej_double(acc);
+    acc = gej_add_ge(acc, b, ((d >> bit) & 1u) == 0);
+  }
+  const fe zi = fe_inv(fe_norm_weak(acc.z));
+  const fe zi2 = fe_sqr(zi);
+  fe_to_words(out, fe_normalize(fe_mul(acc.x, zi2)));
+  fe_to_words(out + 8, fe_normalize(fe_mul(acc.y, fe_mul(zi2, zi))));
+}
+
+// p - n (129 bits): r + n < p  <=>  r < p - n
+#define LAMD_P_MINUS_N {0x2FC9BAEEu, 0x402DA172u, 0x50B75FC4u, 0x45512319u, 1u, 0u, 0u, 0u}
+
+// ECDSA acceptance: R != inf and x(R) mod n == r, tested without inversion
+LAMD_HD bool ecdsa_final(const gej &R, const u32 rw[8]) {
+  if (R.inf) return false;
+  const fe z2 = fe_sqr(R.z);
+  const fe rf = fe_from_words(rw);  // r < n < p
+  bool ok = fe_equal(fe_mul(rf, z2), R.x, 1);
+  const u32 pmn[8] = LAMD_P_MINUS_N;
+  if (!words_ge(rw, pmn)) {  // r + n < p: x(R) may also be r + n
+    const u32 nw[8] = LAMD_SC_N;
+    u32 t[8];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      c += (u64)rw[i] + nw[i];
+      t[i] = (u32)c;
+      c >>= 32;
+    }
+    ok |= fe_equal(fe_mul(fe_from_words(t), z2), R.x, 1);
+  }
+  return ok;
+}
+
+// BIP-340 acceptance: R != inf, y(R) even, x(R) == r
+LAMD_HD bool schnorr_final(const gej &R, const u32 rw[8]) {
+  if (R.inf) return false;
+  const fe z2 = fe_sqr(R.z);
+  const fe rf = fe_from_words(rw);  // r < p checked in prep
+  if (!fe_equal(fe_mul(rf, z2), R.x, 1)) return false;
+  const fe zi = fe_inv(fe_norm_weak(R.z));
+  const fe y = fe_normalize(fe_mul(R.y, fe_mul(fe_sqr(zi), zi)));
+  return (y.n[0] & 1) == 0;
+}
+
+}  // namespace lamd

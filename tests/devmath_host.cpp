@@ -1,0 +1,120 @@
+// CPU build of the DEVICE arithmetic (lightning_amd/csrc/*.h compiled for the host with
+// magnitude checking on).  Test infrastructure only: lets the CPU test-suite drive exactly the
+// code the HIP kernels run (field, scalar, GLV, table build, ladder, final checks) against
+// Python big-ints and the oracle before anything touches a GPU.  Not a product path: the
+// shipped library (liblightning_amd.so) contains no CPU verification code.
+#define LAMD_CHECK_MAG 1
+#define LAMD_GTABLE_WINDOW_BITS 8
+#include "../lightning_amd/csrc/verify_core.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+using namespace lamd;
+
+static void be_to_words(u32 w[8], const u8 *b) { for (int i = 0; i < 8; i++) w[7 - i] = load_be32(b + 4 * i); }
+static void words_to_be(u8 *b, const u32 w[8]) { for (int i = 0; i < 8; i++) { u32 v = w[7 - i]; b[4*i] = v >> 24; b[4*i+1] = v >> 16; b[4*i+2] = v >> 8; b[4*i+3] = v; } }
+
+static fe fe_from_raw(const u32 *limbs, int mag) { fe a; for (int i = 0; i < 9; i++) a.n[i] = limbs[i]; a.mag = mag; fe_verify(a); return a; }
+static void fe_to_raw(u32 *limbs, int *mag, const fe &a) { for (int i = 0; i < 9; i++) limbs[i] = a.n[i]; *mag = a.mag; }
+
+extern "C" {
+// op codes: 0 add, 1 neg(a, mag), 2 mul, 3 sqr, 4 norm_weak, 5 carry, 6 normalize, 7 mul_int(k=b_mag), 8 is_zero (out[0])
+int dm_fe_op(int op, const u32 *a, int amag, const u32 *b, int bmag, u32 *out, int *omag) {
+  fe x = fe_from_raw(a, amag), y, r;
+  if (op == 0 || op == 2) y = fe_from_raw(b, bmag);
+  switch (op) {
+    case 0: r = fe_add(x, y); break;
+    case 1: r = fe_neg(x, amag); break;
+    case 2: r = fe_mul(x, y); break;
+    case 3: r = fe_sqr(x); break;
+    case 4: r = fe_norm_weak(x); break;
+    case 5: r = fe_carry(x); break;
+    case 6: r = fe_normalize(x); break;
+    case 7: r = fe_mul_int(x, (u32)bmag); break;
+    case 8: r = fe_zero(); r.n[0] = fe_is_zero(x); break;
+    default: return -1;
+  }
+  fe_to_raw(out, omag, r);
+  return 0;
+}
+void dm_fe_from_be(const u8 *b, u32 *limbs) { u32 w[8]; be_to_words(w, b); fe a = fe_from_words(w); for (int i = 0; i < 9; i++) limbs[i] = a.n[i]; }
+void dm_fe_to_be(const u32 *limbs, int mag, u8 *b) { fe a = fe_from_raw(limbs, mag); u32 w[8]; fe_to_words(w, fe_normalize(a)); words_to_be(b, w); }
+void dm_fe_inv(const u8 *a, u8 *out) { u32 w[8]; be_to_words(w, a); fe r = fe_inv(fe_from_words(w)); fe_to_words(w, fe_normalize(r)); words_to_be(out, w); }
+int dm_fe_sqrt(const u8 *a, u8 *out) { u32 w[8]; be_to_words(w, a); fe x = fe_from_words(w); fe r = fe_sqrt_candidate(x); int ok = fe_equal(x, fe_sqr(r), 1); fe_to_words(w, fe_normalize(r)); words_to_be(out, w); return ok; }
+int dm_words_ge_p(const u8 *a) { u32 w[8]; be_to_words(w, a); return words_ge_p(w); }
+
+void dm_sc_mul(const u8 *a, const u8 *b, u8 *out) { sc x, y; be_to_words(x.w, a); be_to_words(y.w, b); sc r = sc_mul(x, y); words_to_be(out, r.w); }
+void dm_sc_inv(const u8 *a, u8 *out) { sc x; be_to_words(x.w, a); sc r = sc_inv(x); words_to_be(out, r.w); }
+void dm_sc_neg(const u8 *a, u8 *out) { sc x; be_to_words(x.w, a); sc r = sc_neg(x); words_to_be(out, r.w); }
+int dm_sc_from(const u8 *a, u8 *out) { u32 w[8]; be_to_words(w, a); bool of; sc r = sc_from_words(w, &of); words_to_be(out, r.w); return of; }
+int dm_sc_is_high(const u8 *a) { sc x; be_to_words(x.w, a); return sc_is_high(x); }
+// out: k1mag[16 bytes LE words], top1, neg1, k2mag, top2, neg2 as u32[12]
+void dm_glv_split(const u8 *k, u32 *out) { sc x; be_to_words(x.w, k); glv_half h1, h2; glv_split(&h1, &h2, x);
+  for (int i = 0; i < 4; i++) { out[i] = h1.mag[i]; out[6 + i] = h2.mag[i]; } out[4] = h1.top; out[5] = h1.neg; out[10] = h2.top; out[11] = h2.neg; }
+void dm_bip340_challenge(const u8 *r, const u8 *pk, const u8 *m, u8 *out) {
+  u32 rb[8], pb[8], mb[8], o[8];
+  for (int i = 0; i < 8; i++) { rb[i] = load_be32(r + 4*i); pb[i] = load_be32(pk + 4*i); mb[i] = load_be32(m + 4*i); }
+  bip340_challenge(o, rb, pb, mb);
+  for (int i = 0; i < 8; i++) { out[4*i] = o[i] >> 24; out[4*i+1] = o[i] >> 16; out[4*i+2] = o[i] >> 8; out[4*i+3] = o[i]; }
+}
+int dm_parse_pubkey(const u8 *p, int len, u8 *out64) { u32 qx[8], qy[8]; bool ok = parse_pubkey(p, len, qx, qy); words_to_be(out64, qx); words_to_be(out64 + 32, qy); return ok; }
+
+// ---- static G table (8-bit windows in this build), built with the same entry function the device uses
+static std::vector<u32> g_table;
+void dm_init(void) {
+  if (!g_table.empty()) return;
+  g_table.assign(GTABLE_ENTRIES * 16, 0);
+  const u32 gx[8] = LAMD_GX, gy[8] = LAMD_GY;
+  u32 base[16];
+  memcpy(base, gx, 32); memcpy(base + 8, gy, 32);
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    for (u32 d = 1; d < (1u << GTABLE_WINDOW_BITS); d++)
+      gtable_compute_entry(&g_table[(((size_t)w << GTABLE_WINDOW_BITS) + d) * 16], base, d);
+    // next base = 2^BITS * base
+    gej b = gej_from_ge(ge_from_words(base, base + 8));
+    for (int i = 0; i < GTABLE_WINDOW_BITS; i++) b = gej_double(b);
+    const fe zi = fe_inv(fe_norm_weak(b.z)); const fe zi2 = fe_sqr(zi);
+    fe_to_words(base, fe_normalize(fe_mul(b.x, zi2)));
+    fe_to_words(base + 8, fe_normalize(fe_mul(b.y, fe_mul(zi2, zi))));
+  }
+}
+// table entry as 64 big-endian bytes
+void dm_gtable_entry(int w, u32 d, u8 *out64) { dm_init(); const u32 *e = &g_table[(((size_t)w << GTABLE_WINDOW_BITS) + d) * 16]; words_to_be(out64, e); words_to_be(out64 + 32, e + 8); }
+
+// Whole pipeline exactly as the kernels stage it.  threads = how many "prep threads" share the batch
+// (exercises the Montgomery batch inversion with different group sizes).
+void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8 *pub, int publen, int pubstride, u8 *out, size_t threads) {
+  dm_init();
+  std::vector<prep_rec> recs(n);
+  for (size_t t = 0; t < threads; t++) ecdsa_prep_thread(t, threads, n, hash32, sig64, recs.data());
+  std::vector<u32> slot(SLOT_WORDS);
+  for (size_t i = 0; i < n; i++) {
+    u32 qx[8], qy[8], rw[8];
+    bool ok = parse_pubkey(pub + (size_t)pubstride * i, publen, qx, qy);
+    ok &= (recs[i].flags & PREP_VALID) != 0;
+    if (ok) {
+      const gej R = ecmult_lane(recs[i], ge_from_words(qx, qy), slot.data(), g_table.data());
+      be_to_words(rw, sig64 + 64 * i);
+      ok = ecdsa_final(R, rw);
+    }
+    out[i] = ok;
+  }
+}
+void dm_schnorr_verify_batch(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out) {
+  dm_init();
+  std::vector<u32> slot(SLOT_WORDS);
+  for (size_t i = 0; i < n; i++) {
+    prep_rec rec;
+    schnorr_prep_one(msg32 + 32 * i, pk32 + 32 * i, sig64 + 64 * i, &rec);
+    u32 qx[8], qy[8], rw[8];
+    bool ok = parse_pubkey(pk32 + 32 * i, 32, qx, qy);
+    ok &= (rec.flags & PREP_VALID) != 0;
+    if (ok) {
+      const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slot.data(), g_table.data());
+      be_to_words(rw, sig64 + 64 * i);
+      ok = schnorr_final(R, rw);
+    }
+    out[i] = ok;
+  }
+}
+}

@@ -1,0 +1,257 @@
+"""Drives the DEVICE arithmetic compiled for the host (tests/devmath_host.cpp: same headers the
+HIP kernels include, magnitude assertions on) against Python big-ints, the golden vectors and
+the oracle.  CPU only; this is how the kernels' math is debugged before it reaches a GPU."""
+import ctypes
+import hashlib
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+P, N = pyref.P, pyref.N
+H = bytes.fromhex
+
+
+@pytest.fixture(scope="session")
+def dm():
+    so = os.path.join(HERE, "libdevmath_host.so")
+    srcs = [os.path.join(HERE, "devmath_host.cpp")] + [os.path.join(ROOT, "lightning_amd", "csrc", f)
+                                                       for f in ("lamd_common.h", "fe.h", "scalar.h", "group.h", "sha256.h", "verify_core.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
+    L = ctypes.CDLL(so)
+    L.dm_fe_op.restype = ctypes.c_int
+    L.dm_fe_sqrt.restype = ctypes.c_int
+    L.dm_words_ge_p.restype = ctypes.c_int
+    L.dm_sc_from.restype = ctypes.c_int
+    L.dm_sc_is_high.restype = ctypes.c_int
+    L.dm_parse_pubkey.restype = ctypes.c_int
+    L.dm_init()
+    return L
+
+
+U9 = ctypes.c_uint32 * 9
+
+
+def limbs_val(l):
+    return sum(int(v) << (29 * i) for i, v in enumerate(l))
+
+
+def rand_fe(rnd, mag):
+    lim29, lim24 = (1 << 29) + (1 << 13), (1 << 24) + (1 << 13)
+    mode = rnd.random()
+    if mode < 0.2:
+        return [mag * lim29] * 8 + [mag * lim24]          # every limb at its bound
+    if mode < 0.3:
+        return [0] * 9
+    return [rnd.randrange(mag * lim29 + 1) for _ in range(8)] + [rnd.randrange(mag * lim24 + 1)]
+
+
+def fe_op(dm, op, a, amag, b=None, bmag=0):
+    out = U9()
+    om = ctypes.c_int()
+    rc = dm.dm_fe_op(op, U9(*a), amag, U9(*(b or [0] * 9)), bmag, out, ctypes.byref(om))
+    assert rc == 0
+    return list(out), om.value
+
+
+def test_fe_ops_at_magnitude_bounds(dm):
+    rnd = random.Random(1)
+    for _ in range(3000):
+        ma, mb = rnd.randrange(1, 8), rnd.randrange(1, 8)
+        a, b = rand_fe(rnd, ma), rand_fe(rnd, mb)
+        va, vb = limbs_val(a) % P, limbs_val(b) % P
+        if ma + mb <= 7:
+            r, m = fe_op(dm, 0, a, ma, b, mb)
+            assert limbs_val(r) % P == (va + vb) % P and m == ma + mb
+        if ma + 1 <= 7:
+            r, m = fe_op(dm, 1, a, ma)
+            assert limbs_val(r) % P == (-va) % P and m == ma + 1
+        if ma * mb <= 7:
+            r, m = fe_op(dm, 2, a, ma, b, mb)
+            assert limbs_val(r) % P == va * vb % P and m == 1
+        if ma <= 2:
+            r, m = fe_op(dm, 3, a, ma)
+            assert limbs_val(r) % P == va * va % P
+        for op in (4, 5):
+            r, m = fe_op(dm, op, a, ma)
+            assert limbs_val(r) % P == va
+        r, m = fe_op(dm, 6, a, ma)
+        assert limbs_val(r) == va  # canonical
+        assert all(x < (1 << 29) for x in r[:8]) and r[8] < (1 << 24)
+        k = rnd.randrange(1, 8)
+        if ma * k <= 7:
+            r, m = fe_op(dm, 7, a, ma, None, k)
+            assert limbs_val(r) % P == va * k % P
+        r, _ = fe_op(dm, 8, a, ma)
+        assert r[0] == (va == 0)
+
+
+def test_fe_zero_detection_on_multiples_of_p(dm):
+    # every representation of 0 reachable with lazy limbs: k*p spread over the limbs in different ways
+    rnd = random.Random(2)
+    pl = [0x1FFFFC2F, 0x1FFFFFF7] + [0x1FFFFFFF] * 6 + [0xFFFFFF]
+    for k in range(0, 8):
+        a = [k * x for x in pl]
+        r, _ = fe_op(dm, 8, a, max(k, 1))
+        assert r[0] == 1
+        r, _ = fe_op(dm, 6, a, max(k, 1))
+        assert limbs_val(r) == 0
+        # perturb: +1 must be non-zero
+        a2 = list(a); a2[0] += 1
+        r, _ = fe_op(dm, 8, a2, min(7, k + 1))
+        assert r[0] == 0
+    # values just below / above p and 2^256
+    for v in (P - 1, P, P + 1, 2**256 - 1, 1, 0, P - 977, 2**256 - 2**32 - 978):
+        a = [(v >> (29 * i)) & 0x1FFFFFFF for i in range(8)] + [v >> 232]
+        r, _ = fe_op(dm, 6, a, 1)
+        assert limbs_val(r) == v % P
+
+
+def test_fe_conversions_inv_sqrt(dm):
+    rnd = random.Random(3)
+    for i in range(200):
+        v = rnd.randrange(P) if i > 8 else [0, 1, P - 1, P - 2, 2**255, 977, 2**32 + 977, 2**232, 2**29 - 1][i]
+        b = v.to_bytes(32, "big")
+        l = U9()
+        dm.dm_fe_from_be(b, l)
+        assert limbs_val(l) == v
+        o = ctypes.create_string_buffer(32)
+        dm.dm_fe_to_be(l, 1, o)
+        assert o.raw == b
+        if v:
+            dm.dm_fe_inv(b, o)
+            assert int.from_bytes(o.raw, "big") == pow(v, -1, P)
+        ok = dm.dm_fe_sqrt(b, o)
+        is_qr = pow(v, (P - 1) // 2, P) in (0, 1)
+        assert bool(ok) == is_qr
+        if is_qr:
+            assert pow(int.from_bytes(o.raw, "big"), 2, P) == v
+    for v in (P - 1, P, P + 1, 2**256 - 1, 0, P - 2**32, (P | (1 << 32)) & (2**256 - 1)):
+        assert bool(dm.dm_words_ge_p(v.to_bytes(32, "big"))) == (v >= P)
+
+
+def test_scalar_ops(dm):
+    rnd = random.Random(4)
+    o = ctypes.create_string_buffer(32)
+    specials = [0, 1, 2, N - 1, N - 2, (N - 1) // 2, (N + 1) // 2, 2**128, 2**255, N >> 1]
+    for i in range(300):
+        a = specials[i % len(specials)] if i < 40 else rnd.randrange(N)
+        b = specials[(i // len(specials)) % len(specials)] if i < 40 else rnd.randrange(N)
+        dm.dm_sc_mul(a.to_bytes(32, "big"), b.to_bytes(32, "big"), o)
+        assert int.from_bytes(o.raw, "big") == a * b % N
+        dm.dm_sc_neg(a.to_bytes(32, "big"), o)
+        assert int.from_bytes(o.raw, "big") == (-a) % N
+        assert bool(dm.dm_sc_is_high(a.to_bytes(32, "big"))) == (a > N // 2)
+        raw = rnd.randrange(2**256) if i % 3 else N + rnd.randrange(2**256 - N)
+        of = dm.dm_sc_from(raw.to_bytes(32, "big"), o)
+        assert int.from_bytes(o.raw, "big") == raw % N and bool(of) == (raw >= N)
+    for i in range(25):
+        a = [1, 2, N - 1, 3][i] if i < 4 else rnd.randrange(1, N)
+        dm.dm_sc_inv(a.to_bytes(32, "big"), o)
+        assert int.from_bytes(o.raw, "big") == pow(a, -1, N)
+
+
+LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+
+
+def test_glv_split(dm):
+    rnd = random.Random(5)
+    out = (ctypes.c_uint32 * 12)()
+    bias = int("8" * 32, 16)
+    for i in range(3000):
+        k = [0, 1, N - 1, LAM, N - LAM, 2**128, 2**128 - 1, (N - 1) // 2][i] if i < 8 else rnd.randrange(N)
+        dm.dm_glv_split(k.to_bytes(32, "big"), out)
+        vals = []
+        for off in (0, 6):
+            mag = sum(int(out[off + j]) << (32 * j) for j in range(4)) + (int(out[off + 4]) << 128) - bias
+            assert 0 <= mag < 2**128
+            # digits as the ladder reads them
+            digs = [((int(out[off + (w >> 3)]) >> ((w & 7) * 4)) & 15) - 8 for w in range(32)] + [int(out[off + 4])]
+            assert sum(d * 16**w for w, d in enumerate(digs)) == mag and all(-8 <= d <= 8 for d in digs)
+            vals.append(-mag if out[off + 5] else mag)
+        assert (vals[0] + vals[1] * LAM - k) % N == 0
+
+
+def test_bip340_challenge(dm):
+    rnd = random.Random(6)
+    o = ctypes.create_string_buffer(32)
+    for _ in range(50):
+        r, pk, m = rnd.randbytes(32), rnd.randbytes(32), rnd.randbytes(32)
+        dm.dm_bip340_challenge(r, pk, m, o)
+        assert o.raw == pyref.tagged_hash("BIP0340/challenge", r + pk + m)
+
+
+def test_parse_pubkey_and_gtable(dm, kat):
+    o = ctypes.create_string_buffer(64)
+    for v in kat["pubkey"]:
+        pub = H(v["pub"])
+        if len(pub) not in (33, 65):
+            continue
+        ok = dm.dm_parse_pubkey(pub, len(pub), o)
+        assert bool(ok) == (v["expect"] is not None), v["pub"]
+        if ok:
+            assert o.raw == H(v["expect"])
+    rnd = random.Random(7)
+    for _ in range(40):
+        w, d = rnd.randrange(32), rnd.randrange(1, 256)
+        dm.dm_gtable_entry(w, d, o)
+        pt = pyref.pmul(d << (8 * w), pyref.G)
+        assert o.raw == pt[0].to_bytes(32, "big") + pt[1].to_bytes(32, "big")
+
+
+def _run_ecdsa(dm, rows, threads):
+    n = len(rows)
+    publen = len(rows[0][2])
+    hs = b"".join(r[0] for r in rows)
+    sg = b"".join(r[1] for r in rows)
+    pk = b"".join(r[2] for r in rows)
+    out = ctypes.create_string_buffer(n)
+    dm.dm_ecdsa_verify_batch(ctypes.c_size_t(n), hs, sg, pk, publen, publen, out, ctypes.c_size_t(threads))
+    return [bool(b) for b in out.raw]
+
+
+def test_pipeline_golden_ecdsa(dm, kat):
+    for publen in (33, 65):
+        rows = [(H(v["hash"]), H(v["sig"]), H(v["pub"]), v["expect"], v["name"]) for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
+        assert len(rows) > 100
+        for threads in (1, 7, len(rows)):
+            got = _run_ecdsa(dm, rows, threads)
+            bad = [r[4] for r, g in zip(rows, got) if g != r[3]]
+            assert not bad, (publen, threads, bad[:10])
+
+
+def test_pipeline_golden_schnorr(dm, kat):
+    rows = kat["schnorr"]
+    n = len(rows)
+    out = ctypes.create_string_buffer(n)
+    dm.dm_schnorr_verify_batch(ctypes.c_size_t(n), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["pk"]) for v in rows),
+                               b"".join(H(v["sig"]) for v in rows), out)
+    bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
+    assert not bad, bad[:10]
+
+
+def test_pipeline_random_vs_oracle(dm, orc):
+    rnd = random.Random(8)
+    rows = []
+    for i in range(120):
+        d = rnd.randrange(1, N).to_bytes(32, "big")
+        h = rnd.randbytes(32)
+        sig = orc.ecdsa_sign(h, d, rnd.randrange(1, N).to_bytes(32, "big"))
+        pub = orc.pubkey_create(d)
+        pub33 = bytes([2 + (pub[64] & 1)]) + pub[1:33]
+        c = i % 4
+        if c == 1:
+            h = bytes([h[0] ^ 0x40]) + h[1:]
+        elif c == 2:
+            sig = sig[:40] + bytes([sig[40] ^ 1]) + sig[41:]
+        rows.append((h, sig, pub33))
+    got = _run_ecdsa(dm, rows, 5)
+    exp = [orc.ecdsa_verify(*r) for r in rows]
+    assert got == exp and sum(exp) >= 50
