@@ -1,0 +1,145 @@
+/* lightning_amd -- MI355X (gfx950) batched secp256k1 signature verification.
+ *
+ * C ABI of liblightning_amd.so: the drop-in boundary for Core Lightning's signature-check
+ * hot path.  Every entry point names the reference interface it replaces (paths relative to
+ * the Core Lightning tree, v26.06.6).  Plain pointers and sizes only; all byte formats are the
+ * SERIALISED forms the reference handles at its own boundaries (the opaque in-memory
+ * secp256k1_pubkey / secp256k1_ecdsa_signature layouts are implementation-defined and never
+ * cross this ABI):
+ *     hash / sighash / BIP-340 message : 32 raw bytes   (struct sha256_double, bitcoin/shadouble.h:9-11)
+ *     ECDSA signature                  : 64-byte compact big-endian r||s (wire/fromwire.c:188-199)
+ *     public key                       : 33-byte SEC1 compressed (struct node_id, common/node_id.h:11-13;
+ *                                        pubkey_to_der, bitcoin/pubkey.c:26-34) or 65-byte uncompressed
+ *     BIP-340 signature / x-only key   : 64 / 32 raw bytes (struct bip340sig, bitcoin/signature.h:145-147)
+ *
+ * Verdict convention: ok[i] = 1 iff the reference would have accepted, i.e.
+ *     parse_ok(signature) && parse_ok(key) && verify_ok
+ * so a host-side parse failure and a device-side reject are indistinguishable from the
+ * reference's combined outcome.  There is NO CPU fallback: without a working HIP device every
+ * call returns LAMD_ERR_NO_DEVICE / LAMD_ERR_HIP and the caller must fail closed.
+ *
+ * Threading: a context owns one device, one stream and its staging buffers; calls on one
+ * context must be serialised by the caller (the reference's daemons are single-threaded:
+ * gossipd/gossipd.c:620-625, channeld/channeld.c:7063-7121).  Use one context per thread/GPU.
+ */
+#ifndef LIGHTNING_AMD_H
+#define LIGHTNING_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lamd_ctx lamd_ctx;
+
+enum {
+	LAMD_OK = 0,
+	LAMD_ERR_NO_DEVICE = -1, /* no usable HIP device (or wrong architecture) */
+	LAMD_ERR_HIP = -2,       /* a HIP call failed; lamd_last_error() has the text */
+	LAMD_ERR_ARG = -3,       /* bad argument (NULL, unsupported key length, ...) */
+	LAMD_ERR_NOMEM = -4,
+	LAMD_ERR_STATE = -5      /* streaming API misuse (poll before flush, queue full, ...) */
+};
+
+/* ---- lifecycle.  Replaces the process-global secp256k1_ctx set up in common/setup.c:58
+ * (secp256k1_ctx = wally_get_secp_context(), common/utils.c:16): the one-time work here is the
+ * upload/build of the static table of G multiples in HBM. */
+int lamd_init(lamd_ctx **ctx, int device);
+void lamd_shutdown(lamd_ctx *ctx);
+const char *lamd_last_error(const lamd_ctx *ctx);
+const char *lamd_version(void);
+
+/* ---- batch verification, host buffers in, host verdicts out (H2D + kernels + D2H, synchronous).
+ *
+ * lamd_verify_ecdsa_batch: n independent check_signed_hash() calls (bitcoin/signature.c:174-192,
+ * decl bitcoin/signature.h:85-87).  publen is 33 or 65 for every key of the batch; key i is at
+ * pub + i*pubstride.  With publen 33 this is check_signed_hash_nodeid() (common/node_id.c:72-80).
+ * 65-byte keys may be 0x04 or hybrid 0x06/0x07, as secp256k1_ec_pubkey_parse accepts them. */
+int lamd_verify_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64,
+			    const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
+
+/* n independent check_schnorr_sig() calls (bitcoin/signature.c:408-430, decl signature.h:129-131):
+ * BIP-340 verification of a 32-byte message under an x-only key. */
+int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32,
+			      const uint8_t *sig64, uint8_t *ok);
+
+/* ---- the same with every buffer already resident in HBM (device pointers), asynchronous on the
+ * context's stream (lamd_stream()); the caller synchronises.  This is what bench.py times. */
+int lamd_verify_ecdsa_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64,
+				   const void *d_pub, size_t publen, size_t pubstride, void *d_ok);
+int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg32, const void *d_xonly32,
+				     const void *d_sig64, void *d_ok);
+void *lamd_stream(lamd_ctx *ctx); /* hipStream_t */
+int lamd_synchronize(lamd_ctx *ctx);
+
+/* ---- single-item veneers with the reference's exact boolean semantics (1 = true, 0 = false,
+ * < 0 = engine error: treat as failure).  They run a batch of one: correct but latency-bound;
+ * callers on the hot path should batch. */
+int lamd_check_signed_hash(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
+			   const uint8_t *pubkey, size_t publen);          /* bitcoin/signature.h:85-87 */
+int lamd_check_signed_hash_nodeid(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
+				  const uint8_t node_id33[33]);             /* common/node_id.h:80-82 */
+int lamd_check_schnorr_sig(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t pubkey33[33],
+			   const uint8_t bip340sig64[64]);                   /* bitcoin/signature.h:129-131 */
+
+/* ---- public-key parsing: n independent pubkey_from_der() / pubkey_from_node_id() calls
+ * (bitcoin/pubkey.c:14-24, common/node_id.c:21-27 -> secp256k1_ec_pubkey_parse; publen 33 or 65),
+ * or secp256k1_xonly_pubkey_parse with publen 32 (bitcoin/signature.c:422).  ok[i] = validity,
+ * out64 + 64*i = affine X||Y big-endian (unspecified when invalid).  out64 may be NULL. */
+int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *pub, size_t publen, size_t pubstride,
+			    uint8_t *out64, uint8_t *ok);
+
+/* ---- gossip: gossipd/sigcheck.c on raw wire messages, batched.
+ * msgs: the messages back to back; off[i]..off[i+1] delimits message i (off has n+1 entries).
+ * kind is inferred from the 2-byte type (256 channel_announcement, 257 node_announcement,
+ * 258 channel_update).  For channel_update the signer is not in the message (the reference looks
+ * it up in the gossmap, gossipd/gossmap_manage.c:920-922): node_ids holds one 33-byte id per
+ * message (ignored for the other kinds; may be NULL if the batch has no channel_update).
+ * verdict[i]: 0 = OK (reference returns NULL); k > 0 = first bad signature, numbered as the
+ * reference's messages name them -- channel_announcement: 1 "Bad node_signature_1",
+ * 2 "Bad node_signature_2", 3 "Bad bitcoin_signature_1", 4 "Bad bitcoin_signature_2"
+ * (gossipd/sigcheck.c:78-113); others: 1 "Bad signature for" (:35-41, :144-161);
+ * -1 = malformed: what fromwire_* would have rejected before sigcheck runs (truncated message,
+ * compact signature with r or s >= n, wire/fromwire.c:196-198; invalid bitcoin_key,
+ * bitcoin/pubkey.c:102-113). */
+int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, const uint64_t *off,
+			       const uint8_t *node_ids33, int8_t *verdict);
+
+/* ---- streaming front end for callers that produce triples one at a time (channeld's
+ * commitment_signed loop, channeld/channeld.c:2171,2215-2232; gossip ingest).  Triples are
+ * appended to a pinned staging ring; flush launches everything queued (asynchronous);
+ * poll/wait return the verdicts in submission order. */
+int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
+		     const uint8_t *pubkey, size_t publen); /* returns the ticket (>= 0) or an error */
+int lamd_queue_schnorr(lamd_ctx *ctx, const uint8_t msg32[32], const uint8_t xonly32[32],
+		       const uint8_t sig64[64]);
+int lamd_flush(lamd_ctx *ctx);
+/* 1 = finished (ok[0..*n) filled, tickets in submission order), 0 = still running, < 0 error */
+int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
+int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
+
+/* ---- synthetic workload generation ON THE DEVICE (role of devtools/mkgossip.c:131-147,235-322
+ * in the reference: producing signed test traffic).  Keys and nonces are derived from the seed
+ * with splitmix64; outputs are device buffers.  Not a signing API: secrets are public by
+ * construction. */
+int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t publen,
+			  void *d_hash32, void *d_sig64, void *d_pub);
+int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys,
+			    void *d_msg32, void *d_xonly32, void *d_sig64);
+
+/* ---- introspection for benchmarks / tests */
+typedef struct {
+	int device;
+	int compute_units;
+	char arch[64];
+	size_t gtable_bytes;
+	double last_kernel_ms[4]; /* prep, keys, ecmult, aux of the last *_device call when timing is on */
+} lamd_info;
+int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
+int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTNING_AMD_H */

@@ -1,0 +1,8 @@
+"""lightning_amd: MI355X-native batched secp256k1 signature verification behind Core Lightning's
+check_signed_hash / check_tx_sig / check_schnorr_sig / gossipd sigcheck_* interface.
+
+The product is liblightning_amd.so (C ABI: include/lightning_amd.h; kernels: csrc/).  This
+package is the thin Python front end used by tests and bench.py."""
+from .engine import Engine, LamdError  # noqa: F401
+
+__all__ = ["Engine", "LamdError"]

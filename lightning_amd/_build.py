@@ -1,0 +1,30 @@
+"""Builds liblightning_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "liblightning_amd.so")
+SOURCES = [os.path.join(CSRC, f) for f in ("lamd_engine.hip", "verify_core.h", "group.h", "fe.h", "scalar.h", "sha256.h", "lamd_common.h")] + [
+    os.path.join(ROOT, "include", "lightning_amd.h")]
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in SOURCES)
+
+
+def build(force=False, verbose=False):
+    if not (force or is_stale()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+           "-o", LIB + ".tmp", os.path.join(CSRC, "lamd_engine.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB

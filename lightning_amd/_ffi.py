@@ -1,0 +1,63 @@
+"""ctypes binding of the C ABI declared in include/lightning_amd.h (one line per exported symbol)."""
+import ctypes
+import os
+
+from . import _build
+
+c_u8p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+
+class LamdInfo(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("arch", ctypes.c_char * 64),
+                ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4)]
+
+
+# name -> (restype, argtypes); every symbol of include/lightning_amd.h
+SYMBOLS = {
+    "lamd_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    "lamd_shutdown": (None, [ctypes.c_void_p]),
+    "lamd_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "lamd_version": (ctypes.c_char_p, []),
+    "lamd_verify_ecdsa_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_u8p]),
+    "lamd_verify_schnorr_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "lamd_verify_ecdsa_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_u8p]),
+    "lamd_verify_schnorr_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "lamd_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "lamd_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "lamd_check_signed_hash": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, c_sz]),
+    "lamd_check_signed_hash_nodeid": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
+    "lamd_check_schnorr_sig": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
+    "lamd_pubkey_parse_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_sz, c_sz, c_u8p, c_u8p]),
+    "lamd_sigcheck_gossip_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "lamd_queue_ecdsa": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, c_sz]),
+    "lamd_queue_schnorr": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
+    "lamd_flush": (ctypes.c_int, [ctypes.c_void_p]),
+    "lamd_poll": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
+    "lamd_wait": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
+    "lamd_gen_ecdsa_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_gen_schnorr_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
+    "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+}
+
+_lib = None
+
+
+def load(build_if_needed=True):
+    """dlopen liblightning_amd.so (building it first if the sources are newer).  Raises if it is
+    missing: there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        if build_if_needed and os.path.exists("/opt/rocm/bin/hipcc"):
+            _build.build()
+        if not os.path.exists(_build.LIB):
+            raise RuntimeError("liblightning_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                               "lightning_amd has no CPU fallback")
+        L = ctypes.CDLL(_build.LIB)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError here = header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

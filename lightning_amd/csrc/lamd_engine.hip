@@ -1,0 +1,914 @@
+// liblightning_amd.so: HIP kernels (gfx950) + the C-ABI engine of include/lightning_amd.h.
+// One signature per wavefront lane in every kernel; the arithmetic lives in verify_core.h.
+// There is deliberately no CPU verification path in this library.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lightning_amd.h"
+#include "verify_core.h"
+
+using namespace lamd;
+
+// =====================================================================================
+//                                       kernels
+// =====================================================================================
+
+// ---- static G table: one thread per entry
+__global__ void __launch_bounds__(256) k_gtable_build(u32 *__restrict__ gtable, const u32 *__restrict__ bases) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= GTABLE_ENTRIES) return;
+  const u32 w = (u32)(idx >> GTABLE_WINDOW_BITS), d = (u32)(idx & ((1u << GTABLE_WINDOW_BITS) - 1u));
+  u32 out[16];
+  if (d == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = 0;
+  } else {
+    u32 base[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) base[i] = bases[w * 16 + i];
+    gtable_compute_entry(out, base, d);
+  }
+  uint4 *dst = reinterpret_cast<uint4 *>(gtable + idx * 16);
+#pragma unroll
+  for (int i = 0; i < 4; i++) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+}
+
+// ---- ECDSA scalar preparation: each thread owns signatures tid, tid+T, ... and inverts their
+// s values with one modular inversion (Montgomery's trick)
+__global__ void __launch_bounds__(256) k_ecdsa_prep(size_t n, const u8 *__restrict__ hash32, const u8 *__restrict__ sig64,
+                                                    prep_rec *__restrict__ recs) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  ecdsa_prep_thread(tid, T, n, hash32, sig64, recs);
+}
+
+__global__ void __launch_bounds__(256) k_schnorr_prep(size_t n, const u8 *__restrict__ msg32, const u8 *__restrict__ pk32,
+                                                      const u8 *__restrict__ sig64, prep_rec *__restrict__ recs) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  schnorr_prep_one(msg32 + 32 * i, pk32 + 32 * i, sig64 + 64 * i, &recs[i]);
+}
+
+// ---- public keys: parse / decompress / validate -> 64-byte affine words + validity byte
+__global__ void __launch_bounds__(256) k_keys(size_t n, const u8 *__restrict__ pub, int publen, size_t stride,
+                                              u32 *__restrict__ qwords, u8 *__restrict__ keyok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 qx[8], qy[8];
+  const bool ok = parse_pubkey(pub + stride * i, publen, qx, qy);
+  uint4 *dst = reinterpret_cast<uint4 *>(qwords + i * 16);
+  dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+  dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
+  dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
+  dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
+  keyok[i] = ok;
+}
+
+// ---- the hot kernel: R = u1*G + u2*Q and the acceptance test
+__global__ void __launch_bounds__(256) k_ecmult(size_t n, const prep_rec *__restrict__ recs, const u32 *__restrict__ qwords,
+                                                const u8 *__restrict__ keyok, const u8 *__restrict__ sig64, int mode,
+                                                const u32 *__restrict__ gtable, u32 *__restrict__ slots,
+                                                u8 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  prep_rec rec;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
+    rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
+    rec.k1[0] = c.x; rec.k1[1] = c.y; rec.k1[2] = c.z; rec.k1[3] = c.w;
+    rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
+    rec.flags = e.x;
+  }
+  bool ok = (rec.flags & PREP_VALID) && keyok[i];
+  if (ok) {  // whole waves of rejected inputs skip the ladder (s_cbranch_execz)
+    u32 qx[8], qy[8];
+    const uint4 *src = reinterpret_cast<const uint4 *>(qwords + i * 16);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    qx[0] = a.x; qx[1] = a.y; qx[2] = a.z; qx[3] = a.w; qx[4] = b.x; qx[5] = b.y; qx[6] = b.z; qx[7] = b.w;
+    qy[0] = c.x; qy[1] = c.y; qy[2] = c.z; qy[3] = c.w; qy[4] = d.x; qy[5] = d.y; qy[6] = d.z; qy[7] = d.w;
+    const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slots + i * SLOT_WORDS, gtable);
+    u32 rw[8];
+    load_words_be(rw, sig64 + 64 * i);
+    ok = (mode == MODE_ECDSA) ? ecdsa_final(R, rw) : schnorr_final(R, rw);
+  }
+  out[i] = ok ? 1 : 0;
+}
+
+// ---- gossip: per message, double-SHA256 of the signed tail and expansion into (hash, sig, key) rows
+LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
+  u32 st[8] = LAMD_SHA256_IV;
+  u32 w[16];
+  size_t off = 0;
+  for (; off + 64 <= len; off += 64) {
+    for (int i = 0; i < 16; i++) w[i] = load_be32(p + off + 4 * i);
+    sha256_compress(st, w);
+  }
+  const size_t rem = len - off;
+  for (int i = 0; i < 16; i++) {
+    u32 v = 0;
+    for (int b = 0; b < 4; b++) {
+      const size_t k = (size_t)i * 4 + b;
+      const u32 byte = k < rem ? p[off + k] : (k == rem ? 0x80u : 0u);
+      v = (v << 8) | byte;
+    }
+    w[i] = v;
+  }
+  if (rem >= 56) {
+    sha256_compress(st, w);
+    for (int i = 0; i < 16; i++) w[i] = 0;
+  }
+  w[14] = (u32)(((u64)len * 8) >> 32);
+  w[15] = (u32)((u64)len * 8);
+  sha256_compress(st, w);
+  // second hash over the 32-byte digest
+  for (int i = 0; i < 8; i++) w[i] = st[i];
+  w[8] = 0x80000000u;
+  for (int i = 9; i < 15; i++) w[i] = 0;
+  w[15] = 256;
+  u32 st2[8] = LAMD_SHA256_IV;
+  sha256_compress(st2, w);
+  for (int i = 0; i < 8; i++) {
+    out32[4 * i] = (u8)(st2[i] >> 24); out32[4 * i + 1] = (u8)(st2[i] >> 16);
+    out32[4 * i + 2] = (u8)(st2[i] >> 8); out32[4 * i + 3] = (u8)st2[i];
+  }
+}
+
+enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };
+
+// rowbase[i] = index of message i's first signature row; malformed[i] set here for framing errors
+__global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
+                                                       const u8 *__restrict__ node_ids, const u64 *__restrict__ rowbase,
+                                                       u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub33,
+                                                       u8 *__restrict__ malformed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u8 *m = msgs + off[i];
+  const size_t len = off[i + 1] - off[i];
+  const size_t row = rowbase[i];
+  const size_t nrows = rowbase[i + 1] - row;
+  bool bad = len < 2;
+  const u32 type = bad ? 0 : (((u32)m[0] << 8) | m[1]);
+  size_t signed_off = 66, keyoff = 0;
+  if (type == GOSSIP_CANN) {
+    signed_off = 258;
+    bad |= len < 260;
+    if (!bad) {
+      const size_t flen = ((size_t)m[258] << 8) | m[259];
+      keyoff = 260 + flen + 32 + 8;
+      bad |= len < keyoff + 4 * 33;
+    }
+  } else if (type == GOSSIP_NANN) {
+    bad |= len < 68;
+    if (!bad) {
+      const size_t flen = ((size_t)m[66] << 8) | m[67];
+      keyoff = 68 + flen + 4;
+      bad |= len < keyoff + 33;
+    }
+  } else if (type == GOSSIP_CUPD) {
+    bad |= len < 66;
+  } else {
+    bad = true;
+  }
+  u8 h[32];
+  if (!bad) sha256d_bytes(m + signed_off, len - signed_off, h);
+  for (size_t k = 0; k < nrows; k++) {
+    u8 *hd = hash32 + 32 * (row + k), *sd = sig64 + 64 * (row + k), *pd = pub33 + 33 * (row + k);
+    if (bad) {
+      for (int b = 0; b < 32; b++) hd[b] = 0;
+      for (int b = 0; b < 64; b++) sd[b] = 0;
+      for (int b = 0; b < 33; b++) pd[b] = 0;
+      continue;
+    }
+    const u8 *sp = m + 2 + 64 * k;
+    const u8 *kp = (type == GOSSIP_CUPD) ? node_ids + 33 * i : m + keyoff + 33 * k;
+    u32 rw[8], sw[8];
+    load_words_be(rw, sp);
+    load_words_be(sw, sp + 32);
+    if (words_ge_n(rw) | words_ge_n(sw)) bad = true;  // fromwire_secp256k1_ecdsa_signature fails: malformed
+    for (int b = 0; b < 32; b++) hd[b] = h[b];
+    for (int b = 0; b < 64; b++) sd[b] = sp[b];
+    for (int b = 0; b < 33; b++) pd[b] = kp[b];
+  }
+  malformed[i] = bad;
+}
+
+__global__ void __launch_bounds__(256) k_gossip_reduce(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
+                                                       const u64 *__restrict__ rowbase, const u8 *__restrict__ ok,
+                                                       const u8 *__restrict__ keyok, const u8 *__restrict__ malformed,
+                                                       int8_t *__restrict__ verdict) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t row = rowbase[i], nrows = rowbase[i + 1] - row;
+  int v = 0;
+  bool bad = malformed[i];
+  if (!bad && nrows == 4) bad = !keyok[row + 2] | !keyok[row + 3];  // fromwire_pubkey on bitcoin_key_1/2
+  if (bad) {
+    v = -1;
+  } else {
+    for (size_t k = nrows; k-- > 0;)
+      if (!ok[row + k]) v = (int)k + 1;  // ends on the FIRST failing signature (sigcheck.c:78-113 order)
+  }
+  verdict[i] = (int8_t)v;
+}
+
+// ---- synthetic workload generation (keys, nonces and messages from splitmix64)
+LAMD_HD u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+LAMD_HD void rand_words(u32 w[8], u64 seed, u64 idx, u64 stream) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u64 v = splitmix64(seed ^ splitmix64(idx * 4 + j + (stream << 56)));
+    w[2 * j] = (u32)v;
+    w[2 * j + 1] = (u32)(v >> 32);
+  }
+}
+LAMD_HD sc rand_scalar(u64 seed, u64 idx, u64 stream) {
+  u32 w[8];
+  rand_words(w, seed, idx, stream);
+  sc s = sc_from_words(w, nullptr);
+  if (sc_is_zero(s)) s.w[0] = 1;
+  return s;
+}
+LAMD_HD void store_words_be(u8 *dst, const u32 w[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const u32 v = w[7 - i];
+    dst[4 * i] = (u8)(v >> 24); dst[4 * i + 1] = (u8)(v >> 16); dst[4 * i + 2] = (u8)(v >> 8); dst[4 * i + 3] = (u8)v;
+  }
+}
+// k*G as canonical affine words
+LAMD_HD void gmul_affine(u32 xw[8], u32 yw[8], const sc &k, const u32 *gtable) {
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = (k.w[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    ge pt;
+    pt.x = slot_load_fe(e);
+    pt.y = slot_load_fe(e + 8);
+    acc = gej_add_ge(acc, pt, d == 0);
+  }
+  const fe zi = fe_inv(fe_norm_weak(acc.z));
+  const fe zi2 = fe_sqr(zi);
+  fe_to_words(xw, fe_normalize(fe_mul(acc.x, zi2)));
+  fe_to_words(yw, fe_normalize(fe_mul(acc.y, fe_mul(zi2, zi))));
+}
+LAMD_HD sc sc_add_mod(const sc &a, const sc &b) {
+  u32 t[8];
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (u64)a.w[i] + b.w[i]; t[i] = (u32)c; c >>= 32; }
+  u32 d[8];
+  words_sub_n(d, t);
+  const bool ge = (c != 0) | words_ge_n(t);
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.w[i] = ge ? d[i] : t[i];
+  return r;
+}
+
+__global__ void __launch_bounds__(256) k_gen_ecdsa(size_t n, u64 seed, u64 nkeys, int publen, const u32 *__restrict__ gtable,
+                                                   u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 ki = splitmix64(seed ^ splitmix64(i + (7ULL << 56))) % nkeys;
+  const sc d = rand_scalar(seed, ki, 1);
+  const sc k = rand_scalar(seed, i, 2);
+  u32 zw[8];
+  rand_words(zw, seed, i, 3);
+  u32 qx[8], qy[8], rx[8], ry[8];
+  gmul_affine(qx, qy, d, gtable);
+  gmul_affine(rx, ry, k, gtable);
+  const sc r = sc_from_words(rx, nullptr);
+  const sc z = sc_from_words(zw, nullptr);
+  sc s = sc_mul(sc_inv(k), sc_add_mod(z, sc_mul(r, d)));
+  if (sc_is_high(s)) s = sc_neg(s);
+  store_words_be(hash32 + 32 * i, zw);
+  store_words_be(sig64 + 64 * i, r.w);
+  store_words_be(sig64 + 64 * i + 32, s.w);
+  u8 *p = pub + (size_t)publen * i;
+  if (publen == 65) {
+    p[0] = 4;
+    store_words_be(p + 1, qx);
+    store_words_be(p + 33, qy);
+  } else {
+    p[0] = 2 + (qy[0] & 1);
+    store_words_be(p + 1, qx);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gen_schnorr(size_t n, u64 seed, u64 nkeys, const u32 *__restrict__ gtable,
+                                                     u8 *__restrict__ msg32, u8 *__restrict__ pk32, u8 *__restrict__ sig64) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 ki = splitmix64(seed ^ splitmix64(i + (7ULL << 56))) % nkeys;
+  sc d = rand_scalar(seed, ki, 1);
+  sc k = rand_scalar(seed, i, 2);
+  u32 mw[8];
+  rand_words(mw, seed, i, 3);
+  u32 px[8], py[8], rx[8], ry[8];
+  gmul_affine(px, py, d, gtable);
+  gmul_affine(rx, ry, k, gtable);
+  if (py[0] & 1) d = sc_neg(d);
+  if (ry[0] & 1) k = sc_neg(k);
+  u32 rb[8], pb[8], mb[8], eh[8], ew[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { rb[j] = rx[7 - j]; pb[j] = px[7 - j]; mb[j] = mw[7 - j]; }
+  bip340_challenge(eh, rb, pb, mb);
+#pragma unroll
+  for (int j = 0; j < 8; j++) ew[j] = eh[7 - j];
+  const sc e = sc_from_words(ew, nullptr);
+  const sc s = sc_add_mod(k, sc_mul(e, d));
+  store_words_be(msg32 + 32 * i, mw);
+  store_words_be(pk32 + 32 * i, px);
+  store_words_be(sig64 + 64 * i, rx);
+  store_words_be(sig64 + 64 * i + 32, s.w);
+}
+
+// =====================================================================================
+//                                        engine
+// =====================================================================================
+
+struct devbuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
+
+struct lamd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  u32 *gtable = nullptr;
+  std::string err;
+  // per-call workspaces (grown on demand, reused)
+  devbuf recs, qwords, keyok, slots;
+  devbuf in_a, in_b, in_c, out;       // staging for the host-buffer API
+  devbuf g_msgs, g_off, g_ids, g_rowbase, g_hash, g_sig, g_pub, g_malformed, g_ok, g_verdict;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double last_ms[4] = {0, 0, 0, 0};
+  // streaming queues (pinned host staging)
+  struct queue {
+    u8 *h_a = nullptr, *h_b = nullptr, *h_c = nullptr, *h_ok = nullptr;  // hash/msg, sig, key, verdicts
+    size_t cap = 0, n = 0, inflight = 0;
+    std::vector<int> tickets;
+    devbuf d_a, d_b, d_c, d_ok;
+  } q[Q_KINDS];
+  int next_ticket = 0;
+  int inflight_total = 0;
+  bool flushed = false;
+  hipEvent_t flush_done = nullptr;
+};
+
+#define HIPCHK(ctx, call)                                                                           \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                               \
+      return LAMD_ERR_HIP;                                                                          \
+    }                                                                                               \
+  } while (0)
+
+static int ensure(lamd_ctx *ctx, devbuf *b, size_t bytes) {
+  if (bytes <= b->cap) return LAMD_OK;
+  if (b->p) HIPCHK(ctx, hipFree(b->p));
+  b->p = nullptr;
+  b->cap = 0;
+  size_t want = bytes + bytes / 4 + 4096;
+  if (hipMalloc(&b->p, want) != hipSuccess) {
+    want = bytes;
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) {
+      ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+      return LAMD_ERR_NOMEM;
+    }
+  }
+  b->cap = want;
+  return LAMD_OK;
+}
+static void release(devbuf *b) {
+  if (b->p) (void)hipFree(b->p);
+  b->p = nullptr;
+  b->cap = 0;
+}
+
+static constexpr size_t CHUNK = (size_t)1 << 20;  // signatures per launch (1 GiB of table slots)
+
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" const char *lamd_version(void) { return "lightning_amd 0.1 (gfx950)"; }
+
+extern "C" const char *lamd_last_error(const lamd_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" int lamd_init(lamd_ctx **out, int device) {
+  if (!out) return LAMD_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return LAMD_ERR_NO_DEVICE;
+  if (device < 0 || device >= count) return LAMD_ERR_ARG;
+  lamd_ctx *ctx = new (std::nothrow) lamd_ctx();
+  if (!ctx) return LAMD_ERR_NOMEM;
+  ctx->device = device;
+  *out = ctx;  // returned even on failure so the caller can read lamd_last_error(); shutdown is still valid
+  HIPCHK(ctx, hipSetDevice(device));
+  HIPCHK(ctx, hipGetDeviceProperties(&ctx->prop, device));
+  if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    ctx->err = std::string("unsupported architecture ") + ctx->prop.gcnArchName + " (built for gfx950 only)";
+    return LAMD_ERR_NO_DEVICE;
+  }
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming));
+  // window bases B_w = 2^(16 w) G, computed here with the same group code the kernels use (64 doublings each)
+  std::vector<u32> bases(GTABLE_WINDOWS * 16);
+  {
+    const u32 gx[8] = LAMD_GX, gy[8] = LAMD_GY;
+    u32 cur[16];
+    memcpy(cur, gx, 32);
+    memcpy(cur + 8, gy, 32);
+    for (int w = 0; w < GTABLE_WINDOWS; w++) {
+      memcpy(&bases[w * 16], cur, 64);
+      gej b = gej_from_ge(ge_from_words(cur, cur + 8));
+      for (int i = 0; i < GTABLE_WINDOW_BITS; i++) b = gej_double(b);
+      const fe zi = fe_inv(fe_norm_weak(b.z));
+      const fe zi2 = fe_sqr(zi);
+      fe_to_words(cur, fe_normalize(fe_mul(b.x, zi2)));
+      fe_to_words(cur + 8, fe_normalize(fe_mul(b.y, fe_mul(zi2, zi))));
+    }
+  }
+  u32 *d_bases = nullptr;
+  HIPCHK(ctx, hipMalloc(&d_bases, bases.size() * 4));
+  HIPCHK(ctx, hipMemcpy(d_bases, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMalloc(&ctx->gtable, GTABLE_BYTES));
+  hipLaunchKernelGGL(k_gtable_build, dim3(blocks_for(GTABLE_ENTRIES)), dim3(256), 0, ctx->stream, ctx->gtable, d_bases);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipFree(d_bases));
+  return LAMD_OK;
+}
+
+extern "C" void lamd_shutdown(lamd_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
+                    &ctx->g_msgs, &ctx->g_off, &ctx->g_ids, &ctx->g_rowbase, &ctx->g_hash, &ctx->g_sig, &ctx->g_pub,
+                    &ctx->g_malformed, &ctx->g_ok, &ctx->g_verdict})
+    release(b);
+  for (auto &q : ctx->q) {
+    for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
+      if (*h) (void)hipHostFree(*h);
+    for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
+  }
+  if (ctx->gtable) (void)hipFree(ctx->gtable);
+  for (auto &e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->flush_done) (void)hipEventDestroy(ctx->flush_done);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" void *lamd_stream(lamd_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int lamd_synchronize(lamd_ctx *ctx) {
+  if (!ctx) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->timing) {
+    for (int i = 0; i < 4; i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) == hipSuccess) ctx->last_ms[i] = ms;
+    }
+  }
+  return LAMD_OK;
+}
+
+extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
+  if (!ctx) return LAMD_ERR_ARG;
+  ctx->timing = enable != 0;
+  return LAMD_OK;
+}
+
+extern "C" int lamd_get_info(lamd_ctx *ctx, lamd_info *info) {
+  if (!ctx || !info) return LAMD_ERR_ARG;
+  memset(info, 0, sizeof(*info));
+  info->device = ctx->device;
+  info->compute_units = ctx->prop.multiProcessorCount;
+  strncpy(info->arch, ctx->prop.gcnArchName, sizeof(info->arch) - 1);
+  info->gtable_bytes = GTABLE_BYTES;
+  for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
+  return LAMD_OK;
+}
+
+// One chunk (n <= CHUNK) entirely on the context's stream.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
+static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
+                     size_t keystride, u8 *d_ok, bool time_it) {
+  int rc;
+  if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->qwords, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->slots, n * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  prep_rec *recs = (prep_rec *)ctx->recs.p;
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  if (mode == MODE_ECDSA) {
+    // enough threads to fill the chip, few enough that each amortises its inversion over ~16 signatures
+    size_t threads = (n + 15) / 16;
+    const size_t min_threads = (size_t)ctx->prop.multiProcessorCount * 256;
+    if (threads < min_threads) threads = n < min_threads ? n : min_threads;
+    hipLaunchKernelGGL(k_ecdsa_prep, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, n, d_a, d_sig, recs);
+  } else {
+    hipLaunchKernelGGL(k_schnorr_prep, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_a, d_key, d_sig, recs);
+  }
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  hipLaunchKernelGGL(k_keys, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->qwords.p,
+                     (u8 *)ctx->keyok.p);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  hipLaunchKernelGGL(k_ecmult, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->qwords.p,
+                     (const u8 *)ctx->keyok.p, d_sig, mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, d_ok);
+  if (time_it) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return LAMD_OK;
+}
+
+static int run_device(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
+                      size_t keystride, u8 *d_ok) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (size_t o = 0; o < n; o += CHUNK) {
+    const size_t m = n - o < CHUNK ? n - o : CHUNK;
+    const int rc = run_chunk(ctx, mode, m, d_a + 32 * o, d_sig + 64 * o, d_key + keystride * o, keylen, keystride, d_ok + o,
+                             ctx->timing && o + CHUNK >= n);
+    if (rc != LAMD_OK) return rc;
+  }
+  return LAMD_OK;
+}
+
+extern "C" int lamd_verify_ecdsa_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64,
+                                              const void *d_pub, size_t publen, size_t pubstride, void *d_ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!d_hash32 || !d_sig64 || !d_pub || !d_ok || (publen != 33 && publen != 65) || pubstride < publen) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  return run_device(ctx, MODE_ECDSA, n, (const u8 *)d_hash32, (const u8 *)d_sig64, (const u8 *)d_pub, (int)publen, pubstride,
+                    (u8 *)d_ok);
+}
+
+extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg32, const void *d_xonly32,
+                                                const void *d_sig64, void *d_ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!d_msg32 || !d_xonly32 || !d_sig64 || !d_ok) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  return run_device(ctx, MODE_SCHNORR, n, (const u8 *)d_msg32, (const u8 *)d_sig64, (const u8 *)d_xonly32, 32, 32, (u8 *)d_ok);
+}
+
+static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride,
+                    u8 *ok) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * keystride)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_a.p, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, key, n * keystride, hipMemcpyHostToDevice, ctx->stream));
+  rc = run_device(ctx, mode, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, keylen, keystride,
+                  (u8 *)ctx->out.p);
+  if (rc != LAMD_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);
+}
+
+extern "C" int lamd_verify_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub,
+                                       size_t publen, size_t pubstride, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!hash32 || !sig64 || !pub || !ok || (publen != 33 && publen != 65) || pubstride < publen) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  return run_host(ctx, MODE_ECDSA, n, hash32, sig64, pub, (int)publen, pubstride, ok);
+}
+
+extern "C" int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32,
+                                         const uint8_t *sig64, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!msg32 || !xonly32 || !sig64 || !ok) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  return run_host(ctx, MODE_SCHNORR, n, msg32, sig64, xonly32, 32, 32, ok);
+}
+
+// ---- single-item veneers
+extern "C" int lamd_check_signed_hash(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64], const uint8_t *pubkey,
+                                      size_t publen) {
+  uint8_t ok = 0;
+  const int rc = lamd_verify_ecdsa_batch(ctx, 1, hash32, sig64, pubkey, publen, publen, &ok);
+  return rc != LAMD_OK ? rc : ok;
+}
+extern "C" int lamd_check_signed_hash_nodeid(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
+                                             const uint8_t node_id33[33]) {
+  return lamd_check_signed_hash(ctx, hash32, sig64, node_id33, 33);
+}
+extern "C" int lamd_check_schnorr_sig(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t pubkey33[33],
+                                      const uint8_t bip340sig64[64]) {
+  // bitcoin/signature.c:417-423: the (already valid) key is serialised compressed and its parity byte dropped
+  if (!ctx || !pubkey33) return LAMD_ERR_ARG;
+  uint8_t ok = 0;
+  const int rc = lamd_verify_schnorr_batch(ctx, 1, hash32, pubkey33 + 1, bip340sig64, &ok);
+  return rc != LAMD_OK ? rc : ok;
+}
+
+// ---- public-key parsing
+extern "C" int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *pub, size_t publen, size_t pubstride,
+                                       uint8_t *out64, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!pub || !ok || (publen != 32 && publen != 33 && publen != 65) || pubstride < publen) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * pubstride)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->qwords, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_keys, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
+                     (u32 *)ctx->qwords.p, (u8 *)ctx->keyok.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->keyok.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<u32> words;
+  if (out64) {
+    words.resize(n * 16);
+    HIPCHK(ctx, hipMemcpyAsync(words.data(), ctx->qwords.p, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (out64)
+    for (size_t i = 0; i < n; i++) {
+      store_words_be(out64 + 64 * i, &words[i * 16]);
+      store_words_be(out64 + 64 * i + 32, &words[i * 16 + 8]);
+    }
+  return LAMD_OK;
+}
+
+// ---- gossip
+extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, const uint64_t *off,
+                                          const uint8_t *node_ids33, int8_t *verdict) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!msgs || !off || !verdict) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // host framing pass: signature rows per message (4 for channel_announcement, 1 otherwise)
+  std::vector<u64> rowbase(n + 1);
+  u64 rows = 0;
+  bool need_ids = false;
+  for (size_t i = 0; i < n; i++) {
+    rowbase[i] = rows;
+    const size_t len = off[i + 1] - off[i];
+    const u32 type = len >= 2 ? (((u32)msgs[off[i]] << 8) | msgs[off[i] + 1]) : 0;
+    rows += type == GOSSIP_CANN ? 4 : 1;
+    need_ids |= type == GOSSIP_CUPD;
+  }
+  rowbase[n] = rows;
+  if (need_ids && !node_ids33) {
+    ctx->err = "channel_update in batch but node_ids33 is NULL";
+    return LAMD_ERR_ARG;
+  }
+  const size_t total = off[n] - off[0];
+  int rc;
+  if ((rc = ensure(ctx, &ctx->g_msgs, total + 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_off, (n + 1) * 8)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_ids, n * 33)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_rowbase, (n + 1) * 8)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_hash, rows * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_sig, rows * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_pub, rows * 33 + 16)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_ok, rows)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_verdict, n)) != LAMD_OK) return rc;
+  std::vector<u64> rel(n + 1);
+  for (size_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, msgs + off[0], total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_rowbase.p, rowbase.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (node_ids33) HIPCHK(ctx, hipMemcpyAsync(ctx->g_ids.p, node_ids33, n * 33, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_gossip_expand, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p,
+                     (const u64 *)ctx->g_off.p, (const u8 *)ctx->g_ids.p, (const u64 *)ctx->g_rowbase.p, (u8 *)ctx->g_hash.p,
+                     (u8 *)ctx->g_sig.p, (u8 *)ctx->g_pub.p, (u8 *)ctx->g_malformed.p);
+  HIPCHK(ctx, hipGetLastError());
+  // the rows form one ECDSA batch with 33-byte keys; keyok of the last chunk must survive for the reduce, so the
+  // gossip path runs the whole batch as one chunk sequence and reduces per chunk-aligned message ranges
+  if (rows > CHUNK) {
+    // split on message boundaries so that every message's rows live in one chunk
+    size_t m0 = 0;
+    while (m0 < n) {
+      size_t m1 = m0;
+      while (m1 < n && rowbase[m1 + 1] - rowbase[m0] <= CHUNK) m1++;
+      const size_t r0 = rowbase[m0], nr = rowbase[m1] - r0;
+      rc = run_chunk(ctx, MODE_ECDSA, nr, (const u8 *)ctx->g_hash.p + 32 * r0, (const u8 *)ctx->g_sig.p + 64 * r0,
+                     (const u8 *)ctx->g_pub.p + 33 * r0, 33, 33, (u8 *)ctx->g_ok.p + r0, false);
+      if (rc != LAMD_OK) return rc;
+      // keyok is indexed from the chunk start: hand the reduce kernel pointers rebased to row r0
+      hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(m1 - m0)), dim3(256), 0, ctx->stream, m1 - m0,
+                         (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p + m0, (const u64 *)ctx->g_rowbase.p + m0,
+                         (const u8 *)ctx->g_ok.p, (const u8 *)ctx->keyok.p - r0, (const u8 *)ctx->g_malformed.p + m0,
+                         (int8_t *)ctx->g_verdict.p + m0);
+      HIPCHK(ctx, hipGetLastError());
+      m0 = m1;
+    }
+  } else {
+    rc = run_chunk(ctx, MODE_ECDSA, rows, (const u8 *)ctx->g_hash.p, (const u8 *)ctx->g_sig.p, (const u8 *)ctx->g_pub.p, 33, 33,
+                   (u8 *)ctx->g_ok.p, false);
+    if (rc != LAMD_OK) return rc;
+    hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p,
+                       (const u64 *)ctx->g_off.p, (const u64 *)ctx->g_rowbase.p, (const u8 *)ctx->g_ok.p,
+                       (const u8 *)ctx->keyok.p, (const u8 *)ctx->g_malformed.p, (int8_t *)ctx->g_verdict.p);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  HIPCHK(ctx, hipMemcpyAsync(verdict, ctx->g_verdict.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LAMD_OK;
+}
+
+// ---- streaming queues
+static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes) {
+  if (q.n < q.cap) return LAMD_OK;
+  const size_t ncap = q.cap ? q.cap * 2 : 1024;
+  u8 *na = nullptr, *nb = nullptr, *nc = nullptr, *nk = nullptr;
+  HIPCHK(ctx, hipHostMalloc((void **)&na, ncap * 32, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&nb, ncap * 64, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&nc, ncap * keybytes, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&nk, ncap, hipHostMallocDefault));
+  if (q.n) {
+    memcpy(na, q.h_a, q.n * 32);
+    memcpy(nb, q.h_b, q.n * 64);
+    memcpy(nc, q.h_c, q.n * keybytes);
+  }
+  for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
+    if (*h) (void)hipHostFree(*h);
+  q.h_a = na; q.h_b = nb; q.h_c = nc; q.h_ok = nk;
+  q.cap = ncap;
+  return LAMD_OK;
+}
+static const size_t Q_KEYBYTES[Q_KINDS] = {33, 65, 32};
+
+static int queue_push(lamd_ctx *ctx, int kind, const u8 *a, const u8 *sig, const u8 *key) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!a || !sig || !key) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  if (ctx->flushed) {
+    ctx->err = "queue: results of the previous flush have not been collected (poll/wait first)";
+    return LAMD_ERR_STATE;
+  }
+  lamd_ctx::queue &q = ctx->q[kind];
+  const int rc = queue_reserve(ctx, q, Q_KEYBYTES[kind]);
+  if (rc != LAMD_OK) return rc;
+  memcpy(q.h_a + 32 * q.n, a, 32);
+  memcpy(q.h_b + 64 * q.n, sig, 64);
+  memcpy(q.h_c + Q_KEYBYTES[kind] * q.n, key, Q_KEYBYTES[kind]);
+  q.tickets.push_back(ctx->next_ticket);
+  q.n++;
+  return ctx->next_ticket++;
+}
+extern "C" int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64], const uint8_t *pubkey,
+                                size_t publen) {
+  if (ctx && publen != 33 && publen != 65) {
+    ctx->err = "bad key length";
+    return LAMD_ERR_ARG;
+  }
+  return queue_push(ctx, publen == 33 ? Q_ECDSA33 : Q_ECDSA65, hash32, sig64, pubkey);
+}
+extern "C" int lamd_queue_schnorr(lamd_ctx *ctx, const uint8_t msg32[32], const uint8_t xonly32[32], const uint8_t sig64[64]) {
+  return queue_push(ctx, Q_SCHNORR, msg32, sig64, xonly32);
+}
+
+extern "C" int lamd_flush(lamd_ctx *ctx) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (ctx->flushed) {
+    ctx->err = "flush: previous flush not collected";
+    return LAMD_ERR_STATE;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (int kind = 0; kind < Q_KINDS; kind++) {
+    lamd_ctx::queue &q = ctx->q[kind];
+    if (!q.n) continue;
+    const size_t kb = Q_KEYBYTES[kind];
+    int rc;
+    if ((rc = ensure(ctx, &q.d_a, q.n * 32)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &q.d_b, q.n * 64)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &q.d_c, q.n * kb + 16)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &q.d_ok, q.n)) != LAMD_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, ctx->stream));
+    rc = run_device(ctx, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
+                    (const u8 *)q.d_c.p, (int)kb, kb, (u8 *)q.d_ok.p);
+    if (rc != LAMD_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(q.h_ok, q.d_ok.p, q.n, hipMemcpyDeviceToHost, ctx->stream));
+    q.inflight = q.n;
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->flush_done, ctx->stream));
+  ctx->flushed = true;
+  return LAMD_OK;
+}
+
+static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+  size_t total = 0;
+  int base = -1;
+  for (auto &q : ctx->q)
+    for (size_t i = 0; i < q.inflight; i++) {
+      total++;
+      if (base < 0 || q.tickets[i] < base) base = q.tickets[i];
+    }
+  if (total > cap) {
+    ctx->err = "result buffer too small";
+    return LAMD_ERR_ARG;
+  }
+  for (auto &q : ctx->q) {
+    for (size_t i = 0; i < q.inflight; i++) ok[q.tickets[i] - base] = q.h_ok[i];
+    q.tickets.clear();
+    q.n = 0;
+    q.inflight = 0;
+  }
+  if (n) *n = total;
+  ctx->flushed = false;
+  return 1;
+}
+extern "C" int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+  if (!ctx || !ok) return LAMD_ERR_ARG;
+  if (!ctx->flushed) {
+    ctx->err = "poll before flush";
+    return LAMD_ERR_STATE;
+  }
+  const hipError_t e = hipEventQuery(ctx->flush_done);
+  if (e == hipErrorNotReady) return 0;
+  HIPCHK(ctx, e);
+  return collect(ctx, ok, cap, n);
+}
+extern "C" int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+  if (!ctx || !ok) return LAMD_ERR_ARG;
+  if (!ctx->flushed) {
+    ctx->err = "wait before flush";
+    return LAMD_ERR_STATE;
+  }
+  HIPCHK(ctx, hipEventSynchronize(ctx->flush_done));
+  return collect(ctx, ok, cap, n);
+}
+
+// ---- synthetic workloads
+extern "C" int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t publen, void *d_hash32,
+                                     void *d_sig64, void *d_pub) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!d_hash32 || !d_sig64 || !d_pub || (publen != 33 && publen != 65) || nkeys == 0) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  if (n == 0) return LAMD_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_gen_ecdsa, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys, (int)publen,
+                     (const u32 *)ctx->gtable, (u8 *)d_hash32, (u8 *)d_sig64, (u8 *)d_pub);
+  HIPCHK(ctx, hipGetLastError());
+  return LAMD_OK;
+}
+extern "C" int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, void *d_msg32, void *d_xonly32,
+                                       void *d_sig64) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!d_msg32 || !d_xonly32 || !d_sig64 || nkeys == 0) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  if (n == 0) return LAMD_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_gen_schnorr, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys,
+                     (const u32 *)ctx->gtable, (u8 *)d_msg32, (u8 *)d_xonly32, (u8 *)d_sig64);
+  HIPCHK(ctx, hipGetLastError());
+  return LAMD_OK;
+}

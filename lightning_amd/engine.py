@@ -1,0 +1,178 @@
+"""Python front end over the C ABI (include/lightning_amd.h).  Device memory and streams come
+from PyTorch-ROCm when the *_device methods are used; the numpy methods go through the
+library's own staging.  Nothing here computes: every verdict comes from the HIP kernels."""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+ERRORS = {0: "OK", -1: "no usable gfx950 device", -2: "HIP error", -3: "bad argument", -4: "out of memory", -5: "bad state"}
+
+
+class LamdError(RuntimeError):
+    pass
+
+
+def _u8(a, shape_tail):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1:
+        a = a.reshape(-1, shape_tail)
+    if a.shape[1] != shape_tail:
+        raise ValueError("expected rows of %d bytes, got %r" % (shape_tail, a.shape))
+    return a
+
+
+class Engine:
+    """One context = one GPU, one stream.  Mirrors lamd_init()/lamd_shutdown()."""
+
+    def __init__(self, device=0):
+        self._lib = _ffi.load()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.lamd_init(ctypes.byref(self._ctx), device)
+        if rc != 0:
+            msg = self._lib.lamd_last_error(self._ctx).decode() if self._ctx else ""
+            if self._ctx:
+                self._lib.lamd_shutdown(self._ctx)
+                self._ctx = ctypes.c_void_p()
+            raise LamdError("lamd_init failed: %s %s" % (ERRORS.get(rc, rc), msg))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.lamd_shutdown(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LamdError("%s: %s" % (ERRORS.get(rc, rc), self._lib.lamd_last_error(self._ctx).decode()))
+        return rc
+
+    # ---- host-buffer batches (numpy uint8 in, numpy bool out)
+    def verify_ecdsa(self, hash32, sig64, pub):
+        pub = np.ascontiguousarray(pub, dtype=np.uint8)
+        if pub.ndim != 2 or pub.shape[1] not in (33, 65):
+            raise ValueError("pub must be [n,33] or [n,65]")
+        hash32, sig64 = _u8(hash32, 32), _u8(sig64, 64)
+        n = hash32.shape[0]
+        if not (sig64.shape[0] == n == pub.shape[0]):
+            raise ValueError("row counts differ")
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.lamd_verify_ecdsa_batch(self._ctx, n, hash32.ctypes.data, sig64.ctypes.data, pub.ctypes.data,
+                                                    pub.shape[1], pub.shape[1], ok.ctypes.data))
+        return ok.astype(bool)
+
+    def verify_schnorr(self, msg32, xonly32, sig64):
+        msg32, xonly32, sig64 = _u8(msg32, 32), _u8(xonly32, 32), _u8(sig64, 64)
+        n = msg32.shape[0]
+        if not (xonly32.shape[0] == n == sig64.shape[0]):
+            raise ValueError("row counts differ")
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.lamd_verify_schnorr_batch(self._ctx, n, msg32.ctypes.data, xonly32.ctypes.data, sig64.ctypes.data,
+                                                      ok.ctypes.data))
+        return ok.astype(bool)
+
+    def pubkey_parse(self, pub):
+        pub = np.ascontiguousarray(pub, dtype=np.uint8)
+        n, ln = pub.shape
+        out = np.zeros((n, 64), dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.lamd_pubkey_parse_batch(self._ctx, n, pub.ctypes.data, ln, ln, out.ctypes.data, ok.ctypes.data))
+        return out, ok.astype(bool)
+
+    def sigcheck_gossip(self, msgs, node_ids=None):
+        """msgs: list of bytes (raw wire messages).  node_ids: list of 33-byte ids (or None entries), needed for
+        channel_update.  Returns int8 verdicts (see lamd_sigcheck_gossip_batch)."""
+        n = len(msgs)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(msgs) + b"\x00", dtype=np.uint8)
+        ids_ptr = None
+        if node_ids is not None:
+            ids = np.zeros((n, 33), dtype=np.uint8)
+            for i, k in enumerate(node_ids):
+                if k is not None:
+                    ids[i] = np.frombuffer(k, dtype=np.uint8)
+            ids_ptr = ids.ctypes.data
+        verdict = np.zeros(n, dtype=np.int8)
+        self._chk(self._lib.lamd_sigcheck_gossip_batch(self._ctx, n, blob.ctypes.data, off.ctypes.data, ids_ptr, verdict.ctypes.data))
+        return verdict
+
+    # ---- single-item veneers (reference semantics)
+    def check_signed_hash(self, hash32, sig64, pubkey):
+        return bool(self._chk(self._lib.lamd_check_signed_hash(self._ctx, bytes(hash32), bytes(sig64), bytes(pubkey), len(pubkey))))
+
+    def check_signed_hash_nodeid(self, hash32, sig64, node_id33):
+        return bool(self._chk(self._lib.lamd_check_signed_hash_nodeid(self._ctx, bytes(hash32), bytes(sig64), bytes(node_id33))))
+
+    def check_schnorr_sig(self, hash32, pubkey33, sig64):
+        return bool(self._chk(self._lib.lamd_check_schnorr_sig(self._ctx, bytes(hash32), bytes(pubkey33), bytes(sig64))))
+
+    # ---- streaming
+    def queue_ecdsa(self, hash32, sig64, pubkey):
+        return self._chk(self._lib.lamd_queue_ecdsa(self._ctx, bytes(hash32), bytes(sig64), bytes(pubkey), len(pubkey)))
+
+    def queue_schnorr(self, msg32, xonly32, sig64):
+        return self._chk(self._lib.lamd_queue_schnorr(self._ctx, bytes(msg32), bytes(xonly32), bytes(sig64)))
+
+    def flush(self):
+        self._chk(self._lib.lamd_flush(self._ctx))
+
+    def wait(self, cap=1 << 20):
+        ok = np.zeros(cap, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        self._chk(self._lib.lamd_wait(self._ctx, ok.ctypes.data, cap, ctypes.byref(n)))
+        return ok[:n.value].astype(bool)
+
+    def poll(self, cap=1 << 20):
+        ok = np.zeros(cap, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        rc = self._chk(self._lib.lamd_poll(self._ctx, ok.ctypes.data, cap, ctypes.byref(n)))
+        return ok[:n.value].astype(bool) if rc == 1 else None
+
+    # ---- device-resident API (torch uint8 CUDA tensors; asynchronous on self.stream_ptr)
+    def verify_ecdsa_device(self, d_hash, d_sig, d_pub, d_ok):
+        n, publen = d_pub.shape
+        self._chk(self._lib.lamd_verify_ecdsa_batch_device(self._ctx, n, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr(),
+                                                           publen, publen, d_ok.data_ptr()))
+
+    def verify_schnorr_device(self, d_msg, d_xonly, d_sig, d_ok):
+        n = d_msg.shape[0]
+        self._chk(self._lib.lamd_verify_schnorr_batch_device(self._ctx, n, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr(),
+                                                             d_ok.data_ptr()))
+
+    def gen_ecdsa_device(self, seed, nkeys, d_hash, d_sig, d_pub):
+        n, publen = d_pub.shape
+        self._chk(self._lib.lamd_gen_ecdsa_device(self._ctx, n, seed, nkeys, publen, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr()))
+
+    def gen_schnorr_device(self, seed, nkeys, d_msg, d_xonly, d_sig):
+        n = d_msg.shape[0]
+        self._chk(self._lib.lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
+
+    def synchronize(self):
+        self._chk(self._lib.lamd_synchronize(self._ctx))
+
+    @property
+    def stream_ptr(self):
+        return self._lib.lamd_stream(self._ctx)
+
+    def set_timing(self, on=True):
+        self._chk(self._lib.lamd_set_timing(self._ctx, int(on)))
+
+    def info(self):
+        inf = _ffi.LamdInfo()
+        self._chk(self._lib.lamd_get_info(self._ctx, ctypes.byref(inf)))
+        return dict(device=inf.device, compute_units=inf.compute_units, arch=inf.arch.decode(), gtable_bytes=inf.gtable_bytes,
+                    last_kernel_ms=list(inf.last_kernel_ms))
