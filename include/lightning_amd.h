@@ -128,6 +128,23 @@ int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, 
 int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys,
 			    void *d_msg32, void *d_xonly32, void *d_sig64);
 
+/* ---- device self-test: evaluates every arithmetic primitive and one full ECDSA verification of
+ * the given triple both on the GPU and with the same code on the host, stage by stage.
+ * Returns 0 if every stage agrees, else a bit mask of disagreeing stages (report names them),
+ * or < 0 on engine error.  Diagnostic only; never used to produce a verdict. */
+int lamd_selftest(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
+		  const uint8_t pub33[33], char *report, size_t cap);
+
+/* Diagnostic: a 300-step dependent chain of field squarings (use_mul = 0) or multiplications on
+ * the device, every step re-executed on the host from the device's own input limbs.  Returns the
+ * number of disagreeing steps (0 = healthy), report describes the first few. */
+int lamd_chain_debug(lamd_ctx *ctx, int use_mul, char *report, size_t cap);
+
+/* Diagnostic: every intermediate of the field inversion / square-root addition chains, device vs host. */
+int lamd_inv_debug(lamd_ctx *ctx, char *report, size_t cap);
+
+int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 in several code shapes */
+
 /* ---- introspection for benchmarks / tests */
 typedef struct {
 	int device;

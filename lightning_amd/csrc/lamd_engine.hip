@@ -359,6 +359,7 @@ struct lamd_ctx {
   devbuf g_msgs, g_off, g_ids, g_rowbase, g_hash, g_sig, g_pub, g_malformed, g_ok, g_verdict;
   // timing
   bool timing = false;
+  bool ev_recorded = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double last_ms[4] = {0, 0, 0, 0};
   // streaming queues (pinned host staging)
@@ -487,11 +488,12 @@ extern "C" void *lamd_stream(lamd_ctx *ctx) { return ctx ? (void *)ctx->stream :
 extern "C" int lamd_synchronize(lamd_ctx *ctx) {
   if (!ctx) return LAMD_ERR_ARG;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->timing) {
+  if (ctx->timing && ctx->ev_recorded) {
     for (int i = 0; i < 4; i++) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) == hipSuccess) ctx->last_ms[i] = ms;
     }
+    (void)hipGetLastError();
   }
   return LAMD_OK;
 }
@@ -541,6 +543,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   if (time_it) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    ctx->ev_recorded = true;
   }
   HIPCHK(ctx, hipGetLastError());
   return LAMD_OK;
@@ -881,6 +884,341 @@ extern "C" int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
   }
   HIPCHK(ctx, hipEventSynchronize(ctx->flush_done));
   return collect(ctx, ok, cap, n);
+}
+
+// ---- device self-test: the same inline functions evaluated on the GPU and on the host (this TU's host
+// pass), stage by stage, so a miscompile / hardware difference is localised to one primitive.
+constexpr int ST_LANES = 64;
+constexpr int ST_WORDS = 512;  // output words per lane
+struct st_in { u32 a[8], b[8]; u8 hash[32], sig[64], pub33[33], pad[3]; };
+
+LAMD_HD void selftest_lane(const st_in &in, const u32 *gtable, u32 *slot, u32 *o) {
+  int k = 0;
+  const fe a = fe_from_words(in.a), b = fe_from_words(in.b);
+  u32 w[8];
+  fe_to_words(w, fe_normalize(fe_mul(a, b))); for (int i = 0; i < 8; i++) o[k++] = w[i];                    // 0 fe_mul
+  fe_to_words(w, fe_normalize(fe_sqr(a))); for (int i = 0; i < 8; i++) o[k++] = w[i];                       // 8 fe_sqr
+  fe_to_words(w, fe_normalize(fe_inv(a))); for (int i = 0; i < 8; i++) o[k++] = w[i];                       // 16 fe_inv
+  fe_to_words(w, fe_normalize(fe_sqrt_candidate(a))); for (int i = 0; i < 8; i++) o[k++] = w[i];            // 24 fe_sqrt
+  fe_to_words(w, fe_normalize(fe_add(fe_neg(a, 1), fe_mul_int(b, 3)))); for (int i = 0; i < 8; i++) o[k++] = w[i];  // 32 lazy add/neg
+  sc x, y;
+  bool of;
+  x = sc_from_words(in.a, &of); y = sc_from_words(in.b, &of);
+  const sc m = sc_mul(x, y); for (int i = 0; i < 8; i++) o[k++] = m.w[i];                                    // 40 sc_mul
+  const sc iv = sc_inv(x); for (int i = 0; i < 8; i++) o[k++] = iv.w[i];                                     // 48 sc_inv
+  glv_half h1, h2;
+  glv_split(&h1, &h2, x);
+  for (int i = 0; i < 4; i++) o[k++] = h1.mag[i];
+  o[k++] = h1.top; o[k++] = h1.neg;
+  for (int i = 0; i < 4; i++) o[k++] = h2.mag[i];
+  o[k++] = h2.top; o[k++] = h2.neg;                                                                          // 56..67 glv
+  u32 qx[8], qy[8];
+  const bool kok = parse_pubkey(in.pub33, 33, qx, qy);
+  for (int i = 0; i < 8; i++) o[k++] = qx[i];
+  for (int i = 0; i < 8; i++) o[k++] = qy[i];
+  o[k++] = kok;                                                                                               // 68..84 key
+  prep_rec rec;
+  ecdsa_prep_thread(0, 1, 1, in.hash, in.sig, &rec);
+  for (int i = 0; i < 8; i++) o[k++] = rec.u1[i];
+  for (int i = 0; i < 4; i++) o[k++] = rec.k1[i];
+  for (int i = 0; i < 4; i++) o[k++] = rec.k2[i];
+  o[k++] = rec.flags;                                                                                         // 85..101 prep
+  const ge q = ge_from_words(qx, qy);
+  const fe zg = build_q_table(slot, q);
+  fe_to_words(w, fe_normalize(zg)); for (int i = 0; i < 8; i++) o[k++] = w[i];                              // 102 zg
+  for (int i = 0; i < 8 * SLOT_ENTRY_WORDS; i++) o[k++] = slot[i];                                            // 110..301 table
+  const gej R = ecmult_lane(rec, q, slot, gtable);
+  fe_to_words(w, fe_normalize(R.x)); for (int i = 0; i < 8; i++) o[k++] = w[i];
+  fe_to_words(w, fe_normalize(R.y)); for (int i = 0; i < 8; i++) o[k++] = w[i];
+  fe_to_words(w, fe_normalize(R.z)); for (int i = 0; i < 8; i++) o[k++] = w[i];
+  o[k++] = R.inf;                                                                                             // 302..326 R
+  u32 rw[8];
+  load_words_be(rw, in.sig);
+  o[k++] = ecdsa_final(R, rw);                                                                                // 327 verdict
+  while (k < ST_WORDS) o[k++] = 0;
+}
+__global__ void __launch_bounds__(64) k_selftest(const st_in *in, const u32 *gtable, u32 *slots, u32 *out) {
+  const int i = threadIdx.x;
+  selftest_lane(in[i], gtable, slots + i * SLOT_WORDS, out + i * ST_WORDS);
+}
+
+extern "C" int lamd_selftest(lamd_ctx *ctx, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub33, char *report,
+                             size_t cap) {
+  if (!ctx || !hash32 || !sig64 || !pub33) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<st_in> in(ST_LANES);
+  u64 s = 0x1234567;
+  for (int i = 0; i < ST_LANES; i++) {
+    for (int j = 0; j < 8; j++) { in[i].a[j] = (u32)splitmix64(s++); in[i].b[j] = (u32)splitmix64(s++); }
+    if (i == 1) for (int j = 0; j < 8; j++) in[i].a[j] = 0xFFFFFFFFu;
+    memcpy(in[i].hash, hash32, 32); memcpy(in[i].sig, sig64, 64); memcpy(in[i].pub33, pub33, 33);
+  }
+  st_in *d_in; u32 *d_slots, *d_out;
+  HIPCHK(ctx, hipMalloc(&d_in, sizeof(st_in) * ST_LANES));
+  HIPCHK(ctx, hipMalloc(&d_slots, (size_t)ST_LANES * SLOT_WORDS * 4));
+  HIPCHK(ctx, hipMalloc(&d_out, (size_t)ST_LANES * ST_WORDS * 4));
+  HIPCHK(ctx, hipMemcpy(d_in, in.data(), sizeof(st_in) * ST_LANES, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, (const u32 *)ctx->gtable, d_slots, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<u32> got((size_t)ST_LANES * ST_WORDS), gt(GTABLE_ENTRIES * 16);
+  HIPCHK(ctx, hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(gt.data(), ctx->gtable, GTABLE_BYTES, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_slots); (void)hipFree(d_out);
+  // host evaluation of the same code (host gtable entries recomputed for a sample to check the build kernel)
+  static const struct { int lo, hi; const char *name; } stages[] = {
+      {0, 8, "fe_mul"}, {8, 16, "fe_sqr"}, {16, 24, "fe_inv"}, {24, 32, "fe_sqrt"}, {32, 40, "fe_lazy_add_neg"}, {40, 48, "sc_mul"},
+      {48, 56, "sc_inv"}, {56, 68, "glv_split"}, {68, 85, "parse_pubkey"}, {85, 102, "ecdsa_prep"}, {102, 110, "table_zg"},
+      {110, 302, "q_table"}, {302, 327, "ecmult_R"}, {327, 328, "ecdsa_final"}};
+  int fails = 0;
+  std::string rep;
+  std::vector<u32> slot(SLOT_WORDS), exp(ST_WORDS);
+  for (int i = 0; i < ST_LANES; i++) {
+    selftest_lane(in[i], gt.data(), slot.data(), exp.data());
+    for (size_t st = 0; st < sizeof(stages) / sizeof(stages[0]); st++) {
+      bool bad = false;
+      for (int k = stages[st].lo; k < stages[st].hi; k++) bad |= exp[k] != got[(size_t)i * ST_WORDS + k];
+      if (bad) {
+        fails |= 1 << st;
+        if (rep.size() < 2000) rep += std::string("lane ") + std::to_string(i) + " stage " + stages[st].name + " differs; ";
+      }
+    }
+    if (i == 0) rep += std::string("host verdict lane0=") + std::to_string(exp[327]) + " device=" + std::to_string(got[327]) + "; ";
+  }
+  // G table: recompute a sample of entries on the host from the bases
+  {
+    u32 base[16];
+    const u32 gx[8] = LAMD_GX, gy[8] = LAMD_GY;
+    memcpy(base, gx, 32); memcpy(base + 8, gy, 32);
+    const u32 ds[] = {1, 2, 3, 255, 256, 4097, 65535};
+    for (u32 d : ds) {
+      u32 e[16];
+      gtable_compute_entry(e, base, d);
+      if (memcmp(e, &gt[(size_t)d * 16], 64)) { fails |= 1 << 20; rep += "gtable w0 d=" + std::to_string(d) + " differs; "; }
+    }
+    // window 1 entry 1 must equal 65536*G = window 0 ... (2^16)G: check via doubling
+    gej bb = gej_from_ge(ge_from_words(base, base + 8));
+    for (int i = 0; i < GTABLE_WINDOW_BITS; i++) bb = gej_double(bb);
+    const fe zi = fe_inv(fe_norm_weak(bb.z)); const fe zi2 = fe_sqr(zi);
+    u32 e[16];
+    fe_to_words(e, fe_normalize(fe_mul(bb.x, zi2)));
+    fe_to_words(e + 8, fe_normalize(fe_mul(bb.y, fe_mul(zi2, zi))));
+    if (memcmp(e, &gt[(((size_t)1 << GTABLE_WINDOW_BITS) + 1) * 16], 64)) { fails |= 1 << 21; rep += "gtable w1 d=1 differs; "; }
+  }
+  if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
+  return fails;
+}
+
+// ---- op-level chain debugger: device runs a dependent chain of fe_sqr / fe_mul and records raw limbs in and out of
+// every step; the host re-executes each step on the device's own inputs and reports the first disagreement.
+constexpr int CH_ITERS = 300;
+__global__ void __launch_bounds__(64) k_chain_debug(const st_in *in, u32 *out, int use_mul) {
+  const int lane = threadIdx.x;
+  fe a = fe_from_words(in[lane].a);
+  const fe b = fe_from_words(in[lane].b);
+  u32 *o = out + (size_t)lane * CH_ITERS * 18;
+#pragma unroll 1
+  for (int it = 0; it < CH_ITERS; it++) {
+    for (int i = 0; i < 9; i++) o[it * 18 + i] = a.n[i];
+    const fe r = use_mul ? fe_mul(a, b) : fe_sqr(a);
+    for (int i = 0; i < 9; i++) o[it * 18 + 9 + i] = r.n[i];
+    a = r;
+  }
+}
+extern "C" int lamd_chain_debug(lamd_ctx *ctx, int use_mul, char *report, size_t cap) {
+  if (!ctx) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<st_in> in(ST_LANES);
+  u64 s = 0x7654321;
+  for (int i = 0; i < ST_LANES; i++)
+    for (int j = 0; j < 8; j++) { in[i].a[j] = (u32)splitmix64(s++); in[i].b[j] = (u32)splitmix64(s++); }
+  st_in *d_in; u32 *d_out;
+  const size_t words = (size_t)ST_LANES * CH_ITERS * 18;
+  HIPCHK(ctx, hipMalloc(&d_in, sizeof(st_in) * ST_LANES));
+  HIPCHK(ctx, hipMalloc(&d_out, words * 4));
+  HIPCHK(ctx, hipMemcpy(d_in, in.data(), sizeof(st_in) * ST_LANES, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_chain_debug, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, d_out, use_mul);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<u32> got(words);
+  HIPCHK(ctx, hipMemcpy(got.data(), d_out, words * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  int nbad = 0;
+  std::string rep;
+  char buf[512];
+  for (int lane = 0; lane < ST_LANES; lane++) {
+    const fe b = fe_from_words(in[lane].b);
+    for (int it = 0; it < CH_ITERS; it++) {
+      const u32 *o = &got[((size_t)lane * CH_ITERS + it) * 18];
+      fe a;
+      for (int i = 0; i < 9; i++) a.n[i] = o[i];
+      const fe r = use_mul ? fe_mul(a, b) : fe_sqr(a);
+      bool bad = false;
+      for (int i = 0; i < 9; i++) bad |= r.n[i] != o[9 + i];
+      if (bad) {
+        if (nbad < 3) {
+          snprintf(buf, sizeof buf, "lane %d it %d in=[%x %x %x %x %x %x %x %x %x] dev=[%x %x %x %x %x %x %x %x %x] host=[%x %x %x %x %x %x %x %x %x]; ",
+                   lane, it, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], o[9], o[10], o[11], o[12], o[13], o[14], o[15], o[16], o[17],
+                   r.n[0], r.n[1], r.n[2], r.n[3], r.n[4], r.n[5], r.n[6], r.n[7], r.n[8]);
+          rep += buf;
+          if (use_mul) { snprintf(buf, sizeof buf, "b=[%x %x %x %x %x %x %x %x %x]; ", b.n[0], b.n[1], b.n[2], b.n[3], b.n[4], b.n[5], b.n[6], b.n[7], b.n[8]); rep += buf; }
+        }
+        nbad++;
+      }
+    }
+  }
+  if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
+  return nbad;
+}
+
+// ---- inversion-chain debugger: every intermediate of the addition chain, device vs host
+constexpr int INV_ITEMS = 24;
+LAMD_HD void inv_debug_lane(const u32 aw[8], u32 *o) {
+  const fe a = fe_from_words(aw);
+  fe items[INV_ITEMS];
+  int k = 0;
+  const int ns[8] = {1, 2, 3, 5, 11, 22, 44, 88};
+  for (int j = 0; j < 8; j++) items[k++] = fe_sqr_n(a, ns[j]);  // 0..7
+  const fe x2 = fe_mul(fe_sqr(a), a);
+  const fe x3 = fe_mul(fe_sqr(x2), a);
+  const fe x6 = fe_mul(fe_sqr_n(x3, 3), x3);
+  const fe x9 = fe_mul(fe_sqr_n(x6, 3), x3);
+  const fe x11 = fe_mul(fe_sqr_n(x9, 2), x2);
+  const fe x22 = fe_mul(fe_sqr_n(x11, 11), x11);
+  const fe x44 = fe_mul(fe_sqr_n(x22, 22), x22);
+  const fe x88 = fe_mul(fe_sqr_n(x44, 44), x44);
+  const fe x176 = fe_mul(fe_sqr_n(x88, 88), x88);
+  const fe x220 = fe_mul(fe_sqr_n(x176, 44), x44);
+  const fe x223 = fe_mul(fe_sqr_n(x220, 3), x3);
+  items[k++] = x2; items[k++] = x3; items[k++] = x6; items[k++] = x9; items[k++] = x11; items[k++] = x22;   // 8..13
+  items[k++] = x44; items[k++] = x88; items[k++] = x176; items[k++] = x220; items[k++] = x223;              // 14..18
+  const fe_chain ch = fe_pow_chain(a);
+  items[k++] = ch.x2; items[k++] = ch.x22; items[k++] = ch.x223;                                             // 19..21
+  items[k++] = fe_inv(a);                                                                                     // 22
+  items[k++] = fe_sqrt_candidate(a);                                                                          // 23
+  for (int j = 0; j < INV_ITEMS; j++) {
+    u32 w[8];
+    fe_to_words(w, fe_normalize(items[j]));
+    for (int i = 0; i < 8; i++) o[j * 8 + i] = w[i];
+  }
+}
+__global__ void __launch_bounds__(64) k_inv_debug(const st_in *in, u32 *out) {
+  inv_debug_lane(in[threadIdx.x].a, out + threadIdx.x * INV_ITEMS * 8);
+}
+extern "C" int lamd_inv_debug(lamd_ctx *ctx, char *report, size_t cap) {
+  if (!ctx) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<st_in> in(ST_LANES);
+  u64 s = 0xABCDEF;
+  for (int i = 0; i < ST_LANES; i++)
+    for (int j = 0; j < 8; j++) in[i].a[j] = (u32)splitmix64(s++);
+  st_in *d_in; u32 *d_out;
+  const size_t words = (size_t)ST_LANES * INV_ITEMS * 8;
+  HIPCHK(ctx, hipMalloc(&d_in, sizeof(st_in) * ST_LANES));
+  HIPCHK(ctx, hipMalloc(&d_out, words * 4));
+  HIPCHK(ctx, hipMemcpy(d_in, in.data(), sizeof(st_in) * ST_LANES, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_inv_debug, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<u32> got(words), exp(INV_ITEMS * 8);
+  HIPCHK(ctx, hipMemcpy(got.data(), d_out, words * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  int mask = 0;
+  std::string rep;
+  for (int lane = 0; lane < ST_LANES; lane++) {
+    inv_debug_lane(in[lane].a, exp.data());
+    for (int j = 0; j < INV_ITEMS; j++)
+      if (memcmp(&exp[j * 8], &got[((size_t)lane * INV_ITEMS + j) * 8], 32)) {
+        if (!(mask & (1 << j))) {
+          rep += "item " + std::to_string(j) + " first bad at lane " + std::to_string(lane) + "; ";
+          if (rep.size() < 1500) {
+            char buf[400];
+            const u32 *g = &got[((size_t)lane * INV_ITEMS + j) * 8], *e = &exp[j * 8], *aw = in[lane].a;
+            snprintf(buf, sizeof buf, "a=%08x%08x%08x%08x%08x%08x%08x%08x dev=%08x%08x%08x%08x%08x%08x%08x%08x host=%08x%08x%08x%08x%08x%08x%08x%08x; ",
+                     aw[7], aw[6], aw[5], aw[4], aw[3], aw[2], aw[1], aw[0], g[7], g[6], g[5], g[4], g[3], g[2], g[1], g[0], e[7], e[6], e[5], e[4], e[3], e[2], e[1], e[0]);
+            rep += buf;
+          }
+        }
+        mask |= 1 << j;
+      }
+  }
+  if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
+  return mask;
+}
+
+// ---- x2 debugger: fe_mul(fe_sqr(a), a) in several code shapes, raw limbs out
+__global__ void __launch_bounds__(64) k_x2_debug(const st_in *in, u32 *out) {
+  const int lane = threadIdx.x;
+  u32 *o = out + lane * 64;
+  const fe a = fe_from_words(in[lane].a);
+  {  // A: fused, raw result
+    const fe r = fe_mul(fe_sqr(a), a);
+    for (int i = 0; i < 9; i++) o[i] = r.n[i];
+  }
+  {  // B: intermediate forced through an opaque register barrier
+    fe s2 = fe_sqr(a);
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < 9; i++) asm volatile("" : "+v"(s2.n[i]));
+#endif
+    const fe r = fe_mul(s2, a);
+    for (int i = 0; i < 9; i++) o[9 + i] = s2.n[i];
+    for (int i = 0; i < 9; i++) o[18 + i] = r.n[i];
+  }
+  {  // C: fused then normalized
+    const fe r = fe_normalize(fe_mul(fe_sqr(a), a));
+    for (int i = 0; i < 9; i++) o[27 + i] = r.n[i];
+  }
+  {  // D: a*a via fe_mul, then *a
+    const fe r = fe_mul(fe_mul(a, a), a);
+    for (int i = 0; i < 9; i++) o[36 + i] = r.n[i];
+  }
+}
+extern "C" int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap) {
+  if (!ctx) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<st_in> in(ST_LANES);
+  u64 s = 0xABCDEF;
+  for (int i = 0; i < ST_LANES; i++)
+    for (int j = 0; j < 8; j++) in[i].a[j] = (u32)splitmix64(s++);
+  st_in *d_in; u32 *d_out;
+  HIPCHK(ctx, hipMalloc(&d_in, sizeof(st_in) * ST_LANES));
+  HIPCHK(ctx, hipMalloc(&d_out, ST_LANES * 64 * 4));
+  HIPCHK(ctx, hipMemcpy(d_in, in.data(), sizeof(st_in) * ST_LANES, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_x2_debug, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<u32> got(ST_LANES * 64);
+  HIPCHK(ctx, hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  std::string rep;
+  int mask = 0;
+  char buf[600];
+  for (int lane = 0; lane < ST_LANES; lane++) {
+    const fe a = fe_from_words(in[lane].a);
+    const fe s2 = fe_sqr(a);
+    const fe r = fe_mul(s2, a);
+    const fe rn = fe_normalize(r);
+    const fe rd = fe_mul(fe_mul(a, a), a);
+    const u32 *o = &got[lane * 64];
+    const fe *exps[5] = {&r, &s2, &r, &rn, &rd};
+    const char *names[5] = {"A_fused_raw", "B_sqr_raw", "B_mul_raw", "C_fused_norm", "D_mulmul"};
+    for (int t = 0; t < 5; t++) {
+      bool bad = false;
+      for (int i = 0; i < 9; i++) bad |= exps[t]->n[i] != o[t * 9 + i];
+      if (bad) {
+        if (!(mask & (1 << t))) {
+          const u32 *g = o + t * 9;
+          const u32 *e = exps[t]->n;
+          snprintf(buf, sizeof buf, "%s lane %d dev=[%x %x %x %x %x %x %x %x %x] host=[%x %x %x %x %x %x %x %x %x]; ", names[t], lane, g[0], g[1], g[2], g[3], g[4],
+                   g[5], g[6], g[7], g[8], e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]);
+          rep += buf;
+        }
+        mask |= 1 << t;
+      }
+    }
+  }
+  if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
+  return mask;
 }
 
 // ---- synthetic workloads

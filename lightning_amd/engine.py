@@ -161,6 +161,21 @@ class Engine:
         n = d_msg.shape[0]
         self._chk(self._lib.lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
 
+    def selftest(self, hash32, sig64, pub33):
+        buf = ctypes.create_string_buffer(4096)
+        rc = self._chk(self._lib.lamd_selftest(self._ctx, bytes(hash32), bytes(sig64), bytes(pub33), buf, 4096))
+        return rc, buf.value.decode()
+
+    def chain_debug(self, use_mul):
+        buf = ctypes.create_string_buffer(8192)
+        rc = self._chk(self._lib.lamd_chain_debug(self._ctx, int(use_mul), buf, 8192))
+        return rc, buf.value.decode()
+
+    def inv_debug(self):
+        buf = ctypes.create_string_buffer(8192)
+        rc = self._chk(self._lib.lamd_inv_debug(self._ctx, buf, 8192))
+        return rc, buf.value.decode()
+
     def synchronize(self):
         self._chk(self._lib.lamd_synchronize(self._ctx))
 

@@ -1,0 +1,46 @@
+"""Multi-GPU partitioning of a verification batch.
+
+Every (hash, key, signature) row is independent, so the path shards trivially: rank g of G takes
+a contiguous range of rows and no data-path collective is needed for correctness.  Ranges are cut
+on GROUP boundaries when the caller supplies group sizes, so that the four signatures of one
+channel_announcement, or the 484 signatures of one commitment_signed, stay on one GPU (their
+shared key is then parsed / tabulated once).  The only collective is the all-gather of the
+verdict bytes (RCCL over xGMI on GPUs; gloo in the CPU tests) so that every rank ends with the
+whole verdict vector, as the north star asks.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world, group_sizes=None):
+    """-> int64 array b of world+1 row offsets; rank g owns rows [b[g], b[g+1]).
+    group_sizes: optional sequence summing to n_rows; cuts fall only between groups."""
+    if group_sizes is None:
+        return np.array([(n_rows * g) // world for g in range(world + 1)], dtype=np.int64)
+    ends = np.cumsum(np.asarray(group_sizes, dtype=np.int64))
+    if len(ends) == 0 or ends[-1] != n_rows:
+        raise ValueError("group sizes do not add up to n_rows")
+    b = [0]
+    for g in range(1, world):
+        target = (n_rows * g) // world
+        j = int(np.searchsorted(ends, target, side="left"))  # first group end >= target
+        cut = int(ends[j]) if j < len(ends) else n_rows
+        b.append(max(cut, b[-1]))
+    b.append(n_rows)
+    return np.array(b, dtype=np.int64)
+
+
+def all_gather_verdicts(ok_local, bounds, rank, world):
+    """ok_local: uint8 tensor holding this rank's verdicts (len = bounds[rank+1]-bounds[rank]).
+    Returns the full verdict vector (len bounds[-1]) on every rank.  Shards may be ragged, so the
+    payload is padded to the longest shard (a <= 1 MB, latency-bound collective either way)."""
+    if world == 1:
+        return ok_local
+    sizes = [int(bounds[g + 1] - bounds[g]) for g in range(world)]
+    m = max(sizes)
+    pad = torch.zeros(m, dtype=torch.uint8, device=ok_local.device)
+    pad[:sizes[rank]] = ok_local
+    out = torch.empty(world * m, dtype=torch.uint8, device=ok_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[g * m:g * m + sizes[g]] for g in range(world)])

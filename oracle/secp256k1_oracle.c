@@ -642,7 +642,7 @@ void orc_ecdsa_verify_batch(size_t n, const uint8_t *hash32, const uint8_t *sig6
 {
 	orc_init();
 	long i;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
 	for (i = 0; i < (long)n; i++)
 		out[i] = (uint8_t)orc_ecdsa_verify(hash32 + 32 * i, sig64 + 64 * i, pub + publen * i, publen);
 }
@@ -651,7 +651,7 @@ void orc_schnorr_verify_batch(size_t n, const uint8_t *msg32, const uint8_t *xon
 {
 	orc_init();
 	long i;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
 	for (i = 0; i < (long)n; i++)
 		out[i] = (uint8_t)orc_schnorr_verify(msg32 + 32 * i, xonly32 + 32 * i, sig64 + 64 * i);
 }
