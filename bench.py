@@ -126,6 +126,13 @@ def main():
         ke = np.mean(np.array(kernel_ms["ecdsa"]), axis=0)      # prep, keys, ecmult [ms]
         ks = np.mean(np.array(kernel_ms["schnorr"]), axis=0)
         t_ecmult = ke[2] * 1e-3
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_ecmult_ecdsa_1M"]
+            if n == 1_000_000:
+                traffic, traffic_src = pm["hbm_bytes_per_launch"], pm["source"]
+        except Exception:
+            pass
         achieved = W_ECDSA65 * n / t_ecmult
         algo_bytes = BYTES_ECDSA65 * n
         out = {
@@ -141,7 +148,8 @@ def main():
                       "kernel_ms_schnorr": {"prep": ks[0], "keys": ks[1], "ecmult": ks[2]}},
             "roofline": {"kernel": "k_ecmult (ECDSA launch, %d signatures)" % n, "bound": "valu-int32-mul (not hbm, not mfma)",
                          "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
-                         "algorithmic_mul32_per_verify": W_ECDSA65, "avg_launch_ms": ke[2], "traffic": None,
+                         "algorithmic_mul32_per_verify": W_ECDSA65, "avg_launch_ms": ke[2], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                         "traffic_source": traffic_src,
                          "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,
                                  "peak_GBs": HBM_PEAK_GBS, "frac": algo_bytes / t_ecmult / 1e9 / HBM_PEAK_GBS}},
             "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "against": "verdicts known by construction (all rows)"},
@@ -150,7 +158,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # test infrastructure: the checker / CPU baseline only
             m = min(args.cpu_sample, n)
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             c = [np.ascontiguousarray(x[:m]) for x in we.cols]
             orc.ecdsa_verify_batch(c[0][:64], c[1][:64], c[2][:64], 65, cores)  # table init outside the timed part
             t1 = time.perf_counter()

@@ -10,6 +10,21 @@ SOURCES = [os.path.join(CSRC, f) for f in ("lamd_engine.hip", "verify_core.h", "
     os.path.join(ROOT, "include", "lightning_amd.h")]
 
 
+SHIM = os.path.join(PKG, "liblightning_amd_cln.so")
+SHIM_SOURCES = [os.path.join(CSRC, "cln_shim.cpp"), os.path.join(CSRC, "cln_shim.h")]
+
+
+def build_shim(force=False):
+    """host-side C++ mirror of the reference prototypes (links against liblightning_amd.so)"""
+    if not force and os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in SHIM_SOURCES + [LIB]):
+        return SHIM
+    cxx = os.environ.get("CXX", "g++")
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SHIM + ".tmp", SHIM_SOURCES[0],
+                           "-L" + PKG, "-llightning_amd", "-Wl,-rpath,$ORIGIN"])
+    os.replace(SHIM + ".tmp", SHIM)
+    return SHIM
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -19,6 +34,7 @@ def is_stale():
 
 def build(force=False, verbose=False):
     if not (force or is_stale()):
+        build_shim()
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-codegenprepare-mul24=false: ROCm 7.2's AMDGPUCodeGenPrepare mul24 rewrite miscompiles the fused
@@ -32,4 +48,5 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    build_shim(force=True)
     return LIB

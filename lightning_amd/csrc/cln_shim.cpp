@@ -1,0 +1,272 @@
+// Host mirror of the reference's prototypes over the C ABI (see cln_shim.h).  Host code here is
+// framing only: SHA-256 of message tails / preimages, DER and compact parsing, error strings.
+// Every elliptic-curve decision is made by the HIP kernels behind lamd_*.
+#include "cln_shim.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/lightning_amd.h"
+
+static lamd_ctx *g_ctx;
+static std::string g_err;
+
+extern "C" bool lamd_shim_setup(void) {
+  if (g_ctx) return true;
+  const char *dev = getenv("LAMD_DEVICE");
+  lamd_ctx *c = nullptr;
+  const int rc = lamd_init(&c, dev ? atoi(dev) : 0);
+  if (rc != LAMD_OK) {
+    g_err = std::string("lamd_init failed (") + std::to_string(rc) + "): " + (c ? lamd_last_error(c) : "no device");
+    if (c) lamd_shutdown(c);
+    return false;
+  }
+  g_ctx = c;
+  return true;
+}
+extern "C" void lamd_shim_shutdown(void) {
+  if (g_ctx) lamd_shutdown(g_ctx);
+  g_ctx = nullptr;
+}
+extern "C" const char *lamd_shim_last_error(void) { return g_err.c_str(); }
+
+// ---- SHA-256 (FIPS 180-4), host framing only
+static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void sha256_block(uint32_t st[8], const u8 *b) {
+  uint32_t w[64];
+  for (int i = 0; i < 16; i++) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+  for (int i = 16; i < 64; i++)
+    w[i] = w[i - 16] + (ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] + (ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10));
+  uint32_t a = st[0], bb = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+  for (int i = 0; i < 64; i++) {
+    const uint32_t t1 = h + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+    const uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+    h = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+  }
+  st[0] += a; st[1] += bb; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+static void sha256_host(const u8 *p, size_t len, u8 out[32]) {
+  uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  size_t off = 0;
+  for (; off + 64 <= len; off += 64) sha256_block(st, p + off);
+  u8 tail[128] = {0};
+  const size_t rem = len - off;
+  memcpy(tail, p + off, rem);
+  tail[rem] = 0x80;
+  const size_t tl = rem + 9 <= 64 ? 64 : 128;
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (u8)(bits >> (8 * i));
+  sha256_block(st, tail);
+  if (tl == 128) sha256_block(st, tail + 64);
+  for (int i = 0; i < 8; i++) { out[4 * i] = st[i] >> 24; out[4 * i + 1] = st[i] >> 16; out[4 * i + 2] = st[i] >> 8; out[4 * i + 3] = st[i]; }
+}
+extern "C" void sha256_double(struct sha256_double *shadouble, const void *p, size_t len) {
+  u8 h[32];
+  sha256_host((const u8 *)p, len, h);
+  sha256_host(h, 32, shadouble->sha.u.u8);
+}
+
+// ---- keys
+static bool parse_key(const u8 *ser, size_t len, secp256k1_pubkey *out) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  u8 ok = 0;
+  const int rc = lamd_pubkey_parse_batch(g_ctx, 1, ser, len, len, out->data, &ok);
+  if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return false; }
+  return ok != 0;
+}
+extern "C" bool pubkey_from_der(const u8 *der, size_t len, struct pubkey *key) {
+  if (len != PUBKEY_CMPR_LEN) return false;  // bitcoin/pubkey.c:16
+  return parse_key(der, len, &key->pubkey);
+}
+extern "C" void pubkey_to_der(u8 der[PUBKEY_CMPR_LEN], const struct pubkey *key) {
+  der[0] = 2 + (key->pubkey.data[63] & 1);
+  memcpy(der + 1, key->pubkey.data, 32);
+}
+extern "C" bool pubkey_from_node_id(struct pubkey *key, const struct node_id *id) { return parse_key(id->k, sizeof(id->k), &key->pubkey); }
+
+// ---- signatures
+static const u8 ORDER_N[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFE,
+                               0xBA, 0xAE, 0xDC, 0xE6, 0xAF, 0x48, 0xA0, 0x3B, 0xBF, 0xD2, 0x5E, 0x8C, 0xD0, 0x36, 0x41, 0x41};
+static bool below_n(const u8 v[32]) { return memcmp(v, ORDER_N, 32) < 0; }
+
+extern "C" bool fromwire_secp256k1_ecdsa_signature(const u8 compact[64], secp256k1_ecdsa_signature *sig) {
+  if (!below_n(compact) || !below_n(compact + 32)) return false;  // secp256k1_ecdsa_signature_parse_compact, wire/fromwire.c:196
+  memcpy(sig->data, compact, 64);
+  return true;
+}
+
+// strict DER (what secp256k1_ecdsa_signature_parse_der accepts); out-of-range integers parse as 0
+static bool der_len(size_t *out, const u8 **p, const u8 *end) {
+  if (*p >= end) return false;
+  const unsigned b1 = *((*p)++);
+  if (b1 == 0xFF) return false;
+  if (!(b1 & 0x80)) { *out = b1; return true; }
+  if (b1 == 0x80) return false;
+  size_t left = b1 & 0x7F;
+  if (left > (size_t)(end - *p)) return false;
+  if (**p == 0) return false;
+  if (left > sizeof(size_t)) return false;
+  size_t v = 0;
+  while (left-- > 0) v = (v << 8) | *((*p)++);
+  if (v > (size_t)(end - *p) || v < 128) return false;
+  *out = v;
+  return true;
+}
+static bool der_int(u8 out32[32], const u8 **p, const u8 *end) {
+  size_t rlen;
+  if (*p == end || **p != 0x02) return false;
+  (*p)++;
+  if (!der_len(&rlen, p, end)) return false;
+  if (rlen == 0 || rlen > (size_t)(end - *p)) return false;
+  if ((*p)[0] == 0x00 && rlen > 1 && !((*p)[1] & 0x80)) return false;
+  if ((*p)[0] == 0xFF && rlen > 1 && ((*p)[1] & 0x80)) return false;
+  bool overflow = ((*p)[0] & 0x80) != 0;
+  const u8 *s = *p;
+  size_t l = rlen;
+  if (l > 0 && s[0] == 0) { l--; s++; }
+  if (l > 32) overflow = true;
+  memset(out32, 0, 32);
+  if (!overflow) {
+    memcpy(out32 + 32 - l, s, l);
+    if (!below_n(out32)) overflow = true;
+  }
+  if (overflow) memset(out32, 0, 32);
+  *p += rlen;
+  return true;
+}
+static bool sighash_type_valid(int t) { return t == SIGHASH_ALL || t == (SIGHASH_SINGLE | SIGHASH_ANYONECANPAY); }
+
+extern "C" bool signature_from_der(const u8 *der, size_t len, struct bitcoin_signature *sig) {
+  if (len < 1) return false;
+  const u8 *p = der, *end = der + len - 1;
+  size_t rlen;
+  if (p == end || *(p++) != 0x30) return false;
+  if (!der_len(&rlen, &p, end) || rlen != (size_t)(end - p)) return false;
+  if (!der_int(sig->s.data, &p, end) || !der_int(sig->s.data + 32, &p, end) || p != end) return false;
+  sig->sighash_type = (enum sighash_type)der[len - 1];
+  return sighash_type_valid(der[len - 1]);
+}
+
+// ---- checks
+extern "C" bool check_signed_hash(const struct sha256_double *hash, const secp256k1_ecdsa_signature *signature, const struct pubkey *key) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  u8 pub65[65];
+  pub65[0] = 4;
+  memcpy(pub65 + 1, key->pubkey.data, 64);
+  const int rc = lamd_check_signed_hash(g_ctx, hash->sha.u.u8, signature->data, pub65, 65);
+  if (rc < 0) g_err = lamd_last_error(g_ctx);
+  return rc == 1;
+}
+extern "C" bool check_signed_hash_nodeid(const struct sha256_double *hash, const secp256k1_ecdsa_signature *signature, const struct node_id *id) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  // common/node_id.c:72-80: parse the 33-byte id, then check_signed_hash -- both happen on the device in one call
+  const int rc = lamd_check_signed_hash_nodeid(g_ctx, hash->sha.u.u8, signature->data, id->k);
+  if (rc < 0) g_err = lamd_last_error(g_ctx);
+  return rc == 1;
+}
+extern "C" bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pubkey *pubkey, const struct bip340sig *sig) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  u8 raw[PUBKEY_CMPR_LEN];
+  raw[0] = 2 + (pubkey->data[63] & 1);  // bitcoin/signature.c:417: serialise compressed ...
+  memcpy(raw + 1, pubkey->data, 32);
+  const int rc = lamd_check_schnorr_sig(g_ctx, hash->u.u8, raw, sig->u8);  // ... :422 drops the parity byte
+  if (rc < 0) g_err = lamd_last_error(g_ctx);
+  return rc == 1;
+}
+extern "C" bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script, const struct pubkey *key,
+                             const struct bitcoin_signature *sig) {
+  // bitcoin/signature.c:206-211: only SIGHASH_ALL, or SINGLE|ANYONECANPAY with a witness script
+  if (sig->sighash_type != SIGHASH_ALL) {
+    if (!witness_script) return false;
+    if (sig->sighash_type != (SIGHASH_SINGLE | SIGHASH_ANYONECANPAY)) return false;
+  }
+  struct sha256_double hash;
+  sha256_double(&hash, bip143_preimage, preimage_len);
+  return check_signed_hash(&hash, &sig->s, key);
+}
+
+// ---- gossip veneer
+static std::string hex(const u8 *p, size_t n) {
+  static const char *d = "0123456789abcdef";
+  std::string s;
+  s.reserve(2 * n);
+  for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); }
+  return s;
+}
+// fmt_secp256k1_ecdsa_signature prints the DER serialisation (bitcoin/signature.c:325-335)
+static std::string der_hex(const secp256k1_ecdsa_signature *sig) {
+  u8 out[72];
+  size_t n = 0;
+  auto put_int = [&](const u8 *v) {
+    size_t skip = 0;
+    while (skip < 31 && v[skip] == 0) skip++;
+    const bool pad = v[skip] & 0x80;
+    out[n++] = 0x02;
+    out[n++] = (u8)(32 - skip + (pad ? 1 : 0));
+    if (pad) out[n++] = 0;
+    memcpy(out + n, v + skip, 32 - skip);
+    n += 32 - skip;
+  };
+  n = 2;
+  put_int(sig->data);
+  put_int(sig->data + 32);
+  out[0] = 0x30;
+  out[1] = (u8)(n - 2);
+  return hex(out, n);
+}
+static const char *dup(const std::string &s) {
+  char *r = (char *)malloc(s.size() + 1);
+  memcpy(r, s.c_str(), s.size() + 1);
+  return r;
+}
+static std::string bad(const char *what, const secp256k1_ecdsa_signature *sig, const u8 *msg, size_t len, size_t off, const char *kind) {
+  struct sha256_double h;
+  sha256_double(&h, msg + off, len - off);
+  return std::string(what) + " " + der_hex(sig) + " hash " + hex(h.sha.u.u8, 32) + " on " + kind + " " + hex(msg, len);
+}
+// runs the raw message through the device path; the typed arguments (already parsed by the caller, as in the
+// reference) are what the error string prints
+static int device_verdict(const u8 *msg, size_t len, const struct node_id *id) {
+  if (!g_ctx && !lamd_shim_setup()) return -2;
+  const uint64_t off[2] = {0, len};
+  int8_t v = -2;
+  const int rc = lamd_sigcheck_gossip_batch(g_ctx, 1, msg, off, id ? id->k : nullptr, &v);
+  if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return -2; }
+  return v;
+}
+extern "C" const char *sigcheck_channel_update(const tal_t *, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
+                                               const u8 *update, size_t len) {
+  const int v = device_verdict(update, len, node_id);
+  if (v == 0) return nullptr;
+  if (v == -2) return dup("engine error: " + g_err);
+  return dup(bad("Bad signature for", node_sig, update, len, 66, "channel_update"));
+}
+extern "C" const char *sigcheck_channel_announcement(const tal_t *, const struct node_id *, const struct node_id *, const struct pubkey *,
+                                                     const struct pubkey *, const secp256k1_ecdsa_signature *node1_sig,
+                                                     const secp256k1_ecdsa_signature *node2_sig, const secp256k1_ecdsa_signature *bitcoin1_sig,
+                                                     const secp256k1_ecdsa_signature *bitcoin2_sig, const u8 *announcement, size_t len) {
+  const int v = device_verdict(announcement, len, nullptr);
+  if (v == 0) return nullptr;
+  if (v == -2) return dup("engine error: " + g_err);
+  if (v == -1) return dup(std::string("malformed channel_announcement ") + hex(announcement, len));  // fromwire_* would have failed earlier
+  static const char *names[4] = {"Bad node_signature_1", "Bad node_signature_2", "Bad bitcoin_signature_1", "Bad bitcoin_signature_2"};
+  const secp256k1_ecdsa_signature *sigs[4] = {node1_sig, node2_sig, bitcoin1_sig, bitcoin2_sig};
+  return dup(bad(names[v - 1], sigs[v - 1], announcement, len, 258, "channel_announcement"));
+}
+extern "C" const char *sigcheck_node_announcement(const tal_t *, const struct node_id *, const secp256k1_ecdsa_signature *node_sig,
+                                                  const u8 *node_announcement, size_t len) {
+  const int v = device_verdict(node_announcement, len, nullptr);
+  if (v == 0) return nullptr;
+  if (v == -2) return dup("engine error: " + g_err);
+  return dup(bad("Bad signature for", node_sig, node_announcement, len, 66, "node_announcement"));
+}

@@ -1,0 +1,96 @@
+/* Host-side mirror of Core Lightning's own prototypes for the signature-check path, implemented
+ * over the C ABI of liblightning_amd.so.  Same names, argument meaning and error behaviour as
+ * the reference (v26.06.6):
+ *
+ *   bitcoin/signature.h:85-87    check_signed_hash()
+ *   bitcoin/signature.h:120-124  check_tx_sig()            (see note below)
+ *   bitcoin/signature.h:129-131  check_schnorr_sig()
+ *   bitcoin/signature.h:158-159  signature_from_der()      (bitcoin/signature.c:310-323)
+ *   common/node_id.h:72-82       pubkey_from_node_id(), check_signed_hash_nodeid()
+ *   bitcoin/pubkey.h             pubkey_from_der(), pubkey_to_der()
+ *   bitcoin/shadouble.h:15       sha256_double()
+ *   wire/fromwire.c:188-199      fromwire_secp256k1_ecdsa_signature()
+ *   gossipd/sigcheck.h:7-28      sigcheck_channel_update/_channel_announcement/_node_announcement()
+ *
+ * The opaque types keep the reference's names and sizes; their CONTENT is this library's own
+ * (the reference never looks inside them): secp256k1_ecdsa_signature.data = r||s big-endian,
+ * secp256k1_pubkey.data = affine X||Y big-endian.
+ *
+ * Differences a maintainer has to know about (also in INTEGRATION.md):
+ *  - tal: the sigcheck_* functions return a malloc()ed string (or NULL); the `ctx` argument is
+ *    accepted and ignored.  In-tree one would tal_strdup() it onto ctx.
+ *  - check_tx_sig(): the reference hashes a `struct bitcoin_tx` through libwally
+ *    (bitcoin/signature.c:120-151).  Building BIP143 preimages from transactions is row N1 of
+ *    SURVEY 8(f); here the caller passes the already-serialised BIP143 preimage.  The sighash-type
+ *    gate (:206-211) and everything after it are the reference's.
+ *  - all elliptic-curve work (key decompression, verification) runs on the GPU through
+ *    lamd_*; hashing and DER/compact parsing are host code.  Without a device every check
+ *    fails closed (false / "engine error" string), there is no CPU verification path.
+ */
+#ifndef LIGHTNING_AMD_CLN_SHIM_H
+#define LIGHTNING_AMD_CLN_SHIM_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint8_t u8;
+typedef void tal_t;
+
+struct sha256 { union { uint32_t u32[8]; unsigned char u8[32]; } u; };      /* ccan/crypto/sha256 */
+struct sha256_double { struct sha256 sha; };                                    /* bitcoin/shadouble.h:9-11 */
+typedef struct { unsigned char data[64]; } secp256k1_ecdsa_signature;          /* opaque; here r||s */
+typedef struct { unsigned char data[64]; } secp256k1_pubkey;                   /* opaque; here X||Y */
+struct pubkey { secp256k1_pubkey pubkey; };                                     /* bitcoin/pubkey.h:15-18 */
+struct node_id { u8 k[33]; };                                                   /* common/node_id.h:11-13 */
+struct bip340sig { u8 u8[64]; };                                                /* bitcoin/signature.h:145-147 */
+
+enum sighash_type { SIGHASH_ALL = 1, SIGHASH_NONE = 2, SIGHASH_SINGLE = 3, SIGHASH_ANYONECANPAY = 0x80 };
+struct bitcoin_signature { secp256k1_ecdsa_signature s; enum sighash_type sighash_type; };
+#define PUBKEY_CMPR_LEN 33
+
+/* common/setup.c:38-64 analogue: creates the process-global engine context (device 0 unless
+ * LAMD_DEVICE is set).  Returns false (and every later check fails closed) without a GPU. */
+bool lamd_shim_setup(void);
+void lamd_shim_shutdown(void);
+const char *lamd_shim_last_error(void);
+
+void sha256_double(struct sha256_double *shadouble, const void *p, size_t len);
+
+bool pubkey_from_der(const u8 *der, size_t len, struct pubkey *key);
+void pubkey_to_der(u8 der[PUBKEY_CMPR_LEN], const struct pubkey *key);
+bool pubkey_from_node_id(struct pubkey *key, const struct node_id *id);
+
+/* returns false (the reference calls fromwire_fail) iff r >= n or s >= n */
+bool fromwire_secp256k1_ecdsa_signature(const u8 compact[64], secp256k1_ecdsa_signature *sig);
+bool signature_from_der(const u8 *der, size_t len, struct bitcoin_signature *sig);
+
+bool check_signed_hash(const struct sha256_double *hash, const secp256k1_ecdsa_signature *signature,
+		       const struct pubkey *key);
+bool check_signed_hash_nodeid(const struct sha256_double *hash, const secp256k1_ecdsa_signature *signature,
+			      const struct node_id *id);
+bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pubkey *pubkey, const struct bip340sig *sig);
+/* bip143_preimage: what wally_tx_get_btc_signature_hash() would hash for (tx, input_num, script,
+ * amount, sig->sighash_type); witness_script NULL = legacy (then only SIGHASH_ALL is accepted). */
+bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
+		  const struct pubkey *key, const struct bitcoin_signature *sig);
+
+/* msg_len replaces tal_count(msg).  NULL = OK, else a malloc()ed message with the reference's
+ * exact wording ("Bad node_signature_1 <der-hex> hash <hex> on channel_announcement <hex>", ...). */
+const char *sigcheck_channel_update(const tal_t *ctx, const struct node_id *node_id,
+				    const secp256k1_ecdsa_signature *node_sig, const u8 *update, size_t msg_len);
+const char *sigcheck_channel_announcement(const tal_t *ctx, const struct node_id *node1_id, const struct node_id *node2_id,
+					  const struct pubkey *bitcoin1_key, const struct pubkey *bitcoin2_key,
+					  const secp256k1_ecdsa_signature *node1_sig, const secp256k1_ecdsa_signature *node2_sig,
+					  const secp256k1_ecdsa_signature *bitcoin1_sig, const secp256k1_ecdsa_signature *bitcoin2_sig,
+					  const u8 *announcement, size_t msg_len);
+const char *sigcheck_node_announcement(const tal_t *ctx, const struct node_id *node_id,
+				       const secp256k1_ecdsa_signature *node_sig, const u8 *node_announcement, size_t msg_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

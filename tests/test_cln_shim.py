@@ -1,0 +1,155 @@
+"""The C++ host mirror of the reference's prototypes (lightning_amd/csrc/cln_shim.*).
+CPU part: host framing (DER / compact parsing, SHA256d, sighash-type gate) against the goldens.
+GPU part (-m gpu): the reference's own unit-test expectations through the reference's own names."""
+import ctypes
+import hashlib
+import os
+
+import pytest
+
+H = bytes.fromhex
+
+
+class Sig(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_ubyte * 64)]
+
+
+class BitcoinSig(ctypes.Structure):
+    _fields_ = [("s", Sig), ("sighash_type", ctypes.c_int)]
+
+
+class Pubkey(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_ubyte * 64)]
+
+
+class NodeId(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_ubyte * 33)]
+
+
+class Sha256d(ctypes.Structure):
+    _fields_ = [("u8", ctypes.c_ubyte * 32)]
+
+
+@pytest.fixture(scope="module")
+def shim():
+    from lightning_amd import _build
+    _build.build()
+    L = ctypes.CDLL(_build.build_shim())
+    for n in ("pubkey_from_der", "pubkey_from_node_id", "fromwire_secp256k1_ecdsa_signature", "signature_from_der", "check_signed_hash",
+              "check_signed_hash_nodeid", "check_schnorr_sig", "check_tx_sig", "lamd_shim_setup"):
+        getattr(L, n).restype = ctypes.c_bool
+    for n in ("sigcheck_channel_update", "sigcheck_channel_announcement", "sigcheck_node_announcement", "lamd_shim_last_error"):
+        getattr(L, n).restype = ctypes.c_char_p  # leaks the malloc()ed string; fine in a test
+    return L
+
+
+def test_signature_from_der_goldens(shim, kat):
+    for v in kat["der"]:
+        der = H(v["der"])
+        if not (v.get("full") or v["name"] == "KAT-O"):
+            der = der + b"\x01"  # signature_from_der wants the trailing sighash byte
+        sig = BitcoinSig()
+        ok = shim.signature_from_der(der, len(der), ctypes.byref(sig))
+        if v["expect_sig"] is None:
+            assert not ok, v["name"]
+        else:
+            assert ok, v["name"]
+            assert bytes(sig.s.data) == H(v["expect_sig"]), v["name"]
+            assert sig.sighash_type == (v["expect_sighash"] or 1)
+
+
+def test_fromwire_compact_and_sha256_double(shim, kat):
+    N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    sig = Sig()
+    for r, s, exp in ((1, 1, True), (N - 1, N - 1, True), (N, 1, False), (1, N, False), (2**256 - 1, 5, False), (0, 0, True)):
+        assert shim.fromwire_secp256k1_ecdsa_signature(r.to_bytes(32, "big") + s.to_bytes(32, "big"), ctypes.byref(sig)) == exp
+    for ln in (0, 1, 55, 56, 64, 72, 290, 1000):
+        data = bytes(range(256)) * 4
+        out = Sha256d()
+        shim.sha256_double(ctypes.byref(out), data[:ln], ln)
+        assert bytes(out.u8) == hashlib.sha256(hashlib.sha256(data[:ln]).digest()).digest()
+    for v in kat["bip143"]:
+        out = Sha256d()
+        pre = H(v["preimage"])
+        shim.sha256_double(ctypes.byref(out), pre, len(pre))
+        assert bytes(out.u8) == H(v["expect"])
+
+
+def test_check_tx_sig_sighash_gate_needs_no_device(shim):
+    """bitcoin/signature.c:206-211 rejects before any curve work"""
+    sig = BitcoinSig()
+    key = Pubkey()
+    for t, wit, reaches_verify in ((2, b"\x51", False), (0x83, None, False), (0x81, b"\x51", False), (3, b"\x51", False)):
+        sig.sighash_type = t
+        assert shim.check_tx_sig(b"\x00" * 10, 10, wit, ctypes.byref(key), ctypes.byref(sig)) is False
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_expectations(shim, kat):
+    assert shim.lamd_shim_setup(), shim.lamd_shim_last_error()
+    # ---- gossipd/test/run-check_channel_announcement.c:62-108
+    for name, needle in (("KAT-G/orig", b"Bad node_signature_1"), ("KAT-G/features-stripped", b"Bad node_signature_2")):
+        m = H(next(v for v in kat["gossip"] if v["name"] == name)["msg"])
+        flen = int.from_bytes(m[258:260], "big")
+        koff = 260 + flen + 40
+        sigs = [Sig() for _ in range(4)]
+        for i in range(4):
+            assert shim.fromwire_secp256k1_ecdsa_signature(m[2 + 64 * i:66 + 64 * i], ctypes.byref(sigs[i]))
+        ids = [NodeId.from_buffer_copy(m[koff + 33 * i:koff + 33 * i + 33]) for i in range(2)]
+        keys = [Pubkey() for _ in range(2)]
+        for i in range(2):
+            assert shim.pubkey_from_der(m[koff + 66 + 33 * i:koff + 99 + 33 * i], 33, ctypes.byref(keys[i]))
+        err = shim.sigcheck_channel_announcement(None, ctypes.byref(ids[0]), ctypes.byref(ids[1]), ctypes.byref(keys[0]), ctypes.byref(keys[1]),
+                                                 ctypes.byref(sigs[0]), ctypes.byref(sigs[1]), ctypes.byref(sigs[2]), ctypes.byref(sigs[3]), m, len(m))
+        assert err is not None and needle in err
+        if name == "KAT-G/orig":
+            # the exact text quoted at the top of the reference's test file
+            assert err.startswith(b"Bad node_signature_1 3044022011effc9ed10fceccfae5f9e3fef20d983b06eed030e968fd8d1e6c5905e18f9f02202df6a43f00d7c0ddf52e0467ab1e32394051b72ea6343fb008a4117c265f3d7b "
+                                  b"hash bb92b8f45b48e65ad2f2cfff2242fa921b4cf46f709a372ca7788537e89d9de1 on channel_announcement 010011effc9ed10f")
+    # ---- onchaind/test/run-grind_feerate.c:120-150: one fee matches
+    ko = next(v for v in kat["der"] if v["name"] == "KAT-O")
+    sig = BitcoinSig()
+    der = H(ko["der"])
+    assert shim.signature_from_der(der, len(der), ctypes.byref(sig))
+    key = Pubkey()
+    assert shim.pubkey_from_der(H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f"), 33, ctypes.byref(key))
+    verdicts = {}
+    for v in kat["bip143"]:
+        pre = H(v["preimage"])
+        verdicts[v["name"]] = shim.check_tx_sig(pre, len(pre), b"\x76", ctypes.byref(key), ctypes.byref(sig))
+    assert verdicts["KAT-O/fee=165750"] is True and sum(verdicts.values()) == 1
+    # ---- check_signed_hash / _nodeid / schnorr through the reference's names
+    b11 = next(v for v in kat["ecdsa"] if v["name"] == "KAT-B11")
+    h = Sha256d.from_buffer_copy(H(b11["hash"]))
+    s = Sig()
+    assert shim.fromwire_secp256k1_ecdsa_signature(H(b11["sig"]), ctypes.byref(s))
+    nid = NodeId.from_buffer_copy(H(b11["pub"]))
+    assert shim.check_signed_hash_nodeid(ctypes.byref(h), ctypes.byref(s), ctypes.byref(nid)) is True
+    pk = Pubkey()
+    assert shim.pubkey_from_node_id(ctypes.byref(pk), ctypes.byref(nid))
+    assert shim.check_signed_hash(ctypes.byref(h), ctypes.byref(s), ctypes.byref(pk)) is True
+    out = (ctypes.c_ubyte * 33)()
+    shim.pubkey_to_der(out, ctypes.byref(pk))
+    assert bytes(out) == H(b11["pub"])
+    h2 = Sha256d.from_buffer_copy(bytes([H(b11["hash"])[0] ^ 1]) + H(b11["hash"])[1:])
+    assert shim.check_signed_hash(ctypes.byref(h2), ctypes.byref(s), ctypes.byref(pk)) is False
+    bad = NodeId.from_buffer_copy(b"\x05" + H(b11["pub"])[1:])
+    assert shim.check_signed_hash_nodeid(ctypes.byref(h), ctypes.byref(s), ctypes.byref(bad)) is False  # "If node_id is invalid, it fails here"
+    for v in kat["schnorr"][:15]:
+        # check_schnorr_sig gets a full key; both liftings of the x-only key must give the same verdict
+        pkx = Pubkey()
+        if not shim.pubkey_from_der(b"\x02" + H(v["pk"]), 33, ctypes.byref(pkx)):
+            continue  # not a valid x: the reference could not even construct the pubkey argument
+        msg = Sha256d.from_buffer_copy(H(v["msg"]))
+        sg = Sig.from_buffer_copy(H(v["sig"]))
+        assert shim.check_schnorr_sig(ctypes.byref(msg), ctypes.byref(pkx), ctypes.byref(sg)) == v["expect"], v["name"]
+    # channel_update / node_announcement wording
+    cu = next(v for v in kat["gossip"] if v["name"] == "cupd/lastnibble/0")
+    m = H(cu["msg"])
+    sg = Sig()
+    assert shim.fromwire_secp256k1_ecdsa_signature(m[2:66], ctypes.byref(sg))
+    err = shim.sigcheck_channel_update(None, ctypes.byref(NodeId.from_buffer_copy(H(cu["node_id"]))), ctypes.byref(sg), m, len(m))
+    assert err.startswith(b"Bad signature for 30") and b" on channel_update 0102" in err  # tests/test_gossip.py:2001 greps "Bad signature"
+    ok = next(v for v in kat["gossip"] if v["name"] == "nann/ok/0")
+    m = H(ok["msg"])
+    assert shim.sigcheck_node_announcement(None, None, ctypes.byref(sg), m, len(m)) is None
