@@ -106,6 +106,13 @@ int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *pub, size_t 
 int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, const uint64_t *off,
 			       const uint8_t *node_ids33, int8_t *verdict);
 
+/* Device-resident variant (asynchronous on the context's stream).  d_off: uint64[n+1] byte offsets;
+ * d_rowbase: uint64[n+1], d_rowbase[i] = number of signatures in messages 0..i-1 (4 per
+ * channel_announcement, 1 otherwise), rows = d_rowbase[n] (at most 2^22 per call). */
+int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_off,
+				      const void *d_node_ids33, const void *d_rowbase, size_t rows,
+				      void *d_verdict);
+
 /* ---- streaming front end for callers that produce triples one at a time (channeld's
  * commitment_signed loop, channeld/channeld.c:2171,2215-2232; gossip ingest).  Triples are
  * appended to a pinned staging ring; flush launches everything queued (asynchronous);
@@ -123,10 +130,20 @@ int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
  * in the reference: producing signed test traffic).  Keys and nonces are derived from the seed
  * with splitmix64; outputs are device buffers.  Not a signing API: secrets are public by
  * construction. */
-int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t publen,
+/* group: rows are cut into groups of `group` consecutive rows sharing one key (the 483 HTLC
+ * signatures of a commitment share remote_htlckey, channeld/channeld.c:2224-2225); 0 = every row
+ * draws its key independently from the nkeys identities. */
+int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group, size_t publen,
 			  void *d_hash32, void *d_sig64, void *d_pub);
-int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys,
+int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group,
 			    void *d_msg32, void *d_xonly32, void *d_sig64);
+/* n_cann channel_announcements (432 bytes each, no features, 4 signatures, node keys drawn from
+ * n_nodes identities, bitcoin keys unique) followed by n_cupd channel_updates (138 bytes) signed by
+ * one of the referenced channel's nodes -- built and signed like devtools/mkgossip.c:131-147,235-322.
+ * d_msgs: n_cann*432 + n_cupd*138 bytes; d_node_ids33: (n_cann+n_cupd)*33 bytes (the update's signer;
+ * zero for announcements). */
+int lamd_gen_gossip_device(lamd_ctx *ctx, size_t n_cann, size_t n_cupd, uint64_t seed, size_t n_nodes,
+			   void *d_msgs, void *d_node_ids33);
 
 /* ---- device self-test: evaluates every arithmetic primitive and one full ECDSA verification of
  * the given triple both on the GPU and with the same code on the host, stage by stage.

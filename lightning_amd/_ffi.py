@@ -35,8 +35,10 @@ SYMBOLS = {
     "lamd_flush": (ctypes.c_int, [ctypes.c_void_p]),
     "lamd_poll": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
     "lamd_wait": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
-    "lamd_gen_ecdsa_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
-    "lamd_gen_schnorr_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_gen_ecdsa_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_gen_schnorr_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_gen_gossip_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz, ctypes.c_uint64, c_sz, c_u8p, c_u8p]),
+    "lamd_sigcheck_gossip_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_u8p]),
     "lamd_selftest": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, ctypes.c_char_p, c_sz]),
     "lamd_chain_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, c_sz]),
     "lamd_inv_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),

@@ -278,11 +278,17 @@ LAMD_HD sc sc_add_mod(const sc &a, const sc &b) {
   return r;
 }
 
-__global__ void __launch_bounds__(256) k_gen_ecdsa(size_t n, u64 seed, u64 nkeys, int publen, const u32 *__restrict__ gtable,
+// key of row i: rows are cut into groups of `group` consecutive rows that share one key (group = 0: every row draws its
+// key independently); the group's key index is a seeded hash modulo nkeys
+LAMD_HD u64 gen_key_index(u64 seed, u64 i, u64 nkeys, u64 group) {
+  const u64 g = group ? i / group : i;
+  return splitmix64(seed ^ splitmix64(g + (7ULL << 56))) % nkeys;
+}
+__global__ void __launch_bounds__(256) k_gen_ecdsa(size_t n, u64 seed, u64 nkeys, u64 group, int publen, const u32 *__restrict__ gtable,
                                                    u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u64 ki = splitmix64(seed ^ splitmix64(i + (7ULL << 56))) % nkeys;
+  const u64 ki = gen_key_index(seed, i, nkeys, group);
   const sc d = rand_scalar(seed, ki, 1);
   const sc k = rand_scalar(seed, i, 2);
   u32 zw[8];
@@ -308,11 +314,11 @@ __global__ void __launch_bounds__(256) k_gen_ecdsa(size_t n, u64 seed, u64 nkeys
   }
 }
 
-__global__ void __launch_bounds__(256) k_gen_schnorr(size_t n, u64 seed, u64 nkeys, const u32 *__restrict__ gtable,
+__global__ void __launch_bounds__(256) k_gen_schnorr(size_t n, u64 seed, u64 nkeys, u64 group, const u32 *__restrict__ gtable,
                                                      u8 *__restrict__ msg32, u8 *__restrict__ pk32, u8 *__restrict__ sig64) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u64 ki = splitmix64(seed ^ splitmix64(i + (7ULL << 56))) % nkeys;
+  const u64 ki = gen_key_index(seed, i, nkeys, group);
   sc d = rand_scalar(seed, ki, 1);
   sc k = rand_scalar(seed, i, 2);
   u32 mw[8];
@@ -334,6 +340,92 @@ __global__ void __launch_bounds__(256) k_gen_schnorr(size_t n, u64 seed, u64 nke
   store_words_be(pk32 + 32 * i, px);
   store_words_be(sig64 + 64 * i, rx);
   store_words_be(sig64 + 64 * i + 32, s.w);
+}
+
+// ---- synthetic gossip (shape of devtools/mkgossip.c:131-147,235-322): n_cann channel_announcements (432 B, no
+// features) followed by n_cupd channel_updates (138 B) signed by one of the referenced channel's nodes
+LAMD_HD void sign_ecdsa_words(u32 rw[8], u32 sw[8], const u32 zw[8], const sc &d, const sc &k, const u32 *gtable) {
+  u32 rx[8], ry[8];
+  gmul_affine(rx, ry, k, gtable);
+  const sc r = sc_from_words(rx, nullptr);
+  const sc z = sc_from_words(zw, nullptr);
+  sc s = sc_mul(sc_inv(k), sc_add_mod(z, sc_mul(r, d)));
+  if (sc_is_high(s)) s = sc_neg(s);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { rw[i] = r.w[i]; sw[i] = s.w[i]; }
+}
+LAMD_HD void pubkey33(u8 out[33], const sc &d, const u32 *gtable) {
+  u32 qx[8], qy[8];
+  gmul_affine(qx, qy, d, gtable);
+  out[0] = 2 + (qy[0] & 1);
+  store_words_be(out + 1, qx);
+}
+LAMD_HD void gossip_chan_nodes(u64 seed, u64 c, u64 n_nodes, u64 *a, u64 *b) {
+  *a = splitmix64(seed ^ splitmix64(c + (10ULL << 56))) % n_nodes;
+  *b = splitmix64(seed ^ splitmix64(c + (11ULL << 56))) % n_nodes;
+  if (*b == *a) *b = (*a + 1) % n_nodes;
+}
+constexpr size_t CANN_LEN = 432, CUPD_LEN = 138;
+__global__ void __launch_bounds__(256) k_gen_gossip(size_t n_cann, size_t n_cupd, u64 seed, u64 n_nodes, const u32 *__restrict__ gtable,
+                                                    u8 *__restrict__ msgs, u8 *__restrict__ ids) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cann + n_cupd) return;
+  const u8 chain[32] = {0x6f, 0xe2, 0x8c, 0x0a, 0xb6, 0xf1, 0xb3, 0x72, 0xc1, 0xa6, 0xa2, 0x46, 0xae, 0x63, 0xf7, 0x4f,
+                        0x93, 0x1e, 0x83, 0x65, 0xe1, 0x5a, 0x08, 0x9c, 0x68, 0xd6, 0x19, 0x00, 0x00, 0x00, 0x00, 0x00};
+  u8 h[32];
+  u32 zw[8], rw[8], sw[8];
+  if (i < n_cann) {
+    u8 *m = msgs + i * CANN_LEN;
+    u64 a, b;
+    gossip_chan_nodes(seed, i, n_nodes, &a, &b);
+    sc d[4] = {rand_scalar(seed, a, 1), rand_scalar(seed, b, 1), rand_scalar(seed, 2 * i, 4), rand_scalar(seed, 2 * i + 1, 4)};
+    u8 k0[33], k1[33];
+    pubkey33(k0, d[0], gtable);
+    pubkey33(k1, d[1], gtable);
+    bool swap = false;  // BOLT #7: node_id_1 is the lexicographically lesser
+    for (int j = 0; j < 33; j++)
+      if (k0[j] != k1[j]) { swap = k0[j] > k1[j]; break; }
+    if (swap) { const sc t = d[0]; d[0] = d[1]; d[1] = t; }
+    m[0] = 0x01; m[1] = 0x00;
+    u8 *tail = m + 258;
+    tail[0] = 0; tail[1] = 0;
+    for (int j = 0; j < 32; j++) tail[2 + j] = chain[j];
+    for (int j = 0; j < 8; j++) tail[34 + j] = (u8)((u64)i >> (8 * (7 - j)));
+    for (int j = 0; j < 33; j++) { tail[42 + j] = swap ? k1[j] : k0[j]; tail[75 + j] = swap ? k0[j] : k1[j]; }
+    pubkey33(tail + 108, d[2], gtable);
+    pubkey33(tail + 141, d[3], gtable);
+    sha256d_bytes(tail, CANN_LEN - 258, h);
+    load_words_be(zw, h);
+    for (int j = 0; j < 4; j++) {
+      sign_ecdsa_words(rw, sw, zw, d[j], rand_scalar(seed, 4 * i + j, 5), gtable);
+      store_words_be(m + 2 + 64 * j, rw);
+      store_words_be(m + 2 + 64 * j + 32, sw);
+    }
+    for (int j = 0; j < 33; j++) ids[i * 33 + j] = 0;
+  } else {
+    const size_t u = i - n_cann;
+    u8 *m = msgs + n_cann * CANN_LEN + u * CUPD_LEN;
+    const u64 c = splitmix64(seed ^ splitmix64(u + (12ULL << 56))) % (n_cann ? n_cann : 1);
+    u64 a, b;
+    gossip_chan_nodes(seed, c, n_nodes, &a, &b);
+    const u64 side = splitmix64(seed ^ splitmix64(u + (13ULL << 56))) & 1;
+    const sc d = rand_scalar(seed, side ? b : a, 1);
+    pubkey33(ids + i * 33, d, gtable);
+    m[0] = 0x01; m[1] = 0x02;
+    u8 *body = m + 66;
+    for (int j = 0; j < 32; j++) body[j] = chain[j];
+    for (int j = 0; j < 8; j++) body[32 + j] = (u8)(c >> (8 * (7 - j)));
+    u32 rndw[8];
+    rand_words(rndw, seed, u, 6);
+    for (int j = 0; j < 32; j++) body[40 + j] = (u8)(rndw[j >> 2] >> (8 * (j & 3)));
+    body[44] = 1;               // message_flags: option_channel_htlc_max
+    body[45] = (u8)side;        // channel_flags: direction
+    sha256d_bytes(body, CUPD_LEN - 66, h);
+    load_words_be(zw, h);
+    sign_ecdsa_words(rw, sw, zw, d, rand_scalar(seed, u, 7), gtable);
+    store_words_be(m + 2, rw);
+    store_words_be(m + 34, sw);
+  }
 }
 
 // =====================================================================================
@@ -407,7 +499,7 @@ static void release(devbuf *b) {
   b->cap = 0;
 }
 
-static constexpr size_t CHUNK = (size_t)1 << 20;  // signatures per launch (1 GiB of table slots)
+static constexpr size_t CHUNK = (size_t)1 << 22;  // signatures per launch (4 GiB of table slots at most; allocated on demand)
 
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
@@ -678,6 +770,61 @@ extern "C" int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
 }
 
 // ---- gossip
+// device core: everything resident; h_rowbase (host copy of d_rowbase) lets big batches be cut on message boundaries
+static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d_off, const u8 *d_ids, const u64 *d_rowbase,
+                         const u64 *h_rowbase, size_t rows, int8_t *d_verdict) {
+  int rc;
+  if ((rc = ensure(ctx, &ctx->g_hash, rows * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_sig, rows * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_pub, rows * 33 + 16)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_ok, rows)) != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_gossip_expand, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_msgs, d_off, d_ids, d_rowbase, (u8 *)ctx->g_hash.p,
+                     (u8 *)ctx->g_sig.p, (u8 *)ctx->g_pub.p, (u8 *)ctx->g_malformed.p);
+  HIPCHK(ctx, hipGetLastError());
+  // the rows form one ECDSA batch with 33-byte keys; every message's rows must live in one chunk because the
+  // reduce reads the chunk's key-validity bytes
+  size_t m0 = 0;
+  while (m0 < n) {
+    size_t m1 = n;
+    if (rows > CHUNK) {
+      if (!h_rowbase) {
+        ctx->err = "gossip batch larger than one chunk needs the host row table (use the host-buffer API or split the batch)";
+        return LAMD_ERR_ARG;
+      }
+      m1 = m0;
+      while (m1 < n && h_rowbase[m1 + 1] - h_rowbase[m0] <= CHUNK) m1++;
+    }
+    const size_t r0 = h_rowbase ? h_rowbase[m0] : 0, nr = (h_rowbase ? h_rowbase[m1] : rows) - r0;
+    rc = run_chunk(ctx, MODE_ECDSA, nr, (const u8 *)ctx->g_hash.p + 32 * r0, (const u8 *)ctx->g_sig.p + 64 * r0,
+                   (const u8 *)ctx->g_pub.p + 33 * r0, 33, 33, (u8 *)ctx->g_ok.p + r0, ctx->timing && m1 == n);
+    if (rc != LAMD_OK) return rc;
+    hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(m1 - m0)), dim3(256), 0, ctx->stream, m1 - m0, d_msgs, d_off + m0, d_rowbase + m0,
+                       (const u8 *)ctx->g_ok.p, (const u8 *)ctx->keyok.p - r0, (const u8 *)ctx->g_malformed.p + m0, d_verdict + m0);
+    HIPCHK(ctx, hipGetLastError());
+    m0 = m1;
+  }
+  return LAMD_OK;
+}
+
+extern "C" int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_off, const void *d_node_ids33,
+                                                 const void *d_rowbase, size_t rows, void *d_verdict) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!d_msgs || !d_off || !d_rowbase || !d_verdict || rows == 0) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if (!d_node_ids33) {  // the expand kernel never dereferences it without a channel_update, but keep the pointer valid
+    if ((rc = ensure(ctx, &ctx->g_ids, 64)) != LAMD_OK) return rc;
+    d_node_ids33 = ctx->g_ids.p;
+  }
+  return gossip_device(ctx, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, nullptr, rows,
+                       (int8_t *)d_verdict);
+}
+
 extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, const uint64_t *off,
                                           const uint8_t *node_ids33, int8_t *verdict) {
   if (!ctx) return LAMD_ERR_ARG;
@@ -688,7 +835,7 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // host framing pass: signature rows per message (4 for channel_announcement, 1 otherwise)
-  std::vector<u64> rowbase(n + 1);
+  std::vector<u64> rowbase(n + 1), rel(n + 1);
   u64 rows = 0;
   bool need_ids = false;
   for (size_t i = 0; i < n; i++) {
@@ -709,51 +856,15 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
   if ((rc = ensure(ctx, &ctx->g_off, (n + 1) * 8)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_ids, n * 33)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_rowbase, (n + 1) * 8)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->g_hash, rows * 32)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->g_sig, rows * 64)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->g_pub, rows * 33 + 16)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->g_ok, rows)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_verdict, n)) != LAMD_OK) return rc;
-  std::vector<u64> rel(n + 1);
   for (size_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
   HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, msgs + off[0], total, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->g_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->g_rowbase.p, rowbase.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if (node_ids33) HIPCHK(ctx, hipMemcpyAsync(ctx->g_ids.p, node_ids33, n * 33, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_gossip_expand, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p,
-                     (const u64 *)ctx->g_off.p, (const u8 *)ctx->g_ids.p, (const u64 *)ctx->g_rowbase.p, (u8 *)ctx->g_hash.p,
-                     (u8 *)ctx->g_sig.p, (u8 *)ctx->g_pub.p, (u8 *)ctx->g_malformed.p);
-  HIPCHK(ctx, hipGetLastError());
-  // the rows form one ECDSA batch with 33-byte keys; keyok of the last chunk must survive for the reduce, so the
-  // gossip path runs the whole batch as one chunk sequence and reduces per chunk-aligned message ranges
-  if (rows > CHUNK) {
-    // split on message boundaries so that every message's rows live in one chunk
-    size_t m0 = 0;
-    while (m0 < n) {
-      size_t m1 = m0;
-      while (m1 < n && rowbase[m1 + 1] - rowbase[m0] <= CHUNK) m1++;
-      const size_t r0 = rowbase[m0], nr = rowbase[m1] - r0;
-      rc = run_chunk(ctx, MODE_ECDSA, nr, (const u8 *)ctx->g_hash.p + 32 * r0, (const u8 *)ctx->g_sig.p + 64 * r0,
-                     (const u8 *)ctx->g_pub.p + 33 * r0, 33, 33, (u8 *)ctx->g_ok.p + r0, false);
-      if (rc != LAMD_OK) return rc;
-      // keyok is indexed from the chunk start: hand the reduce kernel pointers rebased to row r0
-      hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(m1 - m0)), dim3(256), 0, ctx->stream, m1 - m0,
-                         (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p + m0, (const u64 *)ctx->g_rowbase.p + m0,
-                         (const u8 *)ctx->g_ok.p, (const u8 *)ctx->keyok.p - r0, (const u8 *)ctx->g_malformed.p + m0,
-                         (int8_t *)ctx->g_verdict.p + m0);
-      HIPCHK(ctx, hipGetLastError());
-      m0 = m1;
-    }
-  } else {
-    rc = run_chunk(ctx, MODE_ECDSA, rows, (const u8 *)ctx->g_hash.p, (const u8 *)ctx->g_sig.p, (const u8 *)ctx->g_pub.p, 33, 33,
-                   (u8 *)ctx->g_ok.p, false);
-    if (rc != LAMD_OK) return rc;
-    hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p,
-                       (const u64 *)ctx->g_off.p, (const u64 *)ctx->g_rowbase.p, (const u8 *)ctx->g_ok.p,
-                       (const u8 *)ctx->keyok.p, (const u8 *)ctx->g_malformed.p, (int8_t *)ctx->g_verdict.p);
-    HIPCHK(ctx, hipGetLastError());
-  }
+  rc = gossip_device(ctx, n, (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p, (const u8 *)ctx->g_ids.p, (const u64 *)ctx->g_rowbase.p,
+                     rowbase.data(), rows, (int8_t *)ctx->g_verdict.p);
+  if (rc != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(verdict, ctx->g_verdict.p, n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return LAMD_OK;
@@ -1222,7 +1333,7 @@ extern "C" int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap) {
 }
 
 // ---- synthetic workloads
-extern "C" int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t publen, void *d_hash32,
+extern "C" int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group, size_t publen, void *d_hash32,
                                      void *d_sig64, void *d_pub) {
   if (!ctx) return LAMD_ERR_ARG;
   if (!d_hash32 || !d_sig64 || !d_pub || (publen != 33 && publen != 65) || nkeys == 0) {
@@ -1231,13 +1342,13 @@ extern "C" int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, siz
   }
   if (n == 0) return LAMD_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_gen_ecdsa, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys, (int)publen,
-                     (const u32 *)ctx->gtable, (u8 *)d_hash32, (u8 *)d_sig64, (u8 *)d_pub);
+  hipLaunchKernelGGL(k_gen_ecdsa, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys, (u64)group,
+                     (int)publen, (const u32 *)ctx->gtable, (u8 *)d_hash32, (u8 *)d_sig64, (u8 *)d_pub);
   HIPCHK(ctx, hipGetLastError());
   return LAMD_OK;
 }
-extern "C" int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, void *d_msg32, void *d_xonly32,
-                                       void *d_sig64) {
+extern "C" int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group, void *d_msg32,
+                                       void *d_xonly32, void *d_sig64) {
   if (!ctx) return LAMD_ERR_ARG;
   if (!d_msg32 || !d_xonly32 || !d_sig64 || nkeys == 0) {
     ctx->err = "bad argument";
@@ -1245,8 +1356,22 @@ extern "C" int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, s
   }
   if (n == 0) return LAMD_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_gen_schnorr, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys,
+  hipLaunchKernelGGL(k_gen_schnorr, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys, (u64)group,
                      (const u32 *)ctx->gtable, (u8 *)d_msg32, (u8 *)d_xonly32, (u8 *)d_sig64);
+  HIPCHK(ctx, hipGetLastError());
+  return LAMD_OK;
+}
+extern "C" int lamd_gen_gossip_device(lamd_ctx *ctx, size_t n_cann, size_t n_cupd, uint64_t seed, size_t n_nodes, void *d_msgs,
+                                      void *d_node_ids33) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!d_msgs || !d_node_ids33 || n_nodes < 2 || (n_cupd && !n_cann)) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  if (n_cann + n_cupd == 0) return LAMD_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_gen_gossip, dim3(blocks_for(n_cann + n_cupd)), dim3(256), 0, ctx->stream, n_cann, n_cupd, (u64)seed, (u64)n_nodes,
+                     (const u32 *)ctx->gtable, (u8 *)d_msgs, (u8 *)d_node_ids33);
   HIPCHK(ctx, hipGetLastError());
   return LAMD_OK;
 }

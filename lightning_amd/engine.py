@@ -153,13 +153,21 @@ class Engine:
         self._chk(self._lib.lamd_verify_schnorr_batch_device(self._ctx, n, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr(),
                                                              d_ok.data_ptr()))
 
-    def gen_ecdsa_device(self, seed, nkeys, d_hash, d_sig, d_pub):
+    def gen_ecdsa_device(self, seed, nkeys, d_hash, d_sig, d_pub, group=0):
         n, publen = d_pub.shape
-        self._chk(self._lib.lamd_gen_ecdsa_device(self._ctx, n, seed, nkeys, publen, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr()))
+        self._chk(self._lib.lamd_gen_ecdsa_device(self._ctx, n, seed, nkeys, group, publen, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr()))
 
-    def gen_schnorr_device(self, seed, nkeys, d_msg, d_xonly, d_sig):
+    def gen_schnorr_device(self, seed, nkeys, d_msg, d_xonly, d_sig, group=0):
         n = d_msg.shape[0]
-        self._chk(self._lib.lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
+        self._chk(self._lib.lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, group, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
+
+    def gen_gossip_device(self, seed, n_cann, n_cupd, n_nodes, d_msgs, d_ids):
+        self._chk(self._lib.lamd_gen_gossip_device(self._ctx, n_cann, n_cupd, seed, n_nodes, d_msgs.data_ptr(), d_ids.data_ptr()))
+
+    def sigcheck_gossip_device(self, n, d_msgs, d_off, d_ids, d_rowbase, rows, d_verdict):
+        self._chk(self._lib.lamd_sigcheck_gossip_batch_device(self._ctx, n, d_msgs.data_ptr(), d_off.data_ptr(),
+                                                              d_ids.data_ptr() if d_ids is not None else None, d_rowbase.data_ptr(), rows,
+                                                              d_verdict.data_ptr()))
 
     def selftest(self, hash32, sig64, pub33):
         buf = ctypes.create_string_buffer(4096)

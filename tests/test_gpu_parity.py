@@ -213,3 +213,94 @@ def test_repeated_keys_and_identical_rows(eng, kat):
     hs[1::2, 7] ^= 1
     got = eng.verify_ecdsa(hs, sg, pk)
     assert got[0::2].all() and not got[1::2].any()
+
+
+def test_cfg4_gossip_replay_small_vs_oracle_and_construction(eng, orc):
+    """BASELINE configs[3] at a size the oracle finishes in seconds: device-built channel_announcements (4 signatures)
+    + channel_updates, 1 % corrupted; per-message verdict = first bad signature"""
+    from lightning_amd import workload
+    w = workload.make_gossip(eng, 600, 2400, n_nodes=50, corrupt_frac=0.05)
+    eng.sigcheck_gossip_device(w.n, w.d_msgs, w.d_off, w.d_ids, w.d_rowbase, w.rows, w.d_verdict)
+    eng.synchronize()
+    got = w.d_verdict.cpu().numpy()
+    assert np.array_equal(got, w.expect), np.nonzero(got != w.expect)[0][:10]
+    assert (w.expect != 0).sum() == 150 and set(np.unique(w.expect[:600])) == {0, 1, 2, 3, 4}
+    # host-buffer API on the same bytes, and the CPU oracle on every message
+    msgs = [w.msgs[int(w.off[i]):int(w.off[i + 1])].tobytes() for i in range(w.n)]
+    ids = [w.ids[i].tobytes() if i >= w.n_cann else None for i in range(w.n)]
+    assert np.array_equal(eng.sigcheck_gossip(msgs, ids), w.expect)
+    for i in list(range(0, 600, 7)) + list(range(600, 3000, 13)):
+        exp = orc.sigcheck_channel_announcement(msgs[i]) if i < 600 else orc.sigcheck_channel_update(msgs[i], ids[i])
+        assert exp == w.expect[i], i
+    # reference framing: 432-byte announcement, 138-byte update with a 72-byte signed region (wire/peer_wire.csv:344-381)
+    assert len(msgs[0]) == 432 and len(msgs[-1]) == 138 and msgs[0][:2] == b"\x01\x00" and msgs[-1][:2] == b"\x01\x02"
+
+
+def test_cfg4_full_size_properties(eng, orc):
+    """500 k channel_announcements + 2 M channel_updates = 4 M verifies on one GPU: every untouched message verifies,
+    every corrupted one reports exactly the corrupted signature; an oracle sample agrees"""
+    from lightning_amd import workload
+    w = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, corrupt_frac=0.01)
+    assert w.rows == 4_000_000 and w.msgs.nbytes - 64 == 500_000 * 432 + 2_000_000 * 138
+    eng.sigcheck_gossip_device(w.n, w.d_msgs, w.d_off, w.d_ids, w.d_rowbase, w.rows, w.d_verdict)
+    eng.synchronize()
+    got = w.d_verdict.cpu().numpy()
+    assert np.array_equal(got, w.expect), (np.nonzero(got != w.expect)[0][:10])
+    assert (got != 0).sum() == 25_000
+    rnd = random.Random(4)
+    for i in [rnd.randrange(w.n) for _ in range(300)] + list(np.nonzero(w.expect)[0][:100]):
+        m = w.msgs[int(w.off[i]):int(w.off[i + 1])].tobytes()
+        exp = orc.sigcheck_channel_announcement(m) if i < w.n_cann else orc.sigcheck_channel_update(m, w.ids[i].tobytes())
+        assert exp == got[i], i
+
+
+def test_cfg5_commit_storm_streaming_batches(eng, orc):
+    """BASELINE configs[4] shape: per channel 1 commitment signature + 483 HTLC signatures under one shared key,
+    every 4th channel BIP-340, streamed as 484-row batches through the queue API; verdicts in ticket order"""
+    from lightning_amd import workload
+    st = workload.make_commit_storm(eng, 12, corrupt_frac=0.01)
+    per = st["per"]
+    assert per == 484 and list(st["kinds"]) == [0, 0, 0, 1] * 3
+    we, ws = st["ecdsa"], st["schnorr"]
+    # HTLC rows of a channel share the key, the commitment row has its own (channeld/channeld.c:2171,2224-2225)
+    pk = we.cols[2].reshape(-1, per, 33)
+    assert (pk[:, 1:, :] == pk[:, 1:2, :]).all() and not (pk[:, 0, :] == pk[:, 1, :]).all(axis=1).any()
+    ie = isx = 0
+    for c, kind in enumerate(st["kinds"]):
+        if kind == 0:
+            sl = slice(ie * per, (ie + 1) * per)
+            for i in range(sl.start, sl.stop):
+                eng.queue_ecdsa(we.cols[0][i].tobytes(), we.cols[1][i].tobytes(), we.cols[2][i].tobytes())
+            eng.flush()
+            got = eng.wait()
+            assert np.array_equal(got, we.expect[sl]), c
+            exp = orc.ecdsa_verify_batch(np.ascontiguousarray(we.cols[0][sl]), np.ascontiguousarray(we.cols[1][sl]),
+                                         np.ascontiguousarray(we.cols[2][sl]), 33, 4).astype(bool)
+            assert np.array_equal(got, exp)
+            ie += 1
+        else:
+            sl = slice(isx * per, (isx + 1) * per)
+            for i in range(sl.start, sl.stop):
+                eng.queue_schnorr(ws.cols[0][i].tobytes(), ws.cols[1][i].tobytes(), ws.cols[2][i].tobytes())
+            eng.flush()
+            got = eng.wait()
+            assert np.array_equal(got, ws.expect[sl]), c
+            exp = orc.schnorr_verify_batch(np.ascontiguousarray(ws.cols[0][sl]), np.ascontiguousarray(ws.cols[1][sl]),
+                                           np.ascontiguousarray(ws.cols[2][sl]), 4).astype(bool)
+            assert np.array_equal(got, exp)
+            isx += 1
+    assert (~we.expect).sum() + (~ws.expect).sum() > 0
+
+
+def test_cfg5_full_size_properties(eng):
+    """10 000 channels x 484 = 4.84 M verifies in super-batches: sign->verify round trip, corrupted rows rejected"""
+    from lightning_amd import workload
+    st = workload.make_commit_storm(eng, 10_000)
+    we, ws = st["ecdsa"], st["schnorr"]
+    assert we.n + ws.n == 4_840_000
+    eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
+    eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
+    eng.synchronize()
+    assert np.array_equal(we.d_ok.cpu().numpy().astype(bool), we.expect)
+    assert np.array_equal(ws.d_ok.cpu().numpy().astype(bool), ws.expect)
+    assert (~we.expect).sum() + (~ws.expect).sum() == int(we.n * 0.001) + int(ws.n * 0.001)
