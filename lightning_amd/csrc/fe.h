@@ -184,63 +184,98 @@ LAMD_HD fe fe_select(bool take_a, const fe &a, const fe &b) {
   return r;
 }
 
-// ---- shared reduction: 17 product columns (+ c[17] = 0 on entry) -> magnitude-1 field element
-LAMD_HD fe fe_reduce_columns(u64 c[18]) {
-  // 1. split the high half into 29-bit limbs
-#pragma unroll
-  for (int k = 9; k < 17; k++) {
-    c[k + 1] += c[k] >> 29;
-    c[k] &= FE_M29;
-  }
-  // 2. fold limb k (weight 2^(29k), k >= 9) onto limbs k-9, k-8 with 2^261 = 31264 + 256*2^29 (mod p)
-  c[8] += c[17] * (u64)FE_R0;     // c[17] <= 2^35
-  c[9] += c[17] << FE_R1_SHIFT;                                       // c[9] <= 2^29 + 2^43
-  c[0] += c[9] * FE_R0;                                               // <= 2^59
-  c[1] += c[9] << FE_R1_SHIFT;
-#pragma unroll
-  for (int k = 10; k < 17; k++) {
-    c[k - 9] += (u64)(u32)c[k] * FE_R0;
-    c[k - 8] += c[k] << FE_R1_SHIFT;
-  }
-  // 3. carry the low half
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    c[k + 1] += c[k] >> 29;
-    c[k] &= FE_M29;
-  }
-  // 4. bits >= 256 of the top limb: 2^256 = 2^32 + 977 = 977 + 8*2^29
-  const u64 e = c[8] >> 24;  // <= 2^40
-  c[8] &= FE_M24;
-  c[0] += e * 977u;
-  c[1] += e << 3;
-  c[1] += c[0] >> 29; c[0] &= FE_M29;
-  c[2] += c[1] >> 29; c[1] &= FE_M29;
-  c[3] += c[2] >> 29; c[2] &= FE_M29;
-  fe r;
-#pragma unroll
-  for (int k = 0; k < 9; k++) r.n[k] = (u32)c[k];
-  FE_SETMAG(r, 1);
-  fe_verify(r);
+// acc += a*b as ONE v_mad_u64_u32 whose 64-bit addend is the running accumulator.  Written as inline asm on
+// the device because hipcc re-associates a C sum of products into "independent column sum, then a separate
+// 64-bit add of the carry" (v_lshl_add_u64, another half-rate issue slot per column); the asm pins the chain.
+// (No builtin exists for this instruction; the carry-out SGPR pair is a dead output, exactly as in hipcc's own
+// code.)  Host builds use the plain C expression.
+LAMD_HD void fe_mac(u64 &acc, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
+#else
+  acc += (u64)a * b;
+#endif
+}
+// same with a small compile-time constant multiplier held in an SGPR
+LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 cy;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "s"(k));
+#else
+  acc += (u64)a * k;
+#endif
+}
+
+// Multiplication / squaring with RUNNING carries: a column's 64-bit sum, shifted right by 29, is the addend of
+// the next column's first multiply-add, so a carry costs one 64-bit shift and one mask per column and no
+// additions.  Two chains run skewed by one column so they can overlap:
+//   high chain  columns 9..16 -> limbs H[9..16] (29 bit each); its last carry is H[17] (<= 2^35)
+//   low chain   columns 0..8; limb H[p] (weight 2^(29p) = 2^(29(p-9)) * 2^261, and 2^261 = R0 + 2^8 * 2^29 mod p)
+//               joins column p-9 as R0*H[p] and column p-8 as 2^8*H[p] -- two more multiply-adds in those chains
+//   tail        H[17] is only known when the high chain ends: its column-8 term (R0*H[17]) joins the last low
+//               column; its column-9 term 2^8*H[17]*2^261 folds once more into limbs 0 and 1 together with the
+//               bits >= 2^256 of column 8 (2^256 = 977 + 8 * 2^29), followed by a three-limb carry
+// PROD(k, acc) must add the partial products of column k into acc with fe_mac().
+#define LAMD_FE_COLUMNS(PROD)                                                                       \
+  u32 h[8];                                                                                         \
+  fe r;                                                                                             \
+  u64 hi = 0, lo = 0;                                                                               \
+  PROD(9, hi);                                                                                      \
+  h[0] = (u32)hi & FE_M29;                                                                          \
+  hi >>= 29;                                                                                        \
+  _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                   \
+    if (k < 7) {                                                                                    \
+      PROD(10 + k, hi);                                                                             \
+      h[k + 1] = (u32)hi & FE_M29;                                                                  \
+      hi >>= 29;                                                                                    \
+    }                                                                                               \
+    PROD(k, lo);                                                                                    \
+    fe_mac_k(lo, h[k], FE_R0);                                                                      \
+    if (k > 0) fe_mac_k(lo, h[k - 1], 1u << FE_R1_SHIFT);                                           \
+    r.n[k] = (u32)lo & FE_M29;                                                                      \
+    lo >>= 29;                                                                                      \
+  }                                                                                                 \
+  const u64 h17 = hi;                                     /* <= 2^35 */                             \
+  PROD(8, lo);                                                                                      \
+  fe_mac_k(lo, h[7], 1u << FE_R1_SHIFT);                                                            \
+  lo += h17 * FE_R0;                                                                                \
+  r.n[8] = (u32)lo & FE_M24;                                                                        \
+  const u64 e = lo >> 24;                                 /* <= 2^40 */                             \
+  u64 t = (u64)r.n[0] + e * 977u + h17 * ((u64)FE_R0 << FE_R1_SHIFT);                                \
+  r.n[0] = (u32)t & FE_M29;                                                                         \
+  t = (t >> 29) + (u64)r.n[1] + (e << 3) + (h17 << (2 * FE_R1_SHIFT));                               \
+  r.n[1] = (u32)t & FE_M29;                                                                         \
+  t = (t >> 29) + (u64)r.n[2];                                                                      \
+  r.n[2] = (u32)t & FE_M29;                                                                         \
+  r.n[3] += (u32)(t >> 29);                                                                         \
+  FE_SETMAG(r, 1);                                                                                  \
+  fe_verify(r);                                                                                     \
   return r;
+
+LAMD_HD void fe_mul_col(const fe &a, const fe &b, int k, u64 &acc) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int j = k - i;
+    if (j < 0 || j > 8) continue;
+    fe_mac(acc, a.n[i], b.n[j]);
+  }
+}
+LAMD_HD void fe_sqr_col(const fe &a, const u32 d[9], int k, u64 &acc) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int j = k - i;
+    if (j < 0 || j > 8 || i > j) continue;
+    fe_mac(acc, (i == j) ? a.n[i] : d[i], a.n[j]);
+  }
 }
 
 // r = a*b; requires mag(a)*mag(b) <= 7
 LAMD_HD fe fe_mul(const fe &a, const fe &b) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7);
-  u64 c[18];
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j < 0 || j > 8) continue;
-      s += (u64)a.n[i] * b.n[j];
-    }
-    c[k] = s;
-  }
-  c[17] = 0;
-  return fe_reduce_columns(c);
+#define LAMD_P(k, acc) fe_mul_col(a, b, k, acc)
+  LAMD_FE_COLUMNS(LAMD_P)
+#undef LAMD_P
 }
 
 // r = a^2; requires mag(a) <= 2
@@ -249,20 +284,9 @@ LAMD_HD fe fe_sqr(const fe &a) {
   u32 d[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
-  u64 c[18];
-#pragma unroll
-  for (int k = 0; k < 17; k++) {
-    u64 s = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      const int j = k - i;
-      if (j < 0 || j > 8 || i > j) continue;
-      s += (i == j) ? (u64)a.n[i] * a.n[i] : (u64)d[i] * a.n[j];
-    }
-    c[k] = s;
-  }
-  c[17] = 0;
-  return fe_reduce_columns(c);
+#define LAMD_P(k, acc) fe_sqr_col(a, d, k, acc)
+  LAMD_FE_COLUMNS(LAMD_P)
+#undef LAMD_P
 }
 
 LAMD_HD fe fe_sqr_n(fe a, int n) {

@@ -55,21 +55,17 @@ LAMD_HD gej gej_double(const gej &a) {
   return r;
 }
 
-// Result of the generic part of a mixed addition, plus what the caller must do if degenerate.
-enum { ADD_OK = 0, ADD_DOUBLE = 1, ADD_INFINITY = 2 };
-
 // r = a + b for Jacobian a (not infinity) and affine b, assuming a != +-b; 8M + 3S.
-// *status reports the degenerate cases (r is then garbage); *h_out = H with Z3 = Z1*H.
-LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, int *status, fe *h_out) {
+// *degenerate = (H == 0): a = +-b and r is garbage -- then *rr_out == 0 tells P + P from P + (-P) (tested by the
+// caller on its cold path only); *h_out = H with Z3 = Z1*H.
+LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, bool *degenerate, fe *h_out, fe *rr_out) {
   gej r;
   const fe zz = fe_sqr(a.z);
   const fe u2 = fe_mul(b.x, zz);
   const fe s2 = fe_mul(b.y, fe_mul(a.z, zz));
   const fe h = fe_norm_weak(fe_add(u2, fe_neg(a.x, 1)));
   const fe rr = fe_norm_weak(fe_add(s2, fe_neg(a.y, 1)));
-  const bool hz = fe_is_zero(h);
-  const bool rz = fe_is_zero(rr);
-  *status = hz ? (rz ? ADD_DOUBLE : ADD_INFINITY) : ADD_OK;
+  *degenerate = fe_is_zero(h);
   const fe hh = fe_sqr(h);
   const fe hhh = fe_mul(h, hh);
   const fe v = fe_mul(a.x, hh);
@@ -79,6 +75,7 @@ LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, int *status, fe *h_out) {
   r.z = fe_mul(a.z, h);
   r.inf = false;
   *h_out = h;
+  *rr_out = rr;
   return r;
 }
 
@@ -94,11 +91,11 @@ LAMD_HD gej gej_select(bool take_a, const gej &a, const gej &b) {
 // Complete mixed addition with a lane predicate: r = skip ? a : a + b.  The degenerate outcomes
 // are handled under a divergent branch that is never taken on honest inputs.
 LAMD_HD gej gej_add_ge(const gej &a, const ge &b, bool skip) {
-  int st;
-  fe h;
-  gej r = gej_add_ge_core(a, b, &st, &h);
-  if (__builtin_expect(!skip && !a.inf && st != ADD_OK, 0)) {
-    if (st == ADD_DOUBLE) {
+  bool degenerate;
+  fe h, rr;
+  gej r = gej_add_ge_core(a, b, &degenerate, &h, &rr);
+  if (__builtin_expect(!skip && !a.inf && degenerate, 0)) {
+    if (fe_is_zero(rr)) {
       r = gej_double(gej_from_ge(b));
     } else {
       r = gej_infinity();

@@ -96,9 +96,21 @@ __global__ void __launch_bounds__(256) k_ecmult(size_t n, const prep_rec *__rest
     const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slots + i * SLOT_WORDS, gtable);
     u32 rw[8];
     load_words_be(rw, sig64 + 64 * i);
-    ok = (mode == MODE_ECDSA) ? ecdsa_final(R, rw) : schnorr_final(R, rw);
+    if (mode == MODE_ECDSA) {
+      ok = ecdsa_final(R, rw);
+    } else {
+      out[i] = schnorr_stage1(R, rw, slots + i * SLOT_WORDS);  // 0 or SCHNORR_PENDING (parity decided by k_schnorr_final)
+      return;
+    }
   }
   out[i] = ok ? 1 : 0;
+}
+
+// ---- BIP-340 stage 2: shared inversion for the y-parity test
+__global__ void __launch_bounds__(256) k_schnorr_final(size_t n, u32 *__restrict__ slots, u8 *__restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  schnorr_final_thread(tid, T, n, slots, out);
 }
 
 // ---- gossip: per message, double-SHA256 of the signed tail and expansion into (hash, sig, key) rows
@@ -632,8 +644,14 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   hipLaunchKernelGGL(k_ecmult, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->qwords.p,
                      (const u8 *)ctx->keyok.p, d_sig, mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, d_ok);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  if (mode == MODE_SCHNORR) {
+    size_t threads = (n + 15) / 16;
+    const size_t min_threads = (size_t)ctx->prop.multiProcessorCount * 256;
+    if (threads < min_threads) threads = n < min_threads ? n : min_threads;
+    hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
+  }
   if (time_it) {
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     ctx->ev_recorded = true;
   }

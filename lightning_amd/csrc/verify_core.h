@@ -227,9 +227,9 @@ LAMD_HD fe build_q_table(u32 *slot, const ge &q) {
   slot_store_fe(slot + SLOT_ENTRY_WORDS + 16, p.y);
 #pragma unroll 1
   for (int i = 2; i < 8; i++) {  // entry i = (i+1)Q = entry(i-1) + Q
-    int st;
-    fe h;
-    p = gej_add_ge_core(p, q, &st, &h);  // (i)Q = +-Q is impossible for i in 2..8: no degenerate case
+    bool degenerate;
+    fe h, rr;
+    p = gej_add_ge_core(p, q, &degenerate, &h, &rr);  // (i)Q = +-Q is impossible for i in 2..8: no degenerate case
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, p.x);
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, p.y);
     slot_store_fe(slot + SLOT_H_OFF + (i - 2) * 8, h);
@@ -348,7 +348,64 @@ LAMD_HD bool ecdsa_final(const gej &R, const u32 rw[8]) {
   return ok;
 }
 
-// BIP-340 acceptance: R != inf, y(R) even, x(R) == r
+// BIP-340 acceptance, split so that the one field inversion it needs (y = Y/Z^3 for the parity test) can be shared:
+//   stage 1 (per lane, in the ecmult kernel): R != inf and x(R) == r tested as r*Z^2 == X; survivors park Y and Z
+//            (raw limbs) in their table slot and report SCHNORR_PENDING
+//   stage 2 (k_schnorr_final): a thread owns signatures i, i+T, ... and inverts all their pending Z with ONE
+//            inversion (Montgomery's trick), then tests the parity of Y * Z^-3
+constexpr u8 SCHNORR_PENDING = 2;
+constexpr int SLOT_FIN_Y = 0, SLOT_FIN_Z = 9, SLOT_FIN_PREFIX = 18;  // word offsets inside the lane's slot
+
+LAMD_HD u8 schnorr_stage1(const gej &R, const u32 rw[8], u32 *slot) {
+  if (R.inf) return 0;
+  const fe z2 = fe_sqr(R.z);
+  const fe rf = fe_from_words(rw);  // r < p checked in prep
+  if (!fe_equal(fe_mul(rf, z2), R.x, 1)) return 0;
+  const fe z = fe_norm_weak(R.z);
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    slot[SLOT_FIN_Y + i] = R.y.n[i];
+    slot[SLOT_FIN_Z + i] = z.n[i];
+  }
+  return SCHNORR_PENDING;
+}
+LAMD_HD fe slot_load_raw(const u32 *src) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = src[i];
+  FE_SETMAG(r, 1);
+  return r;
+}
+LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *slots, u8 *out) {
+  fe acc = fe_set_int(1);
+  size_t last = first;
+  bool any = false;
+#pragma unroll 1
+  for (size_t i = first; i < n; i += stride) {
+    if (out[i] != SCHNORR_PENDING) continue;
+    u32 *slot = slots + i * SLOT_WORDS;
+#pragma unroll
+    for (int k = 0; k < 9; k++) slot[SLOT_FIN_PREFIX + k] = acc.n[k];  // product of the pending Z before i
+    acc = fe_mul(acc, slot_load_raw(slot + SLOT_FIN_Z));
+    last = i;
+    any = true;
+  }
+  if (!any) return;
+  fe inv = fe_inv(acc);
+#pragma unroll 1
+  for (size_t i = last;; i -= stride) {
+    if (out[i] == SCHNORR_PENDING) {
+      const u32 *slot = slots + i * SLOT_WORDS;
+      const fe zi = fe_mul(inv, slot_load_raw(slot + SLOT_FIN_PREFIX));
+      inv = fe_mul(inv, slot_load_raw(slot + SLOT_FIN_Z));
+      const fe y = fe_normalize(fe_mul(slot_load_raw(slot + SLOT_FIN_Y), fe_mul(fe_sqr(zi), zi)));
+      out[i] = (y.n[0] & 1) == 0;
+    }
+    if (i == first) break;
+  }
+}
+
+// BIP-340 acceptance in one piece (single-lane form used by the self-test): R != inf, y(R) even, x(R) == r
 LAMD_HD bool schnorr_final(const gej &R, const u32 rw[8]) {
   if (R.inf) return false;
   const fe z2 = fe_sqr(R.z);

@@ -100,6 +100,25 @@ void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8
     out[i] = ok;
   }
 }
+// two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
+void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {
+  dm_init();
+  std::vector<u32> slots(n * SLOT_WORDS);
+  for (size_t i = 0; i < n; i++) {
+    prep_rec rec;
+    schnorr_prep_one(msg32 + 32 * i, pk32 + 32 * i, sig64 + 64 * i, &rec);
+    u32 qx[8], qy[8], rw[8];
+    bool ok = parse_pubkey(pk32 + 32 * i, 32, qx, qy);
+    ok &= (rec.flags & PREP_VALID) != 0;
+    out[i] = 0;
+    if (ok) {
+      const gej R = ecmult_lane(rec, ge_from_words(qx, qy), &slots[i * SLOT_WORDS], g_table.data());
+      be_to_words(rw, sig64 + 64 * i);
+      out[i] = schnorr_stage1(R, rw, &slots[i * SLOT_WORDS]);
+    }
+  }
+  for (size_t t = 0; t < threads; t++) schnorr_final_thread(t, threads, n, slots.data(), out);
+}
 void dm_schnorr_verify_batch(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out) {
   dm_init();
   std::vector<u32> slot(SLOT_WORDS);

@@ -235,6 +235,12 @@ def test_pipeline_golden_schnorr(dm, kat):
                                b"".join(H(v["sig"]) for v in rows), out)
     bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
     assert not bad, bad[:10]
+    # the two-stage form the kernels use (stage 1 in the ecmult kernel, shared inversion in k_schnorr_final)
+    for threads in (1, 5, n):
+        out2 = ctypes.create_string_buffer(n)
+        dm.dm_schnorr_verify_batch2(ctypes.c_size_t(n), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["pk"]) for v in rows),
+                                    b"".join(H(v["sig"]) for v in rows), out2, ctypes.c_size_t(threads))
+        assert out2.raw == out.raw, threads
 
 
 def test_pipeline_random_vs_oracle(dm, orc):
