@@ -74,16 +74,21 @@ def main():
     ok_all_s = torch.zeros(world * n, dtype=torch.uint8, device=device) if world > 1 else None
 
     kernel_ms = {"ecdsa": [], "schnorr": []}
+    keyed = {}
 
     def step(record):
         eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
         if record:
             eng.synchronize()
-            kernel_ms["ecdsa"].append(eng.info()["last_kernel_ms"][:3])
+            inf = eng.info()
+            kernel_ms["ecdsa"].append(inf["last_kernel_ms"])
+            keyed["ecdsa"] = (inf["last_keyed"], inf["last_unique_keys"])
         eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
         eng.synchronize()
         if record:
-            kernel_ms["schnorr"].append(eng.info()["last_kernel_ms"][:3])
+            inf = eng.info()
+            kernel_ms["schnorr"].append(inf["last_kernel_ms"])
+            keyed["schnorr"] = (inf["last_keyed"], inf["last_unique_keys"])
         if world > 1:  # RCCL all-gather of the boolean result vectors over xGMI
             dist.all_gather_into_tensor(ok_all_e, we.d_ok)
             dist.all_gather_into_tensor(ok_all_s, ws.d_ok)
@@ -144,9 +149,10 @@ def main():
                                    "90%% valid / 10%% invalid, inputs resident in HBM" % (n, n),
                        "rows_per_gpu_per_step": 2 * n, "parallelism": "shard-by-row x%d, RCCL all-gather of verdicts" % world},
             "rates": {"ecdsa65_verifies_per_s_1gpu": n / (ke.sum() * 1e-3), "schnorr_verifies_per_s_1gpu": n / (ks.sum() * 1e-3),
-                      "kernel_ms_ecdsa": {"prep": ke[0], "keys": ke[1], "ecmult": ke[2]},
-                      "kernel_ms_schnorr": {"prep": ks[0], "keys": ks[1], "ecmult": ks[2]}},
-            "roofline": {"kernel": "k_ecmult (ECDSA launch, %d signatures)" % n, "bound": "valu-int32-mul (not hbm, not mfma)",
+                      "kernel_ms_ecdsa": {"prep": ke[0], "keys_and_tables": ke[1], "ecmult": ke[2], "parity_stage": ke[3]},
+                      "kernel_ms_schnorr": {"prep": ks[0], "keys_and_tables": ks[1], "ecmult": ks[2], "parity_stage": ks[3]},
+                      "keyed_path": {k: {"per_key_tables": bool(v[0]), "distinct_keys": int(v[1])} for k, v in keyed.items()}},
+            "roofline": {"kernel": "%s (ECDSA launch, %d signatures)" % ("k_ecmult_keyed" if keyed.get("ecdsa", (0, 0))[0] else "k_ecmult", n), "bound": "valu-int32-mul (not hbm, not mfma)",
                          "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
                          "algorithmic_mul32_per_verify": W_ECDSA65, "avg_launch_ms": ke[2], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,

@@ -162,13 +162,21 @@ int lamd_inv_debug(lamd_ctx *ctx, char *report, size_t cap);
 
 int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 in several code shapes */
 
+/* Diagnostic: copy nbytes at offset of internal work buffer `which` (0 prep records, 1 per-row key validity,
+ * 2 dedupe representative, 3 dedupe uid, 4 key id per row, 5 first row of each distinct key, 6 distinct-key
+ * validity, 7 distinct-key affine words, 8 key tables) to host memory.  Tests only. */
+int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out);
+
 /* ---- introspection for benchmarks / tests */
 typedef struct {
 	int device;
 	int compute_units;
 	char arch[64];
 	size_t gtable_bytes;
-	double last_kernel_ms[4]; /* prep, keys, ecmult, aux of the last *_device call when timing is on */
+	double last_kernel_ms[4]; /* prep, keys (+ key tables), ecmult, BIP-340 parity stage of the last launch sequence when timing is on */
+	size_t last_unique_keys;  /* distinct public keys found in the last chunk (0 if it was not examined) */
+	int last_keyed;           /* 0: per-signature ladder; else the last chunk ran on per-key tables and this is the comb
+				   * spacing used (1 = one position per nibble, 8 = five positions) */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */

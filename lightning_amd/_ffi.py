@@ -10,7 +10,8 @@ c_sz = ctypes.c_size_t
 
 class LamdInfo(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("arch", ctypes.c_char * 64),
-                ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4)]
+                ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4), ("last_unique_keys", ctypes.c_size_t),
+                ("last_keyed", ctypes.c_int)]
 
 
 # name -> (restype, argtypes); every symbol of include/lightning_amd.h
@@ -43,6 +44,7 @@ SYMBOLS = {
     "lamd_chain_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, c_sz]),
     "lamd_inv_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_x2_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
+    "lamd_debug_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_sz, c_sz, c_u8p]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
 }

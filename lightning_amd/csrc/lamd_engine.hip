@@ -69,8 +69,10 @@ __global__ void __launch_bounds__(256) k_keys(size_t n, const u8 *__restrict__ p
   keyok[i] = ok;
 }
 
-// ---- the hot kernel: R = u1*G + u2*Q and the acceptance test
-__global__ void __launch_bounds__(256) k_ecmult(size_t n, const prep_rec *__restrict__ recs, const u32 *__restrict__ qwords,
+// ---- the hot kernel: R = u1*G + u2*Q and the acceptance test.  WAVES = minimum waves per SIMD the register
+// allocator must leave room for (2nd __launch_bounds__ argument); the engine picks the instantiation (LAMD_ECMULT_WAVES).
+template <int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec *__restrict__ recs, const u32 *__restrict__ qwords,
                                                 const u8 *__restrict__ keyok, const u8 *__restrict__ sig64, int mode,
                                                 const u32 *__restrict__ gtable, u32 *__restrict__ slots,
                                                 u8 *__restrict__ out) {
@@ -440,6 +442,110 @@ __global__ void __launch_bounds__(256) k_gen_gossip(size_t n_cann, size_t n_cupd
   }
 }
 
+// ---- keyed path kernels (see verify_core.h "Keyed path")
+LAMD_HD u64 key_hash(const u8 *p, int len) {
+  u64 h = 0x243F6A8885A308D3ULL;
+  for (int o = 0; o < len; o += 8) {
+    u64 c = 0;
+    for (int b = 0; b < 8 && o + b < len; b++) c |= (u64)p[o + b] << (8 * b);
+    h = splitmix64(h ^ c);
+  }
+  return h;
+}
+// open-addressing table of row indices (+1); the first row to claim a slot represents its key
+__global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride,
+                                                       u32 *__restrict__ table, u32 mask, u32 *__restrict__ rep) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u8 *k = keys + stride * i;
+  u32 slot = (u32)key_hash(k, keylen) & mask;
+  for (;;) {
+    const u32 old = atomicCAS(&table[slot], 0u, (u32)i + 1u);
+    if (old == 0u) { rep[i] = (u32)i; return; }
+    const u8 *o = keys + stride * (size_t)(old - 1u);
+    bool same = true;
+    for (int b = 0; b < keylen; b++) same &= o[b] == k[b];
+    if (same) { rep[i] = old - 1u; return; }
+    slot = (slot + 1u) & mask;
+  }
+}
+__global__ void __launch_bounds__(256) k_dedupe_number(size_t n, const u32 *__restrict__ rep, u32 *__restrict__ uid,
+                                                       u32 *__restrict__ counter, u32 *__restrict__ uniq_row) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || rep[i] != (u32)i) return;
+  const u32 u = atomicAdd(counter, 1u);
+  uid[i] = u;
+  uniq_row[u] = (u32)i;
+}
+__global__ void __launch_bounds__(256) k_dedupe_map(size_t n, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
+                                                    u32 *__restrict__ key_id) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) key_id[i] = uid[rep[i]];
+}
+__global__ void __launch_bounds__(256) k_keys_indexed(size_t nuniq, const u8 *__restrict__ pub, int publen, size_t stride,
+                                                      const u32 *__restrict__ uniq_row, u32 *__restrict__ qwords, u8 *__restrict__ keyok) {
+  const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nuniq) return;
+  u32 qx[8], qy[8];
+  const bool ok = parse_pubkey(pub + stride * (size_t)uniq_row[u], publen, qx, qy);
+  uint4 *dst = reinterpret_cast<uint4 *>(qwords + u * 16);
+  dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+  dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
+  dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
+  dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
+  keyok[u] = ok;
+}
+template <int S>
+__global__ void __launch_bounds__(256) k_keytable_build(size_t nuniq, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
+                                                        u32 *__restrict__ tables, u32 *__restrict__ scratch) {
+  const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nuniq || !keyok[u]) return;
+  u32 qx[8], qy[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
+  keytable_build<S>(tables + u * kt_stride(S), scratch + u * kt_scratch_words(S), ge_from_words(qx, qy));
+}
+constexpr int FIN_WORDS = 32;  // BIP-340 stage-1 parking space per row in the keyed path (Y, Z, prefix)
+template <int S>
+__global__ void __launch_bounds__(256) k_ecmult_keyed(size_t n, const prep_rec *__restrict__ recs, const u32 *__restrict__ key_id,
+                                                      const u8 *__restrict__ keyok_u, const u32 *__restrict__ tables,
+                                                      const u8 *__restrict__ sig64, int mode, const u32 *__restrict__ gtable,
+                                                      u32 *__restrict__ fin, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  prep_rec rec;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
+    rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
+    rec.k1[0] = c.x; rec.k1[1] = c.y; rec.k1[2] = c.z; rec.k1[3] = c.w;
+    rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
+    rec.flags = e.x;
+  }
+  const u32 kid = key_id[i];
+  const bool kok = keyok_u[kid];
+  keyok_row[i] = kok;
+  bool ok = (rec.flags & PREP_VALID) && kok;
+  if (ok) {
+    const gej R = ecmult_lane_keyed<S>(rec, tables + (size_t)kid * kt_stride(S), gtable);
+    u32 rw[8];
+    load_words_be(rw, sig64 + 64 * i);
+    if (mode == MODE_ECDSA) {
+      ok = ecdsa_final(R, rw);
+    } else {
+      out[i] = schnorr_stage1(R, rw, fin + i * FIN_WORDS);
+      return;
+    }
+  }
+  out[i] = ok ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_schnorr_final_fin(size_t n, u32 *__restrict__ fin, u8 *__restrict__ out) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  schnorr_final_thread(tid, T, n, fin, out, FIN_WORDS);
+}
+
 // =====================================================================================
 //                                        engine
 // =====================================================================================
@@ -459,11 +565,21 @@ struct lamd_ctx {
   std::string err;
   // per-call workspaces (grown on demand, reused)
   devbuf recs, qwords, keyok, slots;
+  devbuf kd_table, kd_rep, kd_uid, kd_keyid, kd_uniq, kd_counter, kt_tables, kt_scratch, kt_qwords, kt_keyok, kt_fin;  // keyed path
+  int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
+  size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
+  double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
+  double keyed_dense_uses = 48.0;  // ... and for the dense one-position-per-nibble table
+  int keyed_spacing = 0;           // 0 = choose by re-use, else force S = 1 or 8 (LAMD_KEYED_SPACING)
+  int last_spacing = 0;
+  size_t last_unique_keys = 0;
+  bool last_keyed = false;
   devbuf in_a, in_b, in_c, out;       // staging for the host-buffer API
   devbuf g_msgs, g_off, g_ids, g_rowbase, g_hash, g_sig, g_pub, g_malformed, g_ok, g_verdict;
   // timing
   bool timing = false;
   bool ev_recorded = false;
+  int ecmult_waves = 3;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double last_ms[4] = {0, 0, 0, 0};
   // streaming queues (pinned host staging)
@@ -535,6 +651,12 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     ctx->err = std::string("unsupported architecture ") + ctx->prop.gcnArchName + " (built for gfx950 only)";
     return LAMD_ERR_NO_DEVICE;
   }
+  if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
+  if (const char *w = getenv("LAMD_KEYED")) ctx->keyed_mode = atoi(w);
+  if (const char *w = getenv("LAMD_KEYED_MIN_USES")) ctx->keyed_min_uses = atof(w);
+  if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
+  if (const char *w = getenv("LAMD_KEYED_SPACING")) ctx->keyed_spacing = atoi(w) == 1 ? 1 : (atoi(w) == 8 ? 8 : 0);
+  if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming));
@@ -570,6 +692,9 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (devbuf *b : {&ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kd_counter, &ctx->kt_tables,
+                    &ctx->kt_scratch, &ctx->kt_qwords, &ctx->kt_keyok, &ctx->kt_fin})
+    release(b);
   for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
                     &ctx->g_msgs, &ctx->g_off, &ctx->g_ids, &ctx->g_rowbase, &ctx->g_hash, &ctx->g_sig, &ctx->g_pub,
                     &ctx->g_malformed, &ctx->g_ok, &ctx->g_verdict})
@@ -616,19 +741,12 @@ extern "C" int lamd_get_info(lamd_ctx *ctx, lamd_info *info) {
   strncpy(info->arch, ctx->prop.gcnArchName, sizeof(info->arch) - 1);
   info->gtable_bytes = GTABLE_BYTES;
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
+  info->last_unique_keys = ctx->last_unique_keys;
+  info->last_keyed = ctx->last_keyed ? ctx->last_spacing : 0;
   return LAMD_OK;
 }
 
-// One chunk (n <= CHUNK) entirely on the context's stream.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
-static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
-                     size_t keystride, u8 *d_ok, bool time_it) {
-  int rc;
-  if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->qwords, n * 64)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->slots, n * SLOT_WORDS * 4)) != LAMD_OK) return rc;
-  prep_rec *recs = (prep_rec *)ctx->recs.p;
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+static void launch_prep(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, prep_rec *recs) {
   if (mode == MODE_ECDSA) {
     // enough threads to fill the chip, few enough that each amortises its inversion over ~16 signatures
     size_t threads = (n + 15) / 16;
@@ -638,19 +756,103 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   } else {
     hipLaunchKernelGGL(k_schnorr_prep, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_a, d_key, d_sig, recs);
   }
+}
+static size_t final_threads(lamd_ctx *ctx, size_t n) {
+  size_t threads = (n + 15) / 16;
+  const size_t min_threads = (size_t)ctx->prop.multiProcessorCount * 256;
+  if (threads < min_threads) threads = n < min_threads ? n : min_threads;
+  return threads;
+}
+
+// Keyed variant of a chunk: de-duplicate the keys on the device; if they repeat enough, build one window table per
+// distinct key and verify every row against its key's table (no doublings).  Returns 1 if it handled the chunk,
+// 0 if the caller should run the per-signature path, < 0 on error.
+static int run_chunk_keyed(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
+                           size_t keystride, u8 *d_ok, bool time_it) {
+  if (ctx->keyed_mode == 0 || (ctx->keyed_mode < 0 && n < ctx->keyed_min_rows) || n >= 0x7FFFFFFFu) return 0;
+  int rc;
+  size_t m = 1;
+  while (m < 2 * n) m <<= 1;
+  if ((rc = ensure(ctx, &ctx->kd_table, m * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kd_rep, n * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kd_uid, n * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kd_keyid, n * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kd_uniq, n * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kd_counter, 16)) != LAMD_OK) return rc;
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->kd_counter.p, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->kd_table.p,
+                     (u32)(m - 1), (u32 *)ctx->kd_rep.p);
+  hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
+                     (u32 *)ctx->kd_counter.p, (u32 *)ctx->kd_uniq.p);
+  u32 nuniq32 = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&nuniq32, ctx->kd_counter.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t nuniq = nuniq32;
+  ctx->last_unique_keys = nuniq;
+  const bool go = ctx->keyed_mode > 0 ? nuniq < n : (double)n >= ctx->keyed_min_uses * (double)nuniq;
+  if (!go || nuniq == 0) return 0;
+  if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kt_qwords, nuniq * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kt_keyok, nuniq)) != LAMD_OK) return rc;
+  // comb spacing: one position per nibble (no doublings, 25 KiB/key) for heavily re-used keys, five positions otherwise
+  const int S = ctx->keyed_spacing ? ctx->keyed_spacing : ((double)n >= ctx->keyed_dense_uses * (double)nuniq ? 1 : 8);
+  ctx->last_spacing = S;
+  if ((rc = ensure(ctx, &ctx->kt_tables, nuniq * (size_t)kt_stride(S == 1 ? 1 : 8) * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->kt_scratch, nuniq * (size_t)kt_scratch_words(S == 1 ? 1 : 8) * 4)) != LAMD_OK) return rc;
+  if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
+  prep_rec *recs = (prep_rec *)ctx->recs.p;
+  launch_prep(ctx, mode, n, d_a, d_sig, d_key, recs);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
+                     (u32 *)ctx->kd_keyid.p);
+  hipLaunchKernelGGL(k_keys_indexed, dim3(blocks_for(nuniq)), dim3(256), 0, ctx->stream, nuniq, d_key, keylen, keystride,
+                     (const u32 *)ctx->kd_uniq.p, (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
+  hipLaunchKernelGGL(S == 1 ? k_keytable_build<1> : k_keytable_build<8>, dim3(blocks_for(nuniq)), dim3(256), 0, ctx->stream, nuniq,
+                     (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  hipLaunchKernelGGL(S == 1 ? k_ecmult_keyed<1> : k_ecmult_keyed<8>, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->kd_keyid.p,
+                     (const u8 *)ctx->kt_keyok.p, (const u32 *)ctx->kt_tables.p, d_sig, mode, (const u32 *)ctx->gtable,
+                     (u32 *)ctx->kt_fin.p, (u8 *)ctx->keyok.p, d_ok);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  if (mode == MODE_SCHNORR)
+    hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->kt_fin.p, d_ok);
+  if (time_it) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    ctx->ev_recorded = true;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return 1;
+}
+
+// One chunk (n <= CHUNK) entirely on the context's stream.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
+static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
+                     size_t keystride, u8 *d_ok, bool time_it) {
+  int rc;
+  rc = run_chunk_keyed(ctx, mode, n, d_a, d_sig, d_key, keylen, keystride, d_ok, time_it);
+  ctx->last_keyed = rc == 1;
+  if (rc != 0) return rc < 0 ? rc : LAMD_OK;
+  if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->qwords, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->slots, n * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  prep_rec *recs = (prep_rec *)ctx->recs.p;
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  launch_prep(ctx, mode, n, d_a, d_sig, d_key, recs);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   hipLaunchKernelGGL(k_keys, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->qwords.p,
                      (u8 *)ctx->keyok.p);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-  hipLaunchKernelGGL(k_ecmult, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->qwords.p,
-                     (const u8 *)ctx->keyok.p, d_sig, mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, d_ok);
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  if (mode == MODE_SCHNORR) {
-    size_t threads = (n + 15) / 16;
-    const size_t min_threads = (size_t)ctx->prop.multiProcessorCount * 256;
-    if (threads < min_threads) threads = n < min_threads ? n : min_threads;
-    hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
+  {
+    auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
+    hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->qwords.p,
+                       (const u8 *)ctx->keyok.p, d_sig, mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, d_ok);
   }
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  if (mode == MODE_SCHNORR)
+    hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
   if (time_it) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     ctx->ev_recorded = true;
@@ -1348,6 +1550,20 @@ extern "C" int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap) {
   }
   if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
   return mask;
+}
+
+// ---- diagnostic peek into the engine's device work buffers (tests / debugging only)
+extern "C" int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out) {
+  if (!ctx || !out) return LAMD_ERR_ARG;
+  devbuf *bufs[] = {&ctx->recs, &ctx->keyok, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kt_keyok, &ctx->kt_qwords, &ctx->kt_tables};
+  if (which < 0 || which >= (int)(sizeof(bufs) / sizeof(bufs[0])) || !bufs[which]->p || offset + nbytes > bufs[which]->cap) {
+    ctx->err = "debug_read: no such buffer / out of range";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(out, (const u8 *)bufs[which]->p + offset, nbytes, hipMemcpyDeviceToHost));
+  return LAMD_OK;
 }
 
 // ---- synthetic workloads

@@ -209,6 +209,13 @@ LAMD_HD void slot_store_fe(u32 *dst, const fe &a) {
 #pragma unroll
   for (int i = 0; i < 8; i++) dst[i] = w[i];
 }
+LAMD_HD fe slot_load_raw(const u32 *src) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = src[i];
+  FE_SETMAG(r, 1);
+  return r;
+}
 LAMD_HD fe slot_load_fe(const u32 *src) {
   u32 w[8];
 #pragma unroll
@@ -323,6 +330,142 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
   fe_to_words(out + 8, fe_normalize(fe_mul(acc.y, fe_mul(zi2, zi))));
 }
 
+// ================================================================================================
+// Keyed path: when a batch re-uses public keys (gossip node ids, the 483 HTLC signatures of one
+// commitment_signed share remote_htlckey -- channeld/channeld.c:2224-2225), each distinct key gets ONE
+// table in HBM, shared by all of its signatures.  The 32 nibbles of a GLV half-scalar are cut into
+// NPOS = 32/S chunks of S nibbles; the table holds d * 16^(c*S) * Q for chunk c = 0..NPOS (the last one only
+// serves the recoding carry digit) and |digit| d = 1..8 as TRUE affine points (x | beta*x | y).  Evaluation is
+// a comb: for j = S-1..0 { acc *= 16 (4 doublings, skipped first); add nibble c*S+j of every chunk }, i.e.
+// 4(S-1) doublings and 66 mixed additions per verification instead of 132 + 66:
+//   S = 1 (33 positions, 25 KiB/key): no doublings at all -- for heavily re-used keys (>= ~64 signatures/key)
+//   S = 8 ( 5 positions,  4 KiB/key): 28 doublings, a 7x cheaper table -- pays from ~6 signatures per key
+constexpr int kt_npos(int S) { return 32 / S + 1; }
+constexpr int kt_words(int S) { return kt_npos(S) * 8 * SLOT_ENTRY_WORDS; }
+constexpr int kt_stride(int S) { return kt_words(S) + 64; }      // + room for the last position's parked H values
+constexpr int kt_scratch_words(int S) { return kt_npos(S) * 36; } // per key: Jacobian base (27) + prefix (9) per position
+
+LAMD_HD void store_raw(u32 *dst, const fe &a) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) dst[i] = a.n[i];
+}
+
+// One thread builds one key's table.  tab: kt_stride(S) words, scratch: kt_scratch_words(S) (both lane-private).
+template <int S>
+LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
+  constexpr int NP = kt_npos(S);
+  // 1. bases B_c = 16^(c*S) * Q in Jacobian form (a chain of 4*S doublings per position)
+  gej b = gej_from_ge(q);
+#pragma unroll 1
+  for (int pos = 0; pos < NP; pos++) {
+    if (pos) {
+#pragma unroll 1
+      for (int j = 0; j < 4 * S; j++) b = gej_double(b);
+    }
+    store_raw(scratch + pos * 36 + 0, b.x);
+    store_raw(scratch + pos * 36 + 9, b.y);
+    store_raw(scratch + pos * 36 + 18, fe_norm_weak(b.z));
+  }
+  // 2. all bases to affine with one inversion (Montgomery's trick over the Z values)
+  fe acc = fe_set_int(1);
+#pragma unroll 1
+  for (int pos = 0; pos < NP; pos++) {
+    store_raw(scratch + pos * 36 + 27, acc);
+    acc = fe_mul(acc, slot_load_raw(scratch + pos * 36 + 18));
+  }
+  fe inv = fe_inv(acc);
+#pragma unroll 1
+  for (int pos = NP - 1; pos >= 0; pos--) {
+    const fe zi = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 27));
+    inv = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 18));
+    const fe zi2 = fe_sqr(zi);
+    store_raw(scratch + pos * 36 + 0, fe_mul(slot_load_raw(scratch + pos * 36 + 0), zi2));
+    store_raw(scratch + pos * 36 + 9, fe_mul(slot_load_raw(scratch + pos * 36 + 9), fe_mul(zi2, zi)));
+  }
+  // 3. per position: 1B..8B on a shared Z (the per-signature table builder), Zg kept for step 4
+  acc = fe_set_int(1);
+#pragma unroll 1
+  for (int pos = 0; pos < NP; pos++) {
+    ge base;
+    base.x = slot_load_raw(scratch + pos * 36 + 0);
+    base.y = slot_load_raw(scratch + pos * 36 + 9);
+    u32 *t = tab + pos * 8 * SLOT_ENTRY_WORDS;
+    // build_q_table also parks six H values behind its 8 entries: inside the table that is the next position's
+    // first entries (rewritten when that position is built) or, for the last position, the stride padding
+    const fe zg = build_q_table(t, base);
+    store_raw(scratch + pos * 36 + 18, zg);
+    store_raw(scratch + pos * 36 + 27, acc);
+    acc = fe_mul(acc, zg);
+  }
+  // 4. second shared inversion: every entry from (x', beta x', y') on its position's isomorphic curve to true affine
+  inv = fe_inv(acc);
+  const u32 betaw[8] = LAMD_BETA;
+  const fe beta = fe_from_words(betaw);
+#pragma unroll 1
+  for (int pos = NP - 1; pos >= 0; pos--) {
+    const fe zi = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 27));
+    inv = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 18));
+    const fe zi2 = fe_sqr(zi);
+    const fe zi3 = fe_mul(zi2, zi);
+#pragma unroll 1
+    for (int e = 0; e < 8; e++) {
+      u32 *ent = tab + (pos * 8 + e) * SLOT_ENTRY_WORDS;
+      const fe x = fe_mul(slot_load_fe(ent + 0), zi2);
+      const fe y = fe_mul(slot_load_fe(ent + 16), zi3);
+      slot_store_fe(ent + 0, x);
+      slot_store_fe(ent + 8, fe_mul(x, beta));
+      slot_store_fe(ent + 16, y);
+    }
+  }
+}
+
+LAMD_HD gej gej_add_table_digit(const gej &acc, const u32 *tab, int pos, int d, bool lambda_half) {
+  const bool skip = d == 0;
+  const int a = d < 0 ? -d : d;
+  const u32 *e = tab + (pos * 8 + (skip ? 0 : a - 1)) * SLOT_ENTRY_WORDS;
+  ge pt;
+  pt.x = slot_load_fe(e + (lambda_half ? 8 : 0));
+  pt.y = slot_load_fe(e + 16);
+  pt = ge_neg_if(pt, d < 0);
+  return gej_add_ge(acc, pt, skip);
+}
+
+// R = u1*G + (k1 + k2*lambda)*Q from the key's table
+template <int S>
+LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gtable) {
+  constexpr int NC = 32 / S;  // chunks
+  const bool n1 = rec.flags & PREP_K1NEG, n2 = rec.flags & PREP_K2NEG;
+  const u32 t1 = (rec.flags & PREP_K1TOP) ? 1u : 0u, t2 = (rec.flags & PREP_K2TOP) ? 1u : 0u;
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int j = S - 1; j >= 0; j--) {
+    if (j != S - 1) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) acc = gej_double(acc);
+    }
+#pragma unroll 1
+    for (int c = 0; c < NC + (j == 0 ? 1 : 0); c++) {  // at j == 0 the extra position carries nibble 32 (the recoding carry)
+#pragma unroll 1
+      for (int half = 0; half < 2; half++) {
+        int d = half ? glv_digit(rec.k2, t2, c * S + j) : glv_digit(rec.k1, t1, c * S + j);
+        if (half ? n2 : n1) d = -d;
+        acc = gej_add_table_digit(acc, tab, c, d, half != 0);
+      }
+    }
+  }
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);
+    const bool skip = d == 0;
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    ge pt;
+    pt.x = slot_load_fe(e);
+    pt.y = slot_load_fe(e + 8);
+    acc = gej_add_ge(acc, pt, skip);
+  }
+  return acc;
+}
+
 // p - n (129 bits): r + n < p  <=>  r < p - n
 #define LAMD_P_MINUS_N {0x2FC9BAEEu, 0x402DA172u, 0x50B75FC4u, 0x45512319u, 1u, 0u, 0u, 0u}
 
@@ -369,21 +512,14 @@ LAMD_HD u8 schnorr_stage1(const gej &R, const u32 rw[8], u32 *slot) {
   }
   return SCHNORR_PENDING;
 }
-LAMD_HD fe slot_load_raw(const u32 *src) {
-  fe r;
-#pragma unroll
-  for (int i = 0; i < 9; i++) r.n[i] = src[i];
-  FE_SETMAG(r, 1);
-  return r;
-}
-LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *slots, u8 *out) {
+LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *slots, u8 *out, size_t slot_words = SLOT_WORDS) {
   fe acc = fe_set_int(1);
   size_t last = first;
   bool any = false;
 #pragma unroll 1
   for (size_t i = first; i < n; i += stride) {
     if (out[i] != SCHNORR_PENDING) continue;
-    u32 *slot = slots + i * SLOT_WORDS;
+    u32 *slot = slots + i * slot_words;
 #pragma unroll
     for (int k = 0; k < 9; k++) slot[SLOT_FIN_PREFIX + k] = acc.n[k];  // product of the pending Z before i
     acc = fe_mul(acc, slot_load_raw(slot + SLOT_FIN_Z));
@@ -395,7 +531,7 @@ LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *sl
 #pragma unroll 1
   for (size_t i = last;; i -= stride) {
     if (out[i] == SCHNORR_PENDING) {
-      const u32 *slot = slots + i * SLOT_WORDS;
+      const u32 *slot = slots + i * slot_words;
       const fe zi = fe_mul(inv, slot_load_raw(slot + SLOT_FIN_PREFIX));
       inv = fe_mul(inv, slot_load_raw(slot + SLOT_FIN_Z));
       const fe y = fe_normalize(fe_mul(slot_load_raw(slot + SLOT_FIN_Y), fe_mul(fe_sqr(zi), zi)));

@@ -100,6 +100,44 @@ void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8
     out[i] = ok;
   }
 }
+// keyed path: one window table per row's key (no sharing here -- this is an arithmetic test), then the table-driven ecmult
+}  // extern "C"
+template <int S>
+static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  dm_init();
+  std::vector<u32> tab(kt_stride(S)), scratch(kt_scratch_words(S)), fin(n * 32);
+  std::vector<prep_rec> recs(n);
+  if (mode == MODE_ECDSA) ecdsa_prep_thread(0, 1, n, a32, sig64, recs.data());
+  for (size_t i = 0; i < n; i++) {
+    if (mode == MODE_SCHNORR) schnorr_prep_one(a32 + 32 * i, key + (size_t)keylen * i, sig64 + 64 * i, &recs[i]);
+    u32 qx[8], qy[8], rw[8];
+    bool ok = parse_pubkey(key + (size_t)keylen * i, keylen, qx, qy);
+    ok &= (recs[i].flags & PREP_VALID) != 0;
+    out[i] = 0;
+    if (ok) {
+      keytable_build<S>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+      const gej R = ecmult_lane_keyed<S>(recs[i], tab.data(), g_table.data());
+      be_to_words(rw, sig64 + 64 * i);
+      out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
+    }
+  }
+  if (mode == MODE_SCHNORR) schnorr_final_thread(0, 1, n, fin.data(), out, 32);
+}
+extern "C" {
+void dm_verify_keyed(int mode, int S, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  if (S == 1) verify_keyed_t<1>(mode, n, a32, sig64, key, keylen, out);
+  else verify_keyed_t<8>(mode, n, a32, sig64, key, keylen, out);
+}
+// table entry (pos, d) of a key as 64 affine bytes + 32 bytes beta*x
+void dm_keytable_entry(const u8 *key33, int S, int pos, int d, u8 *out96) {
+  std::vector<u32> tab(kt_stride(1)), scratch(kt_scratch_words(1));
+  u32 qx[8], qy[8];
+  parse_pubkey(key33, 33, qx, qy);
+  if (S == 1) keytable_build<1>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  else keytable_build<8>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  const u32 *e = &tab[(pos * 8 + d - 1) * SLOT_ENTRY_WORDS];
+  words_to_be(out96, e); words_to_be(out96 + 32, e + 16); words_to_be(out96 + 64, e + 8);
+}
 // two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
 void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {
   dm_init();

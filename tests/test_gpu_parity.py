@@ -304,3 +304,78 @@ def test_cfg5_full_size_properties(eng):
     assert np.array_equal(we.d_ok.cpu().numpy().astype(bool), we.expect)
     assert np.array_equal(ws.d_ok.cpu().numpy().astype(bool), ws.expect)
     assert (~we.expect).sum() + (~ws.expect).sum() == int(we.n * 0.001) + int(ws.n * 0.001)
+
+
+@pytest.fixture(scope="module", params=[1, 8])
+def eng_keyed(request):
+    """engine forced onto the keyed path (per-key tables) whenever a key repeats at all; both comb spacings"""
+    import os
+    from lightning_amd import Engine
+    os.environ["LAMD_KEYED"] = "1"
+    os.environ["LAMD_KEYED_SPACING"] = str(request.param)
+    try:
+        e = Engine(0)
+    finally:
+        del os.environ["LAMD_KEYED"], os.environ["LAMD_KEYED_SPACING"]
+    e.spacing = request.param
+    yield e
+    e.close()
+
+
+def test_keyed_path_goldens_and_oracle(eng_keyed, orc, kat):
+    e = eng_keyed
+    for publen in (33, 65):
+        vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
+        got = e.verify_ecdsa(_rows([H(v["hash"]) for v in vs], 32), _rows([H(v["sig"]) for v in vs], 64), _rows([H(v["pub"]) for v in vs], publen))
+        bad = [v["name"] for v, g in zip(vs, got) if bool(g) != v["expect"]]
+        assert not bad, bad[:10]
+        inf = e.info()
+        assert inf["last_keyed"] == e.spacing and 0 < inf["last_unique_keys"] < len(vs)
+    vs = kat["schnorr"]
+    got = e.verify_schnorr(_rows([H(v["msg"]) for v in vs], 32), _rows([H(v["pk"]) for v in vs], 32), _rows([H(v["sig"]) for v in vs], 64))
+    bad = [v["name"] for v, g in zip(vs, got) if bool(g) != v["expect"]]
+    assert not bad, bad[:10]
+    assert e.info()["last_keyed"]
+    vs = kat["gossip"]
+    got = e.sigcheck_gossip([H(v["msg"]) for v in vs], [H(v["node_id"]) if "node_id" in v else None for v in vs])
+    assert [int(g) for g in got] == [v["expect"] for v in vs]
+    # random rows (distinct keys mixed with repeats) against the oracle, ragged sizes
+    rnd = random.Random(99)
+    for n in (3, 64, 65, 1000):
+        hs, sg, pk = _random_ecdsa(orc, rnd, n, 33)
+        hs, sg, pk = hs.copy(), sg.copy(), pk.copy()
+        h = n // 2
+        pk[h:2 * h] = pk[:h]                    # second half re-uses the first half's keys ...
+        hs[h:2 * h:2] = hs[:h:2]                # ... every other row an exact duplicate (same verdict),
+        sg[h:2 * h:2] = sg[:h:2]                # the others a foreign signature under that key (reject)
+        got = e.verify_ecdsa(hs, sg, pk)
+        exp = orc.ecdsa_verify_batch(hs, sg, pk, 33, 4).astype(bool)
+        assert np.array_equal(got, exp), n
+
+
+def test_keyed_path_auto_selection_and_parity(eng, orc):
+    """auto mode: a big batch with few distinct keys takes the table path, a batch of distinct keys does not; both agree
+    with the verdicts known by construction and with the oracle on a sample"""
+    from lightning_amd import workload
+    w = workload.make_ecdsa(eng, 30000, nkeys=100, publen=33)
+    eng.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+    eng.synchronize()
+    inf = eng.info()
+    assert inf["last_keyed"] == 1 and 100 <= inf["last_unique_keys"] < 600   # >= 48 signatures per key: dense tables (S = 1)
+    got = w.d_ok.cpu().numpy().astype(bool)
+    assert np.array_equal(got, w.expect), (np.nonzero(got != w.expect)[0][:10], w.classes[got != w.expect][:10])
+    sl = slice(0, 1200)
+    exp = orc.ecdsa_verify_batch(np.ascontiguousarray(w.cols[0][sl]), np.ascontiguousarray(w.cols[1][sl]), np.ascontiguousarray(w.cols[2][sl]), 33, 4)
+    assert np.array_equal(got[sl], exp.astype(bool))
+    w = workload.make_schnorr(eng, 30000, nkeys=2000)
+    eng.verify_schnorr_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+    eng.synchronize()
+    assert eng.info()["last_keyed"] == 8                                       # ~13 signatures per key: comb tables (S = 8)
+    got = w.d_ok.cpu().numpy().astype(bool)
+    assert np.array_equal(got, w.expect), (np.nonzero(got != w.expect)[0][:10], w.classes[got != w.expect][:10])
+    w = workload.make_ecdsa(eng, 30000, nkeys=1 << 40, publen=65)          # all keys distinct
+    eng.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+    eng.synchronize()
+    inf = eng.info()
+    assert not inf["last_keyed"] and inf["last_unique_keys"] > 29000
+    assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
