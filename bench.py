@@ -183,6 +183,12 @@ def main():
             import orc  # test infrastructure: the checker / CPU baseline only
             m = min(args.cpu_sample, n)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:  # a cgroup CPU quota caps what those threads can really use
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+            except Exception:
+                pass
             c = [np.ascontiguousarray(x[:m]) for x in we.cols]
             orc.ecdsa_verify_batch(c[0][:64], c[1][:64], c[2][:64], 65, cores)  # table init outside the timed part
             t1 = time.perf_counter()

@@ -335,7 +335,8 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
 // commitment_signed share remote_htlckey -- channeld/channeld.c:2224-2225), each distinct key gets ONE
 // table in HBM, shared by all of its signatures.  The 32 nibbles of a GLV half-scalar are cut into
 // NPOS = 32/S chunks of S nibbles; the table holds d * 16^(c*S) * Q for chunk c = 0..NPOS (the last one only
-// serves the recoding carry digit) and |digit| d = 1..8 as TRUE affine points (x | beta*x | y).  Evaluation is
+// serves the recoding carry digit) and |digit| d = 1..8 as affine points (x | beta*x | y) of one per-key isomorphic
+// curve (shared Z, no inversion needed to build it).  Evaluation is
 // a comb: for j = S-1..0 { acc *= 16 (4 doublings, skipped first); add nibble c*S+j of every chunk }, i.e.
 // 4(S-1) doublings and 66 mixed additions per verification instead of 132 + 66:
 //   S = 1 (33 positions, 25 KiB/key): no doublings at all -- for heavily re-used keys (>= ~64 signatures/key)
@@ -343,7 +344,7 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
 constexpr int kt_npos(int S) { return 32 / S + 1; }
 constexpr int kt_words(int S) { return kt_npos(S) * 8 * SLOT_ENTRY_WORDS; }
 constexpr int kt_stride(int S) { return kt_words(S) + 64; }      // + room for the last position's parked H values
-constexpr int kt_scratch_words(int S) { return kt_npos(S) * 36; } // per key: Jacobian base (27) + prefix (9) per position
+constexpr int kt_scratch_words(int S) { return kt_npos(S) * 36; } // per key and position: Jacobian base X, Y (18), Z_pos (9), prefix product (9)
 
 LAMD_HD void store_raw(u32 *dst, const fe &a) {
 #pragma unroll
@@ -351,6 +352,13 @@ LAMD_HD void store_raw(u32 *dst, const fe &a) {
 }
 
 // One thread builds one key's table.  tab: kt_stride(S) words, scratch: kt_scratch_words(S) (both lane-private).
+// No inversion anywhere: every position's multiples are first affine on that position's own isomorphic curve
+// (Z_pos = Z of the Jacobian base x the shared Z of its 8 multiples), then all positions are brought to ONE
+// common Zc = prod Z_pos by multiplying with the product of the OTHER positions' Z (prefix x suffix products).
+// The table therefore holds affine points of the curve y^2 = x^3 + 7*Zc^6; Zc is stored behind the entries and the
+// table-driven ecmult multiplies it back into the accumulator's Z before the G additions.
+constexpr int KT_ZC_OFF = 48;  // word offset of Zc inside the 64-word stride padding (the first 48 hold parked H values)
+
 template <int S>
 LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
   constexpr int NP = kt_npos(S);
@@ -366,24 +374,9 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
     store_raw(scratch + pos * 36 + 9, b.y);
     store_raw(scratch + pos * 36 + 18, fe_norm_weak(b.z));
   }
-  // 2. all bases to affine with one inversion (Montgomery's trick over the Z values)
+  // 2. per position: 1B..8B with (X, Y) of the Jacobian base taken as an affine point of the base's isomorphic curve;
+  //    Z_pos = Zg * Z_base; running prefix products prod_{j<pos} Z_j
   fe acc = fe_set_int(1);
-#pragma unroll 1
-  for (int pos = 0; pos < NP; pos++) {
-    store_raw(scratch + pos * 36 + 27, acc);
-    acc = fe_mul(acc, slot_load_raw(scratch + pos * 36 + 18));
-  }
-  fe inv = fe_inv(acc);
-#pragma unroll 1
-  for (int pos = NP - 1; pos >= 0; pos--) {
-    const fe zi = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 27));
-    inv = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 18));
-    const fe zi2 = fe_sqr(zi);
-    store_raw(scratch + pos * 36 + 0, fe_mul(slot_load_raw(scratch + pos * 36 + 0), zi2));
-    store_raw(scratch + pos * 36 + 9, fe_mul(slot_load_raw(scratch + pos * 36 + 9), fe_mul(zi2, zi)));
-  }
-  // 3. per position: 1B..8B on a shared Z (the per-signature table builder), Zg kept for step 4
-  acc = fe_set_int(1);
 #pragma unroll 1
   for (int pos = 0; pos < NP; pos++) {
     ge base;
@@ -393,25 +386,27 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
     // build_q_table also parks six H values behind its 8 entries: inside the table that is the next position's
     // first entries (rewritten when that position is built) or, for the last position, the stride padding
     const fe zg = build_q_table(t, base);
-    store_raw(scratch + pos * 36 + 18, zg);
-    store_raw(scratch + pos * 36 + 27, acc);
-    acc = fe_mul(acc, zg);
+    const fe zpos = fe_mul(zg, slot_load_raw(scratch + pos * 36 + 18));
+    store_raw(scratch + pos * 36 + 18, zpos);
+    store_raw(scratch + pos * 36 + 27, acc);  // prefix
+    acc = fe_mul(acc, zpos);
   }
-  // 4. second shared inversion: every entry from (x', beta x', y') on its position's isomorphic curve to true affine
-  inv = fe_inv(acc);
+  slot_store_fe(tab + kt_words(S) + KT_ZC_OFF, acc);  // Zc
+  // 3. unify: entry *= (prefix * suffix)^2 / ^3
   const u32 betaw[8] = LAMD_BETA;
   const fe beta = fe_from_words(betaw);
+  fe suffix = fe_set_int(1);
 #pragma unroll 1
   for (int pos = NP - 1; pos >= 0; pos--) {
-    const fe zi = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 27));
-    inv = fe_mul(inv, slot_load_raw(scratch + pos * 36 + 18));
-    const fe zi2 = fe_sqr(zi);
-    const fe zi3 = fe_mul(zi2, zi);
+    const fe ratio = fe_mul(suffix, slot_load_raw(scratch + pos * 36 + 27));
+    suffix = fe_mul(suffix, slot_load_raw(scratch + pos * 36 + 18));
+    const fe r2 = fe_sqr(ratio);
+    const fe r3 = fe_mul(r2, ratio);
 #pragma unroll 1
     for (int e = 0; e < 8; e++) {
       u32 *ent = tab + (pos * 8 + e) * SLOT_ENTRY_WORDS;
-      const fe x = fe_mul(slot_load_fe(ent + 0), zi2);
-      const fe y = fe_mul(slot_load_fe(ent + 16), zi3);
+      const fe x = fe_mul(slot_load_fe(ent + 0), r2);
+      const fe y = fe_mul(slot_load_fe(ent + 16), r3);
       slot_store_fe(ent + 0, x);
       slot_store_fe(ent + 8, fe_mul(x, beta));
       slot_store_fe(ent + 16, y);
@@ -453,6 +448,8 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
       }
     }
   }
+  // back from the table's isomorphic curve: (X, Y, Z) -> (X, Y, Z*Zc)
+  acc.z = fe_mul(acc.z, slot_load_fe(tab + kt_words(S) + KT_ZC_OFF));
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);

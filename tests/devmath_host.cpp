@@ -135,8 +135,15 @@ void dm_keytable_entry(const u8 *key33, int S, int pos, int d, u8 *out96) {
   parse_pubkey(key33, 33, qx, qy);
   if (S == 1) keytable_build<1>(tab.data(), scratch.data(), ge_from_words(qx, qy));
   else keytable_build<8>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  // entries are affine on the key's isomorphic curve: x = x_true * Zc^2, y = y_true * Zc^3
+  const int S_ = S == 1 ? 1 : 8;
+  const fe zc = slot_load_fe(&tab[kt_words(S_) + KT_ZC_OFF]);
+  const fe zi = fe_inv(zc), zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
   const u32 *e = &tab[(pos * 8 + d - 1) * SLOT_ENTRY_WORDS];
-  words_to_be(out96, e); words_to_be(out96 + 32, e + 16); words_to_be(out96 + 64, e + 8);
+  u32 w[8];
+  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e), zi2))); words_to_be(out96, w);
+  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 16), zi3))); words_to_be(out96 + 32, w);
+  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 8), zi2))); words_to_be(out96 + 64, w);
 }
 // two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
 void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {
