@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000, help="rows per kind per rank (1 M = BASELINE configs[1], [2])")
     ap.add_argument("--cpu-sample", type=int, default=200_000, help="rows per kind timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--skip-extra", action="store_true", help="skip the cfg4/cfg5 single-GPU data points")
     args = ap.parse_args()
 
     import numpy as np
@@ -178,6 +179,39 @@ def main():
         out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / (time.perf_counter() - t1), "rows": n,
                                  "note": "pageable host buffers in, verdicts out, single synchronous call; not the headline value"}
         mism += int((hv != we.expect).sum())
+        # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
+        # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
+        # configs[4] commit_tx storm (484-signature groups sharing a key) as one super-batch
+        if not args.skip_extra:
+            extra = {}
+            g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
+            ts = []
+            for it in range(3):
+                torch.cuda.synchronize(); eng.synchronize()
+                t1 = time.perf_counter()
+                eng.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
+                eng.synchronize()
+                ts.append(time.perf_counter() - t1)
+            gm = int((g.d_verdict.cpu().numpy() != g.expect).sum())
+            extra["cfg4_gossip_replay"] = {"messages": g.n, "verifies": g.rows, "verifies_per_s": g.rows / min(ts[1:]), "messages_per_s": g.n / min(ts[1:]),
+                                           "mismatches": gm, "keyed_spacing": eng.info()["last_keyed"], "distinct_keys": eng.info()["last_unique_keys"]}
+            del g
+            st = workload.make_commit_storm(eng, 10_000, device=device)
+            ts = []
+            for it in range(3):
+                torch.cuda.synchronize(); eng.synchronize()
+                t1 = time.perf_counter()
+                eng.verify_ecdsa_device(st["ecdsa"].dev[0], st["ecdsa"].dev[1], st["ecdsa"].dev[2], st["ecdsa"].d_ok)
+                eng.verify_schnorr_device(st["schnorr"].dev[0], st["schnorr"].dev[1], st["schnorr"].dev[2], st["schnorr"].d_ok)
+                eng.synchronize()
+                ts.append(time.perf_counter() - t1)
+            sm = int((st["ecdsa"].d_ok.cpu().numpy().astype(bool) != st["ecdsa"].expect).sum() + (st["schnorr"].d_ok.cpu().numpy().astype(bool) != st["schnorr"].expect).sum())
+            nv = st["ecdsa"].n + st["schnorr"].n
+            extra["cfg5_commit_storm_superbatch"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[1:]), "mismatches": sm,
+                                                     "keyed_spacing": eng.info()["last_keyed"]}
+            del st
+            out["other_configs_1gpu"] = extra
+            mism += gm + sm
         if args.cpu_sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # test infrastructure: the checker / CPU baseline only

@@ -175,6 +175,7 @@ typedef struct {
 	size_t gtable_bytes;
 	double last_kernel_ms[4]; /* prep, keys (+ key tables), ecmult, BIP-340 parity stage of the last launch sequence when timing is on */
 	size_t last_unique_keys;  /* distinct public keys found in the last chunk (0 if it was not examined) */
+	size_t last_hot_rows;     /* rows of the last chunk verified against per-key tables (the rest took the ladder) */
 	int last_keyed;           /* 0: per-signature ladder; else the last chunk ran on per-key tables and this is the comb
 				   * spacing used (1 = one position per nibble, 8 = five positions) */
 } lamd_info;

@@ -54,13 +54,17 @@ __global__ void __launch_bounds__(256) k_schnorr_prep(size_t n, const u8 *__rest
   schnorr_prep_one(msg32 + 32 * i, pk32 + 32 * i, sig64 + 64 * i, &recs[i]);
 }
 
+constexpr int FIN_WORDS = 32;  // BIP-340 stage-1 parking space per row (Y, Z, prefix) when rows are not slot-aligned
+
 // ---- public keys: parse / decompress / validate -> 64-byte affine words + validity byte
+// (idx != nullptr: work item i handles input row idx[i]; its outputs stay at position i)
 __global__ void __launch_bounds__(256) k_keys(size_t n, const u8 *__restrict__ pub, int publen, size_t stride,
-                                              u32 *__restrict__ qwords, u8 *__restrict__ keyok) {
+                                              const u32 *__restrict__ idx, u32 *__restrict__ qwords, u8 *__restrict__ keyok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const size_t row = idx ? idx[i] : i;
   u32 qx[8], qy[8];
-  const bool ok = parse_pubkey(pub + stride * i, publen, qx, qy);
+  const bool ok = parse_pubkey(pub + stride * row, publen, qx, qy);
   uint4 *dst = reinterpret_cast<uint4 *>(qwords + i * 16);
   dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
   dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
@@ -75,12 +79,16 @@ template <int WAVES>
 __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec *__restrict__ recs, const u32 *__restrict__ qwords,
                                                 const u8 *__restrict__ keyok, const u8 *__restrict__ sig64, int mode,
                                                 const u32 *__restrict__ gtable, u32 *__restrict__ slots,
+                                                const u32 *__restrict__ idx, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
                                                 u8 *__restrict__ out) {
+  // idx != nullptr (cold rows of a partitioned chunk): work item i verifies input row idx[i]; key data and the table
+  // slot live at position i, the prep record / signature / verdict / BIP-340 parking space (fin) at the row
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const size_t row = idx ? idx[i] : i;
   prep_rec rec;
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
+    const uint4 *src = reinterpret_cast<const uint4 *>(recs + row);
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
     rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
     rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
@@ -88,6 +96,7 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
     rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
     rec.flags = e.x;
   }
+  if (keyok_row) keyok_row[row] = keyok[i];
   bool ok = (rec.flags & PREP_VALID) && keyok[i];
   if (ok) {  // whole waves of rejected inputs skip the ladder (s_cbranch_execz)
     u32 qx[8], qy[8];
@@ -97,15 +106,15 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
     qy[0] = c.x; qy[1] = c.y; qy[2] = c.z; qy[3] = c.w; qy[4] = d.x; qy[5] = d.y; qy[6] = d.z; qy[7] = d.w;
     const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slots + i * SLOT_WORDS, gtable);
     u32 rw[8];
-    load_words_be(rw, sig64 + 64 * i);
+    load_words_be(rw, sig64 + 64 * row);
     if (mode == MODE_ECDSA) {
       ok = ecdsa_final(R, rw);
-    } else {
-      out[i] = schnorr_stage1(R, rw, slots + i * SLOT_WORDS);  // 0 or SCHNORR_PENDING (parity decided by k_schnorr_final)
+    } else {  // 0 or SCHNORR_PENDING (parity decided by k_schnorr_final[_fin])
+      out[row] = schnorr_stage1(R, rw, fin ? fin + row * FIN_WORDS : slots + i * SLOT_WORDS);
       return;
     }
   }
-  out[i] = ok ? 1 : 0;
+  out[row] = ok ? 1 : 0;
 }
 
 // ---- BIP-340 stage 2: shared inversion for the y-parity test
@@ -452,6 +461,27 @@ LAMD_HD u64 key_hash(const u8 *p, int len) {
   }
   return h;
 }
+// Wave-aggregated allocation from a global counter: ONE atomic per wavefront (an uncontended device atomic costs
+// ~10 ns; a million lane-level atomics on one word serialise into >10 ms -- measured).  Every lane of the wave must call
+// it; lanes with pred get consecutive indices.  `weight` (optional) is summed over the pred lanes into *wsum.
+__device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight = 0, u32 *wsum = nullptr) {
+  const u64 mask = __ballot(pred);
+  const u32 lane = threadIdx.x & 63u;
+  const u32 prefix = (u32)__popcll(mask & ((1ull << lane) - 1ull));
+  if (wsum) {
+    u32 w = pred ? weight : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    if (lane == 0 && w) atomicAdd(wsum, w);
+  }
+  u32 base = 0;
+  if (mask == 0) return 0;
+  const int leader = __ffsll((long long)mask) - 1;
+  if ((int)lane == leader) base = atomicAdd(counter, (u32)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  return base + prefix;
+}
+
 // open-addressing table of row indices (+1); the first row to claim a slot represents its key
 __global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride,
                                                        u32 *__restrict__ table, u32 mask, u32 *__restrict__ rep) {
@@ -472,28 +502,57 @@ __global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__res
 __global__ void __launch_bounds__(256) k_dedupe_number(size_t n, const u32 *__restrict__ rep, u32 *__restrict__ uid,
                                                        u32 *__restrict__ counter, u32 *__restrict__ uniq_row) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || rep[i] != (u32)i) return;
-  const u32 u = atomicAdd(counter, 1u);
-  uid[i] = u;
-  uniq_row[u] = (u32)i;
+  const bool is_rep = i < n && rep[i] == (u32)i;
+  const u32 u = wave_alloc(counter, is_rep);
+  if (is_rep) {
+    uid[i] = u;
+    uniq_row[u] = (u32)i;
+  }
 }
 __global__ void __launch_bounds__(256) k_dedupe_map(size_t n, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
-                                                    u32 *__restrict__ key_id) {
+                                                    u32 *__restrict__ key_id, u32 *__restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) key_id[i] = uid[rep[i]];
+  const bool live = i < n;
+  const u32 k = live ? uid[rep[i]] : 0u;
+  if (live) key_id[i] = k;
+  // count[k] += 1, combined per wave and key: neighbouring rows often share a key (the 483 HTLC signatures of one
+  // commitment), and 64 same-address atomics from one wave serialise
+  const u32 lane = threadIdx.x & 63u;
+  u64 todo = __ballot(live);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const u32 kk = __shfl(k, leader, 64);
+    const u64 same = __ballot(live && k == kk);
+    if ((int)lane == leader) atomicAdd(&count[kk], (u32)__popcll(same));
+    todo &= ~same;
+  }
 }
-__global__ void __launch_bounds__(256) k_keys_indexed(size_t nuniq, const u8 *__restrict__ pub, int publen, size_t stride,
-                                                      const u32 *__restrict__ uniq_row, u32 *__restrict__ qwords, u8 *__restrict__ keyok) {
+// counters: [0] distinct keys, [1] hot keys, [2] rows under hot keys, [3]/[4] fill of the hot / cold row lists
+// a key is "hot" (gets a table) when at least min_uses rows carry it
+__global__ void __launch_bounds__(256) k_dedupe_classify(size_t n, const u32 *__restrict__ count, const u32 *__restrict__ uniq_row,
+                                                         u32 min_uses, u32 *__restrict__ counters, u32 *__restrict__ hotidx,
+                                                         u32 *__restrict__ hot_row) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= nuniq) return;
-  u32 qx[8], qy[8];
-  const bool ok = parse_pubkey(pub + stride * (size_t)uniq_row[u], publen, qx, qy);
-  uint4 *dst = reinterpret_cast<uint4 *>(qwords + u * 16);
-  dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
-  dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
-  dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
-  dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
-  keyok[u] = ok;
+  const bool live = u < n && u < counters[0];
+  const u32 c = live ? count[u] : 0u;
+  const bool hot = live && c >= min_uses;
+  const u32 h = wave_alloc(&counters[1], hot, c, &counters[2]);
+  if (hot) {
+    hotidx[u] = h;
+    hot_row[h] = uniq_row[u];
+  } else if (live) {
+    hotidx[u] = 0xFFFFFFFFu;
+  }
+}
+__global__ void __launch_bounds__(256) k_dedupe_partition(size_t n, const u32 *__restrict__ key_id, const u32 *__restrict__ hotidx,
+                                                          u32 *__restrict__ counters, u32 *__restrict__ list_hot, u32 *__restrict__ list_cold) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  const bool hot = live && hotidx[key_id[i]] != 0xFFFFFFFFu;
+  const u32 ph = wave_alloc(&counters[3], hot);
+  const u32 pc = wave_alloc(&counters[4], live && !hot);
+  if (hot) list_hot[ph] = (u32)i;
+  else if (live) list_cold[pc] = (u32)i;
 }
 template <int S>
 __global__ void __launch_bounds__(256) k_keytable_build(size_t nuniq, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
@@ -505,14 +564,16 @@ __global__ void __launch_bounds__(256) k_keytable_build(size_t nuniq, const u32 
   for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
   keytable_build<S>(tables + u * kt_stride(S), scratch + u * kt_scratch_words(S), ge_from_words(qx, qy));
 }
-constexpr int FIN_WORDS = 32;  // BIP-340 stage-1 parking space per row in the keyed path (Y, Z, prefix)
+// work item j verifies row list[j] against the table of its (hot) key
 template <int S>
-__global__ void __launch_bounds__(256) k_ecmult_keyed(size_t n, const prep_rec *__restrict__ recs, const u32 *__restrict__ key_id,
+__global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *__restrict__ list, const prep_rec *__restrict__ recs,
+                                                      const u32 *__restrict__ key_id, const u32 *__restrict__ hotidx,
                                                       const u8 *__restrict__ keyok_u, const u32 *__restrict__ tables,
                                                       const u8 *__restrict__ sig64, int mode, const u32 *__restrict__ gtable,
                                                       u32 *__restrict__ fin, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nlist) return;
+  const size_t i = list[j];
   prep_rec rec;
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
@@ -523,7 +584,7 @@ __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t n, const prep_rec *
     rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
     rec.flags = e.x;
   }
-  const u32 kid = key_id[i];
+  const u32 kid = hotidx[key_id[i]];
   const bool kok = keyok_u[kid];
   keyok_row[i] = kok;
   bool ok = (rec.flags & PREP_VALID) && kok;
@@ -566,6 +627,11 @@ struct lamd_ctx {
   // per-call workspaces (grown on demand, reused)
   devbuf recs, qwords, keyok, slots;
   devbuf kd_table, kd_rep, kd_uid, kd_keyid, kd_uniq, kd_counter, kt_tables, kt_scratch, kt_qwords, kt_keyok, kt_fin;  // keyed path
+  devbuf kd_count, kd_hotidx, kd_hotrow, kd_listhot, kd_listcold, keyok_row;
+  hipStream_t stream2 = nullptr;   // scalar prep runs here, concurrently with the key work on `stream`
+  hipStream_t stream3 = nullptr;   // cold rows of a partitioned chunk
+  hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr;
+  size_t last_hot_rows = 0;
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
@@ -658,6 +724,11 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_SPACING")) ctx->keyed_spacing = atoi(w) == 1 ? 1 : (atoi(w) == 8 ? 8 : 0);
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming));
   // window bases B_w = 2^(16 w) G, computed here with the same group code the kernels use (64 doublings each)
@@ -693,8 +764,14 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (devbuf *b : {&ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kd_counter, &ctx->kt_tables,
-                    &ctx->kt_scratch, &ctx->kt_qwords, &ctx->kt_keyok, &ctx->kt_fin})
+                    &ctx->kt_scratch, &ctx->kt_qwords, &ctx->kt_keyok, &ctx->kt_fin, &ctx->kd_count, &ctx->kd_hotidx, &ctx->kd_hotrow,
+                    &ctx->kd_listhot, &ctx->kd_listcold, &ctx->keyok_row})
     release(b);
+  if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+  if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
+  if (ctx->ev_cold) (void)hipEventDestroy(ctx->ev_cold);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
                     &ctx->g_msgs, &ctx->g_off, &ctx->g_ids, &ctx->g_rowbase, &ctx->g_hash, &ctx->g_sig, &ctx->g_pub,
                     &ctx->g_malformed, &ctx->g_ok, &ctx->g_verdict})
@@ -742,6 +819,7 @@ extern "C" int lamd_get_info(lamd_ctx *ctx, lamd_info *info) {
   info->gtable_bytes = GTABLE_BYTES;
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
   info->last_unique_keys = ctx->last_unique_keys;
+  info->last_hot_rows = ctx->last_hot_rows;
   info->last_keyed = ctx->last_keyed ? ctx->last_spacing : 0;
   return LAMD_OK;
 }
@@ -764,95 +842,134 @@ static size_t final_threads(lamd_ctx *ctx, size_t n) {
   return threads;
 }
 
-// Keyed variant of a chunk: de-duplicate the keys on the device; if they repeat enough, build one window table per
-// distinct key and verify every row against its key's table (no doublings).  Returns 1 if it handled the chunk,
-// 0 if the caller should run the per-signature path, < 0 on error.
-static int run_chunk_keyed(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
-                           size_t keystride, u8 *d_ok, bool time_it) {
-  if (ctx->keyed_mode == 0 || (ctx->keyed_mode < 0 && n < ctx->keyed_min_rows) || n >= 0x7FFFFFFFu) return 0;
+// Per-signature path over `m` work items (all rows when idx == nullptr, else the listed rows): keys -> ladder.
+// Prep records (indexed by row) must already be queued on stream2 / finished (ev_prep).
+static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, const prep_rec *recs, const u8 *d_sig, const u8 *d_key,
+                         int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it) {
   int rc;
-  size_t m = 1;
-  while (m < 2 * n) m <<= 1;
-  if ((rc = ensure(ctx, &ctx->kd_table, m * 4)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kd_rep, n * 4)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kd_uid, n * 4)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kd_keyid, n * 4)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kd_uniq, n * 4)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kd_counter, 16)) != LAMD_OK) return rc;
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->kd_counter.p, 0, 16, ctx->stream));
-  hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->kd_table.p,
-                     (u32)(m - 1), (u32 *)ctx->kd_rep.p);
-  hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
-                     (u32 *)ctx->kd_counter.p, (u32 *)ctx->kd_uniq.p);
-  u32 nuniq32 = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&nuniq32, ctx->kd_counter.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const size_t nuniq = nuniq32;
-  ctx->last_unique_keys = nuniq;
-  const bool go = ctx->keyed_mode > 0 ? nuniq < n : (double)n >= ctx->keyed_min_uses * (double)nuniq;
-  if (!go || nuniq == 0) return 0;
-  if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kt_qwords, nuniq * 64)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kt_keyok, nuniq)) != LAMD_OK) return rc;
-  // comb spacing: one position per nibble (no doublings, 25 KiB/key) for heavily re-used keys, five positions otherwise
-  const int S = ctx->keyed_spacing ? ctx->keyed_spacing : ((double)n >= ctx->keyed_dense_uses * (double)nuniq ? 1 : 8);
-  ctx->last_spacing = S;
-  if ((rc = ensure(ctx, &ctx->kt_tables, nuniq * (size_t)kt_stride(S == 1 ? 1 : 8) * 4)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->kt_scratch, nuniq * (size_t)kt_scratch_words(S == 1 ? 1 : 8) * 4)) != LAMD_OK) return rc;
-  if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
-  prep_rec *recs = (prep_rec *)ctx->recs.p;
-  launch_prep(ctx, mode, n, d_a, d_sig, d_key, recs);
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
-                     (u32 *)ctx->kd_keyid.p);
-  hipLaunchKernelGGL(k_keys_indexed, dim3(blocks_for(nuniq)), dim3(256), 0, ctx->stream, nuniq, d_key, keylen, keystride,
-                     (const u32 *)ctx->kd_uniq.p, (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
-  hipLaunchKernelGGL(S == 1 ? k_keytable_build<1> : k_keytable_build<8>, dim3(blocks_for(nuniq)), dim3(256), 0, ctx->stream, nuniq,
-                     (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
+  if ((rc = ensure(ctx, &ctx->qwords, m * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->keyok, m)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->slots, m * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_keys, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, d_key, keylen, keystride, idx, (u32 *)ctx->qwords.p,
+                     (u8 *)ctx->keyok.p);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-  hipLaunchKernelGGL(S == 1 ? k_ecmult_keyed<1> : k_ecmult_keyed<8>, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->kd_keyid.p,
-                     (const u8 *)ctx->kt_keyok.p, (const u32 *)ctx->kt_tables.p, d_sig, mode, (const u32 *)ctx->gtable,
-                     (u32 *)ctx->kt_fin.p, (u8 *)ctx->keyok.p, d_ok);
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  if (mode == MODE_SCHNORR)
-    hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->kt_fin.p, d_ok);
-  if (time_it) {
-    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    ctx->ev_recorded = true;
-  }
-  HIPCHK(ctx, hipGetLastError());
-  return 1;
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+  auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
+  hipLaunchKernelGGL(kern, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, recs, (const u32 *)ctx->qwords.p, (const u8 *)ctx->keyok.p, d_sig,
+                     mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, idx, fin, keyok_row, d_ok);
+  return LAMD_OK;
 }
 
-// One chunk (n <= CHUNK) entirely on the context's stream.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
+// One chunk (n <= CHUNK) entirely on the context's streams.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
+//  1. scalar prep for every row on stream2 (independent of the key work; joined by event before the ecmult kernels)
+//  2. big chunks: de-duplicate the keys on the device; keys carried by >= keyed_min_uses rows are "hot": each gets a
+//     window table in HBM and its rows are verified by the table-driven kernel (no / few doublings); the other
+//     ("cold") rows take the per-signature ladder.  Small chunks skip 2 (latency-bound: per-signature ladder).
 static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
                      size_t keystride, u8 *d_ok, bool time_it) {
   int rc;
-  rc = run_chunk_keyed(ctx, mode, n, d_a, d_sig, d_key, keylen, keystride, d_ok, time_it);
-  ctx->last_keyed = rc == 1;
-  if (rc != 0) return rc < 0 ? rc : LAMD_OK;
   if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->qwords, n * 64)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->slots, n * SLOT_WORDS * 4)) != LAMD_OK) return rc;
   prep_rec *recs = (prep_rec *)ctx->recs.p;
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-  launch_prep(ctx, mode, n, d_a, d_sig, d_key, recs);
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  hipLaunchKernelGGL(k_keys, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->qwords.p,
-                     (u8 *)ctx->keyok.p);
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  // stream2 must not start before the inputs (possibly still being copied on the main stream) are there
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   {
-    auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
-    hipLaunchKernelGGL(kern, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, recs, (const u32 *)ctx->qwords.p,
-                       (const u8 *)ctx->keyok.p, d_sig, mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, d_ok);
+    hipStream_t main = ctx->stream;
+    ctx->stream = ctx->stream2;
+    launch_prep(ctx, mode, n, d_a, d_sig, d_key, recs);
+    ctx->stream = main;
   }
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  if (mode == MODE_SCHNORR)
-    hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
+  HIPCHK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream2));
+
+  ctx->last_keyed = false;
+  ctx->last_unique_keys = 0;
+  ctx->last_hot_rows = 0;
+  size_t nhot = 0, hot_rows = 0;
+  const bool try_keyed = ctx->keyed_mode != 0 && (ctx->keyed_mode > 0 || n >= ctx->keyed_min_rows) && n < 0x7FFFFFFFu;
+  if (try_keyed) {
+    size_t m = 1;
+    while (m < 2 * n) m <<= 1;
+    if ((rc = ensure(ctx, &ctx->kd_table, m * 4)) != LAMD_OK) return rc;
+    for (devbuf *b : {&ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_hotidx, &ctx->kd_hotrow,
+                      &ctx->kd_listhot, &ctx->kd_listcold})
+      if ((rc = ensure(ctx, b, n * 4)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kd_counter, 32)) != LAMD_OK) return rc;
+    u32 *counters = (u32 *)ctx->kd_counter.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->kd_count.p, 0, n * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(counters, 0, 32, ctx->stream));
+    hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->kd_table.p,
+                       (u32)(m - 1), (u32 *)ctx->kd_rep.p);
+    hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
+                       counters, (u32 *)ctx->kd_uniq.p);
+    hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
+                       (u32 *)ctx->kd_keyid.p, (u32 *)ctx->kd_count.p);
+    const u32 min_uses = ctx->keyed_mode > 0 ? 2u : (u32)(ctx->keyed_min_uses + 0.5);
+    hipLaunchKernelGGL(k_dedupe_classify, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
+                       (const u32 *)ctx->kd_uniq.p, min_uses, counters, (u32 *)ctx->kd_hotidx.p, (u32 *)ctx->kd_hotrow.p);
+    u32 h[3] = {0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, counters, 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_unique_keys = h[0];
+    nhot = h[1];
+    hot_rows = h[2];
+    // tables only pay when enough rows ride on them
+    if (ctx->keyed_mode < 0 && hot_rows < ctx->keyed_min_rows) nhot = hot_rows = 0;
+  }
+  u8 *keyok_row = nullptr;
+  u32 *fin = nullptr;
+  if (nhot) {
+    // comb spacing: one position per nibble (no doublings, 25 KiB/key) for heavily re-used keys, five positions otherwise
+    const int S = ctx->keyed_spacing ? ctx->keyed_spacing : ((double)hot_rows >= ctx->keyed_dense_uses * (double)nhot ? 1 : 8);
+    ctx->last_keyed = true;
+    ctx->last_spacing = S;
+    ctx->last_hot_rows = hot_rows;
+    if ((rc = ensure(ctx, &ctx->keyok_row, n)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kt_qwords, nhot * 64)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kt_keyok, nhot)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kt_tables, nhot * (size_t)kt_stride(S) * 4)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kt_scratch, nhot * (size_t)kt_scratch_words(S) * 4)) != LAMD_OK) return rc;
+    if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
+    keyok_row = (u8 *)ctx->keyok_row.p;
+    fin = mode == MODE_SCHNORR ? (u32 *)ctx->kt_fin.p : nullptr;
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(k_dedupe_partition, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_keyid.p,
+                       (const u32 *)ctx->kd_hotidx.p, (u32 *)ctx->kd_counter.p, (u32 *)ctx->kd_listhot.p, (u32 *)ctx->kd_listcold.p);
+    hipLaunchKernelGGL(k_keys, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, d_key, keylen, keystride, (const u32 *)ctx->kd_hotrow.p,
+                       (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
+    hipLaunchKernelGGL(S == 1 ? k_keytable_build<1> : k_keytable_build<8>, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot,
+                       (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
+    const size_t ncold = n - hot_rows;
+    if (ncold) {
+      // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few
+      // rows, i.e. a latency-bound launch that should hide behind the table work instead of serialising with it
+      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+      hipStream_t main = ctx->stream;
+      ctx->stream = ctx->stream3;
+      rc = launch_direct(ctx, mode, ncold, (const u32 *)ctx->kd_listcold.p, recs, d_sig, d_key, keylen, keystride, fin, keyok_row, d_ok, false);
+      ctx->stream = main;
+      if (rc != LAMD_OK) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
+    }
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+    hipLaunchKernelGGL(S == 1 ? k_ecmult_keyed<1> : k_ecmult_keyed<8>, dim3(blocks_for(hot_rows)), dim3(256), 0, ctx->stream, hot_rows,
+                       (const u32 *)ctx->kd_listhot.p, recs, (const u32 *)ctx->kd_keyid.p, (const u32 *)ctx->kd_hotidx.p,
+                       (const u8 *)ctx->kt_keyok.p, (const u32 *)ctx->kt_tables.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_row, d_ok);
+    if (ncold) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (mode == MODE_SCHNORR)
+      hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, fin, d_ok);
+  } else {
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    rc = launch_direct(ctx, mode, n, nullptr, recs, d_sig, d_key, keylen, keystride, nullptr, nullptr, d_ok, time_it);
+    if (rc != LAMD_OK) return rc;
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (mode == MODE_SCHNORR)
+      hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
+  }
   if (time_it) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     ctx->ev_recorded = true;
@@ -972,7 +1089,7 @@ extern "C" int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_keys, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
-                     (u32 *)ctx->qwords.p, (u8 *)ctx->keyok.p);
+                     (const u32 *)nullptr, (u32 *)ctx->qwords.p, (u8 *)ctx->keyok.p);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ok, ctx->keyok.p, n, hipMemcpyDeviceToHost, ctx->stream));
   std::vector<u32> words;
@@ -1020,7 +1137,8 @@ static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d
                    (const u8 *)ctx->g_pub.p + 33 * r0, 33, 33, (u8 *)ctx->g_ok.p + r0, ctx->timing && m1 == n);
     if (rc != LAMD_OK) return rc;
     hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(m1 - m0)), dim3(256), 0, ctx->stream, m1 - m0, d_msgs, d_off + m0, d_rowbase + m0,
-                       (const u8 *)ctx->g_ok.p, (const u8 *)ctx->keyok.p - r0, (const u8 *)ctx->g_malformed.p + m0, d_verdict + m0);
+                       (const u8 *)ctx->g_ok.p, (ctx->last_keyed ? (const u8 *)ctx->keyok_row.p : (const u8 *)ctx->keyok.p) - r0,
+                       (const u8 *)ctx->g_malformed.p + m0, d_verdict + m0);
     HIPCHK(ctx, hipGetLastError());
     m0 = m1;
   }

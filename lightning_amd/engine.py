@@ -198,4 +198,4 @@ class Engine:
         inf = _ffi.LamdInfo()
         self._chk(self._lib.lamd_get_info(self._ctx, ctypes.byref(inf)))
         return dict(device=inf.device, compute_units=inf.compute_units, arch=inf.arch.decode(), gtable_bytes=inf.gtable_bytes,
-                    last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_keyed=int(inf.last_keyed))
+                    last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_hot_rows=inf.last_hot_rows, last_keyed=int(inf.last_keyed))

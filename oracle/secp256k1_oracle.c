@@ -109,7 +109,47 @@ static void fe_mul(fe *r, const fe *a, const fe *b)
 	for (int i = 1; i < 4; i++) { acc += lo[i]; r->d[i] = (u64)acc; acc >>= 64; }
 	fe_fix(r, (u64)acc);
 }
-static void fe_sqr(fe *r, const fe *a) { fe_mul(r, a, a); }
+static void fe_reduce512(fe *r, const u64 t[8])
+{
+	u128 acc = 0;
+	u64 lo[4];
+	for (int i = 0; i < 4; i++) {
+		acc += (u128)t[4 + i] * FE_PC + t[i];
+		lo[i] = (u64)acc;
+		acc >>= 64;
+	}
+	u64 c = (u64)acc;
+	acc = (u128)c * FE_PC + lo[0];
+	r->d[0] = (u64)acc; acc >>= 64;
+	for (int i = 1; i < 4; i++) { acc += lo[i]; r->d[i] = (u64)acc; acc >>= 64; }
+	fe_fix(r, (u64)acc);
+}
+static void fe_sqr(fe *r, const fe *a)
+{
+	/* cross products once, doubled, plus the four squares */
+	u64 t[8] = {0};
+	for (int i = 0; i < 4; i++) {
+		u64 carry = 0;
+		for (int j = i + 1; j < 4; j++) {
+			u128 acc = (u128)a->d[i] * a->d[j] + t[i + j] + carry;
+			t[i + j] = (u64)acc;
+			carry = (u64)(acc >> 64);
+		}
+		t[i + 4] = carry;
+	}
+	u64 top = 0;
+	for (int i = 0; i < 8; i++) { u64 nt = t[i] >> 63; t[i] = (t[i] << 1) | top; top = nt; }
+	u64 carry = 0;
+	for (int i = 0; i < 4; i++) {
+		u128 sq = (u128)a->d[i] * a->d[i];
+		u128 acc = (u128)t[2 * i] + (u64)sq + carry;
+		t[2 * i] = (u64)acc;
+		acc = (u128)t[2 * i + 1] + (u64)(sq >> 64) + (u64)(acc >> 64);
+		t[2 * i + 1] = (u64)acc;
+		carry = (u64)(acc >> 64);
+	}
+	fe_reduce512(r, t);
+}
 static void fe_mul_int(fe *r, const fe *a, unsigned k)
 {
 	fe acc = {{0, 0, 0, 0}}, t = *a;
@@ -293,9 +333,25 @@ static void gej_add(gej *r, const gej *a, const gej *b)
 }
 static void gej_add_ge(gej *r, const gej *a, const ge *b)
 {
-	gej bj;
-	gej_set_ge(&bj, b);
-	gej_add(r, a, &bj); /* correctness over speed: z2 = 1 multiplications are harmless */
+	/* mixed addition (Z2 = 1): 8M + 3S, same case analysis as gej_add */
+	if (b->inf) { *r = *a; return; }
+	if (a->inf) { gej_set_ge(r, b); return; }
+	fe z1z1, u2, s2, h, rr, t;
+	fe_sqr(&z1z1, &a->z);
+	fe_mul(&u2, &b->x, &z1z1);
+	fe_mul(&s2, &b->y, &a->z); fe_mul(&s2, &s2, &z1z1);
+	fe_sub(&h, &u2, &a->x);
+	fe_sub(&rr, &s2, &a->y);
+	if (u256_is_zero(&h)) {
+		if (u256_is_zero(&rr)) gej_double(r, a); else gej_set_inf(r);
+		return;
+	}
+	fe hh, hhh, v, x3, y3, z3;
+	fe_sqr(&hh, &h); fe_mul(&hhh, &hh, &h); fe_mul(&v, &a->x, &hh);
+	fe_sqr(&x3, &rr); fe_sub(&x3, &x3, &hhh); fe_add(&t, &v, &v); fe_sub(&x3, &x3, &t);
+	fe_sub(&t, &v, &x3); fe_mul(&y3, &rr, &t); fe_mul(&t, &a->y, &hhh); fe_sub(&y3, &y3, &t);
+	fe_mul(&z3, &a->z, &h);
+	r->x = x3; r->y = y3; r->z = z3; r->inf = 0;
 }
 static void ge_set_gej(ge *r, const gej *a)
 {

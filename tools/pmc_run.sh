@@ -4,10 +4,10 @@
 # Counter passes use --kernel-trace only (gpurun refuses --pmc with sys/hip tracing).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/pmc_r01
+OUT=$R/gpurun_out/pmc_r01b
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0"
+CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --skip-extra"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.json 2> $OUT/fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.json 2> $OUT/write.err
