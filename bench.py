@@ -157,6 +157,11 @@ def main():
                          "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
                          "algorithmic_mul32_per_verify": W_ECDSA65, "avg_launch_ms": ke[2], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,
+                         # with per-key tables part of the algorithmic work is done once per key outside the dominant kernel, so the
+                         # per-kernel fraction flatters it; the pipeline figure charges ALL ECDSA kernels of the step (prep + key
+                         # parsing/tables + ecmult + parity stage) against the same algorithmic work
+                         "pipeline": {"ms": float(ke.sum()), "achieved": W_ECDSA65 * n / (ke.sum() * 1e-3) / 1e12,
+                                      "frac": W_ECDSA65 * n / (ke.sum() * 1e-3) / P_MUL32},
                          "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,
                                  "peak_GBs": HBM_PEAK_GBS, "frac": algo_bytes / t_ecmult / 1e9 / HBM_PEAK_GBS}},
             "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "against": "verdicts known by construction (all rows)"},

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 passes written by tools/pmc_run.sh (CSV output) into a text file + profiles/pmc_latest.json.
+usage: pmc_summary.py gpurun_out/pmc_rNN profiles/rNN"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+base, outp = sys.argv[1], sys.argv[2]
+
+
+def load(sub, suffix):
+    f = glob.glob("%s/%s/runc/*_%s.csv" % (base, sub, suffix))
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+# ---- kernel trace: durations per kernel, in launch order; ECDSA launches come before Schnorr launches in every step
+trace = load("trace", "kernel_trace")
+dur = collections.defaultdict(list)
+for r in sorted(trace, key=lambda r: int(r["Start_Timestamp"])):
+    dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+lines = ["# rocprofv3 summary, MI355X, `python bench.py --steps 2 --warmup 1 --cpu-sample 0 --skip-extra` (1 M ECDSA-65 + 1 M BIP-340 per step)",
+         "# pass 1: --kernel-trace --stats; passes 2-5: --kernel-trace --pmc ... (FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2), one counter group per run", "",
+         "[kernel trace: calls, mean us, min us]"]
+for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    if k.startswith("k_"):
+        lines.append("  %-28s %4d %12.1f %12.1f" % (k, len(v), sum(v) / len(v), min(v)))
+lines.append("")
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("fetch", "write", "sq", "sq2"):
+    rows = load(sub, "counter_collection")
+    per = collections.defaultdict(list)
+    for r in rows:
+        per[(short(r["Kernel_Name"]), r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["Grid_Size"])))
+    for (k, c), lst in per.items():
+        lst.sort()
+        big = [v for d, v, g in lst if g >= 500000]      # the 1 M-row launches (drop the generators' / tiny launches)
+        if not big:
+            big = [v for d, v, g in lst]
+        # alternate ECDSA / Schnorr launches
+        if k.startswith("k_ecmult") or k.startswith("k_keytable") or k == "k_keys":
+            vals[k + " [ecdsa]"][c] = big[0::2]
+            vals[k + " [schnorr]"][c] = big[1::2]
+        else:
+            vals[k][c] = big
+mean = lambda l: sum(l) / len(l) if l else float("nan")
+summary = {}
+for k in sorted(vals):
+    if not k.startswith("k_"):
+        continue
+    lines.append("[%s]  (per launch, mean)" % k)
+    d = {}
+    for c in sorted(vals[k]):
+        d[c] = mean(vals[k][c])
+        lines.append("  %-22s %.6g" % (c, d[c]))
+    summary[k] = d
+    lines.append("")
+hot = next((k for k in summary if k.startswith("k_ecmult_keyed") and "[ecdsa]" in k), None) or next(k for k in summary if k.startswith("k_ecmult") and "[ecdsa]" in k)
+e = summary[hot]
+kname = hot.split(" ")[0]
+t = mean(dur[kname][0::2]) * 1e-6 if len(dur[kname]) > 1 else dur[kname][0] * 1e-6
+nwaves = e.get("SQ_WAVES", 15625)
+hbm = (e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024
+lines += ["[derived: %s, ECDSA launch]" % kname,
+          "  kernel duration (trace pass, mean of ECDSA launches)   %.3f ms" % (t * 1e3),
+          "  HBM-side bytes (FETCH_SIZE+WRITE_SIZE)*1024             %.3e B -> %.0f GB/s (%.1f %% of 8 TB/s); FETCH x2 reading: %.3e B" % (
+              hbm, hbm / t / 1e9, hbm / t / 8e12 * 100, (2 * e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024),
+          "  VALU wave-instructions per wave (= per signature lane)  %.0f" % (e["SQ_INSTS_VALU"] / nwaves),
+          "  shader clock (GRBM_GUI_ACTIVE / 8 XCDs / t)             %.2f GHz" % (e["GRBM_GUI_ACTIVE"] / 8 / t / 1e9),
+          "  VALU issue: wave-instr / SIMD / cycle                   %.3f (0.25 = saturated for half-rate ops such as v_mad_u64_u32)" % (
+              e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8)),
+          "  SQ_WAIT_ANY / SQ_WAVE_CYCLES                            %.3f" % (e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]),
+          "  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                       %.3f" % (e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"]), ""]
+open(outp + "_pmc_summary.txt", "w").write("\n".join(lines))
+json.dump({"k_ecmult_ecdsa_1M": {"kernel": kname, "hbm_bytes_per_launch": hbm, "fetch_kib": e.get("FETCH_SIZE"), "write_kib": e.get("WRITE_SIZE"),
+                                  "valu_insts_per_verify": e["SQ_INSTS_VALU"] / nwaves,
+                                  "valu_issue_per_simd_cycle": e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8),
+                                  "source": outp + "_pmc_summary.txt (rocprofv3 --pmc, separate passes; FETCH_SIZE uncorrected)"}},
+          open("profiles/pmc_latest.json", "w"), indent=1)
+print("\n".join(lines))
