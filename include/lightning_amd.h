@@ -108,7 +108,7 @@ int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, con
 
 /* Device-resident variant (asynchronous on the context's stream).  d_off: uint64[n+1] byte offsets;
  * d_rowbase: uint64[n+1], d_rowbase[i] = number of signatures in messages 0..i-1 (4 per
- * channel_announcement, 1 otherwise), rows = d_rowbase[n] (at most 2^22 per call). */
+ * channel_announcement, 1 otherwise), rows = d_rowbase[n] (at most one chunk, 2^22 rows, per call). */
 int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_off,
 				      const void *d_node_ids33, const void *d_rowbase, size_t rows,
 				      void *d_verdict);

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <random>
 #include <string>
 #include <vector>
 
@@ -452,8 +453,10 @@ __global__ void __launch_bounds__(256) k_gen_gossip(size_t n_cann, size_t n_cupd
 }
 
 // ---- keyed path kernels (see verify_core.h "Keyed path")
-LAMD_HD u64 key_hash(const u8 *p, int len) {
-  u64 h = 0x243F6A8885A308D3ULL;
+// seeded per context (std::random_device at lamd_init): public keys come from the network, and a fixed hash would let a
+// peer craft keys that all probe the same slots
+LAMD_HD u64 key_hash(const u8 *p, int len, u64 seed) {
+  u64 h = seed;
   for (int o = 0; o < len; o += 8) {
     u64 c = 0;
     for (int b = 0; b < 8 && o + b < len; b++) c |= (u64)p[o + b] << (8 * b);
@@ -483,12 +486,12 @@ __device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight = 
 }
 
 // open-addressing table of row indices (+1); the first row to claim a slot represents its key
-__global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride,
+__global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride, u64 seed,
                                                        u32 *__restrict__ table, u32 mask, u32 *__restrict__ rep) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const u8 *k = keys + stride * i;
-  u32 slot = (u32)key_hash(k, keylen) & mask;
+  u32 slot = (u32)key_hash(k, keylen, seed) & mask;
   for (;;) {
     const u32 old = atomicCAS(&table[slot], 0u, (u32)i + 1u);
     if (old == 0u) { rep[i] = (u32)i; return; }
@@ -611,6 +614,8 @@ __global__ void __launch_bounds__(256) k_schnorr_final_fin(size_t n, u32 *__rest
 //                                        engine
 // =====================================================================================
 
+static constexpr size_t CHUNK_DEFAULT = (size_t)1 << 22;  // signatures per launch sequence (4 GiB of table slots at most; allocated on demand)
+
 struct devbuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -646,6 +651,8 @@ struct lamd_ctx {
   bool timing = false;
   bool ev_recorded = false;
   int ecmult_waves = 3;
+  u64 hash_seed = 0x243F6A8885A308D3ULL;
+  size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double last_ms[4] = {0, 0, 0, 0};
   // streaming queues (pinned host staging)
@@ -693,13 +700,14 @@ static void release(devbuf *b) {
   b->cap = 0;
 }
 
-static constexpr size_t CHUNK = (size_t)1 << 22;  // signatures per launch (4 GiB of table slots at most; allocated on demand)
 
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 
 extern "C" const char *lamd_version(void) { return "lightning_amd 0.1 (gfx950)"; }
 
 extern "C" const char *lamd_last_error(const lamd_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+static int init_known_answers(lamd_ctx *ctx);
 
 extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (!out) return LAMD_ERR_ARG;
@@ -718,6 +726,11 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     return LAMD_ERR_NO_DEVICE;
   }
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
+  {
+    std::random_device rd;
+    ctx->hash_seed = ((u64)rd() << 32) ^ (u64)rd() ^ 0x243F6A8885A308D3ULL;
+  }
+  if (const char *w = getenv("LAMD_CHUNK_ROWS")) ctx->chunk = (size_t)atoll(w) < 4 ? 4 : (size_t)atoll(w);
   if (const char *w = getenv("LAMD_KEYED")) ctx->keyed_mode = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_MIN_USES")) ctx->keyed_min_uses = atof(w);
   if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
@@ -756,7 +769,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipFree(d_bases));
-  return LAMD_OK;
+  return init_known_answers(ctx);
 }
 
 extern "C" void lamd_shutdown(lamd_ctx *ctx) {
@@ -899,8 +912,8 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->kd_count.p, 0, n * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(counters, 0, 32, ctx->stream));
-    hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, (u32 *)ctx->kd_table.p,
-                       (u32)(m - 1), (u32 *)ctx->kd_rep.p);
+    hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, ctx->hash_seed,
+                       (u32 *)ctx->kd_table.p, (u32)(m - 1), (u32 *)ctx->kd_rep.p);
     hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
                        counters, (u32 *)ctx->kd_uniq.p);
     hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
@@ -981,10 +994,10 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
 static int run_device(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
                       size_t keystride, u8 *d_ok) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  for (size_t o = 0; o < n; o += CHUNK) {
-    const size_t m = n - o < CHUNK ? n - o : CHUNK;
+  for (size_t o = 0; o < n; o += ctx->chunk) {
+    const size_t m = n - o < ctx->chunk ? n - o : ctx->chunk;
     const int rc = run_chunk(ctx, mode, m, d_a + 32 * o, d_sig + 64 * o, d_key + keystride * o, keylen, keystride, d_ok + o,
-                             ctx->timing && o + CHUNK >= n);
+                             ctx->timing && o + ctx->chunk >= n);
     if (rc != LAMD_OK) return rc;
   }
   return LAMD_OK;
@@ -1051,6 +1064,34 @@ extern "C" int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t 
     return LAMD_ERR_ARG;
   }
   return run_host(ctx, MODE_SCHNORR, n, msg32, sig64, xonly32, 32, 32, ok);
+}
+
+
+// ---- known-answer check run by lamd_init: a miscompiled or misbehaving device must not hand out verdicts.
+// ECDSA: the BOLT #11 example signature (reference: common/test/run-bolt11.c:465-467, key :310); BIP-340: official vector 1.
+static const u8 KAT_E_HASH[32] = {0x11, 0x6f, 0xdb, 0x0f, 0x18, 0x35, 0x2c, 0x88, 0x6d, 0xeb, 0x26, 0x3f, 0x64, 0x66, 0xeb, 0x40, 0xe5, 0xe6, 0x51, 0x8b, 0x80, 0x23, 0x1a, 0x1f, 0x9d, 0xf8, 0x60, 0x88, 0xbf, 0xa4, 0x80, 0x43};
+static const u8 KAT_E_SIG[64] = {0x26, 0x9f, 0xa6, 0x8a, 0x60, 0x51, 0xf2, 0x69, 0x91, 0xab, 0x50, 0xeb, 0x85, 0x14, 0x94, 0xd1, 0xa4, 0xb9, 0xc6, 0x16, 0xae, 0xee, 0x89, 0x2f, 0xf5, 0x0a, 0x14, 0x4a, 0xf4, 0x71, 0x55, 0x4a, 0x30, 0x57, 0xb2, 0xfe, 0xe4, 0x59, 0x10, 0xe2, 0x67, 0xc4, 0xef, 0x60, 0x67, 0xda, 0x10, 0x01, 0x6c, 0xf5, 0x51, 0x92, 0x37, 0xb3, 0xca, 0x1c, 0x1c, 0x20, 0x14, 0xcc, 0x1d, 0x6f, 0x69, 0xa6};
+static const u8 KAT_E_PUB[33] = {0x03, 0xe7, 0x15, 0x6a, 0xe3, 0x3b, 0x0a, 0x20, 0x8d, 0x07, 0x44, 0x19, 0x91, 0x63, 0x17, 0x7e, 0x90, 0x9e, 0x80, 0x17, 0x6e, 0x55, 0xd9, 0x7a, 0x2f, 0x22, 0x1e, 0xde, 0x0f, 0x93, 0x4d, 0xd9, 0xad};
+static const u8 KAT_S_MSG[32] = {0x24, 0x3f, 0x6a, 0x88, 0x85, 0xa3, 0x08, 0xd3, 0x13, 0x19, 0x8a, 0x2e, 0x03, 0x70, 0x73, 0x44, 0xa4, 0x09, 0x38, 0x22, 0x29, 0x9f, 0x31, 0xd0, 0x08, 0x2e, 0xfa, 0x98, 0xec, 0x4e, 0x6c, 0x89};
+static const u8 KAT_S_PK[32] = {0xdf, 0xf1, 0xd7, 0x7f, 0x2a, 0x67, 0x1c, 0x5f, 0x36, 0x18, 0x37, 0x26, 0xdb, 0x23, 0x41, 0xbe, 0x58, 0xfe, 0xae, 0x1d, 0xa2, 0xde, 0xce, 0xd8, 0x43, 0x24, 0x0f, 0x7b, 0x50, 0x2b, 0xa6, 0x59};
+static const u8 KAT_S_SIG[64] = {0x68, 0x96, 0xbd, 0x60, 0xee, 0xae, 0x29, 0x6d, 0xb4, 0x8a, 0x22, 0x9f, 0xf7, 0x1d, 0xfe, 0x07, 0x1b, 0xde, 0x41, 0x3e, 0x6d, 0x43, 0xf9, 0x17, 0xdc, 0x8d, 0xcf, 0x8c, 0x78, 0xde, 0x33, 0x41, 0x89, 0x06, 0xd1, 0x1a, 0xc9, 0x76, 0xab, 0xcc, 0xb2, 0x0b, 0x09, 0x12, 0x92, 0xbf, 0xf4, 0xea, 0x89, 0x7e, 0xfc, 0xb6, 0x39, 0xea, 0x87, 0x1c, 0xfa, 0x95, 0xf6, 0xde, 0x33, 0x9e, 0x4b, 0x0a};
+static int init_known_answers(lamd_ctx *ctx) {
+  u8 h[64], s[128], p[66], ok[2] = {9, 9};
+  memcpy(h, KAT_E_HASH, 32); memcpy(h + 32, KAT_E_HASH, 32); h[32] ^= 1;   // second row: wrong hash
+  memcpy(s, KAT_E_SIG, 64); memcpy(s + 64, KAT_E_SIG, 64);
+  memcpy(p, KAT_E_PUB, 33); memcpy(p + 33, KAT_E_PUB, 33);
+  int rc = lamd_verify_ecdsa_batch(ctx, 2, h, s, p, 33, 33, ok);
+  if (rc != LAMD_OK) return rc;
+  if (ok[0] != 1 || ok[1] != 0) { ctx->err = "device self-check failed: ECDSA known answer"; return LAMD_ERR_HIP; }
+  u8 m[64], k[64];
+  memcpy(m, KAT_S_MSG, 32); memcpy(m + 32, KAT_S_MSG, 32); m[40] ^= 0x80;
+  memcpy(k, KAT_S_PK, 32); memcpy(k + 32, KAT_S_PK, 32);
+  memcpy(s, KAT_S_SIG, 64); memcpy(s + 64, KAT_S_SIG, 64);
+  ok[0] = ok[1] = 9;
+  rc = lamd_verify_schnorr_batch(ctx, 2, m, k, s, ok);
+  if (rc != LAMD_OK) return rc;
+  if (ok[0] != 1 || ok[1] != 0) { ctx->err = "device self-check failed: BIP-340 known answer"; return LAMD_ERR_HIP; }
+  return LAMD_OK;
 }
 
 // ---- single-item veneers
@@ -1124,13 +1165,14 @@ static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d
   size_t m0 = 0;
   while (m0 < n) {
     size_t m1 = n;
-    if (rows > CHUNK) {
+    if (rows > ctx->chunk) {
       if (!h_rowbase) {
         ctx->err = "gossip batch larger than one chunk needs the host row table (use the host-buffer API or split the batch)";
         return LAMD_ERR_ARG;
       }
       m1 = m0;
-      while (m1 < n && h_rowbase[m1 + 1] - h_rowbase[m0] <= CHUNK) m1++;
+      while (m1 < n && h_rowbase[m1 + 1] - h_rowbase[m0] <= ctx->chunk) m1++;
+      if (m1 == m0) m1 = m0 + 1;  // a single message never exceeds a chunk (at most 4 rows)
     }
     const size_t r0 = h_rowbase ? h_rowbase[m0] : 0, nr = (h_rowbase ? h_rowbase[m1] : rows) - r0;
     rc = run_chunk(ctx, MODE_ECDSA, nr, (const u8 *)ctx->g_hash.p + 32 * r0, (const u8 *)ctx->g_sig.p + 64 * r0,

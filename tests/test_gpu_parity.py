@@ -379,3 +379,53 @@ def test_keyed_path_auto_selection_and_parity(eng, orc):
     inf = eng.info()
     assert not inf["last_keyed"] and inf["last_unique_keys"] > 29000
     assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
+
+
+def test_chunk_splitting_small_chunks(orc, kat):
+    """batches larger than one launch chunk are cut (on message boundaries for gossip); forced here with 1000-row chunks"""
+    import os
+    from lightning_amd import Engine, workload
+    os.environ["LAMD_CHUNK_ROWS"] = "1000"
+    try:
+        e = Engine(0)
+    finally:
+        del os.environ["LAMD_CHUNK_ROWS"]
+    try:
+        w = workload.make_ecdsa(e, 5300, nkeys=40, publen=33)
+        e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+        e.synchronize()
+        assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
+        assert np.array_equal(e.verify_ecdsa(w.cols[0], w.cols[1], w.cols[2]), w.expect)
+        ws = workload.make_schnorr(e, 3100, nkeys=1 << 40)
+        assert np.array_equal(e.verify_schnorr(ws.cols[0], ws.cols[1], ws.cols[2]), ws.expect)
+        g = workload.make_gossip(e, 700, 900, n_nodes=30, corrupt_frac=0.05)     # 3700 rows -> 4 chunks, cut between messages
+        msgs = [g.msgs[int(g.off[i]):int(g.off[i + 1])].tobytes() for i in range(g.n)]
+        ids = [g.ids[i].tobytes() if i >= g.n_cann else None for i in range(g.n)]
+        assert np.array_equal(e.sigcheck_gossip(msgs, ids), g.expect)
+    finally:
+        e.close()
+
+
+def test_streaming_poll_and_error_states(eng, kat):
+    import time
+    from lightning_amd import LamdError
+    v = kat["ecdsa"][0]
+    with pytest.raises(LamdError):
+        eng.wait()                      # nothing flushed
+    for _ in range(300):
+        eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))
+    eng.flush()
+    with pytest.raises(LamdError):
+        eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))     # results of the previous flush not collected yet
+    with pytest.raises(LamdError):
+        eng.flush()
+    got, t0 = None, time.time()
+    while got is None and time.time() - t0 < 10:
+        got = eng.poll()
+    assert got is not None and len(got) == 300 and all(bool(x) == v["expect"] for x in got)
+    with pytest.raises(ValueError):
+        eng.verify_ecdsa(np.zeros((2, 32), np.uint8), np.zeros((2, 64), np.uint8), np.zeros((2, 40), np.uint8))   # 40-byte keys
+    import ctypes
+    ok = (ctypes.c_uint8 * 2)()
+    rc = eng._lib.lamd_verify_ecdsa_batch(eng._ctx, 2, bytes(64), bytes(128), bytes(80), 40, 40, ok)               # and through the raw ABI
+    assert rc == -3
