@@ -83,6 +83,16 @@ int lamd_check_signed_hash_nodeid(lamd_ctx *ctx, const uint8_t hash32[32], const
 int lamd_check_schnorr_sig(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t pubkey33[33],
 			   const uint8_t bip340sig64[64]);                   /* bitcoin/signature.h:129-131 */
 
+/* ---- n independent check_tx_sig() calls (bitcoin/signature.c:194-221, decl signature.h:120-124) on caller-built
+ * BIP143 preimages: preimage i = preimages[off[i]..off[i+1]) is what wally_tx_get_btc_signature_hash() hashes for
+ * (tx, input, script, amount, sighash_type) -- signature.c:145-148.  The device applies the sighash-type gate
+ * (:206-211: SIGHASH_ALL, or SINGLE|ANYONECANPAY only with a witness script), double-SHA256s the preimage and
+ * verifies.  This is also the shape of onchaind's fee grind (one signature/key against many candidate
+ * transactions, onchaind/onchaind.c:389-438): pass the same sig/key n times. */
+int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *preimages, const uint64_t *off,
+			    const uint8_t *sighash_type, const uint8_t *has_witness_script,
+			    const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
+
 /* ---- public-key parsing: n independent pubkey_from_der() / pubkey_from_node_id() calls
  * (bitcoin/pubkey.c:14-24, common/node_id.c:21-27 -> secp256k1_ec_pubkey_parse; publen 33 or 65),
  * or secp256k1_xonly_pubkey_parse with publen 32 (bitcoin/signature.c:422).  ok[i] = validity,

@@ -29,6 +29,7 @@ SYMBOLS = {
     "lamd_check_signed_hash": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, c_sz]),
     "lamd_check_signed_hash_nodeid": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
     "lamd_check_schnorr_sig": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
+    "lamd_check_tx_sig_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_u8p]),
     "lamd_pubkey_parse_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_sz, c_sz, c_u8p, c_u8p]),
     "lamd_sigcheck_gossip_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p]),
     "lamd_queue_ecdsa": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, c_sz]),

@@ -164,6 +164,26 @@ LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
   }
 }
 
+// ---- check_tx_sig batches: double-SHA256 of caller-built BIP143 preimages (bitcoin/signature.c:120-151 hashes them
+// through libwally) and the sighash-type gate of bitcoin/signature.c:206-211
+__global__ void __launch_bounds__(256) k_txsig_hash(size_t n, const u8 *__restrict__ pre, const u64 *__restrict__ off,
+                                                    const u8 *__restrict__ sighash_type, const u8 *__restrict__ has_witness,
+                                                    u8 *__restrict__ hash32, u8 *__restrict__ gate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u8 t = sighash_type[i];
+  // only SIGHASH_ALL, or SINGLE|ANYONECANPAY with a witness script
+  const bool pass = t == 1 || (t == 0x83 && has_witness[i]);
+  gate[i] = pass;
+  u8 h[32];
+  if (pass) sha256d_bytes(pre + off[i], (size_t)(off[i + 1] - off[i]), h);
+  for (int b = 0; b < 32; b++) hash32[32 * i + b] = pass ? h[b] : 0;
+}
+__global__ void __launch_bounds__(256) k_apply_gate(size_t n, const u8 *__restrict__ gate, u8 *__restrict__ ok) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !gate[i]) ok[i] = 0;
+}
+
 enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };
 
 // rowbase[i] = index of message i's first signature row; malformed[i] set here for framing errors
@@ -1145,6 +1165,48 @@ extern "C" int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
       store_words_be(out64 + 64 * i + 32, &words[i * 16 + 8]);
     }
   return LAMD_OK;
+}
+
+// ---- check_tx_sig batches
+extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *preimages, const uint64_t *off, const uint8_t *sighash_type,
+                                       const uint8_t *has_witness, const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride,
+                                       uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!preimages || !off || !sighash_type || !has_witness || !sig64 || !pub || !ok || (publen != 33 && publen != 65) || pubstride < publen) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t total = off[n] - off[0];
+  std::vector<u64> rel(n + 1);
+  for (size_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+  int rc;
+  if ((rc = ensure(ctx, &ctx->g_msgs, total + 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_off, (n + 1) * 8)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_ids, 2 * n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * pubstride)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  u8 *d_types = (u8 *)ctx->g_ids.p, *d_wit = d_types + n;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, preimages + off[0], total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_types, sighash_type, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_wit, has_witness, n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_txsig_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p,
+                     (const u8 *)d_types, (const u8 *)d_wit, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p);
+  HIPCHK(ctx, hipGetLastError());
+  rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
+                  (u8 *)ctx->out.p);
+  if (rc != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);
 }
 
 // ---- gossip

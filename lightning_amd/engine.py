@@ -84,6 +84,21 @@ class Engine:
                                                       ok.ctypes.data))
         return ok.astype(bool)
 
+    def check_tx_sig_batch(self, preimages, sighash_types, has_witness, sig64, pub):
+        """preimages: list of bytes (BIP143 preimages); returns bool verdicts (gate + SHA256d + verify, all on the device)"""
+        n = len(preimages)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(p) for p in preimages], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(preimages) + b"\x00", dtype=np.uint8)
+        types = np.ascontiguousarray(sighash_types, dtype=np.uint8)
+        wit = np.ascontiguousarray(has_witness, dtype=np.uint8)
+        sig64 = _u8(sig64, 64)
+        pub = np.ascontiguousarray(pub, dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.lamd_check_tx_sig_batch(self._ctx, n, blob.ctypes.data, off.ctypes.data, types.ctypes.data, wit.ctypes.data,
+                                                    sig64.ctypes.data, pub.ctypes.data, pub.shape[1], pub.shape[1], ok.ctypes.data))
+        return ok.astype(bool)
+
     def pubkey_parse(self, pub):
         pub = np.ascontiguousarray(pub, dtype=np.uint8)
         n, ln = pub.shape

@@ -57,6 +57,8 @@ def lib():
         L.orc_schnorr_verify_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_int]
         L.orc_schnorr_verify_batch.restype = None
+        L.orc_sigcheck_gossip_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.orc_sigcheck_gossip_batch.restype = None
         L.orc_init()
         _lib = L
     return _lib
@@ -157,6 +159,15 @@ def schnorr_verify_batch(msgs, xonly, sigs, nthreads=1):
     n = msgs.shape[0]
     out = np.zeros(n, dtype=np.uint8)
     lib().orc_schnorr_verify_batch(n, msgs.ctypes.data, xonly.ctypes.data, sigs.ctypes.data, out.ctypes.data, nthreads)
+    return out
+
+
+def sigcheck_gossip_batch(msgs, off, ids, nthreads=1):
+    """msgs: uint8 blob, off: uint64 [n+1], ids: uint8 [n,33] -> int8 [n]"""
+    import numpy as np
+    n = off.shape[0] - 1
+    out = np.zeros(n, dtype=np.int8)
+    lib().orc_sigcheck_gossip_batch(n, msgs.ctypes.data, off.ctypes.data, ids.ctypes.data, out.ctypes.data, nthreads)
     return out
 
 

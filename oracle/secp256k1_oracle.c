@@ -712,6 +712,25 @@ void orc_schnorr_verify_batch(size_t n, const uint8_t *msg32, const uint8_t *xon
 		out[i] = (uint8_t)orc_schnorr_verify(msg32 + 32 * i, xonly32 + 32 * i, sig64 + 64 * i);
 }
 
+/* per-message gossip verdicts for a concatenated batch (kind from the 2-byte type; node_ids33[i] is the signer of a
+ * channel_update) */
+void orc_sigcheck_gossip_batch(size_t n, const uint8_t *msgs, const uint64_t *off, const uint8_t *node_ids33, int8_t *out,
+			       int nthreads)
+{
+	orc_init();
+	long i;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
+	for (i = 0; i < (long)n; i++) {
+		const uint8_t *m = msgs + off[i];
+		size_t len = (size_t)(off[i + 1] - off[i]);
+		int v = -1;
+		if (len >= 2 && m[0] == 1 && m[1] == 0) v = orc_sigcheck_channel_announcement(m, len);
+		else if (len >= 2 && m[0] == 1 && m[1] == 1) v = orc_sigcheck_node_announcement(m, len);
+		else if (len >= 2 && m[0] == 1 && m[1] == 2) v = orc_sigcheck_channel_update(m, len, node_ids33 + 33 * i);
+		out[i] = (int8_t)v;
+	}
+}
+
 /* ------------------------------------------------------------------ signing (vector generation only) */
 static int seckey_load(sc *d, const uint8_t seckey32[32])
 {

@@ -73,6 +73,9 @@ void orc_ecdsa_verify_batch(size_t n, const uint8_t *hash32, const uint8_t *sig6
 void orc_schnorr_verify_batch(size_t n, const uint8_t *msg32, const uint8_t *xonly32,
 			      const uint8_t *sig64, uint8_t *out, int nthreads);
 
+void orc_sigcheck_gossip_batch(size_t n, const uint8_t *msgs, const uint64_t *off, const uint8_t *node_ids33,
+			       int8_t *out, int nthreads);
+
 /* ---- test-vector generation only (the reference signs via hsmd; never on this path) ---- */
 int orc_pubkey_create(const uint8_t seckey32[32], uint8_t out65[65]);
 int orc_ecdsa_sign(const uint8_t hash32[32], const uint8_t seckey32[32],

@@ -429,3 +429,31 @@ def test_streaming_poll_and_error_states(eng, kat):
     ok = (ctypes.c_uint8 * 2)()
     rc = eng._lib.lamd_verify_ecdsa_batch(eng._ctx, 2, bytes(64), bytes(128), bytes(80), 40, 40, ok)               # and through the raw ABI
     assert rc == -3
+
+
+def test_check_tx_sig_batch_fee_grind_kat(eng, kat):
+    """onchaind/test/run-grind_feerate.c:119-154 through the device: 1000 candidate fees for one HTLC signature/key --
+    check_tx_sig must accept exactly fee = 165 750 sat; plus the sighash-type gate of bitcoin/signature.c:206-211"""
+    import pyref
+    ko = next(v for v in kat["der"] if v["name"] == "KAT-O")
+    sig = H(ko["expect_sig"])
+    key = H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f")
+    tx = H("0200000001e1ebca08cf1c301ac563580a1126d5c8fcb0e5e2043230b852c726553caf1e1d0000000000000000000160ae0a0000000000"
+           "22002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d61927436041796d000000")
+    txid, vout, seq, spk, lock = tx[5:37], 0, 0, tx[56:90], 109
+    ws = H("76a914a8c40c334351dbe8e5908544f1c98fbcfb8719fc8763ac6721038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de05"
+           "4432eb7f7c820120876475527c2103cf8e2f193a6aed60db80af75f3c8d59c2de735b299b7c7083527be9bd23b77a852ae67a914b8bcd51e"
+           "fa35be1e50ae2d5f72f4500acb005c9c88ac6868")
+    fees = list(range(165750 - 600, 165750 + 400))       # the reference grinds 1000 feerates
+    pres = [pyref.bip143_sighash(2, [(txid, vout, seq)], [(700000 - f, spk)], lock, 0, ws, 700000, 1)[1] for f in fees]
+    assert all(len(p) == 290 for p in pres)
+    n = len(fees)
+    got = eng.check_tx_sig_batch(pres, [1] * n, [1] * n, _rows([sig] * n, 64), _rows([key] * n, 33))
+    assert got.sum() == 1 and fees[int(np.argmax(got))] == 165750
+    # the gate: same good preimage under other sighash types / without witness script
+    good = pres[600]
+    types = [1, 0x83, 0x83, 2, 3, 0x81, 0, 1]
+    wit = [1, 1, 0, 1, 1, 1, 1, 0]
+    got = eng.check_tx_sig_batch([good] * 8, types, wit, _rows([sig] * 8, 64), _rows([key] * 8, 33))
+    # only SIGHASH_ALL rows verify (the 0x83 row passes the gate but the signature commits to SIGHASH_ALL's preimage)
+    assert list(got) == [True, False, False, False, False, False, False, True]
