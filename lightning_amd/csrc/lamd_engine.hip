@@ -893,7 +893,7 @@ static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, cons
   return LAMD_OK;
 }
 
-// One chunk (n <= CHUNK) entirely on the context's streams.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
+// One chunk (n <= ctx->chunk rows) entirely on the context's streams.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
 //  1. scalar prep for every row on stream2 (independent of the key work; joined by event before the ecmult kernels)
 //  2. big chunks: de-duplicate the keys on the device; keys carried by >= keyed_min_uses rows are "hot": each gets a
 //     window table in HBM and its rows are verified by the table-driven kernel (no / few doublings); the other
