@@ -186,8 +186,8 @@ typedef struct {
 	double last_kernel_ms[4]; /* prep, keys (+ key tables), ecmult, BIP-340 parity stage of the last launch sequence when timing is on */
 	size_t last_unique_keys;  /* distinct public keys found in the last chunk (0 if it was not examined) */
 	size_t last_hot_rows;     /* rows of the last chunk verified against per-key tables (the rest took the ladder) */
-	int last_keyed;           /* 0: per-signature ladder; else the last chunk ran on per-key tables and this is the comb
-				   * spacing used (1 = one position per nibble, 8 = five positions) */
+	int last_keyed;           /* 0: per-signature ladder only; else rows of the last chunk ran on per-key tables and this is
+				   * the comb spacing used (1 = dense: one table position per window digit, 7 / 8 = comb) */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */

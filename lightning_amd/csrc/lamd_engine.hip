@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(256) k_dedupe_partition(size_t n, const u32 *_
   if (hot) list_hot[ph] = (u32)i;
   else if (live) list_cold[pc] = (u32)i;
 }
-template <int S>
+template <int W, int S>
 __global__ void __launch_bounds__(256) k_keytable_build(size_t nuniq, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
                                                         u32 *__restrict__ tables, u32 *__restrict__ scratch) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -585,10 +585,10 @@ __global__ void __launch_bounds__(256) k_keytable_build(size_t nuniq, const u32 
   u32 qx[8], qy[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
-  keytable_build<S>(tables + u * kt_stride(S), scratch + u * kt_scratch_words(S), ge_from_words(qx, qy));
+  keytable_build<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S), ge_from_words(qx, qy));
 }
 // work item j verifies row list[j] against the table of its (hot) key
-template <int S>
+template <int W, int S>
 __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *__restrict__ list, const prep_rec *__restrict__ recs,
                                                       const u32 *__restrict__ key_id, const u32 *__restrict__ hotidx,
                                                       const u8 *__restrict__ keyok_u, const u32 *__restrict__ tables,
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *_
   keyok_row[i] = kok;
   bool ok = (rec.flags & PREP_VALID) && kok;
   if (ok) {
-    const gej R = ecmult_lane_keyed<S>(rec, tables + (size_t)kid * kt_stride(S), gtable);
+    const gej R = ecmult_lane_keyed<W, S>(rec, tables + (size_t)kid * kt_stride(W, S), gtable);
     u32 rw[8];
     load_words_be(rw, sig64 + 64 * i);
     if (mode == MODE_ECDSA) {
@@ -661,7 +661,8 @@ struct lamd_ctx {
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
   double keyed_dense_uses = 48.0;  // ... and for the dense one-position-per-nibble table
-  int keyed_spacing = 0;           // 0 = choose by re-use, else force S = 1 or 8 (LAMD_KEYED_SPACING)
+  int keyed_spacing = 0;           // 0 = choose by re-use, 1 = force dense tables, anything else = force the comb (LAMD_KEYED_SPACING)
+  int keyed_window = 5;            // window width of the key tables: 5 (default) or 4 (LAMD_KEYED_WINDOW)
   int last_spacing = 0;
   size_t last_unique_keys = 0;
   bool last_keyed = false;
@@ -754,7 +755,8 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED")) ctx->keyed_mode = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_MIN_USES")) ctx->keyed_min_uses = atof(w);
   if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
-  if (const char *w = getenv("LAMD_KEYED_SPACING")) ctx->keyed_spacing = atoi(w) == 1 ? 1 : (atoi(w) == 8 ? 8 : 0);
+  if (const char *w = getenv("LAMD_KEYED_SPACING")) ctx->keyed_spacing = atoi(w) == 1 ? 1 : (atoi(w) > 1 ? 8 : 0);
+  if (const char *w = getenv("LAMD_KEYED_WINDOW")) ctx->keyed_window = atoi(w) == 4 ? 4 : 5;
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -953,16 +955,21 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   u8 *keyok_row = nullptr;
   u32 *fin = nullptr;
   if (nhot) {
-    // comb spacing: one position per nibble (no doublings, 25 KiB/key) for heavily re-used keys, five positions otherwise
-    const int S = ctx->keyed_spacing ? ctx->keyed_spacing : ((double)hot_rows >= ctx->keyed_dense_uses * (double)nhot ? 1 : 8);
+    // table shape: dense (one position per digit, no doublings) for heavily re-used keys, a comb otherwise;
+    // 5-bit windows by default (16 entries per position, 26 digits), 4-bit as the alternative (LAMD_KEYED_WINDOW)
+    const bool dense = ctx->keyed_spacing ? ctx->keyed_spacing == 1 : (double)hot_rows >= ctx->keyed_dense_uses * (double)nhot;
+    const int W = ctx->keyed_window;
+    const int S = dense ? 1 : (W == 5 ? 7 : 8);
+    const size_t stride_w = W == 5 ? (dense ? kt_stride(5, 1) : kt_stride(5, 7)) : (dense ? kt_stride(4, 1) : kt_stride(4, 8));
+    const size_t scratch_w = W == 5 ? (dense ? kt_scratch_words(5, 1) : kt_scratch_words(5, 7)) : (dense ? kt_scratch_words(4, 1) : kt_scratch_words(4, 8));
     ctx->last_keyed = true;
     ctx->last_spacing = S;
     ctx->last_hot_rows = hot_rows;
     if ((rc = ensure(ctx, &ctx->keyok_row, n)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &ctx->kt_qwords, nhot * 64)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &ctx->kt_keyok, nhot)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kt_tables, nhot * (size_t)kt_stride(S) * 4)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kt_scratch, nhot * (size_t)kt_scratch_words(S) * 4)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kt_tables, nhot * stride_w * 4)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->kt_scratch, nhot * scratch_w * 4)) != LAMD_OK) return rc;
     if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
     keyok_row = (u8 *)ctx->keyok_row.p;
     fin = mode == MODE_SCHNORR ? (u32 *)ctx->kt_fin.p : nullptr;
@@ -971,8 +978,11 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
                        (const u32 *)ctx->kd_hotidx.p, (u32 *)ctx->kd_counter.p, (u32 *)ctx->kd_listhot.p, (u32 *)ctx->kd_listcold.p);
     hipLaunchKernelGGL(k_keys, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, d_key, keylen, keystride, (const u32 *)ctx->kd_hotrow.p,
                        (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
-    hipLaunchKernelGGL(S == 1 ? k_keytable_build<1> : k_keytable_build<8>, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot,
-                       (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
+    {
+      auto kb = W == 5 ? (dense ? k_keytable_build<5, 1> : k_keytable_build<5, 7>) : (dense ? k_keytable_build<4, 1> : k_keytable_build<4, 8>);
+      hipLaunchKernelGGL(kb, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p,
+                         (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
+    }
     const size_t ncold = n - hot_rows;
     if (ncold) {
       // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few
@@ -988,7 +998,8 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     }
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-    hipLaunchKernelGGL(S == 1 ? k_ecmult_keyed<1> : k_ecmult_keyed<8>, dim3(blocks_for(hot_rows)), dim3(256), 0, ctx->stream, hot_rows,
+    auto ke = W == 5 ? (dense ? k_ecmult_keyed<5, 1> : k_ecmult_keyed<5, 7>) : (dense ? k_ecmult_keyed<4, 1> : k_ecmult_keyed<4, 8>);
+    hipLaunchKernelGGL(ke, dim3(blocks_for(hot_rows)), dim3(256), 0, ctx->stream, hot_rows,
                        (const u32 *)ctx->kd_listhot.p, recs, (const u32 *)ctx->kd_keyid.p, (const u32 *)ctx->kd_hotidx.p,
                        (const u8 *)ctx->kt_keyok.p, (const u32 *)ctx->kt_tables.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_row, d_ok);
     if (ncold) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));

@@ -223,9 +223,12 @@ LAMD_HD fe slot_load_fe(const u32 *src) {
   return fe_from_words(w);
 }
 
-// Build the lane's table of 1Q..8Q brought to one shared Z (returned): entry e = (e+1)*Q as an
-// affine point of the isomorphic curve y^2 = x^3 + 7*Zg^6, stored as x | beta*x | y.
-LAMD_HD fe build_q_table(u32 *slot, const ge &q) {
+// Build a table of 1Q..NE*Q brought to one shared Z (returned): entry e = (e+1)*Q as an affine point of the
+// isomorphic curve y^2 = x^3 + 7*Zg^6, stored as x | beta*x | y (SLOT_ENTRY_WORDS each); the NE-2 values H of the
+// addition chain are parked right behind the entries (NE*SLOT_ENTRY_WORDS .. + (NE-2)*8 words) until the rescale pass.
+template <int NE>
+LAMD_HD fe build_multiples(u32 *slot, const ge &q) {
+  constexpr int H_OFF = NE * SLOT_ENTRY_WORDS;
   gej p = gej_from_ge(q);
   slot_store_fe(slot + 0, p.x);
   slot_store_fe(slot + 16, p.y);
@@ -233,28 +236,28 @@ LAMD_HD fe build_q_table(u32 *slot, const ge &q) {
   slot_store_fe(slot + SLOT_ENTRY_WORDS + 0, p.x);
   slot_store_fe(slot + SLOT_ENTRY_WORDS + 16, p.y);
 #pragma unroll 1
-  for (int i = 2; i < 8; i++) {  // entry i = (i+1)Q = entry(i-1) + Q
+  for (int i = 2; i < NE; i++) {  // entry i = (i+1)Q = entry(i-1) + Q
     bool degenerate;
     fe h, rr;
-    p = gej_add_ge_core(p, q, &degenerate, &h, &rr);  // (i)Q = +-Q is impossible for i in 2..8: no degenerate case
+    p = gej_add_ge_core(p, q, &degenerate, &h, &rr);  // (i)Q = +-Q is impossible for i in 2..NE: no degenerate case
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, p.x);
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, p.y);
-    slot_store_fe(slot + SLOT_H_OFF + (i - 2) * 8, h);
+    slot_store_fe(slot + H_OFF + (i - 2) * 8, h);
   }
   const fe zg = fe_norm_weak(p.z);
   const u32 betaw[8] = LAMD_BETA;
   const fe beta = fe_from_words(betaw);
-  // entry 7 already has Z = Zg
+  // the last entry already has Z = Zg
   {
-    const fe x = slot_load_fe(slot + 7 * SLOT_ENTRY_WORDS);
-    slot_store_fe(slot + 7 * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
+    const fe x = slot_load_fe(slot + (NE - 1) * SLOT_ENTRY_WORDS);
+    slot_store_fe(slot + (NE - 1) * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
   }
   fe rho = fe_set_int(1);
 #pragma unroll 1
-  for (int i = 6; i >= 0; i--) {
+  for (int i = NE - 2; i >= 0; i--) {
     // rho = Zg / Z_entry(i): entry i+1 = entry i + Q had Z_{i+1} = Z_i * H (H stored at index i-1 for i >= 1),
     // and entry 1 = 2Q has Z = Z_2, entry 0 = Q has Z = 1 so its ratio is Zg itself.
-    if (i >= 1) rho = fe_mul(rho, slot_load_fe(slot + SLOT_H_OFF + (i - 1) * 8));
+    if (i >= 1) rho = fe_mul(rho, slot_load_fe(slot + H_OFF + (i - 1) * 8));
     else rho = zg;
     const fe r2 = fe_sqr(rho);
     const fe r3 = fe_mul(r2, rho);
@@ -266,6 +269,8 @@ LAMD_HD fe build_q_table(u32 *slot, const ge &q) {
   }
   return zg;
 }
+// the per-signature ladder's table: 1Q..8Q inside the lane's 1 KiB slot
+LAMD_HD fe build_q_table(u32 *slot, const ge &q) { return build_multiples<8>(slot, q); }
 
 LAMD_HD int glv_digit(const u32 mag[4], u32 top, int i) {
   // window i of the biased magnitude; i == 32 is the carry bit
@@ -341,40 +346,45 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
 // 4(S-1) doublings and 66 mixed additions per verification instead of 132 + 66:
 //   S = 1 (33 positions, 25 KiB/key): no doublings at all -- for heavily re-used keys (>= ~64 signatures/key)
 //   S = 8 ( 5 positions,  4 KiB/key): 28 doublings, a 7x cheaper table -- pays from ~6 signatures per key
-constexpr int kt_npos(int S) { return 32 / S + 1; }
-constexpr int kt_words(int S) { return kt_npos(S) * 8 * SLOT_ENTRY_WORDS; }
-constexpr int kt_stride(int S) { return kt_words(S) + 64; }      // + room for the last position's parked H values
-constexpr int kt_scratch_words(int S) { return kt_npos(S) * 36; } // per key and position: Jacobian base X, Y (18), Z_pos (9), prefix product (9)
+// Window width W = 4: signed nibbles of the bias-recoded half-scalar as stored in prep_rec (digits -8..7, 8 table entries
+// per position, 32 nibbles + the recoding carry = 33 digits).  W = 5: the kernel re-biases |k| with 16 per 5-bit group
+// (digits -16..15, 16 entries per position); |k| < 2^128 and the bias < 0.52 * 2^130 never carry out of 26 groups, so
+// there is no carry digit: 26 digits dense, padded to 28 (two structurally zero digits) for the 4-position comb.
+constexpr int kt_ne(int W) { return 1 << (W - 1); }                                   // table entries per position
+constexpr int kt_ndigits(int W, int S) { return W == 4 ? 32 : (S == 1 ? 26 : 28); }   // digits handled by the chunks
+constexpr int kt_npos(int W, int S) { return kt_ndigits(W, S) / S + (W == 4 ? 1 : 0); }  // + W = 4's carry position
+constexpr int kt_words(int W, int S) { return kt_npos(W, S) * kt_ne(W) * SLOT_ENTRY_WORDS; }
+constexpr int kt_stride(int W, int S) { return kt_words(W, S) + 128; }  // + the last position's parked H values (<= 112) + Zc
+constexpr int kt_scratch_words(int W, int S) { return kt_npos(W, S) * 36; }  // per position: base X, Y (18), Z_pos (9), prefix (9)
+constexpr int KT_ZC_OFF = 112;  // word offset of Zc inside the stride padding
 
 LAMD_HD void store_raw(u32 *dst, const fe &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) dst[i] = a.n[i];
 }
 
-// One thread builds one key's table.  tab: kt_stride(S) words, scratch: kt_scratch_words(S) (both lane-private).
+// One thread builds one key's table.  tab: kt_stride(W,S) words, scratch: kt_scratch_words(W,S) (both lane-private).
 // No inversion anywhere: every position's multiples are first affine on that position's own isomorphic curve
-// (Z_pos = Z of the Jacobian base x the shared Z of its 8 multiples), then all positions are brought to ONE
+// (Z_pos = Z of the Jacobian base x the shared Z of its multiples), then all positions are brought to ONE
 // common Zc = prod Z_pos by multiplying with the product of the OTHER positions' Z (prefix x suffix products).
 // The table therefore holds affine points of the curve y^2 = x^3 + 7*Zc^6; Zc is stored behind the entries and the
 // table-driven ecmult multiplies it back into the accumulator's Z before the G additions.
-constexpr int KT_ZC_OFF = 48;  // word offset of Zc inside the 64-word stride padding (the first 48 hold parked H values)
-
-template <int S>
+template <int W, int S>
 LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
-  constexpr int NP = kt_npos(S);
-  // 1. bases B_c = 16^(c*S) * Q in Jacobian form (a chain of 4*S doublings per position)
+  constexpr int NP = kt_npos(W, S), NE = kt_ne(W);
+  // 1. bases B_c = 2^(W*S*c) * Q in Jacobian form (a chain of W*S doublings per position)
   gej b = gej_from_ge(q);
 #pragma unroll 1
   for (int pos = 0; pos < NP; pos++) {
     if (pos) {
 #pragma unroll 1
-      for (int j = 0; j < 4 * S; j++) b = gej_double(b);
+      for (int j = 0; j < W * S; j++) b = gej_double(b);
     }
     store_raw(scratch + pos * 36 + 0, b.x);
     store_raw(scratch + pos * 36 + 9, b.y);
     store_raw(scratch + pos * 36 + 18, fe_norm_weak(b.z));
   }
-  // 2. per position: 1B..8B with (X, Y) of the Jacobian base taken as an affine point of the base's isomorphic curve;
+  // 2. per position: 1B..NE*B with (X, Y) of the Jacobian base taken as an affine point of the base's isomorphic curve;
   //    Z_pos = Zg * Z_base; running prefix products prod_{j<pos} Z_j
   fe acc = fe_set_int(1);
 #pragma unroll 1
@@ -382,16 +392,16 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
     ge base;
     base.x = slot_load_raw(scratch + pos * 36 + 0);
     base.y = slot_load_raw(scratch + pos * 36 + 9);
-    u32 *t = tab + pos * 8 * SLOT_ENTRY_WORDS;
-    // build_q_table also parks six H values behind its 8 entries: inside the table that is the next position's
-    // first entries (rewritten when that position is built) or, for the last position, the stride padding
-    const fe zg = build_q_table(t, base);
+    u32 *t = tab + pos * NE * SLOT_ENTRY_WORDS;
+    // build_multiples parks its H values behind the position's entries: that is the next position's first entries
+    // (rewritten when that position is built) or, for the last position, the stride padding
+    const fe zg = build_multiples<NE>(t, base);
     const fe zpos = fe_mul(zg, slot_load_raw(scratch + pos * 36 + 18));
     store_raw(scratch + pos * 36 + 18, zpos);
     store_raw(scratch + pos * 36 + 27, acc);  // prefix
     acc = fe_mul(acc, zpos);
   }
-  slot_store_fe(tab + kt_words(S) + KT_ZC_OFF, acc);  // Zc
+  slot_store_fe(tab + kt_words(W, S) + KT_ZC_OFF, acc);  // Zc
   // 3. unify: entry *= (prefix * suffix)^2 / ^3
   const u32 betaw[8] = LAMD_BETA;
   const fe beta = fe_from_words(betaw);
@@ -403,8 +413,8 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
     const fe r2 = fe_sqr(ratio);
     const fe r3 = fe_mul(r2, ratio);
 #pragma unroll 1
-    for (int e = 0; e < 8; e++) {
-      u32 *ent = tab + (pos * 8 + e) * SLOT_ENTRY_WORDS;
+    for (int e = 0; e < NE; e++) {
+      u32 *ent = tab + (pos * NE + e) * SLOT_ENTRY_WORDS;
       const fe x = fe_mul(slot_load_fe(ent + 0), r2);
       const fe y = fe_mul(slot_load_fe(ent + 16), r3);
       slot_store_fe(ent + 0, x);
@@ -414,10 +424,11 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
   }
 }
 
+template <int NE>
 LAMD_HD gej gej_add_table_digit(const gej &acc, const u32 *tab, int pos, int d, bool lambda_half) {
   const bool skip = d == 0;
   const int a = d < 0 ? -d : d;
-  const u32 *e = tab + (pos * 8 + (skip ? 0 : a - 1)) * SLOT_ENTRY_WORDS;
+  const u32 *e = tab + (pos * NE + (skip ? 0 : a - 1)) * SLOT_ENTRY_WORDS;
   ge pt;
   pt.x = slot_load_fe(e + (lambda_half ? 8 : 0));
   pt.y = slot_load_fe(e + 16);
@@ -425,31 +436,72 @@ LAMD_HD gej gej_add_table_digit(const gej &acc, const u32 *tab, int pos, int d, 
   return gej_add_ge(acc, pt, skip);
 }
 
+// 5-bit recoding of one GLV half from its prep_rec form: |k| = mag + top*2^128 - 0x88..8, then + 16 per 5-bit group
+struct glv5 { u32 v[5]; };
+LAMD_HD glv5 glv5_from_rec(const u32 mag[4], u32 top) {
+  // 16 * sum_{i<28} 32^i as 32-bit words (140 bits)
+  const u32 bias5[5] = {0x21084210u, 0x08421084u, 0x42108421u, 0x10842108u, 0x00000842u};
+  glv5 r;
+  u64 c = 0;
+  u32 t[5];
+  // t = mag + top*2^128 - 0x88888888 x4
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const u64 d = (u64)mag[i] - 0x88888888u - c;
+    t[i] = (u32)d;
+    c = (d >> 32) & 1;
+  }
+  t[4] = top - (u32)c;
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    c += (u64)t[i] + bias5[i];
+    r.v[i] = (u32)c;
+    c >>= 32;
+  }
+  return r;
+}
+LAMD_HD int glv5_digit(const glv5 &g, int i) {
+  const int bit = 5 * i, w = bit >> 5, sh = bit & 31;
+  const u64 win = (u64)g.v[w] | ((u64)(w + 1 < 5 ? g.v[w + 1] : 0u) << 32);
+  return (int)((win >> sh) & 31u) - 16;
+}
+
 // R = u1*G + (k1 + k2*lambda)*Q from the key's table
-template <int S>
+template <int W, int S>
 LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gtable) {
-  constexpr int NC = 32 / S;  // chunks
+  constexpr int ND = kt_ndigits(W, S), NC = ND / S, NE = kt_ne(W);
   const bool n1 = rec.flags & PREP_K1NEG, n2 = rec.flags & PREP_K2NEG;
   const u32 t1 = (rec.flags & PREP_K1TOP) ? 1u : 0u, t2 = (rec.flags & PREP_K2TOP) ? 1u : 0u;
+  glv5 g1, g2;
+  if (W == 5) {
+    g1 = glv5_from_rec(rec.k1, t1);
+    g2 = glv5_from_rec(rec.k2, t2);
+  }
   gej acc = gej_infinity();
 #pragma unroll 1
   for (int j = S - 1; j >= 0; j--) {
     if (j != S - 1) {
 #pragma unroll 1
-      for (int k = 0; k < 4; k++) acc = gej_double(acc);
+      for (int k = 0; k < W; k++) acc = gej_double(acc);
     }
+    // W = 4: at j == 0 the extra position carries nibble 32 (the recoding carry)
 #pragma unroll 1
-    for (int c = 0; c < NC + (j == 0 ? 1 : 0); c++) {  // at j == 0 the extra position carries nibble 32 (the recoding carry)
+    for (int c = 0; c < NC + ((W == 4 && j == 0) ? 1 : 0); c++) {
+      const int i = c * S + j;
+      if (W == 5 && i >= 26) continue;  // padding digits of the 28-digit comb are structurally zero
 #pragma unroll 1
       for (int half = 0; half < 2; half++) {
-        int d = half ? glv_digit(rec.k2, t2, c * S + j) : glv_digit(rec.k1, t1, c * S + j);
+        int d;
+        if (W == 4) d = half ? glv_digit(rec.k2, t2, i) : glv_digit(rec.k1, t1, i);
+        else d = half ? glv5_digit(g2, i) : glv5_digit(g1, i);
         if (half ? n2 : n1) d = -d;
-        acc = gej_add_table_digit(acc, tab, c, d, half != 0);
+        acc = gej_add_table_digit<NE>(acc, tab, c, d, half != 0);
       }
     }
   }
   // back from the table's isomorphic curve: (X, Y, Z) -> (X, Y, Z*Zc)
-  acc.z = fe_mul(acc.z, slot_load_fe(tab + kt_words(S) + KT_ZC_OFF));
+  acc.z = fe_mul(acc.z, slot_load_fe(tab + kt_words(W, S) + KT_ZC_OFF));
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);

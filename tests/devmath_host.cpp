@@ -102,10 +102,10 @@ void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8
 }
 // keyed path: one window table per row's key (no sharing here -- this is an arithmetic test), then the table-driven ecmult
 }  // extern "C"
-template <int S>
+template <int W, int S>
 static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
   dm_init();
-  std::vector<u32> tab(kt_stride(S)), scratch(kt_scratch_words(S)), fin(n * 32);
+  std::vector<u32> tab(kt_stride(W, S)), scratch(kt_scratch_words(W, S)), fin(n * 32);
   std::vector<prep_rec> recs(n);
   if (mode == MODE_ECDSA) ecdsa_prep_thread(0, 1, n, a32, sig64, recs.data());
   for (size_t i = 0; i < n; i++) {
@@ -115,8 +115,8 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
     ok &= (recs[i].flags & PREP_VALID) != 0;
     out[i] = 0;
     if (ok) {
-      keytable_build<S>(tab.data(), scratch.data(), ge_from_words(qx, qy));
-      const gej R = ecmult_lane_keyed<S>(recs[i], tab.data(), g_table.data());
+      keytable_build<W, S>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+      const gej R = ecmult_lane_keyed<W, S>(recs[i], tab.data(), g_table.data());
       be_to_words(rw, sig64 + 64 * i);
       out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
     }
@@ -124,22 +124,26 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
   if (mode == MODE_SCHNORR) schnorr_final_thread(0, 1, n, fin.data(), out, 32);
 }
 extern "C" {
-void dm_verify_keyed(int mode, int S, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
-  if (S == 1) verify_keyed_t<1>(mode, n, a32, sig64, key, keylen, out);
-  else verify_keyed_t<8>(mode, n, a32, sig64, key, keylen, out);
+void dm_verify_keyed(int mode, int W, int S, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  if (W == 4 && S == 1) verify_keyed_t<4, 1>(mode, n, a32, sig64, key, keylen, out);
+  else if (W == 4) verify_keyed_t<4, 8>(mode, n, a32, sig64, key, keylen, out);
+  else if (S == 1) verify_keyed_t<5, 1>(mode, n, a32, sig64, key, keylen, out);
+  else verify_keyed_t<5, 7>(mode, n, a32, sig64, key, keylen, out);
 }
 // table entry (pos, d) of a key as 64 affine bytes + 32 bytes beta*x
-void dm_keytable_entry(const u8 *key33, int S, int pos, int d, u8 *out96) {
-  std::vector<u32> tab(kt_stride(1)), scratch(kt_scratch_words(1));
+void dm_keytable_entry(const u8 *key33, int W, int S, int pos, int d, u8 *out96) {
+  std::vector<u32> tab(kt_stride(5, 1) + kt_stride(4, 1)), scratch(kt_scratch_words(4, 1));
   u32 qx[8], qy[8];
   parse_pubkey(key33, 33, qx, qy);
-  if (S == 1) keytable_build<1>(tab.data(), scratch.data(), ge_from_words(qx, qy));
-  else keytable_build<8>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  int words, ne;
+  if (W == 4 && S == 1) { keytable_build<4, 1>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(4, 1); ne = 8; }
+  else if (W == 4) { keytable_build<4, 8>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(4, 8); ne = 8; }
+  else if (S == 1) { keytable_build<5, 1>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(5, 1); ne = 16; }
+  else { keytable_build<5, 7>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(5, 7); ne = 16; }
   // entries are affine on the key's isomorphic curve: x = x_true * Zc^2, y = y_true * Zc^3
-  const int S_ = S == 1 ? 1 : 8;
-  const fe zc = slot_load_fe(&tab[kt_words(S_) + KT_ZC_OFF]);
+  const fe zc = slot_load_fe(&tab[words + KT_ZC_OFF]);
   const fe zi = fe_inv(zc), zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
-  const u32 *e = &tab[(pos * 8 + d - 1) * SLOT_ENTRY_WORDS];
+  const u32 *e = &tab[(pos * ne + d - 1) * SLOT_ENTRY_WORDS];
   u32 w[8];
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e), zi2))); words_to_be(out96, w);
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 16), zi3))); words_to_be(out96 + 32, w);

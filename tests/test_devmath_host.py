@@ -264,30 +264,32 @@ def test_pipeline_random_vs_oracle(dm, orc):
 
 
 def test_keyed_path_tables_and_verdicts(dm, kat):
-    """per-key window tables hold d*16^(c*S)*Q as true affine points (S = 1: one position per nibble, S = 8: comb of
-    five positions), and the table-driven ecmult gives the golden verdicts for ECDSA (33/65-byte keys) and BIP-340"""
+    """per-key window tables hold d*2^(W*S*c)*Q as affine points of the key's isomorphic curve (W = 4 or 5 bit windows,
+    dense S = 1 or comb), and the table-driven ecmult gives the golden verdicts for ECDSA (33/65-byte keys) and BIP-340"""
     BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
     d = 0x1F2E3D4C5B6A79881726354453627180AABBCCDDEEFF00112233445566778899
     Q = pyref.pubkey_create(d)
     o = ctypes.create_string_buffer(96)
-    for S, cases in ((1, ((0, 1), (0, 8), (1, 3), (7, 5), (31, 8), (32, 1), (32, 8), (16, 2))), (8, ((0, 1), (0, 8), (1, 3), (3, 7), (4, 1), (4, 8)))):
+    shapes = {(4, 1): ((0, 1), (0, 8), (1, 3), (7, 5), (31, 8), (32, 1), (32, 8), (16, 2)), (4, 8): ((0, 1), (0, 8), (1, 3), (3, 7), (4, 1), (4, 8)),
+              (5, 1): ((0, 1), (0, 16), (1, 9), (25, 16), (13, 5)), (5, 7): ((0, 1), (0, 16), (1, 11), (3, 16), (2, 7))}
+    for (W, S), cases in shapes.items():
         for pos, dig in cases:
-            dm.dm_keytable_entry(pyref.ser33(Q), S, pos, dig, o)
-            pt = pyref.pmul(dig * 16**(pos * S) % N, Q)
-            assert o.raw[:32] == pt[0].to_bytes(32, "big") and o.raw[32:64] == pt[1].to_bytes(32, "big"), (S, pos, dig)
+            dm.dm_keytable_entry(pyref.ser33(Q), W, S, pos, dig, o)
+            pt = pyref.pmul(dig * (1 << (W * S * pos)) % N, Q)
+            assert o.raw[:32] == pt[0].to_bytes(32, "big") and o.raw[32:64] == pt[1].to_bytes(32, "big"), (W, S, pos, dig)
             assert int.from_bytes(o.raw[64:], "big") == BETA * pt[0] % P
-    for S in (1, 8):
+    for W, S in shapes:
         for publen in (33, 65):
             rows = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
             rows = rows[:80] + rows[-40:]   # reference KATs + edge classes + special keys / key-less / x(R) = r + n
             out = ctypes.create_string_buffer(len(rows))
-            dm.dm_verify_keyed(0, S, ctypes.c_size_t(len(rows)), b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+            dm.dm_verify_keyed(0, W, S, ctypes.c_size_t(len(rows)), b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
                                b"".join(H(v["pub"]) for v in rows), publen, out)
             bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
-            assert not bad, (S, bad[:10])
+            assert not bad, (W, S, bad[:10])
         rows = kat["schnorr"][:60]
         out = ctypes.create_string_buffer(len(rows))
-        dm.dm_verify_keyed(1, S, ctypes.c_size_t(len(rows)), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+        dm.dm_verify_keyed(1, W, S, ctypes.c_size_t(len(rows)), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
                            b"".join(H(v["pk"]) for v in rows), 32, out)
         bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
-        assert not bad, (S, bad[:10])
+        assert not bad, (W, S, bad[:10])
