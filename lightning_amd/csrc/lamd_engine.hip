@@ -577,16 +577,50 @@ __global__ void __launch_bounds__(256) k_dedupe_partition(size_t n, const u32 *_
   if (hot) list_hot[ph] = (u32)i;
   else if (live) list_cold[pc] = (u32)i;
 }
+// key tables, four stages (verify_core.h "Building one key's table"): bases and prefix run one thread per key, the
+// multiples and the rescale one thread per (key, position) so that a few hundred keys still fill the chip
 template <int W, int S>
-__global__ void __launch_bounds__(256) k_keytable_build(size_t nuniq, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
-                                                        u32 *__restrict__ tables, u32 *__restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_kt_bases(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
+                                                  u32 *__restrict__ scratch) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= nuniq || !keyok[u]) return;
+  if (u >= nkeys || !keyok[u]) return;
   u32 qx[8], qy[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
-  keytable_build<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S), ge_from_words(qx, qy));
+  kt_bases<W, S>(scratch + u * kt_scratch_words(W, S), ge_from_words(qx, qy));
 }
+template <int W, int S>
+__global__ void __launch_bounds__(256) k_kt_multiples(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+                                                      u32 *__restrict__ scratch) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t u = t / kt_npos(W, S);
+  if (u >= nkeys || !keyok[u]) return;
+  kt_multiples<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S), (int)(t % kt_npos(W, S)));
+}
+template <int W, int S>
+__global__ void __launch_bounds__(256) k_kt_prefix(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+                                                   u32 *__restrict__ scratch) {
+  const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nkeys || !keyok[u]) return;
+  kt_prefix<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S));
+}
+template <int W, int S>
+__global__ void __launch_bounds__(256) k_kt_rescale(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+                                                    const u32 *__restrict__ scratch) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t u = t / kt_npos(W, S);
+  if (u >= nkeys || !keyok[u]) return;
+  kt_rescale<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S), (int)(t % kt_npos(W, S)));
+}
+template <int W, int S>
+static void launch_keytables(hipStream_t st, size_t nkeys, const u32 *qwords, const u8 *keyok, u32 *tables, u32 *scratch) {
+  const size_t per_pos = nkeys * kt_npos(W, S);
+  hipLaunchKernelGGL((k_kt_bases<W, S>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, scratch);
+  hipLaunchKernelGGL((k_kt_multiples<W, S>), dim3((unsigned)((per_pos + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
+  hipLaunchKernelGGL((k_kt_prefix<W, S>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
+  hipLaunchKernelGGL((k_kt_rescale<W, S>), dim3((unsigned)((per_pos + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, (const u32 *)scratch);
+}
+
 // work item j verifies row list[j] against the table of its (hot) key
 template <int W, int S>
 __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *__restrict__ list, const prep_rec *__restrict__ recs,
@@ -979,9 +1013,8 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     hipLaunchKernelGGL(k_keys, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, d_key, keylen, keystride, (const u32 *)ctx->kd_hotrow.p,
                        (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
     {
-      auto kb = W == 5 ? (dense ? k_keytable_build<5, 1> : k_keytable_build<5, 7>) : (dense ? k_keytable_build<4, 1> : k_keytable_build<4, 8>);
-      hipLaunchKernelGGL(kb, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p,
-                         (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
+      auto lk = W == 5 ? (dense ? launch_keytables<5, 1> : launch_keytables<5, 7>) : (dense ? launch_keytables<4, 1> : launch_keytables<4, 8>);
+      lk(ctx->stream, nhot, (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
     }
     const size_t ncold = n - hot_rows;
     if (ncold) {

@@ -225,10 +225,9 @@ LAMD_HD fe slot_load_fe(const u32 *src) {
 
 // Build a table of 1Q..NE*Q brought to one shared Z (returned): entry e = (e+1)*Q as an affine point of the
 // isomorphic curve y^2 = x^3 + 7*Zg^6, stored as x | beta*x | y (SLOT_ENTRY_WORDS each); the NE-2 values H of the
-// addition chain are parked right behind the entries (NE*SLOT_ENTRY_WORDS .. + (NE-2)*8 words) until the rescale pass.
+// addition chain are parked in hbuf ((NE-2)*8 words) until the rescale pass.
 template <int NE>
-LAMD_HD fe build_multiples(u32 *slot, const ge &q) {
-  constexpr int H_OFF = NE * SLOT_ENTRY_WORDS;
+LAMD_HD fe build_multiples(u32 *slot, u32 *hbuf, const ge &q) {
   gej p = gej_from_ge(q);
   slot_store_fe(slot + 0, p.x);
   slot_store_fe(slot + 16, p.y);
@@ -242,7 +241,7 @@ LAMD_HD fe build_multiples(u32 *slot, const ge &q) {
     p = gej_add_ge_core(p, q, &degenerate, &h, &rr);  // (i)Q = +-Q is impossible for i in 2..NE: no degenerate case
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, p.x);
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, p.y);
-    slot_store_fe(slot + H_OFF + (i - 2) * 8, h);
+    slot_store_fe(hbuf + (i - 2) * 8, h);
   }
   const fe zg = fe_norm_weak(p.z);
   const u32 betaw[8] = LAMD_BETA;
@@ -257,7 +256,7 @@ LAMD_HD fe build_multiples(u32 *slot, const ge &q) {
   for (int i = NE - 2; i >= 0; i--) {
     // rho = Zg / Z_entry(i): entry i+1 = entry i + Q had Z_{i+1} = Z_i * H (H stored at index i-1 for i >= 1),
     // and entry 1 = 2Q has Z = Z_2, entry 0 = Q has Z = 1 so its ratio is Zg itself.
-    if (i >= 1) rho = fe_mul(rho, slot_load_fe(slot + H_OFF + (i - 1) * 8));
+    if (i >= 1) rho = fe_mul(rho, slot_load_fe(hbuf + (i - 1) * 8));
     else rho = zg;
     const fe r2 = fe_sqr(rho);
     const fe r3 = fe_mul(r2, rho);
@@ -270,7 +269,7 @@ LAMD_HD fe build_multiples(u32 *slot, const ge &q) {
   return zg;
 }
 // the per-signature ladder's table: 1Q..8Q inside the lane's 1 KiB slot
-LAMD_HD fe build_q_table(u32 *slot, const ge &q) { return build_multiples<8>(slot, q); }
+LAMD_HD fe build_q_table(u32 *slot, const ge &q) { return build_multiples<8>(slot, slot + SLOT_H_OFF, q); }
 
 LAMD_HD int glv_digit(const u32 mag[4], u32 top, int i) {
   // window i of the biased magnitude; i == 32 is the carry bit
@@ -354,25 +353,28 @@ constexpr int kt_ne(int W) { return 1 << (W - 1); }                             
 constexpr int kt_ndigits(int W, int S) { return W == 4 ? 32 : (S == 1 ? 26 : 28); }   // digits handled by the chunks
 constexpr int kt_npos(int W, int S) { return kt_ndigits(W, S) / S + (W == 4 ? 1 : 0); }  // + W = 4's carry position
 constexpr int kt_words(int W, int S) { return kt_npos(W, S) * kt_ne(W) * SLOT_ENTRY_WORDS; }
-constexpr int kt_stride(int W, int S) { return kt_words(W, S) + 128; }  // + the last position's parked H values (<= 112) + Zc
-constexpr int kt_scratch_words(int W, int S) { return kt_npos(W, S) * 36; }  // per position: base X, Y (18), Z_pos (9), prefix (9)
-constexpr int KT_ZC_OFF = 112;  // word offset of Zc inside the stride padding
+constexpr int kt_stride(int W, int S) { return kt_words(W, S) + 16; }  // + Zc (8 words), 16-byte aligned
+// scratch per key and position: base X, Y (18), Z_pos (9), prefix product / unify ratio (9), the H values of the chain
+constexpr int kt_pos_scratch(int W) { return 36 + (kt_ne(W) - 2) * 8; }
+constexpr int kt_scratch_words(int W, int S) { return kt_npos(W, S) * kt_pos_scratch(W); }
+constexpr int KT_ZC_OFF = 0;  // word offset of Zc behind the entries
 
 LAMD_HD void store_raw(u32 *dst, const fe &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) dst[i] = a.n[i];
 }
 
-// One thread builds one key's table.  tab: kt_stride(W,S) words, scratch: kt_scratch_words(W,S) (both lane-private).
-// No inversion anywhere: every position's multiples are first affine on that position's own isomorphic curve
-// (Z_pos = Z of the Jacobian base x the shared Z of its multiples), then all positions are brought to ONE
-// common Zc = prod Z_pos by multiplying with the product of the OTHER positions' Z (prefix x suffix products).
-// The table therefore holds affine points of the curve y^2 = x^3 + 7*Zc^6; Zc is stored behind the entries and the
-// table-driven ecmult multiplies it back into the accumulator's Z before the G additions.
+// Building one key's table, in four stages so that stages 2 and 4 can run one thread per (key, position):
+//   1 kt_bases      per key       B_c = 2^(W*S*c) * Q, Jacobian, a chain of W*S doublings per position
+//   2 kt_multiples  per position  1B..NE*B with (X, Y) of the Jacobian base taken as an affine point of the base's
+//                                 isomorphic curve; Z_pos = (shared Z of the multiples) * Z_base
+//   3 kt_prefix     per key       Zc = prod Z_pos and, per position, the product of the OTHER positions' Z
+//   4 kt_rescale    per position  entry *= ratio^2 / ratio^3: every entry becomes an affine point of the ONE curve
+//                                 y^2 = x^3 + 7*Zc^6 -- no inversion anywhere; the table-driven ecmult multiplies Zc back
+//                                 into its accumulator's Z before the G additions
 template <int W, int S>
-LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
-  constexpr int NP = kt_npos(W, S), NE = kt_ne(W);
-  // 1. bases B_c = 2^(W*S*c) * Q in Jacobian form (a chain of W*S doublings per position)
+LAMD_HD void kt_bases(u32 *scratch, const ge &q) {
+  constexpr int NP = kt_npos(W, S), PS = kt_pos_scratch(W);
   gej b = gej_from_ge(q);
 #pragma unroll 1
   for (int pos = 0; pos < NP; pos++) {
@@ -380,48 +382,64 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
 #pragma unroll 1
       for (int j = 0; j < W * S; j++) b = gej_double(b);
     }
-    store_raw(scratch + pos * 36 + 0, b.x);
-    store_raw(scratch + pos * 36 + 9, b.y);
-    store_raw(scratch + pos * 36 + 18, fe_norm_weak(b.z));
+    store_raw(scratch + pos * PS + 0, b.x);
+    store_raw(scratch + pos * PS + 9, b.y);
+    store_raw(scratch + pos * PS + 18, fe_norm_weak(b.z));
   }
-  // 2. per position: 1B..NE*B with (X, Y) of the Jacobian base taken as an affine point of the base's isomorphic curve;
-  //    Z_pos = Zg * Z_base; running prefix products prod_{j<pos} Z_j
+}
+template <int W, int S>
+LAMD_HD void kt_multiples(u32 *tab, u32 *scratch, int pos) {
+  constexpr int NE = kt_ne(W), PS = kt_pos_scratch(W);
+  u32 *sp = scratch + pos * PS;
+  ge base;
+  base.x = slot_load_raw(sp + 0);
+  base.y = slot_load_raw(sp + 9);
+  const fe zg = build_multiples<NE>(tab + pos * NE * SLOT_ENTRY_WORDS, sp + 36, base);
+  store_raw(sp + 18, fe_mul(zg, slot_load_raw(sp + 18)));
+}
+template <int W, int S>
+LAMD_HD void kt_prefix(u32 *tab, u32 *scratch) {
+  constexpr int NP = kt_npos(W, S), PS = kt_pos_scratch(W);
   fe acc = fe_set_int(1);
 #pragma unroll 1
   for (int pos = 0; pos < NP; pos++) {
-    ge base;
-    base.x = slot_load_raw(scratch + pos * 36 + 0);
-    base.y = slot_load_raw(scratch + pos * 36 + 9);
-    u32 *t = tab + pos * NE * SLOT_ENTRY_WORDS;
-    // build_multiples parks its H values behind the position's entries: that is the next position's first entries
-    // (rewritten when that position is built) or, for the last position, the stride padding
-    const fe zg = build_multiples<NE>(t, base);
-    const fe zpos = fe_mul(zg, slot_load_raw(scratch + pos * 36 + 18));
-    store_raw(scratch + pos * 36 + 18, zpos);
-    store_raw(scratch + pos * 36 + 27, acc);  // prefix
-    acc = fe_mul(acc, zpos);
+    store_raw(scratch + pos * PS + 27, acc);  // prefix
+    acc = fe_mul(acc, slot_load_raw(scratch + pos * PS + 18));
   }
   slot_store_fe(tab + kt_words(W, S) + KT_ZC_OFF, acc);  // Zc
-  // 3. unify: entry *= (prefix * suffix)^2 / ^3
-  const u32 betaw[8] = LAMD_BETA;
-  const fe beta = fe_from_words(betaw);
   fe suffix = fe_set_int(1);
 #pragma unroll 1
   for (int pos = NP - 1; pos >= 0; pos--) {
-    const fe ratio = fe_mul(suffix, slot_load_raw(scratch + pos * 36 + 27));
-    suffix = fe_mul(suffix, slot_load_raw(scratch + pos * 36 + 18));
-    const fe r2 = fe_sqr(ratio);
-    const fe r3 = fe_mul(r2, ratio);
-#pragma unroll 1
-    for (int e = 0; e < NE; e++) {
-      u32 *ent = tab + (pos * NE + e) * SLOT_ENTRY_WORDS;
-      const fe x = fe_mul(slot_load_fe(ent + 0), r2);
-      const fe y = fe_mul(slot_load_fe(ent + 16), r3);
-      slot_store_fe(ent + 0, x);
-      slot_store_fe(ent + 8, fe_mul(x, beta));
-      slot_store_fe(ent + 16, y);
-    }
+    const fe ratio = fe_mul(suffix, slot_load_raw(scratch + pos * PS + 27));
+    suffix = fe_mul(suffix, slot_load_raw(scratch + pos * PS + 18));
+    store_raw(scratch + pos * PS + 27, ratio);
   }
+}
+template <int W, int S>
+LAMD_HD void kt_rescale(u32 *tab, const u32 *scratch, int pos) {
+  constexpr int NE = kt_ne(W), PS = kt_pos_scratch(W);
+  const u32 betaw[8] = LAMD_BETA;
+  const fe beta = fe_from_words(betaw);
+  const fe ratio = slot_load_raw(scratch + pos * PS + 27);
+  const fe r2 = fe_sqr(ratio);
+  const fe r3 = fe_mul(r2, ratio);
+#pragma unroll 1
+  for (int e = 0; e < NE; e++) {
+    u32 *ent = tab + (pos * NE + e) * SLOT_ENTRY_WORDS;
+    const fe x = fe_mul(slot_load_fe(ent + 0), r2);
+    const fe y = fe_mul(slot_load_fe(ent + 16), r3);
+    slot_store_fe(ent + 0, x);
+    slot_store_fe(ent + 8, fe_mul(x, beta));
+    slot_store_fe(ent + 16, y);
+  }
+}
+// sequential composition (CPU test harness; the engine launches the stages as separate kernels)
+template <int W, int S>
+LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
+  kt_bases<W, S>(scratch, q);
+  for (int pos = 0; pos < kt_npos(W, S); pos++) kt_multiples<W, S>(tab, scratch, pos);
+  kt_prefix<W, S>(tab, scratch);
+  for (int pos = 0; pos < kt_npos(W, S); pos++) kt_rescale<W, S>(tab, scratch, pos);
 }
 
 template <int NE>

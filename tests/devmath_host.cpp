@@ -132,7 +132,7 @@ void dm_verify_keyed(int mode, int W, int S, size_t n, const u8 *a32, const u8 *
 }
 // table entry (pos, d) of a key as 64 affine bytes + 32 bytes beta*x
 void dm_keytable_entry(const u8 *key33, int W, int S, int pos, int d, u8 *out96) {
-  std::vector<u32> tab(kt_stride(5, 1) + kt_stride(4, 1)), scratch(kt_scratch_words(4, 1));
+  std::vector<u32> tab(kt_stride(5, 1) + kt_stride(4, 1)), scratch(kt_scratch_words(5, 1) + kt_scratch_words(4, 1));
   u32 qx[8], qy[8];
   parse_pubkey(key33, 33, qx, qy);
   int words, ne;
