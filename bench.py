@@ -199,7 +199,7 @@ def main():
                 ts.append(time.perf_counter() - t1)
             gm = int((g.d_verdict.cpu().numpy() != g.expect).sum())
             extra["cfg4_gossip_replay"] = {"messages": g.n, "verifies": g.rows, "verifies_per_s": g.rows / min(ts[1:]), "messages_per_s": g.n / min(ts[1:]),
-                                           "mismatches": gm, "keyed_spacing": eng.info()["last_keyed"], "distinct_keys": eng.info()["last_unique_keys"]}
+                                           "mismatches": gm, "keyed_comb_teeth": eng.info()["last_keyed"], "distinct_keys": eng.info()["last_unique_keys"]}
             del g
             st = workload.make_commit_storm(eng, 10_000, device=device)
             ts = []
@@ -213,7 +213,7 @@ def main():
             sm = int((st["ecdsa"].d_ok.cpu().numpy().astype(bool) != st["ecdsa"].expect).sum() + (st["schnorr"].d_ok.cpu().numpy().astype(bool) != st["schnorr"].expect).sum())
             nv = st["ecdsa"].n + st["schnorr"].n
             extra["cfg5_commit_storm_superbatch"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[1:]), "mismatches": sm,
-                                                     "keyed_spacing": eng.info()["last_keyed"]}
+                                                     "keyed_comb_teeth": eng.info()["last_keyed"]}
             del st
             out["other_configs_1gpu"] = extra
             mism += gm + sm

@@ -187,7 +187,7 @@ typedef struct {
 	size_t last_unique_keys;  /* distinct public keys found in the last chunk (0 if it was not examined) */
 	size_t last_hot_rows;     /* rows of the last chunk verified against per-key tables (the rest took the ladder) */
 	int last_keyed;           /* 0: per-signature ladder only; else rows of the last chunk ran on per-key tables and this is
-				   * the comb spacing used (1 = dense: one table position per window digit, 7 / 8 = comb) */
+				   * the number of comb teeth of those tables (7 or 10) */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */

@@ -578,51 +578,54 @@ __global__ void __launch_bounds__(256) k_dedupe_partition(size_t n, const u32 *_
   else if (live) list_cold[pc] = (u32)i;
 }
 // key tables, four stages (verify_core.h "Building one key's table"): bases and prefix run one thread per key, the
-// multiples and the rescale one thread per (key, position) so that a few hundred keys still fill the chip
-template <int W, int S>
-__global__ void __launch_bounds__(256) k_kt_bases(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
+// chains and the rescale one thread per (key, 16-entry chain) so that a few hundred keys still fill the chip
+template <int T>
+__global__ void __launch_bounds__(256) k_kc_bases(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
                                                   u32 *__restrict__ scratch) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= nkeys || !keyok[u]) return;
   u32 qx[8], qy[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
-  kt_bases<W, S>(scratch + u * kt_scratch_words(W, S), ge_from_words(qx, qy));
+  kc_bases<T>(scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
 }
-template <int W, int S>
-__global__ void __launch_bounds__(256) k_kt_multiples(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
-                                                      u32 *__restrict__ scratch) {
+template <int T>
+__global__ void __launch_bounds__(256) k_kc_chain(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+                                                  u32 *__restrict__ scratch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t u = t / kt_npos(W, S);
+  const size_t u = t / kc_nsub(T);
   if (u >= nkeys || !keyok[u]) return;
-  kt_multiples<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S), (int)(t % kt_npos(W, S)));
+  kc_chain<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
 }
-template <int W, int S>
-__global__ void __launch_bounds__(256) k_kt_prefix(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
-                                                   u32 *__restrict__ scratch) {
+template <int T>
+__global__ void __launch_bounds__(256) k_kc_prefix(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
+                                                   u32 *__restrict__ tables, u32 *__restrict__ scratch) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= nkeys || !keyok[u]) return;
-  kt_prefix<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S));
+  u32 qx[8], qy[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
+  kc_prefix<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
 }
-template <int W, int S>
-__global__ void __launch_bounds__(256) k_kt_rescale(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+template <int T>
+__global__ void __launch_bounds__(256) k_kc_rescale(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
                                                     const u32 *__restrict__ scratch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t u = t / kt_npos(W, S);
+  const size_t u = t / kc_nsub(T);
   if (u >= nkeys || !keyok[u]) return;
-  kt_rescale<W, S>(tables + u * kt_stride(W, S), scratch + u * kt_scratch_words(W, S), (int)(t % kt_npos(W, S)));
+  kc_rescale<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
 }
-template <int W, int S>
+template <int T>
 static void launch_keytables(hipStream_t st, size_t nkeys, const u32 *qwords, const u8 *keyok, u32 *tables, u32 *scratch) {
-  const size_t per_pos = nkeys * kt_npos(W, S);
-  hipLaunchKernelGGL((k_kt_bases<W, S>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, scratch);
-  hipLaunchKernelGGL((k_kt_multiples<W, S>), dim3((unsigned)((per_pos + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
-  hipLaunchKernelGGL((k_kt_prefix<W, S>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
-  hipLaunchKernelGGL((k_kt_rescale<W, S>), dim3((unsigned)((per_pos + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, (const u32 *)scratch);
+  const size_t chains = nkeys * kc_nsub(T);
+  hipLaunchKernelGGL((k_kc_bases<T>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, scratch);
+  hipLaunchKernelGGL((k_kc_chain<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
+  hipLaunchKernelGGL((k_kc_prefix<T>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, tables, scratch);
+  hipLaunchKernelGGL((k_kc_rescale<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, (const u32 *)scratch);
 }
 
 // work item j verifies row list[j] against the table of its (hot) key
-template <int W, int S>
+template <int T>
 __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *__restrict__ list, const prep_rec *__restrict__ recs,
                                                       const u32 *__restrict__ key_id, const u32 *__restrict__ hotidx,
                                                       const u8 *__restrict__ keyok_u, const u32 *__restrict__ tables,
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *_
   keyok_row[i] = kok;
   bool ok = (rec.flags & PREP_VALID) && kok;
   if (ok) {
-    const gej R = ecmult_lane_keyed<W, S>(rec, tables + (size_t)kid * kt_stride(W, S), gtable);
+    const gej R = ecmult_lane_keyed<T>(rec, tables + (size_t)kid * kc_stride(T), gtable);
     u32 rw[8];
     load_words_be(rw, sig64 + 64 * i);
     if (mode == MODE_ECDSA) {
@@ -694,9 +697,8 @@ struct lamd_ctx {
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
-  double keyed_dense_uses = 48.0;  // ... and for the dense one-position-per-nibble table
-  int keyed_spacing = 0;           // 0 = choose by re-use, 1 = force dense tables, anything else = force the comb (LAMD_KEYED_SPACING)
-  int keyed_window = 5;            // window width of the key tables: 5 (default) or 4 (LAMD_KEYED_WINDOW)
+  double keyed_dense_uses = 48.0;  // ... and for the 10-tooth comb (512 entries per key)
+  int keyed_teeth = 0;             // 0 = choose by re-use, 7 or 10 = force that comb (LAMD_KEYED_TEETH)
   int last_spacing = 0;
   size_t last_unique_keys = 0;
   bool last_keyed = false;
@@ -789,8 +791,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED")) ctx->keyed_mode = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_MIN_USES")) ctx->keyed_min_uses = atof(w);
   if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
-  if (const char *w = getenv("LAMD_KEYED_SPACING")) ctx->keyed_spacing = atoi(w) == 1 ? 1 : (atoi(w) > 1 ? 8 : 0);
-  if (const char *w = getenv("LAMD_KEYED_WINDOW")) ctx->keyed_window = atoi(w) == 4 ? 4 : 5;
+  if (const char *w = getenv("LAMD_KEYED_TEETH")) ctx->keyed_teeth = atoi(w) == 7 ? 7 : (atoi(w) == 10 ? 10 : 0);
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
@@ -989,15 +990,13 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   u8 *keyok_row = nullptr;
   u32 *fin = nullptr;
   if (nhot) {
-    // table shape: dense (one position per digit, no doublings) for heavily re-used keys, a comb otherwise;
-    // 5-bit windows by default (16 entries per position, 26 digits), 4-bit as the alternative (LAMD_KEYED_WINDOW)
-    const bool dense = ctx->keyed_spacing ? ctx->keyed_spacing == 1 : (double)hot_rows >= ctx->keyed_dense_uses * (double)nhot;
-    const int W = ctx->keyed_window;
-    const int S = dense ? 1 : (W == 5 ? 7 : 8);
-    const size_t stride_w = W == 5 ? (dense ? kt_stride(5, 1) : kt_stride(5, 7)) : (dense ? kt_stride(4, 1) : kt_stride(4, 8));
-    const size_t scratch_w = W == 5 ? (dense ? kt_scratch_words(5, 1) : kt_scratch_words(5, 7)) : (dense ? kt_scratch_words(4, 1) : kt_scratch_words(4, 8));
+    // comb shape: 7 teeth (64 entries per key, 38 additions + 18 doublings per signature) unless the keys are re-used
+    // heavily enough to pay for 10 teeth (512 entries, 26 + 12)
+    const int T = ctx->keyed_teeth ? ctx->keyed_teeth : ((double)hot_rows >= ctx->keyed_dense_uses * (double)nhot ? 10 : 7);
+    const size_t stride_w = T == 10 ? kc_stride(10) : kc_stride(7);
+    const size_t scratch_w = T == 10 ? kc_scratch_words(10) : kc_scratch_words(7);
     ctx->last_keyed = true;
-    ctx->last_spacing = S;
+    ctx->last_spacing = T;
     ctx->last_hot_rows = hot_rows;
     if ((rc = ensure(ctx, &ctx->keyok_row, n)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &ctx->kt_qwords, nhot * 64)) != LAMD_OK) return rc;
@@ -1013,7 +1012,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     hipLaunchKernelGGL(k_keys, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, d_key, keylen, keystride, (const u32 *)ctx->kd_hotrow.p,
                        (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
     {
-      auto lk = W == 5 ? (dense ? launch_keytables<5, 1> : launch_keytables<5, 7>) : (dense ? launch_keytables<4, 1> : launch_keytables<4, 8>);
+      auto lk = T == 10 ? launch_keytables<10> : launch_keytables<7>;
       lk(ctx->stream, nhot, (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
     }
     const size_t ncold = n - hot_rows;
@@ -1031,7 +1030,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     }
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-    auto ke = W == 5 ? (dense ? k_ecmult_keyed<5, 1> : k_ecmult_keyed<5, 7>) : (dense ? k_ecmult_keyed<4, 1> : k_ecmult_keyed<4, 8>);
+    auto ke = T == 10 ? k_ecmult_keyed<10> : k_ecmult_keyed<7>;
     hipLaunchKernelGGL(ke, dim3(blocks_for(hot_rows)), dim3(256), 0, ctx->stream, hot_rows,
                        (const u32 *)ctx->kd_listhot.p, recs, (const u32 *)ctx->kd_keyid.p, (const u32 *)ctx->kd_hotidx.p,
                        (const u8 *)ctx->kt_keyok.p, (const u32 *)ctx->kt_tables.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_row, d_ok);

@@ -337,95 +337,184 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
 // ================================================================================================
 // Keyed path: when a batch re-uses public keys (gossip node ids, the 483 HTLC signatures of one
 // commitment_signed share remote_htlckey -- channeld/channeld.c:2224-2225), each distinct key gets ONE
-// table in HBM, shared by all of its signatures.  The 32 nibbles of a GLV half-scalar are cut into
-// NPOS = 32/S chunks of S nibbles; the table holds d * 16^(c*S) * Q for chunk c = 0..NPOS (the last one only
-// serves the recoding carry digit) and |digit| d = 1..8 as affine points (x | beta*x | y) of one per-key isomorphic
-// curve (shared Z, no inversion needed to build it).  Evaluation is
-// a comb: for j = S-1..0 { acc *= 16 (4 doublings, skipped first); add nibble c*S+j of every chunk }, i.e.
-// 4(S-1) doublings and 66 mixed additions per verification instead of 132 + 66:
-//   S = 1 (33 positions, 25 KiB/key): no doublings at all -- for heavily re-used keys (>= ~64 signatures/key)
-//   S = 8 ( 5 positions,  4 KiB/key): 28 doublings, a 7x cheaper table -- pays from ~6 signatures per key
-// Window width W = 4: signed nibbles of the bias-recoded half-scalar as stored in prep_rec (digits -8..7, 8 table entries
-// per position, 32 nibbles + the recoding carry = 33 digits).  W = 5: the kernel re-biases |k| with 16 per 5-bit group
-// (digits -16..15, 16 entries per position); |k| < 2^128 and the bias < 0.52 * 2^130 never carry out of 26 groups, so
-// there is no carry digit: 26 digits dense, padded to 28 (two structurally zero digits) for the 4-position comb.
-constexpr int kt_ne(int W) { return 1 << (W - 1); }                                   // table entries per position
-constexpr int kt_ndigits(int W, int S) { return W == 4 ? 32 : (S == 1 ? 26 : 28); }   // digits handled by the chunks
-constexpr int kt_npos(int W, int S) { return kt_ndigits(W, S) / S + (W == 4 ? 1 : 0); }  // + W = 4's carry position
-constexpr int kt_words(int W, int S) { return kt_npos(W, S) * kt_ne(W) * SLOT_ENTRY_WORDS; }
-constexpr int kt_stride(int W, int S) { return kt_words(W, S) + 16; }  // + Zc (8 words), 16-byte aligned
-// scratch per key and position: base X, Y (18), Z_pos (9), prefix product / unify ratio (9), the H values of the chain
-constexpr int kt_pos_scratch(int W) { return 36 + (kt_ne(W) - 2) * 8; }
-constexpr int kt_scratch_words(int W, int S) { return kt_npos(W, S) * kt_pos_scratch(W); }
-constexpr int KT_ZC_OFF = 0;  // word offset of Zc behind the entries
+// table in HBM, shared by all of its signatures: a signed comb (Lim-Lee) with T teeth spaced D bits apart.
+//
+// A GLV half-scalar |k| < 2^129 is made odd (k' = |k| | 1; an even |k| is repaired afterwards by one predicated
+// addition of -+Q) and written with N = T*D digits s_i in {-1, +1}: k' = sum s_i 2^i with s_i = 2*b_i - 1 and b the
+// bits of w = (|k| >> 1) | 2^(N-1).  Column j (0 <= j < D) gathers digits j, j+D, .., j+(T-1)D:
+//      sum_i s_(iD+j) * B_i,  B_i = 2^(iD) * Q,
+// which is +-(B_(T-1) + sum_(i<T-1) +-B_i): one of NE = 2^(T-1) table entries, negated when the top tooth is -1.
+//      acc = inf; for j = D-1..0 { acc = 2*acc; acc += column_j(k1) ; acc += lambda*column_j(k2) }
+// costs 2*D mixed additions and D-1 doublings for BOTH halves -- T = 7: 38 + 18 (was 56 + 30 with 5-bit windows at
+// the same 64 entries per key), T = 10: 26 + 12 with 512 entries for heavily re-used keys.
+// Entries are affine points (x | beta*x | y) of one per-key isomorphic curve y^2 = x^3 + 7*Zc^6 (shared Z, no
+// inversion to build them); entry m = B_(T-1) + sum_(i<T-1) (m_i ? +B_i : -B_i); entry NE is Q itself.
+constexpr int kc_spacing(int T) { return T == 7 ? 19 : T == 8 ? 17 : T == 9 ? 15 : T == 10 ? 13 : 12; }  // T*D >= 129
+constexpr int kc_ne(int T) { return 1 << (T - 1); }
+constexpr int KC_SUB_LOG = 4, KC_SUB = 1 << KC_SUB_LOG;            // entries built by one thread (a Gray-code chain)
+constexpr int kc_nsub(int T) { return kc_ne(T) / KC_SUB; }
+constexpr int kc_words(int T) { return (kc_ne(T) + 1) * SLOT_ENTRY_WORDS; }
+constexpr int kc_stride(int T) { return kc_words(T) + 16; }        // + Zc (8 words), keeps 16-byte alignment
+// scratch per key (words): P0 = entry 0 as a Jacobian point (27) | Zb (9) | C_i = 2*B_i, i < T-1, affine (18 each) |
+// per chain: Z_chain (9), unify ratio (9), the 15 H values of its additions (9 each).  Stage 1 parks its 2T-1
+// Jacobian points (36 words each) in the per-chain area before any chain uses it.
+constexpr int KC_P0 = 0, KC_ZB = 27, KC_C = 36;
+constexpr int kc_sub_off(int T) { return KC_C + (T - 1) * 18; }
+constexpr int KC_SUB_WORDS = 18 + (KC_SUB - 1) * 9;
+constexpr int kc_scratch_words(int T) { return kc_sub_off(T) + kc_nsub(T) * KC_SUB_WORDS; }
+static_assert(kc_nsub(7) * KC_SUB_WORDS >= 13 * 36 && kc_nsub(8) * KC_SUB_WORDS >= 15 * 36, "stage-1 parking space");
 
 LAMD_HD void store_raw(u32 *dst, const fe &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) dst[i] = a.n[i];
 }
 
-// Building one key's table, in four stages so that stages 2 and 4 can run one thread per (key, position):
-//   1 kt_bases      per key       B_c = 2^(W*S*c) * Q, Jacobian, a chain of W*S doublings per position
-//   2 kt_multiples  per position  1B..NE*B with (X, Y) of the Jacobian base taken as an affine point of the base's
-//                                 isomorphic curve; Z_pos = (shared Z of the multiples) * Z_base
-//   3 kt_prefix     per key       Zc = prod Z_pos and, per position, the product of the OTHER positions' Z
-//   4 kt_rescale    per position  entry *= ratio^2 / ratio^3: every entry becomes an affine point of the ONE curve
-//                                 y^2 = x^3 + 7*Zc^6 -- no inversion anywhere; the table-driven ecmult multiplies Zc back
-//                                 into its accumulator's Z before the G additions
-template <int W, int S>
-LAMD_HD void kt_bases(u32 *scratch, const ge &q) {
-  constexpr int NP = kt_npos(W, S), PS = kt_pos_scratch(W);
+// Building one key's table, in four stages so that stages 2 and 4 can run one thread per (key, chain):
+//   1 kc_bases    per key    the doubling chain Q -> 2^((T-1)D) Q, picking up B_i and C_i = 2*B_i on the way; all of
+//                            them brought to one Z (Zb) by products of the others' Z -- no inversion; P0 = B_(T-1) - sum B_i
+//   2 kc_chain    per chain  16 entries in Gray-code order from P0 + (the chain's fixed high teeth): one mixed addition of
+//                            +-C_i per entry, then back to the chain's last Z through the stored H values
+//   3 kc_prefix   per key    Zc = Zb * prod Z_chain, per chain the product of the OTHER chains' Z; the entry of Q
+//   4 kc_rescale  per chain  entry *= ratio^2 / ratio^3 and beta*x: every entry an affine point of y^2 = x^3 + 7*Zc^6
+// No addition here can be degenerate: every operand is (odd integer < 2^136)*Q +- (even integer < 2^136)*Q with Q of
+// prime order n > 2^255.
+template <int T>
+LAMD_HD void kc_bases(u32 *scratch, const ge &q) {
+  constexpr int D = kc_spacing(T), NPT = 2 * T - 1;
+  u32 *tmp = scratch + kc_sub_off(T);  // point 2i = B_i, point 2i+1 = C_i; x | y | z | prefix
   gej b = gej_from_ge(q);
 #pragma unroll 1
-  for (int pos = 0; pos < NP; pos++) {
-    if (pos) {
+  for (int i = 0; i < NPT; i++) {
+    store_raw(tmp + i * 36 + 0, b.x);
+    store_raw(tmp + i * 36 + 9, b.y);
+    store_raw(tmp + i * 36 + 18, fe_norm_weak(b.z));
+    if (i == NPT - 1) break;
+    const int nd = (i & 1) ? D - 1 : 1;
 #pragma unroll 1
-      for (int j = 0; j < W * S; j++) b = gej_double(b);
-    }
-    store_raw(scratch + pos * PS + 0, b.x);
-    store_raw(scratch + pos * PS + 9, b.y);
-    store_raw(scratch + pos * PS + 18, fe_norm_weak(b.z));
+    for (int j = 0; j < nd; j++) b = gej_double(b);
   }
-}
-template <int W, int S>
-LAMD_HD void kt_multiples(u32 *tab, u32 *scratch, int pos) {
-  constexpr int NE = kt_ne(W), PS = kt_pos_scratch(W);
-  u32 *sp = scratch + pos * PS;
-  ge base;
-  base.x = slot_load_raw(sp + 0);
-  base.y = slot_load_raw(sp + 9);
-  const fe zg = build_multiples<NE>(tab + pos * NE * SLOT_ENTRY_WORDS, sp + 36, base);
-  store_raw(sp + 18, fe_mul(zg, slot_load_raw(sp + 18)));
-}
-template <int W, int S>
-LAMD_HD void kt_prefix(u32 *tab, u32 *scratch) {
-  constexpr int NP = kt_npos(W, S), PS = kt_pos_scratch(W);
   fe acc = fe_set_int(1);
 #pragma unroll 1
-  for (int pos = 0; pos < NP; pos++) {
-    store_raw(scratch + pos * PS + 27, acc);  // prefix
-    acc = fe_mul(acc, slot_load_raw(scratch + pos * PS + 18));
+  for (int i = 0; i < NPT; i++) {
+    store_raw(tmp + i * 36 + 27, acc);
+    acc = fe_mul(acc, slot_load_raw(tmp + i * 36 + 18));
   }
-  slot_store_fe(tab + kt_words(W, S) + KT_ZC_OFF, acc);  // Zc
+  store_raw(scratch + KC_ZB, acc);
   fe suffix = fe_set_int(1);
 #pragma unroll 1
-  for (int pos = NP - 1; pos >= 0; pos--) {
-    const fe ratio = fe_mul(suffix, slot_load_raw(scratch + pos * PS + 27));
-    suffix = fe_mul(suffix, slot_load_raw(scratch + pos * PS + 18));
-    store_raw(scratch + pos * PS + 27, ratio);
+  for (int i = NPT - 1; i >= 0; i--) {
+    const fe ratio = fe_mul(suffix, slot_load_raw(tmp + i * 36 + 27));
+    suffix = fe_mul(suffix, slot_load_raw(tmp + i * 36 + 18));
+    const fe r2 = fe_sqr(ratio);
+    const fe x = fe_mul(slot_load_raw(tmp + i * 36 + 0), r2);
+    const fe y = fe_mul(slot_load_raw(tmp + i * 36 + 9), fe_mul(r2, ratio));
+    u32 *dst = (i & 1) ? scratch + KC_C + (i >> 1) * 18 : tmp + i * 36;
+    store_raw(dst + 0, x);
+    store_raw(dst + 9, y);
+  }
+  gej p;
+  p.x = slot_load_raw(tmp + (NPT - 1) * 36 + 0);
+  p.y = slot_load_raw(tmp + (NPT - 1) * 36 + 9);
+  p.z = fe_set_int(1);
+  p.inf = false;
+#pragma unroll 1
+  for (int i = 0; i < T - 1; i++) {
+    ge m;
+    m.x = slot_load_raw(tmp + 2 * i * 36 + 0);
+    m.y = fe_norm_weak(fe_neg(slot_load_raw(tmp + 2 * i * 36 + 9), 1));
+    bool degenerate;
+    fe h, rr;
+    p = gej_add_ge_core(p, m, &degenerate, &h, &rr);
+  }
+  store_raw(scratch + KC_P0 + 0, p.x);
+  store_raw(scratch + KC_P0 + 9, p.y);
+  store_raw(scratch + KC_P0 + 18, fe_norm_weak(p.z));
+}
+template <int T>
+LAMD_HD void kc_chain(u32 *tab, u32 *scratch, int sub) {
+  u32 *sp = scratch + kc_sub_off(T) + sub * KC_SUB_WORDS;
+  u32 *ent = tab + sub * KC_SUB * SLOT_ENTRY_WORDS;
+  gej p;
+  p.x = slot_load_raw(scratch + KC_P0 + 0);
+  p.y = slot_load_raw(scratch + KC_P0 + 9);
+  p.z = slot_load_raw(scratch + KC_P0 + 18);
+  p.inf = false;
+  bool degenerate;
+  fe h, rr;
+#pragma unroll 1
+  for (int b = 0; b < T - 1 - KC_SUB_LOG; b++) {  // the chain's fixed high teeth
+    if ((sub >> b) & 1) {
+      ge c;
+      c.x = slot_load_raw(scratch + KC_C + (KC_SUB_LOG + b) * 18 + 0);
+      c.y = slot_load_raw(scratch + KC_C + (KC_SUB_LOG + b) * 18 + 9);
+      p = gej_add_ge_core(p, c, &degenerate, &h, &rr);
+      p.z = fe_norm_weak(p.z);
+    }
+  }
+  slot_store_fe(ent + 0, p.x);
+  slot_store_fe(ent + 16, p.y);
+#pragma unroll 1
+  for (int g = 1; g < KC_SUB; g++) {
+    const int c = __builtin_ctz((unsigned)g), gr = g ^ (g >> 1);
+    ge pt;
+    pt.x = slot_load_raw(scratch + KC_C + c * 18 + 0);
+    pt.y = slot_load_raw(scratch + KC_C + c * 18 + 9);
+    pt = ge_neg_if(pt, ((gr >> c) & 1) == 0);  // tooth c goes - to +: add 2*B_c; + to -: subtract it
+    p = gej_add_ge_core(p, pt, &degenerate, &h, &rr);
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 0, p.x);
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 16, p.y);
+    store_raw(sp + 18 + (g - 1) * 9, h);
+  }
+  store_raw(sp + 0, fe_norm_weak(p.z));
+  fe rho = fe_set_int(1);
+#pragma unroll 1
+  for (int g = KC_SUB - 2; g >= 0; g--) {  // rho = Z_last / Z_entry(g)
+    rho = fe_mul(rho, slot_load_raw(sp + 18 + g * 9));
+    const int gr = g ^ (g >> 1);
+    const fe r2 = fe_sqr(rho);
+    const fe x = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 0), r2);
+    const fe y = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 16), fe_mul(r2, rho));
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 0, x);
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 16, y);
   }
 }
-template <int W, int S>
-LAMD_HD void kt_rescale(u32 *tab, const u32 *scratch, int pos) {
-  constexpr int NE = kt_ne(W), PS = kt_pos_scratch(W);
+template <int T>
+LAMD_HD void kc_prefix(u32 *tab, u32 *scratch, const ge &q) {
+  constexpr int NS = kc_nsub(T), NE = kc_ne(T);
+  u32 *sp = scratch + kc_sub_off(T);
+  fe acc = fe_set_int(1);
+#pragma unroll 1
+  for (int s = 0; s < NS; s++) {
+    store_raw(sp + s * KC_SUB_WORDS + 9, acc);
+    acc = fe_mul(acc, slot_load_raw(sp + s * KC_SUB_WORDS + 0));
+  }
+  const fe zc = fe_mul(acc, slot_load_raw(scratch + KC_ZB));
+  slot_store_fe(tab + kc_words(T), zc);
+  fe suffix = fe_set_int(1);
+#pragma unroll 1
+  for (int s = NS - 1; s >= 0; s--) {
+    const fe ratio = fe_mul(suffix, slot_load_raw(sp + s * KC_SUB_WORDS + 9));
+    suffix = fe_mul(suffix, slot_load_raw(sp + s * KC_SUB_WORDS + 0));
+    store_raw(sp + s * KC_SUB_WORDS + 9, ratio);
+  }
+  const u32 betaw[8] = LAMD_BETA;
+  const fe z2 = fe_sqr(zc);
+  const fe x = fe_mul(q.x, z2);
+  u32 *e = tab + NE * SLOT_ENTRY_WORDS;
+  slot_store_fe(e + 0, x);
+  slot_store_fe(e + 8, fe_mul(x, fe_from_words(betaw)));
+  slot_store_fe(e + 16, fe_mul(q.y, fe_mul(z2, zc)));
+}
+template <int T>
+LAMD_HD void kc_rescale(u32 *tab, const u32 *scratch, int sub) {
   const u32 betaw[8] = LAMD_BETA;
   const fe beta = fe_from_words(betaw);
-  const fe ratio = slot_load_raw(scratch + pos * PS + 27);
+  const fe ratio = slot_load_raw(scratch + kc_sub_off(T) + sub * KC_SUB_WORDS + 9);
   const fe r2 = fe_sqr(ratio);
   const fe r3 = fe_mul(r2, ratio);
 #pragma unroll 1
-  for (int e = 0; e < NE; e++) {
-    u32 *ent = tab + (pos * NE + e) * SLOT_ENTRY_WORDS;
+  for (int e = 0; e < KC_SUB; e++) {
+    u32 *ent = tab + (sub * KC_SUB + e) * SLOT_ENTRY_WORDS;
     const fe x = fe_mul(slot_load_fe(ent + 0), r2);
     const fe y = fe_mul(slot_load_fe(ent + 16), r3);
     slot_store_fe(ent + 0, x);
@@ -434,35 +523,26 @@ LAMD_HD void kt_rescale(u32 *tab, const u32 *scratch, int pos) {
   }
 }
 // sequential composition (CPU test harness; the engine launches the stages as separate kernels)
-template <int W, int S>
+template <int T>
 LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
-  kt_bases<W, S>(scratch, q);
-  for (int pos = 0; pos < kt_npos(W, S); pos++) kt_multiples<W, S>(tab, scratch, pos);
-  kt_prefix<W, S>(tab, scratch);
-  for (int pos = 0; pos < kt_npos(W, S); pos++) kt_rescale<W, S>(tab, scratch, pos);
+  kc_bases<T>(scratch, q);
+  for (int s = 0; s < kc_nsub(T); s++) kc_chain<T>(tab, scratch, s);
+  kc_prefix<T>(tab, scratch, q);
+  for (int s = 0; s < kc_nsub(T); s++) kc_rescale<T>(tab, scratch, s);
 }
 
-template <int NE>
-LAMD_HD gej gej_add_table_digit(const gej &acc, const u32 *tab, int pos, int d, bool lambda_half) {
-  const bool skip = d == 0;
-  const int a = d < 0 ? -d : d;
-  const u32 *e = tab + (pos * NE + (skip ? 0 : a - 1)) * SLOT_ENTRY_WORDS;
-  ge pt;
-  pt.x = slot_load_fe(e + (lambda_half ? 8 : 0));
-  pt.y = slot_load_fe(e + 16);
-  pt = ge_neg_if(pt, d < 0);
-  return gej_add_ge(acc, pt, skip);
-}
-
-// 5-bit recoding of one GLV half from its prep_rec form: |k| = mag + top*2^128 - 0x88..8, then + 16 per 5-bit group
-struct glv5 { u32 v[5]; };
-LAMD_HD glv5 glv5_from_rec(const u32 mag[4], u32 top) {
-  // 16 * sum_{i<28} 32^i as 32-bit words (140 bits)
-  const u32 bias5[5] = {0x21084210u, 0x08421084u, 0x42108421u, 0x10842108u, 0x00000842u};
-  glv5 r;
+// Comb recoding of one GLV half from its prep_rec form (|k| = mag + top*2^128 - 0x88..8): tooth i holds bits
+// iD..iD+D-1 of w = (|k| >> 1) | 2^(N-1)
+template <int T>
+struct comb_half {
+  u32 tooth[T];
+  bool even;
+};
+template <int T>
+LAMD_HD comb_half<T> comb_from_rec(const u32 mag[4], u32 top) {
+  constexpr int D = kc_spacing(T), N = T * D;
+  u32 t[6];
   u64 c = 0;
-  u32 t[5];
-  // t = mag + top*2^128 - 0x88888888 x4
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const u64 d = (u64)mag[i] - 0x88888888u - c;
@@ -470,56 +550,62 @@ LAMD_HD glv5 glv5_from_rec(const u32 mag[4], u32 top) {
     c = (d >> 32) & 1;
   }
   t[4] = top - (u32)c;
-  c = 0;
+  t[5] = 0;
+  comb_half<T> r;
+  r.even = (t[0] & 1u) == 0;
+  u32 w[6];
 #pragma unroll
-  for (int i = 0; i < 5; i++) {
-    c += (u64)t[i] + bias5[i];
-    r.v[i] = (u32)c;
-    c >>= 32;
+  for (int i = 0; i < 5; i++) w[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  w[5] = 0;
+  w[(N - 1) >> 5] |= 1u << ((N - 1) & 31);
+#pragma unroll
+  for (int i = 0; i < T; i++) {
+    const int word = (i * D) >> 5, sh = (i * D) & 31;
+    u32 v = w[word] >> sh;
+    if (sh + D > 32) v |= w[word + 1] << (32 - sh);
+    r.tooth[i] = v & ((1u << D) - 1u);
   }
   return r;
 }
-LAMD_HD int glv5_digit(const glv5 &g, int i) {
-  const int bit = 5 * i, w = bit >> 5, sh = bit & 31;
-  const u64 win = (u64)g.v[w] | ((u64)(w + 1 < 5 ? g.v[w + 1] : 0u) << 32);
-  return (int)((win >> sh) & 31u) - 16;
-}
 
-// R = u1*G + (k1 + k2*lambda)*Q from the key's table
-template <int W, int S>
+// R = u1*G + (k1 + k2*lambda)*Q from the key's comb table
+template <int T>
 LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gtable) {
-  constexpr int ND = kt_ndigits(W, S), NC = ND / S, NE = kt_ne(W);
+  constexpr int D = kc_spacing(T), NE = kc_ne(T);
   const bool n1 = rec.flags & PREP_K1NEG, n2 = rec.flags & PREP_K2NEG;
-  const u32 t1 = (rec.flags & PREP_K1TOP) ? 1u : 0u, t2 = (rec.flags & PREP_K2TOP) ? 1u : 0u;
-  glv5 g1, g2;
-  if (W == 5) {
-    g1 = glv5_from_rec(rec.k1, t1);
-    g2 = glv5_from_rec(rec.k2, t2);
-  }
+  const comb_half<T> h1 = comb_from_rec<T>(rec.k1, (rec.flags & PREP_K1TOP) ? 1u : 0u);
+  const comb_half<T> h2 = comb_from_rec<T>(rec.k2, (rec.flags & PREP_K2TOP) ? 1u : 0u);
   gej acc = gej_infinity();
 #pragma unroll 1
-  for (int j = S - 1; j >= 0; j--) {
-    if (j != S - 1) {
+  for (int j = D - 1; j >= 0; j--) {
+    if (j != D - 1) acc = gej_double(acc);
 #pragma unroll 1
-      for (int k = 0; k < W; k++) acc = gej_double(acc);
-    }
-    // W = 4: at j == 0 the extra position carries nibble 32 (the recoding carry)
-#pragma unroll 1
-    for (int c = 0; c < NC + ((W == 4 && j == 0) ? 1 : 0); c++) {
-      const int i = c * S + j;
-      if (W == 5 && i >= 26) continue;  // padding digits of the 28-digit comb are structurally zero
-#pragma unroll 1
-      for (int half = 0; half < 2; half++) {
-        int d;
-        if (W == 4) d = half ? glv_digit(rec.k2, t2, i) : glv_digit(rec.k1, t1, i);
-        else d = half ? glv5_digit(g2, i) : glv5_digit(g1, i);
-        if (half ? n2 : n1) d = -d;
-        acc = gej_add_table_digit<NE>(acc, tab, c, d, half != 0);
-      }
+    for (int half = 0; half < 2; half++) {
+      u32 m = 0;
+#pragma unroll
+      for (int i = 0; i < T; i++) m |= (((half ? h2.tooth[i] : h1.tooth[i]) >> j) & 1u) << i;
+      const bool top = (m >> (T - 1)) & 1u;
+      const u32 idx = (top ? m : ~m) & (u32)(NE - 1);
+      const u32 *e = tab + idx * SLOT_ENTRY_WORDS;
+      ge pt;
+      pt.x = slot_load_fe(e + (half ? 8 : 0));
+      pt.y = slot_load_fe(e + 16);
+      pt = ge_neg_if(pt, top == (half ? n2 : n1));  // column value is -entry when the top tooth is -1; times the half's sign
+      acc = gej_add_ge(acc, pt, false);
     }
   }
+  // an even |k| was evaluated as |k| + 1: take sign*Q (sign*lambda*Q) off again
+#pragma unroll 1
+  for (int half = 0; half < 2; half++) {
+    const u32 *e = tab + NE * SLOT_ENTRY_WORDS;
+    ge pt;
+    pt.x = slot_load_fe(e + (half ? 8 : 0));
+    pt.y = slot_load_fe(e + 16);
+    pt = ge_neg_if(pt, !(half ? n2 : n1));
+    acc = gej_add_ge(acc, pt, !(half ? h2.even : h1.even));
+  }
   // back from the table's isomorphic curve: (X, Y, Z) -> (X, Y, Z*Zc)
-  acc.z = fe_mul(acc.z, slot_load_fe(tab + kt_words(W, S) + KT_ZC_OFF));
+  acc.z = fe_mul(acc.z, slot_load_fe(tab + kc_words(T)));
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);

@@ -102,10 +102,10 @@ void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8
 }
 // keyed path: one window table per row's key (no sharing here -- this is an arithmetic test), then the table-driven ecmult
 }  // extern "C"
-template <int W, int S>
+template <int T>
 static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
   dm_init();
-  std::vector<u32> tab(kt_stride(W, S)), scratch(kt_scratch_words(W, S)), fin(n * 32);
+  std::vector<u32> tab(kc_stride(T)), scratch(kc_scratch_words(T)), fin(n * 32);
   std::vector<prep_rec> recs(n);
   if (mode == MODE_ECDSA) ecdsa_prep_thread(0, 1, n, a32, sig64, recs.data());
   for (size_t i = 0; i < n; i++) {
@@ -115,39 +115,74 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
     ok &= (recs[i].flags & PREP_VALID) != 0;
     out[i] = 0;
     if (ok) {
-      keytable_build<W, S>(tab.data(), scratch.data(), ge_from_words(qx, qy));
-      const gej R = ecmult_lane_keyed<W, S>(recs[i], tab.data(), g_table.data());
+      keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+      const gej R = ecmult_lane_keyed<T>(recs[i], tab.data(), g_table.data());
       be_to_words(rw, sig64 + 64 * i);
       out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
     }
   }
   if (mode == MODE_SCHNORR) schnorr_final_thread(0, 1, n, fin.data(), out, 32);
 }
-extern "C" {
-void dm_verify_keyed(int mode, int W, int S, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
-  if (W == 4 && S == 1) verify_keyed_t<4, 1>(mode, n, a32, sig64, key, keylen, out);
-  else if (W == 4) verify_keyed_t<4, 8>(mode, n, a32, sig64, key, keylen, out);
-  else if (S == 1) verify_keyed_t<5, 1>(mode, n, a32, sig64, key, keylen, out);
-  else verify_keyed_t<5, 7>(mode, n, a32, sig64, key, keylen, out);
-}
-// table entry (pos, d) of a key as 64 affine bytes + 32 bytes beta*x
-void dm_keytable_entry(const u8 *key33, int W, int S, int pos, int d, u8 *out96) {
-  std::vector<u32> tab(kt_stride(5, 1) + kt_stride(4, 1)), scratch(kt_scratch_words(5, 1) + kt_scratch_words(4, 1));
-  u32 qx[8], qy[8];
-  parse_pubkey(key33, 33, qx, qy);
-  int words, ne;
-  if (W == 4 && S == 1) { keytable_build<4, 1>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(4, 1); ne = 8; }
-  else if (W == 4) { keytable_build<4, 8>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(4, 8); ne = 8; }
-  else if (S == 1) { keytable_build<5, 1>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(5, 1); ne = 16; }
-  else { keytable_build<5, 7>(tab.data(), scratch.data(), ge_from_words(qx, qy)); words = kt_words(5, 7); ne = 16; }
+template <int T>
+static void keytable_entry_t(const u32 *qx, const u32 *qy, int idx, u8 *out96) {
+  std::vector<u32> tab(kc_stride(T)), scratch(kc_scratch_words(T));
+  keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
   // entries are affine on the key's isomorphic curve: x = x_true * Zc^2, y = y_true * Zc^3
-  const fe zc = slot_load_fe(&tab[words + KT_ZC_OFF]);
+  const fe zc = slot_load_fe(&tab[kc_words(T)]);
   const fe zi = fe_inv(zc), zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
-  const u32 *e = &tab[(pos * ne + d - 1) * SLOT_ENTRY_WORDS];
+  const u32 *e = &tab[idx * SLOT_ENTRY_WORDS];
   u32 w[8];
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e), zi2))); words_to_be(out96, w);
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 16), zi3))); words_to_be(out96 + 32, w);
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 8), zi2))); words_to_be(out96 + 64, w);
+}
+extern "C" {
+int dm_comb_spacing(int T) { return kc_spacing(T); }
+void dm_verify_keyed(int mode, int T, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  if (T == 7) verify_keyed_t<7>(mode, n, a32, sig64, key, keylen, out);
+  else if (T == 8) verify_keyed_t<8>(mode, n, a32, sig64, key, keylen, out);
+  else if (T == 9) verify_keyed_t<9>(mode, n, a32, sig64, key, keylen, out);
+  else verify_keyed_t<10>(mode, n, a32, sig64, key, keylen, out);
+}
+// comb table entry idx (0..2^(T-1): the last one is Q itself) of a key as 64 affine bytes + 32 bytes beta*x
+void dm_keytable_entry(const u8 *key33, int T, int idx, u8 *out96) {
+  u32 qx[8], qy[8];
+  parse_pubkey(key33, 33, qx, qy);
+  if (T == 7) keytable_entry_t<7>(qx, qy, idx, out96);
+  else if (T == 8) keytable_entry_t<8>(qx, qy, idx, out96);
+  else if (T == 9) keytable_entry_t<9>(qx, qy, idx, out96);
+  else keytable_entry_t<10>(qx, qy, idx, out96);
+}
+// R = u1*G + u2*Q through the GLV split, the key's comb table and the table-driven ecmult; returns 0 for infinity
+}  // extern "C"
+template <int T>
+static int ecmult_keyed_t(const u32 *qx, const u32 *qy, const u8 *u1, const u8 *u2, u8 *out64) {
+  dm_init();
+  std::vector<u32> tab(kc_stride(T)), scratch(kc_scratch_words(T));
+  keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  prep_rec rec;
+  sc k; be_to_words(k.w, u2);
+  be_to_words(rec.u1, u1);
+  glv_half h1, h2;
+  glv_split(&h1, &h2, k);
+  for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
+  rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
+  const gej R = ecmult_lane_keyed<T>(rec, tab.data(), g_table.data());
+  if (R.inf) return 0;
+  const fe zi = fe_inv(fe_norm_weak(R.z)), zi2 = fe_sqr(zi);
+  u32 w[8];
+  fe_to_words(w, fe_normalize(fe_mul(R.x, zi2))); words_to_be(out64, w);
+  fe_to_words(w, fe_normalize(fe_mul(R.y, fe_mul(zi2, zi)))); words_to_be(out64 + 32, w);
+  return 1;
+}
+extern "C" {
+int dm_ecmult_keyed(int T, const u8 *key33, const u8 *u1, const u8 *u2, u8 *out64) {
+  u32 qx[8], qy[8];
+  parse_pubkey(key33, 33, qx, qy);
+  if (T == 7) return ecmult_keyed_t<7>(qx, qy, u1, u2, out64);
+  if (T == 8) return ecmult_keyed_t<8>(qx, qy, u1, u2, out64);
+  if (T == 9) return ecmult_keyed_t<9>(qx, qy, u1, u2, out64);
+  return ecmult_keyed_t<10>(qx, qy, u1, u2, out64);
 }
 // two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
 void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {

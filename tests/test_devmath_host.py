@@ -264,32 +264,59 @@ def test_pipeline_random_vs_oracle(dm, orc):
 
 
 def test_keyed_path_tables_and_verdicts(dm, kat):
-    """per-key window tables hold d*2^(W*S*c)*Q as affine points of the key's isomorphic curve (W = 4 or 5 bit windows,
-    dense S = 1 or comb), and the table-driven ecmult gives the golden verdicts for ECDSA (33/65-byte keys) and BIP-340"""
+    """per-key comb tables (T teeth, spacing D) hold 2^((T-1)D)*Q + sum_i +-2^(iD)*Q as affine points of the key's isomorphic
+    curve, plus Q itself, and the table-driven ecmult gives the golden verdicts for ECDSA (33/65-byte keys) and BIP-340"""
     BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
     d = 0x1F2E3D4C5B6A79881726354453627180AABBCCDDEEFF00112233445566778899
     Q = pyref.pubkey_create(d)
     o = ctypes.create_string_buffer(96)
-    shapes = {(4, 1): ((0, 1), (0, 8), (1, 3), (7, 5), (31, 8), (32, 1), (32, 8), (16, 2)), (4, 8): ((0, 1), (0, 8), (1, 3), (3, 7), (4, 1), (4, 8)),
-              (5, 1): ((0, 1), (0, 16), (1, 9), (25, 16), (13, 5)), (5, 7): ((0, 1), (0, 16), (1, 11), (3, 16), (2, 7))}
-    for (W, S), cases in shapes.items():
-        for pos, dig in cases:
-            dm.dm_keytable_entry(pyref.ser33(Q), W, S, pos, dig, o)
-            pt = pyref.pmul(dig * (1 << (W * S * pos)) % N, Q)
-            assert o.raw[:32] == pt[0].to_bytes(32, "big") and o.raw[32:64] == pt[1].to_bytes(32, "big"), (W, S, pos, dig)
+    for T in (7, 8, 9, 10):
+        D = dm.dm_comb_spacing(T)
+        assert T * D >= 129
+        ne = 1 << (T - 1)
+        for idx in sorted({0, 1, 2, 3, 15, 16, 17, 31, ne // 2 - 1, ne // 2, ne - 2, ne - 1, ne, 0x2A % ne, 0x55 % ne}):
+            dm.dm_keytable_entry(pyref.ser33(Q), T, idx, o)
+            if idx == ne:
+                k = 1
+            else:
+                k = (1 << ((T - 1) * D)) + sum((1 if (idx >> i) & 1 else -1) << (i * D) for i in range(T - 1))
+            pt = pyref.pmul(k % N, Q)
+            assert o.raw[:32] == pt[0].to_bytes(32, "big") and o.raw[32:64] == pt[1].to_bytes(32, "big"), (T, idx)
             assert int.from_bytes(o.raw[64:], "big") == BETA * pt[0] % P
-    for W, S in shapes:
+    for T in (7, 8, 9, 10):
         for publen in (33, 65):
             rows = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
             rows = rows[:80] + rows[-40:]   # reference KATs + edge classes + special keys / key-less / x(R) = r + n
             out = ctypes.create_string_buffer(len(rows))
-            dm.dm_verify_keyed(0, W, S, ctypes.c_size_t(len(rows)), b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+            dm.dm_verify_keyed(0, T, ctypes.c_size_t(len(rows)), b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
                                b"".join(H(v["pub"]) for v in rows), publen, out)
             bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
-            assert not bad, (W, S, bad[:10])
+            assert not bad, (T, bad[:10])
         rows = kat["schnorr"][:60]
         out = ctypes.create_string_buffer(len(rows))
-        dm.dm_verify_keyed(1, W, S, ctypes.c_size_t(len(rows)), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+        dm.dm_verify_keyed(1, T, ctypes.c_size_t(len(rows)), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
                            b"".join(H(v["pk"]) for v in rows), 32, out)
         bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
-        assert not bad, (W, S, bad[:10])
+        assert not bad, (T, bad[:10])
+
+
+def test_keyed_ecmult_special_scalars(dm):
+    """u1*G + u2*Q through the comb for scalars that stress the recoding: zero / even / tiny GLV halves, halves that cancel,
+    u2 = +-lambda^i (one half exactly +-1), the partial sums that meet -u1*G, and seeded random ones"""
+    LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    d = 0x6C1F00D5A3E2B4C7918D7E6F5A4B3C2D1E0F99887766554433221100FFEEDDCC
+    Q = pyref.pubkey_create(d)
+    rng = random.Random(77)
+    u2s = [0, 1, 2, 3, 4, N - 1, N - 2, LAM, N - LAM, LAM + 1, LAM - 1, 2 * LAM % N, (LAM + 2) % N, LAM * LAM % N, (N - LAM * LAM) % N,
+           1 << 127, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, ((1 << 127) * LAM + 2) % N, (N + 1) // 2]
+    u2s += [rng.randrange(N) for _ in range(12)]
+    o = ctypes.create_string_buffer(64)
+    for T in (7, 10):
+        for u2 in u2s:
+            for u1 in (0, 1, rng.randrange(N), (-u2 * d) % N, (-u2 * d + 1) % N):
+                got = dm.dm_ecmult_keyed(T, pyref.ser33(Q), u1.to_bytes(32, "big"), u2.to_bytes(32, "big"), o)
+                exp = pyref.padd(pyref.pmul(u1, pyref.G), pyref.pmul(u2, Q))
+                if exp is None:
+                    assert got == 0, (T, hex(u1), hex(u2))
+                else:
+                    assert got == 1 and o.raw == exp[0].to_bytes(32, "big") + exp[1].to_bytes(32, "big"), (T, hex(u1), hex(u2))

@@ -306,20 +306,19 @@ def test_cfg5_full_size_properties(eng):
     assert (~we.expect).sum() + (~ws.expect).sum() == int(we.n * 0.001) + int(ws.n * 0.001)
 
 
-@pytest.fixture(scope="module", params=[(5, 1), (5, 7), (4, 1), (4, 8)])
+@pytest.fixture(scope="module", params=[7, 10])
 def eng_keyed(request):
-    """engine forced onto the keyed path (per-key tables) whenever a key repeats at all; every table shape"""
+    """engine forced onto the keyed path (per-key comb tables) whenever a key repeats at all; both comb shapes"""
     import os
     from lightning_amd import Engine
-    W, S = request.param
+    T = request.param
     os.environ["LAMD_KEYED"] = "1"
-    os.environ["LAMD_KEYED_SPACING"] = str(S)
-    os.environ["LAMD_KEYED_WINDOW"] = str(W)
+    os.environ["LAMD_KEYED_TEETH"] = str(T)
     try:
         e = Engine(0)
     finally:
-        del os.environ["LAMD_KEYED"], os.environ["LAMD_KEYED_SPACING"], os.environ["LAMD_KEYED_WINDOW"]
-    e.spacing = S
+        del os.environ["LAMD_KEYED"], os.environ["LAMD_KEYED_TEETH"]
+    e.spacing = T
     yield e
     e.close()
 
@@ -363,7 +362,7 @@ def test_keyed_path_auto_selection_and_parity(eng, orc):
     eng.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
     eng.synchronize()
     inf = eng.info()
-    assert inf["last_keyed"] == 1 and 100 <= inf["last_unique_keys"] < 600   # >= 48 signatures per key: dense tables (S = 1)
+    assert inf["last_keyed"] == 10 and 100 <= inf["last_unique_keys"] < 600  # >= 48 signatures per key: the 10-tooth comb
     got = w.d_ok.cpu().numpy().astype(bool)
     assert np.array_equal(got, w.expect), (np.nonzero(got != w.expect)[0][:10], w.classes[got != w.expect][:10])
     sl = slice(0, 1200)
@@ -372,7 +371,7 @@ def test_keyed_path_auto_selection_and_parity(eng, orc):
     w = workload.make_schnorr(eng, 30000, nkeys=2000)
     eng.verify_schnorr_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
     eng.synchronize()
-    assert eng.info()["last_keyed"] == 7                                       # ~13 signatures per key: comb tables (5-bit windows, S = 7)
+    assert eng.info()["last_keyed"] == 7                                       # ~13 signatures per key: the 7-tooth comb
     got = w.d_ok.cpu().numpy().astype(bool)
     assert np.array_equal(got, w.expect), (np.nonzero(got != w.expect)[0][:10], w.classes[got != w.expect][:10])
     w = workload.make_ecdsa(eng, 30000, nkeys=1 << 40, publen=65)          # all keys distinct
