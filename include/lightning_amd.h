@@ -64,14 +64,22 @@ int lamd_verify_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, cons
 int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32,
 			      const uint8_t *sig64, uint8_t *ok);
 
-/* ---- the same with every buffer already resident in HBM (device pointers), asynchronous on the
- * context's stream (lamd_stream()); the caller synchronises.  This is what bench.py times. */
+/* ---- the same with every buffer already resident in HBM (device pointers), asynchronous: the work is ordered after
+ * whatever is already queued on the context's stream (lamd_stream()) and the verdicts are complete after
+ * lamd_synchronize(), or, without blocking the host, for a stream passed to lamd_stream_wait_results().  Successive
+ * calls alternate between two internal lanes (own streams and workspaces) so that one call's key de-duplication and
+ * table building run under the previous call's ecmult kernel; LAMD_LANES=1 turns that off (strictly one stream).
+ * This is what bench.py times. */
 int lamd_verify_ecdsa_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64,
 				   const void *d_pub, size_t publen, size_t pubstride, void *d_ok);
 int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg32, const void *d_xonly32,
 				     const void *d_sig64, void *d_ok);
 void *lamd_stream(lamd_ctx *ctx); /* hipStream_t */
 int lamd_synchronize(lamd_ctx *ctx);
+/* `stream` (hipStream_t) waits, on the device, for every verification submitted so far */
+int lamd_stream_wait_results(lamd_ctx *ctx, void *stream);
+/* verification submitted from now on waits, on the device, for what `stream` holds at this moment */
+int lamd_wait_stream(lamd_ctx *ctx, void *stream);
 
 /* ---- single-item veneers with the reference's exact boolean semantics (1 = true, 0 = false,
  * < 0 = engine error: treat as failure).  They run a batch of one: correct but latency-bound;
@@ -188,8 +196,10 @@ typedef struct {
 	size_t last_hot_rows;     /* rows of the last chunk verified against per-key tables (the rest took the ladder) */
 	int last_keyed;           /* 0: per-signature ladder only; else rows of the last chunk ran on per-key tables and this is
 				   * the number of comb teeth of those tables (7 or 10) */
+	int last_mode;            /* 0: the last chunk was ECDSA, 1: BIP-340 */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
+int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 / 1 */
 int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@ c_sz = ctypes.c_size_t
 class LamdInfo(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("arch", ctypes.c_char * 64),
                 ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4), ("last_unique_keys", ctypes.c_size_t),
-                ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int)]
+                ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int), ("last_mode", ctypes.c_int)]
 
 
 # name -> (restype, argtypes); every symbol of include/lightning_amd.h
@@ -48,6 +48,9 @@ SYMBOLS = {
     "lamd_debug_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_sz, c_sz, c_u8p]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_get_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LamdInfo)]),
+    "lamd_stream_wait_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "lamd_wait_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 _lib = None

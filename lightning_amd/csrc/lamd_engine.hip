@@ -590,12 +590,12 @@ __global__ void __launch_bounds__(256) k_kc_bases(size_t nkeys, const u32 *__res
   kc_bases<T>(scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
 }
 template <int T>
-__global__ void __launch_bounds__(256) k_kc_chain(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+__global__ void __launch_bounds__(256) k_kc_chain_fwd(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
                                                   u32 *__restrict__ scratch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t u = t / kc_nsub(T);
   if (u >= nkeys || !keyok[u]) return;
-  kc_chain<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
+  kc_chain_fwd<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
 }
 template <int T>
 __global__ void __launch_bounds__(256) k_kc_prefix(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
@@ -608,20 +608,20 @@ __global__ void __launch_bounds__(256) k_kc_prefix(size_t nkeys, const u32 *__re
   kc_prefix<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
 }
 template <int T>
-__global__ void __launch_bounds__(256) k_kc_rescale(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
+__global__ void __launch_bounds__(256) k_kc_chain_bwd(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
                                                     const u32 *__restrict__ scratch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t u = t / kc_nsub(T);
   if (u >= nkeys || !keyok[u]) return;
-  kc_rescale<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
+  kc_chain_bwd<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
 }
 template <int T>
 static void launch_keytables(hipStream_t st, size_t nkeys, const u32 *qwords, const u8 *keyok, u32 *tables, u32 *scratch) {
   const size_t chains = nkeys * kc_nsub(T);
   hipLaunchKernelGGL((k_kc_bases<T>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, scratch);
-  hipLaunchKernelGGL((k_kc_chain<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
+  hipLaunchKernelGGL((k_kc_chain_fwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
   hipLaunchKernelGGL((k_kc_prefix<T>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, tables, scratch);
-  hipLaunchKernelGGL((k_kc_rescale<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, (const u32 *)scratch);
+  hipLaunchKernelGGL((k_kc_chain_bwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, (const u32 *)scratch);
 }
 
 // work item j verifies row list[j] against the table of its (hot) key
@@ -700,6 +700,7 @@ struct lamd_ctx {
   double keyed_dense_uses = 48.0;  // ... and for the 10-tooth comb (512 entries per key)
   int keyed_teeth = 0;             // 0 = choose by re-use, 7 or 10 = force that comb (LAMD_KEYED_TEETH)
   int last_spacing = 0;
+  int last_mode = 0;
   size_t last_unique_keys = 0;
   bool last_keyed = false;
   devbuf in_a, in_b, in_c, out;       // staging for the host-buffer API
@@ -723,6 +724,17 @@ struct lamd_ctx {
   int inflight_total = 0;
   bool flushed = false;
   hipEvent_t flush_done = nullptr;
+  // Lanes: the device-pointer entry points alternate between two complete sub-contexts (own streams and workspaces, the
+  // G table shared), so that the latency-bound front end of one call (key de-duplication, the count read-back, table
+  // building) runs under the VALU-bound ecmult kernel of the previous one.  A lane's `peer` is the other lane; the
+  // root context (the handle the caller holds) has lane[0..1] and keeps its own stream for staging, queues, generators.
+  lamd_ctx *lane[2] = {nullptr, nullptr};
+  lamd_ctx *peer = nullptr;
+  lamd_ctx *last_lane = nullptr;
+  lamd_ctx *last_chunk_lane = nullptr;  // where the last chunk of this lane's last call ran (itself or its peer)
+  bool is_lane = false;
+  int next_lane = 0;
+  hipEvent_t ev_lane = nullptr, ev_join = nullptr;
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -766,6 +778,57 @@ extern "C" const char *lamd_last_error(const lamd_ctx *ctx) { return ctx ? ctx->
 
 static int init_known_answers(lamd_ctx *ctx);
 
+static int create_streams(lamd_ctx *ctx) {
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming));
+  return LAMD_OK;
+}
+static int make_lanes(lamd_ctx *root) {
+  for (int i = 0; i < 2; i++) {
+    lamd_ctx *L = new (std::nothrow) lamd_ctx();
+    if (!L) return LAMD_ERR_NOMEM;
+    root->lane[i] = L;
+    L->is_lane = true;
+    L->device = root->device;
+    L->prop = root->prop;
+    L->gtable = root->gtable;
+    L->ecmult_waves = root->ecmult_waves;
+    L->hash_seed = root->hash_seed;
+    L->chunk = root->chunk;
+    L->keyed_mode = root->keyed_mode;
+    L->keyed_min_rows = root->keyed_min_rows;
+    L->keyed_min_uses = root->keyed_min_uses;
+    L->keyed_dense_uses = root->keyed_dense_uses;
+    L->keyed_teeth = root->keyed_teeth;
+    const int rc = create_streams(L);
+    if (rc != LAMD_OK) { root->err = L->err; return rc; }
+  }
+  root->lane[0]->peer = root->lane[1];
+  root->lane[1]->peer = root->lane[0];
+  return LAMD_OK;
+}
+// the lane the next device-pointer call runs on, ordered after whatever is already queued on the context's own stream
+static int pick_lane(lamd_ctx *root, lamd_ctx **out) {
+  *out = root;
+  if (!root->lane[0]) return LAMD_OK;
+  lamd_ctx *L = root->lane[root->next_lane];
+  root->next_lane ^= 1;
+  root->last_lane = L;
+  L->timing = root->timing;
+  HIPCHK(root, hipEventRecord(root->ev_lane, root->stream));
+  HIPCHK(root, hipStreamWaitEvent(L->stream, root->ev_lane, 0));
+  *out = L;
+  return LAMD_OK;
+}
+
 extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (!out) return LAMD_ERR_ARG;
   *out = nullptr;
@@ -793,14 +856,8 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
   if (const char *w = getenv("LAMD_KEYED_TEETH")) ctx->keyed_teeth = atoi(w) == 7 ? 7 : (atoi(w) == 10 ? 10 : 0);
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
-  for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming));
+  int rc = create_streams(ctx);
+  if (rc != LAMD_OK) return rc;
   // window bases B_w = 2^(16 w) G, computed here with the same group code the kernels use (64 doublings each)
   std::vector<u32> bases(GTABLE_WINDOWS * 16);
   {
@@ -826,12 +883,21 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipFree(d_bases));
+  const char *lanes = getenv("LAMD_LANES");
+  if (!lanes || atoi(lanes) != 1) {
+    rc = make_lanes(ctx);
+    if (rc != LAMD_OK) return rc;
+  }
   return init_known_answers(ctx);
 }
 
 extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  for (auto &L : ctx->lane) {
+    if (L) lamd_shutdown(L);
+    L = nullptr;
+  }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (devbuf *b : {&ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kd_counter, &ctx->kt_tables,
                     &ctx->kt_scratch, &ctx->kt_qwords, &ctx->kt_keyok, &ctx->kt_fin, &ctx->kd_count, &ctx->kd_hotidx, &ctx->kd_hotrow,
@@ -851,7 +917,9 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
       if (*h) (void)hipHostFree(*h);
     for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
   }
-  if (ctx->gtable) (void)hipFree(ctx->gtable);
+  if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
+  if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->flush_done) (void)hipEventDestroy(ctx->flush_done);
@@ -863,6 +931,11 @@ extern "C" void *lamd_stream(lamd_ctx *ctx) { return ctx ? (void *)ctx->stream :
 
 extern "C" int lamd_synchronize(lamd_ctx *ctx) {
   if (!ctx) return LAMD_ERR_ARG;
+  for (lamd_ctx *L : ctx->lane) {
+    if (!L) continue;
+    const int rc = lamd_synchronize(L);
+    if (rc != LAMD_OK) { ctx->err = L->err; return rc; }
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->timing && ctx->ev_recorded) {
     for (int i = 0; i < 4; i++) {
@@ -874,14 +947,44 @@ extern "C" int lamd_synchronize(lamd_ctx *ctx) {
   return LAMD_OK;
 }
 
-extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
+// `stream` (a hipStream_t of the caller) waits for every verification submitted so far -- without blocking the host
+extern "C" int lamd_stream_wait_results(lamd_ctx *ctx, void *stream) {
   if (!ctx) return LAMD_ERR_ARG;
-  ctx->timing = enable != 0;
+  for (lamd_ctx *L : {ctx->lane[0], ctx->lane[1], ctx}) {
+    if (!L) continue;
+    HIPCHK(ctx, hipEventRecord(L->ev_join, L->stream));
+    HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, L->ev_join, 0));
+  }
+  return LAMD_OK;
+}
+// verification submitted from now on waits for what `stream` holds at this moment (e.g. a consumer of an earlier result buffer)
+extern "C" int lamd_wait_stream(lamd_ctx *ctx, void *stream) {
+  if (!ctx) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, (hipStream_t)stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
   return LAMD_OK;
 }
 
+extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
+  if (!ctx) return LAMD_ERR_ARG;
+  ctx->timing = enable != 0;
+  for (lamd_ctx *L : ctx->lane)
+    if (L) L->timing = ctx->timing;
+  return LAMD_OK;
+}
+
+static int get_info_of(lamd_ctx *ctx, lamd_info *info);
 extern "C" int lamd_get_info(lamd_ctx *ctx, lamd_info *info) {
   if (!ctx || !info) return LAMD_ERR_ARG;
+  return get_info_of(ctx->last_lane ? ctx->last_lane : ctx, info);
+}
+// the same for one lane (0 or 1): with two lanes, alternate calls land on alternate lanes
+extern "C" int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info) {
+  if (!ctx || !info || lane < 0 || lane > 1) return LAMD_ERR_ARG;
+  return get_info_of(ctx->lane[lane] ? ctx->lane[lane] : ctx, info);
+}
+static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
+  if (ctx->last_chunk_lane) ctx = ctx->last_chunk_lane;
   memset(info, 0, sizeof(*info));
   info->device = ctx->device;
   info->compute_units = ctx->prop.multiProcessorCount;
@@ -891,6 +994,7 @@ extern "C" int lamd_get_info(lamd_ctx *ctx, lamd_info *info) {
   info->last_unique_keys = ctx->last_unique_keys;
   info->last_hot_rows = ctx->last_hot_rows;
   info->last_keyed = ctx->last_keyed ? ctx->last_spacing : 0;
+  info->last_mode = ctx->last_mode;
   return LAMD_OK;
 }
 
@@ -953,6 +1057,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   HIPCHK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream2));
 
   ctx->last_keyed = false;
+  ctx->last_mode = mode;
   ctx->last_unique_keys = 0;
   ctx->last_hot_rows = 0;
   size_t nhot = 0, hot_rows = 0;
@@ -1057,11 +1162,28 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
 static int run_device(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
                       size_t keystride, u8 *d_ok) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  for (size_t o = 0; o < n; o += ctx->chunk) {
+  bool forked = false;
+  size_t k = 0;
+  for (size_t o = 0; o < n; o += ctx->chunk, k++) {
     const size_t m = n - o < ctx->chunk ? n - o : ctx->chunk;
-    const int rc = run_chunk(ctx, mode, m, d_a + 32 * o, d_sig + 64 * o, d_key + keystride * o, keylen, keystride, d_ok + o,
+    lamd_ctx *W = (k & 1) && ctx->peer ? ctx->peer : ctx;  // odd chunks on the other lane: its front end overlaps this lane's ecmult
+    W->timing = ctx->timing;
+    if (W != ctx && !forked) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev_lane, ctx->stream));  // whatever precedes the call on this lane (staging, gossip expand)
+      HIPCHK(ctx, hipStreamWaitEvent(W->stream, ctx->ev_lane, 0));
+      forked = true;
+    }
+    const int rc = run_chunk(W, mode, m, d_a + 32 * o, d_sig + 64 * o, d_key + keystride * o, keylen, keystride, d_ok + o,
                              ctx->timing && o + ctx->chunk >= n);
-    if (rc != LAMD_OK) return rc;
+    ctx->last_chunk_lane = W;
+    if (rc != LAMD_OK) {
+      if (W != ctx) ctx->err = W->err;
+      return rc;
+    }
+  }
+  if (forked) {  // what follows on this lane (result copies, gossip reduce) needs the other lane's chunks too
+    HIPCHK(ctx, hipEventRecord(ctx->peer->ev_join, ctx->peer->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->peer->ev_join, 0));
   }
   return LAMD_OK;
 }
@@ -1074,8 +1196,12 @@ extern "C" int lamd_verify_ecdsa_batch_device(lamd_ctx *ctx, size_t n, const voi
     ctx->err = "bad argument";
     return LAMD_ERR_ARG;
   }
-  return run_device(ctx, MODE_ECDSA, n, (const u8 *)d_hash32, (const u8 *)d_sig64, (const u8 *)d_pub, (int)publen, pubstride,
-                    (u8 *)d_ok);
+  lamd_ctx *L;
+  int rc = pick_lane(ctx, &L);
+  if (rc != LAMD_OK) return rc;
+  rc = run_device(L, MODE_ECDSA, n, (const u8 *)d_hash32, (const u8 *)d_sig64, (const u8 *)d_pub, (int)publen, pubstride, (u8 *)d_ok);
+  if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
+  return rc;
 }
 
 extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg32, const void *d_xonly32,
@@ -1086,7 +1212,12 @@ extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const v
     ctx->err = "bad argument";
     return LAMD_ERR_ARG;
   }
-  return run_device(ctx, MODE_SCHNORR, n, (const u8 *)d_msg32, (const u8 *)d_sig64, (const u8 *)d_xonly32, 32, 32, (u8 *)d_ok);
+  lamd_ctx *L;
+  int rc = pick_lane(ctx, &L);
+  if (rc != LAMD_OK) return rc;
+  rc = run_device(L, MODE_SCHNORR, n, (const u8 *)d_msg32, (const u8 *)d_sig64, (const u8 *)d_xonly32, 32, 32, (u8 *)d_ok);
+  if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
+  return rc;
 }
 
 static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride,
@@ -1301,13 +1432,17 @@ extern "C" int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const 
     return LAMD_ERR_ARG;
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc;
+  lamd_ctx *L;
+  int rc = pick_lane(ctx, &L);
+  if (rc != LAMD_OK) return rc;
   if (!d_node_ids33) {  // the expand kernel never dereferences it without a channel_update, but keep the pointer valid
-    if ((rc = ensure(ctx, &ctx->g_ids, 64)) != LAMD_OK) return rc;
-    d_node_ids33 = ctx->g_ids.p;
+    if ((rc = ensure(L, &L->g_ids, 64)) != LAMD_OK) { ctx->err = L->err; return rc; }
+    d_node_ids33 = L->g_ids.p;
   }
-  return gossip_device(ctx, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, nullptr, rows,
-                       (int8_t *)d_verdict);
+  rc = gossip_device(L, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, nullptr, rows,
+                     (int8_t *)d_verdict);
+  if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
+  return rc;
 }
 
 extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, const uint64_t *off,

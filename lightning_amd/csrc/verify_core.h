@@ -372,10 +372,11 @@ LAMD_HD void store_raw(u32 *dst, const fe &a) {
 // Building one key's table, in four stages so that stages 2 and 4 can run one thread per (key, chain):
 //   1 kc_bases    per key    the doubling chain Q -> 2^((T-1)D) Q, picking up B_i and C_i = 2*B_i on the way; all of
 //                            them brought to one Z (Zb) by products of the others' Z -- no inversion; P0 = B_(T-1) - sum B_i
-//   2 kc_chain    per chain  16 entries in Gray-code order from P0 + (the chain's fixed high teeth): one mixed addition of
-//                            +-C_i per entry, then back to the chain's last Z through the stored H values
+//   2 kc_chain_fwd per chain 16 entries in Gray-code order from P0 + (the chain's fixed high teeth): one mixed addition of
+//                            +-C_i per entry (Jacobian X, Y parked in the table, the H values in scratch)
 //   3 kc_prefix   per key    Zc = Zb * prod Z_chain, per chain the product of the OTHER chains' Z; the entry of Q
-//   4 kc_rescale  per chain  entry *= ratio^2 / ratio^3 and beta*x: every entry an affine point of y^2 = x^3 + 7*Zc^6
+//   4 kc_chain_bwd per chain walks the chain backwards multiplying up Zc / (Zb * Z_entry) from the H values:
+//                            entry *= ratio^2 / ratio^3 and beta*x -- every entry an affine point of y^2 = x^3 + 7*Zc^6
 // No addition here can be degenerate: every operand is (odd integer < 2^136)*Q +- (even integer < 2^136)*Q with Q of
 // prime order n > 2^255.
 template <int T>
@@ -431,7 +432,7 @@ LAMD_HD void kc_bases(u32 *scratch, const ge &q) {
   store_raw(scratch + KC_P0 + 18, fe_norm_weak(p.z));
 }
 template <int T>
-LAMD_HD void kc_chain(u32 *tab, u32 *scratch, int sub) {
+LAMD_HD void kc_chain_fwd(u32 *tab, u32 *scratch, int sub) {
   u32 *sp = scratch + kc_sub_off(T) + sub * KC_SUB_WORDS;
   u32 *ent = tab + sub * KC_SUB * SLOT_ENTRY_WORDS;
   gej p;
@@ -466,17 +467,6 @@ LAMD_HD void kc_chain(u32 *tab, u32 *scratch, int sub) {
     store_raw(sp + 18 + (g - 1) * 9, h);
   }
   store_raw(sp + 0, fe_norm_weak(p.z));
-  fe rho = fe_set_int(1);
-#pragma unroll 1
-  for (int g = KC_SUB - 2; g >= 0; g--) {  // rho = Z_last / Z_entry(g)
-    rho = fe_mul(rho, slot_load_raw(sp + 18 + g * 9));
-    const int gr = g ^ (g >> 1);
-    const fe r2 = fe_sqr(rho);
-    const fe x = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 0), r2);
-    const fe y = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 16), fe_mul(r2, rho));
-    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 0, x);
-    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 16, y);
-  }
 }
 template <int T>
 LAMD_HD void kc_prefix(u32 *tab, u32 *scratch, const ge &q) {
@@ -506,29 +496,31 @@ LAMD_HD void kc_prefix(u32 *tab, u32 *scratch, const ge &q) {
   slot_store_fe(e + 16, fe_mul(q.y, fe_mul(z2, zc)));
 }
 template <int T>
-LAMD_HD void kc_rescale(u32 *tab, const u32 *scratch, int sub) {
+LAMD_HD void kc_chain_bwd(u32 *tab, const u32 *scratch, int sub) {
   const u32 betaw[8] = LAMD_BETA;
   const fe beta = fe_from_words(betaw);
-  const fe ratio = slot_load_raw(scratch + kc_sub_off(T) + sub * KC_SUB_WORDS + 9);
-  const fe r2 = fe_sqr(ratio);
-  const fe r3 = fe_mul(r2, ratio);
+  const u32 *sp = scratch + kc_sub_off(T) + sub * KC_SUB_WORDS;
+  u32 *ent = tab + sub * KC_SUB * SLOT_ENTRY_WORDS;
+  fe rho = slot_load_raw(sp + 9);  // Zc / (Zb * Z_chain): the last entry's ratio
 #pragma unroll 1
-  for (int e = 0; e < KC_SUB; e++) {
-    u32 *ent = tab + (sub * KC_SUB + e) * SLOT_ENTRY_WORDS;
-    const fe x = fe_mul(slot_load_fe(ent + 0), r2);
-    const fe y = fe_mul(slot_load_fe(ent + 16), r3);
-    slot_store_fe(ent + 0, x);
-    slot_store_fe(ent + 8, fe_mul(x, beta));
-    slot_store_fe(ent + 16, y);
+  for (int g = KC_SUB - 1; g >= 0; g--) {  // rho = Zc / (Zb * Z_entry(g)): entry g+1 = entry g +- C had Z_(g+1) = Z_g * H_(g+1)
+    if (g != KC_SUB - 1) rho = fe_mul(rho, slot_load_raw(sp + 18 + g * 9));
+    const int gr = g ^ (g >> 1);
+    const fe r2 = fe_sqr(rho);
+    const fe x = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 0), r2);
+    const fe y = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 16), fe_mul(r2, rho));
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 0, x);
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 16, y);
   }
 }
 // sequential composition (CPU test harness; the engine launches the stages as separate kernels)
 template <int T>
 LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
   kc_bases<T>(scratch, q);
-  for (int s = 0; s < kc_nsub(T); s++) kc_chain<T>(tab, scratch, s);
+  for (int s = 0; s < kc_nsub(T); s++) kc_chain_fwd<T>(tab, scratch, s);
   kc_prefix<T>(tab, scratch, q);
-  for (int s = 0; s < kc_nsub(T); s++) kc_rescale<T>(tab, scratch, s);
+  for (int s = 0; s < kc_nsub(T); s++) kc_chain_bwd<T>(tab, scratch, s);
 }
 
 // Comb recoding of one GLV half from its prep_rec form (|k| = mag + top*2^128 - 0x88..8): tooth i holds bits

@@ -209,8 +209,19 @@ class Engine:
     def set_timing(self, on=True):
         self._chk(self._lib.lamd_set_timing(self._ctx, int(on)))
 
-    def info(self):
+    def stream_wait_results(self, stream_ptr):
+        """make a caller's HIP stream wait (on the device) for every verification submitted so far"""
+        self._chk(self._lib.lamd_stream_wait_results(self._ctx, ctypes.c_void_p(stream_ptr)))
+
+    def wait_stream(self, stream_ptr):
+        """verification submitted from now on waits (on the device) for what the caller's stream holds now"""
+        self._chk(self._lib.lamd_wait_stream(self._ctx, ctypes.c_void_p(stream_ptr)))
+
+    def info(self, lane=None):
         inf = _ffi.LamdInfo()
-        self._chk(self._lib.lamd_get_info(self._ctx, ctypes.byref(inf)))
+        if lane is None:
+            self._chk(self._lib.lamd_get_info(self._ctx, ctypes.byref(inf)))
+        else:
+            self._chk(self._lib.lamd_get_lane_info(self._ctx, int(lane), ctypes.byref(inf)))
         return dict(device=inf.device, compute_units=inf.compute_units, arch=inf.arch.decode(), gtable_bytes=inf.gtable_bytes,
-                    last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_hot_rows=inf.last_hot_rows, last_keyed=int(inf.last_keyed))
+                    last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_hot_rows=inf.last_hot_rows, last_keyed=int(inf.last_keyed), last_mode=int(inf.last_mode))

@@ -4,6 +4,7 @@ import random
 
 import numpy as np
 import pytest
+import torch
 
 import pyref
 
@@ -459,3 +460,62 @@ def test_check_tx_sig_batch_fee_grind_kat(eng, kat):
     # SIGHASH_ALL passes the gate with or without a witness script, SINGLE|ANYONECANPAY only with one (here the caller
     # handed the same preimage bytes, so that row verifies too); every other type is rejected before any hashing
     assert [bool(x) for x in got] == [True, True, False, False, False, False, False, True]
+
+
+def test_lanes_back_to_back_calls_without_host_sync(eng, orc):
+    """successive device-pointer calls alternate between the engine's two lanes and overlap on the GPU; every call's
+    verdict vector must still be complete and right after ONE synchronize, for ECDSA, BIP-340 and gossip interleaved"""
+    from lightning_amd import workload
+    ws = []
+    for r in range(3):
+        ws.append(("e", workload.make_ecdsa(eng, 40000 + 777 * r, seed=900 + r, nkeys=300 * (r + 1), publen=33 if r % 2 else 65)))
+        ws.append(("s", workload.make_schnorr(eng, 30000 + 555 * r, seed=950 + r, nkeys=1 << 40 if r == 1 else 500)))
+    g = workload.make_gossip(eng, 3000, 5000, n_nodes=200, corrupt_frac=0.03)
+    eng.synchronize()
+    for rep in range(3):
+        for kind, w in ws:
+            w.d_ok.zero_()
+        torch.cuda.synchronize()
+        for kind, w in ws:
+            (eng.verify_ecdsa_device if kind == "e" else eng.verify_schnorr_device)(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+        g.d_verdict.fill_(99)
+        torch.cuda.synchronize()
+        eng.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
+        eng.synchronize()
+        gv = g.d_verdict
+        for kind, w in ws:
+            assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect), (rep, kind, w.n)
+        assert np.array_equal(gv.cpu().numpy(), g.expect)
+    inf = [eng.info(0), eng.info(1)]
+    assert {i["last_mode"] for i in inf} <= {0, 1}
+    # a caller's stream can wait for the results on the device instead of blocking the host
+    kind, w = ws[0]
+    w.d_ok.zero_()
+    torch.cuda.synchronize()
+    eng.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+    eng.stream_wait_results(torch.cuda.current_stream().cuda_stream)
+    got = w.d_ok.clone()                       # on torch's stream: ordered after the verification by the event
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().astype(bool), w.expect)
+    eng.synchronize()
+
+
+def test_single_lane_mode_matches(orc):
+    import os
+    from lightning_amd import Engine, workload
+    os.environ["LAMD_LANES"] = "1"
+    try:
+        e = Engine(0)
+    finally:
+        del os.environ["LAMD_LANES"]
+    try:
+        w = workload.make_ecdsa(e, 50000, seed=31, nkeys=700, publen=33)
+        s = workload.make_schnorr(e, 20000, seed=32, nkeys=100)
+        e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+        e.verify_schnorr_device(s.dev[0], s.dev[1], s.dev[2], s.d_ok)
+        e.synchronize()
+        assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
+        assert np.array_equal(s.d_ok.cpu().numpy().astype(bool), s.expect)
+        assert e.info(0) == e.info(1) == e.info()
+    finally:
+        e.close()
