@@ -32,6 +32,9 @@ def is_stale():
     return any(os.path.getmtime(s) > t for s in SOURCES)
 
 
+EXTRA = os.environ.get("LAMD_BUILD_FLAGS", "").split()
+
+
 def build(force=False, verbose=False):
     if not (force or is_stale()):
         build_shim()
@@ -42,7 +45,7 @@ def build(force=False, verbose=False):
     # an ISA emulator, so it is a code-generation bug, not a hardware hazard -- DESIGN.md "toolchain notes").
     # lamd_selftest() re-checks every primitive on the device against the host evaluation of the same code.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-           "-mllvm", "-amdgpu-codegenprepare-mul24=false",
+           "-mllvm", "-amdgpu-codegenprepare-mul24=false"] + EXTRA + [
            "-o", LIB + ".tmp", os.path.join(CSRC, "lamd_engine.hip")]
     if verbose:
         print(" ".join(cmd))

@@ -296,7 +296,7 @@ LAMD_HD void gmul_affine(u32 xw[8], u32 yw[8], const sc &k, const u32 *gtable) {
   gej acc = gej_infinity();
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
-    const u32 d = (k.w[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);
+    const u32 d = gtable_digit(k.w, w);
     const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
     ge pt;
     pt.x = slot_load_fe(e);
@@ -1692,9 +1692,10 @@ extern "C" int lamd_selftest(lamd_ctx *ctx, const uint8_t *hash32, const uint8_t
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, (const u32 *)ctx->gtable, d_slots, d_out);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<u32> got((size_t)ST_LANES * ST_WORDS), gt(GTABLE_ENTRIES * 16);
+  // the first entries of window 0 and of window 1 are all the host-side check below looks at
+  std::vector<u32> got((size_t)ST_LANES * ST_WORDS), gt((((size_t)1 << GTABLE_WINDOW_BITS) + 2) * 16);
   HIPCHK(ctx, hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
-  HIPCHK(ctx, hipMemcpy(gt.data(), ctx->gtable, GTABLE_BYTES, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(gt.data(), ctx->gtable, gt.size() * 4, hipMemcpyDeviceToHost));
   (void)hipFree(d_in); (void)hipFree(d_slots); (void)hipFree(d_out);
   // host evaluation of the same code (host gtable entries recomputed for a sample to check the build kernel)
   static const struct { int lo, hi; const char *name; } stages[] = {

@@ -41,12 +41,19 @@ constexpr int SLOT_H_OFF = 8 * SLOT_ENTRY_WORDS;  // 6 x 8 words of H_2..H_7
 // 16-bit windows (64 MiB, lives in HBM / Infinity Cache) make u1*G sixteen mixed additions.
 // The CPU test harness builds the same code with 8-bit windows to keep its table small.
 #ifndef LAMD_GTABLE_WINDOW_BITS
-#define LAMD_GTABLE_WINDOW_BITS 16
+#define LAMD_GTABLE_WINDOW_BITS 22
 #endif
 constexpr int GTABLE_WINDOW_BITS = LAMD_GTABLE_WINDOW_BITS;
-constexpr int GTABLE_WINDOWS = 256 / GTABLE_WINDOW_BITS;
+constexpr int GTABLE_WINDOWS = (256 + GTABLE_WINDOW_BITS - 1) / GTABLE_WINDOW_BITS;
 constexpr size_t GTABLE_ENTRIES = (size_t)GTABLE_WINDOWS << GTABLE_WINDOW_BITS;
 constexpr size_t GTABLE_BYTES = GTABLE_ENTRIES * 64;
+// window w of a 256-bit scalar (8 little-endian words); windows may straddle a word and run past bit 255
+LAMD_HD u32 gtable_digit(const u32 k[8], int w) {
+  const int bit = w * GTABLE_WINDOW_BITS, i = bit >> 5, sh = bit & 31;
+  u32 v = k[i] >> sh;
+  if ((32 % GTABLE_WINDOW_BITS) != 0 && sh + GTABLE_WINDOW_BITS > 32 && i + 1 < 8) v |= k[i + 1] << (32 - sh);
+  return v & ((1u << GTABLE_WINDOW_BITS) - 1u);
+}
 
 // ---- byte loads: 32 big-endian bytes -> 8 little-endian words (w[0] least significant)
 LAMD_HD u32 load_be32(const u8 *p) {
@@ -308,7 +315,7 @@ LAMD_HD gej ecmult_lane(const prep_rec &rec, const ge &q, u32 *slot, const u32 *
   // + u1*G from the 16-bit-window table
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
-    const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);
+    const u32 d = gtable_digit(rec.u1, w);
     const bool skip = d == 0;
     const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
     ge pt;
@@ -600,7 +607,7 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
   acc.z = fe_mul(acc.z, slot_load_fe(tab + kc_words(T)));
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
-    const u32 d = (rec.u1[(w * GTABLE_WINDOW_BITS) >> 5] >> ((w * GTABLE_WINDOW_BITS) & 31)) & ((1u << GTABLE_WINDOW_BITS) - 1u);
+    const u32 d = gtable_digit(rec.u1, w);
     const bool skip = d == 0;
     const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
     ge pt;

@@ -4,7 +4,9 @@
 // Python big-ints and the oracle before anything touches a GPU.  Not a product path: the
 // shipped library (liblightning_amd.so) contains no CPU verification code.
 #define LAMD_CHECK_MAG 1
+#ifndef LAMD_GTABLE_WINDOW_BITS
 #define LAMD_GTABLE_WINDOW_BITS 8
+#endif
 #include "../lightning_amd/csrc/verify_core.h"
 #include <stdlib.h>
 #include <string.h>
@@ -100,6 +102,7 @@ void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8
     out[i] = ok;
   }
 }
+#ifndef DM_NO_KEYED
 // keyed path: one window table per row's key (no sharing here -- this is an arithmetic test), then the table-driven ecmult
 }  // extern "C"
 template <int T>
@@ -184,6 +187,7 @@ int dm_ecmult_keyed(int T, const u8 *key33, const u8 *u1, const u8 *u2, u8 *out6
   if (T == 9) return ecmult_keyed_t<9>(qx, qy, u1, u2, out64);
   return ecmult_keyed_t<10>(qx, qy, u1, u2, out64);
 }
+#endif  // DM_NO_KEYED
 // two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
 void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {
   dm_init();
