@@ -43,7 +43,7 @@ for sub in ("fetch", "write", "sq", "sq2"):
         if not big:
             big = [v for d, v, g in lst]
         # alternate ECDSA / Schnorr launches
-        if k.startswith("k_ecmult") or k.startswith("k_keytable") or k == "k_keys":
+        if k.startswith("k_ecmult") or k.startswith("k_kc_") or k == "k_keys":
             vals[k + " [ecdsa]"][c] = big[0::2]
             vals[k + " [schnorr]"][c] = big[1::2]
         else:
@@ -64,14 +64,20 @@ hot = next((k for k in summary if k.startswith("k_ecmult_keyed") and "[ecdsa]" i
 e = summary[hot]
 kname = hot.split(" ")[0]
 t = mean(dur[kname][0::2]) * 1e-6 if len(dur[kname]) > 1 else dur[kname][0] * 1e-6
+# counter passes serialise the kernels (no overlap between the engine's lanes): take that pass's own duration for rates
+def pass_t(sub):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e9 for r in sorted(load(sub, "kernel_trace"), key=lambda r: int(r["Start_Timestamp"]))
+         if short(r["Kernel_Name"]) == kname and int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) >= 500000]
+    return mean(d[0::2]) if d else t
+t_sq, t_fetch = pass_t("sq"), pass_t("fetch")
 nwaves = e.get("SQ_WAVES", 15625)
 hbm = (e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024
 lines += ["[derived: %s, ECDSA launch]" % kname,
-          "  kernel duration (trace pass, mean of ECDSA launches)   %.3f ms" % (t * 1e3),
+          "  kernel duration: trace pass (lanes overlap) %.3f ms; counter passes (kernels serialised) %.3f ms" % (t * 1e3, t_sq * 1e3),
           "  HBM-side bytes (FETCH_SIZE+WRITE_SIZE)*1024             %.3e B -> %.0f GB/s (%.1f %% of 8 TB/s); FETCH x2 reading: %.3e B" % (
-              hbm, hbm / t / 1e9, hbm / t / 8e12 * 100, (2 * e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024),
+              hbm, hbm / t_fetch / 1e9, hbm / t_fetch / 8e12 * 100, (2 * e.get("FETCH_SIZE", 0) + e.get("WRITE_SIZE", 0)) * 1024),
           "  VALU wave-instructions per wave (= per signature lane)  %.0f" % (e["SQ_INSTS_VALU"] / nwaves),
-          "  shader clock (GRBM_GUI_ACTIVE / 8 XCDs / t)             %.2f GHz" % (e["GRBM_GUI_ACTIVE"] / 8 / t / 1e9),
+          "  shader clock (GRBM_GUI_ACTIVE / 8 XCDs / t)             %.2f GHz" % (e["GRBM_GUI_ACTIVE"] / 8 / t_sq / 1e9),
           "  VALU issue: wave-instr / SIMD / cycle                   %.3f (0.25 = saturated for half-rate ops such as v_mad_u64_u32)" % (
               e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8)),
           "  SQ_WAIT_ANY / SQ_WAVE_CYCLES                            %.3f" % (e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]),
