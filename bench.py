@@ -60,7 +60,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: lightning_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): the collective path runs even with one rank, so that a 1-GPU box can test it
+    multi = world > 1 or ("RANK" in os.environ and os.environ.get("LAMD_BENCH_GATHER", "0") == "1")
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(device))
 
@@ -71,8 +73,8 @@ def main():
     n = args.n
     we = workload.make_ecdsa(eng, n, seed=workload.SEED_CFG2 + rank, nkeys=65536, publen=65, device=device)
     ws = workload.make_schnorr(eng, n, seed=workload.SEED_CFG3 + rank, nkeys=65536, device=device)
-    ok_all_e = torch.zeros(world * n, dtype=torch.uint8, device=device) if world > 1 else None
-    ok_all_s = torch.zeros(world * n, dtype=torch.uint8, device=device) if world > 1 else None
+    ok_all_e = torch.zeros(world * n, dtype=torch.uint8, device=device) if multi else None
+    ok_all_s = torch.zeros(world * n, dtype=torch.uint8, device=device) if multi else None
 
     kernel_ms = {"ecdsa": [], "schnorr": []}
     keyed = {}
@@ -84,7 +86,7 @@ def main():
         # front end (key de-duplication, table building) of one batch runs under the ecmult kernel of the previous one
         eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
         eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
-        if world > 1:  # RCCL all-gather of the boolean result vectors over xGMI, ordered by events on the device
+        if multi:  # RCCL all-gather of the boolean result vectors over xGMI, ordered by events on the device
             eng.stream_wait_results(tstream)
             dist.all_gather_into_tensor(ok_all_e, we.d_ok)
             dist.all_gather_into_tensor(ok_all_s, ws.d_ok)
@@ -100,7 +102,7 @@ def main():
             keyed[which] = (inf["last_keyed"], inf["last_unique_keys"])
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         eng.synchronize()
@@ -127,7 +129,7 @@ def main():
         if not kernel_ms[k]:          # LAMD_LANES=1: only the last call's events survive the timed region
             kernel_ms[k] = isolated[k]
             keyed.setdefault(k, keyed.get("schnorr", (0, 0)))
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -136,7 +138,7 @@ def main():
     got_e = we.d_ok.cpu().numpy().astype(bool)
     got_s = ws.d_ok.cpu().numpy().astype(bool)
     mism = int((got_e != we.expect).sum() + (got_s != ws.expect).sum())
-    if world > 1:
+    if multi:
         # every rank must hold every other rank's verdicts after the all-gather
         sl = slice(rank * n, (rank + 1) * n)
         mism += int((ok_all_e[sl].cpu().numpy().astype(bool) != we.expect).sum())
@@ -271,7 +273,7 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     if not args.no_parity and rank == 0 and mism:
         raise SystemExit("PARITY FAILURE: %d mismatching verdicts" % mism)

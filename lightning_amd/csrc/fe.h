@@ -189,10 +189,19 @@ LAMD_HD fe fe_select(bool take_a, const fe &a, const fe &b) {
 // 64-bit add of the carry" (v_lshl_add_u64, another half-rate issue slot per column); the asm pins the chain.
 // (No builtin exists for this instruction; the carry-out SGPR pair is a dead output, exactly as in hipcc's own
 // code.)  Host builds use the plain C expression.
+// CH: which of fe_mul's two interleaved chains the multiply-add belongs to.  The chains discard their carry-out into
+// different scalar registers (an SGPR pair / VCC): with one shared register hipcc's hazard recogniser sees every
+// inline-asm statement re-define a register the previous one defined and, assuming the worst about opaque asm (a
+// dst-forwarding hazard that v_mad_u64_u32 does not have), puts an s_nop between every two of them.
+template <int CH = 0>
 LAMD_HD void fe_mac(u64 &acc, u32 a, u32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  u64 cy;
-  asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
+  if (CH == 0) {
+    u64 cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(cy) : "v"(a), "v"(b));
+  } else {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+  }
 #else
   acc += (u64)a * b;
 #endif
@@ -221,23 +230,23 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
   u32 h[8];                                                                                         \
   fe r;                                                                                             \
   u64 hi = 0, lo = 0;                                                                               \
-  PROD(9, hi);                                                                                      \
+  PROD(9, hi, 1);                                                                                   \
   h[0] = (u32)hi & FE_M29;                                                                          \
   hi >>= 29;                                                                                        \
   _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                   \
     if (k < 7) {                                                                                    \
-      PROD(10 + k, hi);                                                                             \
+      PROD(10 + k, hi, 1);                                                                          \
       h[k + 1] = (u32)hi & FE_M29;                                                                  \
       hi >>= 29;                                                                                    \
     }                                                                                               \
-    PROD(k, lo);                                                                                    \
+    PROD(k, lo, 0);                                                                                 \
     fe_mac_k(lo, h[k], FE_R0);                                                                      \
     if (k > 0) fe_mac_k(lo, h[k - 1], 1u << FE_R1_SHIFT);                                           \
     r.n[k] = (u32)lo & FE_M29;                                                                      \
     lo >>= 29;                                                                                      \
   }                                                                                                 \
   const u64 h17 = hi;                                     /* <= 2^35 */                             \
-  PROD(8, lo);                                                                                      \
+  PROD(8, lo, 0);                                                                                   \
   fe_mac_k(lo, h[7], 1u << FE_R1_SHIFT);                                                            \
   lo += h17 * FE_R0;                                                                                \
   r.n[8] = (u32)lo & FE_M24;                                                                        \
@@ -253,27 +262,29 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
   fe_verify(r);                                                                                     \
   return r;
 
+template <int CH>
 LAMD_HD void fe_mul_col(const fe &a, const fe &b, int k, u64 &acc) {
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     const int j = k - i;
     if (j < 0 || j > 8) continue;
-    fe_mac(acc, a.n[i], b.n[j]);
+    fe_mac<CH>(acc, a.n[i], b.n[j]);
   }
 }
+template <int CH>
 LAMD_HD void fe_sqr_col(const fe &a, const u32 d[9], int k, u64 &acc) {
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     const int j = k - i;
     if (j < 0 || j > 8 || i > j) continue;
-    fe_mac(acc, (i == j) ? a.n[i] : d[i], a.n[j]);
+    fe_mac<CH>(acc, (i == j) ? a.n[i] : d[i], a.n[j]);
   }
 }
 
 // r = a*b; requires mag(a)*mag(b) <= 7
 LAMD_HD fe fe_mul(const fe &a, const fe &b) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7);
-#define LAMD_P(k, acc) fe_mul_col(a, b, k, acc)
+#define LAMD_P(k, acc, ch) fe_mul_col<ch>(a, b, k, acc)
   LAMD_FE_COLUMNS(LAMD_P)
 #undef LAMD_P
 }
@@ -284,7 +295,7 @@ LAMD_HD fe fe_sqr(const fe &a) {
   u32 d[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
-#define LAMD_P(k, acc) fe_sqr_col(a, d, k, acc)
+#define LAMD_P(k, acc, ch) fe_sqr_col<ch>(a, d, k, acc)
   LAMD_FE_COLUMNS(LAMD_P)
 #undef LAMD_P
 }
