@@ -14,6 +14,10 @@
 // bitcoin/signature.c:188,425 reaches through secp256k1_ecdsa_verify / schnorrsig_verify.
 #pragma once
 #include "lamd_common.h"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LAMD_FE_NO_ASM_BLOCK)
+#define LAMD_FE_ASM_BLOCK 1
+#include "fe_asm.inc"
+#endif
 
 namespace lamd {
 
@@ -225,8 +229,11 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
 //   tail        H[17] is only known when the high chain ends: its column-8 term (R0*H[17]) joins the last low
 //               column; its column-9 term 2^8*H[17]*2^261 folds once more into limbs 0 and 1 together with the
 //               bits >= 2^256 of column 8 (2^256 = 977 + 8 * 2^29), followed by a three-limb carry
-// PROD(k, acc) must add the partial products of column k into acc with fe_mac().
-#define LAMD_FE_COLUMNS(PROD)                                                                       \
+// PROD(k, acc, ch) must add the partial products of column k into acc with fe_mac<ch>().
+// On the device the chains run as one hand-ordered asm statement per multiply (LAMD_FE_ASM_BLOCK, generated into
+// fe_asm.inc by tools/gen_fe_asm.py from exactly this schedule); the C form below is what the host build checks and what
+// -DLAMD_FE_NO_ASM_BLOCK falls back to.
+#define LAMD_FE_CHAINS(PROD)                                                                        \
   u32 h[8];                                                                                         \
   fe r;                                                                                             \
   u64 hi = 0, lo = 0;                                                                               \
@@ -245,9 +252,11 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
     r.n[k] = (u32)lo & FE_M29;                                                                      \
     lo >>= 29;                                                                                      \
   }                                                                                                 \
-  const u64 h17 = hi;                                     /* <= 2^35 */                             \
   PROD(8, lo, 0);                                                                                   \
-  fe_mac_k(lo, h[7], 1u << FE_R1_SHIFT);                                                            \
+  fe_mac_k(lo, h[7], 1u << FE_R1_SHIFT);
+// r.n[0..7], lo (column 8 so far) and hi (= H[17], <= 2^35) -> the finished product
+#define LAMD_FE_TAIL                                                                                \
+  const u64 h17 = hi;                                     /* <= 2^35 */                             \
   lo += h17 * FE_R0;                                                                                \
   r.n[8] = (u32)lo & FE_M24;                                                                        \
   const u64 e = lo >> 24;                                 /* <= 2^40 */                             \
@@ -284,9 +293,25 @@ LAMD_HD void fe_sqr_col(const fe &a, const u32 d[9], int k, u64 &acc) {
 // r = a*b; requires mag(a)*mag(b) <= 7
 LAMD_HD fe fe_mul(const fe &a, const fe &b) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7);
+#if defined(LAMD_FE_ASM_BLOCK)
+  // the chains as ONE asm statement (fe_asm.inc): no compiler-inserted s_nop between the dependent multiply-adds
+  fe r;
+  u64 hi, lo;
+  u32 t0, t1, t2;
+  asm(LAMD_FE_MUL_ASM
+      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+      : "v"(a.n[0]), "v"(a.n[1]), "v"(a.n[2]), "v"(a.n[3]), "v"(a.n[4]), "v"(a.n[5]), "v"(a.n[6]), "v"(a.n[7]), "v"(a.n[8]),
+        "v"(b.n[0]), "v"(b.n[1]), "v"(b.n[2]), "v"(b.n[3]), "v"(b.n[4]), "v"(b.n[5]), "v"(b.n[6]), "v"(b.n[7]), "v"(b.n[8]),
+        "s"(FE_R0), "s"(1u << FE_R1_SHIFT)
+      : "vcc");
+  LAMD_FE_TAIL
+#else
 #define LAMD_P(k, acc, ch) fe_mul_col<ch>(a, b, k, acc)
-  LAMD_FE_COLUMNS(LAMD_P)
+  LAMD_FE_CHAINS(LAMD_P)
+  LAMD_FE_TAIL
 #undef LAMD_P
+#endif
 }
 
 // r = a^2; requires mag(a) <= 2
@@ -295,9 +320,24 @@ LAMD_HD fe fe_sqr(const fe &a) {
   u32 d[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
+#if defined(LAMD_FE_ASM_BLOCK)
+  fe r;
+  u64 hi, lo;
+  u32 t0, t1, t2;
+  asm(LAMD_FE_SQR_ASM
+      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+      : "v"(a.n[0]), "v"(a.n[1]), "v"(a.n[2]), "v"(a.n[3]), "v"(a.n[4]), "v"(a.n[5]), "v"(a.n[6]), "v"(a.n[7]), "v"(a.n[8]),
+        "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]),
+        "s"(FE_R0), "s"(1u << FE_R1_SHIFT)
+      : "vcc");
+  LAMD_FE_TAIL
+#else
 #define LAMD_P(k, acc, ch) fe_sqr_col<ch>(a, d, k, acc)
-  LAMD_FE_COLUMNS(LAMD_P)
+  LAMD_FE_CHAINS(LAMD_P)
+  LAMD_FE_TAIL
 #undef LAMD_P
+#endif
 }
 
 LAMD_HD fe fe_sqr_n(fe a, int n) {
