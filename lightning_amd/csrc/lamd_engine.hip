@@ -1692,10 +1692,17 @@ extern "C" int lamd_selftest(lamd_ctx *ctx, const uint8_t *hash32, const uint8_t
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, (const u32 *)ctx->gtable, d_slots, d_out);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  // the first entries of window 0 and of window 1 are all the host-side check below looks at
-  std::vector<u32> got((size_t)ST_LANES * ST_WORDS), gt((((size_t)1 << GTABLE_WINDOW_BITS) + 2) * 16);
+  // the host re-runs the whole lane, G additions included: it needs the device's table (a diagnostic: 3 GiB over PCIe is fine)
+  std::vector<u32> got((size_t)ST_LANES * ST_WORDS);
+  struct host_table {
+    u32 *p = (u32 *)malloc(GTABLE_BYTES);
+    ~host_table() { free(p); }
+    u32 *data() { return p; }
+    u32 &operator[](size_t i) { return p[i]; }
+  } gt;
+  if (!gt.p) { ctx->err = "selftest: no host memory for the G table copy"; return LAMD_ERR_NOMEM; }
   HIPCHK(ctx, hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
-  HIPCHK(ctx, hipMemcpy(gt.data(), ctx->gtable, gt.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(gt.data(), ctx->gtable, GTABLE_BYTES, hipMemcpyDeviceToHost));
   (void)hipFree(d_in); (void)hipFree(d_slots); (void)hipFree(d_out);
   // host evaluation of the same code (host gtable entries recomputed for a sample to check the build kernel)
   static const struct { int lo, hi; const char *name; } stages[] = {

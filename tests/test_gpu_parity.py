@@ -519,3 +519,17 @@ def test_single_lane_mode_matches(orc):
         assert e.info(0) == e.info(1) == e.info()
     finally:
         e.close()
+
+
+def test_device_self_diagnostics(eng, kat):
+    """the diagnostic entry points (every arithmetic stage evaluated on the device and, with the same inline functions, on
+    the host) must report no difference -- they are how a code-generation problem is localised on a new toolchain"""
+    v = next(x for x in kat["ecdsa"] if x["name"] == "KAT-B11")
+    rc, rep = eng.selftest(H(v["hash"]), H(v["sig"]), H(v["pub"]))
+    assert rc == 0, rep
+    assert "host verdict lane0=1 device=1" in rep
+    rc, rep = eng.inv_debug()
+    assert rc == 0, rep
+    for use_mul in (0, 1):
+        rc, rep = eng.chain_debug(use_mul)
+        assert rc == 0, rep
