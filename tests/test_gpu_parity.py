@@ -404,6 +404,12 @@ def test_chunk_splitting_small_chunks(orc, kat):
         msgs = [g.msgs[int(g.off[i]):int(g.off[i + 1])].tobytes() for i in range(g.n)]
         ids = [g.ids[i].tobytes() if i >= g.n_cann else None for i in range(g.n)]
         assert np.array_equal(e.sigcheck_gossip(msgs, ids), g.expect)
+        # device-pointer gossip: expand on one lane, chunks alternating between both lanes, reduce after the join
+        g.d_verdict.fill_(77)
+        torch.cuda.synchronize()
+        e.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
+        e.synchronize()
+        assert np.array_equal(g.d_verdict.cpu().numpy(), g.expect)
     finally:
         e.close()
 
@@ -533,3 +539,14 @@ def test_device_self_diagnostics(eng, kat):
     for use_mul in (0, 1):
         rc, rep = eng.chain_debug(use_mul)
         assert rc == 0, rep
+
+
+def test_one_call_larger_than_a_chunk_full_size(eng):
+    """5 M rows in ONE call: two launch chunks (2^22 + the rest) on alternating lanes, 300 k distinct keys"""
+    from lightning_amd import workload
+    w = workload.make_ecdsa(eng, 5_000_000, seed=4242, nkeys=300_000, publen=33)
+    eng.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+    eng.synchronize()
+    got = w.d_ok.cpu().numpy().astype(bool)
+    assert np.array_equal(got, w.expect), np.nonzero(got != w.expect)[0][:10]
+    assert 0 < (~w.expect).sum() < w.n
