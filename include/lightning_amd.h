@@ -101,6 +101,19 @@ int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *preimages, c
 			    const uint8_t *sighash_type, const uint8_t *has_witness_script,
 			    const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
 
+/* grind_htlc_tx_fee() (onchaind/onchaind.c:388-438): find the feerate whose fee makes `sig64` (one remote HTLC signature,
+ * one key) verify.  For feerate = min_feerate..max_feerate: fee = feerate * weight / 1000 (amount_tx_fee), equal consecutive
+ * fees are tried once, fees above input_sat end the search; candidate = the transaction with output 0 paying
+ * input_sat - fee.  The caller hands the BIP143 preimage of the transaction as it stands (any output-0 amount; the 32
+ * bytes of hashOutputs sit 40 bytes before its end, bitcoin/signature.c:120-151) and the serialised outputs that
+ * hashOutputs covers (amount of output 0 first).  All hashing and curve work runs on the device; (r/s)*Q is computed once
+ * and each candidate costs two small double-SHA256 and the G-table additions.  Returns 1 = found (*feerate, *fee = the
+ * lowest matching feerate and its fee, exactly the pair the reference's ascending loop stops at), 0 = none, < 0 error. */
+int lamd_grind_htlc_tx_fee(lamd_ctx *ctx, const uint8_t *preimage, size_t preimage_len, const uint8_t *outputs,
+			   size_t outputs_len, uint64_t input_sat, uint64_t weight, uint32_t min_feerate,
+			   uint32_t max_feerate, const uint8_t sig64[64], uint8_t sighash_type, int has_witness_script,
+			   const uint8_t pubkey33[33], uint32_t *feerate, uint64_t *fee);
+
 /* ---- public-key parsing: n independent pubkey_from_der() / pubkey_from_node_id() calls
  * (bitcoin/pubkey.c:14-24, common/node_id.c:21-27 -> secp256k1_ec_pubkey_parse; publen 33 or 65),
  * or secp256k1_xonly_pubkey_parse with publen 32 (bitcoin/signature.c:422).  ok[i] = validity,

@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(256) k_schnorr_final(size_t n, u32 *__restrict
 }
 
 // ---- gossip: per message, double-SHA256 of the signed tail and expansion into (hash, sig, key) rows
-LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
-  u32 st[8] = LAMD_SHA256_IV;
+// SHA256(SHA256(m)) where the first `done` bytes of m (a multiple of 64) are already absorbed into st; p = the rest
+LAMD_HD void sha256d_finish(u32 st[8], const u8 *p, size_t len, size_t done, u8 out32[32]) {
   u32 w[16];
   size_t off = 0;
   for (; off + 64 <= len; off += 64) {
@@ -148,8 +148,8 @@ LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
     sha256_compress(st, w);
     for (int i = 0; i < 16; i++) w[i] = 0;
   }
-  w[14] = (u32)(((u64)len * 8) >> 32);
-  w[15] = (u32)((u64)len * 8);
+  w[14] = (u32)(((u64)(done + len) * 8) >> 32);
+  w[15] = (u32)((u64)(done + len) * 8);
   sha256_compress(st, w);
   // second hash over the 32-byte digest
   for (int i = 0; i < 8; i++) w[i] = st[i];
@@ -162,6 +162,10 @@ LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
     out32[4 * i] = (u8)(st2[i] >> 24); out32[4 * i + 1] = (u8)(st2[i] >> 16);
     out32[4 * i + 2] = (u8)(st2[i] >> 8); out32[4 * i + 3] = (u8)st2[i];
   }
+}
+LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
+  u32 st[8] = LAMD_SHA256_IV;
+  sha256d_finish(st, p, len, 0, out32);
 }
 
 // ---- check_tx_sig batches: double-SHA256 of caller-built BIP143 preimages (bitcoin/signature.c:120-151 hashes them
@@ -182,6 +186,97 @@ __global__ void __launch_bounds__(256) k_txsig_hash(size_t n, const u8 *__restri
 __global__ void __launch_bounds__(256) k_apply_gate(size_t n, const u8 *__restrict__ gate, u8 *__restrict__ ok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && !gate[i]) ok[i] = 0;
+}
+
+// ---- fee grind (onchaind/onchaind.c:388-438 grind_htlc_tx_fee): ONE signature and key, many candidate fees.  Every
+// candidate changes output 0's amount, hence hashOutputs, hence the sighash z -- but r, s and Q stay: with w = 1/s,
+// R = (z*w)*G + (r*w)*Q, so (r*w)*Q is computed once (k_grind_setup, the ordinary GLV ladder) and a candidate costs two
+// small double-SHA256, one scalar multiplication and the 12 G-table additions.
+constexpr int GRIND_MAX_OUTPUTS = 192;  // serialised outputs that go into hashOutputs (an HTLC tx has one 43-byte output)
+constexpr int GRIND_MAX_TAIL = 128;     // preimage bytes from the last 64-byte boundary before hashOutputs to the end
+struct grind_setup {
+  u32 valid;
+  u32 sinv[8], rw[8], px[8], py[8];  // 1/s, r, affine (r/s)*Q
+  u32 mid[8];                        // SHA-256 state after the preimage's leading whole blocks
+};
+__global__ void __launch_bounds__(64) k_grind_setup(const u8 *__restrict__ sig64, const u8 *__restrict__ pub33,
+                                                    const u8 *__restrict__ pre, u32 lead_blocks, u32 *__restrict__ slot,
+                                                    const u32 *__restrict__ gtable, grind_setup *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  grind_setup g;
+  sc r, s;
+  bool ok;
+  ecdsa_load_rs(sig64, &r, &s, &ok);
+  u32 qx[8], qy[8];
+  ok &= parse_pubkey(pub33, 33, qx, qy);
+  g.valid = ok;
+  u32 st[8] = LAMD_SHA256_IV;
+  for (u32 b = 0; b < lead_blocks; b++) {
+    u32 w[16];
+    for (int i = 0; i < 16; i++) w[i] = load_be32(pre + 64 * (size_t)b + 4 * i);
+    sha256_compress(st, w);
+  }
+  for (int i = 0; i < 8; i++) { g.mid[i] = st[i]; g.sinv[i] = g.rw[i] = g.px[i] = g.py[i] = 0; }
+  if (ok) {
+    const sc sinv = sc_inv(s);
+    const sc u2 = sc_mul(r, sinv);
+    glv_half h1, h2;
+    glv_split(&h1, &h2, u2);
+    prep_rec rec;
+    for (int i = 0; i < 8; i++) rec.u1[i] = 0;
+    for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
+    rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
+    const gej P = ecmult_lane(rec, ge_from_words(qx, qy), slot, gtable);
+    if (P.inf) {
+      g.valid = 0;  // unreachable: r/s != 0 and Q has prime order
+    } else {
+      const fe zi = fe_inv(fe_norm_weak(P.z)), zi2 = fe_sqr(zi);
+      fe_to_words(g.px, fe_normalize(fe_mul(P.x, zi2)));
+      fe_to_words(g.py, fe_normalize(fe_mul(P.y, fe_mul(zi2, zi))));
+      for (int i = 0; i < 8; i++) { g.sinv[i] = sinv.w[i]; g.rw[i] = r.w[i]; }
+    }
+  }
+  *out = g;
+}
+// candidate c = feerate min_rate + c; *best = the smallest matching c (0xFFFFFFFF: none)
+__global__ void __launch_bounds__(256) k_grind(u32 ncand, u32 min_rate, u64 weight, u64 input_sat, const u8 *__restrict__ tail,
+                                               u32 tail_len, u32 lead_bytes, const u8 *__restrict__ outputs, u32 outputs_len,
+                                               const grind_setup *__restrict__ setup, const u32 *__restrict__ gtable,
+                                               u32 *__restrict__ best) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncand || !setup->valid) return;
+  const u64 rate = (u64)min_rate + c;
+  const u64 fee = rate * weight / 1000;                                    // amount_tx_fee(), common/amount.c
+  if (c > 0 && (rate - 1) * weight / 1000 == fee) return;                  // "don't check same fee twice"
+  if (fee > input_sat) return;                                             // amount_sat_sub() fails: the reference stops here
+  const u64 amount = input_sat - fee;
+  u8 buf[GRIND_MAX_OUTPUTS > GRIND_MAX_TAIL ? GRIND_MAX_OUTPUTS : GRIND_MAX_TAIL];
+  u8 h[32];
+  for (u32 i = 0; i < outputs_len; i++) buf[i] = i < 8 ? (u8)(amount >> (8 * i)) : outputs[i];
+  sha256d_bytes(buf, outputs_len, h);                                      // hashOutputs
+  const u32 ho = tail_len - 40;                                            // ... sits 40 bytes before the end of the preimage
+  for (u32 i = 0; i < tail_len; i++) buf[i] = (i >= ho && i < ho + 32) ? h[i - ho] : tail[i];
+  u32 st[8];
+  for (int i = 0; i < 8; i++) st[i] = setup->mid[i];
+  sha256d_finish(st, buf, tail_len, lead_bytes, h);                        // the sighash
+  u32 zw[8];
+  load_words_be(zw, h);
+  sc sinv;
+  for (int i = 0; i < 8; i++) sinv.w[i] = setup->sinv[i];
+  const sc u1 = sc_mul(sc_from_words(zw, nullptr), sinv);
+  u32 rw[8], pw[16];
+  for (int i = 0; i < 8; i++) { rw[i] = setup->rw[i]; pw[i] = setup->px[i]; pw[8 + i] = setup->py[i]; }
+  gej acc = gej_from_ge(ge_from_words(pw, pw + 8));
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = gtable_digit(u1.w, w);
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    ge pt;
+    pt.x = slot_load_fe(e);
+    pt.y = slot_load_fe(e + 8);
+    acc = gej_add_ge(acc, pt, d == 0);
+  }
+  if (ecdsa_final(acc, rw)) atomicMin(best, c);
 }
 
 enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };
@@ -1381,6 +1476,56 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
   return lamd_synchronize(ctx);
+}
+
+// ---- fee grind: see k_grind.  Returns 1 (found; *feerate, *fee set), 0 (no candidate verifies) or an error < 0.
+extern "C" int lamd_grind_htlc_tx_fee(lamd_ctx *ctx, const uint8_t *preimage, size_t preimage_len, const uint8_t *outputs,
+                                      size_t outputs_len, uint64_t input_sat, uint64_t weight, uint32_t min_feerate,
+                                      uint32_t max_feerate, const uint8_t sig64[64], uint8_t sighash_type, int has_witness_script,
+                                      const uint8_t pubkey33[33], uint32_t *feerate, uint64_t *fee) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!preimage || !outputs || !sig64 || !pubkey33 || !feerate || !fee || preimage_len < 40 + 4 || outputs_len < 9 ||
+      outputs_len > (size_t)GRIND_MAX_OUTPUTS || weight == 0 || weight > ((uint64_t)1 << 31)) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  // the sighash-type gate of check_tx_sig (bitcoin/signature.c:206-211) is the same for every candidate
+  if (!(sighash_type == 1 || (sighash_type == 0x83 && has_witness_script))) return 0;
+  if (max_feerate < min_feerate) return 0;
+  const size_t ncand = (size_t)max_feerate - min_feerate + 1;
+  if (ncand > ((size_t)1 << 30)) {
+    ctx->err = "feerate range too large";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t lead = ((preimage_len - 40) / 64) * 64, tail_len = preimage_len - lead;  // hashOutputs starts in the first tail block
+  // staging: preimage | outputs | sig | key | setup | best
+  const size_t o_out = (preimage_len + 15) & ~(size_t)15, o_sig = (o_out + outputs_len + 15) & ~(size_t)15, o_key = o_sig + 64,
+               o_setup = o_key + 48, o_best = o_setup + ((sizeof(grind_setup) + 15) & ~(size_t)15), total = o_best + 16;
+  int rc;
+  if ((rc = ensure(ctx, &ctx->g_msgs, total)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->slots, (size_t)SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  std::vector<u8> stage(total, 0);
+  memcpy(&stage[0], preimage, preimage_len);
+  memcpy(&stage[o_out], outputs, outputs_len);
+  memcpy(&stage[o_sig], sig64, 64);
+  memcpy(&stage[o_key], pubkey33, 33);
+  memset(&stage[o_best], 0xFF, 4);
+  u8 *d = (u8 *)ctx->g_msgs.p;
+  HIPCHK(ctx, hipMemcpyAsync(d, stage.data(), total, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_grind_setup, dim3(1), dim3(64), 0, ctx->stream, d + o_sig, d + o_key, d, (u32)(lead / 64), (u32 *)ctx->slots.p,
+                     (const u32 *)ctx->gtable, (grind_setup *)(d + o_setup));
+  hipLaunchKernelGGL(k_grind, dim3(blocks_for(ncand)), dim3(256), 0, ctx->stream, (u32)ncand, min_feerate, weight, input_sat, d + lead,
+                     (u32)tail_len, (u32)lead, d + o_out, (u32)outputs_len, (const grind_setup *)(d + o_setup), (const u32 *)ctx->gtable,
+                     (u32 *)(d + o_best));
+  HIPCHK(ctx, hipGetLastError());
+  u32 best = 0xFFFFFFFFu;
+  HIPCHK(ctx, hipMemcpyAsync(&best, d + o_best, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (best == 0xFFFFFFFFu) return 0;
+  *feerate = min_feerate + best;
+  *fee = (uint64_t)*feerate * weight / 1000;
+  return 1;
 }
 
 // ---- gossip

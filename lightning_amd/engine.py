@@ -99,6 +99,15 @@ class Engine:
                                                     sig64.ctypes.data, pub.ctypes.data, pub.shape[1], pub.shape[1], ok.ctypes.data))
         return ok.astype(bool)
 
+    def grind_htlc_tx_fee(self, preimage, outputs, input_sat, weight, min_feerate, max_feerate, sig64, sighash_type, has_witness, pub33):
+        """grind_htlc_tx_fee (onchaind/onchaind.c:388-438) on the device: (feerate, fee) of the lowest matching feerate, or None"""
+        rate, fee = ctypes.c_uint32(0), ctypes.c_uint64(0)
+        pre, outs, sig, key = bytes(preimage), bytes(outputs), bytes(sig64), bytes(pub33)
+        rc = self._chk(self._lib.lamd_grind_htlc_tx_fee(self._ctx, pre, len(pre), outs, len(outs), int(input_sat), int(weight), int(min_feerate),
+                                                         int(max_feerate), sig, int(sighash_type), int(bool(has_witness)), key,
+                                                         ctypes.byref(rate), ctypes.byref(fee)))
+        return (rate.value, fee.value) if rc == 1 else None
+
     def pubkey_parse(self, pub):
         pub = np.ascontiguousarray(pub, dtype=np.uint8)
         n, ln = pub.shape

@@ -403,3 +403,29 @@ def bip143_sighash(version, inputs, outputs, locktime, in_idx, script, amount, s
            + s.to_bytes(4, "little") + ho + locktime.to_bytes(4, "little")
            + sighash_type.to_bytes(4, "little"))
     return sha256d(pre), pre
+
+
+def grind_htlc_tx_fee(preimage, outputs, input_sat, weight, min_feerate, max_feerate, sig64, sighash_type, has_witness, pub33,
+                      verify=None):
+    """grind_htlc_tx_fee(), onchaind/onchaind.c:388-438, on serialised inputs: `preimage` is the BIP143 preimage of the
+    transaction as it stands (hashOutputs sits 40 bytes before its end, bitcoin/signature.c:120-151), `outputs` the serialised
+    outputs hashOutputs covers (amount of output 0 first).  Returns (feerate, fee) of the first feerate whose fee verifies,
+    else None.  fee = amount_tx_fee(feerate, weight) (common/amount.c:698-707); equal consecutive fees are tried once
+    (:420-424); a fee above the input amount ends the loop (:425-426); the check is check_tx_sig (:430-432) with its
+    sighash-type gate (bitcoin/signature.c:206-211).  `verify(hash32, sig64, pub33)` defaults to ecdsa_verify."""
+    verify = verify or ecdsa_verify
+    prev = None
+    for rate in range(min_feerate, max_feerate + 1):
+        fee = rate * weight // 1000
+        if fee == prev:
+            continue
+        prev = fee
+        if fee > input_sat:
+            break
+        if not (sighash_type == 1 or (sighash_type == 0x83 and has_witness)):
+            continue
+        outs = (input_sat - fee).to_bytes(8, "little") + bytes(outputs[8:])
+        pre = bytes(preimage[:-40]) + sha256d(outs) + bytes(preimage[-8:])
+        if verify(sha256d(pre), sig64, pub33):
+            return rate, fee
+    return None

@@ -404,12 +404,12 @@ def test_chunk_splitting_small_chunks(orc, kat):
         msgs = [g.msgs[int(g.off[i]):int(g.off[i + 1])].tobytes() for i in range(g.n)]
         ids = [g.ids[i].tobytes() if i >= g.n_cann else None for i in range(g.n)]
         assert np.array_equal(e.sigcheck_gossip(msgs, ids), g.expect)
-        # device-pointer gossip: expand on one lane, chunks alternating between both lanes, reduce after the join
-        g.d_verdict.fill_(77)
-        torch.cuda.synchronize()
-        e.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
+        # device-pointer gossip larger than one chunk is refused (the cut has to fall between messages, which needs the
+        # host copy of the row table): the caller splits, or uses the host-buffer entry point above
+        from lightning_amd import LamdError
+        with pytest.raises(LamdError):
+            e.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
         e.synchronize()
-        assert np.array_equal(g.d_verdict.cpu().numpy(), g.expect)
     finally:
         e.close()
 
@@ -550,3 +550,76 @@ def test_one_call_larger_than_a_chunk_full_size(eng):
     got = w.d_ok.cpu().numpy().astype(bool)
     assert np.array_equal(got, w.expect), np.nonzero(got != w.expect)[0][:10]
     assert 0 < (~w.expect).sum() < w.n
+
+
+def _kat_o(kat):
+    ko = next(v for v in kat["der"] if v["name"] == "KAT-O")
+    sig = H(ko["expect_sig"])
+    key = H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f")
+    tx = H("0200000001e1ebca08cf1c301ac563580a1126d5c8fcb0e5e2043230b852c726553caf1e1d0000000000000000000160ae0a0000000000"
+           "22002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d61927436041796d000000")
+    txid, vout, seq, spk, lock = tx[5:37], 0, 0, tx[56:90], 109
+    ws = H("76a914a8c40c334351dbe8e5908544f1c98fbcfb8719fc8763ac6721038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de05"
+           "4432eb7f7c820120876475527c2103cf8e2f193a6aed60db80af75f3c8d59c2de735b299b7c7083527be9bd23b77a852ae67a914b8bcd51e"
+           "fa35be1e50ae2d5f72f4500acb005c9c88ac6868")
+    amount_in_tx = int.from_bytes(tx[47:55], "little")
+    pre = pyref.bip143_sighash(2, [(txid, vout, seq)], [(amount_in_tx, spk)], lock, 0, ws, 700000, 1)[1]
+    outputs = amount_in_tx.to_bytes(8, "little") + bytes([len(spk)]) + spk
+    return sig, key, pre, outputs
+
+
+def test_grind_htlc_tx_fee_reference_kat(eng, kat, orc):
+    """onchaind/test/run-grind_feerate.c:119-154 as the reference runs it: weight 663, feerates 249 001..250 000, input
+    700 000 sat -> fee 165 750 (feerate 250 000); the device grind must stop where the reference's ascending loop stops"""
+    sig, key, pre, outputs = _kat_o(kat)
+    assert len(pre) == 290 and len(outputs) == 43
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 1, True, key) == (250000, 165750)
+    ver = lambda h, s, k: orc.ecdsa_verify(h, s, k)
+    assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 1, True, key, verify=ver) == (250000, 165750)
+    # wider and shifted ranges: always the LOWEST feerate giving fee 165 750 (250 000 * 663 / 1000 = 165 750 exactly)
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 0, 400000, sig, 1, True, key) == (250000, 165750)
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 250000, 250000, sig, 1, True, key) == (250000, 165750)
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 250001, 250001, sig, 1, True, key) == (250001, 165750)  # same fee, first in range
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 250002, 300000, sig, 1, True, key) is None
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 0, 249998, sig, 1, True, key) is None
+    # the preimage's own hashOutputs bytes are irrelevant (every candidate replaces them)
+    junk = pre[:-40] + bytes(32) + pre[-8:]
+    assert eng.grind_htlc_tx_fee(junk, outputs, 700000, 663, 249001, 250000, sig, 1, True, key) == (250000, 165750)
+    # gate, wrong key / signature, fee above the input
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 0x83, False, key) is None
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 2, True, key) is None
+    other = H("02" + "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798")
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 1, True, other) is None
+    bad = sig[:40] + bytes([sig[40] ^ 1]) + sig[41:]
+    assert eng.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, bad, 1, True, key) is None
+    assert eng.grind_htlc_tx_fee(pre, outputs, 165749, 663, 0, 400000, sig, 1, True, key) is None       # input too small for that fee
+
+
+def test_grind_htlc_tx_fee_random_vs_oracle(eng, orc):
+    """seeded synthetic HTLC transactions signed at a hidden feerate: the device grind and the restated reference loop
+    (pyref.grind_htlc_tx_fee over the C oracle's ECDSA) must return the same (feerate, fee) -- or both nothing"""
+    rnd = random.Random(2024)
+    ver = lambda h, s, k: orc.ecdsa_verify(h, s, k)
+    for case in range(12):
+        sk = rnd.randrange(1, pyref.N).to_bytes(32, "big")
+        pub = pyref.ser33(pyref.pubkey_create(int.from_bytes(sk, "big")))
+        script = bytes(rnd.randrange(256) for _ in range(rnd.choice((1, 25, 133, 140, 200))))
+        spk = bytes([0, 32]) + bytes(rnd.randrange(256) for _ in range(32))
+        input_sat = rnd.randrange(50_000, 5_000_000)
+        weight = rnd.choice((663, 703, 666, 706, 1000, 1))
+        lo = rnd.randrange(0, 30_000)
+        hi = lo + rnd.randrange(0, 3000)
+        hidden = rnd.randrange(max(0, lo - 50), hi + 50) if case % 4 else hi + 1000       # sometimes outside the range
+        fee = hidden * weight // 1000
+        amount = max(0, input_sat - fee)
+        txid = bytes(rnd.randrange(256) for _ in range(32))
+        stype = 0x83 if case % 3 == 0 else 1
+        sighash, pre = pyref.bip143_sighash(2, [(txid, rnd.randrange(4), rnd.randrange(2))], [(amount, spk)], rnd.randrange(1 << 31), 0, script, input_sat, stype)
+        sig = orc.ecdsa_sign(sighash, sk, bytes(rnd.randrange(256) for _ in range(32)))
+        outputs = amount.to_bytes(8, "little") + bytes([len(spk)]) + spk
+        start = pre[:-40] + bytes(rnd.randrange(256) for _ in range(32)) + pre[-8:]
+        exp = pyref.grind_htlc_tx_fee(start, outputs, input_sat, weight, lo, hi, sig, stype, True, pub, verify=ver)
+        got = eng.grind_htlc_tx_fee(start, outputs, input_sat, weight, lo, hi, sig, stype, True, pub)
+        assert got == exp, (case, got, exp)
+        if lo <= hidden <= hi and fee <= input_sat:
+            assert got is not None and got[1] == fee

@@ -136,3 +136,24 @@ def test_batch_drivers_match_single(orc):
         exp.append(i % 3 != 0)
     for th in (1, 2):
         assert list(orc.ecdsa_verify_batch(hs, sg, pk, 33, th).astype(bool)) == exp
+
+
+def test_fee_grind_restatement_reproduces_reference_kat(kat, orc):
+    """onchaind/test/run-grind_feerate.c:119-154: weight 663, feerates 249 001..250 000 over a 700 000 sat input must end
+    at fee 165 750 -- the restated loop (pyref.grind_htlc_tx_fee) over the C oracle's ECDSA"""
+    H = bytes.fromhex
+    ko = next(v for v in kat["der"] if v["name"] == "KAT-O")
+    sig = H(ko["expect_sig"])
+    key = H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f")
+    tx = H("0200000001e1ebca08cf1c301ac563580a1126d5c8fcb0e5e2043230b852c726553caf1e1d0000000000000000000160ae0a0000000000"
+           "22002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d61927436041796d000000")
+    spk = tx[56:90]
+    ws = H("76a914a8c40c334351dbe8e5908544f1c98fbcfb8719fc8763ac6721038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de05"
+           "4432eb7f7c820120876475527c2103cf8e2f193a6aed60db80af75f3c8d59c2de735b299b7c7083527be9bd23b77a852ae67a914b8bcd51e"
+           "fa35be1e50ae2d5f72f4500acb005c9c88ac6868")
+    pre = pyref.bip143_sighash(2, [(tx[5:37], 0, 0)], [(700000, spk)], 109, 0, ws, 700000, 1)[1]
+    outputs = (700000).to_bytes(8, "little") + bytes([len(spk)]) + spk
+    ver = lambda h, s, k: orc.ecdsa_verify(h, s, k)
+    assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 1, True, key, verify=ver) == (250000, 165750)
+    assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 249999, sig, 1, True, key, verify=ver) is None
+    assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 0x83, False, key, verify=ver) is None
