@@ -240,6 +240,28 @@ def main():
             extra["cfg5_commit_storm_superbatch"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[1:]), "mismatches": sm,
                                                      "keyed_comb_teeth": eng.info()["last_keyed"]}
             del st
+            # onchaind's fee grind with the reference's own transaction (onchaind/test/run-grind_feerate.c):
+            # every feerate 0..250 000 at weight 663 for one signature/key, hashing + verification on the device
+            try:
+                kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
+                H = bytes.fromhex
+                gsig = H(next(v for v in kat["der"] if v["name"] == "KAT-O")["expect_sig"])
+                gpre = H(next(v for v in kat["bip143"] if v["name"] == "KAT-O/fee=0")["preimage"])
+                gspk = H("002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d6192743604179")
+                gout = (700000).to_bytes(8, "little") + bytes([len(gspk)]) + gspk
+                gkey = H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f")
+                ts, res = [], None
+                for _ in range(6):
+                    t1 = time.perf_counter()
+                    res = eng.grind_htlc_tx_fee(gpre, gout, 700000, 663, 0, 250000, gsig, 1, True, gkey)
+                    ts.append(time.perf_counter() - t1)
+                gbad = 0 if res == (250000, 165750) else 1
+                extra["fee_grind_250k_feerates"] = {"feerates": 250001, "distinct_fees": 165751, "found": list(res) if res else None,
+                                                    "ms_per_grind": min(ts[1:]) * 1e3, "candidate_fees_per_s": 165751 / min(ts[1:]), "mismatches": gbad,
+                                                    "note": "one call = the whole loop of onchaind.c:388-438 (host buffers in, answer out)"}
+                mism += gbad
+            except FileNotFoundError:
+                pass
             out["other_configs_1gpu"] = extra
             mism += gm + sm
         if args.cpu_sample > 0:

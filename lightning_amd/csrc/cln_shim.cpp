@@ -195,6 +195,22 @@ extern "C" bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, con
   return check_signed_hash(&hash, &sig->s, key);
 }
 
+extern "C" bool grind_htlc_tx_fee(uint64_t *fee_sat, const u8 *bip143_preimage, size_t preimage_len, const u8 *outputs, size_t outputs_len,
+                                  uint64_t input_sat, const struct bitcoin_signature *remotesig, const u8 *wscript, uint64_t weight,
+                                  uint32_t min_possible_feerate, uint32_t max_possible_feerate, const struct pubkey *other_htlc_key) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  u8 der[PUBKEY_CMPR_LEN];
+  pubkey_to_der(der, other_htlc_key);
+  uint32_t rate = 0;
+  uint64_t fee = 0;
+  const int rc = lamd_grind_htlc_tx_fee(g_ctx, bip143_preimage, preimage_len, outputs, outputs_len, input_sat, weight, min_possible_feerate,
+                                        max_possible_feerate, remotesig->s.data, (uint8_t)remotesig->sighash_type, wscript != nullptr, der, &rate, &fee);
+  if (rc < 0) g_err = lamd_last_error(g_ctx);
+  if (rc != 1) return false;
+  *fee_sat = fee;
+  return true;
+}
+
 // ---- gossip veneer
 static std::string hex(const u8 *p, size_t n) {
   static const char *d = "0123456789abcdef";

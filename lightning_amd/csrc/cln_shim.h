@@ -5,6 +5,7 @@
  *   bitcoin/signature.h:85-87    check_signed_hash()
  *   bitcoin/signature.h:120-124  check_tx_sig()            (see note below)
  *   bitcoin/signature.h:129-131  check_schnorr_sig()
+ *   onchaind/onchaind.c:388-438  grind_htlc_tx_fee()       (static there; its statics become arguments)
  *   bitcoin/signature.h:158-159  signature_from_der()      (bitcoin/signature.c:310-323)
  *   common/node_id.h:72-82       pubkey_from_node_id(), check_signed_hash_nodeid()
  *   bitcoin/pubkey.h             pubkey_from_der(), pubkey_to_der()
@@ -77,6 +78,15 @@ bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pubkey *pubkey
  * amount, sig->sighash_type); witness_script NULL = legacy (then only SIGHASH_ALL is accepted). */
 bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
 		  const struct pubkey *key, const struct bitcoin_signature *sig);
+
+/* onchaind/onchaind.c:388-438.  The reference's file-scope state becomes arguments (min/max_possible_feerate,
+ * keyset->other_htlc_key) and the transaction is given as its BIP143 preimage, the serialised outputs that hashOutputs
+ * covers and the input amount (see lamd_grind_htlc_tx_fee).  true: *fee = the fee whose signature check passed, found at
+ * the lowest feerate of the range that produces it -- where the reference's ascending loop stops.  (On failure the
+ * reference leaves the last fee it tried in *fee; here *fee is untouched.) */
+bool grind_htlc_tx_fee(uint64_t *fee_sat, const u8 *bip143_preimage, size_t preimage_len, const u8 *outputs, size_t outputs_len,
+		       uint64_t input_sat, const struct bitcoin_signature *remotesig, const u8 *wscript, uint64_t weight,
+		       uint32_t min_possible_feerate, uint32_t max_possible_feerate, const struct pubkey *other_htlc_key);
 
 /* msg_len replaces tal_count(msg).  NULL = OK, else a malloc()ed message with the reference's
  * exact wording ("Bad node_signature_1 <der-hex> hash <hex> on channel_announcement <hex>", ...). */

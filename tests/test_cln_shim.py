@@ -118,6 +118,19 @@ def test_reference_unit_test_expectations(shim, kat):
         pre = H(v["preimage"])
         verdicts[v["name"]] = shim.check_tx_sig(pre, len(pre), b"\x76", ctypes.byref(key), ctypes.byref(sig))
     assert verdicts["KAT-O/fee=165750"] is True and sum(verdicts.values()) == 1
+    # ... and the grind itself as the test runs it: weight 663, max_possible_feerate 250 000, 1000 iterations
+    pre = H(next(v for v in kat["bip143"] if v["name"] == "KAT-O/fee=0")["preimage"])
+    spk = H("002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d6192743604179")
+    outputs = (700000).to_bytes(8, "little") + bytes([len(spk)]) + spk
+    fee = ctypes.c_uint64(0)
+    shim.grind_htlc_tx_fee.restype = ctypes.c_bool
+    shim.grind_htlc_tx_fee.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64,
+                                       ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    assert shim.grind_htlc_tx_fee(ctypes.byref(fee), pre, len(pre), outputs, len(outputs), 700000, ctypes.byref(sig), b"\x76", 663, 249001, 250000,
+                                  ctypes.byref(key)) is True
+    assert fee.value == 165750
+    assert shim.grind_htlc_tx_fee(ctypes.byref(fee), pre, len(pre), outputs, len(outputs), 700000, ctypes.byref(sig), b"\x76", 663, 0, 249000,
+                                  ctypes.byref(key)) is False
     # ---- check_signed_hash / _nodeid / schnorr through the reference's names
     b11 = next(v for v in kat["ecdsa"] if v["name"] == "KAT-B11")
     h = Sha256d.from_buffer_copy(H(b11["hash"]))
