@@ -101,6 +101,16 @@ int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *preimages, c
 			    const uint8_t *sighash_type, const uint8_t *has_witness_script,
 			    const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
 
+/* n independent secp256k1_ecdsa_recoverable_signature_parse_compact() + secp256k1_ecdsa_recover() calls as made by
+ * common/bolt11.c:1021-1046 (invoices without an `n` field) and lightningd/signmessage.c:193: sig64 = r||s, recid 0..3.
+ * pub33[i] = the recovered key, compressed (what node_id_from_pubkey() stores), ok[i] = 1; where the library calls would
+ * fail (r or s >= n or zero, recid > 3, recid & 2 with r >= p - n, no curve point with that x, infinity) ok[i] = 0 and the
+ * key bytes are zero.  There is no low-S rule on this path, as in the reference. */
+int lamd_ecdsa_recover_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *recid,
+			     uint8_t *pub33, uint8_t *ok);
+int lamd_ecdsa_recover_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64, const void *d_recid,
+				    void *d_pub33, void *d_ok);
+
 /* grind_htlc_tx_fee() (onchaind/onchaind.c:388-438): find the feerate whose fee makes `sig64` (one remote HTLC signature,
  * one key) verify.  For feerate = min_feerate..max_feerate: fee = feerate * weight / 1000 (amount_tx_fee), equal consecutive
  * fees are tried once, fees above input_sat end the search; candidate = the transaction with output 0 paying

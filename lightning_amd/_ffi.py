@@ -30,6 +30,8 @@ SYMBOLS = {
     "lamd_check_signed_hash_nodeid": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
     "lamd_check_schnorr_sig": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
     "lamd_check_tx_sig_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_u8p]),
+    "lamd_ecdsa_recover_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "lamd_ecdsa_recover_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
     "lamd_grind_htlc_tx_fee": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, c_u8p, c_sz, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
                                               ctypes.c_uint32, c_u8p, ctypes.c_uint8, ctypes.c_int, c_u8p, ctypes.POINTER(ctypes.c_uint32),
                                               ctypes.POINTER(ctypes.c_uint64)]),

@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
     load_words_be(rw, sig64 + 64 * row);
     if (mode == MODE_ECDSA) {
       ok = ecdsa_final(R, rw);
+    } else if (mode == MODE_RECOVER) {  // 0 or SCHNORR_PENDING with the Jacobian key parked in the slot (k_recover_final)
+      out[row] = recover_stage1(R, slots + i * SLOT_WORDS);
+      return;
     } else {  // 0 or SCHNORR_PENDING (parity decided by k_schnorr_final[_fin])
       out[row] = schnorr_stage1(R, rw, fin ? fin + row * FIN_WORDS : slots + i * SLOT_WORDS);
       return;
@@ -123,6 +126,19 @@ __global__ void __launch_bounds__(256) k_schnorr_final(size_t n, u32 *__restrict
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t T = (size_t)gridDim.x * blockDim.x;
   schnorr_final_thread(tid, T, n, slots, out);
+}
+
+// ---- public-key recovery: prep (Montgomery batch inversion of r, like the ECDSA prep) and the shared-inversion final stage
+__global__ void __launch_bounds__(256) k_recover_prep(size_t n, const u8 *__restrict__ hash32, const u8 *__restrict__ sig64,
+                                                      const u8 *__restrict__ recid, prep_rec *__restrict__ recs, u8 *__restrict__ rkey33) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  recover_prep_thread(tid, T, n, hash32, sig64, recid, recs, rkey33);
+}
+__global__ void __launch_bounds__(256) k_recover_final(size_t n, u32 *__restrict__ slots, u8 *__restrict__ out, u8 *__restrict__ pub33) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t T = (size_t)gridDim.x * blockDim.x;
+  recover_final_thread(tid, T, n, slots, out, pub33);
 }
 
 // ---- gossip: per message, double-SHA256 of the signed tail and expansion into (hash, sig, key) rows
@@ -1474,6 +1490,67 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   if (rc != LAMD_OK) return rc;
   hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
   HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);
+}
+
+// ---- ECDSA public-key recovery (verify_core.h "ECDSA public-key recovery"): out_pub33[i] = the compressed key, ok[i] = 1, or
+// a zeroed key and ok[i] = 0 where libsecp256k1's parse/recover would fail
+static int recover_device(lamd_ctx *ctx, size_t n, const u8 *d_hash, const u8 *d_sig, const u8 *d_recid, u8 *d_pub33, u8 *d_ok) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  for (size_t o = 0; o < n; o += ctx->chunk) {
+    const size_t m = n - o < ctx->chunk ? n - o : ctx->chunk;
+    if ((rc = ensure(ctx, &ctx->recs, m * sizeof(prep_rec))) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->g_pub, m * 33 + 16)) != LAMD_OK) return rc;
+    prep_rec *recs = (prep_rec *)ctx->recs.p;
+    hipLaunchKernelGGL(k_recover_prep, dim3(blocks_for(final_threads(ctx, m))), dim3(256), 0, ctx->stream, m, d_hash + 32 * o, d_sig + 64 * o,
+                       d_recid + o, recs, (u8 *)ctx->g_pub.p);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
+    rc = launch_direct(ctx, MODE_RECOVER, m, nullptr, recs, d_sig + 64 * o, (const u8 *)ctx->g_pub.p, 33, 33, nullptr, nullptr, d_ok + o, false);
+    if (rc != LAMD_OK) return rc;
+    hipLaunchKernelGGL(k_recover_final, dim3(blocks_for(final_threads(ctx, m))), dim3(256), 0, ctx->stream, m, (u32 *)ctx->slots.p, d_ok + o,
+                       d_pub33 + 33 * o);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return LAMD_OK;
+}
+extern "C" int lamd_ecdsa_recover_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64, const void *d_recid,
+                                               void *d_pub33, void *d_ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!d_hash32 || !d_sig64 || !d_recid || !d_pub33 || !d_ok) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  lamd_ctx *L;
+  int rc = pick_lane(ctx, &L);
+  if (rc != LAMD_OK) return rc;
+  rc = recover_device(L, n, (const u8 *)d_hash32, (const u8 *)d_sig64, (const u8 *)d_recid, (u8 *)d_pub33, (u8 *)d_ok);
+  if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
+  return rc;
+}
+extern "C" int lamd_ecdsa_recover_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *recid,
+                                        uint8_t *pub33, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!hash32 || !sig64 || !recid || !pub33 || !ok) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * 34)) != LAMD_OK) return rc;  // recid | keys out
+  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  u8 *d_recid = (u8 *)ctx->in_c.p, *d_keys = d_recid + n;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_a.p, hash32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_recid, recid, n, hipMemcpyHostToDevice, ctx->stream));
+  rc = recover_device(ctx, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, d_recid, d_keys, (u8 *)ctx->out.p);
+  if (rc != LAMD_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(pub33, d_keys, n * 33, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
   return lamd_synchronize(ctx);
 }

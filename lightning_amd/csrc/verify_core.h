@@ -20,7 +20,7 @@
 
 namespace lamd {
 
-enum { MODE_ECDSA = 0, MODE_SCHNORR = 1 };
+enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
 
 // ---- per-signature record produced by prep, consumed by ecmult (80 bytes, 16-byte aligned)
 struct prep_rec {
@@ -688,6 +688,149 @@ LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *sl
       inv = fe_mul(inv, slot_load_raw(slot + SLOT_FIN_Z));
       const fe y = fe_normalize(fe_mul(slot_load_raw(slot + SLOT_FIN_Y), fe_mul(fe_sqr(zi), zi)));
       out[i] = (y.n[0] & 1) == 0;
+    }
+    if (i == first) break;
+  }
+}
+
+// ---- ECDSA public-key recovery (secp256k1_ecdsa_recover as reached from common/bolt11.c:1041-1046 and
+// lightningd/signmessage.c:193): Q = (s/r)*R - (z/r)*G with R = the point whose x is r (+ n when recid & 2) and whose y
+// has parity recid & 1.  It is the verification ecmult with (u1, u2, key) = (-z/r, s/r, R): the prep below writes the same
+// prep_rec and R as a 33-byte compressed key for k_keys; the ecmult kernel parks the Jacobian result and k_recover_final
+// brings it to affine with one shared inversion per thread.
+// Fails (ok = 0) exactly where libsecp256k1 does: r or s >= n (recoverable_signature_parse_compact), recid > 3, r or s = 0,
+// recid & 2 with r >= p - n, x not on the curve, Q = infinity.  No low-S rule here.
+LAMD_HD void recover_load(const u8 *sig64, u8 recid, sc *r, sc *s, bool *ok) {
+  u32 rw[8], sw[8];
+  load_words_be(rw, sig64);
+  load_words_be(sw, sig64 + 32);
+  bool v = !words_ge_n(rw) & !words_ge_n(sw) & (recid < 4);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { r->w[i] = rw[i]; s->w[i] = sw[i]; }
+  v &= !sc_is_zero(*r) & !sc_is_zero(*s);
+  if (recid & 2) {
+    const u32 pmn[8] = LAMD_P_MINUS_N;
+    v &= !words_ge(rw, pmn);
+  }
+  *ok = v;
+}
+LAMD_HD void recover_prep_thread(size_t first, size_t stride, size_t n, const u8 *hash32, const u8 *sig64, const u8 *recid,
+                                 prep_rec *recs, u8 *rkey33) {
+  sc acc;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc.w[i] = (i == 0);
+  size_t last = first;
+  bool any = false;
+#pragma unroll 1
+  for (size_t i = first; i < n; i += stride) {
+    sc r, s;
+    bool ok;
+    recover_load(sig64 + 64 * i, recid[i], &r, &s, &ok);
+#pragma unroll
+    for (int k = 0; k < 8; k++) recs[i].u1[k] = acc.w[k];  // product of the valid r before i
+    if (ok) acc = sc_mul(acc, r);
+    last = i;
+    any = true;
+  }
+  if (!any) return;
+  sc inv = sc_inv(acc);
+#pragma unroll 1
+  for (size_t i = last;; i -= stride) {
+    sc r, s, prefix;
+    bool ok;
+    recover_load(sig64 + 64 * i, recid[i], &r, &s, &ok);
+#pragma unroll
+    for (int k = 0; k < 8; k++) prefix.w[k] = recs[i].u1[k];
+    prep_rec out;
+#pragma unroll
+    for (int k = 0; k < 8; k++) out.u1[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { out.k1[k] = 0x88888888u; out.k2[k] = 0x88888888u; }
+    out.flags = 0;
+    out.pad[0] = out.pad[1] = out.pad[2] = 0;
+    u8 *key = rkey33 + 33 * i;
+    for (int b = 0; b < 33; b++) key[b] = 0;  // prefix 0: k_keys rejects the row
+    if (ok) {
+      const sc rinv = sc_mul(inv, prefix);
+      inv = sc_mul(inv, r);
+      u32 zw[8];
+      load_words_be(zw, hash32 + 32 * i);
+      const sc z = sc_from_words(zw, nullptr);
+      const sc u1 = sc_neg(sc_mul(z, rinv));
+      const sc u2 = sc_mul(s, rinv);
+      glv_half h1, h2;
+      glv_split(&h1, &h2, u2);
+#pragma unroll
+      for (int k = 0; k < 8; k++) out.u1[k] = u1.w[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { out.k1[k] = h1.mag[k]; out.k2[k] = h2.mag[k]; }
+      out.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) |
+                  (h2.top ? PREP_K2TOP : 0);
+      // x(R) = r, or r + n (< p: checked in recover_load)
+      u32 xw[8];
+      u64 c = 0;
+      const u32 nw[8] = LAMD_SC_N;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        c += (u64)r.w[k] + ((recid[i] & 2) ? nw[k] : 0u);
+        xw[k] = (u32)c;
+        c >>= 32;
+      }
+      key[0] = 2 + (recid[i] & 1);
+      for (int k = 0; k < 8; k++) {
+        const u32 v = xw[7 - k];
+        key[1 + 4 * k] = (u8)(v >> 24); key[2 + 4 * k] = (u8)(v >> 16); key[3 + 4 * k] = (u8)(v >> 8); key[4 + 4 * k] = (u8)v;
+      }
+    }
+    recs[i] = out;
+    if (i == first) break;
+  }
+}
+constexpr int SLOT_REC_X = 0, SLOT_REC_Y = 9, SLOT_REC_Z = 18, SLOT_REC_PREFIX = 27;
+LAMD_HD u8 recover_stage1(const gej &Q, u32 *slot) {
+  if (Q.inf) return 0;
+  const fe z = fe_norm_weak(Q.z);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { slot[SLOT_REC_X + k] = Q.x.n[k]; slot[SLOT_REC_Y + k] = Q.y.n[k]; slot[SLOT_REC_Z + k] = z.n[k]; }
+  return SCHNORR_PENDING;
+}
+// out[i]: SCHNORR_PENDING -> 1 with the compressed key in pub33[i]; everything else -> 0 and a zeroed key
+LAMD_HD void recover_final_thread(size_t first, size_t stride, size_t n, u32 *slots, u8 *out, u8 *pub33) {
+  fe acc = fe_set_int(1);
+  size_t last = first;
+  bool any = false;
+#pragma unroll 1
+  for (size_t i = first; i < n; i += stride) {
+    last = i;
+    any = true;
+    if (out[i] != SCHNORR_PENDING) continue;
+    u32 *slot = slots + i * SLOT_WORDS;
+#pragma unroll
+    for (int k = 0; k < 9; k++) slot[SLOT_REC_PREFIX + k] = acc.n[k];
+    acc = fe_mul(acc, slot_load_raw(slot + SLOT_REC_Z));
+  }
+  if (!any) return;
+  fe inv = fe_inv(acc);
+#pragma unroll 1
+  for (size_t i = last;; i -= stride) {
+    u8 *key = pub33 + 33 * i;
+    if (out[i] == SCHNORR_PENDING) {
+      const u32 *slot = slots + i * SLOT_WORDS;
+      const fe zi = fe_mul(inv, slot_load_raw(slot + SLOT_REC_PREFIX));
+      inv = fe_mul(inv, slot_load_raw(slot + SLOT_REC_Z));
+      const fe zi2 = fe_sqr(zi);
+      u32 xw[8];
+      fe_to_words(xw, fe_normalize(fe_mul(slot_load_raw(slot + SLOT_REC_X), zi2)));
+      const fe y = fe_normalize(fe_mul(slot_load_raw(slot + SLOT_REC_Y), fe_mul(zi2, zi)));
+      key[0] = 2 + (y.n[0] & 1);
+      for (int k = 0; k < 8; k++) {
+        const u32 v = xw[7 - k];
+        key[1 + 4 * k] = (u8)(v >> 24); key[2 + 4 * k] = (u8)(v >> 16); key[3 + 4 * k] = (u8)(v >> 8); key[4 + 4 * k] = (u8)v;
+      }
+      out[i] = 1;
+    } else {
+      for (int b = 0; b < 33; b++) key[b] = 0;
+      out[i] = 0;
     }
     if (i == first) break;
   }

@@ -99,6 +99,33 @@ class Engine:
                                                     sig64.ctypes.data, pub.ctypes.data, pub.shape[1], pub.shape[1], ok.ctypes.data))
         return ok.astype(bool)
 
+    def ecdsa_recover(self, hash32, sig64, recid):
+        """numpy uint8 [n,32], [n,64], [n] -> (keys uint8 [n,33], ok bool [n]); secp256k1_ecdsa_recover semantics"""
+        hash32, sig64 = _u8(hash32, 32), _u8(sig64, 64)
+        recid = np.ascontiguousarray(recid, dtype=np.uint8)
+        n = hash32.shape[0]
+        keys = np.zeros((n, 33), dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        if n:
+            self._chk(self._lib.lamd_ecdsa_recover_batch(self._ctx, n, hash32.ctypes.data, sig64.ctypes.data, recid.ctypes.data,
+                                                         keys.ctypes.data, ok.ctypes.data))
+        return keys, ok.astype(bool)
+
+    def _after_torch(self):
+        """order the next submission after what torch's current stream holds (the tensors handed to the *_device methods are
+        usually produced there); a device-side event, no host synchronisation.  The caller still has to keep the tensors alive
+        until the results are complete."""
+        try:
+            import torch
+            self._chk(self._lib.lamd_wait_stream(self._ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        except ImportError:
+            pass
+
+    def ecdsa_recover_device(self, d_hash32, d_sig64, d_recid, d_pub33, d_ok):
+        self._after_torch()
+        self._chk(self._lib.lamd_ecdsa_recover_batch_device(self._ctx, d_hash32.shape[0], d_hash32.data_ptr(), d_sig64.data_ptr(),
+                                                            d_recid.data_ptr(), d_pub33.data_ptr(), d_ok.data_ptr()))
+
     def grind_htlc_tx_fee(self, preimage, outputs, input_sat, weight, min_feerate, max_feerate, sig64, sighash_type, has_witness, pub33):
         """grind_htlc_tx_fee (onchaind/onchaind.c:388-438) on the device: (feerate, fee) of the lowest matching feerate, or None"""
         rate, fee = ctypes.c_uint32(0), ctypes.c_uint64(0)
@@ -169,11 +196,13 @@ class Engine:
     # ---- device-resident API (torch uint8 CUDA tensors; asynchronous on self.stream_ptr)
     def verify_ecdsa_device(self, d_hash, d_sig, d_pub, d_ok):
         n, publen = d_pub.shape
+        self._after_torch()
         self._chk(self._lib.lamd_verify_ecdsa_batch_device(self._ctx, n, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr(),
                                                            publen, publen, d_ok.data_ptr()))
 
     def verify_schnorr_device(self, d_msg, d_xonly, d_sig, d_ok):
         n = d_msg.shape[0]
+        self._after_torch()
         self._chk(self._lib.lamd_verify_schnorr_batch_device(self._ctx, n, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr(),
                                                              d_ok.data_ptr()))
 
@@ -189,6 +218,7 @@ class Engine:
         self._chk(self._lib.lamd_gen_gossip_device(self._ctx, n_cann, n_cupd, seed, n_nodes, d_msgs.data_ptr(), d_ids.data_ptr()))
 
     def sigcheck_gossip_device(self, n, d_msgs, d_off, d_ids, d_rowbase, rows, d_verdict):
+        self._after_torch()
         self._chk(self._lib.lamd_sigcheck_gossip_batch_device(self._ctx, n, d_msgs.data_ptr(), d_off.data_ptr(),
                                                               d_ids.data_ptr() if d_ids is not None else None, d_rowbase.data_ptr(), rows,
                                                               d_verdict.data_ptr()))

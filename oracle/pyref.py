@@ -429,3 +429,29 @@ def grind_htlc_tx_fee(preimage, outputs, input_sat, weight, min_feerate, max_fee
         if verify(sha256d(pre), sig64, pub33):
             return rate, fee
     return None
+
+
+def ecdsa_recover(hash32, sig64, recid):
+    """secp256k1_ecdsa_recoverable_signature_parse_compact + secp256k1_ecdsa_recover as called at common/bolt11.c:1021-1046
+    and lightningd/signmessage.c:193 (SEC1 4.1.6 with the library's failure rules): the public key point, or None.
+    Fails when r or s >= n (parse), recid not in 0..3, r or s = 0, recid & 2 and r >= p - n, no point with that x,
+    or the result is infinity.  No low-S requirement."""
+    r = int.from_bytes(sig64[:32], "big")
+    s = int.from_bytes(sig64[32:], "big")
+    if r >= N or s >= N or not 0 <= recid <= 3:
+        return None
+    if r == 0 or s == 0:
+        return None
+    x = r
+    if recid & 2:
+        if r >= P - N:
+            return None
+        x = r + N
+    R = lift_x(x)                       # even y
+    if R is None:
+        return None
+    if recid & 1:
+        R = pneg(R)
+    z = int.from_bytes(hash32, "big") % N
+    rinv = pow(r, -1, N)
+    return padd(pmul(s * rinv % N, R), pmul((-z * rinv) % N, G))

@@ -188,6 +188,26 @@ int dm_ecmult_keyed(int T, const u8 *key33, const u8 *u1, const u8 *u2, u8 *out6
   return ecmult_keyed_t<10>(qx, qy, u1, u2, out64);
 }
 #endif  // DM_NO_KEYED
+// public-key recovery exactly as the kernels stage it: prep (batch inversion over `threads` owners) -> key parse of R ->
+// ladder -> shared-inversion final stage
+void dm_recover_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8 *recid, u8 *pub33, u8 *ok, size_t threads) {
+  dm_init();
+  std::vector<prep_rec> recs(n);
+  std::vector<u8> rkey(n * 33);
+  for (size_t t = 0; t < threads; t++) recover_prep_thread(t, threads, n, hash32, sig64, recid, recs.data(), rkey.data());
+  std::vector<u32> slots(n * SLOT_WORDS);
+  for (size_t i = 0; i < n; i++) {
+    u32 qx[8], qy[8];
+    bool v = parse_pubkey(&rkey[33 * i], 33, qx, qy);
+    v &= (recs[i].flags & PREP_VALID) != 0;
+    ok[i] = 0;
+    if (v) {
+      const gej Q = ecmult_lane(recs[i], ge_from_words(qx, qy), &slots[i * SLOT_WORDS], g_table.data());
+      ok[i] = recover_stage1(Q, &slots[i * SLOT_WORDS]);
+    }
+  }
+  for (size_t t = 0; t < threads; t++) recover_final_thread(t, threads, n, slots.data(), ok, pub33);
+}
 // two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
 void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {
   dm_init();

@@ -350,3 +350,72 @@ def test_gtable_windows_that_straddle_words(kat):
                               b"".join(H(v["sig"]) for v in rows), out)
     bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
     assert not bad, bad[:10]
+
+
+def _recover_cases(orc, rnd, n):
+    """rows (hash, sig, recid, expected key or None) covering valid recoveries under both parities, r/s range failures,
+    recid 2/3 (r + n), x off the curve, high-S signatures (fine on this path) and the infinity result"""
+    rows = []
+    for i in range(n):
+        sk = rnd.randrange(1, N)
+        h = bytes(rnd.randrange(256) for _ in range(32))
+        sig = orc.ecdsa_sign(h, sk.to_bytes(32, "big"), bytes(rnd.randrange(256) for _ in range(32)))
+        recid = rnd.randrange(2)
+        c = i % 10
+        if c == 5:                                   # high S: same R, s -> n - s flips which recid gives the signer
+            s = N - int.from_bytes(sig[32:], "big")
+            sig = sig[:32] + s.to_bytes(32, "big")
+        elif c == 6:
+            recid = rnd.randrange(2, 4)              # r + n >= p almost always -> failure
+        elif c == 7:
+            sig = rnd.choice((bytes(32) + sig[32:], sig[:32] + bytes(32), N.to_bytes(32, "big") + sig[32:], sig[:32] + (N + 1).to_bytes(32, "big")))
+        elif c == 8:
+            recid = rnd.choice((4, 7, 255))
+        elif c == 9:
+            sig = rnd.randrange(1, N).to_bytes(32, "big") + sig[32:]      # random r: half of them have no point
+        rows.append((h, sig, recid))
+    # tiny r so that recid 2/3 (x = r + n < p) can succeed, and the infinity outcome: Q = (s R - z G)/r = inf when s R = z G
+    for r in range(1, 40):
+        for recid in range(4):
+            rows.append((bytes(rnd.randrange(256) for _ in range(32)), r.to_bytes(32, "big") + rnd.randrange(1, N).to_bytes(32, "big"), recid))
+    k = rnd.randrange(1, N)
+    R = pyref.pmul(k, pyref.G)
+    r, s = R[0] % N, rnd.randrange(1, N)
+    z = s * k % N                                     # s*R = (s k) G = z G
+    rows.append((z.to_bytes(32, "big"), r.to_bytes(32, "big") + s.to_bytes(32, "big"), R[1] & 1))
+    return rows
+
+
+def test_recover_pipeline_vs_pyref(dm, orc):
+    rnd = random.Random(4711)
+    rows = _recover_cases(orc, rnd, 120)
+    n = len(rows)
+    for threads in (1, 7):
+        pub = ctypes.create_string_buffer(33 * n)
+        ok = ctypes.create_string_buffer(n)
+        dm.dm_recover_batch(ctypes.c_size_t(n), b"".join(r[0] for r in rows), b"".join(r[1] for r in rows), bytes(r[2] & 0xFF for r in rows),
+                            pub, ok, ctypes.c_size_t(threads))
+        good = 0
+        for i, (h, sig, recid) in enumerate(rows):
+            exp = pyref.ecdsa_recover(h, sig, recid)
+            got = pub.raw[33 * i:33 * i + 33]
+            if exp is None:
+                assert ok.raw[i] == 0 and got == bytes(33), (i, recid, sig.hex())
+            else:
+                assert ok.raw[i] == 1 and got == pyref.ser33(exp), (i, recid, sig.hex())
+                good += 1
+                if int.from_bytes(sig[32:], "big") <= N // 2:
+                    assert orc.ecdsa_verify(h, sig, got)      # a recovered key verifies its (low-S) signature
+        assert good >= 70 and good < n
+
+
+def test_recover_goldens_host(dm, kat):
+    rows = kat["recover"]
+    n = len(rows)
+    pub = ctypes.create_string_buffer(33 * n)
+    ok = ctypes.create_string_buffer(n)
+    dm.dm_recover_batch(ctypes.c_size_t(n), b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+                        bytes(v["recid"] & 0xFF for v in rows), pub, ok, ctypes.c_size_t(3))
+    for i, v in enumerate(rows):
+        got = pub.raw[33 * i:33 * i + 33].hex() if ok.raw[i] else None
+        assert got == v["expect"], v["name"]

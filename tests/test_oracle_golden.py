@@ -157,3 +157,15 @@ def test_fee_grind_restatement_reproduces_reference_kat(kat, orc):
     assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 1, True, key, verify=ver) == (250000, 165750)
     assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 249999, sig, 1, True, key, verify=ver) is None
     assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 0x83, False, key, verify=ver) is None
+
+
+def test_recover_goldens(kat):
+    """public-key recovery: the reference's own BOLT11 test invoices (common/test/run-bolt11.c) all recover the key the test
+    pins (:310); plus the other recovery id and synthesised failure classes"""
+    H = bytes.fromhex
+    ref = [v for v in kat["recover"] if v["name"].startswith("KAT-B11R/") and "other" not in v["name"]]
+    assert len(ref) >= 10 and all(v["expect"] == "03e7156ae33b0a208d0744199163177e909e80176e55d97a2f221ede0f934dd9ad" for v in ref)
+    for v in kat["recover"]:
+        got = pyref.ecdsa_recover(H(v["hash"]), H(v["sig"]), v["recid"])
+        assert (pyref.ser33(got).hex() if got else None) == v["expect"], v["name"]
+    assert sum(1 for v in kat["recover"] if v["expect"] is None) >= 15
