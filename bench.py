@@ -262,6 +262,27 @@ def main():
                 mism += gbad
             except FileNotFoundError:
                 pass
+            # public-key recovery over the ECDSA batch of the main step: both recovery ids, the signer's
+            # compressed key must come back from exactly one of them on every untouched row
+            d_keys = [torch.zeros((n, 33), dtype=torch.uint8, device=device) for _ in range(2)]
+            d_oks = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(2)]
+            d_rids = [torch.full((n,), r, dtype=torch.uint8, device=device) for r in (0, 1)]
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(4):
+                t1 = time.perf_counter()
+                for r in (0, 1):
+                    eng.ecdsa_recover_device(we.dev[0], we.dev[1], d_rids[r], d_keys[r], d_oks[r])
+                eng.synchronize()
+                ts.append(time.perf_counter() - t1)
+            xs = we.dev[2][:, 1:33]                                     # x of the signer (65-byte keys: 04 | x | y)
+            par = (we.dev[2][:, 64] & 1) + 2
+            hit = [((d_keys[r][:, 1:] == xs).all(dim=1) & (d_keys[r][:, 0] == par) & (d_oks[r] == 1)) for r in (0, 1)]
+            goodrows = torch.from_numpy(we.expect).to(device)
+            rbad = int((~(hit[0] ^ hit[1]) & goodrows).sum())
+            extra["ecdsa_recover"] = {"recoveries": 2 * n, "recoveries_per_s": 2 * n / min(ts[1:]), "mismatches": rbad,
+                                      "check": "signer's key from exactly one recovery id on every valid row"}
+            mism += rbad
             out["other_configs_1gpu"] = extra
             mism += gm + sm
         if args.cpu_sample > 0:

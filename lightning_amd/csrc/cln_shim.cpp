@@ -195,6 +195,28 @@ extern "C" bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, con
   return check_signed_hash(&hash, &sig->s, key);
 }
 
+extern "C" int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *, secp256k1_ecdsa_recoverable_signature *sig,
+                                                                    const unsigned char *input64, int recid) {
+  if (recid < 0 || recid > 3 || !below_n(input64) || !below_n(input64 + 32)) {
+    memset(sig->data, 0, sizeof(sig->data));
+    return 0;
+  }
+  memcpy(sig->data, input64, 64);
+  sig->data[64] = (unsigned char)recid;
+  return 1;
+}
+extern "C" int secp256k1_ecdsa_recover(const void *, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
+                                       const unsigned char *msghash32) {
+  memset(pubkey->data, 0, sizeof(pubkey->data));
+  if (!g_ctx && !lamd_shim_setup()) return 0;
+  u8 key33[33], ok = 0;
+  const int rc = lamd_ecdsa_recover_batch(g_ctx, 1, msghash32, sig->data, sig->data + 64, key33, &ok);
+  if (rc < 0) g_err = lamd_last_error(g_ctx);
+  if (rc != LAMD_OK || !ok) return 0;
+  return parse_key(key33, 33, pubkey) ? 1 : 0;
+}
+extern "C" void node_id_from_pubkey(struct node_id *id, const struct pubkey *key) { pubkey_to_der(id->k, key); }
+
 extern "C" bool grind_htlc_tx_fee(uint64_t *fee_sat, const u8 *bip143_preimage, size_t preimage_len, const u8 *outputs, size_t outputs_len,
                                   uint64_t input_sat, const struct bitcoin_signature *remotesig, const u8 *wscript, uint64_t weight,
                                   uint32_t min_possible_feerate, uint32_t max_possible_feerate, const struct pubkey *other_htlc_key) {

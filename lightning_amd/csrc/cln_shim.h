@@ -5,6 +5,7 @@
  *   bitcoin/signature.h:85-87    check_signed_hash()
  *   bitcoin/signature.h:120-124  check_tx_sig()            (see note below)
  *   bitcoin/signature.h:129-131  check_schnorr_sig()
+ *   common/bolt11.c:1021-1046    secp256k1_ecdsa_recoverable_signature_parse_compact(), secp256k1_ecdsa_recover()
  *   onchaind/onchaind.c:388-438  grind_htlc_tx_fee()       (static there; its statics become arguments)
  *   bitcoin/signature.h:158-159  signature_from_der()      (bitcoin/signature.c:310-323)
  *   common/node_id.h:72-82       pubkey_from_node_id(), check_signed_hash_nodeid()
@@ -78,6 +79,16 @@ bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pubkey *pubkey
  * amount, sig->sighash_type); witness_script NULL = legacy (then only SIGHASH_ALL is accepted). */
 bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
 		  const struct pubkey *key, const struct bitcoin_signature *sig);
+
+/* Public-key recovery as common/bolt11.c:1021-1046 and lightningd/signmessage.c:193 use it, under libsecp256k1's own
+ * names and return conventions (1 = ok, 0 = failure; the context argument is accepted and ignored).  The opaque
+ * recoverable signature holds r||s||recid. */
+typedef struct { unsigned char data[65]; } secp256k1_ecdsa_recoverable_signature;
+int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *ctx, secp256k1_ecdsa_recoverable_signature *sig,
+							 const unsigned char *input64, int recid);
+int secp256k1_ecdsa_recover(const void *ctx, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
+			    const unsigned char *msghash32);
+void node_id_from_pubkey(struct node_id *id, const struct pubkey *key);   /* common/node_id.c:12-19 */
 
 /* onchaind/onchaind.c:388-438.  The reference's file-scope state becomes arguments (min/max_possible_feerate,
  * keyset->other_htlc_key) and the transaction is given as its BIP143 preimage, the serialised outputs that hashOutputs

@@ -166,3 +166,25 @@ def test_reference_unit_test_expectations(shim, kat):
     ok = next(v for v in kat["gossip"] if v["name"] == "nann/ok/0")
     m = H(ok["msg"])
     assert shim.sigcheck_node_announcement(None, None, ctypes.byref(sg), m, len(m)) is None
+
+
+@pytest.mark.gpu
+def test_bolt11_recovery_through_libsecp_names(shim, kat):
+    """common/bolt11.c:1021-1046 as written there: parse the 64+1 byte signature, recover, node_id_from_pubkey -- for the
+    reference's own test invoices (common/test/run-bolt11.c) the receiver id must be the key the test pins at :310"""
+    assert shim.lamd_shim_setup(), shim.lamd_shim_last_error()
+
+    class RecSig(ctypes.Structure):
+        _fields_ = [("data", ctypes.c_ubyte * 65)]
+    for v in kat["recover"]:
+        if not v["name"].startswith("KAT-B11R/") and v["recid"] > 3:
+            rs = RecSig()
+            assert shim.secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"]) == 0
+            continue
+        rs, pk, nid = RecSig(), Pubkey(), NodeId()
+        parsed = shim.secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"])
+        got = None
+        if parsed and shim.secp256k1_ecdsa_recover(None, ctypes.byref(pk), ctypes.byref(rs), H(v["hash"])):
+            shim.node_id_from_pubkey(ctypes.byref(nid), ctypes.byref(pk))
+            got = bytes(nid.k).hex()
+        assert got == v["expect"], v["name"]
