@@ -239,6 +239,38 @@ def main():
             nv = st["ecdsa"].n + st["schnorr"].n
             extra["cfg5_commit_storm_superbatch"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[1:]), "mismatches": sm,
                                                      "keyed_comb_teeth": eng.info()["last_keyed"]}
+            # the same storm as STREAMING batches from host memory: commitments (484 signatures each) are appended to the pinned
+            # staging queue, every 256 commitments are flushed as one batch, two flushes stay in flight while the third staging
+            # set is being filled (lamd_queue_*_batch / lamd_flush / lamd_wait) -- H2D, verification and D2H all inside the clock
+            per, grp = st["per"], 256 * st["per"]
+            ts, sbad = [], 0
+            for it in range(3):
+                jobs = []
+                for kind in ("ecdsa", "schnorr"):
+                    wl = st[kind]
+                    for o in range(0, wl.n, grp):
+                        jobs.append((kind, wl, o, min(wl.n, o + grp)))
+                jobs.sort(key=lambda j: j[2])                     # interleave the two kinds as the channels would arrive
+                pend, sbad = [], 0
+                t1 = time.perf_counter()
+                for kind, wl, a, b in jobs:
+                    if kind == "ecdsa":
+                        eng.queue_ecdsa_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
+                    else:
+                        eng.queue_schnorr_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
+                    eng.flush()
+                    pend.append((wl, a, b))
+                    if len(pend) == 2:
+                        wl0, a0, b0 = pend.pop(0)
+                        sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
+                while pend:
+                    wl0, a0, b0 = pend.pop(0)
+                    sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
+                ts.append(time.perf_counter() - t1)
+            extra["cfg5_commit_storm_streaming"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[1:]), "mismatches": sbad,
+                                                    "batch": "256 commitments (123 904 signatures) per flush, 2 flushes in flight",
+                                                    "note": "inputs in host memory: staging memcpy + H2D + verification + D2H inside the clock"}
+            mism += sbad
             del st
             # onchaind's fee grind with the reference's own transaction (onchaind/test/run-grind_feerate.c):
             # every feerate 0..250 000 at weight 663 for one signature/key, hashing + verification on the device

@@ -156,12 +156,18 @@ int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg
 
 /* ---- streaming front end for callers that produce triples one at a time (channeld's
  * commitment_signed loop, channeld/channeld.c:2171,2215-2232; gossip ingest).  Triples are
- * appended to a pinned staging ring; flush launches everything queued (asynchronous);
- * poll/wait return the verdicts in submission order. */
+ * appended to a pinned staging set; flush launches everything queued so far as one batch (asynchronous) and opens the
+ * next set, so queueing continues while flushes are in flight: up to 3 flushes may be outstanding (LAMD_ERR_STATE beyond
+ * that, until one is collected), successive flushes run on alternating lanes.  poll/wait return the verdicts of the
+ * OLDEST outstanding flush, in submission (ticket) order. */
 int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
 		     const uint8_t *pubkey, size_t publen); /* returns the ticket (>= 0) or an error */
 int lamd_queue_schnorr(lamd_ctx *ctx, const uint8_t msg32[32], const uint8_t xonly32[32],
 		       const uint8_t sig64[64]);
+/* n triples at once (row strides 32, 64, pubstride): returns the first ticket, the others follow consecutively */
+int lamd_queue_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey,
+			   size_t publen, size_t pubstride);
+int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64);
 int lamd_flush(lamd_ctx *ctx);
 /* 1 = finished (ok[0..*n) filled, tickets in submission order), 0 = still running, < 0 error */
 int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);

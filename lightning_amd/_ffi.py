@@ -39,6 +39,8 @@ SYMBOLS = {
     "lamd_sigcheck_gossip_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p]),
     "lamd_queue_ecdsa": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, c_sz]),
     "lamd_queue_schnorr": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
+    "lamd_queue_ecdsa_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_sz, c_sz]),
+    "lamd_queue_schnorr_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p]),
     "lamd_flush": (ctypes.c_int, [ctypes.c_void_p]),
     "lamd_poll": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
     "lamd_wait": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),

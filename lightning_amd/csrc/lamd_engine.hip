@@ -790,6 +790,7 @@ struct devbuf {
 };
 
 enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
+constexpr int QUEUE_SETS = 3;
 
 struct lamd_ctx {
   int device = 0;
@@ -824,17 +825,22 @@ struct lamd_ctx {
   size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double last_ms[4] = {0, 0, 0, 0};
-  // streaming queues (pinned host staging)
+  // streaming queues (pinned host staging): QUEUE_SETS sets, one being filled while up to QUEUE_SETS - 1 flushed ones are
+  // in flight (each on the lane picked at its flush), collected oldest first
   struct queue {
     u8 *h_a = nullptr, *h_b = nullptr, *h_c = nullptr, *h_ok = nullptr;  // hash/msg, sig, key, verdicts
-    size_t cap = 0, n = 0, inflight = 0;
+    size_t cap = 0, n = 0;
     std::vector<int> tickets;
     devbuf d_a, d_b, d_c, d_ok;
-  } q[Q_KINDS];
+  };
+  struct queue_set {
+    queue q[Q_KINDS];
+    hipEvent_t done = nullptr;
+  } qs[QUEUE_SETS];
+  int q_open = 0;                 // the set being filled, -1 when every set is in flight
+  int q_fifo[QUEUE_SETS] = {0};   // flushed sets, oldest first
+  int q_inflight = 0;
   int next_ticket = 0;
-  int inflight_total = 0;
-  bool flushed = false;
-  hipEvent_t flush_done = nullptr;
   // Lanes: the device-pointer entry points alternate between two complete sub-contexts (own streams and workspaces, the
   // G table shared), so that the latency-bound front end of one call (key de-duplication, the count read-back, table
   // building) runs under the VALU-bound ecmult kernel of the previous one.  A lane's `peer` is the other lane; the
@@ -899,7 +905,8 @@ static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
-  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flush_done, hipEventDisableTiming));
+  if (!ctx->is_lane)
+    for (auto &qs : ctx->qs) HIPCHK(ctx, hipEventCreateWithFlags(&qs.done, hipEventDisableTiming));
   return LAMD_OK;
 }
 static int make_lanes(lamd_ctx *root) {
@@ -1023,17 +1030,19 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
                     &ctx->g_msgs, &ctx->g_off, &ctx->g_ids, &ctx->g_rowbase, &ctx->g_hash, &ctx->g_sig, &ctx->g_pub,
                     &ctx->g_malformed, &ctx->g_ok, &ctx->g_verdict})
     release(b);
-  for (auto &q : ctx->q) {
-    for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
-      if (*h) (void)hipHostFree(*h);
-    for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
+  for (auto &qs : ctx->qs) {
+    for (auto &q : qs.q) {
+      for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
+        if (*h) (void)hipHostFree(*h);
+      for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
+    }
+    if (qs.done) (void)hipEventDestroy(qs.done);
   }
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
   if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
-  if (ctx->flush_done) (void)hipEventDestroy(ctx->flush_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1734,25 +1743,43 @@ static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes) {
 }
 static const size_t Q_KEYBYTES[Q_KINDS] = {33, 65, 32};
 
-static int queue_push(lamd_ctx *ctx, int kind, const u8 *a, const u8 *sig, const u8 *key) {
+static int queue_reserve_n(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, size_t extra) {
+  while (q.n + extra > q.cap) {
+    const size_t keep = q.n;
+    q.n = q.cap;  // make queue_reserve grow
+    const int rc = queue_reserve(ctx, q, keybytes);
+    q.n = keep;
+    if (rc != LAMD_OK) return rc;
+  }
+  return LAMD_OK;
+}
+// appends n triples (row strides 32 / 64 / keystride); returns the ticket of the first one
+static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *sig, const u8 *key, size_t keystride) {
   if (!ctx) return LAMD_ERR_ARG;
-  if (!a || !sig || !key) {
+  if (!a || !sig || !key || n == 0 || n > (size_t)0x3FFFFFFF || keystride < Q_KEYBYTES[kind]) {
     ctx->err = "bad argument";
     return LAMD_ERR_ARG;
   }
-  if (ctx->flushed) {
-    ctx->err = "queue: results of the previous flush have not been collected (poll/wait first)";
+  if (ctx->q_open < 0) {
+    ctx->err = "queue: every staging set is in flight (collect a flush with poll/wait first)";
     return LAMD_ERR_STATE;
   }
-  lamd_ctx::queue &q = ctx->q[kind];
-  const int rc = queue_reserve(ctx, q, Q_KEYBYTES[kind]);
+  lamd_ctx::queue &q = ctx->qs[ctx->q_open].q[kind];
+  const size_t kb = Q_KEYBYTES[kind];
+  const int rc = queue_reserve_n(ctx, q, kb, n);
   if (rc != LAMD_OK) return rc;
-  memcpy(q.h_a + 32 * q.n, a, 32);
-  memcpy(q.h_b + 64 * q.n, sig, 64);
-  memcpy(q.h_c + Q_KEYBYTES[kind] * q.n, key, Q_KEYBYTES[kind]);
-  q.tickets.push_back(ctx->next_ticket);
-  q.n++;
-  return ctx->next_ticket++;
+  memcpy(q.h_a + 32 * q.n, a, 32 * n);
+  memcpy(q.h_b + 64 * q.n, sig, 64 * n);
+  if (keystride == kb) {
+    memcpy(q.h_c + kb * q.n, key, kb * n);
+  } else {
+    for (size_t i = 0; i < n; i++) memcpy(q.h_c + kb * (q.n + i), key + keystride * i, kb);
+  }
+  const int first = ctx->next_ticket;
+  for (size_t i = 0; i < n; i++) q.tickets.push_back(first + (int)i);
+  q.n += n;
+  ctx->next_ticket += (int)n;
+  return first;
 }
 extern "C" int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64], const uint8_t *pubkey,
                                 size_t publen) {
@@ -1760,47 +1787,75 @@ extern "C" int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const u
     ctx->err = "bad key length";
     return LAMD_ERR_ARG;
   }
-  return queue_push(ctx, publen == 33 ? Q_ECDSA33 : Q_ECDSA65, hash32, sig64, pubkey);
+  return queue_push(ctx, publen == 33 ? Q_ECDSA33 : Q_ECDSA65, 1, hash32, sig64, pubkey, publen);
 }
 extern "C" int lamd_queue_schnorr(lamd_ctx *ctx, const uint8_t msg32[32], const uint8_t xonly32[32], const uint8_t sig64[64]) {
-  return queue_push(ctx, Q_SCHNORR, msg32, sig64, xonly32);
+  return queue_push(ctx, Q_SCHNORR, 1, msg32, sig64, xonly32, 32);
 }
-
+// n triples at once (one commitment_signed: 1 + up to 483 signatures); returns the first ticket, the rest follow consecutively
+extern "C" int lamd_queue_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey,
+                                      size_t publen, size_t pubstride) {
+  if (ctx && publen != 33 && publen != 65) {
+    ctx->err = "bad key length";
+    return LAMD_ERR_ARG;
+  }
+  return queue_push(ctx, publen == 33 ? Q_ECDSA33 : Q_ECDSA65, n, hash32, sig64, pubkey, pubstride);
+}
+extern "C" int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64) {
+  return queue_push(ctx, Q_SCHNORR, n, msg32, sig64, xonly32, 32);
+}
+// Launches everything queued so far as one batch per kind (asynchronous, on the next lane) and opens the next staging set:
+// queueing continues while up to QUEUE_SETS - 1 flushes are in flight.
 extern "C" int lamd_flush(lamd_ctx *ctx) {
   if (!ctx) return LAMD_ERR_ARG;
-  if (ctx->flushed) {
-    ctx->err = "flush: previous flush not collected";
+  if (ctx->q_open < 0) {
+    ctx->err = "flush: every staging set is in flight (collect a flush with poll/wait first)";
     return LAMD_ERR_STATE;
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  lamd_ctx::queue_set &qs = ctx->qs[ctx->q_open];
+  lamd_ctx *L;
+  int rc = pick_lane(ctx, &L);
+  if (rc != LAMD_OK) return rc;
   for (int kind = 0; kind < Q_KINDS; kind++) {
-    lamd_ctx::queue &q = ctx->q[kind];
+    lamd_ctx::queue &q = qs.q[kind];
     if (!q.n) continue;
     const size_t kb = Q_KEYBYTES[kind];
-    int rc;
     if ((rc = ensure(ctx, &q.d_a, q.n * 32)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_b, q.n * 64)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_c, q.n * kb + 16)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_ok, q.n)) != LAMD_OK) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, ctx->stream));
-    rc = run_device(ctx, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
+    HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
+    rc = run_device(L, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
                     (const u8 *)q.d_c.p, (int)kb, kb, (u8 *)q.d_ok.p);
-    if (rc != LAMD_OK) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(q.h_ok, q.d_ok.p, q.n, hipMemcpyDeviceToHost, ctx->stream));
-    q.inflight = q.n;
+    if (rc != LAMD_OK) {
+      if (L != ctx) ctx->err = L->err;
+      return rc;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(q.h_ok, q.d_ok.p, q.n, hipMemcpyDeviceToHost, L->stream));
   }
-  HIPCHK(ctx, hipEventRecord(ctx->flush_done, ctx->stream));
-  ctx->flushed = true;
+  HIPCHK(ctx, hipEventRecord(qs.done, L->stream));
+  ctx->q_fifo[ctx->q_inflight++] = ctx->q_open;
+  // the next set to fill: any set that is not in flight
+  ctx->q_open = -1;
+  for (int sidx = 0; sidx < QUEUE_SETS && ctx->q_open < 0; sidx++) {
+    bool busy = false;
+    for (int k = 0; k < ctx->q_inflight; k++) busy |= ctx->q_fifo[k] == sidx;
+    if (!busy) ctx->q_open = sidx;
+  }
   return LAMD_OK;
 }
 
+// verdicts of the OLDEST flush, tickets in submission order
 static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+  const int sidx = ctx->q_fifo[0];
+  lamd_ctx::queue_set &qs = ctx->qs[sidx];
   size_t total = 0;
   int base = -1;
-  for (auto &q : ctx->q)
-    for (size_t i = 0; i < q.inflight; i++) {
+  for (auto &q : qs.q)
+    for (size_t i = 0; i < q.n; i++) {
       total++;
       if (base < 0 || q.tickets[i] < base) base = q.tickets[i];
     }
@@ -1808,34 +1863,35 @@ static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
     ctx->err = "result buffer too small";
     return LAMD_ERR_ARG;
   }
-  for (auto &q : ctx->q) {
-    for (size_t i = 0; i < q.inflight; i++) ok[q.tickets[i] - base] = q.h_ok[i];
+  for (auto &q : qs.q) {
+    for (size_t i = 0; i < q.n; i++) ok[q.tickets[i] - base] = q.h_ok[i];
     q.tickets.clear();
     q.n = 0;
-    q.inflight = 0;
   }
   if (n) *n = total;
-  ctx->flushed = false;
+  for (int k = 1; k < ctx->q_inflight; k++) ctx->q_fifo[k - 1] = ctx->q_fifo[k];
+  ctx->q_inflight--;
+  if (ctx->q_open < 0) ctx->q_open = sidx;
   return 1;
 }
 extern "C" int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
   if (!ctx || !ok) return LAMD_ERR_ARG;
-  if (!ctx->flushed) {
+  if (!ctx->q_inflight) {
     ctx->err = "poll before flush";
     return LAMD_ERR_STATE;
   }
-  const hipError_t e = hipEventQuery(ctx->flush_done);
+  const hipError_t e = hipEventQuery(ctx->qs[ctx->q_fifo[0]].done);
   if (e == hipErrorNotReady) return 0;
   HIPCHK(ctx, e);
   return collect(ctx, ok, cap, n);
 }
 extern "C" int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
   if (!ctx || !ok) return LAMD_ERR_ARG;
-  if (!ctx->flushed) {
+  if (!ctx->q_inflight) {
     ctx->err = "wait before flush";
     return LAMD_ERR_STATE;
   }
-  HIPCHK(ctx, hipEventSynchronize(ctx->flush_done));
+  HIPCHK(ctx, hipEventSynchronize(ctx->qs[ctx->q_fifo[0]].done));
   return collect(ctx, ok, cap, n);
 }
 

@@ -178,6 +178,17 @@ class Engine:
     def queue_schnorr(self, msg32, xonly32, sig64):
         return self._chk(self._lib.lamd_queue_schnorr(self._ctx, bytes(msg32), bytes(xonly32), bytes(sig64)))
 
+    def queue_ecdsa_batch(self, hash32, sig64, pub):
+        """numpy uint8 [n,32], [n,64], [n,33|65]: first ticket"""
+        hash32, sig64 = _u8(hash32, 32), _u8(sig64, 64)
+        pub = np.ascontiguousarray(pub, dtype=np.uint8)
+        return self._chk(self._lib.lamd_queue_ecdsa_batch(self._ctx, hash32.shape[0], hash32.ctypes.data, sig64.ctypes.data, pub.ctypes.data,
+                                                          pub.shape[1], pub.shape[1]))
+
+    def queue_schnorr_batch(self, msg32, xonly32, sig64):
+        msg32, xonly32, sig64 = _u8(msg32, 32), _u8(xonly32, 32), _u8(sig64, 64)
+        return self._chk(self._lib.lamd_queue_schnorr_batch(self._ctx, msg32.shape[0], msg32.ctypes.data, xonly32.ctypes.data, sig64.ctypes.data))
+
     def flush(self):
         self._chk(self._lib.lamd_flush(self._ctx))
 

@@ -423,14 +423,20 @@ def test_streaming_poll_and_error_states(eng, kat):
     for _ in range(300):
         eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))
     eng.flush()
+    eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))         # queueing goes on while a flush is in flight ...
+    eng.flush()
+    eng.flush()                                                     # ... an empty flush is a (third) outstanding flush too
     with pytest.raises(LamdError):
-        eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))     # results of the previous flush not collected yet
+        eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))     # every staging set is in flight
     with pytest.raises(LamdError):
         eng.flush()
     got, t0 = None, time.time()
     while got is None and time.time() - t0 < 10:
         got = eng.poll()
     assert got is not None and len(got) == 300 and all(bool(x) == v["expect"] for x in got)
+    assert list(eng.wait()) == [v["expect"]] and len(eng.wait()) == 0   # oldest first: the 1-row flush, then the empty one
+    with pytest.raises(LamdError):
+        eng.poll()                                                  # nothing outstanding any more
     with pytest.raises(ValueError):
         eng.verify_ecdsa(np.zeros((2, 32), np.uint8), np.zeros((2, 64), np.uint8), np.zeros((2, 40), np.uint8))   # 40-byte keys
     import ctypes
@@ -675,3 +681,29 @@ def test_recover_then_verify_round_trip_full_size(eng):
         s_hi = w.dev[1][:, 32] >= 0x80
         assert bool(((v == 1) | ~rec_ok | s_hi).all())
         assert not bool((v[~rec_ok] == 1).any())
+
+
+def test_streaming_pipelined_flushes(eng, orc):
+    """a sidecar's inner loop: keep two flushes in flight while the next batch is being queued; verdicts come back per flush,
+    oldest first, in ticket order, and equal the oracle's"""
+    rnd = random.Random(555)
+    batches = []
+    for b in range(7):
+        n = rnd.choice((1, 37, 484, 484, 1500))
+        hs, sg, pk = _random_ecdsa(orc, rnd, n, 33)
+        sg = sg.copy()
+        sg[::3, 5] ^= 0x10
+        batches.append((hs, sg, pk, orc.ecdsa_verify_batch(hs, sg, pk, 33, 4).astype(bool)))
+    outstanding, results = [], []
+    for hs, sg, pk, exp in batches:
+        for i in range(hs.shape[0]):
+            eng.queue_ecdsa(hs[i].tobytes(), sg[i].tobytes(), pk[i].tobytes())
+        eng.flush()
+        outstanding.append(exp)
+        if len(outstanding) == 2:                       # one being collected, one in flight, one being filled
+            results.append((eng.wait(), outstanding.pop(0)))
+    while outstanding:
+        results.append((eng.wait(), outstanding.pop(0)))
+    assert len(results) == len(batches)
+    for got, exp in results:
+        assert np.array_equal(np.asarray(got, dtype=bool), exp)
