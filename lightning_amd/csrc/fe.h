@@ -256,13 +256,14 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
   fe_mac_k(lo, h[7], 1u << FE_R1_SHIFT);
 // r.n[0..7], lo (column 8 so far) and hi (= H[17], <= 2^35) -> the finished product
 #define LAMD_FE_TAIL                                                                                \
-  const u64 h17 = hi;                                     /* <= 2^35 */                             \
-  lo += h17 * FE_R0;                                                                                \
+  LAMD_ASSERT((hi >> 32) == 0);                           /* column 16 is one product: H[17] < 2^26 */ \
+  const u32 h17 = (u32)hi;                                                                          \
+  lo += (u64)h17 * FE_R0;                                                                           \
   r.n[8] = (u32)lo & FE_M24;                                                                        \
   const u64 e = lo >> 24;                                 /* <= 2^40 */                             \
-  u64 t = (u64)r.n[0] + e * 977u + h17 * ((u64)FE_R0 << FE_R1_SHIFT);                                \
+  u64 t = (u64)r.n[0] + e * 977u + (u64)h17 * (FE_R0 << FE_R1_SHIFT);                               \
   r.n[0] = (u32)t & FE_M29;                                                                         \
-  t = (t >> 29) + (u64)r.n[1] + (e << 3) + (h17 << (2 * FE_R1_SHIFT));                               \
+  t = (t >> 29) + (u64)r.n[1] + (e << 3) + ((u64)h17 << (2 * FE_R1_SHIFT));                          \
   r.n[1] = (u32)t & FE_M29;                                                                         \
   t = (t >> 29) + (u64)r.n[2];                                                                      \
   r.n[2] = (u32)t & FE_M29;                                                                         \

@@ -821,6 +821,7 @@ struct lamd_ctx {
   bool timing = false;
   bool ev_recorded = false;
   int ecmult_waves = 3;
+  size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
   u64 hash_seed = 0x243F6A8885A308D3ULL;
   size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -919,6 +920,7 @@ static int make_lanes(lamd_ctx *root) {
     L->prop = root->prop;
     L->gtable = root->gtable;
     L->ecmult_waves = root->ecmult_waves;
+    L->prep_batch = root->prep_batch;
     L->hash_seed = root->hash_seed;
     L->chunk = root->chunk;
     L->keyed_mode = root->keyed_mode;
@@ -964,6 +966,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     return LAMD_ERR_NO_DEVICE;
   }
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
+  if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   {
     std::random_device rd;
     ctx->hash_seed = ((u64)rd() << 32) ^ (u64)rd() ^ 0x243F6A8885A308D3ULL;
@@ -1121,7 +1124,7 @@ static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
 static void launch_prep(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, prep_rec *recs) {
   if (mode == MODE_ECDSA) {
     // enough threads to fill the chip, few enough that each amortises its inversion over ~16 signatures
-    size_t threads = (n + 15) / 16;
+    size_t threads = (n + ctx->prep_batch - 1) / ctx->prep_batch;
     const size_t min_threads = (size_t)ctx->prop.multiProcessorCount * 256;
     if (threads < min_threads) threads = n < min_threads ? n : min_threads;
     hipLaunchKernelGGL(k_ecdsa_prep, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, n, d_a, d_sig, recs);
