@@ -3,6 +3,8 @@ check_signed_hash / check_tx_sig / check_schnorr_sig / gossipd sigcheck_* interf
 
 The product is liblightning_amd.so (C ABI: include/lightning_amd.h; kernels: csrc/).  This
 package is the thin Python front end used by tests and bench.py."""
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts: the engine's lanes need their own hardware queues (DESIGN.md 3.3)
 from .engine import Engine, LamdError  # noqa: F401
 
 __all__ = ["Engine", "LamdError"]

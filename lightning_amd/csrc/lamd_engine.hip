@@ -811,7 +811,7 @@ struct lamd_ctx {
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
   double keyed_dense_uses = 48.0;  // ... and for the 10-tooth comb (512 entries per key)
   int keyed_teeth = 0;             // 0 = choose by re-use, 7 or 10 = force that comb (LAMD_KEYED_TEETH)
-  int last_spacing = 0;
+  int last_teeth = 0;
   int last_mode = 0;
   size_t last_unique_keys = 0;
   bool last_keyed = false;
@@ -889,6 +889,13 @@ static void release(devbuf *b) {
 
 
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  The
+// engine uses up to 9 streams (root + two lanes, each with a prep and a cold-row side stream); with 4 queues one lane's prep
+// kernel lands behind the other lane's ecmult kernel and the lanes stop overlapping (measured: two 484-row flushes in flight
+// 880 -> 1 640 batches/s, the 2 M-row step 170 -> 182 M verifies/s with >= 8 queues).  The runtime reads the variable once,
+// at its first API call, so it is set when this library is loaded -- unless the host application has set it already.
+__attribute__((constructor)) static void lamd_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 extern "C" const char *lamd_version(void) { return "lightning_amd 0.1 (gfx950)"; }
 
@@ -1116,7 +1123,7 @@ static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
   info->last_unique_keys = ctx->last_unique_keys;
   info->last_hot_rows = ctx->last_hot_rows;
-  info->last_keyed = ctx->last_keyed ? ctx->last_spacing : 0;
+  info->last_keyed = ctx->last_keyed ? ctx->last_teeth : 0;
   info->last_mode = ctx->last_mode;
   return LAMD_OK;
 }
@@ -1160,7 +1167,7 @@ static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, cons
 // One chunk (n <= ctx->chunk rows) entirely on the context's streams.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
 //  1. scalar prep for every row on stream2 (independent of the key work; joined by event before the ecmult kernels)
 //  2. big chunks: de-duplicate the keys on the device; keys carried by >= keyed_min_uses rows are "hot": each gets a
-//     window table in HBM and its rows are verified by the table-driven kernel (no / few doublings); the other
+//     comb table in HBM and its rows are verified by the table-driven kernel (18 doublings instead of 132); the other
 //     ("cold") rows take the per-signature ladder.  Small chunks skip 2 (latency-bound: per-signature ladder).
 static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
                      size_t keystride, u8 *d_ok, bool time_it) {
@@ -1224,7 +1231,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     const size_t stride_w = T == 10 ? kc_stride(10) : kc_stride(7);
     const size_t scratch_w = T == 10 ? kc_scratch_words(10) : kc_scratch_words(7);
     ctx->last_keyed = true;
-    ctx->last_spacing = T;
+    ctx->last_teeth = T;
     ctx->last_hot_rows = hot_rows;
     if ((rc = ensure(ctx, &ctx->keyok_row, n)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &ctx->kt_qwords, nhot * 64)) != LAMD_OK) return rc;

@@ -1,5 +1,6 @@
 import json
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts: the engine's lanes need their own hardware queues
 import sys
 
 import pytest

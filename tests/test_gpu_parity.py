@@ -319,7 +319,7 @@ def eng_keyed(request):
         e = Engine(0)
     finally:
         del os.environ["LAMD_KEYED"], os.environ["LAMD_KEYED_TEETH"]
-    e.spacing = T
+    e.teeth = T
     yield e
     e.close()
 
@@ -332,7 +332,7 @@ def test_keyed_path_goldens_and_oracle(eng_keyed, orc, kat):
         bad = [v["name"] for v, g in zip(vs, got) if bool(g) != v["expect"]]
         assert not bad, bad[:10]
         inf = e.info()
-        assert inf["last_keyed"] == e.spacing and 0 < inf["last_unique_keys"] < len(vs)
+        assert inf["last_keyed"] == e.teeth and 0 < inf["last_unique_keys"] < len(vs)
     vs = kat["schnorr"]
     got = e.verify_schnorr(_rows([H(v["msg"]) for v in vs], 32), _rows([H(v["pk"]) for v in vs], 32), _rows([H(v["sig"]) for v in vs], 64))
     bad = [v["name"] for v, g in zip(vs, got) if bool(g) != v["expect"]]
