@@ -201,6 +201,11 @@ def main():
                          "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
                          "executed_mul32_per_verify": w_exec, "avg_launch_ms": ke[2], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,
+                         # in the timed region the kernel shares the chip with the other lane's front end (de-duplication, table building,
+                         # scalar prep), which stretches its launch; alone (one call at a time, measured right after the timed region):
+                         "isolated": {"launch_ms": float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2]),
+                                      "achieved": w_exec * n / (float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2]) * 1e-3) / 1e12,
+                                      "frac": w_exec * n / (float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2]) * 1e-3) / P_MUL32},
                          # the multiplier instructions are about half of the kernel's VALU instructions and the VALU issue port is the limit
                          "valu_issue": valu_issue,
                          # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time:
@@ -227,10 +232,13 @@ def main():
             ts = np.sort(np.array(ts[5:])) * 1e3
             lat["ecdsa65_batch_%d" % bs] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)])}
         out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
-        t1 = time.perf_counter()
-        hv = eng.verify_ecdsa(we.cols[0], we.cols[1], we.cols[2])
-        out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / (time.perf_counter() - t1), "rows": n,
-                                 "note": "pageable host buffers in, verdicts out, single synchronous call; not the headline value"}
+        tp = []
+        for _ in range(3):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
+            t1 = time.perf_counter()
+            hv = eng.verify_ecdsa(we.cols[0], we.cols[1], we.cols[2])
+            tp.append(time.perf_counter() - t1)
+        out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / min(tp[1:]), "first_call_verifies_per_s": n / tp[0], "rows": n,
+                                 "note": "pageable host buffers in, verdicts out, one synchronous call (best of two after a warm-up call); not the headline value"}
         mism += int((hv != we.expect).sum())
         # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
         # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
