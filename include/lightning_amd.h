@@ -67,8 +67,9 @@ int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, con
 /* ---- the same with every buffer already resident in HBM (device pointers), asynchronous: the work is ordered after
  * whatever is already queued on the context's stream (lamd_stream()) and the verdicts are complete after
  * lamd_synchronize(), or, without blocking the host, for a stream passed to lamd_stream_wait_results().  Successive
- * calls alternate between two internal lanes (own streams and workspaces) so that one call's key de-duplication and
- * table building run under the previous call's ecmult kernel; LAMD_LANES=1 turns that off (strictly one stream).
+ * calls rotate over LAMD_LANES internal lanes (default 4; own streams and workspaces) so that one call's key
+ * de-duplication and table building run under the ecmult kernels of the calls before it; LAMD_LANES=1 turns that off
+ * (strictly one stream).
  * This is what bench.py times. */
 int lamd_verify_ecdsa_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64,
 				   const void *d_pub, size_t publen, size_t pubstride, void *d_ok);
@@ -157,7 +158,7 @@ int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg
 /* ---- streaming front end for callers that produce triples one at a time (channeld's
  * commitment_signed loop, channeld/channeld.c:2171,2215-2232; gossip ingest).  Triples are
  * appended to a pinned staging set; flush launches everything queued so far as one batch (asynchronous) and opens the
- * next set, so queueing continues while flushes are in flight: up to 3 flushes may be outstanding (LAMD_ERR_STATE beyond
+ * next set, so queueing continues while flushes are in flight: up to 5 flushes may be outstanding (LAMD_ERR_STATE beyond
  * that, until one is collected), successive flushes run on alternating lanes.  poll/wait return the verdicts of the
  * OLDEST outstanding flush, in submission (ticket) order. */
 int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
@@ -226,9 +227,10 @@ typedef struct {
 	int last_keyed;           /* 0: per-signature ladder only; else rows of the last chunk ran on per-key tables and this is
 				   * the number of comb teeth of those tables (7 or 10) */
 	int last_mode;            /* 0: the last chunk was ECDSA, 1: BIP-340 */
+	int lanes;                /* number of lanes (LAMD_LANES, default 4; 1 = strictly one stream) */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
-int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 / 1 */
+int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 .. lanes-1 */
 int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */
 
 #ifdef __cplusplus

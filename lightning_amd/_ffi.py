@@ -11,7 +11,7 @@ c_sz = ctypes.c_size_t
 class LamdInfo(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("arch", ctypes.c_char * 64),
                 ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4), ("last_unique_keys", ctypes.c_size_t),
-                ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int), ("last_mode", ctypes.c_int)]
+                ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int), ("last_mode", ctypes.c_int), ("lanes", ctypes.c_int)]
 
 
 # name -> (restype, argtypes); every symbol of include/lightning_amd.h

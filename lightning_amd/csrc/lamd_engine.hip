@@ -790,7 +790,8 @@ struct devbuf {
 };
 
 enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
-constexpr int QUEUE_SETS = 3;
+constexpr int MAX_LANES = 8;
+constexpr int QUEUE_SETS = 5;
 
 struct lamd_ctx {
   int device = 0;
@@ -842,11 +843,12 @@ struct lamd_ctx {
   int q_fifo[QUEUE_SETS] = {0};   // flushed sets, oldest first
   int q_inflight = 0;
   int next_ticket = 0;
-  // Lanes: the device-pointer entry points alternate between two complete sub-contexts (own streams and workspaces, the
-  // G table shared), so that the latency-bound front end of one call (key de-duplication, the count read-back, table
-  // building) runs under the VALU-bound ecmult kernel of the previous one.  A lane's `peer` is the other lane; the
-  // root context (the handle the caller holds) has lane[0..1] and keeps its own stream for staging, queues, generators.
-  lamd_ctx *lane[2] = {nullptr, nullptr};
+  // Lanes: the device-pointer entry points rotate over LAMD_LANES (default 4) complete sub-contexts (own streams and
+  // workspaces, the G table shared), so that the latency-bound front end of one call (key de-duplication, the count
+  // read-back, table building) runs under the VALU-bound ecmult kernels of the calls before it.  A lane's `peer` is the
+  // next lane; the root context (the handle the caller holds) keeps its own stream for staging, queues, generators.
+  lamd_ctx *lane[MAX_LANES] = {};
+  int nlanes = 0;
   lamd_ctx *peer = nullptr;
   lamd_ctx *last_lane = nullptr;
   lamd_ctx *last_chunk_lane = nullptr;  // where the last chunk of this lane's last call ran (itself or its peer)
@@ -917,8 +919,8 @@ static int create_streams(lamd_ctx *ctx) {
     for (auto &qs : ctx->qs) HIPCHK(ctx, hipEventCreateWithFlags(&qs.done, hipEventDisableTiming));
   return LAMD_OK;
 }
-static int make_lanes(lamd_ctx *root) {
-  for (int i = 0; i < 2; i++) {
+static int make_lanes(lamd_ctx *root, int count) {
+  for (int i = 0; i < count; i++) {
     lamd_ctx *L = new (std::nothrow) lamd_ctx();
     if (!L) return LAMD_ERR_NOMEM;
     root->lane[i] = L;
@@ -938,8 +940,8 @@ static int make_lanes(lamd_ctx *root) {
     const int rc = create_streams(L);
     if (rc != LAMD_OK) { root->err = L->err; return rc; }
   }
-  root->lane[0]->peer = root->lane[1];
-  root->lane[1]->peer = root->lane[0];
+  root->nlanes = count;
+  for (int i = 0; i < count; i++) root->lane[i]->peer = root->lane[(i + 1) % count];
   return LAMD_OK;
 }
 // the lane the next device-pointer call runs on, ordered after whatever is already queued on the context's own stream
@@ -947,7 +949,7 @@ static int pick_lane(lamd_ctx *root, lamd_ctx **out) {
   *out = root;
   if (!root->lane[0]) return LAMD_OK;
   lamd_ctx *L = root->lane[root->next_lane];
-  root->next_lane ^= 1;
+  root->next_lane = (root->next_lane + 1) % root->nlanes;
   root->last_lane = L;
   L->timing = root->timing;
   HIPCHK(root, hipEventRecord(root->ev_lane, root->stream));
@@ -1012,8 +1014,9 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipFree(d_bases));
   const char *lanes = getenv("LAMD_LANES");
-  if (!lanes || atoi(lanes) != 1) {
-    rc = make_lanes(ctx);
+  const int nl = lanes ? atoi(lanes) : 4;
+  if (nl > 1) {
+    rc = make_lanes(ctx, nl > MAX_LANES ? MAX_LANES : nl);
     if (rc != LAMD_OK) return rc;
   }
   return init_known_answers(ctx);
@@ -1080,7 +1083,8 @@ extern "C" int lamd_synchronize(lamd_ctx *ctx) {
 // `stream` (a hipStream_t of the caller) waits for every verification submitted so far -- without blocking the host
 extern "C" int lamd_stream_wait_results(lamd_ctx *ctx, void *stream) {
   if (!ctx) return LAMD_ERR_ARG;
-  for (lamd_ctx *L : {ctx->lane[0], ctx->lane[1], ctx}) {
+  for (int i = 0; i <= MAX_LANES; i++) {
+    lamd_ctx *L = i < MAX_LANES ? ctx->lane[i] : ctx;
     if (!L) continue;
     HIPCHK(ctx, hipEventRecord(L->ev_join, L->stream));
     HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, L->ev_join, 0));
@@ -1106,12 +1110,16 @@ extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
 static int get_info_of(lamd_ctx *ctx, lamd_info *info);
 extern "C" int lamd_get_info(lamd_ctx *ctx, lamd_info *info) {
   if (!ctx || !info) return LAMD_ERR_ARG;
-  return get_info_of(ctx->last_lane ? ctx->last_lane : ctx, info);
+  const int rc = get_info_of(ctx->last_lane ? ctx->last_lane : ctx, info);
+  info->lanes = ctx->nlanes ? ctx->nlanes : 1;
+  return rc;
 }
 // the same for one lane (0 or 1): with two lanes, alternate calls land on alternate lanes
 extern "C" int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info) {
-  if (!ctx || !info || lane < 0 || lane > 1) return LAMD_ERR_ARG;
-  return get_info_of(ctx->lane[lane] ? ctx->lane[lane] : ctx, info);
+  if (!ctx || !info || lane < 0 || lane >= (ctx->nlanes ? ctx->nlanes : 1)) return LAMD_ERR_ARG;
+  const int rc = get_info_of(ctx->lane[lane] ? ctx->lane[lane] : ctx, info);
+  info->lanes = ctx->nlanes ? ctx->nlanes : 1;
+  return rc;
 }
 static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   if (ctx->last_chunk_lane) ctx = ctx->last_chunk_lane;

@@ -274,4 +274,4 @@ class Engine:
         else:
             self._chk(self._lib.lamd_get_lane_info(self._ctx, int(lane), ctypes.byref(inf)))
         return dict(device=inf.device, compute_units=inf.compute_units, arch=inf.arch.decode(), gtable_bytes=inf.gtable_bytes,
-                    last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_hot_rows=inf.last_hot_rows, last_keyed=int(inf.last_keyed), last_mode=int(inf.last_mode))
+                    last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_hot_rows=inf.last_hot_rows, last_keyed=int(inf.last_keyed), last_mode=int(inf.last_mode), lanes=int(inf.lanes))

@@ -425,7 +425,8 @@ def test_streaming_poll_and_error_states(eng, kat):
     eng.flush()
     eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))         # queueing goes on while a flush is in flight ...
     eng.flush()
-    eng.flush()                                                     # ... an empty flush is a (third) outstanding flush too
+    for _ in range(3):
+        eng.flush()                                                 # ... an empty flush is an outstanding flush too: five in all
     with pytest.raises(LamdError):
         eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"]))     # every staging set is in flight
     with pytest.raises(LamdError):
@@ -434,7 +435,8 @@ def test_streaming_poll_and_error_states(eng, kat):
     while got is None and time.time() - t0 < 10:
         got = eng.poll()
     assert got is not None and len(got) == 300 and all(bool(x) == v["expect"] for x in got)
-    assert list(eng.wait()) == [v["expect"]] and len(eng.wait()) == 0   # oldest first: the 1-row flush, then the empty one
+    assert list(eng.wait()) == [v["expect"]]                        # oldest first: the 1-row flush, then the empty ones
+    assert [len(eng.wait()) for _ in range(3)] == [0, 0, 0]
     with pytest.raises(LamdError):
         eng.poll()                                                  # nothing outstanding any more
     with pytest.raises(ValueError):
@@ -498,8 +500,8 @@ def test_lanes_back_to_back_calls_without_host_sync(eng, orc):
         for kind, w in ws:
             assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect), (rep, kind, w.n)
         assert np.array_equal(gv.cpu().numpy(), g.expect)
-    inf = [eng.info(0), eng.info(1)]
-    assert {i["last_mode"] for i in inf} <= {0, 1}
+    inf = [eng.info(k) for k in range(eng.info()["lanes"])]
+    assert len(inf) == 4 and {i["last_mode"] for i in inf} <= {0, 1}
     # a caller's stream can wait for the results on the device instead of blocking the host
     kind, w = ws[0]
     w.d_ok.zero_()
@@ -514,7 +516,7 @@ def test_lanes_back_to_back_calls_without_host_sync(eng, orc):
 
 def test_single_lane_mode_matches(orc):
     import os
-    from lightning_amd import Engine, workload
+    from lightning_amd import Engine, LamdError, workload
     os.environ["LAMD_LANES"] = "1"
     try:
         e = Engine(0)
@@ -528,7 +530,9 @@ def test_single_lane_mode_matches(orc):
         e.synchronize()
         assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
         assert np.array_equal(s.d_ok.cpu().numpy().astype(bool), s.expect)
-        assert e.info(0) == e.info(1) == e.info()
+        assert e.info()["lanes"] == 1 and e.info(0) == e.info()
+        with pytest.raises(LamdError):
+            e.info(1)
     finally:
         e.close()
 
@@ -700,7 +704,7 @@ def test_streaming_pipelined_flushes(eng, orc):
             eng.queue_ecdsa(hs[i].tobytes(), sg[i].tobytes(), pk[i].tobytes())
         eng.flush()
         outstanding.append(exp)
-        if len(outstanding) == 2:                       # one being collected, one in flight, one being filled
+        if len(outstanding) == 3:                       # up to three in flight while the next one is being filled
             results.append((eng.wait(), outstanding.pop(0)))
     while outstanding:
         results.append((eng.wait(), outstanding.pop(0)))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Small-batch streaming: commitments of 484 signatures, one flush each, two flushes in flight.
+"""Small-batch streaming: commitments of 484 signatures, one flush each, 1 / 2 / 4 flushes in flight.
 usage: [LAMD_LANES=1] python tools/stream_small_batches.py   (prints batches/s and signatures/s)"""
 import json
 import os
@@ -17,7 +17,7 @@ w = st["ecdsa"]
 per = st["per"]
 nb = w.n // per
 out = {}
-for depth in (1, 2):
+for depth in (1, 2, 4):
     best = 0.0
     for rep in range(3):
         pend, bad = [], 0
