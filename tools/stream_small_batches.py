@@ -37,5 +37,5 @@ for depth in (1, 2, 4):
         assert bad == 0
         best = max(best, nb / dt)
     out["in_flight_%d" % depth] = {"batches_per_s": best, "signatures_per_s": best * per}
-out["lanes"] = os.environ.get("LAMD_LANES", "2")
+out["lanes"] = os.environ.get("LAMD_LANES", "4 (default)")
 print(json.dumps(out))
