@@ -71,6 +71,10 @@ def ossl():
         L = ctypes.CDLL(_OSSL)
         L.ossl_ecdsa_verify.argtypes = [_u8p, _u8p, _u8p, ctypes.c_size_t]
         L.ossl_ecdsa_verify.restype = ctypes.c_int
+        L.ossl_schnorr_verify.argtypes = [_u8p, _u8p, _u8p]
+        L.ossl_schnorr_verify.restype = ctypes.c_int
+        L.ossl_ecdsa_recover.argtypes = [_u8p, _u8p, ctypes.c_int, _u8p]
+        L.ossl_ecdsa_recover.restype = ctypes.c_int
         _ossl = L
     return _ossl
 
@@ -173,3 +177,15 @@ def sigcheck_gossip_batch(msgs, off, ids, nthreads=1):
 
 def ossl_ecdsa_verify(hash32, sig64, pub):
     return ossl().ossl_ecdsa_verify(bytes(hash32), bytes(sig64), bytes(pub), len(pub))
+
+
+def ossl_schnorr_verify(msg32, xonly32, sig64):
+    return ossl().ossl_schnorr_verify(bytes(msg32), bytes(xonly32), bytes(sig64))
+
+
+def ossl_ecdsa_recover(hash32, sig64, recid):
+    """compressed key, None where the library calls would fail"""
+    out = ctypes.create_string_buffer(33)
+    rc = ossl().ossl_ecdsa_recover(bytes(hash32), bytes(sig64), int(recid), out)
+    assert rc >= 0
+    return out.raw if rc == 1 else None

@@ -15,7 +15,9 @@
  *  (2) the BIP-340 official vectors 0-14 (recalled offline; 0-4 self-authenticate by
  *      re-signing, 5-14 by their documented property),
  *  (3) the spec-level Python big-int model oracle/pyref.py on seeded random + edge rows,
- *  (4) OpenSSL's independent secp256k1 ECDSA (oracle/openssl_xcheck.c) on random rows.
+ *  (4) OpenSSL (oracle/openssl_xcheck.c): its own ECDSA verification, and for BIP-340 and public-key recovery a third
+ *      statement of the protocol over OpenSSL's generic curve arithmetic and SHA-256, on every golden vector and on
+ *      seeded random / damaged rows.
  * libsecp256k1's own edge semantics (not exercised by any in-tree reference test) are
  * therefore pinned by (2)-(4), not by the reference: see DESIGN.md "parity status".
  */
