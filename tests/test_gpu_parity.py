@@ -654,6 +654,19 @@ def test_recover_goldens_and_random(eng, kat, orc):
             e = pyref.ecdsa_recover(hs[i].tobytes(), sg[i].tobytes(), int(rid[i]))
             assert (keys[i].tobytes() if ok[i] else None) == (pyref.ser33(e) if e else None), (n, i)
     assert eng.ecdsa_recover(np.zeros((0, 32), np.uint8), np.zeros((0, 64), np.uint8), np.zeros(0, np.uint8))[1].shape == (0,)
+    # a few thousand rows against the OpenSSL-arithmetic restatement (independent of pyref and of the device code)
+    n = 4000
+    hs, sg, pk = _random_ecdsa(orc, rnd, n, 33)
+    sg = sg.copy()
+    sg[::9, 40] ^= 0x04
+    rid = np.array([rnd.randrange(2) for _ in range(n)], dtype=np.uint8)
+    keys, ok = eng.ecdsa_recover(hs, sg, rid)
+    hit = 0
+    for i in range(n):
+        e = orc.ossl_ecdsa_recover(hs[i].tobytes(), sg[i].tobytes(), int(rid[i]))
+        assert (keys[i].tobytes() if ok[i] else None) == e, i
+        hit += e == pk[i].tobytes()
+    assert 0.3 * n < hit < 0.7 * n                    # the signer's key comes back for about half of the random recovery ids
 
 
 def test_recover_then_verify_round_trip_full_size(eng):
