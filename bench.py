@@ -88,16 +88,32 @@ def main():
 
     tstream = torch.cuda.current_stream().cuda_stream
 
+    # multi-rank: verdicts alternate between two buffer pairs so that the all-gather of step k (on torch's stream, ordered
+    # after step k by a device-side event) can still be reading pair k%2 while step k+1 already writes the other pair; a
+    # pair is reused only after the gather that read it has finished (side stream + event, no host synchronisation)
+    ok_e = [we.d_ok, torch.zeros_like(we.d_ok)] if multi else [we.d_ok]
+    ok_s = [ws.d_ok, torch.zeros_like(ws.d_ok)] if multi else [ws.d_ok]
+    gathered = [None, None]
+    side = torch.cuda.Stream() if multi else None
+    stepno = [0]
+    eng.auto_order = False   # the inputs were generated and synchronised before the loop: no per-call ordering after torch's stream
+
     def step(record):
-        # no host synchronisation inside a step: successive calls alternate between the engine's two lanes, so the
-        # front end (key de-duplication, table building) of one batch runs under the ecmult kernel of the previous one
-        eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
-        eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
-        if multi:  # RCCL all-gather of the boolean result vectors over xGMI, ordered by events on the device
+        # no host synchronisation inside a step: successive calls rotate over the engine's lanes, so the front end (key
+        # de-duplication, table building) of one batch runs under the ecmult kernels of the batches before it
+        b = stepno[0] % len(ok_e)
+        stepno[0] += 1
+        if multi and gathered[b] is not None:
+            side.wait_event(gathered[b])
+            eng.wait_stream(side.cuda_stream)
+        eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], ok_e[b])
+        eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ok_s[b])
+        if multi:  # RCCL all-gather of the boolean result vectors over xGMI
             eng.stream_wait_results(tstream)
-            dist.all_gather_into_tensor(ok_all_e, we.d_ok)
-            dist.all_gather_into_tensor(ok_all_s, ws.d_ok)
-            eng.wait_stream(tstream)
+            dist.all_gather_into_tensor(ok_all_e, ok_e[b])
+            dist.all_gather_into_tensor(ok_all_s, ok_s[b])
+            gathered[b] = torch.cuda.Event()
+            gathered[b].record()
 
     def record_kernel_times():
         # HIP events recorded on the lanes' own streams around each kernel group of the LAST step inside the timed region
@@ -123,6 +139,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     record_kernel_times()
+    eng.auto_order = True
     # the same kernels once more, one call at a time (nothing else on the GPU): the isolated durations
     isolated = {"ecdsa": [], "schnorr": []}
     for _ in range(2):

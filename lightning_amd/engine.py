@@ -115,6 +115,8 @@ class Engine:
         """order the next submission after what torch's current stream holds (the tensors handed to the *_device methods are
         usually produced there); a device-side event, no host synchronisation.  The caller still has to keep the tensors alive
         until the results are complete."""
+        if not getattr(self, "auto_order", True):
+            return
         try:
             import torch
             self._chk(self._lib.lamd_wait_stream(self._ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
