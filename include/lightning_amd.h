@@ -42,6 +42,8 @@ enum {
 	LAMD_ERR_STATE = -5      /* streaming API misuse (poll before flush, queue full, ...) */
 };
 
+/* A context is NOT thread-safe: one per calling thread, or serialise the calls.  Every entry point returns a
+ * LAMD_ERR_* code (< 0) or a documented non-negative value; lamd_last_error() describes the last failure. */
 /* ---- lifecycle.  Replaces the process-global secp256k1_ctx set up in common/setup.c:58
  * (secp256k1_ctx = wally_get_secp_context(), common/utils.c:16): the one-time work here is the
  * upload/build of the static table of G multiples in HBM. */
