@@ -849,6 +849,7 @@ struct lamd_ctx {
   // next lane; the root context (the handle the caller holds) keeps its own stream for staging, queues, generators.
   lamd_ctx *lane[MAX_LANES] = {};
   int nlanes = 0;
+  u32 *h_counts = nullptr;  // pinned host words for the de-duplication counters' read-back
   lamd_ctx *peer = nullptr;
   lamd_ctx *last_lane = nullptr;
   lamd_ctx *last_chunk_lane = nullptr;  // where the last chunk of this lane's last call ran (itself or its peer)
@@ -912,6 +913,7 @@ static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+  HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, 64, hipHostMallocDefault));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
@@ -1052,6 +1054,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     if (qs.done) (void)hipEventDestroy(qs.done);
   }
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
+  if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
   if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
@@ -1221,7 +1224,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     const u32 min_uses = ctx->keyed_mode > 0 ? 2u : (u32)(ctx->keyed_min_uses + 0.5);
     hipLaunchKernelGGL(k_dedupe_classify, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
                        (const u32 *)ctx->kd_uniq.p, min_uses, counters, (u32 *)ctx->kd_hotidx.p, (u32 *)ctx->kd_hotrow.p);
-    u32 h[3] = {0, 0, 0};
+    u32 *h = ctx->h_counts;  // pinned: the copy is a plain DMA, no staging through a bounce buffer
     HIPCHK(ctx, hipMemcpyAsync(h, counters, 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->last_unique_keys = h[0];

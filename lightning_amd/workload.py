@@ -54,6 +54,7 @@ class Workload:
     def to_device(self, device):
         self.dev = [torch.from_numpy(c).to(device) for c in self.cols]
         self.d_ok = torch.zeros(self.n, dtype=torch.uint8, device=device)
+        torch.cuda.synchronize()   # uploads complete before any engine lane (own streams) may read them
         return self
 
 
@@ -181,6 +182,7 @@ def make_gossip(engine, n_cann, n_cupd, n_nodes=15000, seed=SEED_CFG4, corrupt_f
     w.d_rowbase = torch.from_numpy(rowbase.view(np.int64)).to(device)
     w.d_ids = d_ids
     w.d_verdict = torch.zeros(n, dtype=torch.int8, device=device)
+    torch.cuda.synchronize()   # the uploads above must have LANDED before an engine lane (its own stream) reads them
     return w
 
 
