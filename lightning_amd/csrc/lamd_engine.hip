@@ -869,7 +869,12 @@ struct lamd_ctx {
 
 static int ensure(lamd_ctx *ctx, devbuf *b, size_t bytes) {
   if (bytes <= b->cap) return LAMD_OK;
-  if (b->p) HIPCHK(ctx, hipFree(b->p));
+  // growing a workspace: an earlier, still running call of this context may be using the old one.  Do not rely on
+  // hipFree() waiting for other streams -- drain the device first (rare: sizes settle after the first calls).
+  if (b->p) {
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipFree(b->p));
+  }
   b->p = nullptr;
   b->cap = 0;
   size_t want = bytes + bytes / 4 + 4096;
