@@ -142,48 +142,6 @@ __global__ void __launch_bounds__(256) k_recover_final(size_t n, u32 *__restrict
 }
 
 // ---- gossip: per message, double-SHA256 of the signed tail and expansion into (hash, sig, key) rows
-// SHA256(SHA256(m)) where the first `done` bytes of m (a multiple of 64) are already absorbed into st; p = the rest
-LAMD_HD void sha256d_finish(u32 st[8], const u8 *p, size_t len, size_t done, u8 out32[32]) {
-  u32 w[16];
-  size_t off = 0;
-  for (; off + 64 <= len; off += 64) {
-    for (int i = 0; i < 16; i++) w[i] = load_be32(p + off + 4 * i);
-    sha256_compress(st, w);
-  }
-  const size_t rem = len - off;
-  for (int i = 0; i < 16; i++) {
-    u32 v = 0;
-    for (int b = 0; b < 4; b++) {
-      const size_t k = (size_t)i * 4 + b;
-      const u32 byte = k < rem ? p[off + k] : (k == rem ? 0x80u : 0u);
-      v = (v << 8) | byte;
-    }
-    w[i] = v;
-  }
-  if (rem >= 56) {
-    sha256_compress(st, w);
-    for (int i = 0; i < 16; i++) w[i] = 0;
-  }
-  w[14] = (u32)(((u64)(done + len) * 8) >> 32);
-  w[15] = (u32)((u64)(done + len) * 8);
-  sha256_compress(st, w);
-  // second hash over the 32-byte digest
-  for (int i = 0; i < 8; i++) w[i] = st[i];
-  w[8] = 0x80000000u;
-  for (int i = 9; i < 15; i++) w[i] = 0;
-  w[15] = 256;
-  u32 st2[8] = LAMD_SHA256_IV;
-  sha256_compress(st2, w);
-  for (int i = 0; i < 8; i++) {
-    out32[4 * i] = (u8)(st2[i] >> 24); out32[4 * i + 1] = (u8)(st2[i] >> 16);
-    out32[4 * i + 2] = (u8)(st2[i] >> 8); out32[4 * i + 3] = (u8)st2[i];
-  }
-}
-LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
-  u32 st[8] = LAMD_SHA256_IV;
-  sha256d_finish(st, p, len, 0, out32);
-}
-
 // ---- check_tx_sig batches: double-SHA256 of caller-built BIP143 preimages (bitcoin/signature.c:120-151 hashes them
 // through libwally) and the sighash-type gate of bitcoin/signature.c:206-211
 __global__ void __launch_bounds__(256) k_txsig_hash(size_t n, const u8 *__restrict__ pre, const u64 *__restrict__ off,
@@ -204,54 +162,13 @@ __global__ void __launch_bounds__(256) k_apply_gate(size_t n, const u8 *__restri
   if (i < n && !gate[i]) ok[i] = 0;
 }
 
-// ---- fee grind (onchaind/onchaind.c:388-438 grind_htlc_tx_fee): ONE signature and key, many candidate fees.  Every
-// candidate changes output 0's amount, hence hashOutputs, hence the sighash z -- but r, s and Q stay: with w = 1/s,
-// R = (z*w)*G + (r*w)*Q, so (r*w)*Q is computed once (k_grind_setup, the ordinary GLV ladder) and a candidate costs two
-// small double-SHA256, one scalar multiplication and the 12 G-table additions.
-constexpr int GRIND_MAX_OUTPUTS = 192;  // serialised outputs that go into hashOutputs (an HTLC tx has one 43-byte output)
-constexpr int GRIND_MAX_TAIL = 128;     // preimage bytes from the last 64-byte boundary before hashOutputs to the end
-struct grind_setup {
-  u32 valid;
-  u32 sinv[8], rw[8], px[8], py[8];  // 1/s, r, affine (r/s)*Q
-  u32 mid[8];                        // SHA-256 state after the preimage's leading whole blocks
-};
+// ---- fee grind (verify_core.h "fee grind"): one thread prepares, one thread per candidate feerate
 __global__ void __launch_bounds__(64) k_grind_setup(const u8 *__restrict__ sig64, const u8 *__restrict__ pub33,
                                                     const u8 *__restrict__ pre, u32 lead_blocks, u32 *__restrict__ slot,
                                                     const u32 *__restrict__ gtable, grind_setup *__restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   grind_setup g;
-  sc r, s;
-  bool ok;
-  ecdsa_load_rs(sig64, &r, &s, &ok);
-  u32 qx[8], qy[8];
-  ok &= parse_pubkey(pub33, 33, qx, qy);
-  g.valid = ok;
-  u32 st[8] = LAMD_SHA256_IV;
-  for (u32 b = 0; b < lead_blocks; b++) {
-    u32 w[16];
-    for (int i = 0; i < 16; i++) w[i] = load_be32(pre + 64 * (size_t)b + 4 * i);
-    sha256_compress(st, w);
-  }
-  for (int i = 0; i < 8; i++) { g.mid[i] = st[i]; g.sinv[i] = g.rw[i] = g.px[i] = g.py[i] = 0; }
-  if (ok) {
-    const sc sinv = sc_inv(s);
-    const sc u2 = sc_mul(r, sinv);
-    glv_half h1, h2;
-    glv_split(&h1, &h2, u2);
-    prep_rec rec;
-    for (int i = 0; i < 8; i++) rec.u1[i] = 0;
-    for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
-    rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
-    const gej P = ecmult_lane(rec, ge_from_words(qx, qy), slot, gtable);
-    if (P.inf) {
-      g.valid = 0;  // unreachable: r/s != 0 and Q has prime order
-    } else {
-      const fe zi = fe_inv(fe_norm_weak(P.z)), zi2 = fe_sqr(zi);
-      fe_to_words(g.px, fe_normalize(fe_mul(P.x, zi2)));
-      fe_to_words(g.py, fe_normalize(fe_mul(P.y, fe_mul(zi2, zi))));
-      for (int i = 0; i < 8; i++) { g.sinv[i] = sinv.w[i]; g.rw[i] = r.w[i]; }
-    }
-  }
+  grind_prepare(&g, sig64, pub33, pre, lead_blocks, slot, gtable);
   *out = g;
 }
 // candidate c = feerate min_rate + c; *best = the smallest matching c (0xFFFFFFFF: none)
@@ -261,38 +178,7 @@ __global__ void __launch_bounds__(256) k_grind(u32 ncand, u32 min_rate, u64 weig
                                                u32 *__restrict__ best) {
   const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncand || !setup->valid) return;
-  const u64 rate = (u64)min_rate + c;
-  const u64 fee = rate * weight / 1000;                                    // amount_tx_fee(), common/amount.c
-  if (c > 0 && (rate - 1) * weight / 1000 == fee) return;                  // "don't check same fee twice"
-  if (fee > input_sat) return;                                             // amount_sat_sub() fails: the reference stops here
-  const u64 amount = input_sat - fee;
-  u8 buf[GRIND_MAX_OUTPUTS > GRIND_MAX_TAIL ? GRIND_MAX_OUTPUTS : GRIND_MAX_TAIL];
-  u8 h[32];
-  for (u32 i = 0; i < outputs_len; i++) buf[i] = i < 8 ? (u8)(amount >> (8 * i)) : outputs[i];
-  sha256d_bytes(buf, outputs_len, h);                                      // hashOutputs
-  const u32 ho = tail_len - 40;                                            // ... sits 40 bytes before the end of the preimage
-  for (u32 i = 0; i < tail_len; i++) buf[i] = (i >= ho && i < ho + 32) ? h[i - ho] : tail[i];
-  u32 st[8];
-  for (int i = 0; i < 8; i++) st[i] = setup->mid[i];
-  sha256d_finish(st, buf, tail_len, lead_bytes, h);                        // the sighash
-  u32 zw[8];
-  load_words_be(zw, h);
-  sc sinv;
-  for (int i = 0; i < 8; i++) sinv.w[i] = setup->sinv[i];
-  const sc u1 = sc_mul(sc_from_words(zw, nullptr), sinv);
-  u32 rw[8], pw[16];
-  for (int i = 0; i < 8; i++) { rw[i] = setup->rw[i]; pw[i] = setup->px[i]; pw[8 + i] = setup->py[i]; }
-  gej acc = gej_from_ge(ge_from_words(pw, pw + 8));
-#pragma unroll 1
-  for (int w = 0; w < GTABLE_WINDOWS; w++) {
-    const u32 d = gtable_digit(u1.w, w);
-    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
-    ge pt;
-    pt.x = slot_load_fe(e);
-    pt.y = slot_load_fe(e + 8);
-    acc = gej_add_ge(acc, pt, d == 0);
-  }
-  if (ecdsa_final(acc, rw)) atomicMin(best, c);
+  if (grind_candidate(c, min_rate, weight, input_sat, tail, tail_len, lead_bytes, outputs, outputs_len, *setup, gtable)) atomicMin(best, c);
 }
 
 enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };

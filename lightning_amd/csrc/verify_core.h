@@ -694,6 +694,134 @@ LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *sl
   }
 }
 
+// ---- double SHA-256 over byte strings (gossip tails, BIP143 preimages: bitcoin/shadouble.c:7-11)
+// SHA256(SHA256(m)) where the first `done` bytes of m (a multiple of 64) are already absorbed into st; p = the rest
+LAMD_HD void sha256d_finish(u32 st[8], const u8 *p, size_t len, size_t done, u8 out32[32]) {
+  u32 w[16];
+  size_t off = 0;
+  for (; off + 64 <= len; off += 64) {
+    for (int i = 0; i < 16; i++) w[i] = load_be32(p + off + 4 * i);
+    sha256_compress(st, w);
+  }
+  const size_t rem = len - off;
+  for (int i = 0; i < 16; i++) {
+    u32 v = 0;
+    for (int b = 0; b < 4; b++) {
+      const size_t k = (size_t)i * 4 + b;
+      const u32 byte = k < rem ? p[off + k] : (k == rem ? 0x80u : 0u);
+      v = (v << 8) | byte;
+    }
+    w[i] = v;
+  }
+  if (rem >= 56) {
+    sha256_compress(st, w);
+    for (int i = 0; i < 16; i++) w[i] = 0;
+  }
+  w[14] = (u32)(((u64)(done + len) * 8) >> 32);
+  w[15] = (u32)((u64)(done + len) * 8);
+  sha256_compress(st, w);
+  // second hash over the 32-byte digest
+  for (int i = 0; i < 8; i++) w[i] = st[i];
+  w[8] = 0x80000000u;
+  for (int i = 9; i < 15; i++) w[i] = 0;
+  w[15] = 256;
+  u32 st2[8] = LAMD_SHA256_IV;
+  sha256_compress(st2, w);
+  for (int i = 0; i < 8; i++) {
+    out32[4 * i] = (u8)(st2[i] >> 24); out32[4 * i + 1] = (u8)(st2[i] >> 16);
+    out32[4 * i + 2] = (u8)(st2[i] >> 8); out32[4 * i + 3] = (u8)st2[i];
+  }
+}
+LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
+  u32 st[8] = LAMD_SHA256_IV;
+  sha256d_finish(st, p, len, 0, out32);
+}
+
+
+// ---- fee grind (onchaind/onchaind.c:388-438 grind_htlc_tx_fee): ONE signature and key, many candidate fees.  Every
+// candidate changes output 0's amount, hence hashOutputs, hence the sighash z -- but r, s and Q stay: with w = 1/s,
+// R = (z*w)*G + (r*w)*Q, so (r*w)*Q is computed once (grind_prepare, the ordinary GLV ladder) and a candidate costs two
+// small double-SHA256, one scalar multiplication and the G-table additions.
+constexpr int GRIND_MAX_OUTPUTS = 192;  // serialised outputs that go into hashOutputs (an HTLC tx has one 43-byte output)
+constexpr int GRIND_MAX_TAIL = 128;     // preimage bytes from the last 64-byte boundary before hashOutputs to the end
+struct grind_setup {
+  u32 valid;
+  u32 sinv[8], rw[8], px[8], py[8];  // 1/s, r, affine (r/s)*Q
+  u32 mid[8];                        // SHA-256 state after the preimage's leading whole blocks
+};
+LAMD_HD void grind_prepare(grind_setup *out, const u8 *sig64, const u8 *pub33, const u8 *pre, u32 lead_blocks, u32 *slot, const u32 *gtable) {
+  grind_setup g;
+  sc r, s;
+  bool ok;
+  ecdsa_load_rs(sig64, &r, &s, &ok);
+  u32 qx[8], qy[8];
+  ok &= parse_pubkey(pub33, 33, qx, qy);
+  g.valid = ok;
+  u32 st[8] = LAMD_SHA256_IV;
+  for (u32 b = 0; b < lead_blocks; b++) {
+    u32 w[16];
+    for (int i = 0; i < 16; i++) w[i] = load_be32(pre + 64 * (size_t)b + 4 * i);
+    sha256_compress(st, w);
+  }
+  for (int i = 0; i < 8; i++) { g.mid[i] = st[i]; g.sinv[i] = g.rw[i] = g.px[i] = g.py[i] = 0; }
+  if (ok) {
+    const sc sinv = sc_inv(s);
+    const sc u2 = sc_mul(r, sinv);
+    glv_half h1, h2;
+    glv_split(&h1, &h2, u2);
+    prep_rec rec;
+    for (int i = 0; i < 8; i++) rec.u1[i] = 0;
+    for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
+    rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
+    const gej P = ecmult_lane(rec, ge_from_words(qx, qy), slot, gtable);
+    if (P.inf) {
+      g.valid = 0;  // unreachable: r/s != 0 and Q has prime order
+    } else {
+      const fe zi = fe_inv(fe_norm_weak(P.z)), zi2 = fe_sqr(zi);
+      fe_to_words(g.px, fe_normalize(fe_mul(P.x, zi2)));
+      fe_to_words(g.py, fe_normalize(fe_mul(P.y, fe_mul(zi2, zi))));
+      for (int i = 0; i < 8; i++) { g.sinv[i] = sinv.w[i]; g.rw[i] = r.w[i]; }
+    }
+  }
+  *out = g;
+}
+// does candidate c (feerate min_rate + c) verify?  false also for the candidates the reference's loop never checks
+LAMD_HD bool grind_candidate(u32 c, u32 min_rate, u64 weight, u64 input_sat, const u8 *tail, u32 tail_len, u32 lead_bytes,
+                             const u8 *outputs, u32 outputs_len, const grind_setup &setup, const u32 *gtable) {
+  const u64 rate = (u64)min_rate + c;
+  const u64 fee = rate * weight / 1000;                                    // amount_tx_fee(), common/amount.c:698-707
+  if (c > 0 && (rate - 1) * weight / 1000 == fee) return false;            // "don't check same fee twice"
+  if (fee > input_sat) return false;                                       // amount_sat_sub() fails: the reference stops here
+  const u64 amount = input_sat - fee;
+  u8 buf[GRIND_MAX_OUTPUTS > GRIND_MAX_TAIL ? GRIND_MAX_OUTPUTS : GRIND_MAX_TAIL];
+  u8 h[32];
+  for (u32 i = 0; i < outputs_len; i++) buf[i] = i < 8 ? (u8)(amount >> (8 * i)) : outputs[i];
+  sha256d_bytes(buf, outputs_len, h);                                      // hashOutputs
+  const u32 ho = tail_len - 40;                                            // ... sits 40 bytes before the end of the preimage
+  for (u32 i = 0; i < tail_len; i++) buf[i] = (i >= ho && i < ho + 32) ? h[i - ho] : tail[i];
+  u32 st[8];
+  for (int i = 0; i < 8; i++) st[i] = setup.mid[i];
+  sha256d_finish(st, buf, tail_len, lead_bytes, h);                        // the sighash
+  u32 zw[8];
+  load_words_be(zw, h);
+  sc sinv;
+  for (int i = 0; i < 8; i++) sinv.w[i] = setup.sinv[i];
+  const sc u1 = sc_mul(sc_from_words(zw, nullptr), sinv);
+  u32 rw[8], pw[16];
+  for (int i = 0; i < 8; i++) { rw[i] = setup.rw[i]; pw[i] = setup.px[i]; pw[8 + i] = setup.py[i]; }
+  gej acc = gej_from_ge(ge_from_words(pw, pw + 8));
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = gtable_digit(u1.w, w);
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    ge pt;
+    pt.x = slot_load_fe(e);
+    pt.y = slot_load_fe(e + 8);
+    acc = gej_add_ge(acc, pt, d == 0);
+  }
+  return ecdsa_final(acc, rw);
+}
+
 // ---- ECDSA public-key recovery (secp256k1_ecdsa_recover as reached from common/bolt11.c:1041-1046 and
 // lightningd/signmessage.c:193): Q = (s/r)*R - (z/r)*G with R = the point whose x is r (+ n when recid & 2) and whose y
 // has parity recid & 1.  It is the verification ecmult with (u1, u2, key) = (-z/r, s/r, R): the prep below writes the same

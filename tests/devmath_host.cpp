@@ -208,6 +208,26 @@ void dm_recover_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8 *rec
   }
   for (size_t t = 0; t < threads; t++) recover_final_thread(t, threads, n, slots.data(), ok, pub33);
 }
+// fee grind as the engine stages it (lamd_grind_htlc_tx_fee): prepare once, then every candidate feerate; returns 1 and the
+// lowest matching feerate / its fee, or 0
+int dm_grind(const u8 *pre, size_t pre_len, const u8 *outputs, size_t outputs_len, uint64_t input_sat, uint64_t weight, u32 min_rate,
+             u32 max_rate, const u8 *sig64, int sighash_type, int has_witness, const u8 *pub33, u32 *rate_out, uint64_t *fee_out) {
+  dm_init();
+  if (!(sighash_type == 1 || (sighash_type == 0x83 && has_witness))) return 0;
+  if (max_rate < min_rate) return 0;
+  const size_t lead = ((pre_len - 40) / 64) * 64, tail_len = pre_len - lead;
+  std::vector<u32> slot(SLOT_WORDS);
+  grind_setup g;
+  grind_prepare(&g, sig64, pub33, pre, (u32)(lead / 64), slot.data(), g_table.data());
+  if (!g.valid) return 0;
+  for (u32 c = 0; c <= max_rate - min_rate; c++)
+    if (grind_candidate(c, min_rate, weight, input_sat, pre + lead, (u32)tail_len, (u32)lead, outputs, (u32)outputs_len, g, g_table.data())) {
+      *rate_out = min_rate + c;
+      *fee_out = (uint64_t)(min_rate + c) * weight / 1000;
+      return 1;
+    }
+  return 0;
+}
 // two-stage form exactly as the kernels run it (shared inversion over `threads` owners)
 void dm_schnorr_verify_batch2(size_t n, const u8 *msg32, const u8 *pk32, const u8 *sig64, u8 *out, size_t threads) {
   dm_init();

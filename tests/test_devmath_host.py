@@ -419,3 +419,47 @@ def test_recover_goldens_host(dm, kat):
     for i, v in enumerate(rows):
         got = pub.raw[33 * i:33 * i + 33].hex() if ok.raw[i] else None
         assert got == v["expect"], v["name"]
+
+
+def _host_grind(dm, pre, outputs, input_sat, weight, lo, hi, sig, stype, wit, pub):
+    rate, fee = ctypes.c_uint32(0), ctypes.c_uint64(0)
+    dm.dm_grind.restype = ctypes.c_int
+    rc = dm.dm_grind(bytes(pre), ctypes.c_size_t(len(pre)), bytes(outputs), ctypes.c_size_t(len(outputs)), ctypes.c_uint64(input_sat),
+                     ctypes.c_uint64(weight), ctypes.c_uint32(lo), ctypes.c_uint32(hi), bytes(sig), int(stype), int(wit), bytes(pub),
+                     ctypes.byref(rate), ctypes.byref(fee))
+    return (rate.value, fee.value) if rc == 1 else None
+
+
+def test_fee_grind_host_build_vs_reference_kat_and_restated_loop(dm, kat, orc):
+    """the device code of the fee grind (grind_prepare / grind_candidate, compiled for the host) against the reference's own
+    known answer (onchaind/test/run-grind_feerate.c: fee 165 750 at feerate 250 000) and against the restated loop on seeded cases"""
+    ko = next(v for v in kat["der"] if v["name"] == "KAT-O")
+    sig = H(ko["expect_sig"])
+    key = H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f")
+    pre = H(next(v for v in kat["bip143"] if v["name"] == "KAT-O/fee=0")["preimage"])
+    spk = H("002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d6192743604179")
+    outputs = (700000).to_bytes(8, "little") + bytes([len(spk)]) + spk
+    assert _host_grind(dm, pre, outputs, 700000, 663, 249800, 250000, sig, 1, True, key) == (250000, 165750)
+    assert _host_grind(dm, pre, outputs, 700000, 663, 250001, 250001, sig, 1, True, key) == (250001, 165750)
+    assert _host_grind(dm, pre, outputs, 700000, 663, 249800, 249998, sig, 1, True, key) is None
+    assert _host_grind(dm, pre, outputs, 700000, 663, 249800, 250000, sig, 0x83, False, key) is None
+    rnd = random.Random(99)
+    ver = lambda h, s, k: orc.ecdsa_verify(h, s, k)
+    for case in range(8):
+        sk = rnd.randrange(1, N).to_bytes(32, "big")
+        pub = pyref.ser33(pyref.pubkey_create(int.from_bytes(sk, "big")))
+        script = bytes(rnd.randrange(256) for _ in range(rnd.choice((1, 25, 133, 200))))
+        spk = bytes([0, 32]) + bytes(rnd.randrange(256) for _ in range(32))
+        input_sat = rnd.randrange(50_000, 5_000_000)
+        weight = rnd.choice((663, 703, 1000, 1))
+        lo = rnd.randrange(0, 30_000)
+        hi = lo + rnd.randrange(0, 300)
+        hidden = rnd.randrange(max(0, lo - 20), hi + 20)
+        fee = hidden * weight // 1000
+        amount = max(0, input_sat - fee)
+        stype = 0x83 if case % 3 == 0 else 1
+        sighash, pre = pyref.bip143_sighash(2, [(bytes(rnd.randrange(256) for _ in range(32)), 1, 0)], [(amount, spk)], 500000 + case, 0, script, input_sat, stype)
+        sig = orc.ecdsa_sign(sighash, sk, bytes(rnd.randrange(256) for _ in range(32)))
+        outputs = amount.to_bytes(8, "little") + bytes([len(spk)]) + spk
+        exp = pyref.grind_htlc_tx_fee(pre, outputs, input_sat, weight, lo, hi, sig, stype, True, pub, verify=ver)
+        assert _host_grind(dm, pre, outputs, input_sat, weight, lo, hi, sig, stype, True, pub) == exp, case
