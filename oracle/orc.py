@@ -40,6 +40,7 @@ def lib():
             "orc_sigcheck_channel_announcement": [_u8p, ctypes.c_size_t],
             "orc_sigcheck_channel_update": [_u8p, ctypes.c_size_t, _u8p],
             "orc_sigcheck_node_announcement": [_u8p, ctypes.c_size_t],
+            "orc_ecdsa_recover": [_u8p, _u8p, ctypes.c_int, _u8p],
             "orc_pubkey_create": [_u8p, _u8p],
             "orc_ecdsa_sign": [_u8p, _u8p, _u8p, _u8p],
             "orc_schnorr_sign": [_u8p, _u8p, _u8p, _u8p],
@@ -59,6 +60,9 @@ def lib():
         L.orc_schnorr_verify_batch.restype = None
         L.orc_sigcheck_gossip_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.orc_sigcheck_gossip_batch.restype = None
+        L.orc_ecdsa_recover_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+        L.orc_ecdsa_recover_batch.restype = None
         L.orc_init()
         _lib = L
     return _lib
@@ -189,3 +193,20 @@ def ossl_ecdsa_recover(hash32, sig64, recid):
     rc = ossl().ossl_ecdsa_recover(bytes(hash32), bytes(sig64), int(recid), out)
     assert rc >= 0
     return out.raw if rc == 1 else None
+
+
+def ecdsa_recover(hash32, sig64, recid):
+    """compressed key or None (C oracle)"""
+    out = ctypes.create_string_buffer(33)
+    return out.raw if lib().orc_ecdsa_recover(bytes(hash32), bytes(sig64), int(recid), out) else None
+
+
+def ecdsa_recover_batch(hashes, sigs, recids, nthreads=1):
+    """numpy uint8 [n,32], [n,64], [n] -> (keys uint8 [n,33], ok uint8 [n])"""
+    import numpy as np
+    n = hashes.shape[0]
+    keys = np.zeros((n, 33), dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    recids = np.ascontiguousarray(recids, dtype=np.uint8)
+    lib().orc_ecdsa_recover_batch(n, hashes.ctypes.data, sigs.ctypes.data, recids.ctypes.data, keys.ctypes.data, ok.ctypes.data, nthreads)
+    return keys, ok

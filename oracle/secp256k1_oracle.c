@@ -654,6 +654,51 @@ int orc_schnorr_verify(const uint8_t msg32[32], const uint8_t xonly32[32], const
 	return u256_cmp(&Ra.x, &rx) == 0;
 }
 
+/* secp256k1_ecdsa_recoverable_signature_parse_compact + secp256k1_ecdsa_recover as called at common/bolt11.c:1021-1046 and
+ * lightningd/signmessage.c:193 (SEC1 4.1.6): Q = (s/r)*R - (z/r)*G, R = the point with x = r (+ n if recid & 2) and
+ * y parity recid & 1.  Fails like the library: r or s >= n or zero, recid outside 0..3, r + n >= p, no such point, Q = inf.
+ * No low-S rule.  out33 = compressed Q. */
+int orc_ecdsa_recover(const uint8_t hash32[32], const uint8_t sig64[64], int recid, uint8_t out33[33])
+{
+	sc r, s, z, ri, u1, u2;
+	u256 x;
+	uint8_t k33[33];
+	ge R, Qa;
+	gej Q;
+	memset(out33, 0, 33);
+	if (recid < 0 || recid > 3) return 0;
+	if (sc_from_be(&r, sig64) || sc_from_be(&s, sig64 + 32)) return 0;
+	if (u256_is_zero(&r) || u256_is_zero(&s)) return 0;
+	x = r;
+	if (recid & 2) {
+		if (u256_add(&x, &r, &SC_N)) return 0;
+		if (u256_cmp(&x, &FE_P) >= 0) return 0;
+	}
+	k33[0] = (uint8_t)(2 + (recid & 1));
+	u256_to_be(k33 + 1, &x);
+	if (!pubkey_parse_ge(&R, k33, 33)) return 0;
+	sc_from_be(&z, hash32);
+	sc_inv(&ri, &r);
+	sc_mul(&u1, &z, &ri);
+	sc_neg(&u1, &u1);
+	sc_mul(&u2, &s, &ri);
+	ecmult(&Q, &u1, &u2, &R);
+	if (Q.inf) return 0;
+	ge_set_gej(&Qa, &Q);
+	out33[0] = (uint8_t)(2 + (Qa.y.d[0] & 1));
+	u256_to_be(out33 + 1, &Qa.x);
+	return 1;
+}
+void orc_ecdsa_recover_batch(size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *recid, uint8_t *pub33,
+			     uint8_t *ok, int nthreads)
+{
+	orc_init();
+	long i;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
+	for (i = 0; i < (long)n; i++)
+		ok[i] = (uint8_t)orc_ecdsa_recover(hash32 + 32 * i, sig64 + 64 * i, recid[i], pub33 + 33 * i);
+}
+
 /* ------------------------------------------------------------------ gossip veneer */
 int orc_sigcheck_channel_announcement(const uint8_t *msg, size_t len)
 {

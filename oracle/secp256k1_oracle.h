@@ -61,6 +61,12 @@ int orc_ecdsa_verify(const uint8_t hash32[32], const uint8_t sig64[64],
 int orc_schnorr_verify(const uint8_t msg32[32], const uint8_t xonly32[32],
 		       const uint8_t sig64[64]);
 
+/* secp256k1_ecdsa_recoverable_signature_parse_compact + secp256k1_ecdsa_recover (common/bolt11.c:1021-1046,
+ * lightningd/signmessage.c:193): 1 and the compressed key, or 0 (and a zeroed key) where the library calls fail */
+int orc_ecdsa_recover(const uint8_t hash32[32], const uint8_t sig64[64], int recid, uint8_t out33[33]);
+void orc_ecdsa_recover_batch(size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *recid, uint8_t *pub33,
+			     uint8_t *ok, int nthreads);
+
 /* gossipd/sigcheck.c on raw wire messages.  Return 0 = OK (reference returns NULL),
  * k>0 = the k-th signature is the first bad one (channel_announcement: 1 node_signature_1,
  * 2 node_signature_2, 3 bitcoin_signature_1, 4 bitcoin_signature_2; others: 1),

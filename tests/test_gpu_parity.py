@@ -667,6 +667,16 @@ def test_recover_goldens_and_random(eng, kat, orc):
         assert (keys[i].tobytes() if ok[i] else None) == e, i
         hit += e == pk[i].tobytes()
     assert 0.3 * n < hit < 0.7 * n                    # the signer's key comes back for about half of the random recovery ids
+    # and 60 000 rows against the C oracle's batch driver
+    n = 60000
+    hs, sg, pk = _random_ecdsa(orc, rnd, 2000, 33)
+    hs, sg = np.tile(hs, (30, 1)), np.tile(sg, (30, 1))
+    tw = np.frombuffer(bytes(rnd.randrange(256) for _ in range(n)), dtype=np.uint8)
+    hs = hs.copy(); hs[:, 7] ^= tw                    # 60 000 distinct hashes under 2 000 signatures: all recover SOME key
+    rid = (tw & 3).astype(np.uint8) % 2
+    keys, ok = eng.ecdsa_recover(hs, sg, rid)
+    ck, cok = orc.ecdsa_recover_batch(np.ascontiguousarray(hs), np.ascontiguousarray(sg), rid, 8)
+    assert np.array_equal(ok, cok.astype(bool)) and np.array_equal(keys, ck) and ok.sum() > 0.4 * n
 
 
 def test_recover_then_verify_round_trip_full_size(eng):
