@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=1_000_000, help="rows per kind per rank (1 M = BASELINE configs[1], [2])")
-    ap.add_argument("--cpu-sample", type=int, default=200_000, help="rows per kind timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows per kind timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--skip-extra", action="store_true", help="skip the cfg4/cfg5 single-GPU data points")
     args = ap.parse_args()
