@@ -8,7 +8,7 @@ when the timed region starts; every rank processes its own 2 M-row batch (weak s
 data-path collective); with more than one rank the verdict vectors are all-gathered over RCCL
 inside the timed region, as the north star asks.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py                       # = --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
