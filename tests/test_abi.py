@@ -50,3 +50,16 @@ def test_product_never_touches_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("isomorphic", ""), os.path.join(dp, f)
                 assert "pyref" not in txt
+
+
+def test_generated_fe_asm_is_current():
+    """lightning_amd/csrc/fe_asm.inc is generated: it must be exactly what tools/gen_fe_asm.py writes, and must hold the
+    multiply-add counts fe.h documents (97 per multiplication, 61 per squaring)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "gen_fe_asm.py")]).decode()
+    cur = open(os.path.join(root, "lightning_amd", "csrc", "fe_asm.inc")).read()
+    assert out == cur
+    mul, sqr = cur.split("#define LAMD_FE_SQR_ASM")[0], cur.split("#define LAMD_FE_SQR_ASM")[1]
+    assert mul.count("v_mad_u64_u32 v[") == 97 and sqr.count("v_mad_u64_u32 v[") == 61
