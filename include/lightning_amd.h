@@ -163,6 +163,8 @@ int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg
  * next set, so queueing continues while flushes are in flight: up to 5 flushes may be outstanding (LAMD_ERR_STATE beyond
  * that, until one is collected), successive flushes run on alternating lanes.  poll/wait return the verdicts of the
  * OLDEST outstanding flush, in submission (ticket) order. */
+/* A ticket is the position of the triple's verdict in the vector its flush returns: tickets count 0, 1, 2, ... across
+ * the kinds inside the open staging set and restart at 0 after every lamd_flush() (fewer than 2^30 triples per flush). */
 int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
 		     const uint8_t *pubkey, size_t publen); /* returns the ticket (>= 0) or an error */
 int lamd_queue_schnorr(lamd_ctx *ctx, const uint8_t msg32[32], const uint8_t xonly32[32],
@@ -195,27 +197,8 @@ int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys
 int lamd_gen_gossip_device(lamd_ctx *ctx, size_t n_cann, size_t n_cupd, uint64_t seed, size_t n_nodes,
 			   void *d_msgs, void *d_node_ids33);
 
-/* ---- device self-test: evaluates every arithmetic primitive and one full ECDSA verification of
- * the given triple both on the GPU and with the same code on the host, stage by stage.
- * Returns 0 if every stage agrees, else a bit mask of disagreeing stages (report names them),
- * or < 0 on engine error.  Diagnostic only; never used to produce a verdict. */
-int lamd_selftest(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
-		  const uint8_t pub33[33], char *report, size_t cap);
-
-/* Diagnostic: a 300-step dependent chain of field squarings (use_mul = 0) or multiplications on
- * the device, every step re-executed on the host from the device's own input limbs.  Returns the
- * number of disagreeing steps (0 = healthy), report describes the first few. */
-int lamd_chain_debug(lamd_ctx *ctx, int use_mul, char *report, size_t cap);
-
-/* Diagnostic: every intermediate of the field inversion / square-root addition chains, device vs host. */
-int lamd_inv_debug(lamd_ctx *ctx, char *report, size_t cap);
-
-int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 in several code shapes */
-
-/* Diagnostic: copy nbytes at offset of internal work buffer `which` (0 prep records, 1 per-row key validity,
- * 2 dedupe representative, 3 dedupe uid, 4 key id per row, 5 first row of each distinct key, 6 distinct-key
- * validity, 7 distinct-key affine words, 8 key tables) to host memory.  Tests only. */
-int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out);
+/* Diagnostics (device self-test, arithmetic fuzzers, work-buffer peeks) live in lightning_amd_debug.h: they are exported by the
+ * same library but are not part of the drop-in boundary. */
 
 /* ---- introspection for benchmarks / tests */
 typedef struct {

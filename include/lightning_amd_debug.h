@@ -1,0 +1,45 @@
+/* lightning_amd -- diagnostics exported by liblightning_amd.so next to the product ABI (include/lightning_amd.h).
+ * None of these produces a verdict; tests and bring-up tooling use them to localise a miscompile or a hardware
+ * difference to one primitive (DESIGN.md "toolchain notes"). */
+#ifndef LIGHTNING_AMD_DEBUG_H
+#define LIGHTNING_AMD_DEBUG_H
+#include "lightning_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device self-test: evaluates every arithmetic primitive and one full ECDSA verification of
+ * the given triple both on the GPU and with the same code on the host, stage by stage.
+ * Returns 0 if every stage agrees, else a bit mask of disagreeing stages (report names them),
+ * or < 0 on engine error.  Diagnostic only; never used to produce a verdict. */
+int lamd_selftest(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64],
+		  const uint8_t pub33[33], char *report, size_t cap);
+
+/* Diagnostic: a 300-step dependent chain of field squarings (use_mul = 0) or multiplications on
+ * the device, every step re-executed on the host from the device's own input limbs.  Returns the
+ * number of disagreeing steps (0 = healthy), report describes the first few. */
+int lamd_chain_debug(lamd_ctx *ctx, int use_mul, char *report, size_t cap);
+
+/* Diagnostic: every intermediate of the field inversion / square-root addition chains, device vs host. */
+int lamd_inv_debug(lamd_ctx *ctx, char *report, size_t cap);
+
+int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 in several code shapes */
+
+/* Diagnostic: copy nbytes at offset of internal work buffer `which` (0 prep records, 1 per-row key validity,
+ * 2 dedupe representative, 3 dedupe uid, 4 key id per row, 5 first row of each distinct key, 6 distinct-key
+ * validity, 7 distinct-key affine words, 8 key tables) to host memory.  Tests only. */
+int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out);
+
+/* Randomised arithmetic fuzz ON THE DEVICE: `lanes` lanes x `iters` iterations; every iteration draws operands at the
+ * magnitude limits the group law uses (limbs up to 7 x 2^29, a fifth of them exactly at the bound) and runs fe_mul in
+ * every legal magnitude pairing, fe_sqr, the lazy add/neg/normalisations, gej_double and the mixed addition with live
+ * values carried across iterations, folding every raw result limb into a per-lane checksum.  The host pass of the same
+ * inline functions recomputes every checksum.  Returns the number of lanes whose checksums differ (0 = healthy);
+ * *ops (may be NULL) = field multiplications + squarings executed on the device. */
+int lamd_fuzz_field(lamd_ctx *ctx, size_t lanes, int iters, uint64_t seed, uint64_t *ops, char *report, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTNING_AMD_DEBUG_H */

@@ -6,8 +6,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "liblightning_amd.so")
-SOURCES = [os.path.join(CSRC, f) for f in ("lamd_engine.hip", "verify_core.h", "group.h", "fe.h", "scalar.h", "sha256.h", "lamd_common.h")] + [
-    os.path.join(ROOT, "include", "lightning_amd.h")]
+SOURCES = [os.path.join(CSRC, f) for f in ("lamd_engine.hip", "verify_core.h", "group.h", "fe.h", "fe_asm.inc", "fuzz.h", "scalar.h", "sha256.h",
+                                           "lamd_common.h")] + [
+    os.path.join(ROOT, "include", "lightning_amd.h"), os.path.join(ROOT, "include", "lightning_amd_debug.h")]
 
 
 SHIM = os.path.join(PKG, "liblightning_amd_cln.so")

@@ -14,7 +14,7 @@ class LamdInfo(ctypes.Structure):
                 ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int), ("last_mode", ctypes.c_int), ("lanes", ctypes.c_int)]
 
 
-# name -> (restype, argtypes); every symbol of include/lightning_amd.h
+# name -> (restype, argtypes); every symbol of include/lightning_amd.h and include/lightning_amd_debug.h
 SYMBOLS = {
     "lamd_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
     "lamd_shutdown": (None, [ctypes.c_void_p]),
@@ -53,6 +53,7 @@ SYMBOLS = {
     "lamd_inv_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_x2_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_debug_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_sz, c_sz, c_u8p]),
+    "lamd_fuzz_field": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, c_sz]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_get_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LamdInfo)]),

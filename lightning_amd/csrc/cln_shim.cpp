@@ -269,7 +269,7 @@ static const char *dup(const std::string &s) {
 }
 static std::string bad(const char *what, const secp256k1_ecdsa_signature *sig, const u8 *msg, size_t len, size_t off, const char *kind) {
   struct sha256_double h;
-  sha256_double(&h, msg + off, len - off);
+  sha256_double(&h, msg + (off < len ? off : len), off < len ? len - off : 0);
   return std::string(what) + " " + der_hex(sig) + " hash " + hex(h.sha.u.u8, 32) + " on " + kind + " " + hex(msg, len);
 }
 // runs the raw message through the device path; the typed arguments (already parsed by the caller, as in the
@@ -287,6 +287,7 @@ extern "C" const char *sigcheck_channel_update(const tal_t *, const struct node_
   const int v = device_verdict(update, len, node_id);
   if (v == 0) return nullptr;
   if (v == -2) return dup("engine error: " + g_err);
+  if (v == -1) return dup(std::string("malformed channel_update ") + hex(update, len));  // fromwire_* would have failed earlier
   return dup(bad("Bad signature for", node_sig, update, len, 66, "channel_update"));
 }
 extern "C" const char *sigcheck_channel_announcement(const tal_t *, const struct node_id *, const struct node_id *, const struct pubkey *,
@@ -306,5 +307,6 @@ extern "C" const char *sigcheck_node_announcement(const tal_t *, const struct no
   const int v = device_verdict(node_announcement, len, nullptr);
   if (v == 0) return nullptr;
   if (v == -2) return dup("engine error: " + g_err);
+  if (v == -1) return dup(std::string("malformed node_announcement ") + hex(node_announcement, len));
   return dup(bad("Bad signature for", node_sig, node_announcement, len, 66, "node_announcement"));
 }

@@ -11,7 +11,9 @@
 #include <vector>
 
 #include "../../include/lightning_amd.h"
+#include "../../include/lightning_amd_debug.h"
 #include "verify_core.h"
+#include "fuzz.h"
 
 using namespace lamd;
 
@@ -181,8 +183,6 @@ __global__ void __launch_bounds__(256) k_grind(u32 ncand, u32 min_rate, u64 weig
   if (grind_candidate(c, min_rate, weight, input_sat, tail, tail_len, lead_bytes, outputs, outputs_len, *setup, gtable)) atomicMin(best, c);
 }
 
-enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };
-
 // rowbase[i] = index of message i's first signature row; malformed[i] set here for framing errors
 __global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
                                                        const u8 *__restrict__ node_ids, const u64 *__restrict__ rowbase,
@@ -194,29 +194,10 @@ __global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__res
   const size_t len = off[i + 1] - off[i];
   const size_t row = rowbase[i];
   const size_t nrows = rowbase[i + 1] - row;
-  bool bad = len < 2;
-  const u32 type = bad ? 0 : (((u32)m[0] << 8) | m[1]);
-  size_t signed_off = 66, keyoff = 0;
-  if (type == GOSSIP_CANN) {
-    signed_off = 258;
-    bad |= len < 260;
-    if (!bad) {
-      const size_t flen = ((size_t)m[258] << 8) | m[259];
-      keyoff = 260 + flen + 32 + 8;
-      bad |= len < keyoff + 4 * 33;
-    }
-  } else if (type == GOSSIP_NANN) {
-    bad |= len < 68;
-    if (!bad) {
-      const size_t flen = ((size_t)m[66] << 8) | m[67];
-      keyoff = 68 + flen + 4;
-      bad |= len < keyoff + 33;
-    }
-  } else if (type == GOSSIP_CUPD) {
-    bad |= len < 66;
-  } else {
-    bad = true;
-  }
+  const gossip_frame fr = gossip_parse_frame(m, len);
+  bool bad = fr.bad;
+  const u32 type = fr.type;
+  const size_t signed_off = fr.signed_off, keyoff = fr.keyoff;
   u8 h[32];
   if (!bad) sha256d_bytes(m + signed_off, len - signed_off, h);
   for (size_t k = 0; k < nrows; k++) {
@@ -718,17 +699,17 @@ struct lamd_ctx {
   struct queue {
     u8 *h_a = nullptr, *h_b = nullptr, *h_c = nullptr, *h_ok = nullptr;  // hash/msg, sig, key, verdicts
     size_t cap = 0, n = 0;
-    std::vector<int> tickets;
+    std::vector<u32> tickets;  // position of each row in the verdict vector this staging set returns
     devbuf d_a, d_b, d_c, d_ok;
   };
   struct queue_set {
     queue q[Q_KINDS];
     hipEvent_t done = nullptr;
+    size_t rows = 0;  // triples queued into this set so far = the next ticket
   } qs[QUEUE_SETS];
   int q_open = 0;                 // the set being filled, -1 when every set is in flight
   int q_fifo[QUEUE_SETS] = {0};   // flushed sets, oldest first
   int q_inflight = 0;
-  int next_ticket = 0;
   // Lanes: the device-pointer entry points rotate over LAMD_LANES (default 4) complete sub-contexts (own streams and
   // workspaces, the G table shared), so that the latency-bound front end of one call (key de-duplication, the count
   // read-back, table building) runs under the VALU-bound ecmult kernels of the calls before it.  A lane's `peer` is the
@@ -1676,8 +1657,15 @@ static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *
     ctx->err = "queue: every staging set is in flight (collect a flush with poll/wait first)";
     return LAMD_ERR_STATE;
   }
-  lamd_ctx::queue &q = ctx->qs[ctx->q_open].q[kind];
+  lamd_ctx::queue_set &set = ctx->qs[ctx->q_open];
+  lamd_ctx::queue &q = set.q[kind];
   const size_t kb = Q_KEYBYTES[kind];
+  // tickets are positions inside the open staging set (they restart at 0 after every flush), so they never overflow and
+  // collect() needs no arithmetic across sets; a set holds fewer than 2^30 triples
+  if (set.rows + n > (size_t)0x3FFFFFFF) {
+    ctx->err = "queue: staging set full (flush first)";
+    return LAMD_ERR_STATE;
+  }
   const int rc = queue_reserve_n(ctx, q, kb, n);
   if (rc != LAMD_OK) return rc;
   memcpy(q.h_a + 32 * q.n, a, 32 * n);
@@ -1687,11 +1675,11 @@ static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *
   } else {
     for (size_t i = 0; i < n; i++) memcpy(q.h_c + kb * (q.n + i), key + keystride * i, kb);
   }
-  const int first = ctx->next_ticket;
-  for (size_t i = 0; i < n; i++) q.tickets.push_back(first + (int)i);
+  const size_t first = set.rows;
+  for (size_t i = 0; i < n; i++) q.tickets.push_back((u32)(first + i));
   q.n += n;
-  ctx->next_ticket += (int)n;
-  return first;
+  set.rows += n;
+  return (int)first;
 }
 extern "C" int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64], const uint8_t *pubkey,
                                 size_t publen) {
@@ -1764,22 +1752,17 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
 static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
   const int sidx = ctx->q_fifo[0];
   lamd_ctx::queue_set &qs = ctx->qs[sidx];
-  size_t total = 0;
-  int base = -1;
-  for (auto &q : qs.q)
-    for (size_t i = 0; i < q.n; i++) {
-      total++;
-      if (base < 0 || q.tickets[i] < base) base = q.tickets[i];
-    }
+  const size_t total = qs.rows;
   if (total > cap) {
     ctx->err = "result buffer too small";
     return LAMD_ERR_ARG;
   }
   for (auto &q : qs.q) {
-    for (size_t i = 0; i < q.n; i++) ok[q.tickets[i] - base] = q.h_ok[i];
+    for (size_t i = 0; i < q.n; i++) ok[q.tickets[i]] = q.h_ok[i];
     q.tickets.clear();
     q.n = 0;
   }
+  qs.rows = 0;
   if (n) *n = total;
   for (int k = 1; k < ctx->q_inflight; k++) ctx->q_fifo[k - 1] = ctx->q_fifo[k];
   ctx->q_inflight--;
@@ -2148,6 +2131,36 @@ extern "C" int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap) {
   }
   if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
   return mask;
+}
+
+// ---- randomised arithmetic fuzz (fuzz.h): the same inline function on the device and in this TU's host pass
+__global__ void __launch_bounds__(256) k_fuzz_field(size_t lanes, int iters, u64 seed, u64 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < lanes) out[i] = fuzz_lane(seed, i, iters);
+}
+extern "C" int lamd_fuzz_field(lamd_ctx *ctx, size_t lanes, int iters, uint64_t seed, uint64_t *ops, char *report, size_t cap) {
+  if (!ctx || lanes == 0 || lanes > ((size_t)1 << 24) || iters < 1 || iters > 100000) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  u64 *d_out = nullptr;
+  HIPCHK(ctx, hipMalloc(&d_out, lanes * 8));
+  hipLaunchKernelGGL(k_fuzz_field, dim3(blocks_for(lanes)), dim3(256), 0, ctx->stream, lanes, iters, (u64)seed, d_out);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<u64> got(lanes);
+  HIPCHK(ctx, hipMemcpyAsync(got.data(), d_out, lanes * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_out);
+  int nbad = 0;
+  std::string rep;
+  for (size_t i = 0; i < lanes; i++) {
+    const u64 exp = fuzz_lane(seed, i, iters);
+    if (exp != got[i]) {
+      if (nbad < 4) rep += "lane " + std::to_string(i) + " device " + std::to_string(got[i]) + " host " + std::to_string(exp) + "; ";
+      nbad++;
+    }
+  }
+  if (ops) *ops = (uint64_t)lanes * ((uint64_t)iters * FZ_OPS_PER_ITER + FZ_OPS_TAIL);
+  if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
+  return nbad;
 }
 
 // ---- diagnostic peek into the engine's device work buffers (tests / debugging only)

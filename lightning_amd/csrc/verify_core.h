@@ -738,6 +738,86 @@ LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
 }
 
 
+// ---- gossip framing: what fromwire_channel_announcement / _node_announcement / _channel_update (generated from
+// wire/peer_wire.csv:344-381) reject before gossipd/sigcheck.c runs, so that the batch entry points can take raw wire bytes.
+enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };
+// BigSize (BOLT #1, common/bigsize.c:53-104): bytes consumed, 0 = truncated or not minimally encoded
+LAMD_HD size_t wire_bigsize(const u8 *p, size_t max, u64 *val) {
+  if (max < 1) return 0;
+  const u32 t = p[0];
+  if (t < 0xfd) { *val = t; return 1; }
+  const size_t width = t == 0xfd ? 2 : (t == 0xfe ? 4 : 8);
+  if (max < 1 + width) return 0;
+  u64 v = 0;
+  for (size_t i = 0; i < width; i++) v = (v << 8) | p[1 + i];
+  *val = v;
+  const u64 floor = t == 0xfd ? 0xfdull : (t == 0xfe ? 0x10000ull : 0x100000000ull);
+  return v < floor ? 0 : 1 + width;
+}
+// node_ann_tlvs (peer_wire.csv:367-369) under fromwire_tlv's rules (wire/tlvstream.c:144-300): strictly increasing types,
+// lengths inside the message, unknown even types fail, unknown odd ones are skipped; record 1 (option_will_fund) is a
+// lease_rates: u16 u16 u16 u32 tu32 = 10..14 bytes, the tu32 minimal (wire/fromwire.c:115-150)
+LAMD_HD bool wire_node_ann_tlvs_ok(const u8 *p, size_t max) {
+  bool first = true;
+  u64 prev = 0;
+  while (max > 0) {
+    u64 type, length;
+    size_t l = wire_bigsize(p, max, &type);
+    if (!l) return false;
+    p += l; max -= l;
+    if (!first && type <= prev) return false;
+    first = false; prev = type;
+    if (type != 1 && (type & 1) == 0) return false;
+    l = wire_bigsize(p, max, &length);
+    if (!l) return false;
+    p += l; max -= l;
+    if (length > max) return false;
+    if (type == 1 && (length < 10 || length > 14 || (length > 10 && p[10] == 0))) return false;
+    p += length; max -= (size_t)length;
+  }
+  return true;
+}
+struct gossip_frame {
+  u32 type;
+  bool bad;           // fromwire_* would fail on the framing alone (signature ranges / key validity are checked elsewhere)
+  size_t signed_off;  // the signed region is [signed_off, len)
+  size_t keyoff;      // channel_announcement: the four keys; node_announcement: node_id
+};
+LAMD_HD gossip_frame gossip_parse_frame(const u8 *m, size_t len) {
+  gossip_frame f;
+  f.bad = len < 2;
+  f.type = f.bad ? 0 : (((u32)m[0] << 8) | m[1]);
+  f.signed_off = 66;
+  f.keyoff = 0;
+  if (f.type == GOSSIP_CANN) {
+    f.signed_off = 258;
+    f.bad |= len < 260;
+    if (!f.bad) {
+      const size_t flen = ((size_t)m[258] << 8) | m[259];
+      f.keyoff = 260 + flen + 32 + 8;
+      f.bad |= len < f.keyoff + 4 * 33;
+    }
+  } else if (f.type == GOSSIP_NANN) {
+    f.bad |= len < 68;
+    if (!f.bad) {
+      const size_t flen = ((size_t)m[66] << 8) | m[67];
+      f.keyoff = 68 + flen + 4;
+      // node_id 33 | rgb_color 3 | alias 32 | addrlen u16 | addresses | tlvs
+      f.bad |= len < f.keyoff + 70;
+      if (!f.bad) {
+        const size_t end = f.keyoff + 70 + (((size_t)m[f.keyoff + 68] << 8) | m[f.keyoff + 69]);
+        f.bad |= len < end;
+        if (!f.bad) f.bad |= !wire_node_ann_tlvs_ok(m + end, len - end);
+      }
+    }
+  } else if (f.type == GOSSIP_CUPD) {
+    f.bad |= len < 138;  // every fixed field of peer_wire.csv:370-381; trailing bytes are tolerated (and signed)
+  } else {
+    f.bad = true;
+  }
+  return f;
+}
+
 // ---- fee grind (onchaind/onchaind.c:388-438 grind_htlc_tx_fee): ONE signature and key, many candidate fees.  Every
 // candidate changes output 0's amount, hence hashOutputs, hence the sighash z -- but r, s and Q stay: with w = 1/s,
 // R = (z*w)*G + (r*w)*Q, so (r*w)*Q is computed once (grind_prepare, the ordinary GLV ladder) and a candidate costs two

@@ -221,13 +221,16 @@ class Engine:
 
     def gen_ecdsa_device(self, seed, nkeys, d_hash, d_sig, d_pub, group=0):
         n, publen = d_pub.shape
+        self._after_torch()   # the output tensors may still be being filled on torch's stream (torch.zeros)
         self._chk(self._lib.lamd_gen_ecdsa_device(self._ctx, n, seed, nkeys, group, publen, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr()))
 
     def gen_schnorr_device(self, seed, nkeys, d_msg, d_xonly, d_sig, group=0):
         n = d_msg.shape[0]
+        self._after_torch()
         self._chk(self._lib.lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, group, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
 
     def gen_gossip_device(self, seed, n_cann, n_cupd, n_nodes, d_msgs, d_ids):
+        self._after_torch()
         self._chk(self._lib.lamd_gen_gossip_device(self._ctx, n_cann, n_cupd, seed, n_nodes, d_msgs.data_ptr(), d_ids.data_ptr()))
 
     def sigcheck_gossip_device(self, n, d_msgs, d_off, d_ids, d_rowbase, rows, d_verdict):
@@ -250,6 +253,13 @@ class Engine:
         buf = ctypes.create_string_buffer(8192)
         rc = self._chk(self._lib.lamd_inv_debug(self._ctx, buf, 8192))
         return rc, buf.value.decode()
+
+    def fuzz_field(self, lanes=16384, iters=64, seed=1):
+        """(mismatching lanes, field operations executed on the device, report)"""
+        buf = ctypes.create_string_buffer(4096)
+        ops = ctypes.c_uint64(0)
+        rc = self._chk(self._lib.lamd_fuzz_field(self._ctx, lanes, iters, seed, ctypes.byref(ops), buf, 4096))
+        return rc, ops.value, buf.value.decode()
 
     def synchronize(self):
         self._chk(self._lib.lamd_synchronize(self._ctx))

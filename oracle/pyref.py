@@ -346,9 +346,50 @@ def sigcheck_channel_announcement(msg):
     return 0
 
 
+def bigsize_read(b, pos):
+    """BigSize (BOLT #1, common/bigsize.c:53-104): (value, new position) or None when truncated / not minimal"""
+    if pos >= len(b):
+        return None
+    t = b[pos]
+    if t < 0xFD:
+        return t, pos + 1
+    width, floor = {0xFD: (2, 0xFD), 0xFE: (4, 1 << 16), 0xFF: (8, 1 << 32)}[t]
+    if pos + 1 + width > len(b):
+        return None
+    v = int.from_bytes(b[pos + 1:pos + 1 + width], "big")
+    return None if v < floor else (v, pos + 1 + width)
+
+
+def node_ann_tlvs_ok(b):
+    """the tlv stream that ends a node_announcement (wire/peer_wire.csv:367-369) under fromwire_tlv's rules
+    (wire/tlvstream.c:144-300); known record 1 = lease_rates: u16 u16 u16 u32 tu32 (10..14 bytes, minimal tu32)"""
+    pos, prev = 0, None
+    while pos < len(b):
+        r = bigsize_read(b, pos)
+        if r is None:
+            return False
+        typ, pos = r
+        if prev is not None and typ <= prev:
+            return False
+        prev = typ
+        if typ != 1 and typ % 2 == 0:
+            return False
+        r = bigsize_read(b, pos)
+        if r is None:
+            return False
+        ln, pos = r
+        if ln > len(b) - pos:
+            return False
+        if typ == 1 and (not 10 <= ln <= 14 or (ln > 10 and b[pos + 10] == 0)):
+            return False
+        pos += ln
+    return True
+
+
 def sigcheck_channel_update(msg, node_id33):
-    """gossipd/sigcheck.c:9-43.  0 = OK, 1 = 'Bad signature', -1 = malformed."""
-    if len(msg) < 66 or msg[0:2] != b"\x01\x02":
+    """gossipd/sigcheck.c:9-43.  0 = OK, 1 = 'Bad signature', -1 = malformed (fromwire_channel_update needs all
+    138 bytes of fixed fields, wire/peer_wire.csv:370-381)."""
+    if len(msg) < 138 or msg[0:2] != b"\x01\x02":
         return -1
     if sig_parse_compact(msg[2:66]) is None:
         return -1
@@ -356,16 +397,20 @@ def sigcheck_channel_update(msg, node_id33):
 
 
 def sigcheck_node_announcement(msg, node_id33=None):
-    """gossipd/sigcheck.c:118-164.  node_id defaults to the one embedded in the message."""
+    """gossipd/sigcheck.c:118-164.  node_id defaults to the one embedded in the message.  -1 = what
+    fromwire_node_announcement rejects (truncated fixed part / addresses, bad tlv stream)."""
     if len(msg) < 68 or msg[0:2] != b"\x01\x01":
         return -1
     if sig_parse_compact(msg[2:66]) is None:
         return -1
+    flen = int.from_bytes(msg[66:68], "big")
+    off = 68 + flen + 4
+    if len(msg) < off + 70:
+        return -1
+    addrlen = int.from_bytes(msg[off + 68:off + 70], "big")
+    if len(msg) < off + 70 + addrlen or not node_ann_tlvs_ok(msg[off + 70 + addrlen:]):
+        return -1
     if node_id33 is None:
-        flen = int.from_bytes(msg[66:68], "big")
-        off = 68 + flen + 4
-        if len(msg) < off + 33:
-            return -1
         node_id33 = msg[off:off + 33]
     return 0 if _check_nodeid(sha256d(msg[66:]), msg[2:66], node_id33) else 1
 

@@ -717,9 +717,60 @@ int orc_sigcheck_channel_announcement(const uint8_t *msg, size_t len)
 		if (!orc_ecdsa_verify(h, msg + 2 + 64 * i, msg + koff + 33 * i, 33)) return i + 1;
 	return 0;
 }
+/* BigSize (BOLT #1) as common/bigsize.c:53-104 reads it: 0 = truncated or not minimally encoded, else bytes consumed */
+static size_t bigsize_read(const uint8_t *p, size_t max, uint64_t *val)
+{
+	if (max < 1) return 0;
+	if (p[0] < 0xfd) { *val = p[0]; return 1; }
+	if (p[0] == 0xfd) {
+		if (max < 3) return 0;
+		*val = ((uint64_t)p[1] << 8) | p[2];
+		return *val < 0xfd ? 0 : 3;
+	}
+	if (p[0] == 0xfe) {
+		if (max < 5) return 0;
+		*val = ((uint64_t)p[1] << 24) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 8) | p[4];
+		return (*val >> 16) == 0 ? 0 : 5;
+	}
+	if (max < 9) return 0;
+	*val = 0;
+	for (int i = 1; i <= 8; i++) *val = (*val << 8) | p[i];
+	return (*val >> 32) == 0 ? 0 : 9;
+}
+/* the node_ann_tlvs stream that ends a node_announcement (wire/peer_wire.csv:367-369), by the rules of
+ * fromwire_tlv (wire/tlvstream.c:144-300): types strictly increasing, BigSize minimal, length inside the message,
+ * unknown even types fail, unknown odd ones are skipped; the one known record, 1 = option_will_fund, is a lease_rates
+ * (peer_wire.csv:214-219: u16 u16 u16 u32 tu32 -- 10 to 14 bytes, the tu32 without a leading zero byte,
+ * wire/fromwire.c:115-150) */
+static int node_ann_tlvs_ok(const uint8_t *p, size_t max)
+{
+	int first = 1;
+	uint64_t prev = 0;
+	while (max > 0) {
+		uint64_t type, length;
+		size_t l = bigsize_read(p, max, &type);
+		if (!l) return 0;
+		p += l; max -= l;
+		if (!first && type <= prev) return 0;
+		first = 0; prev = type;
+		if (type != 1 && (type & 1) == 0) return 0;
+		l = bigsize_read(p, max, &length);
+		if (!l) return 0;
+		p += l; max -= l;
+		if (length > max) return 0;
+		if (type == 1) {
+			if (length < 10 || length > 14) return 0;
+			if (length > 10 && p[10] == 0) return 0;
+		}
+		p += length; max -= (size_t)length;
+	}
+	return 1;
+}
 int orc_sigcheck_channel_update(const uint8_t *msg, size_t len, const uint8_t node_id33[33])
 {
-	if (len < 66 || msg[0] != 0x01 || msg[1] != 0x02) return -1;
+	/* fromwire_channel_update reads every fixed field (peer_wire.csv:370-381: 138 bytes); trailing bytes are tolerated
+	 * and signed */
+	if (len < 138 || msg[0] != 0x01 || msg[1] != 0x02) return -1;
 	if (!orc_sig_parse_compact(msg + 2)) return -1;
 	uint8_t h[32];
 	orc_sha256d(msg + 66, len - 66, h); /* sigcheck.c:30-33 */
@@ -731,7 +782,11 @@ int orc_sigcheck_node_announcement(const uint8_t *msg, size_t len)
 	if (!orc_sig_parse_compact(msg + 2)) return -1;
 	size_t flen = ((size_t)msg[66] << 8) | msg[67];
 	size_t off = 68 + flen + 4;
-	if (len < off + 33) return -1;
+	/* node_id | rgb_color 3 | alias 32 | addrlen u16 | addresses | node_ann_tlvs (peer_wire.csv:357-367) */
+	if (len < off + 33 + 3 + 32 + 2) return -1;
+	size_t addrlen = ((size_t)msg[off + 68] << 8) | msg[off + 69];
+	if (len < off + 70 + addrlen) return -1;
+	if (!node_ann_tlvs_ok(msg + off + 70 + addrlen, len - (off + 70 + addrlen))) return -1;
 	uint8_t h[32];
 	orc_sha256d(msg + 66, len - 66, h); /* sigcheck.c:138-141 */
 	return orc_ecdsa_verify(h, msg + 2, msg + off, 33) ? 0 : 1;

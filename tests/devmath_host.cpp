@@ -265,3 +265,14 @@ void dm_schnorr_verify_batch(size_t n, const u8 *msg32, const u8 *pk32, const u8
   }
 }
 }
+
+// ---- gossip framing (verify_core.h "gossip framing"): bad flag, type, signed region offset, key offset
+extern "C" int dm_gossip_frame(const u8 *m, size_t len, u32 *type, size_t *signed_off, size_t *keyoff) {
+  const gossip_frame f = gossip_parse_frame(m, len);
+  *type = f.type; *signed_off = f.signed_off; *keyoff = f.keyoff;
+  return f.bad;
+}
+
+// ---- the device fuzzer's lane function with magnitude assertions on (lamd_fuzz_field runs the same function on the GPU)
+#include "../lightning_amd/csrc/fuzz.h"
+extern "C" uint64_t dm_fuzz_lane(uint64_t seed, uint64_t lane, int iters) { return fuzz_lane(seed, lane, iters); }

@@ -440,6 +440,55 @@ def main():
     out["gossip"].append(dict(name="cann/malformed-r>=n", kind="channel_announcement", msg=bytes(mb).hex(),
                               expect=R.sigcheck_channel_announcement(bytes(mb)), source="wire/fromwire.c:196-198"))
 
+    # ---- framing: what fromwire_channel_update / fromwire_node_announcement reject before sigcheck runs (wire/peer_wire.csv:357-381,
+    # wire/tlvstream.c:144-300, common/bigsize.c:53-104).  Every message here carries a VALID signature over its own tail, so a
+    # verdict of -1 can only come from the framing rules.
+    frng = Rng("lightning_amd/golden/gossip-framing/v1")
+    fd, fk = frng.scalar(), None
+    fk = R.ser33(R.pubkey_create(fd))
+
+    def signed(type2, tail):
+        return type2 + R.ecdsa_sign(R.sha256d(tail), fd, frng.scalar()) + tail
+
+    cu_body = chain + frng.bytes(8) + frng.bytes(4) + b"\x01\x00" + frng.bytes(2 + 8 + 4 + 4 + 8)
+    for cut in (0, 1, 40, 71):                                  # truncated fixed part: 66, 67, 106, 137 bytes
+        m = signed(b"\x01\x02", cu_body[:cut])
+        out["gossip"].append(dict(name="cupd/truncated/%d" % len(m), kind="channel_update", msg=m.hex(), node_id=fk.hex(),
+                                  expect=R.sigcheck_channel_update(m, fk), source="synth gossip-framing/v1"))
+        assert out["gossip"][-1]["expect"] == -1
+    m = signed(b"\x01\x02", cu_body + frng.bytes(5))            # trailing bytes are tolerated (and signed)
+    out["gossip"].append(dict(name="cupd/trailing", kind="channel_update", msg=m.hex(), node_id=fk.hex(),
+                              expect=R.sigcheck_channel_update(m, fk), source="synth gossip-framing/v1"))
+    assert out["gossip"][-1]["expect"] == 0
+
+    def nann(feat, addrs, tlvs, cut=None, addrlen=None):
+        body = len(feat).to_bytes(2, "big") + feat + frng.bytes(4) + fk + frng.bytes(3) + frng.bytes(32)
+        body += (len(addrs) if addrlen is None else addrlen).to_bytes(2, "big") + addrs + tlvs
+        if cut is not None:
+            body = body[:cut]
+        return signed(b"\x01\x01", body)
+
+    lease = frng.bytes(10)
+    cases = [("ok/plain", nann(b"", b"", b""), 0), ("ok/addrs", nann(frng.bytes(3), frng.bytes(14), b""), 0),
+             ("trunc/in-node-id", nann(b"", b"", b"", cut=2 + 4 + 20), -1), ("trunc/in-alias", nann(b"", b"", b"", cut=2 + 4 + 33 + 3 + 10), -1),
+             ("trunc/no-addrlen", nann(b"", b"", b"", cut=2 + 4 + 33 + 3 + 32 + 1), -1), ("trunc/addrs-short", nann(b"", frng.bytes(5), b"", addrlen=9), -1),
+             ("trunc/features-past-end", nann(b"", b"", b"", cut=1), -1),
+             ("tlv/lease10", nann(b"", b"", b"\x01\x0a" + lease), 0), ("tlv/lease12", nann(b"", b"", b"\x01\x0c" + lease + b"\x01\x00"), 0),
+             ("tlv/lease14", nann(b"", frng.bytes(7), b"\x01\x0e" + lease + b"\xff\x00\x00\x01"), 0),
+             ("tlv/lease-tu32-leading-zero", nann(b"", b"", b"\x01\x0c" + lease + b"\x00\x01"), -1),
+             ("tlv/lease-too-short", nann(b"", b"", b"\x01\x09" + lease[:9]), -1), ("tlv/lease-too-long", nann(b"", b"", b"\x01\x0f" + lease + frng.bytes(5)), -1),
+             ("tlv/unknown-odd", nann(b"", b"", b"\x03\x02ab"), 0), ("tlv/unknown-even", nann(b"", b"", b"\x02\x02ab"), -1),
+             ("tlv/odd-after-lease", nann(b"", b"", b"\x01\x0a" + lease + b"\xfd\x01\x01\x00"), 0),
+             ("tlv/not-increasing", nann(b"", b"", b"\x03\x00\x03\x00"), -1), ("tlv/decreasing", nann(b"", b"", b"\x05\x00\x03\x00"), -1),
+             ("tlv/type-not-minimal", nann(b"", b"", b"\xfd\x00\x03\x00"), -1), ("tlv/len-not-minimal", nann(b"", b"", b"\x03\xfd\x00\x01a"), -1),
+             ("tlv/len-past-end", nann(b"", b"", b"\x03\x05ab"), -1), ("tlv/type-only", nann(b"", b"", b"\x03"), -1),
+             ("tlv/bigsize-truncated", nann(b"", b"", b"\xfe\x00\x01"), -1),
+             ("tlv/big-odd-type", nann(b"", b"", b"\xfe\x00\x01\x00\x01\x00"), 0)]
+    for nm, m, exp in cases:
+        got = R.sigcheck_node_announcement(m)
+        assert got == exp, (nm, got, exp)
+        out["gossip"].append(dict(name="nann/" + nm, kind="node_announcement", msg=m.hex(), expect=got, source="synth gossip-framing/v1"))
+
     # ---- KAT-B11R: public-key recovery.  Every invoice string the reference's own test decodes successfully
     # (common/test/run-bolt11.c, test_b11("ln...")) carries a 64-byte signature + recovery id over
     # SHA256(hrp || data) (common/bolt11.c:1000-1046); all of them are "signed with priv_key e126f68f..." (:301), whose public key

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "lightning_amd.h")).read()
+def _declared(header="lightning_amd.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(lamd_[a-z0-9_]+)\s*\(", src)))
 
@@ -18,8 +18,11 @@ def _declared():
 def test_header_symbols_exported_and_bound():
     from lightning_amd import _ffi
     lib = _ffi.load()
-    names = _declared()
-    assert len(names) >= 20
+    product, debug = _declared(), _declared("lightning_amd_debug.h")
+    assert len(product) >= 20 and not set(product) & set(debug)
+    # the drop-in boundary carries no diagnostics
+    assert not [n for n in product if "debug" in n or "selftest" in n or "fuzz" in n]
+    names = sorted(product + debug)
     for n in names:
         assert hasattr(lib, n), "liblightning_amd.so does not export %s" % n
         assert n in _ffi.SYMBOLS, "ctypes binding missing for %s" % n

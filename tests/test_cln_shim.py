@@ -188,3 +188,45 @@ def test_bolt11_recovery_through_libsecp_names(shim, kat):
             shim.node_id_from_pubkey(ctypes.byref(nid), ctypes.byref(pk))
             got = bytes(nid.k).hex()
         assert got == v["expect"], v["name"]
+
+
+def _cfg1_rows():
+    blob = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1.bin"), "rb").read()
+    assert len(blob) == 1024 * 130
+    return [(blob[o:o + 32], blob[o + 32:o + 96], blob[o + 96:o + 129], bool(blob[o + 129])) for o in range(0, len(blob), 130)]
+
+
+def test_cfg1_fixture_on_the_cpu_oracle(kat, orc):
+    """BASELINE configs[0]: 1 024 ECDSA triples, seed 0xC1A00001, one by one through the CPU oracle's
+    check_signed_hash equivalent; the reference-held KAT-G / KAT-O / KAT-B11 rows are rows 0..13; exact ok[]"""
+    import pyref
+    rows = _cfg1_rows()
+    kats = [v for v in kat["ecdsa"] if v["name"].startswith("KAT")]
+    assert len(kats) == 14 and {v["name"].split("/")[0] for v in kats} == {"KAT-G", "KAT-O", "KAT-B11"}
+    for (h, s, p, e), v in zip(rows, kats):
+        assert (h.hex(), s.hex(), p.hex(), e) == (v["hash"], v["sig"], v["pub"], v["expect"])
+    got = [bool(orc.ecdsa_verify(h, s, p)) for h, s, p, _ in rows]
+    assert got == [e for _, _, _, e in rows]
+    assert 880 <= sum(got) <= 960
+    for h, s, p, e in rows[:14] + rows[14::37]:
+        assert pyref.ecdsa_verify(h, s, p) == e
+
+
+@pytest.mark.gpu
+def test_cfg1_one_by_one_through_check_signed_hash(shim):
+    """the same 1 024 triples pushed ONE BY ONE through the shim's check_signed_hash() (bitcoin/signature.c:174-192 shape:
+    parsed signature + parsed key), and through check_signed_hash_nodeid(); exact ok[]"""
+    assert shim.lamd_shim_setup(), shim.lamd_shim_last_error()
+    rows = _cfg1_rows()
+    got, got_id = [], []
+    for h, s, p, e in rows:
+        hh, sg, pk = Sha256d.from_buffer_copy(h), Sig(), Pubkey()
+        sig_ok = shim.fromwire_secp256k1_ecdsa_signature(s, ctypes.byref(sg))
+        key_ok = shim.pubkey_from_der(p, 33, ctypes.byref(pk))
+        # the reference cannot even call check_signed_hash when either parse fails: that IS the combined verdict
+        got.append(bool(sig_ok and key_ok and shim.check_signed_hash(ctypes.byref(hh), ctypes.byref(sg), ctypes.byref(pk))))
+        nid = NodeId.from_buffer_copy(p)
+        got_id.append(bool(sig_ok and shim.check_signed_hash_nodeid(ctypes.byref(hh), ctypes.byref(sg), ctypes.byref(nid))))
+    exp = [e for _, _, _, e in rows]
+    assert got == exp, [i for i in range(1024) if got[i] != exp[i]][:10]
+    assert got_id == exp

@@ -22,7 +22,7 @@ H = bytes.fromhex
 def dm():
     so = os.path.join(HERE, "libdevmath_host.so")
     srcs = [os.path.join(HERE, "devmath_host.cpp")] + [os.path.join(ROOT, "lightning_amd", "csrc", f)
-                                                       for f in ("lamd_common.h", "fe.h", "scalar.h", "group.h", "sha256.h", "verify_core.h")]
+                                                       for f in ("lamd_common.h", "fe.h", "scalar.h", "group.h", "sha256.h", "verify_core.h", "fuzz.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", so, srcs[0]])
     L = ctypes.CDLL(so)
@@ -463,3 +463,58 @@ def test_fee_grind_host_build_vs_reference_kat_and_restated_loop(dm, kat, orc):
         outputs = amount.to_bytes(8, "little") + bytes([len(spk)]) + spk
         exp = pyref.grind_htlc_tx_fee(pre, outputs, input_sat, weight, lo, hi, sig, stype, True, pub, verify=ver)
         assert _host_grind(dm, pre, outputs, input_sat, weight, lo, hi, sig, stype, True, pub) == exp, case
+
+
+def test_gossip_framing_host_build_vs_goldens_and_oracle(dm, kat, orc):
+    """the device's framing rules (what fromwire_* rejects) on the host: every gossip golden, plus random truncations and
+    byte flips in the framing fields, against the C oracle's verdict == -1"""
+    dm.dm_gossip_frame.restype = ctypes.c_int
+
+    def frame_bad(m):
+        t, so, ko = ctypes.c_uint32(), ctypes.c_size_t(), ctypes.c_size_t()
+        return bool(dm.dm_gossip_frame(m, len(m), ctypes.byref(t), ctypes.byref(so), ctypes.byref(ko)))
+
+    def oracle_verdict(v, m):
+        if v["kind"] == "channel_announcement":
+            return orc.sigcheck_channel_announcement(m)
+        if v["kind"] == "channel_update":
+            return orc.sigcheck_channel_update(m, H(v["node_id"]))
+        return orc.sigcheck_node_announcement(m)
+
+    nbad = 0
+    for v in kat["gossip"]:
+        m = H(v["msg"])
+        assert oracle_verdict(v, m) == v["expect"], v["name"]
+        if v["expect"] != -1:
+            assert not frame_bad(m), v["name"]
+        elif "framing" in v["source"]:
+            assert frame_bad(m), v["name"]
+            nbad += 1
+    assert nbad >= 20
+    rnd = random.Random(77)
+    base = [v for v in kat["gossip"] if v["expect"] == 0]
+    for it in range(3000):
+        v = rnd.choice(base)
+        m = bytearray(H(v["msg"]))
+        if rnd.random() < 0.5:
+            m = m[:rnd.randrange(len(m) + 1)]
+        else:
+            # flip a byte outside the signatures: lengths, tlv bytes, addrlen ... (keys may stop parsing: not framing)
+            lo = 258 if v["kind"] == "channel_announcement" else 66
+            m[rnd.randrange(lo, len(m))] ^= 1 << rnd.randrange(8)
+        m = bytes(m)
+        # framing-bad must imply oracle -1; oracle -1 beyond framing (key / sig range) is decided by other kernels
+        if frame_bad(m):
+            assert oracle_verdict(v, m) == -1, (v["name"], m.hex())
+        elif v["kind"] != "channel_announcement":
+            assert oracle_verdict(v, m) != -1, (v["name"], m.hex())
+
+
+def test_fuzz_lane_respects_magnitude_bounds(dm):
+    """the GPU fuzzer's lane function (csrc/fuzz.h) under the host build's magnitude assertions: every operand it feeds the
+    primitives is inside the bounds the group law guarantees, so a device/host checksum difference can only be a device fault"""
+    dm.dm_fuzz_lane.restype = ctypes.c_uint64
+    dm.dm_fuzz_lane.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+    seen = {dm.dm_fuzz_lane(1, lane, 8) for lane in range(300)}
+    assert len(seen) == 300
+    assert dm.dm_fuzz_lane(1, 5, 8) == dm.dm_fuzz_lane(1, 5, 8) != dm.dm_fuzz_lane(2, 5, 8)

@@ -166,7 +166,7 @@ def test_streaming_queue_mixed_kinds_in_ticket_order(eng, orc, kat):
             tickets.append(eng.queue_ecdsa(H(v["hash"]), H(v["sig"]), H(v["pub"])))
         else:
             tickets.append(eng.queue_schnorr(H(v["msg"]), H(v["pk"]), H(v["sig"])))
-    assert tickets == list(range(tickets[0], tickets[0] + len(items)))
+    assert tickets == list(range(len(items)))      # a ticket is the position in the flush's verdict vector
     eng.flush()
     got = eng.wait()
     assert [bool(g) for g in got] == [v["expect"] for _, v in items]
@@ -174,7 +174,7 @@ def test_streaming_queue_mixed_kinds_in_ticket_order(eng, orc, kat):
     t = eng.queue_ecdsa(H(es[0]["hash"]), H(es[0]["sig"]), H(es[0]["pub"]))
     eng.flush()
     got = eng.wait()
-    assert len(got) == 1 and bool(got[0]) == es[0]["expect"] and t == tickets[-1] + 1
+    assert len(got) == 1 and bool(got[0]) == es[0]["expect"] and t == 0      # tickets restart with every flush
 
 
 def test_device_generator_round_trip_and_oracle_sample(eng, orc):
