@@ -207,16 +207,27 @@ typedef struct {
 	char arch[64];
 	size_t gtable_bytes;
 	double last_kernel_ms[4]; /* prep, keys (+ key tables), ecmult, BIP-340 parity stage of the last launch sequence when timing is on */
-	size_t last_unique_keys;  /* distinct public keys found in the last chunk (0 if it was not examined) */
-	size_t last_hot_rows;     /* rows of the last chunk verified against per-key tables (the rest took the ladder) */
-	int last_keyed;           /* 0: per-signature ladder only; else rows of the last chunk ran on per-key tables and this is
-				   * the number of comb teeth of those tables (7 or 10) */
+	/* counts of the last chunk that took the keyed path (read back asynchronously: exact after lamd_synchronize()) */
+	size_t last_unique_keys;  /* distinct public keys among the rows the cache did not know */
+	size_t last_hot_rows;     /* rows verified against per-key comb tables (the rest took the per-signature ladder) */
+	int last_keyed;           /* 0: ladder only; else the largest comb used (7 or 10 teeth) */
 	int last_mode;            /* 0: the last chunk was ECDSA, 1: BIP-340 */
 	int lanes;                /* number of lanes (LAMD_LANES, default 4; 1 = strictly one stream) */
+	size_t last_cache_hits;   /* rows whose key already had a table in the cache */
+	size_t last_cold_rows;    /* rows that took the ladder */
+	size_t last_new_tables;   /* comb tables built by that chunk */
+	size_t last_suspect_rows; /* rows re-decided by the complete addition formulas (crafted scalars / result at infinity) */
+	int cache_enabled;        /* LAMD_CACHE (default 1): comb tables persist across calls */
+	size_t cache_entries, cache_capacity; /* keys with a cached table (as last read back) / LAMD_CACHE_KEYS + LAMD_CACHE_KEYS10 */
+	size_t cache_resets;      /* how often the bounded cache was emptied because it filled up */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 .. lanes-1 */
 int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */
+/* Empties the key-table cache (drains the device first).  The cache is bounded (LAMD_CACHE_KEYS 7-tooth tables, 2^20 by
+ * default = 6.3 GB of HBM; LAMD_CACHE_KEYS10 10-tooth tables, 2^16 = 3.2 GB) and empties itself when it fills up;
+ * benchmarks call this to measure the cold path. */
+int lamd_cache_clear(lamd_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,10 @@ c_sz = ctypes.c_size_t
 class LamdInfo(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("arch", ctypes.c_char * 64),
                 ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4), ("last_unique_keys", ctypes.c_size_t),
-                ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int), ("last_mode", ctypes.c_int), ("lanes", ctypes.c_int)]
+                ("last_hot_rows", ctypes.c_size_t), ("last_keyed", ctypes.c_int), ("last_mode", ctypes.c_int), ("lanes", ctypes.c_int),
+                ("last_cache_hits", ctypes.c_size_t), ("last_cold_rows", ctypes.c_size_t), ("last_new_tables", ctypes.c_size_t),
+                ("last_suspect_rows", ctypes.c_size_t), ("cache_enabled", ctypes.c_int), ("cache_entries", ctypes.c_size_t),
+                ("cache_capacity", ctypes.c_size_t), ("cache_resets", ctypes.c_size_t)]
 
 
 # name -> (restype, argtypes); every symbol of include/lightning_amd.h and include/lightning_amd_debug.h
@@ -56,6 +59,7 @@ SYMBOLS = {
     "lamd_fuzz_field": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, c_sz]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_cache_clear": (ctypes.c_int, [ctypes.c_void_p]),
     "lamd_get_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LamdInfo)]),
     "lamd_stream_wait_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_wait_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -79,6 +79,28 @@ LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, bool *degenerate, fe *h_o
   return r;
 }
 
+// The same formula with nothing around it: no zero test of H, no infinity / skip handling.  For callers that detect
+// every degenerate event afterwards: H == 0 (a = +-b) makes Z3 = Z1*H zero, and a zero Z stays zero through every later
+// doubling (Z3 = 2*Y*Z) and addition (Z3 = Z*H), so one fe_is_zero(Z) at the end of a chain of these catches them all
+// (p is prime: Z1*H = 0 only if a factor is).  b.y may have magnitude 2 (ge_neg_if_lazy).
+LAMD_HD gej gej_add_ge_fast(const gej &a, const ge &b) {
+  gej r;
+  const fe zz = fe_sqr(a.z);
+  const fe u2 = fe_mul(b.x, zz);
+  const fe s2 = fe_mul(b.y, fe_mul(a.z, zz));
+  const fe h = fe_norm_weak(fe_add(u2, fe_neg(a.x, 1)));
+  const fe rr = fe_norm_weak(fe_add(s2, fe_neg(a.y, 1)));
+  const fe hh = fe_sqr(h);
+  const fe hhh = fe_mul(h, hh);
+  const fe v = fe_mul(a.x, hh);
+  r.x = fe_norm_weak(fe_add(fe_sqr(rr), fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3)));
+  const fe t = fe_add(v, fe_neg(r.x, 1));  // (3)
+  r.y = fe_norm_weak(fe_add(fe_mul(rr, t), fe_neg(fe_mul(a.y, hhh), 1)));
+  r.z = fe_mul(a.z, h);
+  r.inf = false;
+  return r;
+}
+
 LAMD_HD gej gej_select(bool take_a, const gej &a, const gej &b) {
   gej r;
   r.x = fe_select(take_a, a.x, b.x);
@@ -110,6 +132,23 @@ LAMD_HD ge ge_neg_if(const ge &a, bool neg) {
   ge r;
   r.x = a.x;
   r.y = fe_select(neg, fe_norm_weak(fe_neg(a.y, 1)), a.y);
+  return r;
+}
+
+// Conditional negation without a normalisation pass: y' = neg ? 2p - y : y, limb-wise as (y ^ m) + (m & (2*p_i + 1))
+// (two's complement: ~y + 2p_i + 1 = 2p_i - y, and y <= 2p_i for a magnitude-1 y) -- three simple ops per limb.  The result has magnitude 2.
+LAMD_HD ge ge_neg_if_lazy(const ge &a, bool neg) {
+  LAMD_ASSERT(FE_MAG(a.y) <= 1);
+  ge r;
+  r.x = a.x;
+  const u32 m = neg ? 0xFFFFFFFFu : 0u;
+  r.y.n[0] = (a.y.n[0] ^ m) + (m & (2u * FE_P0 + 1u));
+  r.y.n[1] = (a.y.n[1] ^ m) + (m & (2u * FE_P1 + 1u));
+#pragma unroll
+  for (int i = 2; i < 8; i++) r.y.n[i] = (a.y.n[i] ^ m) + (m & (2u * FE_PM + 1u));
+  r.y.n[8] = (a.y.n[8] ^ m) + (m & (2u * FE_P8 + 1u));
+  FE_SETMAG(r.y, 2);
+  fe_verify(r.y);
   return r;
 }
 

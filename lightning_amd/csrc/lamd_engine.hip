@@ -17,6 +17,8 @@
 
 using namespace lamd;
 
+constexpr int MAX_LANES = 8;
+
 // =====================================================================================
 //                                       kernels
 // =====================================================================================
@@ -61,10 +63,12 @@ constexpr int FIN_WORDS = 32;  // BIP-340 stage-1 parking space per row (Y, Z, p
 
 // ---- public keys: parse / decompress / validate -> 64-byte affine words + validity byte
 // (idx != nullptr: work item i handles input row idx[i]; its outputs stay at position i)
+// (count != nullptr: the number of work items is min(*count, n), known only on the device)
 __global__ void __launch_bounds__(256) k_keys(size_t n, const u8 *__restrict__ pub, int publen, size_t stride,
-                                              const u32 *__restrict__ idx, u32 *__restrict__ qwords, u8 *__restrict__ keyok) {
+                                              const u32 *__restrict__ idx, u32 *__restrict__ qwords, u8 *__restrict__ keyok,
+                                              const u32 *__restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || (count && i >= *count)) return;
   const size_t row = idx ? idx[i] : i;
   u32 qx[8], qy[8];
   const bool ok = parse_pubkey(pub + stride * row, publen, qx, qy);
@@ -83,11 +87,11 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
                                                 const u8 *__restrict__ keyok, const u8 *__restrict__ sig64, int mode,
                                                 const u32 *__restrict__ gtable, u32 *__restrict__ slots,
                                                 const u32 *__restrict__ idx, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
-                                                u8 *__restrict__ out) {
+                                                u8 *__restrict__ out, const u32 *__restrict__ count) {
   // idx != nullptr (cold rows of a partitioned chunk): work item i verifies input row idx[i]; key data and the table
   // slot live at position i, the prep record / signature / verdict / BIP-340 parking space (fin) at the row
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || (count && i >= *count)) return;
   const size_t row = idx ? idx[i] : i;
   prep_rec rec;
   {
@@ -483,11 +487,86 @@ __device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight = 
   return base + prefix;
 }
 
-// open-addressing table of row indices (+1); the first row to claim a slot represents its key
+// Key-table cache.  One entry per distinct public key that has a comb table: the serialised key bytes
+// (what the callers hand over: 33 / 65 SEC1 or 32 x-only -- no parsing needed to look a key up), the comb shape, the table
+// slot in the pool of that shape, and who published it when (an entry is usable by a call only if the host has SEEN the
+// publishing call complete, or it ran earlier on the same lane's stream: `vis`).  meta = teeth (7 / 10; 0 = the key does
+// not parse: its rows are rejected without a table) | lane << 8.
+struct cache_ent {
+  u32 kw[17];  // key bytes, zero padded, little-endian packed; kw[16] = byte 64 | length << 8
+  u32 meta, seq, tabslot;
+};
+struct cache_vis { u32 seq[MAX_LANES + 1]; };
+constexpr u32 ENT_NONE = 0xFFFFFFFFu;
+enum { C_ENT = 0, C_USED7 = 1, C_USED10 = 2, C_WORDS = 4 };  // cache counters
+// per-call counters ("plan"): everything the host used to read back to size the next launches now stays on the device;
+// launches cover upper bounds and the kernels take their real extent from here
+enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_WORDS = 16 };
+constexpr u8 VERDICT_SUSPECT = 3;  // the bare-formula ecmult met Z = 0: the complete form decides (k_ecmult_keyed_careful)
+
+LAMD_HD void key_words(u32 kw[17], const u8 *p, int len) {
+#pragma unroll 1
+  for (int w = 0; w < 17; w++) {
+    u32 v = 0;
+    for (int b = 0; b < 4; b++) {
+      const int k = 4 * w + b;
+      if (k < len) v |= (u32)p[k] << (8 * b);
+    }
+    kw[w] = v;
+  }
+  kw[16] |= (u32)len << 8;
+}
+LAMD_HD u64 key_words_hash(const u32 kw[17], u64 seed) {
+  u64 h = seed;
+#pragma unroll 1
+  for (int w = 0; w < 16; w += 2) h = splitmix64(h ^ ((u64)kw[w] | ((u64)kw[w + 1] << 32)));
+  return splitmix64(h ^ kw[16]);
+}
+
+// one thread per row: probe the cache; hits go straight onto the row list of their comb shape
+__global__ void __launch_bounds__(256) k_cache_lookup(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride, u64 seed,
+                                                      const u32 *index, u32 mask, const cache_ent *ents, cache_vis vis,
+                                                      u32 *__restrict__ row_ent, u32 *__restrict__ plan, u32 *__restrict__ list7,
+                                                      u32 *__restrict__ list10, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  u32 found = ENT_NONE, T = 255;
+  if (live) {
+    u32 kw[17];
+    key_words(kw, keys + stride * i, keylen);
+    u32 slot = (u32)key_words_hash(kw, seed) & mask;
+    for (int probe = 0; probe < 64; probe++) {
+      const u32 id = index[slot];
+      if (id == 0u) break;
+      const cache_ent *e = ents + (id - 1u);
+      const u32 seq = e->seq, meta = e->meta;
+      if (seq != 0u && seq <= vis.seq[(meta >> 8) & 15u]) {
+        bool same = true;
+#pragma unroll 1
+        for (int w = 0; w < 17; w++) same &= e->kw[w] == kw[w];
+        if (same) { found = id - 1u; T = meta & 0xFFu; break; }
+      }
+      slot = (slot + 1u) & mask;
+    }
+    row_ent[i] = found;
+  }
+  const u32 p7 = wave_alloc(&plan[P_L7], T == 7u), p10 = wave_alloc(&plan[P_L10], T == 10u);
+  (void)wave_alloc(&plan[P_HITS], found != ENT_NONE);
+  if (T == 7u) list7[p7] = (u32)i;
+  else if (T == 10u) list10[p10] = (u32)i;
+  else if (T == 0u) {  // a key that does not parse
+    out[i] = 0;
+    if (keyok_row) keyok_row[i] = 0;
+  }
+}
+
+// open-addressing table of row indices (+1) over the rows the cache did not know; the first row to claim a slot represents its key
 __global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride, u64 seed,
-                                                       u32 *__restrict__ table, u32 mask, u32 *__restrict__ rep) {
+                                                       const u32 *__restrict__ row_ent, u32 *__restrict__ table, u32 mask,
+                                                       u32 *__restrict__ rep) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (row_ent[i] != ENT_NONE) { rep[i] = ENT_NONE; return; }
   const u8 *k = keys + stride * i;
   u32 slot = (u32)key_hash(k, keylen, seed) & mask;
   for (;;) {
@@ -501,21 +580,20 @@ __global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__res
   }
 }
 __global__ void __launch_bounds__(256) k_dedupe_number(size_t n, const u32 *__restrict__ rep, u32 *__restrict__ uid,
-                                                       u32 *__restrict__ counter, u32 *__restrict__ uniq_row) {
+                                                       u32 *__restrict__ plan, u32 *__restrict__ uniq_row) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool is_rep = i < n && rep[i] == (u32)i;
-  const u32 u = wave_alloc(counter, is_rep);
+  const u32 u = wave_alloc(&plan[P_UNIQ], is_rep);
   if (is_rep) {
     uid[i] = u;
     uniq_row[u] = (u32)i;
   }
 }
 __global__ void __launch_bounds__(256) k_dedupe_map(size_t n, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
-                                                    u32 *__restrict__ key_id, u32 *__restrict__ count) {
+                                                    u32 *__restrict__ count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
+  const bool live = i < n && rep[i] != ENT_NONE;
   const u32 k = live ? uid[rep[i]] : 0u;
-  if (live) key_id[i] = k;
   // count[k] += 1, combined per wave and key: neighbouring rows often share a key (the 483 HTLC signatures of one
   // commitment), and 64 same-address atomics from one wave serialise
   const u32 lane = threadIdx.x & 63u;
@@ -528,39 +606,87 @@ __global__ void __launch_bounds__(256) k_dedupe_map(size_t n, const u32 *__restr
     todo &= ~same;
   }
 }
-// counters: [0] distinct keys, [1] hot keys, [2] rows under hot keys, [3]/[4] fill of the hot / cold row lists
-// a key is "hot" (gets a table) when at least min_uses rows carry it
+// one thread per distinct new key: keys carried by >= thr7 rows get a 7-tooth comb, by >= thr10 rows a 10-tooth comb (table
+// slot + cache entry allocated here, wave-aggregated; a full pool simply leaves the key without a table)
+struct cache_caps { u32 ent, t7, t10; };
 __global__ void __launch_bounds__(256) k_dedupe_classify(size_t n, const u32 *__restrict__ count, const u32 *__restrict__ uniq_row,
-                                                         u32 min_uses, u32 *__restrict__ counters, u32 *__restrict__ hotidx,
-                                                         u32 *__restrict__ hot_row) {
+                                                         u32 thr7, u32 thr10, u32 *__restrict__ plan, u32 *cc, cache_caps caps,
+                                                         u32 hk7_cap, u32 hk10_cap, u32 *__restrict__ newent, u32 *__restrict__ hk7_row,
+                                                         u32 *__restrict__ hk7_ent, u32 *__restrict__ hk7_slot, u32 *__restrict__ hk10_row,
+                                                         u32 *__restrict__ hk10_ent, u32 *__restrict__ hk10_slot) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = u < n && u < counters[0];
+  const bool live = u < n && u < plan[P_UNIQ];
   const u32 c = live ? count[u] : 0u;
-  const bool hot = live && c >= min_uses;
-  const u32 h = wave_alloc(&counters[1], hot, c, &counters[2]);
-  if (hot) {
-    hotidx[u] = h;
-    hot_row[h] = uniq_row[u];
-  } else if (live) {
-    hotidx[u] = 0xFFFFFFFFu;
+  const bool want10 = live && c >= thr10;
+  const u32 s10 = wave_alloc(&cc[C_USED10], want10);
+  const bool ok10 = want10 && s10 < caps.t10;
+  const bool want7 = live && !ok10 && c >= (thr7 < thr10 ? thr7 : thr10);
+  const u32 s7 = wave_alloc(&cc[C_USED7], want7);
+  const bool ok7 = want7 && s7 < caps.t7;
+  const u32 eid = wave_alloc(&cc[C_ENT], ok7 | ok10);
+  const bool oke = (ok7 | ok10) && eid < caps.ent;
+  const u32 j7 = wave_alloc(&plan[P_HK7], oke && ok7), j10 = wave_alloc(&plan[P_HK10], oke && ok10);
+  bool placed = false;
+  if (oke && ok7 && j7 < hk7_cap) { hk7_row[j7] = uniq_row[u]; hk7_ent[j7] = eid; hk7_slot[j7] = s7; placed = true; }
+  if (oke && ok10 && j10 < hk10_cap) { hk10_row[j10] = uniq_row[u]; hk10_ent[j10] = eid; hk10_slot[j10] = s10; placed = true; }
+  if (live) newent[u] = placed ? eid : ENT_NONE;
+}
+// the new keys' cache entries (after their tables are complete) and, in cache mode, their index slots
+__global__ void __launch_bounds__(256) k_cache_publish(const u32 *__restrict__ plan, int which, u32 cap, const u32 *__restrict__ hk_row,
+                                                       const u32 *__restrict__ hk_ent, const u32 *__restrict__ hk_slot,
+                                                       const u8 *__restrict__ keyok, const u8 *__restrict__ keys, int keylen, size_t stride,
+                                                       u32 T, u32 lane, u32 seq, u64 seed, cache_ent *ents, u32 *index, u32 mask, int do_index) {
+  const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 cnt = plan[which] < cap ? plan[which] : cap;
+  if (j >= cnt) return;
+  cache_ent e;
+  key_words(e.kw, keys + stride * (size_t)hk_row[j], keylen);
+  e.meta = (keyok[j] ? T : 0u) | (lane << 8);
+  e.seq = seq;
+  e.tabslot = hk_slot[j];
+  const u32 id = hk_ent[j];
+  ents[id] = e;
+  if (!do_index) return;
+  __threadfence();
+  u32 slot = (u32)key_words_hash(e.kw, seed) & mask;
+  for (;;) {  // the index is at least twice the entry capacity: a free slot exists
+    if (atomicCAS(&index[slot], 0u, id + 1u) == 0u) break;
+    slot = (slot + 1u) & mask;
   }
 }
-__global__ void __launch_bounds__(256) k_dedupe_partition(size_t n, const u32 *__restrict__ key_id, const u32 *__restrict__ hotidx,
-                                                          u32 *__restrict__ counters, u32 *__restrict__ list_hot, u32 *__restrict__ list_cold) {
+// rows the cache did not know: those whose key just got a table join the row list of its shape, the rest take the ladder
+__global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ row_ent, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
+                                                   const u32 *__restrict__ newent, const cache_ent *__restrict__ ents, u32 *__restrict__ plan,
+                                                   u32 *__restrict__ list7, u32 *__restrict__ list10, u32 *__restrict__ listcold,
+                                                   u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  const bool hot = live && hotidx[key_id[i]] != 0xFFFFFFFFu;
-  const u32 ph = wave_alloc(&counters[3], hot);
-  const u32 pc = wave_alloc(&counters[4], live && !hot);
-  if (hot) list_hot[ph] = (u32)i;
-  else if (live) list_cold[pc] = (u32)i;
+  const bool miss = i < n && rep[i] != ENT_NONE;
+  u32 T = 255;
+  if (miss) {
+    const u32 e = newent[uid[rep[i]]];
+    if (e != ENT_NONE) {
+      row_ent[i] = e;
+      T = ents[e].meta & 0xFFu;
+    }
+  }
+  const u32 p7 = wave_alloc(&plan[P_L7], miss && T == 7u), p10 = wave_alloc(&plan[P_L10], miss && T == 10u);
+  const u32 pc = wave_alloc(&plan[P_COLD], miss && T == 255u);
+  if (!miss) return;
+  if (T == 7u) list7[p7] = (u32)i;
+  else if (T == 10u) list10[p10] = (u32)i;
+  else if (T == 0u) {
+    out[i] = 0;
+    if (keyok_row) keyok_row[i] = 0;
+  } else listcold[pc] = (u32)i;
 }
 // key tables, four stages (verify_core.h "Building one key's table"): bases and prefix run one thread per key, the
-// chains and the rescale one thread per (key, 16-entry chain) so that a few hundred keys still fill the chip
+// chains and the rescale one thread per (key, 16-entry chain) so that a few hundred keys still fill the chip.
+// nkeys = min(plan[which], cap); key u's table lives in slot slots[u] of the pool.
 template <int T>
-__global__ void __launch_bounds__(256) k_kc_bases(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
-                                                  u32 *__restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_kc_bases(const u32 *__restrict__ plan, int which, u32 cap, const u32 *__restrict__ qwords,
+                                                  const u8 *__restrict__ keyok, u32 *__restrict__ scratch) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nkeys = plan[which] < cap ? plan[which] : cap;
   if (u >= nkeys || !keyok[u]) return;
   u32 qx[8], qy[8];
 #pragma unroll
@@ -568,50 +694,60 @@ __global__ void __launch_bounds__(256) k_kc_bases(size_t nkeys, const u32 *__res
   kc_bases<T>(scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
 }
 template <int T>
-__global__ void __launch_bounds__(256) k_kc_chain_fwd(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
-                                                  u32 *__restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_kc_chain_fwd(const u32 *__restrict__ plan, int which, u32 cap, const u8 *__restrict__ keyok,
+                                                      u32 *__restrict__ pool, const u32 *__restrict__ slots, u32 *__restrict__ scratch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t u = t / kc_nsub(T);
+  const u32 nkeys = plan[which] < cap ? plan[which] : cap;
   if (u >= nkeys || !keyok[u]) return;
-  kc_chain_fwd<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
+  kc_chain_fwd<T>(pool + (size_t)slots[u] * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
 }
 template <int T>
-__global__ void __launch_bounds__(256) k_kc_prefix(size_t nkeys, const u32 *__restrict__ qwords, const u8 *__restrict__ keyok,
-                                                   u32 *__restrict__ tables, u32 *__restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_kc_prefix(const u32 *__restrict__ plan, int which, u32 cap, const u32 *__restrict__ qwords,
+                                                   const u8 *__restrict__ keyok, u32 *__restrict__ pool, const u32 *__restrict__ slots,
+                                                   u32 *__restrict__ scratch) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 nkeys = plan[which] < cap ? plan[which] : cap;
   if (u >= nkeys || !keyok[u]) return;
   u32 qx[8], qy[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) { qx[i] = qwords[u * 16 + i]; qy[i] = qwords[u * 16 + 8 + i]; }
-  kc_prefix<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
+  kc_prefix<T>(pool + (size_t)slots[u] * kc_stride(T), scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
 }
 template <int T>
-__global__ void __launch_bounds__(256) k_kc_chain_bwd(size_t nkeys, const u8 *__restrict__ keyok, u32 *__restrict__ tables,
-                                                    const u32 *__restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_kc_chain_bwd(const u32 *__restrict__ plan, int which, u32 cap, const u8 *__restrict__ keyok,
+                                                      u32 *__restrict__ pool, const u32 *__restrict__ slots, const u32 *__restrict__ scratch) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t u = t / kc_nsub(T);
+  const u32 nkeys = plan[which] < cap ? plan[which] : cap;
   if (u >= nkeys || !keyok[u]) return;
-  kc_chain_bwd<T>(tables + u * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
+  kc_chain_bwd<T>(pool + (size_t)slots[u] * kc_stride(T), scratch + u * kc_scratch_words(T), (int)(t % kc_nsub(T)));
 }
 template <int T>
-static void launch_keytables(hipStream_t st, size_t nkeys, const u32 *qwords, const u8 *keyok, u32 *tables, u32 *scratch) {
-  const size_t chains = nkeys * kc_nsub(T);
-  hipLaunchKernelGGL((k_kc_bases<T>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, scratch);
-  hipLaunchKernelGGL((k_kc_chain_fwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, scratch);
-  hipLaunchKernelGGL((k_kc_prefix<T>), dim3((unsigned)((nkeys + 255) / 256)), dim3(256), 0, st, nkeys, qwords, keyok, tables, scratch);
-  hipLaunchKernelGGL((k_kc_chain_bwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, nkeys, keyok, tables, (const u32 *)scratch);
+static void launch_keytables(hipStream_t st, const u32 *plan, int which, size_t cap, const u32 *qwords, const u8 *keyok, u32 *pool,
+                             const u32 *slots, u32 *scratch) {
+  const size_t chains = cap * kc_nsub(T);
+  hipLaunchKernelGGL((k_kc_bases<T>), dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, plan, which, (u32)cap, qwords, keyok, scratch);
+  hipLaunchKernelGGL((k_kc_chain_fwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, plan, which, (u32)cap, keyok, pool, slots, scratch);
+  hipLaunchKernelGGL((k_kc_prefix<T>), dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, plan, which, (u32)cap, qwords, keyok, pool, slots, scratch);
+  hipLaunchKernelGGL((k_kc_chain_bwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, plan, which, (u32)cap, keyok, pool, slots,
+                     (const u32 *)scratch);
 }
 
-// work item j verifies row list[j] against the table of its (hot) key
-template <int T>
-__global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *__restrict__ list, const prep_rec *__restrict__ recs,
-                                                      const u32 *__restrict__ key_id, const u32 *__restrict__ hotidx,
-                                                      const u8 *__restrict__ keyok_u, const u32 *__restrict__ tables,
+// work item j verifies row list[j] against the comb table of its key (plan[which] rows; the launch covers an upper bound).
+// The hot form: bare addition formulas, one Z == 0 test at the end; a lane that meets it reports VERDICT_SUSPECT and
+// k_ecmult_keyed_careful decides that row with the complete formulas.
+template <int T, bool CAREFUL, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, int which, const u32 *__restrict__ list,
+                                                      const prep_rec *__restrict__ recs, const u32 *__restrict__ row_ent,
+                                                      const cache_ent *__restrict__ ents, const u32 *__restrict__ pool,
                                                       const u8 *__restrict__ sig64, int mode, const u32 *__restrict__ gtable,
                                                       u32 *__restrict__ fin, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nlist) return;
+  if (j >= plan[which]) return;
+  if (CAREFUL && plan[P_SUSPECT] == 0) return;
   const size_t i = list[j];
+  if (CAREFUL && out[i] != VERDICT_SUSPECT) return;
   prep_rec rec;
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
@@ -622,12 +758,23 @@ __global__ void __launch_bounds__(256) k_ecmult_keyed(size_t nlist, const u32 *_
     rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
     rec.flags = e.x;
   }
-  const u32 kid = hotidx[key_id[i]];
-  const bool kok = keyok_u[kid];
-  keyok_row[i] = kok;
-  bool ok = (rec.flags & PREP_VALID) && kok;
+  const cache_ent *ce = ents + row_ent[i];
+  const u32 *tab = pool + (size_t)ce->tabslot * kc_stride(T);
+  if (!CAREFUL && keyok_row) keyok_row[i] = 1;  // rows on these lists have a parsed key (the others were rejected by lookup / partition)
+  bool ok = (rec.flags & PREP_VALID) != 0;
   if (ok) {
-    const gej R = ecmult_lane_keyed<T>(rec, tables + (size_t)kid * kc_stride(T), gtable);
+    gej R;
+    if (CAREFUL) {
+      R = ecmult_lane_keyed<T>(rec, tab, gtable);
+    } else {
+      bool suspect;
+      R = ecmult_lane_keyed_fast<T>(rec, tab, gtable, &suspect);
+      if (suspect) {
+        out[i] = VERDICT_SUSPECT;
+        atomicAdd(&plan[P_SUSPECT], 1u);
+        return;
+      }
+    }
     u32 rw[8];
     load_words_be(rw, sig64 + 64 * i);
     if (mode == MODE_ECDSA) {
@@ -657,7 +804,6 @@ struct devbuf {
 };
 
 enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
-constexpr int MAX_LANES = 8;
 constexpr int QUEUE_SETS = 5;
 
 struct lamd_ctx {
@@ -668,27 +814,52 @@ struct lamd_ctx {
   std::string err;
   // per-call workspaces (grown on demand, reused)
   devbuf recs, qwords, keyok, slots;
-  devbuf kd_table, kd_rep, kd_uid, kd_keyid, kd_uniq, kd_counter, kt_tables, kt_scratch, kt_qwords, kt_keyok, kt_fin;  // keyed path
-  devbuf kd_count, kd_hotidx, kd_hotrow, kd_listhot, kd_listcold, keyok_row;
+  // keyed path: row -> cache entry, de-duplication of the rows the cache did not know, new keys per comb shape (hk7 / hk10:
+  // representative row, cache entry, table slot; parsed key, validity, build scratch), row lists per shape + cold rows
+  devbuf row_ent, kd_table, kd_rep, kd_uid, kd_uniq, kd_count, kd_newent, plan, kt_fin;
+  devbuf hk7_row, hk7_ent, hk7_slot, hk7_qwords, hk7_keyok, hk7_scratch, hk10_row, hk10_ent, hk10_slot, hk10_qwords, hk10_keyok, hk10_scratch;
+  devbuf list7, list10, listcold;
+  u32 *h_plan = nullptr;   // pinned read-back of the last call's plan + cache counters (statistics only: nothing waits for it)
+  // Key-table cache.  The root context owns the shared one (LAMD_CACHE=1, default): entries + index + one table pool per
+  // comb shape, filled by whichever lane meets a key often enough, looked up by every later call.  With LAMD_CACHE=0 every
+  // lane uses its own private instance without an index, reset at the start of each call (tables live for one call).
+  struct key_cache {
+    bool shared = false;
+    u32 cap_ent = 0, cap7 = 0, cap10 = 0, index_mask = 0;
+    devbuf ents, index, pool7, pool10, counters;
+  } cache_store;
+  key_cache *cache = nullptr;       // what this context's calls use (lanes: the root's when shared)
+  lamd_ctx *root = nullptr;         // lanes: the context that owns them
+  int lane_id = 0;                  // 0 = the root context itself, 1.. = lanes
+  u32 call_seq = 0;                 // root: sequence number of the last submitted keyed call
+  u32 pub_seq[MAX_LANES + 1] = {};  // root: per lane (by lane_id), the sequence number of its last publishing call ...
+  hipEvent_t ev_pub[MAX_LANES + 1] = {};   // ... and the event recorded after it
+  u32 vis_seq[MAX_LANES + 1] = {};  // root: per lane, the newest publishing call the host has SEEN complete
+  bool pub_pending[MAX_LANES + 1] = {};
+  int cache_mode = 1;               // LAMD_CACHE
+  size_t cache_keys = (size_t)1 << 20, cache_keys10 = (size_t)1 << 16;   // LAMD_CACHE_KEYS / LAMD_CACHE_KEYS10
+  u32 cache_hwm[3] = {0, 0, 0};     // root: last counters read back (entries, 7-tooth slots, 10-tooth slots)
+  u32 cache_resets = 0;
+  size_t last_hits = 0, last_cold = 0, last_l7 = 0, last_l10 = 0;
+  devbuf keyok_row;
   hipStream_t stream2 = nullptr;   // scalar prep runs here, concurrently with the key work on `stream`
   hipStream_t stream3 = nullptr;   // cold rows of a partitioned chunk
   hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr;
-  size_t last_hot_rows = 0;
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
   double keyed_dense_uses = 48.0;  // ... and for the 10-tooth comb (512 entries per key)
   int keyed_teeth = 0;             // 0 = choose by re-use, 7 or 10 = force that comb (LAMD_KEYED_TEETH)
-  int last_teeth = 0;
   int last_mode = 0;
-  size_t last_unique_keys = 0;
-  bool last_keyed = false;
+  size_t last_n = 0;
+  bool last_keyed_call = false;
   devbuf in_a, in_b, in_c, out;       // staging for the host-buffer API
   devbuf g_msgs, g_off, g_ids, g_rowbase, g_hash, g_sig, g_pub, g_malformed, g_ok, g_verdict;
   // timing
   bool timing = false;
   bool ev_recorded = false;
   int ecmult_waves = 3;
+  int keyed_waves = 4;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3 or 4)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
   u64 hash_seed = 0x243F6A8885A308D3ULL;
   size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
@@ -716,7 +887,6 @@ struct lamd_ctx {
   // next lane; the root context (the handle the caller holds) keeps its own stream for staging, queues, generators.
   lamd_ctx *lane[MAX_LANES] = {};
   int nlanes = 0;
-  u32 *h_counts = nullptr;  // pinned host words for the de-duplication counters' read-back
   lamd_ctx *peer = nullptr;
   lamd_ctx *last_lane = nullptr;
   lamd_ctx *last_chunk_lane = nullptr;  // where the last chunk of this lane's last call ran (itself or its peer)
@@ -777,6 +947,9 @@ extern "C" const char *lamd_version(void) { return "lightning_amd 0.1 (gfx950)";
 extern "C" const char *lamd_last_error(const lamd_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 static int init_known_answers(lamd_ctx *ctx);
+static int cache_alloc(lamd_ctx *owner, lamd_ctx::key_cache *kc, size_t keys7, size_t keys10, bool shared);
+static int cache_reset(lamd_ctx *root);
+static int cache_maybe_reset(lamd_ctx *root);
 
 static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -785,7 +958,10 @@ static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
-  HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, 64, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_plan, (P_WORDS + C_WORDS) * 4, hipHostMallocDefault));
+  memset(ctx->h_plan, 0, (P_WORDS + C_WORDS) * 4);
+  if (!ctx->is_lane)
+    for (auto &e : ctx->ev_pub) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
@@ -799,10 +975,14 @@ static int make_lanes(lamd_ctx *root, int count) {
     if (!L) return LAMD_ERR_NOMEM;
     root->lane[i] = L;
     L->is_lane = true;
+    L->root = root;
+    L->lane_id = i + 1;
+    L->cache_mode = root->cache_mode;
     L->device = root->device;
     L->prop = root->prop;
     L->gtable = root->gtable;
     L->ecmult_waves = root->ecmult_waves;
+    L->keyed_waves = root->keyed_waves;
     L->prep_batch = root->prep_batch;
     L->hash_seed = root->hash_seed;
     L->chunk = root->chunk;
@@ -821,6 +1001,8 @@ static int make_lanes(lamd_ctx *root, int count) {
 // the lane the next device-pointer call runs on, ordered after whatever is already queued on the context's own stream
 static int pick_lane(lamd_ctx *root, lamd_ctx **out) {
   *out = root;
+  const int rcc = cache_maybe_reset(root);
+  if (rcc != LAMD_OK) return rcc;
   if (!root->lane[0]) return LAMD_OK;
   lamd_ctx *L = root->lane[root->next_lane];
   root->next_lane = (root->next_lane + 1) % root->nlanes;
@@ -849,6 +1031,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     return LAMD_ERR_NO_DEVICE;
   }
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
+  if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 3 ? 3 : 4;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   {
     std::random_device rd;
@@ -860,6 +1043,9 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
   if (const char *w = getenv("LAMD_KEYED_TEETH")) ctx->keyed_teeth = atoi(w) == 7 ? 7 : (atoi(w) == 10 ? 10 : 0);
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
+  if (const char *w = getenv("LAMD_CACHE")) ctx->cache_mode = atoi(w) != 0;
+  if (const char *w = getenv("LAMD_CACHE_KEYS")) ctx->cache_keys = (size_t)atoll(w) < 64 ? 64 : (size_t)atoll(w);
+  if (const char *w = getenv("LAMD_CACHE_KEYS10")) ctx->cache_keys10 = (size_t)atoll(w) < 16 ? 16 : (size_t)atoll(w);
   int rc = create_streams(ctx);
   if (rc != LAMD_OK) return rc;
   // window bases B_w = 2^(16 w) G, computed here with the same group code the kernels use (64 doublings each)
@@ -887,6 +1073,11 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipFree(d_bases));
+  if (ctx->cache_mode) {  // the shared key-table cache: entries, index, one table pool per comb shape
+    if ((rc = cache_alloc(ctx, &ctx->cache_store, ctx->cache_keys, ctx->cache_keys10, true)) != LAMD_OK) return rc;
+    if ((rc = cache_reset(ctx)) != LAMD_OK) return rc;
+    ctx->cache_resets = 0;
+  }
   const char *lanes = getenv("LAMD_LANES");
   const int nl = lanes ? atoi(lanes) : 4;
   if (nl > 1) {
@@ -904,10 +1095,14 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     L = nullptr;
   }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (devbuf *b : {&ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kd_counter, &ctx->kt_tables,
-                    &ctx->kt_scratch, &ctx->kt_qwords, &ctx->kt_keyok, &ctx->kt_fin, &ctx->kd_count, &ctx->kd_hotidx, &ctx->kd_hotrow,
-                    &ctx->kd_listhot, &ctx->kd_listcold, &ctx->keyok_row})
+  for (devbuf *b : {&ctx->row_ent, &ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->plan,
+                    &ctx->kt_fin, &ctx->hk7_row, &ctx->hk7_ent, &ctx->hk7_slot, &ctx->hk7_qwords, &ctx->hk7_keyok, &ctx->hk7_scratch,
+                    &ctx->hk10_row, &ctx->hk10_ent, &ctx->hk10_slot, &ctx->hk10_qwords, &ctx->hk10_keyok, &ctx->hk10_scratch, &ctx->list7,
+                    &ctx->list10, &ctx->listcold, &ctx->keyok_row, &ctx->cache_store.ents, &ctx->cache_store.index, &ctx->cache_store.pool7,
+                    &ctx->cache_store.pool10, &ctx->cache_store.counters})
     release(b);
+  for (auto &e : ctx->ev_pub)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
   if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
   if (ctx->ev_cold) (void)hipEventDestroy(ctx->ev_cold);
@@ -926,7 +1121,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     if (qs.done) (void)hipEventDestroy(qs.done);
   }
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
-  if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+  if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
@@ -997,6 +1192,7 @@ extern "C" int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info) {
   return rc;
 }
 static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
+  lamd_ctx *root = ctx->root ? ctx->root : ctx;
   if (ctx->last_chunk_lane) ctx = ctx->last_chunk_lane;
   memset(info, 0, sizeof(*info));
   info->device = ctx->device;
@@ -1004,10 +1200,22 @@ static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   strncpy(info->arch, ctx->prop.gcnArchName, sizeof(info->arch) - 1);
   info->gtable_bytes = GTABLE_BYTES;
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
-  info->last_unique_keys = ctx->last_unique_keys;
-  info->last_hot_rows = ctx->last_hot_rows;
-  info->last_keyed = ctx->last_keyed ? ctx->last_teeth : 0;
   info->last_mode = ctx->last_mode;
+  // the counts of the last keyed call come from the pinned copy its stream wrote at the end: exact after lamd_synchronize()
+  if (ctx->last_keyed_call && ctx->h_plan) {
+    const volatile u32 *h = ctx->h_plan;
+    info->last_unique_keys = h[P_UNIQ];
+    info->last_hot_rows = (size_t)h[P_L7] + h[P_L10];
+    info->last_keyed = h[P_L10] ? 10 : (h[P_L7] ? 7 : 0);
+    info->last_cache_hits = h[P_HITS];
+    info->last_cold_rows = h[P_COLD];
+    info->last_new_tables = (size_t)h[P_HK7] + h[P_HK10];
+    info->last_suspect_rows = h[P_SUSPECT];
+  }
+  info->cache_enabled = root->cache_mode != 0 && root->cache_store.shared;
+  info->cache_entries = root->cache_hwm[0];
+  info->cache_capacity = root->cache_store.cap_ent;
+  info->cache_resets = root->cache_resets;
   return LAMD_OK;
 }
 
@@ -1029,32 +1237,84 @@ static size_t final_threads(lamd_ctx *ctx, size_t n) {
   return threads;
 }
 
-// Per-signature path over `m` work items (all rows when idx == nullptr, else the listed rows): keys -> ladder.
-// Prep records (indexed by row) must already be queued on stream2 / finished (ev_prep).
-static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, const prep_rec *recs, const u8 *d_sig, const u8 *d_key,
-                         int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it) {
+// Per-signature path over up to `m` work items (all rows when idx == nullptr, else the listed rows; count != nullptr: the
+// real number of items is *count, on the device): keys -> ladder.  Prep records (indexed by row) must already be queued
+// on stream2 / finished (ev_prep).
+static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, const u32 *count, const prep_rec *recs, const u8 *d_sig,
+                         const u8 *d_key, int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it) {
   int rc;
   if ((rc = ensure(ctx, &ctx->qwords, m * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->keyok, m)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->slots, m * SLOT_WORDS * 4)) != LAMD_OK) return rc;
   hipLaunchKernelGGL(k_keys, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, d_key, keylen, keystride, idx, (u32 *)ctx->qwords.p,
-                     (u8 *)ctx->keyok.p);
+                     (u8 *)ctx->keyok.p, count);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
   auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
   hipLaunchKernelGGL(kern, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, recs, (const u32 *)ctx->qwords.p, (const u8 *)ctx->keyok.p, d_sig,
-                     mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, idx, fin, keyok_row, d_ok);
+                     mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, idx, fin, keyok_row, d_ok, count);
   return LAMD_OK;
 }
 
-// One chunk (n <= ctx->chunk rows) entirely on the context's streams.  d_key: 33/65-byte SEC1 keys or 32-byte x-only.
-//  1. scalar prep for every row on stream2 (independent of the key work; joined by event before the ecmult kernels)
-//  2. big chunks: de-duplicate the keys on the device; keys carried by >= keyed_min_uses rows are "hot": each gets a
-//     comb table in HBM and its rows are verified by the table-driven kernel (18 doublings instead of 132); the other
-//     ("cold") rows take the per-signature ladder.  Small chunks skip 2 (latency-bound: per-signature ladder).
-static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
-                     size_t keystride, u8 *d_ok, bool time_it) {
+// ---- key-table cache plumbing
+static int cache_alloc(lamd_ctx *owner, lamd_ctx::key_cache *kc, size_t keys7, size_t keys10, bool shared) {
   int rc;
+  kc->shared = shared;
+  const size_t ents = keys7 + keys10;
+  if (ents > kc->cap_ent || keys7 > kc->cap7 || keys10 > kc->cap10) {
+    if ((rc = ensure(owner, &kc->ents, ents * sizeof(cache_ent))) != LAMD_OK) return rc;
+    if ((rc = ensure(owner, &kc->pool7, keys7 * kc_stride(7) * 4)) != LAMD_OK) return rc;
+    if ((rc = ensure(owner, &kc->pool10, keys10 * kc_stride(10) * 4)) != LAMD_OK) return rc;
+    if ((rc = ensure(owner, &kc->counters, C_WORDS * 4)) != LAMD_OK) return rc;
+    kc->cap_ent = (u32)ents;
+    kc->cap7 = (u32)keys7;
+    kc->cap10 = (u32)keys10;
+    if (shared) {
+      size_t m = 1;
+      while (m < 2 * ents) m <<= 1;
+      if ((rc = ensure(owner, &kc->index, m * 4)) != LAMD_OK) return rc;
+      kc->index_mask = (u32)(m - 1);
+    }
+  }
+  return LAMD_OK;
+}
+// empties the shared cache (every lane must be idle): entries, index and allocation counters back to zero
+static int cache_reset(lamd_ctx *root) {
+  lamd_ctx::key_cache *kc = &root->cache_store;
+  HIPCHK(root, hipDeviceSynchronize());
+  HIPCHK(root, hipMemset(kc->ents.p, 0, (size_t)kc->cap_ent * sizeof(cache_ent)));
+  HIPCHK(root, hipMemset(kc->index.p, 0, ((size_t)kc->index_mask + 1) * 4));
+  HIPCHK(root, hipMemset(kc->counters.p, 0, C_WORDS * 4));
+  for (int l = 0; l <= MAX_LANES; l++) { root->pub_seq[l] = root->vis_seq[l] = 0; root->pub_pending[l] = false; }
+  root->call_seq = 0;
+  root->cache_hwm[0] = root->cache_hwm[1] = root->cache_hwm[2] = 0;
+  for (lamd_ctx *L : root->lane)
+    if (L && L->h_plan) memset(L->h_plan, 0, (P_WORDS + C_WORDS) * 4);
+  if (root->h_plan) memset(root->h_plan, 0, (P_WORDS + C_WORDS) * 4);
+  root->cache_resets++;
+  return LAMD_OK;
+}
+extern "C" int lamd_cache_clear(lamd_ctx *ctx) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (ctx->cache_mode == 0 || !ctx->cache_store.shared) return LAMD_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return cache_reset(ctx);
+}
+
+// One chunk (n <= ctx->chunk rows) entirely on the context's streams; nothing in here waits for the device.
+// d_key: 33/65-byte SEC1 keys or 32-byte x-only.
+//  1. scalar prep for every row on stream2 (independent of the key work; joined by event before the ecmult kernels)
+//  2. rows whose key has a comb table in the cache go straight onto the row list of that comb shape
+//  3. the other rows are de-duplicated on the device; keys carried by enough of them get a table now (7 teeth: 38 additions
+//     + 18 doublings per signature instead of the ladder's 66 + 132; 10 teeth for heavily used keys: 26 + 12) and, in
+//     cache mode, an entry for the calls after this one; the remaining ("cold") rows take the per-signature ladder
+//  4. table-driven ecmult per comb shape, the ladder for the cold rows on a third stream
+// Every count in between (distinct keys, new tables, rows per list) stays on the device (`plan`): launches cover upper
+// bounds.  keyok_out (optional, n bytes): per-row key validity for the gossip reduce.
+static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
+                     size_t keystride, u8 *d_ok, u8 *keyok_out, bool time_it) {
+  int rc;
+  lamd_ctx *root = ctx->root ? ctx->root : ctx;
   if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
   prep_rec *recs = (prep_rec *)ctx->recs.p;
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
@@ -1069,101 +1329,166 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream2));
 
-  ctx->last_keyed = false;
   ctx->last_mode = mode;
-  ctx->last_unique_keys = 0;
-  ctx->last_hot_rows = 0;
-  size_t nhot = 0, hot_rows = 0;
-  const bool try_keyed = ctx->keyed_mode != 0 && (ctx->keyed_mode > 0 || n >= ctx->keyed_min_rows) && n < 0x7FFFFFFFu;
-  if (try_keyed) {
-    size_t m = 1;
-    while (m < 2 * n) m <<= 1;
-    if ((rc = ensure(ctx, &ctx->kd_table, m * 4)) != LAMD_OK) return rc;
-    for (devbuf *b : {&ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_hotidx, &ctx->kd_hotrow,
-                      &ctx->kd_listhot, &ctx->kd_listcold})
-      if ((rc = ensure(ctx, b, n * 4)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kd_counter, 32)) != LAMD_OK) return rc;
-    u32 *counters = (u32 *)ctx->kd_counter.p;
-    HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->kd_count.p, 0, n * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(counters, 0, 32, ctx->stream));
-    hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, ctx->hash_seed,
-                       (u32 *)ctx->kd_table.p, (u32)(m - 1), (u32 *)ctx->kd_rep.p);
-    hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
-                       counters, (u32 *)ctx->kd_uniq.p);
-    hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
-                       (u32 *)ctx->kd_keyid.p, (u32 *)ctx->kd_count.p);
-    const u32 min_uses = ctx->keyed_mode > 0 ? 2u : (u32)(ctx->keyed_min_uses + 0.5);
-    hipLaunchKernelGGL(k_dedupe_classify, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
-                       (const u32 *)ctx->kd_uniq.p, min_uses, counters, (u32 *)ctx->kd_hotidx.p, (u32 *)ctx->kd_hotrow.p);
-    u32 *h = ctx->h_counts;  // pinned: the copy is a plain DMA, no staging through a bounce buffer
-    HIPCHK(ctx, hipMemcpyAsync(h, counters, 12, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->last_unique_keys = h[0];
-    nhot = h[1];
-    hot_rows = h[2];
-    // tables only pay when enough rows ride on them
-    if (ctx->keyed_mode < 0 && hot_rows < ctx->keyed_min_rows) nhot = hot_rows = 0;
-  }
-  u8 *keyok_row = nullptr;
-  u32 *fin = nullptr;
-  if (nhot) {
-    // comb shape: 7 teeth (64 entries per key, 38 additions + 18 doublings per signature) unless the keys are re-used
-    // heavily enough to pay for 10 teeth (512 entries, 26 + 12)
-    const int T = ctx->keyed_teeth ? ctx->keyed_teeth : ((double)hot_rows >= ctx->keyed_dense_uses * (double)nhot ? 10 : 7);
-    const size_t stride_w = T == 10 ? kc_stride(10) : kc_stride(7);
-    const size_t scratch_w = T == 10 ? kc_scratch_words(10) : kc_scratch_words(7);
-    ctx->last_keyed = true;
-    ctx->last_teeth = T;
-    ctx->last_hot_rows = hot_rows;
-    if ((rc = ensure(ctx, &ctx->keyok_row, n)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kt_qwords, nhot * 64)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kt_keyok, nhot)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kt_tables, nhot * stride_w * 4)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->kt_scratch, nhot * scratch_w * 4)) != LAMD_OK) return rc;
-    if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
-    keyok_row = (u8 *)ctx->keyok_row.p;
-    fin = mode == MODE_SCHNORR ? (u32 *)ctx->kt_fin.p : nullptr;
+  ctx->last_n = n;
+  const bool use_cache = root->cache_mode != 0 && root->cache_store.shared;
+  // small batches are latency-bound: without a cache to consult they go straight to the ladder; with one, they are looked
+  // up, and only keys that fill most of the batch (a commitment's HTLC key) are worth a table of their own
+  const bool small = n < ctx->keyed_min_rows && ctx->keyed_mode <= 0;
+  const bool keyed = ctx->keyed_mode != 0 && n < 0x7FFFFFFFu && (use_cache || !small);
+  ctx->last_keyed_call = keyed;
+  if (!keyed) {
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(k_dedupe_partition, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_keyid.p,
-                       (const u32 *)ctx->kd_hotidx.p, (u32 *)ctx->kd_counter.p, (u32 *)ctx->kd_listhot.p, (u32 *)ctx->kd_listcold.p);
-    hipLaunchKernelGGL(k_keys, dim3(blocks_for(nhot)), dim3(256), 0, ctx->stream, nhot, d_key, keylen, keystride, (const u32 *)ctx->kd_hotrow.p,
-                       (u32 *)ctx->kt_qwords.p, (u8 *)ctx->kt_keyok.p);
-    {
-      auto lk = T == 10 ? launch_keytables<10> : launch_keytables<7>;
-      lk(ctx->stream, nhot, (const u32 *)ctx->kt_qwords.p, (const u8 *)ctx->kt_keyok.p, (u32 *)ctx->kt_tables.p, (u32 *)ctx->kt_scratch.p);
-    }
-    const size_t ncold = n - hot_rows;
-    if (ncold) {
-      // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few
-      // rows, i.e. a latency-bound launch that should hide behind the table work instead of serialising with it
-      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
-      hipStream_t main = ctx->stream;
-      ctx->stream = ctx->stream3;
-      rc = launch_direct(ctx, mode, ncold, (const u32 *)ctx->kd_listcold.p, recs, d_sig, d_key, keylen, keystride, fin, keyok_row, d_ok, false);
-      ctx->stream = main;
-      if (rc != LAMD_OK) return rc;
-      HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
-    }
-    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-    auto ke = T == 10 ? k_ecmult_keyed<10> : k_ecmult_keyed<7>;
-    hipLaunchKernelGGL(ke, dim3(blocks_for(hot_rows)), dim3(256), 0, ctx->stream, hot_rows,
-                       (const u32 *)ctx->kd_listhot.p, recs, (const u32 *)ctx->kd_keyid.p, (const u32 *)ctx->kd_hotidx.p,
-                       (const u8 *)ctx->kt_keyok.p, (const u32 *)ctx->kt_tables.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_row, d_ok);
-    if (ncold) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
-    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (mode == MODE_SCHNORR)
-      hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, fin, d_ok);
-  } else {
-    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    rc = launch_direct(ctx, mode, n, nullptr, recs, d_sig, d_key, keylen, keystride, nullptr, nullptr, d_ok, time_it);
+    rc = launch_direct(ctx, mode, n, nullptr, nullptr, recs, d_sig, d_key, keylen, keystride, nullptr, keyok_out, d_ok, time_it);
     if (rc != LAMD_OK) return rc;
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (mode == MODE_SCHNORR)
       hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
+    if (time_it) {
+      HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+      ctx->ev_recorded = true;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return LAMD_OK;
   }
+
+  // thresholds: rows per key that pay for a 7-tooth / a 10-tooth comb
+  u32 thr7 = ctx->keyed_mode > 0 ? 2u : (u32)(ctx->keyed_min_uses + 0.5), thr10 = (u32)(ctx->keyed_dense_uses + 0.5);
+  if (ctx->keyed_teeth == 7) thr10 = 0xFFFFFFFFu;
+  if (ctx->keyed_teeth == 10) { thr10 = thr7; thr7 = 0xFFFFFFFFu; }
+  if (small) {  // only a key that carries a large share of a small batch
+    thr7 = 0xFFFFFFFFu;
+    if (ctx->keyed_teeth != 7) thr10 = (u32)(ctx->keyed_dense_uses + 0.5);
+  }
+  if (thr7 < 2) thr7 = 2;
+  if (thr10 < 2) thr10 = 2;
+  const size_t hk7_cap = thr7 == 0xFFFFFFFFu ? 1 : n / thr7 + 1, hk10_cap = thr10 == 0xFFFFFFFFu ? 1 : n / thr10 + 1;
+  lamd_ctx::key_cache *kc = use_cache ? &root->cache_store : &ctx->cache_store;
+  if (!use_cache && (rc = cache_alloc(ctx, kc, hk7_cap, hk10_cap, false)) != LAMD_OK) return rc;
+  size_t m = 1;
+  while (m < 2 * n) m <<= 1;
+  if ((rc = ensure(ctx, &ctx->kd_table, m * 4)) != LAMD_OK) return rc;
+  for (devbuf *b : {&ctx->row_ent, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->list7, &ctx->list10,
+                    &ctx->listcold})
+    if ((rc = ensure(ctx, b, n * 4)) != LAMD_OK) return rc;
+  for (devbuf *b : {&ctx->hk7_row, &ctx->hk7_ent, &ctx->hk7_slot})
+    if ((rc = ensure(ctx, b, hk7_cap * 4)) != LAMD_OK) return rc;
+  for (devbuf *b : {&ctx->hk10_row, &ctx->hk10_ent, &ctx->hk10_slot})
+    if ((rc = ensure(ctx, b, hk10_cap * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->hk7_qwords, hk7_cap * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->hk7_keyok, hk7_cap)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->hk7_scratch, hk7_cap * kc_scratch_words(7) * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->hk10_qwords, hk10_cap * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->hk10_keyok, hk10_cap)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->hk10_scratch, hk10_cap * kc_scratch_words(10) * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->plan, P_WORDS * 4)) != LAMD_OK) return rc;
+  if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
+  u32 *plan = (u32 *)ctx->plan.p, *cc = (u32 *)kc->counters.p;
+  u32 *row_ent = (u32 *)ctx->row_ent.p, *list7 = (u32 *)ctx->list7.p, *list10 = (u32 *)ctx->list10.p, *listcold = (u32 *)ctx->listcold.p;
+  u32 *fin = mode == MODE_SCHNORR ? (u32 *)ctx->kt_fin.p : nullptr;
+  const cache_ent *ents = (const cache_ent *)kc->ents.p;
+
+  HIPCHK(ctx, hipMemsetAsync(plan, 0, P_WORDS * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->kd_count.p, 0, n * 4, ctx->stream));
+  u32 seq = 0;
+  if (use_cache) {
+    // what this call may use: entries published by calls the host has seen complete, or earlier on this lane's stream
+    for (int l = 0; l <= MAX_LANES; l++)
+      if (root->pub_pending[l] && hipEventQuery(root->ev_pub[l]) == hipSuccess) {
+        root->vis_seq[l] = root->pub_seq[l];
+        root->pub_pending[l] = false;
+      }
+    (void)hipGetLastError();
+    cache_vis vis;
+    for (int l = 0; l <= MAX_LANES; l++) vis.seq[l] = root->vis_seq[l];
+    vis.seq[ctx->lane_id] = root->pub_seq[ctx->lane_id];
+    seq = ++root->call_seq;
+    hipLaunchKernelGGL(k_cache_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                       (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok);
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(row_ent, 0xFF, n * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(cc, 0, C_WORDS * 4, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                     (const u32 *)row_ent, (u32 *)ctx->kd_table.p, (u32)(m - 1), (u32 *)ctx->kd_rep.p);
+  hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
+                     plan, (u32 *)ctx->kd_uniq.p);
+  hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
+                     (u32 *)ctx->kd_count.p);
+  cache_caps caps = {kc->cap_ent, kc->cap7, kc->cap10};
+  hipLaunchKernelGGL(k_dedupe_classify, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
+                     (const u32 *)ctx->kd_uniq.p, thr7, thr10, plan, cc, caps, (u32)hk7_cap, (u32)hk10_cap, (u32 *)ctx->kd_newent.p,
+                     (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
+                     (u32 *)ctx->hk10_slot.p);
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  // the new keys: parse, build their tables, publish
+  if (thr7 != 0xFFFFFFFFu) {
+    hipLaunchKernelGGL(k_keys, dim3(blocks_for(hk7_cap)), dim3(256), 0, ctx->stream, hk7_cap, d_key, keylen, keystride, (const u32 *)ctx->hk7_row.p,
+                       (u32 *)ctx->hk7_qwords.p, (u8 *)ctx->hk7_keyok.p, (const u32 *)(plan + P_HK7));
+    launch_keytables<7>(ctx->stream, plan, P_HK7, hk7_cap, (const u32 *)ctx->hk7_qwords.p, (const u8 *)ctx->hk7_keyok.p, (u32 *)kc->pool7.p,
+                        (const u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk7_scratch.p);
+    hipLaunchKernelGGL(k_cache_publish, dim3(blocks_for(hk7_cap)), dim3(256), 0, ctx->stream, (const u32 *)plan, (int)P_HK7, (u32)hk7_cap,
+                       (const u32 *)ctx->hk7_row.p, (const u32 *)ctx->hk7_ent.p, (const u32 *)ctx->hk7_slot.p, (const u8 *)ctx->hk7_keyok.p, d_key,
+                       keylen, keystride, 7u, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
+                       kc->index_mask, (int)use_cache);
+  }
+  if (thr10 != 0xFFFFFFFFu) {
+    hipLaunchKernelGGL(k_keys, dim3(blocks_for(hk10_cap)), dim3(256), 0, ctx->stream, hk10_cap, d_key, keylen, keystride, (const u32 *)ctx->hk10_row.p,
+                       (u32 *)ctx->hk10_qwords.p, (u8 *)ctx->hk10_keyok.p, (const u32 *)(plan + P_HK10));
+    launch_keytables<10>(ctx->stream, plan, P_HK10, hk10_cap, (const u32 *)ctx->hk10_qwords.p, (const u8 *)ctx->hk10_keyok.p, (u32 *)kc->pool10.p,
+                         (const u32 *)ctx->hk10_slot.p, (u32 *)ctx->hk10_scratch.p);
+    hipLaunchKernelGGL(k_cache_publish, dim3(blocks_for(hk10_cap)), dim3(256), 0, ctx->stream, (const u32 *)plan, (int)P_HK10, (u32)hk10_cap,
+                       (const u32 *)ctx->hk10_row.p, (const u32 *)ctx->hk10_ent.p, (const u32 *)ctx->hk10_slot.p, (const u8 *)ctx->hk10_keyok.p, d_key,
+                       keylen, keystride, 10u, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
+                       kc->index_mask, (int)use_cache);
+  }
+  if (use_cache) {
+    HIPCHK(ctx, hipEventRecord(root->ev_pub[ctx->lane_id], ctx->stream));
+    root->pub_seq[ctx->lane_id] = seq;
+    root->pub_pending[ctx->lane_id] = true;
+  }
+  hipLaunchKernelGGL(k_partition, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
+                     (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok);
+  // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few rows, i.e.
+  // a latency-bound launch that should hide behind the table-driven kernels instead of serialising with them
+  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+  {
+    hipStream_t main = ctx->stream;
+    ctx->stream = ctx->stream3;
+    rc = launch_direct(ctx, mode, n, (const u32 *)listcold, (const u32 *)(plan + P_COLD), recs, d_sig, d_key, keylen, keystride, fin, keyok_out,
+                       d_ok, false);
+    ctx->stream = main;
+    if (rc != LAMD_OK) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
+  }
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+  // (the bare-formula kernels fit 4 waves per SIMD with a 5-dword spill, or 3 without: LAMD_KEYED_WAVES)
+  auto fast7 = ctx->keyed_waves == 3 ? k_ecmult_keyed<7, false, 3> : k_ecmult_keyed<7, false, 4>;
+  auto fast10 = ctx->keyed_waves == 3 ? k_ecmult_keyed<10, false, 3> : k_ecmult_keyed<10, false, 4>;
+  const bool run7 = thr7 != 0xFFFFFFFFu || use_cache, run10 = thr10 != 0xFFFFFFFFu || use_cache;
+  if (run7)
+    hipLaunchKernelGGL(fast7, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs, (const u32 *)row_ent, ents,
+                       (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
+  if (run10)
+    hipLaunchKernelGGL(fast10, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs, (const u32 *)row_ent, ents,
+                       (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
+  // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
+  if (run7)
+    hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs,
+                       (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
+  if (run10)
+    hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs,
+                       (const u32 *)row_ent, ents, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
+  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  if (mode == MODE_SCHNORR)
+    hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, fin, d_ok);
+  // statistics (and the cache's fill level) for whoever looks later: nothing waits for this copy
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_plan, plan, P_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_plan + P_WORDS, cc, C_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (time_it) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     ctx->ev_recorded = true;
@@ -1172,8 +1497,26 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   return LAMD_OK;
 }
 
+// the shared cache is bounded: when the last fill level read back nears a capacity, drain the device and start over
+static int cache_maybe_reset(lamd_ctx *root) {
+  if (root->cache_mode == 0 || !root->cache_store.shared) return LAMD_OK;
+  const lamd_ctx::key_cache &kc = root->cache_store;
+  u32 hw[3] = {0, 0, 0};
+  for (int i = 0; i <= MAX_LANES; i++) {
+    const lamd_ctx *L = i < MAX_LANES ? root->lane[i] : root;
+    if (!L || !L->h_plan) continue;
+    for (int k = 0; k < 3; k++) {
+      const u32 v = ((volatile const u32 *)L->h_plan)[P_WORDS + k];
+      if (v > hw[k]) hw[k] = v;
+    }
+  }
+  for (int k = 0; k < 3; k++) root->cache_hwm[k] = hw[k];
+  if ((double)hw[0] > 0.9 * kc.cap_ent || (double)hw[1] > 0.9 * kc.cap7 || (double)hw[2] > 0.9 * kc.cap10) return cache_reset(root);
+  return LAMD_OK;
+}
+
 static int run_device(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
-                      size_t keystride, u8 *d_ok) {
+                      size_t keystride, u8 *d_ok, u8 *keyok_out = nullptr) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   bool forked = false;
   size_t k = 0;
@@ -1187,7 +1530,7 @@ static int run_device(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8
       forked = true;
     }
     const int rc = run_chunk(W, mode, m, d_a + 32 * o, d_sig + 64 * o, d_key + keystride * o, keylen, keystride, d_ok + o,
-                             ctx->timing && o + ctx->chunk >= n);
+                             keyok_out ? keyok_out + o : nullptr, ctx->timing && o + ctx->chunk >= n);
     ctx->last_chunk_lane = W;
     if (rc != LAMD_OK) {
       if (W != ctx) ctx->err = W->err;
@@ -1237,6 +1580,7 @@ static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *si
                     u8 *ok) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
+  if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_c, n * keystride)) != LAMD_OK) return rc;
@@ -1337,7 +1681,7 @@ extern "C" int lamd_pubkey_parse_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   if ((rc = ensure(ctx, &ctx->keyok, n)) != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_keys, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
-                     (const u32 *)nullptr, (u32 *)ctx->qwords.p, (u8 *)ctx->keyok.p);
+                     (const u32 *)nullptr, (u32 *)ctx->qwords.p, (u8 *)ctx->keyok.p, (const u32 *)nullptr);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ok, ctx->keyok.p, n, hipMemcpyDeviceToHost, ctx->stream));
   std::vector<u32> words;
@@ -1409,7 +1753,7 @@ static int recover_device(lamd_ctx *ctx, size_t n, const u8 *d_hash, const u8 *d
     hipLaunchKernelGGL(k_recover_prep, dim3(blocks_for(final_threads(ctx, m))), dim3(256), 0, ctx->stream, m, d_hash + 32 * o, d_sig + 64 * o,
                        d_recid + o, recs, (u8 *)ctx->g_pub.p);
     HIPCHK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
-    rc = launch_direct(ctx, MODE_RECOVER, m, nullptr, recs, d_sig + 64 * o, (const u8 *)ctx->g_pub.p, 33, 33, nullptr, nullptr, d_ok + o, false);
+    rc = launch_direct(ctx, MODE_RECOVER, m, nullptr, nullptr, recs, d_sig + 64 * o, (const u8 *)ctx->g_pub.p, 33, 33, nullptr, nullptr, d_ok + o, false);
     if (rc != LAMD_OK) return rc;
     hipLaunchKernelGGL(k_recover_final, dim3(blocks_for(final_threads(ctx, m))), dim3(256), 0, ctx->stream, m, (u32 *)ctx->slots.p, d_ok + o,
                        d_pub33 + 33 * o);
@@ -1508,42 +1852,26 @@ extern "C" int lamd_grind_htlc_tx_fee(lamd_ctx *ctx, const uint8_t *preimage, si
 }
 
 // ---- gossip
-// device core: everything resident; h_rowbase (host copy of d_rowbase) lets big batches be cut on message boundaries
-static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d_off, const u8 *d_ids, const u64 *d_rowbase,
-                         const u64 *h_rowbase, size_t rows, int8_t *d_verdict) {
+// device core: everything resident.  The signature rows of all messages form one ECDSA batch with 33-byte keys (cut into
+// chunks like any other batch: a message's rows may straddle a chunk); the reduce runs once over all messages.
+static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d_off, const u8 *d_ids, const u64 *d_rowbase, size_t rows,
+                         int8_t *d_verdict) {
   int rc;
   if ((rc = ensure(ctx, &ctx->g_hash, rows * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_sig, rows * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_pub, rows * 33 + 16)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_ok, rows)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->keyok_row, rows)) != LAMD_OK) return rc;
   hipLaunchKernelGGL(k_gossip_expand, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_msgs, d_off, d_ids, d_rowbase, (u8 *)ctx->g_hash.p,
                      (u8 *)ctx->g_sig.p, (u8 *)ctx->g_pub.p, (u8 *)ctx->g_malformed.p);
   HIPCHK(ctx, hipGetLastError());
-  // the rows form one ECDSA batch with 33-byte keys; every message's rows must live in one chunk because the
-  // reduce reads the chunk's key-validity bytes
-  size_t m0 = 0;
-  while (m0 < n) {
-    size_t m1 = n;
-    if (rows > ctx->chunk) {
-      if (!h_rowbase) {
-        ctx->err = "gossip batch larger than one chunk needs the host row table (use the host-buffer API or split the batch)";
-        return LAMD_ERR_ARG;
-      }
-      m1 = m0;
-      while (m1 < n && h_rowbase[m1 + 1] - h_rowbase[m0] <= ctx->chunk) m1++;
-      if (m1 == m0) m1 = m0 + 1;  // a single message never exceeds a chunk (at most 4 rows)
-    }
-    const size_t r0 = h_rowbase ? h_rowbase[m0] : 0, nr = (h_rowbase ? h_rowbase[m1] : rows) - r0;
-    rc = run_chunk(ctx, MODE_ECDSA, nr, (const u8 *)ctx->g_hash.p + 32 * r0, (const u8 *)ctx->g_sig.p + 64 * r0,
-                   (const u8 *)ctx->g_pub.p + 33 * r0, 33, 33, (u8 *)ctx->g_ok.p + r0, ctx->timing && m1 == n);
-    if (rc != LAMD_OK) return rc;
-    hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(m1 - m0)), dim3(256), 0, ctx->stream, m1 - m0, d_msgs, d_off + m0, d_rowbase + m0,
-                       (const u8 *)ctx->g_ok.p, (ctx->last_keyed ? (const u8 *)ctx->keyok_row.p : (const u8 *)ctx->keyok.p) - r0,
-                       (const u8 *)ctx->g_malformed.p + m0, d_verdict + m0);
-    HIPCHK(ctx, hipGetLastError());
-    m0 = m1;
-  }
+  rc = run_device(ctx, MODE_ECDSA, rows, (const u8 *)ctx->g_hash.p, (const u8 *)ctx->g_sig.p, (const u8 *)ctx->g_pub.p, 33, 33, (u8 *)ctx->g_ok.p,
+                  (u8 *)ctx->keyok_row.p);
+  if (rc != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_gossip_reduce, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_msgs, d_off, d_rowbase, (const u8 *)ctx->g_ok.p,
+                     (const u8 *)ctx->keyok_row.p, (const u8 *)ctx->g_malformed.p, d_verdict);
+  HIPCHK(ctx, hipGetLastError());
   return LAMD_OK;
 }
 
@@ -1563,8 +1891,7 @@ extern "C" int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const 
     if ((rc = ensure(L, &L->g_ids, 64)) != LAMD_OK) { ctx->err = L->err; return rc; }
     d_node_ids33 = L->g_ids.p;
   }
-  rc = gossip_device(L, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, nullptr, rows,
-                     (int8_t *)d_verdict);
+  rc = gossip_device(L, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, rows, (int8_t *)d_verdict);
   if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
   return rc;
 }
@@ -1607,7 +1934,7 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
   HIPCHK(ctx, hipMemcpyAsync(ctx->g_rowbase.p, rowbase.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   if (node_ids33) HIPCHK(ctx, hipMemcpyAsync(ctx->g_ids.p, node_ids33, n * 33, hipMemcpyHostToDevice, ctx->stream));
   rc = gossip_device(ctx, n, (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p, (const u8 *)ctx->g_ids.p, (const u64 *)ctx->g_rowbase.p,
-                     rowbase.data(), rows, (int8_t *)ctx->g_verdict.p);
+                     rows, (int8_t *)ctx->g_verdict.p);
   if (rc != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(verdict, ctx->g_verdict.p, n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2166,7 +2493,7 @@ extern "C" int lamd_fuzz_field(lamd_ctx *ctx, size_t lanes, int iters, uint64_t 
 // ---- diagnostic peek into the engine's device work buffers (tests / debugging only)
 extern "C" int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out) {
   if (!ctx || !out) return LAMD_ERR_ARG;
-  devbuf *bufs[] = {&ctx->recs, &ctx->keyok, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_keyid, &ctx->kd_uniq, &ctx->kt_keyok, &ctx->kt_qwords, &ctx->kt_tables};
+  devbuf *bufs[] = {&ctx->recs, &ctx->keyok, &ctx->kd_rep, &ctx->kd_uid, &ctx->row_ent, &ctx->kd_uniq, &ctx->hk7_keyok, &ctx->hk7_qwords, &ctx->cache_store.pool7};
   if (which < 0 || which >= (int)(sizeof(bufs) / sizeof(bufs[0])) || !bufs[which]->p || offset + nbytes > bufs[which]->cap) {
     ctx->err = "debug_read: no such buffer / out of range";
     return LAMD_ERR_ARG;

@@ -568,6 +568,144 @@ LAMD_HD comb_half<T> comb_from_rec(const u32 mag[4], u32 top) {
   return r;
 }
 
+// Both GLV halves as ODD magnitudes, so that the comb needs no repair additions: an even half is fixed in the scalar
+// domain by adding a vector of the GLV lattice {(x, y): x + y*lambda = 0 mod n} -- (a1, b1) has both components odd,
+// (a2, b2) = (even, odd), and (a1 - a2, b1 - b2) = (b1, b1 - a1) = (odd, even) (constants of glv_split, scalar.h) -- which
+// leaves k1 + k2*lambda unchanged and the halves below 2^128 + 1.09 * 2^128 < 2^130 <= 2^(T*D) for both combs.
+template <int T>
+struct comb_pair {
+  u32 tooth1[T], tooth2[T];
+  bool n1, n2;  // signs of the (adjusted) halves
+};
+LAMD_HD void s160_add(u32 r[5], const u32 a[5], const u32 b[5]) {
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) { c += (u64)a[i] + b[i]; r[i] = (u32)c; c >>= 32; }
+}
+LAMD_HD void s160_negate_if(u32 r[5], const u32 a[5], bool neg) {
+  const u32 m = neg ? 0xFFFFFFFFu : 0u;
+  u64 c = neg ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) { c += (u64)(a[i] ^ m); r[i] = (u32)c; c >>= 32; }
+}
+template <int T>
+LAMD_HD comb_pair<T> comb_from_rec_odd(const prep_rec &rec) {
+  constexpr int D = kc_spacing(T), N = T * D;
+  static_assert(N >= 130, "comb must cover the adjusted halves");
+  // |k_i| from the biased form (mag + top * 2^128 - 0x88..8), as signed 160-bit integers
+  u32 k[2][5];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const u32 *mag = h ? rec.k2 : rec.k1;
+    const u32 top = (rec.flags & (h ? PREP_K2TOP : PREP_K1TOP)) ? 1u : 0u;
+    u32 t[5];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u64 d = (u64)mag[i] - 0x88888888u - c;
+      t[i] = (u32)d;
+      c = (d >> 32) & 1;
+    }
+    t[4] = top - (u32)c;
+    s160_negate_if(k[h], t, (rec.flags & (h ? PREP_K2NEG : PREP_K1NEG)) != 0);
+  }
+  const bool e1 = (k[0][0] & 1u) == 0, e2 = (k[1][0] & 1u) == 0;
+  // lattice vectors as two's-complement words: A1 = a1, B1 = b1 = a1 - a2, A2 = a2, KY = b1 - a1
+  const u32 A1[5] = {0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u, 0x00000000u};
+  const u32 B1[5] = {0xF5401B3Du, 0x90AB8056u, 0xFEF177D7u, 0x1BBC8129u, 0xFFFFFFFFu};
+  const u32 A2[5] = {0x9D44CFD8u, 0x57C1108Du, 0xA8E2F3F6u, 0x14CA50F7u, 0x00000001u};
+  const u32 KY[5] = {0x62BB3028u, 0xA83EEF72u, 0x571D0C09u, 0xEB35AF08u, 0xFFFFFFFEu};
+  u32 ax[5], ay[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    // both even: (a1, b1); k1 even only: (b1, b1 - a1); k2 even only: (a2, a1); both odd: nothing
+    ax[i] = e1 ? (e2 ? A1[i] : B1[i]) : (e2 ? A2[i] : 0u);
+    ay[i] = e1 ? (e2 ? B1[i] : KY[i]) : (e2 ? A1[i] : 0u);
+  }
+  s160_add(k[0], k[0], ax);
+  s160_add(k[1], k[1], ay);
+  comb_pair<T> r;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const bool neg = (k[h][4] >> 31) != 0;
+    u32 m[6];
+    s160_negate_if(m, k[h], neg);
+    m[5] = 0;
+    LAMD_ASSERT((m[0] & 1u) == 1u && m[4] < 4u);
+    u32 w[6];
+#pragma unroll
+    for (int i = 0; i < 5; i++) w[i] = (m[i] >> 1) | (m[i + 1] << 31);
+    w[5] = 0;
+    w[(N - 1) >> 5] |= 1u << ((N - 1) & 31);
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+      const int word = (i * D) >> 5, sh = (i * D) & 31;
+      u32 v = w[word] >> sh;
+      if (sh + D > 32) v |= w[word + 1] << (32 - sh);
+      (h ? r.tooth2 : r.tooth1)[i] = v & ((1u << D) - 1u);
+    }
+    (h ? r.n2 : r.n1) = neg;
+  }
+  return r;
+}
+
+// The hot form of the table-driven ecmult: both halves odd (no repair additions), the first column initialises the
+// accumulator (no infinity handling), every addition is the bare formula (gej_add_ge_fast) and the G windows skip a zero
+// digit by branching.  Degenerate events (an addition meeting +-its operand: adversarial scalars only, or the result being
+// infinity) leave Z = 0, which the caller tests ONCE: *suspect = true means "verdict unknown, run ecmult_lane_keyed".
+template <int T>
+LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u32 *gtable, bool *suspect) {
+  constexpr int D = kc_spacing(T), NE = kc_ne(T);
+  const comb_pair<T> cp = comb_from_rec_odd<T>(rec);
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int j = D - 1; j >= 0; j--) {
+    if (j != D - 1) acc = gej_double(acc);
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      u32 m = 0;
+#pragma unroll
+      for (int i = 0; i < T; i++) m |= (((half ? cp.tooth2[i] : cp.tooth1[i]) >> j) & 1u) << i;
+      const bool top = (m >> (T - 1)) & 1u;
+      const u32 idx = (top ? m : ~m) & (u32)(NE - 1);
+      const u32 *e = tab + idx * SLOT_ENTRY_WORDS;
+      ge pt;
+      pt.x = slot_load_fe(e + (half ? 8 : 0));
+      pt.y = slot_load_fe(e + 16);
+      pt = ge_neg_if_lazy(pt, top == (half ? cp.n2 : cp.n1));
+      if (j == D - 1 && half == 0) {  // uniform across the wave: the first point is the accumulator
+        acc.x = pt.x;
+        acc.y = fe_norm_weak(pt.y);
+        acc.z = fe_set_int(1);
+        acc.inf = false;
+      } else {
+        acc = gej_add_ge_fast(acc, pt);
+      }
+    }
+  }
+  acc.z = fe_mul(acc.z, slot_load_fe(tab + kc_words(T)));
+  // the windows of u1 come off a 256-bit shift register: no dynamic indexing of the scalar (which would put it in scratch)
+  u32 uw[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) uw[i] = rec.u1[i];
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = uw[0] & ((1u << GTABLE_WINDOW_BITS) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) uw[i] = (uw[i] >> GTABLE_WINDOW_BITS) | (uw[i + 1] << (32 - GTABLE_WINDOW_BITS));
+    uw[7] >>= GTABLE_WINDOW_BITS;
+    if (d != 0) {  // a zero digit (2^-22 per window) is a divergent skip, not a select
+      const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+      ge pt;
+      pt.x = slot_load_fe(e);
+      pt.y = slot_load_fe(e + 8);
+      acc = gej_add_ge_fast(acc, pt);
+    }
+  }
+  *suspect = fe_is_zero(acc.z);
+  return acc;
+}
+
 // R = u1*G + (k1 + k2*lambda)*Q from the key's comb table
 template <int T>
 LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gtable) {

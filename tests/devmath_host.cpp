@@ -103,6 +103,8 @@ void dm_ecdsa_verify_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8
   }
 }
 #ifndef DM_NO_KEYED
+static size_t g_suspects;  // how often the bare-formula ecmult reported Z = 0 and the complete form decided
+size_t dm_suspects(int reset) { const size_t v = g_suspects; if (reset) g_suspects = 0; return v; }
 // keyed path: one window table per row's key (no sharing here -- this is an arithmetic test), then the table-driven ecmult
 }  // extern "C"
 template <int T>
@@ -119,7 +121,10 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
     out[i] = 0;
     if (ok) {
       keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
-      const gej R = ecmult_lane_keyed<T>(recs[i], tab.data(), g_table.data());
+      // as the kernels stage it: the bare-formula form first, the complete form only when it reports Z = 0
+      bool suspect;
+      gej R = ecmult_lane_keyed_fast<T>(recs[i], tab.data(), g_table.data(), &suspect);
+      if (suspect) { g_suspects++; R = ecmult_lane_keyed<T>(recs[i], tab.data(), g_table.data()); }
       be_to_words(rw, sig64 + 64 * i);
       out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
     }
@@ -170,7 +175,19 @@ static int ecmult_keyed_t(const u32 *qx, const u32 *qy, const u8 *u1, const u8 *
   glv_split(&h1, &h2, k);
   for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
   rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
-  const gej R = ecmult_lane_keyed<T>(rec, tab.data(), g_table.data());
+  bool suspect;
+  gej R = ecmult_lane_keyed_fast<T>(rec, tab.data(), g_table.data(), &suspect);
+  const gej Rc = ecmult_lane_keyed<T>(rec, tab.data(), g_table.data());
+  if (suspect) {
+    g_suspects++;
+    R = Rc;
+  } else {
+    // the two forms must describe the same point: X1*Z2^2 == X2*Z1^2, Y1*Z2^3 == Y2*Z1^3
+    if (Rc.inf) return -1;
+    const fe z1 = fe_norm_weak(R.z), z2 = fe_norm_weak(Rc.z), z1s = fe_sqr(z1), z2s = fe_sqr(z2);
+    if (!fe_equal(fe_mul(R.x, z2s), fe_mul(Rc.x, z1s), 1)) return -1;
+    if (!fe_equal(fe_mul(R.y, fe_mul(z2s, z2)), fe_mul(Rc.y, fe_mul(z1s, z1)), 1)) return -1;
+  }
   if (R.inf) return 0;
   const fe zi = fe_inv(fe_norm_weak(R.z)), zi2 = fe_sqr(zi);
   u32 w[8];

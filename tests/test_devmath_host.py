@@ -311,15 +311,29 @@ def test_keyed_ecmult_special_scalars(dm):
            1 << 127, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, ((1 << 127) * LAM + 2) % N, (N + 1) // 2]
     u2s += [rng.randrange(N) for _ in range(12)]
     o = ctypes.create_string_buffer(64)
+    dm.dm_suspects.restype = ctypes.c_size_t
     for T in (7, 10):
+        dm.dm_suspects(1)
+        ninf = 0
         for u2 in u2s:
             for u1 in (0, 1, rng.randrange(N), (-u2 * d) % N, (-u2 * d + 1) % N):
+                # dm_ecmult_keyed runs the bare-formula form (both halves made odd by a lattice vector, no repair additions, one
+                # Z == 0 test at the end) AND the complete form, and returns -1 if they describe different points
                 got = dm.dm_ecmult_keyed(T, pyref.ser33(Q), u1.to_bytes(32, "big"), u2.to_bytes(32, "big"), o)
                 exp = pyref.padd(pyref.pmul(u1, pyref.G), pyref.pmul(u2, Q))
                 if exp is None:
                     assert got == 0, (T, hex(u1), hex(u2))
+                    ninf += 1
                 else:
                     assert got == 1 and o.raw == exp[0].to_bytes(32, "big") + exp[1].to_bytes(32, "big"), (T, hex(u1), hex(u2))
+        # every infinity result (and every crafted collision) went through the complete form; honest random scalars never do
+        assert dm.dm_suspects(1) >= ninf > 0
+        for _ in range(40):
+            u1, u2 = rng.randrange(N), rng.randrange(N)
+            assert dm.dm_ecmult_keyed(T, pyref.ser33(Q), u1.to_bytes(32, "big"), u2.to_bytes(32, "big"), o) == 1
+            exp = pyref.padd(pyref.pmul(u1, pyref.G), pyref.pmul(u2, Q))
+            assert o.raw == exp[0].to_bytes(32, "big") + exp[1].to_bytes(32, "big")
+        assert dm.dm_suspects(1) == 0
 
 
 def test_gtable_windows_that_straddle_words(kat):

@@ -359,11 +359,13 @@ def test_keyed_path_auto_selection_and_parity(eng, orc):
     """auto mode: a big batch with few distinct keys takes the table path, a batch of distinct keys does not; both agree
     with the verdicts known by construction and with the oracle on a sample"""
     from lightning_amd import workload
+    eng.cache_clear()                       # the counts below are those of keys met for the first time
     w = workload.make_ecdsa(eng, 30000, nkeys=100, publen=33)
     eng.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
     eng.synchronize()
     inf = eng.info()
     assert inf["last_keyed"] == 10 and 100 <= inf["last_unique_keys"] < 600  # >= 48 signatures per key: the 10-tooth comb
+    assert inf["last_cache_hits"] == 0 and 90 <= inf["last_new_tables"] <= 110
     got = w.d_ok.cpu().numpy().astype(bool)
     assert np.array_equal(got, w.expect), (np.nonzero(got != w.expect)[0][:10], w.classes[got != w.expect][:10])
     sl = slice(0, 1200)
@@ -384,7 +386,7 @@ def test_keyed_path_auto_selection_and_parity(eng, orc):
 
 
 def test_chunk_splitting_small_chunks(orc, kat):
-    """batches larger than one launch chunk are cut (on message boundaries for gossip); forced here with 1000-row chunks"""
+    """batches larger than one launch chunk are cut; forced here with 1000-row chunks"""
     import os
     from lightning_amd import Engine, workload
     os.environ["LAMD_CHUNK_ROWS"] = "1000"
@@ -400,16 +402,16 @@ def test_chunk_splitting_small_chunks(orc, kat):
         assert np.array_equal(e.verify_ecdsa(w.cols[0], w.cols[1], w.cols[2]), w.expect)
         ws = workload.make_schnorr(e, 3100, nkeys=1 << 40)
         assert np.array_equal(e.verify_schnorr(ws.cols[0], ws.cols[1], ws.cols[2]), ws.expect)
-        g = workload.make_gossip(e, 700, 900, n_nodes=30, corrupt_frac=0.05)     # 3700 rows -> 4 chunks, cut between messages
+        g = workload.make_gossip(e, 700, 900, n_nodes=30, corrupt_frac=0.05)     # 3700 rows -> 4 chunks
         msgs = [g.msgs[int(g.off[i]):int(g.off[i + 1])].tobytes() for i in range(g.n)]
         ids = [g.ids[i].tobytes() if i >= g.n_cann else None for i in range(g.n)]
         assert np.array_equal(e.sigcheck_gossip(msgs, ids), g.expect)
-        # device-pointer gossip larger than one chunk is refused (the cut has to fall between messages, which needs the
-        # host copy of the row table): the caller splits, or uses the host-buffer entry point above
-        from lightning_amd import LamdError
-        with pytest.raises(LamdError):
-            e.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
+        # the device-pointer entry cuts the same way (a message's four rows may straddle two chunks and two lanes)
+        g.d_verdict.fill_(77)
+        torch.cuda.synchronize()
+        e.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
         e.synchronize()
+        assert np.array_equal(g.d_verdict.cpu().numpy(), g.expect)
     finally:
         e.close()
 
@@ -734,3 +736,87 @@ def test_streaming_pipelined_flushes(eng, orc):
     assert len(results) == len(batches)
     for got, exp in results:
         assert np.array_equal(np.asarray(got, dtype=bool), exp)
+
+
+def test_key_table_cache_warm_cold_and_bounded(orc):
+    """the key-table cache: a second call over the same keys builds no table and verifies every row from cached combs (same
+    verdicts); keys that do not parse are cached as such; a cache too small for the traffic empties itself and carries on;
+    LAMD_CACHE=0 (tables live for one call) gives the same verdicts"""
+    import os
+    from lightning_amd import Engine, workload
+    with Engine(0) as e:
+        w = workload.make_ecdsa(e, 60000, seed=5151, nkeys=4000, publen=33)          # 15 rows per key: 7-tooth combs
+        s = workload.make_schnorr(e, 40000, seed=5252, nkeys=300)                    # 133 rows per key: 10-tooth combs
+        for rep in range(3):
+            w.d_ok.fill_(9); s.d_ok.fill_(9)
+            torch.cuda.synchronize()
+            e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+            e.synchronize()
+            ie = e.info()
+            e.verify_schnorr_device(s.dev[0], s.dev[1], s.dev[2], s.d_ok)
+            e.synchronize()
+            isch = e.info()
+            assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect), rep
+            assert np.array_equal(s.d_ok.cpu().numpy().astype(bool), s.expect), rep
+            if rep == 0:
+                assert ie["last_cache_hits"] == 0 and ie["last_new_tables"] > 3500 and ie["last_keyed"] == 7
+                assert isch["last_new_tables"] >= 290 and isch["last_keyed"] == 10
+                cold_rows = ie["last_cold_rows"]
+            elif rep == 2:   # by now the host has seen the publishing calls complete: every table comes from the cache
+                assert ie["last_new_tables"] == 0 and ie["last_cache_hits"] >= 60000 - cold_rows - 100 and ie["last_keyed"] == 7
+                assert isch["last_new_tables"] == 0 and isch["last_cache_hits"] > 39000 and isch["last_keyed"] == 10
+        assert e.info()["cache_enabled"] and e.info()["cache_resets"] == 0
+        # a small batch under a cached key rides the cached comb (a commitment's 483 HTLC signatures on a known key)
+        k = s.cols[1][0]
+        sel = np.nonzero((s.cols[1] == k).all(axis=1))[0][:100]
+        got = e.verify_schnorr(s.cols[0][sel], s.cols[1][sel], s.cols[2][sel])
+        assert np.array_equal(got, s.expect[sel]) and e.info()["last_cache_hits"] == len(sel)
+        # oracle pin on a sample of the cached-path verdicts
+        exp = orc.ecdsa_verify_batch(w.cols[0][:1500], w.cols[1][:1500], w.cols[2][:1500], 33, 4).astype(bool)
+        assert np.array_equal(w.d_ok.cpu().numpy()[:1500].astype(bool), exp)
+        e.cache_clear()
+        e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+        e.synchronize()
+        assert e.info()["last_cache_hits"] == 0 and e.info()["cache_resets"] == 1
+    os.environ["LAMD_CACHE_KEYS"] = "600"
+    os.environ["LAMD_CACHE_KEYS10"] = "40"
+    try:
+        with Engine(0) as e:
+            for rep in range(6):   # 4000 + 300 keys per round through a cache of 640: fills, falls back to the ladder, empties itself
+                w = workload.make_ecdsa(e, 30000, seed=6000 + rep, nkeys=2000, publen=65)
+                s = workload.make_schnorr(e, 20000, seed=6100 + rep, nkeys=150)
+                e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+                e.verify_schnorr_device(s.dev[0], s.dev[1], s.dev[2], s.d_ok)
+                e.synchronize()
+                assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect), rep
+                assert np.array_equal(s.d_ok.cpu().numpy().astype(bool), s.expect), rep
+            assert e.info()["cache_resets"] >= 1 and e.info()["cache_capacity"] == 640
+    finally:
+        del os.environ["LAMD_CACHE_KEYS"], os.environ["LAMD_CACHE_KEYS10"]
+    os.environ["LAMD_CACHE"] = "0"
+    try:
+        with Engine(0) as e:
+            w = workload.make_ecdsa(e, 50000, seed=5151, nkeys=3000, publen=33)
+            for rep in range(2):
+                e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+                e.synchronize()
+                assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
+                assert not e.info()["cache_enabled"] and e.info()["last_cache_hits"] == 0 and e.info()["last_new_tables"] > 2500
+    finally:
+        del os.environ["LAMD_CACHE"]
+
+
+def test_keyed_fast_path_degenerate_rows_take_the_complete_formulas(eng_keyed, kat):
+    """golden rows built so that an addition inside the comb meets +-its operand, or the result is the point at infinity
+    (u1*G = -u2*Q), leave Z = 0 in the bare-formula kernel: they must be re-decided by the complete formulas, not guessed"""
+    e = eng_keyed
+    vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 66 and any(t in v["name"] for t in ("u1G==u2Q", "R=inf", "Q=G", "Q=lamG"))]
+    assert len(vs) >= 6
+    reps = 4                                    # each key several times: forced onto per-key tables (LAMD_KEYED=1)
+    hs = _rows([H(v["hash"]) for v in vs] * reps, 32)
+    sg = _rows([H(v["sig"]) for v in vs] * reps, 64)
+    pk = _rows([H(v["pub"]) for v in vs] * reps, 33)
+    got = e.verify_ecdsa(hs, sg, pk)
+    assert [bool(g) for g in got] == [v["expect"] for v in vs] * reps
+    inf = e.info()
+    assert inf["last_hot_rows"] > 0 and inf["last_suspect_rows"] > 0

@@ -4,7 +4,7 @@
 # Counter passes use --kernel-trace only (gpurun refuses --pmc with sys/hip tracing).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/pmc_r01h
+OUT=$R/gpurun_out/pmc_${1:-r02}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --skip-extra"
