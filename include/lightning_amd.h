@@ -104,6 +104,26 @@ int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *preimages, c
 			    const uint8_t *sighash_type, const uint8_t *has_witness_script,
 			    const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
 
+/* ---- the same from TRANSACTION TEMPLATES: n independent check_tx_sig(tx, input_num, script, witness_script, key, sig) calls
+ * (bitcoin/signature.c:194-221) with the BIP143 signature hash of bitcoin_tx_hash_for_sig() (:120-151, libwally's
+ * wally_tx_get_btc_signature_hash with WALLY_TX_FLAG_USE_WITNESS) computed ON THE DEVICE: hashPrevouts / hashSequence /
+ * hashOutputs, the preimage and its double SHA-256 are streamed piecewise, nothing is serialised on the host.
+ * Row i describes one (transaction, input, signature):
+ *   version[i], locktime[i]
+ *   inputs40 + 40*in_off[i] .. in_off[i+1]   : the transaction's inputs, 40 bytes each: txid (32, as hashed) | vout u32 LE | nSequence u32 LE
+ *   input_num[i]                              : which input the signature is for (>= the number of inputs: verdict 0; the reference asserts)
+ *   amount_sat[i]                             : that input's amount (psbt_input_get_amount)
+ *   outputs + out_off[i] .. out_off[i+1]      : the n_outputs[i] outputs in wire form (amount u64 LE | CompactSize | scriptPubKey), back to back
+ *   scripts + script_off[i] .. script_off[i+1]: the script the reference would hash -- the witness script, or the redeemscript when there is none
+ *   sighash_type[i], has_witness_script[i]    : the gate of :206-211 (SIGHASH_ALL, or SINGLE|ANYONECANPAY only with a witness script)
+ * All offsets are uint64, arrays of n+1 entries.  The Elements branch (:136-143) is out of scope. */
+int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime,
+			       const uint8_t *inputs40, const uint64_t *in_off, const uint32_t *input_num, const uint64_t *amount_sat,
+			       const uint8_t *outputs, const uint64_t *out_off, const uint32_t *n_outputs,
+			       const uint8_t *scripts, const uint64_t *script_off,
+			       const uint8_t *sighash_type, const uint8_t *has_witness_script,
+			       const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
+
 /* n independent secp256k1_ecdsa_recoverable_signature_parse_compact() + secp256k1_ecdsa_recover() calls as made by
  * common/bolt11.c:1021-1046 (invoices without an `n` field) and lightningd/signmessage.c:193: sig64 = r||s, recid 0..3.
  * pub33[i] = the recovered key, compressed (what node_id_from_pubkey() stores), ok[i] = 1; where the library calls would
@@ -152,7 +172,7 @@ int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, con
 
 /* Device-resident variant (asynchronous on the context's stream).  d_off: uint64[n+1] byte offsets;
  * d_rowbase: uint64[n+1], d_rowbase[i] = number of signatures in messages 0..i-1 (4 per
- * channel_announcement, 1 otherwise), rows = d_rowbase[n] (at most one chunk, 2^22 rows, per call). */
+ * channel_announcement, 1 otherwise), rows = d_rowbase[n]. */
 int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_off,
 				      const void *d_node_ids33, const void *d_rowbase, size_t rows,
 				      void *d_verdict);

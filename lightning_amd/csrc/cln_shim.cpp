@@ -12,6 +12,7 @@
 #include "../../include/lightning_amd.h"
 
 static lamd_ctx *g_ctx;
+static bool g_ctx_owned;
 static std::string g_err;
 
 extern "C" bool lamd_shim_setup(void) {
@@ -25,11 +26,38 @@ extern "C" bool lamd_shim_setup(void) {
     return false;
   }
   g_ctx = c;
+  g_ctx_owned = true;
   return true;
 }
+extern "C" void lamd_shim_use_context(void *p) {
+  if (g_ctx && g_ctx_owned) lamd_shutdown(g_ctx);
+  g_ctx = (lamd_ctx *)p;
+  g_ctx_owned = false;
+}
 extern "C" void lamd_shim_shutdown(void) {
-  if (g_ctx) lamd_shutdown(g_ctx);
+  if (g_ctx && g_ctx_owned) lamd_shutdown(g_ctx);
   g_ctx = nullptr;
+}
+
+// ---- tal-style arrays (ccan/tal keeps the length with the allocation; so does this)
+struct tal_hdr { size_t len; size_t magic; };
+static const size_t TAL_MAGIC = 0x7A11ED0C0FFEE000ull;
+extern "C" u8 *shim_tal_dup(const tal_t *, const u8 *src, size_t len) {
+  tal_hdr *h = (tal_hdr *)malloc(sizeof(tal_hdr) + (len ? len : 1));
+  if (!h) return nullptr;
+  h->len = len;
+  h->magic = TAL_MAGIC;
+  if (len) memcpy(h + 1, src, len);
+  return (u8 *)(h + 1);
+}
+extern "C" size_t tal_bytelen(const void *ptr) {
+  if (!ptr) return 0;
+  const tal_hdr *h = (const tal_hdr *)ptr - 1;
+  if (h->magic != TAL_MAGIC) abort();  // not a tal array: the reference would read garbage too
+  return h->len;
+}
+extern "C" void shim_tal_free(const void *ptr) {
+  if (ptr) free((tal_hdr *)ptr - 1);
 }
 extern "C" const char *lamd_shim_last_error(void) { return g_err.c_str(); }
 
@@ -183,8 +211,8 @@ extern "C" bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pub
   if (rc < 0) g_err = lamd_last_error(g_ctx);
   return rc == 1;
 }
-extern "C" bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script, const struct pubkey *key,
-                             const struct bitcoin_signature *sig) {
+extern "C" bool check_tx_sig_preimage(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script, const struct pubkey *key,
+                                      const struct bitcoin_signature *sig) {
   // bitcoin/signature.c:206-211: only SIGHASH_ALL, or SINGLE|ANYONECANPAY with a witness script
   if (sig->sighash_type != SIGHASH_ALL) {
     if (!witness_script) return false;
@@ -193,6 +221,49 @@ extern "C" bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, con
   struct sha256_double hash;
   sha256_double(&hash, bip143_preimage, preimage_len);
   return check_signed_hash(&hash, &sig->s, key);
+}
+static void put_compact_size(std::string &o, uint64_t v) {
+  if (v < 0xfd) o.push_back((char)v);
+  else if (v <= 0xffff) { o.push_back((char)0xfd); o.push_back((char)v); o.push_back((char)(v >> 8)); }
+  else { o.push_back((char)0xfe); for (int i = 0; i < 4; i++) o.push_back((char)(v >> (8 * i))); }
+}
+extern "C" bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, const u8 *redeemscript, const u8 *witness_script,
+                             const struct pubkey *key, const struct bitcoin_signature *sig) {
+  const bool use_segwit = witness_script != nullptr;                   // bitcoin/signature.c:198-199
+  const u8 *script = use_segwit ? witness_script : redeemscript;
+  // :206-211 -- rejected before anything is hashed (the device applies the same gate again)
+  if (sig->sighash_type != SIGHASH_ALL) {
+    if (!witness_script) return false;
+    if (sig->sighash_type != (SIGHASH_SINGLE | SIGHASH_ANYONECANPAY)) return false;
+  }
+  if (input_num >= tx->num_inputs) abort();                            // assert(input_num < tx->wtx->num_inputs), :213
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  // flatten the template: that is all the host does -- hashPrevouts/Sequence/Outputs, the preimage and SHA256d run on the device
+  std::string in, out;
+  for (size_t i = 0; i < tx->num_inputs; i++) {
+    in.append((const char *)tx->inputs[i].txid, 32);
+    for (int b = 0; b < 4; b++) in.push_back((char)(tx->inputs[i].index >> (8 * b)));
+    for (int b = 0; b < 4; b++) in.push_back((char)(tx->inputs[i].sequence >> (8 * b)));
+  }
+  for (size_t i = 0; i < tx->num_outputs; i++) {
+    for (int b = 0; b < 8; b++) out.push_back((char)(tx->outputs[i].amount_sat >> (8 * b)));
+    const size_t sl = tal_bytelen(tx->outputs[i].script);
+    put_compact_size(out, sl);
+    out.append((const char *)tx->outputs[i].script, sl);
+  }
+  const uint32_t version = tx->version, locktime = tx->locktime, inum = (uint32_t)input_num, nout = (uint32_t)tx->num_outputs;
+  const uint64_t in_off[2] = {0, tx->num_inputs}, out_off[2] = {0, out.size()}, sc_off[2] = {0, tal_bytelen(script)};
+  const uint64_t amount = tx->inputs[input_num].amount_sat;
+  const u8 type = (u8)sig->sighash_type, wit = use_segwit ? 1 : 0;
+  u8 pub65[65], ok = 0;
+  pub65[0] = 4;
+  memcpy(pub65 + 1, key->pubkey.data, 64);
+  const u8 dummy = 0;
+  const int rc = lamd_check_tx_sig_tx_batch(g_ctx, 1, &version, &locktime, (const u8 *)in.data(), in_off, &inum, &amount,
+                                            out.empty() ? &dummy : (const u8 *)out.data(), out_off, &nout, script ? script : &dummy, sc_off, &type, &wit,
+                                            sig->s.data, pub65, 65, 65, &ok);
+  if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return false; }
+  return ok != 0;
 }
 
 extern "C" int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *, secp256k1_ecdsa_recoverable_signature *sig,

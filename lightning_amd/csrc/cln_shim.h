@@ -21,10 +21,11 @@
  * Differences a maintainer has to know about (also in INTEGRATION.md):
  *  - tal: the sigcheck_* functions return a malloc()ed string (or NULL); the `ctx` argument is
  *    accepted and ignored.  In-tree one would tal_strdup() it onto ctx.
- *  - check_tx_sig(): the reference hashes a `struct bitcoin_tx` through libwally
- *    (bitcoin/signature.c:120-151).  Building BIP143 preimages from transactions is row N1 of
- *    SURVEY 8(f); here the caller passes the already-serialised BIP143 preimage.  The sighash-type
- *    gate (:206-211) and everything after it are the reference's.
+ *  - check_tx_sig() has the reference's prototype (bitcoin/signature.h:120-124).  `struct bitcoin_tx` here is a plain
+ *    mirror of what that path reads from the reference's libwally-backed one (version, locktime, inputs with the amounts
+ *    the PSBT carries, outputs); the two script arguments are tal-style arrays whose length travels with the pointer
+ *    (tal_bytelen(), as in the reference) -- make them with shim_tal_dup().  The BIP143 hash of
+ *    bitcoin_tx_hash_for_sig() (:120-151) is computed on the device.
  *  - all elliptic-curve work (key decompression, verification) runs on the GPU through
  *    lamd_*; hashing and DER/compact parsing are host code.  Without a device every check
  *    fails closed (false / "engine error" string), there is no CPU verification path.
@@ -57,6 +58,8 @@ struct bitcoin_signature { secp256k1_ecdsa_signature s; enum sighash_type sighas
 /* common/setup.c:38-64 analogue: creates the process-global engine context (device 0 unless
  * LAMD_DEVICE is set).  Returns false (and every later check fails closed) without a GPU. */
 bool lamd_shim_setup(void);
+/* adopt an engine context the process already owns instead of creating one (the caller keeps ownership) */
+void lamd_shim_use_context(void *lamd_ctx_ptr);
 void lamd_shim_shutdown(void);
 const char *lamd_shim_last_error(void);
 
@@ -75,10 +78,35 @@ bool check_signed_hash(const struct sha256_double *hash, const secp256k1_ecdsa_s
 bool check_signed_hash_nodeid(const struct sha256_double *hash, const secp256k1_ecdsa_signature *signature,
 			      const struct node_id *id);
 bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pubkey *pubkey, const struct bip340sig *sig);
-/* bip143_preimage: what wally_tx_get_btc_signature_hash() would hash for (tx, input_num, script,
- * amount, sig->sighash_type); witness_script NULL = legacy (then only SIGHASH_ALL is accepted). */
-bool check_tx_sig(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
+/* tal-style byte arrays: the length is stored in front of the data, tal_bytelen() reads it (ccan/tal in the reference) */
+u8 *shim_tal_dup(const tal_t *ctx, const u8 *src, size_t len);
+size_t tal_bytelen(const void *ptr);
+void shim_tal_free(const void *ptr);
+
+/* what check_tx_sig()/bitcoin_tx_hash_for_sig() read from the reference's struct bitcoin_tx (bitcoin/tx.h: wtx + psbt) */
+struct bitcoin_tx_input {
+	u8 txid[32];         /* as serialised in the transaction (and hashed) */
+	uint32_t index;      /* vout */
+	uint32_t sequence;
+	uint64_t amount_sat; /* psbt_input_get_amount(tx->psbt, in) */
+};
+struct bitcoin_tx_output {
+	uint64_t amount_sat;
+	const u8 *script;    /* scriptPubKey, tal-style array */
+};
+struct bitcoin_tx {
+	uint32_t version, locktime;
+	size_t num_inputs, num_outputs;
+	const struct bitcoin_tx_input *inputs;
+	const struct bitcoin_tx_output *outputs;
+};
+/* bitcoin/signature.h:120-124, same argument order and meaning: witness_script NULL = hash `subscript`, and then only
+ * SIGHASH_ALL is accepted (bitcoin/signature.c:198-211). */
+bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, const u8 *subscript, const u8 *witness_script,
 		  const struct pubkey *key, const struct bitcoin_signature *sig);
+/* the round-1 form, kept for callers that already hold the serialised BIP143 preimage */
+bool check_tx_sig_preimage(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
+			   const struct pubkey *key, const struct bitcoin_signature *sig);
 
 /* Public-key recovery as common/bolt11.c:1021-1046 and lightningd/signmessage.c:193 use it, under libsecp256k1's own
  * names and return conventions (1 = ok, 0 = failure; the context argument is accepted and ignored).  The opaque

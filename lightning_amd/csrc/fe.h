@@ -16,7 +16,11 @@
 #include "lamd_common.h"
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LAMD_FE_NO_ASM_BLOCK)
 #define LAMD_FE_ASM_BLOCK 1
+#if defined(LAMD_FE_ASM_INC)  // tools/fe_bench.hip times alternative schedules of the generator
+#include LAMD_FE_ASM_INC
+#else
 #include "fe_asm.inc"
+#endif
 #endif
 
 namespace lamd {
@@ -299,13 +303,15 @@ LAMD_HD fe fe_mul(const fe &a, const fe &b) {
   fe r;
   u64 hi, lo;
   u32 t0, t1, t2;
+  u64 cy0, cy1;  // dead carry-outs of the two chains (SGPR pairs; unused when the schedule sends them to VCC)
+  (void)cy0; (void)cy1;
   asm(LAMD_FE_MUL_ASM
       : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo) LAMD_FE_ASM_EXTRA_OUT
       : "v"(a.n[0]), "v"(a.n[1]), "v"(a.n[2]), "v"(a.n[3]), "v"(a.n[4]), "v"(a.n[5]), "v"(a.n[6]), "v"(a.n[7]), "v"(a.n[8]),
         "v"(b.n[0]), "v"(b.n[1]), "v"(b.n[2]), "v"(b.n[3]), "v"(b.n[4]), "v"(b.n[5]), "v"(b.n[6]), "v"(b.n[7]), "v"(b.n[8]),
-        "s"(FE_R0), "s"(1u << FE_R1_SHIFT)
-      : "vcc");
+        "s"(FE_R0), "s"(1u << FE_R1_SHIFT) LAMD_FE_ASM_EXTRA_IN
+      : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_TAIL
 #else
 #define LAMD_P(k, acc, ch) fe_mul_col<ch>(a, b, k, acc)
@@ -325,13 +331,15 @@ LAMD_HD fe fe_sqr(const fe &a) {
   fe r;
   u64 hi, lo;
   u32 t0, t1, t2;
+  u64 cy0, cy1;  // dead carry-outs of the two chains (SGPR pairs; unused when the schedule sends them to VCC)
+  (void)cy0; (void)cy1;
   asm(LAMD_FE_SQR_ASM
       : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo) LAMD_FE_ASM_EXTRA_OUT
       : "v"(a.n[0]), "v"(a.n[1]), "v"(a.n[2]), "v"(a.n[3]), "v"(a.n[4]), "v"(a.n[5]), "v"(a.n[6]), "v"(a.n[7]), "v"(a.n[8]),
         "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]),
-        "s"(FE_R0), "s"(1u << FE_R1_SHIFT)
-      : "vcc");
+        "s"(FE_R0), "s"(1u << FE_R1_SHIFT) LAMD_FE_ASM_EXTRA_IN
+      : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_TAIL
 #else
 #define LAMD_P(k, acc, ch) fe_sqr_col<ch>(a, d, k, acc)

@@ -163,6 +163,35 @@ __global__ void __launch_bounds__(256) k_txsig_hash(size_t n, const u8 *__restri
   if (pass) sha256d_bytes(pre + off[i], (size_t)(off[i + 1] - off[i]), h);
   for (int b = 0; b < 32; b++) hash32[32 * i + b] = pass ? h[b] : 0;
 }
+// ---- check_tx_sig from transaction templates: the BIP143 hash of bitcoin_tx_hash_for_sig() (bitcoin/signature.c:120-151) computed
+// here from flat template arrays (verify_core.h "BIP143 signature hash on the device"), plus the sighash-type gate of :206-211
+__global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__restrict__ version, const u32 *__restrict__ locktime,
+                                                       const u8 *__restrict__ inputs40, const u64 *__restrict__ in_off,
+                                                       const u32 *__restrict__ input_num, const u64 *__restrict__ amount,
+                                                       const u8 *__restrict__ outputs, const u64 *__restrict__ out_off,
+                                                       const u32 *__restrict__ n_outputs, const u8 *__restrict__ scripts,
+                                                       const u64 *__restrict__ script_off, const u8 *__restrict__ sighash_type,
+                                                       const u8 *__restrict__ has_witness, u8 *__restrict__ hash32, u8 *__restrict__ gate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u8 t = sighash_type[i];
+  bool pass = t == 1 || (t == 0x83 && has_witness[i]);
+  u8 h[32];
+  for (int b = 0; b < 32; b++) h[b] = 0;
+  if (pass) {
+    tx_view tv;
+    tv.version = version[i];
+    tv.locktime = locktime[i];
+    tv.inputs = inputs40 + 40 * in_off[i];
+    tv.n_in = (u32)(in_off[i + 1] - in_off[i]);
+    tv.outputs = outputs + out_off[i];
+    tv.outputs_len = (size_t)(out_off[i + 1] - out_off[i]);
+    tv.n_out = n_outputs[i];
+    pass = bip143_sighash(tv, input_num[i], scripts + script_off[i], (size_t)(script_off[i + 1] - script_off[i]), amount[i], t, h);
+  }
+  gate[i] = pass;
+  for (int b = 0; b < 32; b++) hash32[32 * i + b] = h[b];
+}
 __global__ void __launch_bounds__(256) k_apply_gate(size_t n, const u8 *__restrict__ gate, u8 *__restrict__ ok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && !gate[i]) ok[i] = 0;
@@ -859,7 +888,7 @@ struct lamd_ctx {
   bool timing = false;
   bool ev_recorded = false;
   int ecmult_waves = 3;
-  int keyed_waves = 4;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3 or 4)
+  int keyed_waves = 3;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3: no spill; 4: a 5-dword spill, measured 60 % slower)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
   u64 hash_seed = 0x243F6A8885A308D3ULL;
   size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
@@ -1031,7 +1060,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     return LAMD_ERR_NO_DEVICE;
   }
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
-  if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 3 ? 3 : 4;
+  if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   {
     std::random_device rd;
@@ -1518,6 +1547,7 @@ static int cache_maybe_reset(lamd_ctx *root) {
 static int run_device(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
                       size_t keystride, u8 *d_ok, u8 *keyok_out = nullptr) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->root) ctx->last_lane = nullptr;  // a call on the context's own streams (host-buffer entry points): lamd_get_info() reports it
   bool forked = false;
   size_t k = 0;
   for (size_t o = 0; o < n; o += ctx->chunk, k++) {
@@ -1730,6 +1760,57 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_txsig_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p,
                      (const u8 *)d_types, (const u8 *)d_wit, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p);
+  HIPCHK(ctx, hipGetLastError());
+  rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
+                  (u8 *)ctx->out.p);
+  if (rc != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);
+}
+
+extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40,
+                                          const uint64_t *in_off, const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs,
+                                          const uint64_t *out_off, const uint32_t *n_outputs, const uint8_t *scripts, const uint64_t *script_off,
+                                          const uint8_t *sighash_type, const uint8_t *has_witness, const uint8_t *sig64, const uint8_t *pub,
+                                          size_t publen, size_t pubstride, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!version || !locktime || !inputs40 || !in_off || !input_num || !amount_sat || !outputs || !out_off || !n_outputs || !scripts || !script_off ||
+      !sighash_type || !has_witness || !sig64 || !pub || !ok || (publen != 33 && publen != 65) || pubstride < publen) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+  // one staging blob: fixed-width columns first (8-byte aligned), then the three byte strings
+  const size_t nin = (size_t)(in_off[n] - in_off[0]), nout_b = (size_t)(out_off[n] - out_off[0]), nsc = (size_t)(script_off[n] - script_off[0]);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+  const size_t o_inoff = take((n + 1) * 8), o_outoff = take((n + 1) * 8), o_scoff = take((n + 1) * 8), o_amt = take(n * 8), o_ver = take(n * 4),
+               o_lock = take(n * 4), o_inum = take(n * 4), o_nout = take(n * 4), o_type = take(n), o_wit = take(n), o_in = take(nin * 40 + 16),
+               o_out = take(nout_b + 16), o_sc = take(nsc + 16), total = o;
+  std::vector<u8> st(total, 0);
+  auto rel = [&](size_t at, const uint64_t *src) { for (size_t i = 0; i <= n; i++) ((u64 *)&st[at])[i] = src[i] - src[0]; };
+  rel(o_inoff, in_off); rel(o_outoff, out_off); rel(o_scoff, script_off);
+  memcpy(&st[o_amt], amount_sat, n * 8); memcpy(&st[o_ver], version, n * 4); memcpy(&st[o_lock], locktime, n * 4);
+  memcpy(&st[o_inum], input_num, n * 4); memcpy(&st[o_nout], n_outputs, n * 4); memcpy(&st[o_type], sighash_type, n); memcpy(&st[o_wit], has_witness, n);
+  memcpy(&st[o_in], inputs40 + 40 * in_off[0], nin * 40); memcpy(&st[o_out], outputs + out_off[0], nout_b); memcpy(&st[o_sc], scripts + script_off[0], nsc);
+  if ((rc = ensure(ctx, &ctx->g_msgs, total)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * pubstride)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  const u8 *d = (const u8 *)ctx->g_msgs.p;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, st.data(), total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_txsig_tx_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)(d + o_ver), (const u32 *)(d + o_lock), d + o_in,
+                     (const u64 *)(d + o_inoff), (const u32 *)(d + o_inum), (const u64 *)(d + o_amt), d + o_out, (const u64 *)(d + o_outoff),
+                     (const u32 *)(d + o_nout), d + o_sc, (const u64 *)(d + o_scoff), d + o_type, d + o_wit, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p);
   HIPCHK(ctx, hipGetLastError());
   rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
                   (u8 *)ctx->out.p);

@@ -876,6 +876,147 @@ LAMD_HD void sha256d_bytes(const u8 *p, size_t len, u8 out32[32]) {
 }
 
 
+// ---- BIP143 signature hash on the device: what bitcoin_tx_hash_for_sig() (bitcoin/signature.c:120-151) obtains from
+// libwally's wally_tx_get_btc_signature_hash(..., WALLY_TX_FLAG_USE_WITNESS) -- always the segwit form, whichever script
+// check_tx_sig() picked (:198-199).  Streaming SHA-256 over the pieces, nothing is materialised:
+//   nVersion | hashPrevouts | hashSequence | outpoint | varint(len) script | amount | nSequence | hashOutputs | nLockTime | type
+//   hashPrevouts = 0 with ANYONECANPAY; hashSequence = 0 with ANYONECANPAY, SINGLE or NONE; hashOutputs = all outputs (ALL), output
+//   [input index] (SINGLE, 0 when there is none) or 0 (NONE)
+struct sha_stream {
+  u32 st[8];
+  u32 w[16];
+  u32 fill;   // bytes in w
+  u64 total;  // bytes absorbed
+};
+LAMD_HD void shs_init(sha_stream *s) {
+  const u32 iv[8] = LAMD_SHA256_IV;
+  for (int i = 0; i < 8; i++) s->st[i] = iv[i];
+  for (int i = 0; i < 16; i++) s->w[i] = 0;
+  s->fill = 0;
+  s->total = 0;
+}
+LAMD_HD void shs_update(sha_stream *s, const u8 *p, size_t n) {
+  for (size_t k = 0; k < n; k++) {
+    s->w[s->fill >> 2] |= (u32)p[k] << (24 - 8 * (s->fill & 3));
+    if (++s->fill == 64) {
+      sha256_compress(s->st, s->w);
+      for (int i = 0; i < 16; i++) s->w[i] = 0;
+      s->fill = 0;
+    }
+  }
+  s->total += n;
+}
+LAMD_HD void shs_update_le(sha_stream *s, u64 v, int bytes) {
+  u8 b[8];
+  for (int i = 0; i < bytes; i++) b[i] = (u8)(v >> (8 * i));
+  shs_update(s, b, (size_t)bytes);
+}
+LAMD_HD void shs_final_double(sha_stream *s, u8 out32[32]) {  // SHA256(SHA256(everything absorbed))
+  const u64 bits = s->total * 8;
+  const u8 pad = 0x80;
+  shs_update(s, &pad, 1);
+  const u8 zero = 0;
+  while (s->fill != 56) shs_update(s, &zero, 1);
+  s->w[14] = (u32)(bits >> 32);
+  s->w[15] = (u32)bits;
+  sha256_compress(s->st, s->w);
+  u32 w[16];
+  for (int i = 0; i < 8; i++) w[i] = s->st[i];
+  w[8] = 0x80000000u;
+  for (int i = 9; i < 15; i++) w[i] = 0;
+  w[15] = 256;
+  u32 st2[8] = LAMD_SHA256_IV;
+  sha256_compress(st2, w);
+  for (int i = 0; i < 8; i++) {
+    out32[4 * i] = (u8)(st2[i] >> 24); out32[4 * i + 1] = (u8)(st2[i] >> 16);
+    out32[4 * i + 2] = (u8)(st2[i] >> 8); out32[4 * i + 3] = (u8)st2[i];
+  }
+}
+// Bitcoin's CompactSize at p (at most `max` bytes available): bytes consumed (0 = truncated)
+LAMD_HD size_t tx_compact_size(const u8 *p, size_t max, u64 *val) {
+  if (max < 1) return 0;
+  if (p[0] < 0xfd) { *val = p[0]; return 1; }
+  const size_t width = p[0] == 0xfd ? 2 : (p[0] == 0xfe ? 4 : 8);
+  if (max < 1 + width) return 0;
+  u64 v = 0;
+  for (size_t i = 0; i < width; i++) v |= (u64)p[1 + i] << (8 * i);
+  *val = v;
+  return 1 + width;
+}
+LAMD_HD void shs_update_compact_size(sha_stream *s, u64 v) {
+  if (v < 0xfd) shs_update_le(s, v, 1);
+  else if (v <= 0xffff) { shs_update_le(s, 0xfd, 1); shs_update_le(s, v, 2); }
+  else if (v <= 0xffffffffull) { shs_update_le(s, 0xfe, 1); shs_update_le(s, v, 4); }
+  else { shs_update_le(s, 0xff, 1); shs_update_le(s, v, 8); }
+}
+// One transaction as flat bytes: inputs = n_in x (txid 32 | vout u32 LE | nSequence u32 LE); outputs = the n_out outputs in wire
+// form (amount u64 LE | CompactSize | scriptPubKey) back to back.
+struct tx_view {
+  u32 version, locktime;
+  const u8 *inputs;
+  u32 n_in;
+  const u8 *outputs;
+  size_t outputs_len;
+  u32 n_out;
+};
+// false: the template is inconsistent (input index out of range -- the reference asserts, :213 -- or outputs that do not parse)
+LAMD_HD bool bip143_sighash(const tx_view &t, u32 in_idx, const u8 *script, size_t script_len, u64 amount, u32 sighash_type, u8 out32[32]) {
+  if (in_idx >= t.n_in) return false;
+  const bool acp = (sighash_type & 0x80u) != 0;
+  const u32 base = sighash_type & 0x1fu;
+  const bool single = base == 3, none = base == 2;
+  u8 hp[32], hs[32], ho[32];
+  for (int i = 0; i < 32; i++) hp[i] = hs[i] = ho[i] = 0;
+  sha_stream s;
+  if (!acp) {
+    shs_init(&s);
+    for (u32 i = 0; i < t.n_in; i++) shs_update(&s, t.inputs + 40 * (size_t)i, 36);
+    shs_final_double(&s, hp);
+  }
+  if (!acp && !single && !none) {
+    shs_init(&s);
+    for (u32 i = 0; i < t.n_in; i++) shs_update(&s, t.inputs + 40 * (size_t)i + 36, 4);
+    shs_final_double(&s, hs);
+  }
+  // walk the outputs once: they must parse, and SINGLE needs the boundaries of output [in_idx]
+  size_t pos = 0, one_off = 0, one_len = 0;
+  for (u32 k = 0; k < t.n_out; k++) {
+    if (t.outputs_len - pos < 8) return false;
+    u64 sl;
+    const size_t l = tx_compact_size(t.outputs + pos + 8, t.outputs_len - pos - 8, &sl);
+    if (!l || sl > t.outputs_len - pos - 8 - l) return false;
+    const size_t len = 8 + l + (size_t)sl;
+    if (k == in_idx) { one_off = pos; one_len = len; }
+    pos += len;
+  }
+  if (pos != t.outputs_len) return false;
+  if (single) {
+    if (in_idx < t.n_out) {
+      shs_init(&s);
+      shs_update(&s, t.outputs + one_off, one_len);
+      shs_final_double(&s, ho);
+    }
+  } else if (!none) {
+    shs_init(&s);
+    shs_update(&s, t.outputs, t.outputs_len);
+    shs_final_double(&s, ho);
+  }
+  shs_init(&s);
+  shs_update_le(&s, t.version, 4);
+  shs_update(&s, hp, 32);
+  shs_update(&s, hs, 32);
+  shs_update(&s, t.inputs + 40 * (size_t)in_idx, 36);
+  shs_update_compact_size(&s, script_len);
+  shs_update(&s, script, script_len);
+  shs_update_le(&s, amount, 8);
+  shs_update(&s, t.inputs + 40 * (size_t)in_idx + 36, 4);
+  shs_update(&s, ho, 32);
+  shs_update_le(&s, t.locktime, 4);
+  shs_update_le(&s, sighash_type, 4);
+  shs_final_double(&s, out32);
+  return true;
+}
+
 // ---- gossip framing: what fromwire_channel_announcement / _node_announcement / _channel_update (generated from
 // wire/peer_wire.csv:344-381) reject before gossipd/sigcheck.c runs, so that the batch entry points can take raw wire bytes.
 enum { GOSSIP_CANN = 256, GOSSIP_NANN = 257, GOSSIP_CUPD = 258 };

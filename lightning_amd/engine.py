@@ -99,6 +99,34 @@ class Engine:
                                                     sig64.ctypes.data, pub.ctypes.data, pub.shape[1], pub.shape[1], ok.ctypes.data))
         return ok.astype(bool)
 
+    def check_tx_sig_tx_batch(self, txs, sig64, pub):
+        """txs: list of dicts {version, locktime, inputs: [(txid32, vout, sequence)], outputs: [(amount, spk)], input_num, amount, script,
+        sighash_type, has_witness}; the BIP143 sighash is computed on the device (lamd_check_tx_sig_tx_batch).  Returns bool verdicts."""
+        n = len(txs)
+        u32 = lambda k: np.array([t[k] for t in txs], dtype=np.uint32)
+        inputs = b"".join(b"".join(bytes(i[0]) + int(i[1]).to_bytes(4, "little") + int(i[2]).to_bytes(4, "little") for i in t["inputs"]) for t in txs)
+
+        def varint(v):
+            return bytes([v]) if v < 0xfd else (b"\xfd" + v.to_bytes(2, "little") if v <= 0xffff else b"\xfe" + v.to_bytes(4, "little"))
+        outs = [b"".join(int(a).to_bytes(8, "little") + varint(len(spk)) + bytes(spk) for a, spk in t["outputs"]) for t in txs]
+        scripts = [bytes(t["script"]) for t in txs]
+        off = lambda lens: np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        in_off, out_off, sc_off = off([len(t["inputs"]) for t in txs]), off([len(o) for o in outs]), off([len(x) for x in scripts])
+        blob = lambda b: np.frombuffer(b + b"\x00", dtype=np.uint8)
+        ib, ob, sb = blob(inputs), blob(b"".join(outs)), blob(b"".join(scripts))
+        ver, lock, inum, nout = u32("version"), u32("locktime"), u32("input_num"), np.array([len(t["outputs"]) for t in txs], dtype=np.uint32)
+        amt = np.array([t["amount"] for t in txs], dtype=np.uint64)
+        types = np.array([t["sighash_type"] for t in txs], dtype=np.uint8)
+        wit = np.array([1 if t["has_witness"] else 0 for t in txs], dtype=np.uint8)
+        sig64 = _u8(sig64, 64)
+        pub = np.ascontiguousarray(pub, dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.lamd_check_tx_sig_tx_batch(self._ctx, n, ver.ctypes.data, lock.ctypes.data, ib.ctypes.data, in_off.ctypes.data, inum.ctypes.data,
+                                                       amt.ctypes.data, ob.ctypes.data, out_off.ctypes.data, nout.ctypes.data, sb.ctypes.data,
+                                                       sc_off.ctypes.data, types.ctypes.data, wit.ctypes.data, sig64.ctypes.data, pub.ctypes.data,
+                                                       pub.shape[1], pub.shape[1], ok.ctypes.data))
+        return ok.astype(bool)
+
     def ecdsa_recover(self, hash32, sig64, recid):
         """numpy uint8 [n,32], [n,64], [n] -> (keys uint8 [n,33], ok bool [n]); secp256k1_ecdsa_recover semantics"""
         hash32, sig64 = _u8(hash32, 32), _u8(sig64, 64)

@@ -429,17 +429,20 @@ def _varint(n):
 def bip143_sighash(version, inputs, outputs, locktime, in_idx, script, amount, sighash_type):
     """inputs: [(txid32_le_bytes, vout, sequence)], outputs: [(amount, spk)].
     libwally wally_tx_get_btc_signature_hash(..., WALLY_TX_FLAG_USE_WITNESS) as called at
-    bitcoin/signature.c:145-148; only SIGHASH_ALL and SINGLE|ANYONECANPAY (signature.h:38-41)."""
+    bitcoin/signature.c:145-148 (check_tx_sig lets only SIGHASH_ALL and SINGLE|ANYONECANPAY through, signature.h:38-41; the other
+    BIP143 modes are modelled so that the device code can be compared on every type)."""
     acp = bool(sighash_type & 0x80)
-    single = (sighash_type & 0x7F) == 3
+    single, none = (sighash_type & 0x1F) == 3, (sighash_type & 0x1F) == 2          # BIP143: the low five bits select the output mode
     zero = b"\x00" * 32
     hp = zero if acp else sha256d(b"".join(t + v.to_bytes(4, "little") for t, v, _ in inputs))
-    hs = zero if (acp or single) else sha256d(b"".join(s.to_bytes(4, "little") for _, _, s in inputs))
+    hs = zero if (acp or single or none) else sha256d(b"".join(s.to_bytes(4, "little") for _, _, s in inputs))
 
     def ser_out(o):
         return o[0].to_bytes(8, "little") + _varint(len(o[1])) + o[1]
     if single:
         ho = sha256d(ser_out(outputs[in_idx])) if in_idx < len(outputs) else zero
+    elif none:
+        ho = zero
     else:
         ho = sha256d(b"".join(ser_out(o) for o in outputs))
     t, v, s = inputs[in_idx]

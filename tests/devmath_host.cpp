@@ -293,3 +293,11 @@ extern "C" int dm_gossip_frame(const u8 *m, size_t len, u32 *type, size_t *signe
 // ---- the device fuzzer's lane function with magnitude assertions on (lamd_fuzz_field runs the same function on the GPU)
 #include "../lightning_amd/csrc/fuzz.h"
 extern "C" uint64_t dm_fuzz_lane(uint64_t seed, uint64_t lane, int iters) { return fuzz_lane(seed, lane, iters); }
+
+// ---- BIP143 sighash of a flat transaction template (verify_core.h "BIP143 signature hash on the device")
+extern "C" int dm_bip143(u32 version, u32 locktime, const u8 *inputs, u32 n_in, const u8 *outputs, size_t outputs_len, u32 n_out, u32 in_idx,
+                         const u8 *script, size_t script_len, uint64_t amount, u32 sighash_type, u8 *out32) {
+  tx_view t;
+  t.version = version; t.locktime = locktime; t.inputs = inputs; t.n_in = n_in; t.outputs = outputs; t.outputs_len = outputs_len; t.n_out = n_out;
+  return bip143_sighash(t, in_idx, script, script_len, amount, sighash_type, out32);
+}

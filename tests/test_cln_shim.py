@@ -30,6 +30,33 @@ class Sha256d(ctypes.Structure):
     _fields_ = [("u8", ctypes.c_ubyte * 32)]
 
 
+class TxInput(ctypes.Structure):
+    _fields_ = [("txid", ctypes.c_ubyte * 32), ("index", ctypes.c_uint32), ("sequence", ctypes.c_uint32), ("amount_sat", ctypes.c_uint64)]
+
+
+class TxOutput(ctypes.Structure):
+    _fields_ = [("amount_sat", ctypes.c_uint64), ("script", ctypes.c_void_p)]
+
+
+class BitcoinTx(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_uint32), ("locktime", ctypes.c_uint32), ("num_inputs", ctypes.c_size_t), ("num_outputs", ctypes.c_size_t),
+                ("inputs", ctypes.POINTER(TxInput)), ("outputs", ctypes.POINTER(TxOutput))]
+
+
+def make_tx(shim, version, locktime, inputs, outputs):
+    """inputs: [(txid32, vout, sequence, amount)], outputs: [(amount, spk)] -> (BitcoinTx, keepalive)"""
+    ins = (TxInput * len(inputs))()
+    for k, (txid, vout, seq, amt) in enumerate(inputs):
+        ins[k].txid[:] = txid
+        ins[k].index, ins[k].sequence, ins[k].amount_sat = vout, seq, amt
+    outs = (TxOutput * max(1, len(outputs)))()
+    for k, (amt, spk) in enumerate(outputs):
+        outs[k].amount_sat = amt
+        outs[k].script = shim.shim_tal_dup(None, spk, len(spk))
+    tx = BitcoinTx(version, locktime, len(inputs), len(outputs), ins, outs)
+    return tx, (ins, outs)
+
+
 @pytest.fixture(scope="module")
 def shim():
     from lightning_amd import _build
@@ -40,6 +67,12 @@ def shim():
         getattr(L, n).restype = ctypes.c_bool
     for n in ("sigcheck_channel_update", "sigcheck_channel_announcement", "sigcheck_node_announcement", "lamd_shim_last_error"):
         getattr(L, n).restype = ctypes.c_char_p  # leaks the malloc()ed string; fine in a test
+    L.check_tx_sig_preimage.restype = ctypes.c_bool
+    L.shim_tal_dup.restype = ctypes.c_void_p
+    L.shim_tal_dup.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.tal_bytelen.restype = ctypes.c_size_t
+    L.tal_bytelen.argtypes = [ctypes.c_void_p]
+    L.check_tx_sig.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return L
 
 
@@ -76,12 +109,18 @@ def test_fromwire_compact_and_sha256_double(shim, kat):
 
 
 def test_check_tx_sig_sighash_gate_needs_no_device(shim):
-    """bitcoin/signature.c:206-211 rejects before any curve work"""
+    """bitcoin/signature.c:206-211 rejects before any curve work -- through the reference's own prototype
+    (struct bitcoin_tx *, input_num, subscript, witness_script, key, sig) and through the preimage form"""
     sig = BitcoinSig()
     key = Pubkey()
+    tx, keep = make_tx(shim, 2, 0, [(bytes(32), 0, 0, 1000)], [(900, b"\x00\x14" + bytes(20))])
+    sub = shim.shim_tal_dup(None, b"\x76\xa9", 2)
+    assert shim.tal_bytelen(sub) == 2
     for t, wit, reaches_verify in ((2, b"\x51", False), (0x83, None, False), (0x81, b"\x51", False), (3, b"\x51", False)):
         sig.sighash_type = t
-        assert shim.check_tx_sig(b"\x00" * 10, 10, wit, ctypes.byref(key), ctypes.byref(sig)) is False
+        assert shim.check_tx_sig_preimage(b"\x00" * 10, 10, wit, ctypes.byref(key), ctypes.byref(sig)) is False
+        w = shim.shim_tal_dup(None, wit, len(wit)) if wit is not None else None
+        assert shim.check_tx_sig(ctypes.byref(tx), 0, sub, w, ctypes.byref(key), ctypes.byref(sig)) is False
 
 
 @pytest.mark.gpu
@@ -116,8 +155,21 @@ def test_reference_unit_test_expectations(shim, kat):
     verdicts = {}
     for v in kat["bip143"]:
         pre = H(v["preimage"])
-        verdicts[v["name"]] = shim.check_tx_sig(pre, len(pre), b"\x76", ctypes.byref(key), ctypes.byref(sig))
+        verdicts[v["name"]] = shim.check_tx_sig_preimage(pre, len(pre), b"\x76", ctypes.byref(key), ctypes.byref(sig))
     assert verdicts["KAT-O/fee=165750"] is True and sum(verdicts.values()) == 1
+    # ... and as onchaind calls it (onchaind.c:430-432): check_tx_sig(tx, 0, NULL, wscript, &keyset->other_htlc_key, remotesig) on the
+    # transaction itself -- the BIP143 hash is built on the device from the template
+    rawtx = H("0200000001e1ebca08cf1c301ac563580a1126d5c8fcb0e5e2043230b852c726553caf1e1d0000000000000000000160ae0a0000000000"
+              "22002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d61927436041796d000000")
+    wscript = H("76a914a8c40c334351dbe8e5908544f1c98fbcfb8719fc8763ac6721038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de05"
+                "4432eb7f7c820120876475527c2103cf8e2f193a6aed60db80af75f3c8d59c2de735b299b7c7083527be9bd23b77a852ae67a914b8bcd51e"
+                "fa35be1e50ae2d5f72f4500acb005c9c88ac6868")
+    ws = shim.shim_tal_dup(None, wscript, len(wscript))
+    got = {}
+    for fee in (165749, 165750, 165751, 0):
+        tx, keep = make_tx(shim, 2, 109, [(rawtx[5:37], 0, 0, 700000)], [(700000 - fee, rawtx[56:90])])
+        got[fee] = shim.check_tx_sig(ctypes.byref(tx), 0, None, ws, ctypes.byref(key), ctypes.byref(sig))
+    assert got == {165749: False, 165750: True, 165751: False, 0: False}
     # ... and the grind itself as the test runs it: weight 663, max_possible_feerate 250 000, 1000 iterations
     pre = H(next(v for v in kat["bip143"] if v["name"] == "KAT-O/fee=0")["preimage"])
     spk = H("002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d6192743604179")

@@ -532,3 +532,54 @@ def test_fuzz_lane_respects_magnitude_bounds(dm):
     seen = {dm.dm_fuzz_lane(1, lane, 8) for lane in range(300)}
     assert len(seen) == 300
     assert dm.dm_fuzz_lane(1, 5, 8) == dm.dm_fuzz_lane(1, 5, 8) != dm.dm_fuzz_lane(2, 5, 8)
+
+
+def _rand_tx(rnd):
+    n_in, n_out = rnd.choice([1, 1, 1, 2, 3, 7]), rnd.choice([0, 1, 1, 2, 3, 5])
+    inputs = [(bytes(rnd.randrange(256) for _ in range(32)), rnd.randrange(1 << 32), rnd.randrange(1 << 32)) for _ in range(n_in)]
+    outputs = [(rnd.randrange(1 << 51), bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 22, 34, 34, 100, 253, 300])))) for _ in range(n_out)]
+    script = bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 25, 71, 133, 133, 252, 253, 254, 400])))
+    return rnd.choice([1, 2, 2, 0xFFFFFFFF]), inputs, outputs, rnd.randrange(1 << 32), script, rnd.randrange(1 << 51)
+
+
+def _tx_flat(inputs, outputs):
+    ib = b"".join(t + v.to_bytes(4, "little") + s.to_bytes(4, "little") for t, v, s in inputs)
+    ob = b"".join(a.to_bytes(8, "little") + pyref._varint(len(spk)) + spk for a, spk in outputs)
+    return ib, ob
+
+
+def test_bip143_sighash_host_build_vs_pyref_and_reference_kat(dm, kat):
+    """the device's BIP143 code (streaming SHA-256 over the template's pieces) on the host: the reference's own transaction
+    (onchaind/test/run-grind_feerate.c: 290-byte preimage, sighash 45fa7ea1... at fee 165 750) and 100 000 random templates
+    -- every sighash type the format defines, inputs/outputs/script sizes across the CompactSize boundaries -- against the
+    spec-level model"""
+    dm.dm_bip143.restype = ctypes.c_int
+    dm.dm_bip143.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
+                             ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
+    o = ctypes.create_string_buffer(32)
+    tx = H("0200000001e1ebca08cf1c301ac563580a1126d5c8fcb0e5e2043230b852c726553caf1e1d0000000000000000000160ae0a0000000000"
+           "22002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d61927436041796d000000")
+    ws = H("76a914a8c40c334351dbe8e5908544f1c98fbcfb8719fc8763ac6721038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de05"
+           "4432eb7f7c820120876475527c2103cf8e2f193a6aed60db80af75f3c8d59c2de735b299b7c7083527be9bd23b77a852ae67a914b8bcd51e"
+           "fa35be1e50ae2d5f72f4500acb005c9c88ac6868")
+    spk = tx[56:90]
+    for v in kat["bip143"]:
+        fee = int(v["name"].split("=")[1])
+        ib, ob = _tx_flat([(tx[5:37], 0, 0)], [(700000 - fee, spk)])
+        assert dm.dm_bip143(2, 109, ib, 1, ob, len(ob), 1, 0, ws, len(ws), 700000, 1, o) == 1
+        assert o.raw == H(v["expect"]), v["name"]
+    assert any(v["expect"].startswith("45fa7ea15e62277f") for v in kat["bip143"])
+    rnd = random.Random(143)
+    for it in range(100_000):
+        version, inputs, outputs, lock, script, amount = _rand_tx(rnd)
+        ib, ob = _tx_flat(inputs, outputs)
+        sht = rnd.choice([1, 1, 0x83, 0x83, 2, 3, 0x81, 0x82])
+        idx = rnd.randrange(len(inputs))
+        ok = dm.dm_bip143(version, lock, ib, len(inputs), ob, len(ob), len(outputs), idx, script, len(script), amount, sht, o)
+        assert ok == 1 and o.raw == pyref.bip143_sighash(version, inputs, outputs, lock, idx, script, amount, sht)[0], (it, sht)
+    # inconsistent templates are refused, not hashed
+    version, inputs, outputs, lock, script, amount = 2, [(bytes(32), 0, 0)], [(5, b"\x51")], 0, b"\x51", 9
+    ib, ob = _tx_flat(inputs, outputs)
+    assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob), 1, 1, script, 1, amount, 1, o) == 0          # input index out of range
+    assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob) - 1, 1, 0, script, 1, amount, 1, o) == 0      # truncated outputs
+    assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob), 2, 0, script, 1, amount, 1, o) == 0          # fewer outputs than claimed

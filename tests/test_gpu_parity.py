@@ -810,13 +810,58 @@ def test_keyed_fast_path_degenerate_rows_take_the_complete_formulas(eng_keyed, k
     """golden rows built so that an addition inside the comb meets +-its operand, or the result is the point at infinity
     (u1*G = -u2*Q), leave Z = 0 in the bare-formula kernel: they must be re-decided by the complete formulas, not guessed"""
     e = eng_keyed
-    vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 66 and any(t in v["name"] for t in ("u1G==u2Q", "R=inf", "Q=G", "Q=lamG"))]
-    assert len(vs) >= 6
-    reps = 4                                    # each key several times: forced onto per-key tables (LAMD_KEYED=1)
-    hs = _rows([H(v["hash"]) for v in vs] * reps, 32)
-    sg = _rows([H(v["sig"]) for v in vs] * reps, 64)
-    pk = _rows([H(v["pub"]) for v in vs] * reps, 33)
-    got = e.verify_ecdsa(hs, sg, pk)
-    assert [bool(g) for g in got] == [v["expect"] for v in vs] * reps
-    inf = e.info()
-    assert inf["last_hot_rows"] > 0 and inf["last_suspect_rows"] > 0
+    for publen, tags in ((65, ("u1G==u2Q", "R=inf")), (33, ("Q=G", "Q=lamG"))):
+        vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen and any(t in v["name"] for t in tags)]
+        assert len(vs) >= 6
+        reps = 4                                    # each key several times: forced onto per-key tables (LAMD_KEYED=1)
+        hs = _rows([H(v["hash"]) for v in vs] * reps, 32)
+        sg = _rows([H(v["sig"]) for v in vs] * reps, 64)
+        pk = _rows([H(v["pub"]) for v in vs] * reps, publen)
+        got = e.verify_ecdsa(hs, sg, pk)
+        assert [bool(g) for g in got] == [v["expect"] for v in vs] * reps
+        if publen == 65:
+            # u1*G + u2*Q = infinity, or the last addition is a doubling: Z = 0 in the bare formulas
+            inf = e.info()
+            assert inf["last_hot_rows"] > 0 and inf["last_suspect_rows"] >= 4 * reps, inf
+
+
+def test_check_tx_sig_from_transaction_templates_vs_spec_model(eng, orc):
+    """check_tx_sig with the BIP143 hash built on the device (lamd_check_tx_sig_tx_batch): random transaction templates signed
+    with the oracle's signer over pyref's sighash; a third of the rows damaged (amount, script byte, output, sequence, wrong
+    input, sighash type outside the gate); verdicts against pyref sighash + oracle verify"""
+    rnd = random.Random(1430)
+    txs, sigs, pubs, exp = [], [], [], []
+    keys = [(bytes(rnd.randrange(1, 256) for _ in range(32))) for _ in range(12)]
+    pubs33 = [pyref.ser33(pyref.pubkey_create(int.from_bytes(d, "big"))) for d in keys]
+    for it in range(3000):
+        n_in, n_out = rnd.choice([1, 1, 2, 4]), rnd.choice([1, 1, 2, 3])
+        inputs = [(bytes(rnd.randrange(256) for _ in range(32)), rnd.randrange(1 << 32), rnd.randrange(1 << 32)) for _ in range(n_in)]
+        outputs = [(rnd.randrange(1 << 40), bytes(rnd.randrange(256) for _ in range(rnd.choice([22, 34, 34, 43])))) for _ in range(n_out)]
+        script = bytes(rnd.randrange(256) for _ in range(rnd.choice([25, 71, 133, 133, 260])))
+        t = dict(version=2, locktime=rnd.randrange(1 << 32), inputs=inputs, outputs=outputs, input_num=rnd.randrange(n_in),
+                 amount=rnd.randrange(1 << 44), script=script, sighash_type=rnd.choice([1, 1, 1, 0x83]), has_witness=True)
+        k = rnd.randrange(len(keys))
+        h = pyref.bip143_sighash(2, inputs, outputs, t["locktime"], t["input_num"], script, t["amount"], t["sighash_type"])[0]
+        sig = orc.ecdsa_sign(h, keys[k], bytes(rnd.randrange(1, 256) for _ in range(32)))
+        dmg = rnd.randrange(18)
+        if dmg == 0:
+            t["amount"] ^= 1
+        elif dmg == 1:
+            t["script"] = script[:-1] + bytes([script[-1] ^ 4])
+        elif dmg == 2:
+            t["outputs"] = [(outputs[0][0] + 1, outputs[0][1])] + outputs[1:]
+        elif dmg == 3:
+            t["inputs"] = [(inputs[0][0], inputs[0][1], inputs[0][2] ^ 1)] + inputs[1:]
+        elif dmg == 4 and n_in > 1:
+            t["input_num"] = (t["input_num"] + 1) % n_in
+        elif dmg == 5:
+            t["sighash_type"] = rnd.choice([2, 3, 0x81, 0x82, 0])          # outside the gate: rejected whatever the signature
+        elif dmg == 6:
+            t["has_witness"] = False                                       # SINGLE|ANYONECANPAY needs a witness script; ALL does not
+        h2 = pyref.bip143_sighash(2, t["inputs"], t["outputs"], t["locktime"], t["input_num"], t["script"], t["amount"], t["sighash_type"])[0]
+        gate = t["sighash_type"] == 1 or (t["sighash_type"] == 0x83 and t["has_witness"])
+        txs.append(t); sigs.append(sig); pubs.append(pubs33[k])
+        exp.append(bool(gate and orc.ecdsa_verify(h2, sig, pubs33[k])))
+    got = eng.check_tx_sig_tx_batch(txs, _rows(sigs, 64), _rows(pubs, 33))
+    assert [bool(g) for g in got] == exp
+    assert 1500 < sum(exp) < 2900

@@ -16,11 +16,22 @@ HI, LO = 20, 22                      # v[20:21], v[22:23]
 # latency anyway): same throughput, but the plain order is 5 % faster for a single latency-bound wave (484-row batch
 # 1.14 ms vs 1.21 ms), so the plain order is what ships.
 INTERLEAVE = "--interleave" in sys.argv
+# --carry=sgpr: the (dead) carry-out of the two chains goes to two SGPR pairs instead of VCC (two extra outputs %13, %14; inputs move up by two).
+#   Measured (tools/fe_bench.hip): v_mad_u64_u32 with a VCC carry-out saturates at 2.9e13 lane-ops/s whatever the occupancy, with an SGPR pair
+#   it reaches 3.2e13 at 4 waves per SIMD and 3.7e13 at 8.
+# --mask=sgpr: the 29-bit mask comes from an SGPR input (last operand) instead of a 32-bit literal (4-byte shorter encoding)
+# --shift=alignbit: the 64-bit right shift as v_alignbit_b32 + v_lshrrev_b32
+CARRY_SGPR = "--carry=sgpr" in sys.argv
+MASK_SGPR = "--mask=sgpr" in sys.argv
+SHIFT_ALIGN = "--shift=alignbit" in sys.argv
+NX = 2 if CARRY_SGPR else 0          # extra outputs in front of the inputs
 R = lambda k: "%%%d" % k             # r[k]
 T = lambda k: "%%%d" % (8 + k % 3)   # h[k] lives in rotating temp k mod 3
-A = lambda i: "%%%d" % (13 + i)
-B = lambda i: "%%%d" % (22 + i)
-SR0, S256 = "%31", "%32"
+A = lambda i: "%%%d" % (13 + NX + i)
+B = lambda i: "%%%d" % (22 + NX + i)
+SR0, S256 = "%%%d" % (31 + NX), "%%%d" % (32 + NX)
+MASK = "%%%d" % (33 + NX) if MASK_SGPR else "0x1fffffff"
+CY = {True: "%13" if CARRY_SGPR else "vcc", False: "%14" if CARRY_SGPR else "vcc"}   # keyed by "is the high chain"
 hi, lo = "v[%d:%d]" % (HI, HI + 1), "v[%d:%d]" % (LO, LO + 1)
 hil, lol = "v%d" % HI, "v%d" % LO
 
@@ -35,25 +46,36 @@ def column(acc, k, square, first):
             x, y = (A(i), A(j)) if i == j else (B(i), A(j))      # B = doubled limbs
         else:
             x, y = A(i), B(j)
-        out.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, x, y, "0" if first and not out else acc))
+        out.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, CY[acc == hi], x, y, "0" if first and not out else acc))
+    return out
+
+
+def extract(dst, acc):
+    """dst = acc & (2^29 - 1); acc >>= 29"""
+    accl, acch = ("v%d" % HI, "v%d" % (HI + 1)) if acc == hi else ("v%d" % LO, "v%d" % (LO + 1))
+    out = ["v_and_b32 %s, %s, %s" % (dst, MASK, accl)]
+    if SHIFT_ALIGN:
+        out += ["v_alignbit_b32 %s, %s, %s, 29" % (accl, acch, accl), "v_lshrrev_b32 %s, 29, %s" % (acch, acch)]
+    else:
+        out.append("v_lshrrev_b64 %s, 29, %s" % (acc, acc))
     return out
 
 
 def body(square):
     # per step: (high-chain instructions, low-chain instructions); step 0 is the head (column 9 alone)
-    steps = [(column(hi, 9, square, True) + ["v_and_b32 %s, 0x1fffffff, %s" % (T(0), hil), "v_lshrrev_b64 %s, 29, %s" % (hi, hi)], [])]
+    steps = [(column(hi, 9, square, True) + extract(T(0), hi), [])]
     for k in range(8):
         h = []
         if k < 7:
             h = column(hi, 10 + k, square, False)
-            h += ["v_and_b32 %s, 0x1fffffff, %s" % (T(k + 1), hil), "v_lshrrev_b64 %s, 29, %s" % (hi, hi)]
+            h += extract(T(k + 1), hi)
         l = column(lo, k, square, k == 0)
-        l.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (lo, T(k), SR0, lo))
+        l.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (lo, CY[False], T(k), SR0, lo))
         if k > 0:
-            l.append("v_mad_u64_u32 %s, vcc, %s, %s, %s" % (lo, T(k - 1), S256, lo))
-        l += ["v_and_b32 %s, 0x1fffffff, %s" % (R(k), lol), "v_lshrrev_b64 %s, 29, %s" % (lo, lo)]
+            l.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (lo, CY[False], T(k - 1), S256, lo))
+        l += extract(R(k), lo)
         steps.append((h, l))
-    steps.append(([], column(lo, 8, square, False) + ["v_mad_u64_u32 %s, vcc, %s, %s, %s" % (lo, T(7), S256, lo)]))
+    steps.append(([], column(lo, 8, square, False) + ["v_mad_u64_u32 %s, %s, %s, %s, %s" % (lo, CY[False], T(7), S256, lo)]))
     ins = []
     for h, l in steps:
         # within a step the two lists are independent (h writes T(k+1), l reads T(k), T(k-1)): alternate them
@@ -82,5 +104,9 @@ def emit(name, square):
 print("// GENERATED by tools/gen_fe_asm.py -- do not edit.  See that file for the operand map.")
 print("#define LAMD_FE_ASM_HI \"{v[%d:%d]}\"" % (HI, HI + 1))
 print("#define LAMD_FE_ASM_LO \"{v[%d:%d]}\"" % (LO, LO + 1))
+print("// extra operands of the asm statements in fe.h (cy0, cy1: dead carry-outs; the 29-bit mask)")
+print("#define LAMD_FE_ASM_EXTRA_OUT %s" % (', "=&s"(cy0), "=&s"(cy1)' if CARRY_SGPR else ""))
+print("#define LAMD_FE_ASM_EXTRA_IN %s" % (', "s"(FE_M29)' if MASK_SGPR else ""))
+print("#define LAMD_FE_ASM_CLOBBER %s" % ("" if CARRY_SGPR else '"vcc"'))
 emit("LAMD_FE_MUL_ASM", False)
 emit("LAMD_FE_SQR_ASM", True)
