@@ -1,0 +1,121 @@
+/* lightning_amd_gossipd.h -- batched gossip ingest: the receive side of Core Lightning's gossipd
+ * (gossipd/gossipd.c:172-286 handle_recv_gossip -> gossipd/gossmap_manage.c:620-753 channel_announcement,
+ * :878-1120 channel_update, :1129-1248 node_announcement, :753-872 get_txout reply, :1255-1342 queued messages,
+ * :1358-1390 new block) restructured around ONE device call per drained queue instead of one libsecp256k1 call per
+ * signature.  C ABI, host code in liblightning_amd_cln.so (lightning_amd/csrc/gossip_ingest.cpp).
+ *
+ * How a batch runs (lamd_gossipd_process):
+ *   1. every queued message (what connectd forwards, connectd/multiplex.c:829-842: source peer + raw wire message) is
+ *      framed on the host, and the filters that need no curve arithmetic are evaluated against the state as it is
+ *      BEFORE the batch: malformed framing / r,s >= n, unknown chain_hash, unreasonable timestamp, short_channel_id
+ *      already known / pending / in the txout-failure set;
+ *   2. everything whose outcome can depend on a signature is verified in one lamd_sigcheck_gossip_batch() call
+ *      (identical (message, signer) pairs -- the same announcement relayed by several peers -- once); announcements
+ *      that step 1 already knows it will drop only have their two bitcoin keys parsed (lamd_pubkey_parse_batch),
+ *      because fromwire_channel_announcement rejects an invalid key as "Malformed" BEFORE any of those filters
+ *      (bitcoin/pubkey.c:102-113);
+ *   3. the messages are applied strictly in arrival order with the reference's own control flow, the precomputed
+ *      verdicts standing in for the sigcheck_*() calls -- so every ordering dependency (a channel_update waits for its
+ *      channel_announcement to be accepted and confirmed, :1060-1097; a duplicate announcement is dropped only if the
+ *      earlier copy was accepted, :673-676) resolves exactly as it does one message at a time.
+ * What is kept: the announce/update/node maps, the pending and too-early announcement maps with their queued
+ * channel_updates and node_announcements, the txout-failure set, and an append-only store (records with timestamps,
+ * deletions marked).  What is not: pruning, dying/spent channels, compaction, the seeker, local (known_amount)
+ * announcements, the gossip_store file format -- events tell the host daemon what the reference would have done
+ * (send a warning, ask lightningd for a txout, append to / delete from the store) and it does the I/O.
+ *
+ * Everything observable is reported through the event callback, in the order the reference would produce it; texts
+ * (warnings, traces) are the reference's own format strings. */
+#ifndef LIGHTNING_AMD_GOSSIPD_H
+#define LIGHTNING_AMD_GOSSIPD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lightning_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lamd_gossipd lamd_gossipd;
+
+enum lamd_gossipd_event_kind {
+	LAMD_GEV_WARNING = 1,        /* queue_peer_msg(towire_warningfmt(text)) to peer (gossipd.c:277-283, gossmap_manage.c:589-596) */
+	LAMD_GEV_GET_TXOUT = 2,      /* towire_gossipd_get_txout(scid) to lightningd (gossmap_manage.c:749-750, :1385-1386) */
+	LAMD_GEV_STORE_ADD = 3,      /* gossip_store_add(data, timestamp): record number `index`, wire type `type` */
+	LAMD_GEV_STORE_DEL = 4,      /* gossip_store_del(record `index`) */
+	LAMD_GEV_STORE_SET_TS = 5,   /* gossip_store_set_timestamp(record `index`, timestamp) (gossmap_manage.c:950-951) */
+	LAMD_GEV_PEER_UPDATE = 6,    /* tell_lightningd_peer_update: scid, values[0..4] = fee_base, fee_ppm, cltv, htlc_min, htlc_max */
+	LAMD_GEV_TRACE = 7,          /* status_peer_trace(peer, text): "Bad gossip order: ..." (gossmap_manage.c:576-579), the Received ... lines */
+	LAMD_GEV_QUERY_CHANNEL = 8,  /* query_unknown_channel(peer, scid) (gossmap_manage.c:908) */
+	LAMD_GEV_QUERY_NODE = 9,     /* query_unknown_node(peer, node id in data) (gossmap_manage.c:1232) */
+	LAMD_GEV_GOOD_GOSSIP = 10,   /* peer_supplied_good_gossip(peer, 1) */
+	LAMD_GEV_TXOUT_FAILED = 11,  /* txout_failures_add(scid) (gossmap_manage.c:868-869) */
+	LAMD_GEV_DEBUG = 12          /* status_debug / status_trace lines without a peer */
+};
+
+typedef struct lamd_gossipd_event {
+	int kind;
+	int has_peer;
+	uint8_t peer[33];
+	uint64_t scid;
+	uint64_t index;      /* store record number */
+	uint32_t type;       /* wire type of a store record */
+	uint32_t timestamp;
+	uint64_t values[5];
+	const char *text;    /* NUL-terminated, valid during the callback */
+	const uint8_t *data; /* valid during the callback */
+	size_t len;
+} lamd_gossipd_event;
+
+typedef void (*lamd_gossipd_event_fn)(void *user, const lamd_gossipd_event *ev);
+
+typedef struct lamd_gossipd_config {
+	uint8_t chain_hash[32];   /* chainparams->genesis_blockhash as it appears on the wire */
+	uint8_t our_id[33];       /* daemon->id: updates for channels INTO this node are reported (gossmap_manage.c:973-983) */
+	uint32_t blockheight;     /* daemon->current_blockheight (0 = unknown) */
+	uint64_t now;             /* seconds since the epoch; 0 = read the clock at every lamd_gossipd_process() */
+	uint32_t prune_interval;  /* GOSSIP_PRUNE_INTERVAL: 1209600 (0 = that default) */
+} lamd_gossipd_config;
+
+/* A verification back end with the signature of lamd_sigcheck_gossip_batch / lamd_pubkey_parse_batch.  The product uses
+ * the engine (lamd_gossipd_new with a context); the hook exists so that the host logic can be tested on a machine
+ * without a GPU against a sequential model -- the library itself contains no CPU verification. */
+typedef int (*lamd_gossipd_sigcheck_fn)(void *user, size_t n, const uint8_t *msgs, const uint64_t *off, const uint8_t *node_ids33,
+					int8_t *verdict);
+typedef int (*lamd_gossipd_keyparse_fn)(void *user, size_t n, const uint8_t *pub33, uint8_t *ok);
+
+/* ctx: the engine context verdicts come from (NULL only when lamd_gossipd_set_backend() is called before the first
+ * lamd_gossipd_process()).  Returns NULL on allocation failure. */
+lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_config *cfg, lamd_gossipd_event_fn on_event, void *user);
+void lamd_gossipd_free(lamd_gossipd *g);
+void lamd_gossipd_set_backend(lamd_gossipd *g, lamd_gossipd_sigcheck_fn sigcheck, lamd_gossipd_keyparse_fn keyparse, void *user);
+
+/* connectd -> gossipd: one raw peer message (type 256/257/258) from source_peer33 (may be NULL: generated locally).
+ * Queues only; LAMD_ERR_STATE when more than 500 000 messages are waiting (connectd drops there, multiplex.c:829-833). */
+int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, const uint8_t *msg, size_t len);
+/* Drains the queue as ONE batch (see above).  Returns the number of messages applied, or a negative LAMD_ERR_*. */
+long lamd_gossipd_process(lamd_gossipd *g);
+/* lightningd's answer to LAMD_GEV_GET_TXOUT (gossmap_manage.c:753-872); script_len 0 = no unspent output.  Channel_updates
+ * and node_announcements that were waiting are verified (one batch) and applied once nothing is pending any more. */
+int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const uint8_t *script, size_t script_len);
+/* gossmap_manage_new_block (:1358-1390): too-early announcements that are now deep enough become pending */
+int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight);
+void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now);
+
+typedef struct lamd_gossipd_stats {
+	uint64_t messages;          /* applied so far */
+	uint64_t batches;           /* device calls for signatures */
+	uint64_t verified_messages; /* messages sent to the device for signatures (after de-duplication) */
+	uint64_t verified_sigs;     /* signatures those carried (4 per channel_announcement) */
+	uint64_t keyparse_messages; /* announcements whose bitcoin keys only were parsed */
+	uint64_t duplicates;        /* identical (message, signer) pairs verified once */
+	uint64_t late_verifies;     /* sigcheck needed during the ordered replay that the plan had not foreseen (0 expected) */
+	uint64_t channels, nodes, pending, early, queued_updates, queued_nodes, store_records;
+} lamd_gossipd_stats;
+void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

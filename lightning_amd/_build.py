@@ -12,7 +12,8 @@ SOURCES = [os.path.join(CSRC, f) for f in ("lamd_engine.hip", "verify_core.h", "
 
 
 SHIM = os.path.join(PKG, "liblightning_amd_cln.so")
-SHIM_SOURCES = [os.path.join(CSRC, "cln_shim.cpp"), os.path.join(CSRC, "cln_shim.h")]
+SHIM_CPP = [os.path.join(CSRC, "cln_shim.cpp"), os.path.join(CSRC, "gossip_ingest.cpp")]
+SHIM_SOURCES = SHIM_CPP + [os.path.join(CSRC, "cln_shim.h"), os.path.join(CSRC, "verify_core.h"), os.path.join(ROOT, "include", "lightning_amd_gossipd.h")]
 
 
 def build_shim(force=False):
@@ -20,8 +21,8 @@ def build_shim(force=False):
     if not force and os.path.exists(SHIM) and all(os.path.getmtime(s) <= os.path.getmtime(SHIM) for s in SHIM_SOURCES + [LIB]):
         return SHIM
     cxx = os.environ.get("CXX", "g++")
-    subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", SHIM + ".tmp", SHIM_SOURCES[0],
-                           "-L" + PKG, "-llightning_amd", "-Wl,-rpath,$ORIGIN"])
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function", "-o", SHIM + ".tmp"] + SHIM_CPP +
+                          ["-L" + PKG, "-llightning_amd", "-Wl,-rpath,$ORIGIN"])
     os.replace(SHIM + ".tmp", SHIM)
     return SHIM
 

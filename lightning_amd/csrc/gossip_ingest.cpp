@@ -1,0 +1,774 @@
+// Batched gossip ingest (include/lightning_amd_gossipd.h): gossipd's receive path -- gossipd/gossipd.c:172-286 and
+// gossipd/gossmap_manage.c:620-1342 of the reference -- with every signature of a drained queue decided by ONE device call.
+//
+// Structure (deliberately not the reference's): plan() walks the queue once and decides, from framing and from the state as it
+// is before the batch, which (message, signer) pairs can ever reach a sigcheck_*() call; verify() sends those to the device;
+// apply_*() then run the reference's control flow per message in arrival order with verdict look-ups where the reference calls
+// sigcheck_*().  The warning / trace texts are the reference's format strings (file:line cited at each).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lightning_amd_gossipd.h"
+#include "cln_shim.h"
+#include "verify_core.h"  // gossip_parse_frame(): the same framing rules the device applies
+
+namespace {
+
+using lamd::gossip_frame;
+using lamd::gossip_parse_frame;
+using lamd::GOSSIP_CANN;
+using lamd::GOSSIP_CUPD;
+using lamd::GOSSIP_NANN;
+using lamd::u32;
+using lamd::u64;
+
+typedef std::vector<u8> bytes;
+struct nodeid {
+  u8 k[33];
+  bool operator<(const nodeid &o) const { return memcmp(k, o.k, 33) < 0; }
+  bool operator==(const nodeid &o) const { return memcmp(k, o.k, 33) == 0; }
+};
+
+std::string hexs(const u8 *p, size_t n) {
+  static const char *d = "0123456789abcdef";
+  std::string s;
+  s.reserve(2 * n);
+  for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); }
+  return s;
+}
+std::string hexs(const bytes &b) { return hexs(b.data(), b.size()); }
+u64 be64(const u8 *p) { u64 v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
+u32 be32(const u8 *p) { return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | p[3]; }
+u32 be16(const u8 *p) { return ((u32)p[0] << 8) | p[1]; }
+// fmt_short_channel_id (bitcoin/short_channel_id.c:56-62)
+std::string fmt_scid(u64 scid) {
+  char b[64];
+  snprintf(b, sizeof b, "%dx%dx%d", (int)(scid >> 40), (int)((scid >> 16) & 0xFFFFFF), (int)(scid & 0xFFFF));
+  return b;
+}
+u32 scid_blocknum(u64 scid) { return (u32)(scid >> 40); }
+// bitcoin/short_channel_id.h:82-87, ANNOUNCE_MIN_DEPTH 6
+bool scid_depth_announceable(u64 scid, u32 height) { return (u64)scid_blocknum(scid) + 6 - 1 <= height; }
+// fmt_secp256k1_ecdsa_signature prints the DER form (bitcoin/signature.c:325-335)
+std::string der_hex(const u8 sig64[64]) {
+  u8 out[72];
+  size_t n = 2;
+  for (int h = 0; h < 2; h++) {
+    const u8 *v = sig64 + 32 * h;
+    size_t skip = 0;
+    while (skip < 31 && v[skip] == 0) skip++;
+    const bool pad = v[skip] & 0x80;
+    out[n++] = 0x02;
+    out[n++] = (u8)(32 - skip + (pad ? 1 : 0));
+    if (pad) out[n++] = 0;
+    memcpy(out + n, v + skip, 32 - skip);
+    n += 32 - skip;
+  }
+  out[0] = 0x30;
+  out[1] = (u8)(n - 2);
+  return hexs(out, n);
+}
+const u8 ORDER_N[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFE,
+                        0xBA, 0xAE, 0xDC, 0xE6, 0xAF, 0x48, 0xA0, 0x3B, 0xBF, 0xD2, 0x5E, 0x8C, 0xD0, 0x36, 0x41, 0x41};
+bool sig_in_range(const u8 *sig64) { return memcmp(sig64, ORDER_N, 32) < 0 && memcmp(sig64 + 32, ORDER_N, 32) < 0; }  // wire/fromwire.c:196
+
+// gossipd/sigcheck.c:21-26,52-113,150-157: the text for "first bad signature = which" (1-based)
+std::string sigcheck_text(u32 type, int which, const bytes &m) {
+  const size_t off = type == GOSSIP_CANN ? 258 : 66;
+  struct sha256_double h;
+  sha256_double(&h, m.data() + off, m.size() - off);
+  static const char *names[4] = {"Bad node_signature_1", "Bad node_signature_2", "Bad bitcoin_signature_1", "Bad bitcoin_signature_2"};
+  const char *what = type == GOSSIP_CANN ? names[which - 1] : "Bad signature for";
+  const u8 *sig = m.data() + 2 + (type == GOSSIP_CANN ? 64 * (which - 1) : 0);
+  const char *kind = type == GOSSIP_CANN ? "channel_announcement" : (type == GOSSIP_CUPD ? "channel_update" : "node_announcement");
+  return std::string(what) + " " + der_hex(sig) + " hash " + hexs(h.sha.u.u8, 32) + " on " + kind + " " + hexs(m);
+}
+
+// common/wireaddr.c:30-68,858-891: does fromwire_wireaddr_array() accept the `addresses` field?
+bool wireaddrs_ok(const u8 *p, size_t len) {
+  while (len) {
+    const u8 type = p[0];
+    p++; len--;
+    size_t alen;
+    switch (type) {
+      case 1: alen = 4; break;
+      case 2: alen = 16; break;
+      case 3: alen = 10; break;
+      case 4: alen = 35; break;
+      case 5:
+        if (len < 1) return false;
+        alen = p[0];
+        p++; len--;
+        break;
+      default: return true;  // unknown type: stop there
+    }
+    if (len < alen + 2) return false;
+    p += alen + 2; len -= alen + 2;
+  }
+  return true;
+}
+
+struct pending_cannounce {  // gossmap_manage.c:36-45
+  bytes msg;
+  bool has_src;
+  nodeid src;
+  nodeid node[2];
+  bytes spk;
+};
+struct pending_cupdate {  // :47-62
+  u64 scid;
+  u8 mflags, cflags;
+  u32 cltv, fee_base, fee_ppm, timestamp;
+  u64 hmin, hmax;
+  bytes update;
+  bool has_src;
+  nodeid src;
+};
+struct pending_nannounce {  // :64-70
+  nodeid id;
+  u32 timestamp;
+  bytes msg;
+  bool has_src;
+  nodeid src;
+};
+struct chan {
+  nodeid node[2];
+  u64 cann_rec;
+  bool set[2];
+  u64 cupd_rec[2];
+};
+struct node {
+  u32 nchans;
+  bool announced;
+  u64 nann_rec;
+};
+struct record { u32 type, timestamp; bool deleted; };
+
+struct queued { bytes msg; bool has_src; nodeid src; };
+
+// one message of a batch as plan() saw it
+struct planned {
+  u32 type;
+  bool malformed;     // framing / signature range: decided on the host
+  bool addrs_bad;     // node_announcement only
+  int slot;           // verification slot with the signer the plan expects (-1: none)
+  int keyslot;        // channel_announcement whose bitcoin keys only are parsed (-1: none)
+  u64 scid;
+};
+
+}  // namespace
+
+struct lamd_gossipd {
+  lamd_ctx *ctx = nullptr;
+  lamd_gossipd_config cfg;
+  lamd_gossipd_event_fn on_event = nullptr;
+  void *user = nullptr;
+  lamd_gossipd_sigcheck_fn be_sig = nullptr;
+  lamd_gossipd_keyparse_fn be_key = nullptr;
+  void *be_user = nullptr;
+  lamd_gossipd_stats st;
+
+  std::vector<queued> queue;
+  std::map<u64, chan> chans;
+  std::map<nodeid, node> nodes;
+  std::map<u64, pending_cannounce> pending_ann, early_ann;  // ordered: new_block walks early_ann by ascending scid
+  std::vector<pending_cupdate> pending_cupdates, early_cupdates;
+  std::vector<pending_nannounce> pending_nannounces;
+  std::map<u64, bool> txout_failures;
+  std::vector<record> store;
+
+  // verdicts of the batch being applied: (message bytes + signer) -> verdict
+  std::unordered_map<std::string, int> verdicts;
+
+  u64 now() const { return cfg.now ? cfg.now : (u64)time(nullptr); }
+
+  // ---- events
+  void emit(lamd_gossipd_event &ev) { if (on_event) on_event(user, &ev); }
+  void ev_text(int kind, bool has_peer, const nodeid *peer, const std::string &text) {
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = kind;
+    ev.has_peer = has_peer;
+    if (has_peer) memcpy(ev.peer, peer->k, 33);
+    ev.text = text.c_str();
+    emit(ev);
+  }
+  void ev_scid(int kind, bool has_peer, const nodeid *peer, u64 scid) {
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = kind;
+    ev.has_peer = has_peer;
+    if (has_peer) memcpy(ev.peer, peer->k, 33);
+    ev.scid = scid;
+    emit(ev);
+  }
+  void warning(bool has_peer, const nodeid *peer, const std::string &text) { ev_text(LAMD_GEV_WARNING, has_peer, peer, text); }
+  // gossmap_manage.c:576-579
+  void bad_gossip(bool has_peer, const nodeid *peer, const std::string &text) { ev_text(LAMD_GEV_TRACE, has_peer, peer, "Bad gossip order: " + text); }
+  // :582-597
+  void peer_warning(bool has_peer, const nodeid *peer, const std::string &text) {
+    bad_gossip(has_peer, peer, text);
+    if (has_peer) warning(true, peer, text);
+  }
+  void good_gossip(bool has_peer, const nodeid *peer) {
+    if (!has_peer) return;  // gossipd.c:70-71
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_GOOD_GOSSIP;
+    ev.has_peer = 1;
+    memcpy(ev.peer, peer->k, 33);
+    emit(ev);
+  }
+  u64 store_add(u32 type, u32 timestamp, const u8 *data, size_t len) {
+    store.push_back(record{type, timestamp, false});
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_STORE_ADD;
+    ev.index = store.size() - 1;
+    ev.type = type;
+    ev.timestamp = timestamp;
+    ev.data = data;
+    ev.len = len;
+    emit(ev);
+    return store.size() - 1;
+  }
+  void store_del(u64 idx) {
+    store[idx].deleted = true;
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_STORE_DEL;
+    ev.index = idx;
+    ev.type = store[idx].type;
+    emit(ev);
+  }
+  void store_set_ts(u64 idx, u32 ts) {
+    store[idx].timestamp = ts;
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_STORE_SET_TS;
+    ev.index = idx;
+    ev.timestamp = ts;
+    emit(ev);
+  }
+  void peer_update(bool has_peer, const nodeid *peer, u64 scid, u32 fee_base, u32 fee_ppm, u32 cltv, u64 hmin, u64 hmax) {
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_PEER_UPDATE;
+    ev.has_peer = has_peer;
+    if (has_peer) memcpy(ev.peer, peer->k, 33);
+    ev.scid = scid;
+    ev.values[0] = fee_base; ev.values[1] = fee_ppm; ev.values[2] = cltv; ev.values[3] = hmin; ev.values[4] = hmax;
+    emit(ev);
+  }
+
+  // ---- verification back end
+  int backend_sigcheck(size_t n, const u8 *msgs, const uint64_t *off, const u8 *ids, int8_t *verdict) {
+    if (be_sig) return be_sig(be_user, n, msgs, off, ids, verdict);
+    if (!ctx) return LAMD_ERR_ARG;
+    return lamd_sigcheck_gossip_batch(ctx, n, msgs, off, ids, verdict);
+  }
+  int backend_keyparse(size_t n, const u8 *pub33, u8 *ok) {
+    if (be_key) return be_key(be_user, n, pub33, ok);
+    if (!ctx) return LAMD_ERR_ARG;
+    return lamd_pubkey_parse_batch(ctx, n, pub33, 33, 33, nullptr, ok);
+  }
+  static std::string vkey(const bytes &m, const nodeid *signer) {
+    std::string k((const char *)m.data(), m.size());
+    if (signer) k.append((const char *)signer->k, 33);
+    return k;
+  }
+  // verdict of (message, signer); verifies on the spot if the plan did not foresee the pair
+  int verdict_of(const bytes &m, const nodeid *signer) {
+    const std::string k = vkey(m, signer);
+    auto it = verdicts.find(k);
+    if (it != verdicts.end()) return it->second;
+    st.late_verifies++;
+    const uint64_t off[2] = {0, m.size()};
+    int8_t v = -2;
+    const int rc = backend_sigcheck(1, m.data(), off, signer ? signer->k : nullptr, &v);
+    const int out = rc == LAMD_OK ? v : -2;
+    verdicts[k] = out;
+    return out;
+  }
+
+  struct slotlist {
+    std::vector<const bytes *> msg;
+    std::vector<const nodeid *> signer;
+    std::unordered_map<std::string, int> index;
+    int add(lamd_gossipd *g, const bytes &m, const nodeid *signer_) {
+      const std::string k = vkey(m, signer_);
+      auto it = index.find(k);
+      if (it != index.end()) { g->st.duplicates++; return it->second; }
+      const int s = (int)msg.size();
+      index.emplace(k, s);
+      msg.push_back(&m);
+      signer.push_back(signer_);
+      return s;
+    }
+  };
+  // one device call for the signatures of `sl`; verdicts land in this->verdicts
+  int verify(const slotlist &sl) {
+    const size_t n = sl.msg.size();
+    if (!n) return LAMD_OK;
+    bytes blob, ids(33 * n, 0);
+    std::vector<uint64_t> off(n + 1, 0);
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) total += sl.msg[i]->size();
+    blob.reserve(total);
+    for (size_t i = 0; i < n; i++) {
+      blob.insert(blob.end(), sl.msg[i]->begin(), sl.msg[i]->end());
+      off[i + 1] = blob.size();
+      if (sl.signer[i]) memcpy(&ids[33 * i], sl.signer[i]->k, 33);
+      st.verified_sigs += ((*sl.msg[i])[0] == 1 && (*sl.msg[i])[1] == 0) ? 4 : 1;
+    }
+    std::vector<int8_t> v(n, -2);
+    const int rc = backend_sigcheck(n, blob.data(), off.data(), ids.data(), v.data());
+    if (rc != LAMD_OK) return rc;
+    for (auto &kv : sl.index) verdicts[kv.first] = v[kv.second];
+    st.batches++;
+    st.verified_messages += n;
+    return LAMD_OK;
+  }
+
+  bool known_scid(u64 scid) const { return chans.count(scid) || pending_ann.count(scid) || early_ann.count(scid); }
+  bool timestamp_reasonable(u32 ts) const {  // gossmap_manage.c:1001-1012
+    const int64_t n = (int64_t)now();
+    if ((int64_t)ts > n + 24 * 60 * 60) return false;
+    if ((int64_t)ts < n - (int64_t)(cfg.prune_interval ? cfg.prune_interval : 1209600u)) return false;
+    return true;
+  }
+
+  // ---- gossmap_manage_channel_announcement (:620-753) with the sigcheck verdict `v` (or the key-only verdict) known
+  void apply_cann(const queued &q, const planned &p, int key_ok) {
+    const bytes &m = q.msg;
+    std::string err;
+    do {
+      if (p.malformed || (p.keyslot >= 0 && !key_ok)) { err = "Malformed channel_announcement " + hexs(m); break; }  // :648
+      int v = 0;
+      if (p.keyslot < 0) {
+        v = verdict_of(m, nullptr);
+        if (v == -1) { err = "Malformed channel_announcement " + hexs(m); break; }  // an invalid bitcoin key: fromwire_pubkey
+        if (v == -2) { err = "engine error"; break; }
+      }
+      const gossip_frame f = gossip_parse_frame(m.data(), m.size());
+      const size_t flen = be16(&m[258]);
+      nodeid id1, id2;
+      memcpy(id1.k, &m[f.keyoff], 33);
+      memcpy(id2.k, &m[f.keyoff + 33], 33);
+      if (!(id1 < id2)) {  // :661-665
+        err = "node_id_1 must be the lesser node id! 1=" + hexs(id1.k, 33) + ", 2=" + hexs(id2.k, 33);
+        break;
+      }
+      if (memcmp(&m[260 + flen], cfg.chain_hash, 32) != 0) return;  // :671-672
+      const u64 scid = p.scid;
+      if (txout_failures.count(scid)) return;                         // :679-681
+      if (known_scid(scid)) return;                                   // :684-687
+      if (p.keyslot >= 0) {  // the plan expected one of the drops above: verify now (never seen in practice)
+        v = verdict_of(m, nullptr);
+        if (v == -2) { err = "engine error"; break; }
+      }
+      if (v > 0) { err = sigcheck_text(GOSSIP_CANN, v, m); break; }   // :689-696
+      pending_cannounce pca;
+      pca.msg = m;
+      pca.has_src = q.has_src;
+      pca.src = q.src;
+      pca.node[0] = id1;
+      pca.node[1] = id2;
+      {  // scriptpubkey_p2wsh(bitcoin_redeem_2of2(key1, key2)) (:699-702; bitcoin/script.c:149-165): keys in DER order
+        const u8 *k1 = &m[f.keyoff + 66], *k2 = &m[f.keyoff + 99];
+        if (memcmp(k1, k2, 33) >= 0) std::swap(k1, k2);
+        u8 script[71];
+        script[0] = 0x52; script[1] = 33; memcpy(script + 2, k1, 33);
+        script[35] = 33; memcpy(script + 36, k2, 33);
+        script[69] = 0x52; script[70] = 0xae;
+        u8 h[32];
+        sha256_single(script, sizeof script, h);
+        pca.spk.resize(34);
+        pca.spk[0] = 0x00; pca.spk[1] = 0x20;
+        memcpy(&pca.spk[2], h, 32);
+      }
+      const u32 height = cfg.blockheight;
+      if (!scid_depth_announceable(scid, height)) {  // :724-741
+        if (height != 0 && scid_blocknum(scid) > height + 12) {
+          char b[32];
+          snprintf(b, sizeof b, "%u", height);
+          err = "Bad gossip order: ignoring channel_announcement " + fmt_scid(scid) + " at blockheight " + b;
+          break;
+        }
+        early_ann.emplace(scid, std::move(pca));
+        return;
+      }
+      pending_ann.emplace(scid, std::move(pca));  // :744-750
+      ev_scid(LAMD_GEV_GET_TXOUT, false, nullptr, scid);
+      return;
+    } while (0);
+    warning(q.has_src, &q.src, err);  // gossipd.c:277-283
+  }
+
+  // ---- process_channel_update (:878-998); returns the error text ("" = none)
+  std::string process_channel_update(const pending_cupdate &u) {
+    const int dir = u.cflags & 1;
+    auto it = chans.find(u.scid);
+    if (it == chans.end()) {
+      if (txout_failures.count(u.scid)) return "";  // :901-905
+      ev_scid(LAMD_GEV_QUERY_CHANNEL, u.has_src, &u.src, u.scid);
+      bad_gossip(u.has_src, &u.src, "Unknown channel " + fmt_scid(u.scid));
+      return "";
+    }
+    chan &c = it->second;
+    const int v = verdict_of(u.update, &c.node[dir]);  // :920-926
+    if (v == -2) return "engine error";
+    if (v != 0) return sigcheck_text(GOSSIP_CUPD, 1, u.update);
+    if (u.mflags & 2) return "Do not set DONT_FORWARD on public channel_updates (" + fmt_scid(u.scid) + ")";  // :929-932
+    if (c.set[dir]) {  // :935-946
+      if (store[c.cupd_rec[dir]].timestamp >= u.timestamp) return "";
+    } else if (!c.set[!dir]) {
+      store_set_ts(c.cann_rec, u.timestamp);  // :950-951
+    }
+    const u64 rec = store_add(GOSSIP_CUPD, u.timestamp, u.update.data(), u.update.size());  // :955
+    if (c.set[dir]) store_del(c.cupd_rec[dir]);                                             // :966-967
+    c.set[dir] = true;
+    c.cupd_rec[dir] = rec;
+    nodeid ours;
+    memcpy(ours.k, cfg.our_id, 33);
+    if (c.node[!dir] == ours) peer_update(u.has_src, &u.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);  // :970-980
+    good_gossip(u.has_src, &u.src);
+    char b[16];
+    snprintf(b, sizeof b, "/%d now ", dir);
+    ev_text(LAMD_GEV_TRACE, u.has_src, &u.src, "Received channel_update for channel " + fmt_scid(u.scid) + b + ((u.cflags & 2) ? "DISABLED" : "ACTIVE"));
+    return "";
+  }
+
+  static pending_cupdate parse_cupdate(const queued &q) {
+    const bytes &m = q.msg;
+    pending_cupdate u;
+    u.scid = be64(&m[98]);
+    u.timestamp = be32(&m[106]);
+    u.mflags = m[110];
+    u.cflags = m[111];
+    u.cltv = be16(&m[112]);
+    u.hmin = be64(&m[114]);
+    u.fee_base = be32(&m[122]);
+    u.fee_ppm = be32(&m[126]);
+    u.hmax = be64(&m[130]);
+    u.update = m;
+    u.has_src = q.has_src;
+    u.src = q.src;
+    return u;
+  }
+  // ---- gossmap_manage_channel_update (:1014-1120)
+  void apply_cupd(const queued &q, const planned &p) {
+    const bytes &m = q.msg;
+    std::string err;
+    do {
+      if (p.malformed) { err = "channel_update: malformed " + hexs(m); break; }  // :1044-1046
+      if (memcmp(&m[66], cfg.chain_hash, 32) != 0) return;                       // :1054-1057
+      pending_cupdate u = parse_cupdate(q);
+      if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
+      if (pending_ann.count(u.scid)) { pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
+      if (early_ann.count(u.scid)) { early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
+      if (!chans.count(u.scid) && q.has_src && verdict_of(m, &q.src) == 0) {                // :1107-1116
+        peer_update(true, &q.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);
+        return;
+      }
+      err = process_channel_update(u);
+    } while (0);
+    if (!err.empty()) warning(q.has_src, &q.src, err);
+  }
+
+  // ---- process_node_announcement (:1122-1160)
+  void process_node_announcement(node &n, u32 timestamp, const nodeid &id, const bytes &m, bool has_src, const nodeid *src) {
+    if (n.announced && store[n.nann_rec].timestamp >= timestamp) return;
+    const u64 rec = store_add(GOSSIP_NANN, timestamp, m.data(), m.size());
+    if (n.announced) store_del(n.nann_rec);
+    n.announced = true;
+    n.nann_rec = rec;
+    good_gossip(has_src, src);
+    ev_text(LAMD_GEV_TRACE, has_src, src, "Received node_announcement for node " + hexs(id.k, 33));
+  }
+  void unknown_node(bool has_src, const nodeid *src, const nodeid &id) {  // :1231-1238
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_QUERY_NODE;
+    ev.has_peer = has_src;
+    if (has_src) memcpy(ev.peer, src->k, 33);
+    ev.data = id.k;
+    ev.len = 33;
+    emit(ev);
+    bad_gossip(has_src, src, "node_announcement: unknown node " + hexs(id.k, 33));
+  }
+  // ---- gossmap_manage_node_announcement (:1162-1243)
+  void apply_nann(const queued &q, const planned &p) {
+    const bytes &m = q.msg;
+    std::string err;
+    do {
+      if (p.malformed) { err = "node_announcement: malformed " + hexs(m); break; }  // :1197-1198
+      if (p.addrs_bad) { err = "node_announcement: malformed wireaddrs  in " + hexs(m); break; }  // :1210-1213 (tal_hex(NULL) is "")
+      const int v = verdict_of(m, nullptr);
+      if (v == -2) { err = "engine error"; break; }
+      if (v == -1) { err = "node_announcement: malformed " + hexs(m); break; }
+      if (v != 0) { err = sigcheck_text(GOSSIP_NANN, 1, m); break; }  // :1216-1219
+      const gossip_frame f = gossip_parse_frame(m.data(), m.size());
+      nodeid id;
+      memcpy(id.k, &m[f.keyoff], 33);
+      const u32 timestamp = be32(&m[f.keyoff - 4]);
+      auto it = nodes.find(id);
+      if (it == nodes.end()) {
+        if (!pending_ann.empty() || !early_ann.empty()) {  // :1224-1230
+          pending_nannounce pn;
+          pn.id = id; pn.timestamp = timestamp; pn.msg = m; pn.has_src = q.has_src; pn.src = q.src;
+          pending_nannounces.push_back(std::move(pn));
+          return;
+        }
+        unknown_node(q.has_src, &q.src, id);
+        return;
+      }
+      process_node_announcement(it->second, timestamp, id, m, q.has_src, &q.src);
+      return;
+    } while (0);
+    warning(q.has_src, &q.src, err);
+  }
+
+  // ---- reprocess_queued_msgs (:1284-1342): the signatures of every waiting channel_update whose channel now exists go to
+  // the device as one batch first
+  int reprocess_queued_msgs() {
+    const bool pending_empty = pending_ann.empty(), early_empty = early_ann.empty();
+    if (!pending_empty && !early_empty) return LAMD_OK;
+    slotlist sl;
+    auto plan_list = [&](const std::vector<pending_cupdate> &l) {
+      for (const pending_cupdate &u : l) {
+        auto it = chans.find(u.scid);
+        if (it != chans.end()) sl.add(this, u.update, &it->second.node[u.cflags & 1]);
+      }
+    };
+    verdicts.clear();
+    if (pending_empty) plan_list(pending_cupdates);
+    if (early_empty) plan_list(early_cupdates);
+    const int rc = verify(sl);
+    if (rc != LAMD_OK) return rc;
+    auto process_pending = [&](const pending_cupdate &u) {  // :1245-1268
+      const std::string err = process_channel_update(u);
+      if (!err.empty()) peer_warning(u.has_src, &u.src, "channel_update: " + err);
+    };
+    if (pending_empty) {
+      std::vector<pending_cupdate> l;
+      l.swap(pending_cupdates);
+      for (const pending_cupdate &u : l) process_pending(u);
+    }
+    if (early_empty) {
+      std::vector<pending_cupdate> l;
+      l.swap(early_cupdates);
+      for (pending_cupdate &u : l) {
+        if (pending_ann.count(u.scid)) { pending_cupdates.push_back(std::move(u)); continue; }
+        process_pending(u);
+      }
+    }
+    if (early_empty && pending_empty) {
+      std::vector<pending_nannounce> l;
+      l.swap(pending_nannounces);
+      for (const pending_nannounce &pn : l) {
+        auto it = nodes.find(pn.id);
+        if (it == nodes.end()) { unknown_node(pn.has_src, &pn.src, pn.id); continue; }
+        process_node_announcement(it->second, pn.timestamp, pn.id, pn.msg, pn.has_src, &pn.src);
+      }
+    }
+    verdicts.clear();
+    return LAMD_OK;
+  }
+
+  static void sha256_single(const u8 *p, size_t len, u8 out[32]);
+};
+
+// single SHA-256 through the device header's host build (sha256.h): only P2WSH scripts use it
+void lamd_gossipd::sha256_single(const u8 *p, size_t len, u8 out[32]) {
+  lamd::sha_stream s;
+  lamd::shs_init(&s);
+  lamd::shs_update(&s, p, len);
+  // finish a single hash: pad, length, output the state
+  const u64 bits = s.total * 8;
+  const u8 pad = 0x80, zero = 0;
+  lamd::shs_update(&s, &pad, 1);
+  while (s.fill != 56) lamd::shs_update(&s, &zero, 1);
+  s.w[14] = (u32)(bits >> 32);
+  s.w[15] = (u32)bits;
+  lamd::sha256_compress(s.st, s.w);
+  for (int i = 0; i < 8; i++) { out[4 * i] = (u8)(s.st[i] >> 24); out[4 * i + 1] = (u8)(s.st[i] >> 16); out[4 * i + 2] = (u8)(s.st[i] >> 8); out[4 * i + 3] = (u8)s.st[i]; }
+}
+
+extern "C" lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_config *cfg, lamd_gossipd_event_fn on_event, void *user) {
+  if (!cfg) return nullptr;
+  lamd_gossipd *g = new (std::nothrow) lamd_gossipd;
+  if (!g) return nullptr;
+  g->ctx = ctx;
+  g->cfg = *cfg;
+  g->on_event = on_event;
+  g->user = user;
+  memset(&g->st, 0, sizeof g->st);
+  return g;
+}
+extern "C" void lamd_gossipd_free(lamd_gossipd *g) { delete g; }
+extern "C" void lamd_gossipd_set_backend(lamd_gossipd *g, lamd_gossipd_sigcheck_fn sigcheck, lamd_gossipd_keyparse_fn keyparse, void *user) {
+  if (!g) return;
+  g->be_sig = sigcheck;
+  g->be_key = keyparse;
+  g->be_user = user;
+}
+extern "C" void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now) { if (g) g->cfg.now = now; }
+
+extern "C" int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, const uint8_t *msg, size_t len) {
+  if (!g || (!msg && len)) return LAMD_ERR_ARG;
+  if (g->queue.size() > 500000) return LAMD_ERR_STATE;  // connectd/multiplex.c:832-833
+  queued q;
+  q.msg.assign(msg, msg + len);
+  q.has_src = source_peer33 != nullptr;
+  memset(q.src.k, 0, 33);
+  if (source_peer33) memcpy(q.src.k, source_peer33, 33);
+  g->queue.push_back(std::move(q));
+  return LAMD_OK;
+}
+
+extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
+  if (!g) return LAMD_ERR_ARG;
+  std::vector<queued> batch;
+  batch.swap(g->queue);
+  const size_t n = batch.size();
+  if (!n) return 0;
+  // ---- plan: which (message, signer) pairs can reach a sigcheck_*() call, judged from the state before the batch
+  std::vector<planned> plan(n);
+  lamd_gossipd::slotlist sl;
+  bytes keyblob;
+  for (size_t i = 0; i < n; i++) {
+    const queued &q = batch[i];
+    const bytes &m = q.msg;
+    planned &p = plan[i];
+    const gossip_frame f = gossip_parse_frame(m.data(), m.size());
+    p.type = f.type;
+    p.malformed = f.bad;
+    p.addrs_bad = false;
+    p.slot = p.keyslot = -1;
+    p.scid = 0;
+    if (f.type == GOSSIP_CANN) {
+      if (!p.malformed)
+        for (int s = 0; s < 4; s++) p.malformed |= !sig_in_range(&m[2 + 64 * s]);
+      if (p.malformed) continue;
+      const size_t flen = be16(&m[258]);
+      p.scid = be64(&m[260 + flen + 32]);
+      const bool order_bad = memcmp(&m[f.keyoff], &m[f.keyoff + 33], 33) >= 0;
+      const bool drop = order_bad || memcmp(&m[260 + flen], g->cfg.chain_hash, 32) != 0 || g->txout_failures.count(p.scid) || g->known_scid(p.scid);
+      if (drop) {  // fromwire_pubkey still decides between "Malformed" and the silent drop / the node-order warning
+        p.keyslot = (int)(keyblob.size() / 66);
+        keyblob.insert(keyblob.end(), &m[f.keyoff + 66], &m[f.keyoff + 132]);
+        g->st.keyparse_messages++;
+      } else {
+        p.slot = sl.add(g, m, nullptr);
+      }
+    } else if (f.type == GOSSIP_CUPD) {
+      if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
+      if (p.malformed) continue;
+      p.scid = be64(&m[98]);
+      if (memcmp(&m[66], g->cfg.chain_hash, 32) != 0 || !g->timestamp_reasonable(be32(&m[106]))) continue;
+      auto it = g->chans.find(p.scid);
+      if (it != g->chans.end()) p.slot = sl.add(g, m, &it->second.node[m[111] & 1]);
+      else if (q.has_src) p.slot = sl.add(g, m, &q.src);  // the private-update probe of :1107-1109 (unused if the channel turns out to be pending)
+    } else if (f.type == GOSSIP_NANN) {
+      if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
+      if (p.malformed) continue;
+      const size_t alen = be16(&m[f.keyoff + 68]);
+      p.addrs_bad = !wireaddrs_ok(&m[f.keyoff + 70], alen);
+      if (!p.addrs_bad) p.slot = sl.add(g, m, nullptr);
+    }
+  }
+  // ---- verify: one call for the signatures, one for the keys of announcements that are dropped anyway
+  g->verdicts.clear();
+  int rc = g->verify(sl);
+  if (rc != LAMD_OK) { g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
+  std::vector<u8> keyok(keyblob.size() / 33, 0);
+  if (!keyok.empty()) {
+    rc = g->backend_keyparse(keyok.size(), keyblob.data(), keyok.data());
+    if (rc != LAMD_OK) { g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
+  }
+  // ---- apply in arrival order
+  for (size_t i = 0; i < n; i++) {
+    const queued &q = batch[i];
+    const planned &p = plan[i];
+    if (p.type == GOSSIP_CANN) g->apply_cann(q, p, p.keyslot >= 0 ? (keyok[2 * p.keyslot] && keyok[2 * p.keyslot + 1]) : 1);
+    else if (p.type == GOSSIP_CUPD) g->apply_cupd(q, p);
+    else if (p.type == GOSSIP_NANN) g->apply_nann(q, p);
+    // other types never reach gossipd's three handlers (gossipd.c:206-264)
+    g->st.messages++;
+  }
+  g->verdicts.clear();
+  return (long)n;
+}
+
+extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const uint8_t *script, size_t script_len) {
+  if (!g) return LAMD_ERR_ARG;
+  auto it = g->pending_ann.find(scid);
+  if (it == g->pending_ann.end()) return LAMD_OK;  // :770-780
+  pending_cannounce pca = std::move(it->second);
+  g->pending_ann.erase(it);
+  bool bad = false;
+  if (script_len == 0) {
+    bad = true;  // :789-809 (the rate-limited trace is not reproduced)
+  } else if (script_len != pca.spk.size() || memcmp(script, pca.spk.data(), script_len) != 0) {
+    g->peer_warning(pca.has_src, &pca.src, "channel_announcement: txout " + fmt_scid(scid) + " expected " + hexs(pca.spk) + ", got " + hexs(script, script_len));  // :811-817
+    bad = true;
+  }
+  if (bad) {
+    g->txout_failures[scid] = true;  // :868-869
+    g->ev_scid(LAMD_GEV_TXOUT_FAILED, false, nullptr, scid);
+    return LAMD_OK;  // (the reference does not reprocess the queues on this path either)
+  }
+  if (g->chans.count(scid)) return LAMD_OK;  // :825-846 "Redundant channel_announce"
+  // :849-852
+  chan c;
+  c.node[0] = pca.node[0];
+  c.node[1] = pca.node[1];
+  c.set[0] = c.set[1] = false;
+  c.cupd_rec[0] = c.cupd_rec[1] = 0;
+  c.cann_rec = g->store_add(GOSSIP_CANN, 0, pca.msg.data(), pca.msg.size());
+  u8 amt[10] = {0x10, 0x05};  // WIRE_GOSSIP_STORE_CHANNEL_AMOUNT = 4101
+  for (int i = 0; i < 8; i++) amt[2 + i] = (u8)(sat >> (56 - 8 * i));
+  g->store_add(4101, 0, amt, sizeof amt);
+  g->chans.emplace(scid, c);
+  for (int i = 0; i < 2; i++) {
+    node &nd = g->nodes[pca.node[i]];  // value-initialised on first sight
+    nd.nchans++;
+  }
+  return g->reprocess_queued_msgs();  // :864
+}
+
+extern "C" int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight) {
+  if (!g) return LAMD_ERR_ARG;
+  g->cfg.blockheight = blockheight;
+  for (auto it = g->early_ann.begin(); it != g->early_ann.end();) {  // :1362-1387, ascending scid
+    const u64 scid = it->first;
+    if (!scid_depth_announceable(scid, blockheight)) break;
+    pending_cannounce pca = std::move(it->second);
+    it = g->early_ann.erase(it);
+    if (!g->pending_ann.emplace(scid, std::move(pca)).second) continue;
+    g->ev_scid(LAMD_GEV_GET_TXOUT, false, nullptr, scid);
+  }
+  return LAMD_OK;
+}
+
+extern "C" void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats *out) {
+  if (!g || !out) return;
+  *out = g->st;
+  out->channels = g->chans.size();
+  out->nodes = g->nodes.size();
+  out->pending = g->pending_ann.size();
+  out->early = g->early_ann.size();
+  out->queued_updates = g->pending_cupdates.size() + g->early_cupdates.size();
+  out->queued_nodes = g->pending_nannounces.size();
+  out->store_records = g->store.size();
+}

@@ -30,6 +30,17 @@ def test_header_symbols_exported_and_bound():
     assert b"gfx950" in lib.lamd_version()
 
 
+def test_gossipd_header_symbols_exported():
+    """include/lightning_amd_gossipd.h (the batched gossip ingest) lives in the host-side library next to the reference-named mirror"""
+    from lightning_amd import _build, gossipd
+    names = _declared("lightning_amd_gossipd.h")
+    assert len(names) >= 9
+    lib = ctypes.CDLL(_build.build_shim())
+    for n in names:
+        assert hasattr(lib, n), "liblightning_amd_cln.so does not export %s" % n
+    assert gossipd._load() is not None
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
