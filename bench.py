@@ -45,6 +45,98 @@ BYTES_ECDSA65 = 32 + 64 + 65 + 1
 BYTES_SCHNORR = 32 + 32 + 64 + 1
 
 
+def sharded_configs(eng, rank, world, device, tstream):
+    """BASELINE configs[3] and [4] the way the north star words them: ONE global job split over the ranks on message /
+    commitment boundaries (lightning_amd.sharding.run_sharded: shard -> verify locally -> ragged RCCL all-gather of the verdict
+    bytes), every rank ending with the whole verdict vector.  Strong scaling: the job is fixed, the time is max over ranks.
+    Every rank generates the same synthetic job (same seed) and touches only its shard."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from lightning_amd import sharding, workload
+    out = {}
+
+    def timed(fn, reps):
+        ts, res = [], None
+        for _ in range(reps):
+            dist.barrier()
+            torch.cuda.synchronize(); eng.synchronize()
+            t1 = time.perf_counter()
+            res = fn()
+            torch.cuda.synchronize(); eng.synchronize()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts.append(float(t.item()))
+        return ts, res
+
+    # ---- configs[3]: gossip replay, 500 k channel_announcement + 2 M channel_update, sharded by message
+    g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
+    b = sharding.shard_bounds(g.n, world)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    rb = (g.d_rowbase[lo:hi + 1] - g.d_rowbase[lo]).contiguous()
+    rows = int(g.rowbase[hi] - g.rowbase[lo])
+    d_v = torch.zeros(hi - lo, dtype=torch.int8, device=device)
+    torch.cuda.synchronize()
+
+    def gossip_range(a, z):
+        assert (a, z) == (lo, hi)
+        eng.sigcheck_gossip_device(z - a, g.d_msgs, g.d_off[a:z + 1], g.d_ids[a:z], rb, rows, d_v)
+        eng.stream_wait_results(tstream)     # the collective (torch's stream) starts when the verdicts exist: device-side edge
+        return d_v
+    ts, (full, _) = timed(lambda: sharding.run_sharded(g.n, rank, world, gossip_range), 2 + eng.info()["lanes"])
+    bad = int((full.cpu().numpy() != g.expect).sum())
+    out["cfg4_gossip_replay_sharded"] = {"messages": g.n, "verifies": g.rows, "ranks": world, "shard_messages": [int(b[k + 1] - b[k]) for k in range(world)],
+                                         "verifies_per_s": g.rows / min(ts[-2:]), "messages_per_s": g.n / min(ts[-2:]), "ms": min(ts[-2:]) * 1e3,
+                                         "mismatches": bad, "scaling": "strong",
+                                         "note": "raw wire messages resident in HBM; per rank: framing + SHA256d + verification of its shard, then the "
+                                                 "ragged all-gather of int8 verdicts; every rank checks the WHOLE gathered vector against construction"}
+    del g, d_v, rb
+    # ---- configs[4]: commit_tx storm, 10 k channels x 484, streaming batches from host memory, 484-row groups kept whole
+    st = workload.make_commit_storm(eng, 10_000, device=device)
+    per, grp = st["per"], 256 * st["per"]
+
+    def storm():
+        res = {}
+        for kind in ("ecdsa", "schnorr"):
+            wl = st[kind]
+
+            def stream_range(a, z, wl=wl, kind=kind):
+                got = np.zeros(z - a, dtype=np.uint8)
+                pend = []
+
+                def collect():
+                    o, e = pend.pop(0)
+                    got[o - a:e - a] = eng.wait()
+                for o in range(a, z, grp):
+                    e = min(z, o + grp)
+                    if kind == "ecdsa":
+                        eng.queue_ecdsa_batch(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
+                    else:
+                        eng.queue_schnorr_batch(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
+                    eng.flush()
+                    pend.append((o, e))
+                    if len(pend) == 3:
+                        collect()
+                while pend:
+                    collect()
+                return torch.from_numpy(got).to(device)
+            res[kind] = sharding.run_sharded(wl.n, rank, world, stream_range, [per] * (wl.n // per))
+        return res
+    ts, res = timed(storm, 3)
+    bad, shard_rows = 0, {}
+    for kind in ("ecdsa", "schnorr"):
+        full, bb = res[kind]
+        bad += int((full.cpu().numpy().astype(bool) != st[kind].expect).sum())
+        shard_rows[kind] = [int(bb[k + 1] - bb[k]) for k in range(world)]
+        assert all(int(x) % per == 0 for x in bb)
+    nv = st["ecdsa"].n + st["schnorr"].n
+    out["cfg5_commit_storm_streaming_sharded"] = {"channels": 10_000, "verifies": nv, "ranks": world, "shard_rows": shard_rows,
+                                                  "verifies_per_s": nv / min(ts[1:]), "ms": min(ts[1:]) * 1e3, "mismatches": bad, "scaling": "strong",
+                                                  "note": "inputs in host memory: per rank its commitments stream through the pinned staging queue "
+                                                          "(256 commitments per flush, 3 flushes in flight), then the ragged all-gather of the verdict bytes"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +289,13 @@ def main():
         dist.all_reduce(m)
         mism = int(m.item())
 
+    # ---- the two "8 GPUs" configs of BASELINE.json as ONE job split over the ranks (all ranks take part in the collectives)
+    sharded = None
+    if multi and not args.skip_extra:
+        sharded = sharded_configs(eng, rank, world, device, tstream)
+        for v in sharded.values():
+            mism += v["mismatches"] if rank == 0 else 0
+
     out = None
     if rank == 0:
         total = world * 2 * n * args.steps
@@ -272,10 +371,12 @@ def main():
                            "cache_hits_last_call": [int(i["last_cache_hits"]) for i in warm_info], "new_tables_last_call": [int(i["last_new_tables"]) for i in warm_info],
                            "comb_teeth_last_call": [int(i["last_keyed"]) for i in warm_info]},
         }
+        if sharded is not None:
+            out["sharded_configs"] = sharded
         # ---- batch latency (the metric's second half) and the PCIe-inclusive rate: host buffers in -> verdicts in
         # host memory out, through lamd_verify_ecdsa_batch (pageable numpy memory; never `value`)
         lat = {}
-        for bs in (1, 484, 4096):
+        for bs in ((1, 484, 4096) if world == 1 else ()):
             hh, ss, pp = [np.ascontiguousarray(x[:bs]) for x in we.cols]
             ts = []
             for it in range(60 if bs > 1 else 120):
@@ -284,7 +385,8 @@ def main():
                 ts.append(time.perf_counter() - t1)
             ts = np.sort(np.array(ts[5:])) * 1e3
             lat["ecdsa65_batch_%d" % bs] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)])}
-        out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
+        if lat:
+            out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
         tp = []
         for _ in range(3):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
             t1 = time.perf_counter()
@@ -296,7 +398,7 @@ def main():
         # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
         # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
         # configs[4] commit_tx storm (484-signature groups sharing a key) as one super-batch
-        if not args.skip_extra:
+        if not args.skip_extra and world == 1:
             extra = {}
             g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
             ts = []
@@ -401,7 +503,7 @@ def main():
             mism += rbad
             out["other_configs_1gpu"] = extra
             mism += gm + sm
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # the CPU baseline is a rank-0, N=1 leg
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # test infrastructure: the checker / CPU baseline only
             m = min(args.cpu_sample, n)

@@ -46,7 +46,13 @@ enum {
  * LAMD_ERR_* code (< 0) or a documented non-negative value; lamd_last_error() describes the last failure. */
 /* ---- lifecycle.  Replaces the process-global secp256k1_ctx set up in common/setup.c:58
  * (secp256k1_ctx = wally_get_secp_context(), common/utils.c:16): the one-time work here is the
- * upload/build of the static table of G multiples in HBM. */
+ * upload/build of the static table of G multiples in HBM.
+ * Hardware queues: the context runs its calls on several HIP streams ("lanes", LAMD_LANES) that only overlap when each has a
+ * hardware queue of its own.  ROCm reads GPU_MAX_HW_QUEUES (default 4) at the runtime's FIRST call: this library sets it to 16
+ * from a load-time constructor unless the host already set it -- a host that initialises HIP before loading the library should
+ * export GPU_MAX_HW_QUEUES=16 itself.  Create the context BEFORE an RCCL communicator (ncclCommInitRank / torch.distributed
+ * init_process_group): RCCL's own streams otherwise take hardware queues first and the lanes end up sharing one (measured:
+ * -8 % on the 2 M-row step).  Correctness does not depend on either (tests run at 4, 16 and 32 queues). */
 int lamd_init(lamd_ctx **ctx, int device);
 void lamd_shutdown(lamd_ctx *ctx);
 const char *lamd_last_error(const lamd_ctx *ctx);

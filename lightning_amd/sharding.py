@@ -37,10 +37,27 @@ def all_gather_verdicts(ok_local, bounds, rank, world):
     payload is padded to the longest shard (a <= 1 MB, latency-bound collective either way)."""
     if world == 1:
         return ok_local
+    dt = ok_local.dtype
+    if dt != torch.uint8:            # int8 gossip verdicts travel as bytes
+        ok_local = ok_local.view(torch.uint8)
     sizes = [int(bounds[g + 1] - bounds[g]) for g in range(world)]
     m = max(sizes)
     pad = torch.zeros(m, dtype=torch.uint8, device=ok_local.device)
     pad[:sizes[rank]] = ok_local
     out = torch.empty(world * m, dtype=torch.uint8, device=ok_local.device)
     dist.all_gather_into_tensor(out, pad)
-    return torch.cat([out[g * m:g * m + sizes[g]] for g in range(world)])
+    return torch.cat([out[g * m:g * m + sizes[g]] for g in range(world)]).view(dt)
+
+
+def run_sharded(n_verdicts, rank, world, verify_range, group_sizes=None):
+    """The north-star split of ONE global job over `world` ranks: rank g verifies verdict positions [b[g], b[g+1]) -- cut on group
+    boundaries (a channel_announcement's four signatures, a commitment's 484) -- through `verify_range(lo, hi)` (-> 1-D uint8 / int8
+    tensor of hi-lo verdicts on the rank's device: the engine on GPUs, a CPU checker in the gloo test), then every rank receives the
+    whole verdict vector (ragged all-gather).  Returns (full_verdicts, bounds).  bench.py --gpus N runs BASELINE configs[3] and [4]
+    through this function; tests/test_sharding_gloo.py runs the same function under gloo."""
+    b = shard_bounds(n_verdicts, world, group_sizes)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    local = verify_range(lo, hi)
+    if local.numel() != hi - lo:
+        raise ValueError("verify_range returned %d verdicts for %d positions" % (local.numel(), hi - lo))
+    return all_gather_verdicts(local, b, rank, world), b

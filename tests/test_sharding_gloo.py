@@ -63,12 +63,41 @@ def _worker(rank, world, port, q):
     A = lambda rows, w: np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), w)
     hs, sg, pk = A(hs, 32), A(sg, 64), A(pk, 33)
     groups = [4] * 20 + [1] * 21
-    b = sharding.shard_bounds(n, world, groups)
-    lo, hi = int(b[rank]), int(b[rank + 1])
-    local = orc.ecdsa_verify_batch(np.ascontiguousarray(hs[lo:hi]), np.ascontiguousarray(sg[lo:hi]), np.ascontiguousarray(pk[lo:hi]), 33, 1)
-    full = sharding.all_gather_verdicts(torch.from_numpy(local), b, rank, world).numpy()
+    seen = []
+
+    def verify_range(lo, hi):          # the role Engine.verify_*_device / the streaming queue play in bench.py's sharded_configs()
+        seen.append((lo, hi))
+        return torch.from_numpy(orc.ecdsa_verify_batch(np.ascontiguousarray(hs[lo:hi]), np.ascontiguousarray(sg[lo:hi]),
+                                                       np.ascontiguousarray(pk[lo:hi]), 33, 1))
+    full, b = sharding.run_sharded(n, rank, world, verify_range, groups)    # exactly what bench.py --gpus N calls for configs[4]
+    lo, hi = seen[0]
+    assert (lo, hi) == (int(b[rank]), int(b[rank + 1]))
     ref = orc.ecdsa_verify_batch(hs, sg, pk, 33, 1)
-    q.put((rank, bool(np.array_equal(full, ref)), int(ref.sum()), lo, hi))
+    ok = bool(np.array_equal(full.numpy(), ref))
+    # configs[3] shape: raw gossip messages, int8 verdicts (first bad signature), sharded by message
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gossip_stream as gs
+    net = gs.Net(orc, 777, n_nodes=8, n_chans=9)
+    msgs, ids = [], []
+    for c in range(9):
+        m = net.cann(c)
+        msgs.append(gs.damage(net.rnd, m, "sig") if c % 4 == 1 else m); ids.append(bytes(33))
+    for k in range(23):
+        c, d = k % 9, k & 1
+        m = net.cupd(c, d, gs.NOW - k)
+        msgs.append(gs.damage(net.rnd, m, "tail") if k % 6 == 2 else m); ids.append(net.node_id[net.chans[c]["n"][d]])
+    off = np.concatenate([[0], np.cumsum([len(m) for m in msgs])]).astype(np.uint64)
+    blob = np.frombuffer(b"".join(msgs) + b"\x00", dtype=np.uint8)
+    idarr = np.frombuffer(b"".join(ids), dtype=np.uint8).reshape(len(ids), 33)
+
+    def gossip_range(lo, hi):
+        sub = off[lo:hi + 1] - off[lo]
+        return torch.from_numpy(orc.sigcheck_gossip_batch(np.ascontiguousarray(blob[int(off[lo]):int(off[hi]) + 1]), sub.astype(np.uint64),
+                                                          np.ascontiguousarray(idarr[lo:hi]), 1))
+    gfull, gb = sharding.run_sharded(len(msgs), rank, world, gossip_range)
+    gref = orc.sigcheck_gossip_batch(blob, off, idarr, 1)
+    ok = ok and gfull.dtype == torch.int8 and bool(np.array_equal(gfull.numpy(), gref)) and int((gref > 0).sum()) >= 5 and int((gref == 0).sum()) >= 15
+    q.put((rank, ok, int(ref.sum()), lo, hi))
     dist.destroy_process_group()
 
 
