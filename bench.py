@@ -147,6 +147,10 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--skip-extra", action="store_true", help="skip the cfg4/cfg5 single-GPU data points")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: everything libraries print there (RCCL's version banner on the first
+    # collective) goes to stderr instead
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -280,7 +284,8 @@ def main():
     # the isolated calls just made
     got_e = we.d_ok.cpu().numpy().astype(bool)
     got_s = ws.d_ok.cpu().numpy().astype(bool)
-    mism = int((got_e != we.expect).sum() + (got_s != ws.expect).sum()) + mism_cold + mism_warm
+    mism_iso = int((got_e != we.expect).sum() + (got_s != ws.expect).sum())
+    mism = mism_iso + mism_cold + mism_warm
     if multi:
         # every rank must hold every other rank's verdicts after the all-gather
         sl = slice(rank * n, (rank + 1) * n)
@@ -361,7 +366,8 @@ def main():
                                       "frac": 2 * w_exec * n / (dt / args.steps) / P_MUL32},
                          "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,
                                  "peak_GBs": HBM_PEAK_GBS, "frac": algo_bytes / t_ecmult / 1e9 / HBM_PEAK_GBS}},
-            "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "against": "verdicts known by construction (all rows; the last timed step of "
+            "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "mismatches_by_leg": {"cold_loop": mism_cold, "warm_loop": mism_warm, "isolated_calls": mism_iso},
+                       "against": "verdicts known by construction (all rows; the last timed step of "
                        "both loops writes into poisoned verdict buffers)"},
             # `value` above is COLD: every call builds the comb tables of its keys again (LAMD_CACHE=0), as a stateless library
             # would.  With the key-table cache (the default for serving: gossip node ids and channel keys recur) the same loop is
@@ -531,8 +537,7 @@ def main():
             out["parity"]["oracle_rows_checked"] = 2 * m
             out["parity"]["oracle_mismatches"] = cm
             mism += cm
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     eng_cold.close()
     if multi:

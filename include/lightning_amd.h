@@ -77,7 +77,8 @@ int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, con
  * lamd_synchronize(), or, without blocking the host, for a stream passed to lamd_stream_wait_results().  Successive
  * calls rotate over LAMD_LANES internal lanes (default 4; own streams and workspaces) so that one call's key
  * de-duplication and table building run under the ecmult kernels of the calls before it; LAMD_LANES=1 turns that off
- * (strictly one stream).
+ * (strictly one stream).  d_ok is never read and is written once per call, with final verdicts (one device-to-device copy at the
+ * end of the call): calls in flight at the same time may be handed the same verdict buffer.
  * This is what bench.py times. */
 int lamd_verify_ecdsa_batch_device(lamd_ctx *ctx, size_t n, const void *d_hash32, const void *d_sig64,
 				   const void *d_pub, size_t publen, size_t pubstride, void *d_ok);
@@ -129,6 +130,21 @@ int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version,
 			       const uint8_t *scripts, const uint64_t *script_off,
 			       const uint8_t *sighash_type, const uint8_t *has_witness_script,
 			       const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
+
+/* ---- BOLT #12 signatures: n independent bolt12_check_signature(fields, messagename, fieldname, key, sig) calls
+ * (common/bolt12.c:80-92): merkle_tlv() over the TLV stream minus its signature fields (types 240..1000) and
+ * sighash_from_merkle() (common/bolt12_merkle.c:227-318: H("LnLeaf"), H("LnNonce"|first-tlv), H("LnBranch"), tag
+ * "lightning"|messagename|fieldname, bitcoin/signature.c:389-405) run on the device in front of the BIP-340 verification of
+ * check_schnorr_sig() (:408-430).  Row i: the serialised TLV stream tlvs + off[i] .. off[i+1] (off: n+1 entries) as it came off
+ * the wire -- the reference hashes the re-serialised fields, which for a stream fromwire_tlv() accepts (minimal BigSize, ascending
+ * types) are these bytes; a stream breaking those rules gets verdict 0 -- key33 + keystride*i the signer (33-byte compressed key:
+ * the parity byte is dropped as :417-422 do), sig64 + 64*i the signature. */
+int lamd_bolt12_check_signature_batch(lamd_ctx *ctx, size_t n, const uint8_t *tlvs, const uint64_t *off, const char *messagename,
+				      const char *fieldname, const uint8_t *key33, size_t keystride, const uint8_t *sig64, uint8_t *ok);
+/* the two hashes alone: merkle32 + 32*i = merkle_tlv(), sighash32 + 32*i = sighash_from_merkle() (either may be NULL), ok[i] = the
+ * stream obeys the TLV rules and holds at least one non-signature field */
+int lamd_bolt12_merkle_batch(lamd_ctx *ctx, size_t n, const uint8_t *tlvs, const uint64_t *off, const char *messagename,
+			     const char *fieldname, uint8_t *merkle32, uint8_t *sighash32, uint8_t *ok);
 
 /* n independent secp256k1_ecdsa_recoverable_signature_parse_compact() + secp256k1_ecdsa_recover() calls as made by
  * common/bolt11.c:1021-1046 (invoices without an `n` field) and lightningd/signmessage.c:193: sig64 = r||s, recid 0..3.

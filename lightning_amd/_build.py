@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     # 64-bit column arithmetic of fe.h (a^2*a came out wrong on gfx950; reproduced instruction-for-instruction by
     # an ISA emulator, so it is a code-generation bug, not a hardware hazard -- DESIGN.md "toolchain notes").
     # lamd_selftest() re-checks every primitive on the device against the host evaluation of the same code.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-unknown-pragmas",
            "-mllvm", "-amdgpu-codegenprepare-mul24=false"] + EXTRA + [
            "-o", LIB + ".tmp", os.path.join(CSRC, "lamd_engine.hip")]
     if verbose:

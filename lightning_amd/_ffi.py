@@ -34,6 +34,8 @@ SYMBOLS = {
     "lamd_check_schnorr_sig": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
     "lamd_check_tx_sig_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_u8p]),
     "lamd_check_tx_sig_tx_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz] + [c_u8p] * 15 + [c_sz, c_sz, c_u8p]),
+    "lamd_bolt12_check_signature_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, ctypes.c_char_p, ctypes.c_char_p, c_u8p, c_sz, c_u8p, c_u8p]),
+    "lamd_bolt12_merkle_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, ctypes.c_char_p, ctypes.c_char_p, c_u8p, c_u8p, c_u8p]),
     "lamd_ecdsa_recover_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
     "lamd_ecdsa_recover_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),
     "lamd_grind_htlc_tx_fee": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, c_u8p, c_sz, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,

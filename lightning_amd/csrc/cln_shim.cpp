@@ -266,6 +266,55 @@ extern "C" bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, cons
   return ok != 0;
 }
 
+// ---- BOLT #12: the fields are re-serialised (towire of type, length, value: bolt12_merkle.c:33-40) and hashed on the device
+static void put_bigsize(std::string &o, uint64_t v) {
+  if (v < 0xfd) o.push_back((char)v);
+  else if (v <= 0xffff) { o.push_back((char)0xfd); for (int i = 1; i >= 0; i--) o.push_back((char)(v >> (8 * i))); }
+  else if (v <= 0xffffffffull) { o.push_back((char)0xfe); for (int i = 3; i >= 0; i--) o.push_back((char)(v >> (8 * i))); }
+  else { o.push_back((char)0xff); for (int i = 7; i >= 0; i--) o.push_back((char)(v >> (8 * i))); }
+}
+static std::string serialise_fields(const struct tlv_field *fields) {
+  std::string o;
+  const size_t n = tal_bytelen(fields) / sizeof(struct tlv_field);
+  for (size_t i = 0; i < n; i++) {
+    put_bigsize(o, fields[i].numtype);
+    put_bigsize(o, fields[i].length);
+    o.append((const char *)fields[i].value, fields[i].length);
+  }
+  return o;
+}
+static bool bolt12_hashes(const struct tlv_field *fields, const char *messagename, const char *fieldname, u8 *merkle32, u8 *sighash32) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  const std::string st = serialise_fields(fields);
+  const uint64_t off[2] = {0, st.size()};
+  u8 ok = 0, dummy = 0;
+  const int rc = lamd_bolt12_merkle_batch(g_ctx, 1, st.empty() ? &dummy : (const u8 *)st.data(), off, messagename, fieldname, merkle32, sighash32, &ok);
+  if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return false; }
+  return ok != 0;
+}
+extern "C" void merkle_tlv(const struct tlv_field *fields, struct sha256 *merkle) {
+  if (!bolt12_hashes(fields, "", "", merkle->u.u8, nullptr)) memset(merkle->u.u8, 0, 32);  // "a distinctive all-zeroes" (bolt12_merkle.c:297-299)
+}
+extern "C" void sighash_from_merkle(const char *messagename, const char *fieldname, const struct sha256 *merkle, struct sha256 *sighash) {
+  const std::string tag = std::string("lightning") + messagename + fieldname;  // bip340_sighash_init, bitcoin/signature.c:389-405
+  u8 buf[96];
+  sha256_host((const u8 *)tag.data(), tag.size(), buf);
+  memcpy(buf + 32, buf, 32);
+  memcpy(buf + 64, merkle->u.u8, 32);
+  sha256_host(buf, sizeof buf, sighash->u.u8);
+}
+extern "C" bool bolt12_check_signature(const struct tlv_field *fields, const char *messagename, const char *fieldname, const struct pubkey *key,
+                                       const struct bip340sig *sig) {
+  if (!g_ctx && !lamd_shim_setup()) return false;
+  const std::string st = serialise_fields(fields);
+  const uint64_t off[2] = {0, st.size()};
+  u8 der[PUBKEY_CMPR_LEN], ok = 0, dummy = 0;
+  pubkey_to_der(der, key);
+  const int rc = lamd_bolt12_check_signature_batch(g_ctx, 1, st.empty() ? &dummy : (const u8 *)st.data(), off, messagename, fieldname, der, 33, sig->u8, &ok);
+  if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return false; }
+  return ok != 0;
+}
+
 extern "C" int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *, secp256k1_ecdsa_recoverable_signature *sig,
                                                                     const unsigned char *input64, int recid) {
   if (recid < 0 || recid > 3 || !below_n(input64) || !below_n(input64 + 32)) {

@@ -108,6 +108,20 @@ bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, const u8 *subsc
 bool check_tx_sig_preimage(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
 			   const struct pubkey *key, const struct bitcoin_signature *sig);
 
+/* BOLT #12 (common/bolt12.c:80-92, common/bolt12_merkle.h:8-12,70-79).  `fields` is a tal-style array of struct tlv_field
+ * (wire/tlvstream.h:16-26; make it with shim_tal_dup(): tal_count = tal_bytelen / sizeof) in stream order; the merkle tree and the tagged
+ * hash are computed on the device from the re-serialised fields, the verification is check_schnorr_sig()'s. */
+struct tlv_field {
+	const void *meta;   /* const struct tlv_record_type *: unused here */
+	uint64_t numtype;
+	size_t length;
+	u8 *value;
+};
+void merkle_tlv(const struct tlv_field *fields, struct sha256 *merkle);
+void sighash_from_merkle(const char *messagename, const char *fieldname, const struct sha256 *merkle, struct sha256 *sighash);
+bool bolt12_check_signature(const struct tlv_field *fields, const char *messagename, const char *fieldname, const struct pubkey *key,
+			    const struct bip340sig *sig);
+
 /* Public-key recovery as common/bolt11.c:1021-1046 and lightningd/signmessage.c:193 use it, under libsecp256k1's own
  * names and return conventions (1 = ok, 0 = failure; the context argument is accepted and ignored).  The opaque
  * recoverable signature holds r||s||recid. */

@@ -8,6 +8,8 @@
 
 #include <random>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/lightning_amd.h"
@@ -191,6 +193,18 @@ __global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__re
   }
   gate[i] = pass;
   for (int b = 0; b < 32; b++) hash32[32 * i + b] = h[b];
+}
+// ---- BOLT #12: merkle root + tagged signature hash of one TLV stream per lane (bolt12.h); valid[i] = the stream obeys the TLV rules
+__global__ void __launch_bounds__(64) k_bolt12_hash(size_t n, const u8 *__restrict__ tlvs, const u64 *__restrict__ off, bolt12_mids mids,
+                                                    u8 *__restrict__ root32, u8 *__restrict__ msg32, u8 *__restrict__ valid) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u8 root[32], msg[32];
+  for (int b = 0; b < 32; b++) root[b] = msg[b] = 0;
+  const bool ok = bolt12_merkle_root(tlvs + off[i], (size_t)(off[i + 1] - off[i]), mids, root);
+  if (ok) bolt12_sighash(mids, root, msg);
+  valid[i] = ok;
+  for (int b = 0; b < 32; b++) { if (root32) root32[32 * i + b] = root[b]; msg32[32 * i + b] = msg[b]; }
 }
 __global__ void __launch_bounds__(256) k_apply_gate(size_t n, const u8 *__restrict__ gate, u8 *__restrict__ ok) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -842,7 +856,7 @@ struct lamd_ctx {
   u32 *gtable = nullptr;
   std::string err;
   // per-call workspaces (grown on demand, reused)
-  devbuf recs, qwords, keyok, slots;
+  devbuf recs, qwords, keyok, slots, vbuf;
   // keyed path: row -> cache entry, de-duplication of the rows the cache did not know, new keys per comb shape (hk7 / hk10:
   // representative row, cache entry, table slot; parsed key, validity, build scratch), row lists per shape + cold rows
   devbuf row_ent, kd_table, kd_rep, kd_uid, kd_uniq, kd_count, kd_newent, plan, kt_fin;
@@ -890,6 +904,7 @@ struct lamd_ctx {
   int ecmult_waves = 3;
   int keyed_waves = 3;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3: no spill; 4: a 5-dword spill, measured 60 % slower)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
+  size_t prep_min_threads = 0;  // LAMD_PREP_MIN_THREADS: fewest prep threads of a large batch (0 = 256 per CU)
   u64 hash_seed = 0x243F6A8885A308D3ULL;
   size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -899,7 +914,8 @@ struct lamd_ctx {
   struct queue {
     u8 *h_a = nullptr, *h_b = nullptr, *h_c = nullptr, *h_ok = nullptr;  // hash/msg, sig, key, verdicts
     size_t cap = 0, n = 0;
-    std::vector<u32> tickets;  // position of each row in the verdict vector this staging set returns
+    struct span { size_t row0; u32 ticket0; size_t count; };
+    std::vector<span> tickets;  // rows [row0, row0 + count) of this queue return as verdicts [ticket0, ...) of the staging set
     devbuf d_a, d_b, d_c, d_ok;
   };
   struct queue_set {
@@ -1013,6 +1029,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->ecmult_waves = root->ecmult_waves;
     L->keyed_waves = root->keyed_waves;
     L->prep_batch = root->prep_batch;
+    L->prep_min_threads = root->prep_min_threads;
     L->hash_seed = root->hash_seed;
     L->chunk = root->chunk;
     L->keyed_mode = root->keyed_mode;
@@ -1062,6 +1079,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
+  if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
   {
     std::random_device rd;
     ctx->hash_seed = ((u64)rd() << 32) ^ (u64)rd() ^ 0x243F6A8885A308D3ULL;
@@ -1137,7 +1155,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (ctx->ev_cold) (void)hipEventDestroy(ctx->ev_cold);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
-  for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
+  for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->vbuf, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
                     &ctx->g_msgs, &ctx->g_off, &ctx->g_ids, &ctx->g_rowbase, &ctx->g_hash, &ctx->g_sig, &ctx->g_pub,
                     &ctx->g_malformed, &ctx->g_ok, &ctx->g_verdict})
     release(b);
@@ -1252,7 +1270,7 @@ static void launch_prep(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const 
   if (mode == MODE_ECDSA) {
     // enough threads to fill the chip, few enough that each amortises its inversion over ~16 signatures
     size_t threads = (n + ctx->prep_batch - 1) / ctx->prep_batch;
-    const size_t min_threads = (size_t)ctx->prop.multiProcessorCount * 256;
+    const size_t min_threads = ctx->prep_min_threads ? ctx->prep_min_threads : (size_t)ctx->prop.multiProcessorCount * 256;
     if (threads < min_threads) threads = n < min_threads ? n : min_threads;
     hipLaunchKernelGGL(k_ecdsa_prep, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, n, d_a, d_sig, recs);
   } else {
@@ -1341,10 +1359,17 @@ extern "C" int lamd_cache_clear(lamd_ctx *ctx) {
 // Every count in between (distinct keys, new tables, rows per list) stays on the device (`plan`): launches cover upper
 // bounds.  keyok_out (optional, n bytes): per-row key validity for the gossip reduce.
 static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 *d_sig, const u8 *d_key, int keylen,
-                     size_t keystride, u8 *d_ok, u8 *keyok_out, bool time_it) {
+                     size_t keystride, u8 *d_ok_caller, u8 *keyok_out, bool time_it) {
   int rc;
   lamd_ctx *root = ctx->root ? ctx->root : ctx;
   if ((rc = ensure(ctx, &ctx->recs, n * sizeof(prep_rec))) != LAMD_OK) return rc;
+  // The kernels of a call talk to each other through the verdict bytes (VERDICT_SUSPECT, SCHNORR_PENDING): that state lives in
+  // a workspace of the lane, and the caller's buffer receives the FINAL verdicts in one copy at the end of the call.  (It used to
+  // be the caller's buffer itself: two calls in flight on different lanes that were handed the same verdict buffer -- bench.py's
+  // steps -- then saw each other's markers, and the shared inversion of the BIP-340 parity stage, which walks its rows twice,
+  // rejected valid signatures whenever the set of pending rows changed between the passes.)
+  if ((rc = ensure(ctx, &ctx->vbuf, n)) != LAMD_OK) return rc;
+  u8 *d_ok = (u8 *)ctx->vbuf.p;
   prep_rec *recs = (prep_rec *)ctx->recs.p;
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   // stream2 must not start before the inputs (possibly still being copied on the main stream) are there
@@ -1373,6 +1398,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     if (mode == MODE_SCHNORR)
       hipLaunchKernelGGL(k_schnorr_final, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, (u32 *)ctx->slots.p, d_ok);
+    HIPCHK(ctx, hipMemcpyAsync(d_ok_caller, d_ok, n, hipMemcpyDeviceToDevice, ctx->stream));
     if (time_it) {
       HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
       ctx->ev_recorded = true;
@@ -1515,6 +1541,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   if (mode == MODE_SCHNORR)
     hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, fin, d_ok);
+  HIPCHK(ctx, hipMemcpyAsync(d_ok_caller, d_ok, n, hipMemcpyDeviceToDevice, ctx->stream));
   // statistics (and the cache's fill level) for whoever looks later: nothing waits for this copy
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_plan, plan, P_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_plan + P_WORDS, cc, C_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1615,9 +1642,13 @@ static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *si
   if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_c, n * keystride)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  // the keys first: key de-duplication and table building only need them.  All three copies stay on ONE stream: the caller's
+  // buffers are pageable, so the runtime stages them itself (the call blocks while it does); issuing the hash / signature copies on
+  // the prep stream instead gained nothing and a 1 M-row batch came back with 5 % wrong verdicts (pageable copies in flight on two
+  // streams; not root-caused) -- the pinned staging sets of the streaming queue (lamd_flush) do split their transfers.
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, key, n * keystride, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_a.p, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, key, n * keystride, hipMemcpyHostToDevice, ctx->stream));
   rc = run_device(ctx, mode, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, keylen, keystride,
                   (u8 *)ctx->out.p);
   if (rc != LAMD_OK) return rc;
@@ -1819,6 +1850,72 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
   return lamd_synchronize(ctx);
+}
+
+// ---- BOLT #12 signatures: n independent bolt12_check_signature(fields, messagename, fieldname, key, sig) calls (common/bolt12.c:80-92)
+static int bolt12_hash_device(lamd_ctx *ctx, size_t n, const uint8_t *tlvs, const uint64_t *off, const char *messagename, const char *fieldname,
+                              u8 *d_root, u8 *d_msg, u8 *d_valid) {
+  const size_t total = (size_t)(off[n] - off[0]);
+  std::vector<u64> rel(n + 1);
+  for (size_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
+  int rc;
+  if ((rc = ensure(ctx, &ctx->g_msgs, total + 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_off, (n + 1) * 8)) != LAMD_OK) return rc;
+  bolt12_mids mids;
+  const u8 leaf[6] = {'L', 'n', 'L', 'e', 'a', 'f'}, branch[8] = {'L', 'n', 'B', 'r', 'a', 'n', 'c', 'h'};
+  bolt12_tag_midstate(leaf, 6, leaf, 0, mids.leaf);
+  bolt12_tag_midstate(branch, 8, branch, 0, mids.branch);
+  const std::string tag2 = std::string(messagename) + fieldname;   // "lightning" || messagename || fieldname (bitcoin/signature.c:389-405)
+  bolt12_tag_midstate((const u8 *)"lightning", 9, (const u8 *)tag2.data(), tag2.size(), mids.sig);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, tlvs + off[0], total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_off.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // rel lives on this frame
+  hipLaunchKernelGGL(k_bolt12_hash, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p, mids,
+                     d_root, d_msg, d_valid);
+  HIPCHK(ctx, hipGetLastError());
+  return LAMD_OK;
+}
+extern "C" int lamd_bolt12_merkle_batch(lamd_ctx *ctx, size_t n, const uint8_t *tlvs, const uint64_t *off, const char *messagename,
+                                        const char *fieldname, uint8_t *merkle32, uint8_t *sighash32, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!tlvs || !off || !messagename || !fieldname || !ok) { ctx->err = "bad argument"; return LAMD_ERR_ARG; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = bolt12_hash_device(ctx, n, tlvs, off, messagename, fieldname, (u8 *)ctx->in_b.p, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
+  if (merkle32) HIPCHK(ctx, hipMemcpyAsync(merkle32, ctx->in_b.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (sighash32) HIPCHK(ctx, hipMemcpyAsync(sighash32, ctx->in_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->g_malformed.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);
+}
+extern "C" int lamd_bolt12_check_signature_batch(lamd_ctx *ctx, size_t n, const uint8_t *tlvs, const uint64_t *off, const char *messagename,
+                                                 const char *fieldname, const uint8_t *key33, size_t keystride, const uint8_t *sig64, uint8_t *ok) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!tlvs || !off || !messagename || !fieldname || !key33 || keystride < 33 || !sig64 || !ok) { ctx->err = "bad argument"; return LAMD_ERR_ARG; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  // check_schnorr_sig serialises the key compressed and drops the parity byte (bitcoin/signature.c:417-422)
+  std::vector<u8> xonly(n * 32);
+  for (size_t i = 0; i < n; i++) memcpy(&xonly[32 * i], key33 + keystride * i + 1, 32);
+  if ((rc = bolt12_hash_device(ctx, n, tlvs, off, messagename, fieldname, nullptr, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, xonly.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
+  rc = run_device(ctx, MODE_SCHNORR, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, 32, 32, (u8 *)ctx->out.p);
+  if (rc != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);   // xonly lives on this frame
 }
 
 // ---- ECDSA public-key recovery (verify_core.h "ECDSA public-key recovery"): out_pub33[i] = the compressed key, ok[i] = 1, or
@@ -2023,6 +2120,37 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
 }
 
 // ---- streaming queues
+// Filling the pinned staging set is the host's share of a streamed batch (~130-160 bytes per signature); one thread copies at
+// ~10 GB/s, which is less than the device verifies (cfg5: 4.84 M signatures = 775 MB per 14 ms).  Large pushes are therefore cut
+// into pieces and copied by a few short-lived threads.
+struct copy_job { u8 *dst; const u8 *src; size_t bytes; };
+static void par_copy(const copy_job *jobs, int njobs) {
+  size_t total = 0;
+  for (int i = 0; i < njobs; i++) total += jobs[i].bytes;
+  static const int max_threads = [] {
+    const char *e = getenv("LAMD_COPY_THREADS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    int t = e ? atoi(e) : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
+    return t < 1 ? 1 : (t > 16 ? 16 : t);
+  }();
+  if (total < ((size_t)4 << 20) || max_threads == 1) {
+    for (int i = 0; i < njobs; i++) memcpy(jobs[i].dst, jobs[i].src, jobs[i].bytes);
+    return;
+  }
+  // pieces of ~total/threads bytes, walking the jobs in order
+  std::vector<copy_job> pieces;
+  const size_t piece = (total + max_threads - 1) / max_threads;
+  for (int i = 0; i < njobs; i++)
+    for (size_t o = 0; o < jobs[i].bytes; o += piece) pieces.push_back({jobs[i].dst + o, jobs[i].src + o, std::min(piece, jobs[i].bytes - o)});
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (size_t k; (k = next.fetch_add(1)) < pieces.size();) memcpy(pieces[k].dst, pieces[k].src, pieces[k].bytes);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < max_threads; t++) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+}
 static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes) {
   if (q.n < q.cap) return LAMD_OK;
   const size_t ncap = q.cap ? q.cap * 2 : 1024;
@@ -2076,15 +2204,19 @@ static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *
   }
   const int rc = queue_reserve_n(ctx, q, kb, n);
   if (rc != LAMD_OK) return rc;
-  memcpy(q.h_a + 32 * q.n, a, 32 * n);
-  memcpy(q.h_b + 64 * q.n, sig, 64 * n);
   if (keystride == kb) {
-    memcpy(q.h_c + kb * q.n, key, kb * n);
+    const copy_job jobs[3] = {{q.h_a + 32 * q.n, a, 32 * n}, {q.h_b + 64 * q.n, sig, 64 * n}, {q.h_c + kb * q.n, key, kb * n}};
+    par_copy(jobs, 3);
   } else {
+    const copy_job jobs[2] = {{q.h_a + 32 * q.n, a, 32 * n}, {q.h_b + 64 * q.n, sig, 64 * n}};
+    par_copy(jobs, 2);
     for (size_t i = 0; i < n; i++) memcpy(q.h_c + kb * (q.n + i), key + keystride * i, kb);
   }
   const size_t first = set.rows;
-  for (size_t i = 0; i < n; i++) q.tickets.push_back((u32)(first + i));
+  if (!q.tickets.empty() && q.tickets.back().row0 + q.tickets.back().count == q.n && q.tickets.back().ticket0 + q.tickets.back().count == first)
+    q.tickets.back().count += n;  // consecutive pushes of one kind: one span
+  else
+    q.tickets.push_back({q.n, (u32)first, n});
   q.n += n;
   set.rows += n;
   return (int)first;
@@ -2133,9 +2265,16 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     if ((rc = ensure(ctx, &q.d_b, q.n * 64)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_c, q.n * kb + 16)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_ok, q.n)) != LAMD_OK) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream));
-    HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream));
+    // keys first (main stream: de-duplication / tables can start), hashes + signatures on the lane's prep stream (see run_host)
+    const bool split = q.n <= L->chunk;
+    hipStream_t s_as = split ? L->stream2 : L->stream;
     HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
+    if (split) {
+      HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, s_as));
+    HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, s_as));
     rc = run_device(L, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
                     (const u8 *)q.d_c.p, (int)kb, kb, (u8 *)q.d_ok.p);
     if (rc != LAMD_OK) {
@@ -2166,7 +2305,7 @@ static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
     return LAMD_ERR_ARG;
   }
   for (auto &q : qs.q) {
-    for (size_t i = 0; i < q.n; i++) ok[q.tickets[i]] = q.h_ok[i];
+    for (const auto &sp : q.tickets) memcpy(ok + sp.ticket0, q.h_ok + sp.row0, sp.count);
     q.tickets.clear();
     q.n = 0;
   }

@@ -170,6 +170,165 @@ LAMD_HD sc sc_inv(const sc &a) {
   return t;
 }
 
+// ---- The multiplicative work of the ECDSA preparation (prefix products, the shared inversion, u1 = z/s, u2 = r/s) in 9 limbs
+// of 29 bits, the representation fe.h uses for the field: a product column (<= 9 partial products of 2^58) accumulates in one
+// 64-bit register without carry handling, and 2^261 = 32 * (2^256 - n) (mod n) is a 134-bit constant, so the high half folds back
+// with 9x5, 5x5 and 1x5 limb products.  Values are residues below 2^261 with exactly carried limbs (not reduced below n until
+// sc29_to_sc); 161 multiply-adds per multiplication against 64 + 70 + the 32-bit carry chains of sc_mul above.
+struct sc29 { u32 n[9]; };
+constexpr u32 SC29_M = 0x1FFFFFFFu;
+#define LAMD_SC29_C {0x1937D7E0u, 0x0DA1732Fu, 0x1AFE2201u, 0x08C6542Du, 0x00028AA2u}  /* 2^261 mod n = 32 * LAMD_SC_NC, 29-bit limbs */
+
+LAMD_HD sc29 sc29_from_words(const u32 w[8]) {  // any 256-bit value
+  sc29 r;
+  r.n[0] = w[0] & SC29_M;
+  r.n[1] = ((w[0] >> 29) | (w[1] << 3)) & SC29_M;
+  r.n[2] = ((w[1] >> 26) | (w[2] << 6)) & SC29_M;
+  r.n[3] = ((w[2] >> 23) | (w[3] << 9)) & SC29_M;
+  r.n[4] = ((w[3] >> 20) | (w[4] << 12)) & SC29_M;
+  r.n[5] = ((w[4] >> 17) | (w[5] << 15)) & SC29_M;
+  r.n[6] = ((w[5] >> 14) | (w[6] << 18)) & SC29_M;
+  r.n[7] = ((w[6] >> 11) | (w[7] << 21)) & SC29_M;
+  r.n[8] = w[7] >> 8;
+  return r;
+}
+LAMD_HD sc29 sc29_from_sc(const sc &a) { return sc29_from_words(a.w); }
+LAMD_HD sc29 sc29_one() {
+  sc29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = i == 0;
+  return r;
+}
+// canonical representative in [0, n)
+LAMD_HD sc sc29_to_sc(const sc29 &a) {
+  // 261 bits as nine 32-bit words (the ninth holds bits 256..260)
+  u32 w[9];
+  w[0] = a.n[0] | (a.n[1] << 29);
+  w[1] = (a.n[1] >> 3) | (a.n[2] << 26);
+  w[2] = (a.n[2] >> 6) | (a.n[3] << 23);
+  w[3] = (a.n[3] >> 9) | (a.n[4] << 20);
+  w[4] = (a.n[4] >> 12) | (a.n[5] << 17);
+  w[5] = (a.n[5] >> 15) | (a.n[6] << 14);
+  w[6] = (a.n[6] >> 18) | (a.n[7] << 11);
+  w[7] = (a.n[7] >> 21) | (a.n[8] << 8);
+  w[8] = a.n[8] >> 24;
+  const u32 nc[5] = LAMD_SC_NC;
+  // v = low256 + q * (2^256 - n), twice: q <= 31 first, then the carry bit of that addition
+  u32 q = w[8];
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      c += (u64)w[i] + (i < 5 ? (u64)q * nc[i] : 0u);
+      w[i] = (u32)c;
+      c >>= 32;
+    }
+    q = (u32)c;
+  }
+  return sc_from_words(w, nullptr);  // < 2^256 < 2n: one conditional subtraction
+}
+// exact carries of `len` 64-bit columns into 29-bit limbs; the last limb takes what is left (caller knows it is small)
+template <int LEN>
+LAMD_HD void sc29_carry(u32 *out, const u64 *col) {
+  u64 cy = 0;
+#pragma unroll
+  for (int k = 0; k < LEN; k++) {
+    cy += col[k];
+    out[k] = (u32)cy & SC29_M;
+    cy >>= 29;
+  }
+  out[LEN] = (u32)cy;
+}
+LAMD_HD sc29 sc29_mul(const sc29 &a, const sc29 &b) {
+  const u32 C[5] = LAMD_SC29_C;
+  u64 col[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    u64 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int j = k - i;
+      if (j < 0 || j > 8) continue;
+      acc += (u64)a.n[i] * b.n[j];
+    }
+    col[k] = acc;
+  }
+  u32 t[18];
+  sc29_carry<17>(t, col);  // t[17] < 2^30
+  // fold 1: t[9..17] * 2^261 = t[9..17] * C -> columns 0..12
+  u64 d[13];
+#pragma unroll
+  for (int k = 0; k < 13; k++) {
+    u64 acc = k < 9 ? t[k] : 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int i = k - j;
+      if (i < 0 || i > 8) continue;
+      acc += (u64)t[9 + i] * C[j];
+    }
+    d[k] = acc;
+  }
+  u32 r1[14];
+  sc29_carry<13>(r1, d);
+  // fold 2: r1[9..13] (5 limbs) * C -> columns 0..8
+  u64 e[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    u64 acc = r1[k];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      const int i = k - j;
+      if (i < 0 || i > 4) continue;
+      acc += (u64)r1[9 + i] * C[j];
+    }
+    e[k] = acc;
+  }
+  u32 r2[10];
+  sc29_carry<9>(r2, e);
+  // folds 3 and 4: the limb above 2^261 is < 2^9, then 0 or 1; after the fourth the value is below 2^261
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    u64 f[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) f[k] = (u64)r2[k] + (k < 5 ? (u64)r2[9] * C[k] : 0u);
+    sc29_carry<9>(r2, f);
+  }
+  LAMD_ASSERT(r2[9] == 0);
+  sc29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.n[i] = r2[i];
+  return r;
+}
+LAMD_HD sc29 sc29_sqr_n(sc29 a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; i++) a = sc29_mul(a, a);
+  return a;
+}
+// a^(n-2), the chain of sc_inv
+LAMD_HD sc29 sc29_inv(const sc29 &a) {
+  const sc29 x2 = sc29_mul(sc29_sqr_n(a, 1), a);
+  const sc29 x4 = sc29_mul(sc29_sqr_n(x2, 2), x2);
+  const sc29 x8 = sc29_mul(sc29_sqr_n(x4, 4), x4);
+  const sc29 x16 = sc29_mul(sc29_sqr_n(x8, 8), x8);
+  const sc29 x32 = sc29_mul(sc29_sqr_n(x16, 16), x16);
+  const sc29 x64 = sc29_mul(sc29_sqr_n(x32, 32), x32);
+  sc29 t = sc29_mul(sc29_sqr_n(x64, 32), x32);
+  t = sc29_mul(sc29_sqr_n(t, 16), x16);
+  t = sc29_mul(sc29_sqr_n(t, 8), x8);
+  t = sc29_mul(sc29_sqr_n(t, 4), x4);
+  t = sc29_mul(sc29_sqr_n(t, 2), x2);
+  t = sc29_mul(sc29_sqr_n(t, 1), a);  // a^(2^127 - 1)
+  t = sc29_sqr_n(t, 1);               // bit 128 of n-2 is 0
+  const u32 low[4] = {0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u};
+#pragma unroll 1
+  for (int i = 127; i >= 0; i--) {
+    t = sc29_mul(t, t);
+    if ((low[i >> 5] >> (i & 31)) & 1) t = sc29_mul(t, a);
+  }
+  return t;
+}
+
 // ---- GLV endomorphism split: k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128.
 // Lattice basis (a1, b1), (a2, b2) of {(x, y): x + y*lambda = 0 mod n}; g1 = round(2^384*b2/n),
 // g2 = round(2^384*(-b1)/n); c1 = round(k*g1 / 2^384), c2 = round(k*g2 / 2^384);

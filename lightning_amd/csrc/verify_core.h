@@ -121,9 +121,9 @@ LAMD_HD void ecdsa_load_rs(const u8 *sig64, sc *r, sc *s, bool *ok) {
 
 LAMD_HD void ecdsa_prep_thread(size_t first, size_t stride, size_t n, const u8 *hash32, const u8 *sig64,
                                prep_rec *recs) {
-  sc acc;
-#pragma unroll
-  for (int i = 0; i < 8; i++) acc.w[i] = (i == 0);
+  // prefix products, the inversion and u1, u2 run in the 9x29 representation (scalar.h); the record of row i keeps the prefix
+  // product between the passes in its first nine words (u1[0..7], k1[0])
+  sc29 acc = sc29_one();
   size_t last = first;
   bool any = false;
 #pragma unroll 1
@@ -132,20 +132,23 @@ LAMD_HD void ecdsa_prep_thread(size_t first, size_t stride, size_t n, const u8 *
     bool ok;
     ecdsa_load_rs(sig64 + 64 * i, &r, &s, &ok);
 #pragma unroll
-    for (int k = 0; k < 8; k++) recs[i].u1[k] = acc.w[k];  // product of the valid s before i
-    if (ok) acc = sc_mul(acc, s);
+    for (int k = 0; k < 8; k++) recs[i].u1[k] = acc.n[k];  // product of the valid s before i
+    recs[i].k1[0] = acc.n[8];
+    if (ok) acc = sc29_mul(acc, sc29_from_sc(s));
     last = i;
     any = true;
   }
   if (!any) return;
-  sc inv = sc_inv(acc);
+  sc29 inv = sc29_inv(acc);
 #pragma unroll 1
   for (size_t i = last;; i -= stride) {
-    sc r, s, prefix;
+    sc r, s;
+    sc29 prefix;
     bool ok;
     ecdsa_load_rs(sig64 + 64 * i, &r, &s, &ok);
 #pragma unroll
-    for (int k = 0; k < 8; k++) prefix.w[k] = recs[i].u1[k];
+    for (int k = 0; k < 8; k++) prefix.n[k] = recs[i].u1[k];
+    prefix.n[8] = recs[i].k1[0];
     prep_rec out;
 #pragma unroll
     for (int k = 0; k < 8; k++) out.u1[k] = 0;
@@ -154,13 +157,12 @@ LAMD_HD void ecdsa_prep_thread(size_t first, size_t stride, size_t n, const u8 *
     out.flags = 0;
     out.pad[0] = out.pad[1] = out.pad[2] = 0;
     if (ok) {
-      const sc w = sc_mul(inv, prefix);  // s_i^-1
-      inv = sc_mul(inv, s);
+      const sc29 w = sc29_mul(inv, prefix);  // s_i^-1
+      inv = sc29_mul(inv, sc29_from_sc(s));
       u32 zw[8];
-      load_words_be(zw, hash32 + 32 * i);
-      const sc z = sc_from_words(zw, nullptr);
-      const sc u1 = sc_mul(z, w);
-      const sc u2 = sc_mul(r, w);
+      load_words_be(zw, hash32 + 32 * i);    // any 256-bit value: reduced by the multiplication
+      const sc u1 = sc29_to_sc(sc29_mul(sc29_from_words(zw), w));
+      const sc u2 = sc29_to_sc(sc29_mul(sc29_from_sc(r), w));
       glv_half h1, h2;
       glv_split(&h1, &h2, u2);
 #pragma unroll
@@ -1096,6 +1098,10 @@ LAMD_HD gossip_frame gossip_parse_frame(const u8 *m, size_t len) {
   }
   return f;
 }
+
+}  // namespace lamd
+#include "bolt12.h"
+namespace lamd {
 
 // ---- fee grind (onchaind/onchaind.c:388-438 grind_htlc_tx_fee): ONE signature and key, many candidate fees.  Every
 // candidate changes output 0's amount, hence hashOutputs, hence the sighash z -- but r, s and Q stay: with w = 1/s,

@@ -127,6 +127,29 @@ class Engine:
                                                        pub.shape[1], pub.shape[1], ok.ctypes.data))
         return ok.astype(bool)
 
+    @staticmethod
+    def _streams(streams):
+        off = np.concatenate([[0], np.cumsum([len(x) for x in streams])]).astype(np.uint64)
+        return np.frombuffer(b"".join(bytes(x) for x in streams) + b"\x00", dtype=np.uint8), off
+
+    def bolt12_check_signature_batch(self, streams, messagename, fieldname, key33, sig64):
+        """streams: list of serialised TLV streams; key33 uint8 [n,33]; sig64 uint8 [n,64] -> bool verdicts (lamd_bolt12_check_signature_batch)"""
+        blob, off = self._streams(streams)
+        key33, sig64 = _u8(key33, 33), _u8(sig64, 64)
+        ok = np.zeros(len(streams), dtype=np.uint8)
+        self._chk(self._lib.lamd_bolt12_check_signature_batch(self._ctx, len(streams), blob.ctypes.data, off.ctypes.data, messagename, fieldname,
+                                                              key33.ctypes.data, 33, sig64.ctypes.data, ok.ctypes.data))
+        return ok.astype(bool)
+
+    def bolt12_merkle_batch(self, streams, messagename, fieldname):
+        """-> (merkle roots uint8 [n,32], signature hashes uint8 [n,32], ok bool [n])"""
+        blob, off = self._streams(streams)
+        n = len(streams)
+        mk, sh, ok = np.zeros((n, 32), dtype=np.uint8), np.zeros((n, 32), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        self._chk(self._lib.lamd_bolt12_merkle_batch(self._ctx, n, blob.ctypes.data, off.ctypes.data, messagename, fieldname, mk.ctypes.data,
+                                                     sh.ctypes.data, ok.ctypes.data))
+        return mk, sh, ok.astype(bool)
+
     def ecdsa_recover(self, hash32, sig64, recid):
         """numpy uint8 [n,32], [n,64], [n] -> (keys uint8 [n,33], ok bool [n]); secp256k1_ecdsa_recover semantics"""
         hash32, sig64 = _u8(hash32, 32), _u8(sig64, 64)

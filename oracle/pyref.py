@@ -503,3 +503,85 @@ def ecdsa_recover(hash32, sig64, recid):
     z = int.from_bytes(hash32, "big") % N
     rinv = pow(r, -1, N)
     return padd(pmul(s * rinv % N, R), pmul((-z * rinv) % N, G))
+
+
+# ---- BOLT #12 signatures: merkle_tlv() + sighash_from_merkle() (common/bolt12_merkle.c:48-318) in front of BIP-340
+def bigsize(v):
+    """common/bigsize.c bigsize_put"""
+    if v < 0xfd:
+        return bytes([v])
+    if v <= 0xffff:
+        return b"\xfd" + v.to_bytes(2, "big")
+    if v <= 0xffffffff:
+        return b"\xfe" + v.to_bytes(4, "big")
+    return b"\xff" + v.to_bytes(8, "big")
+
+
+def tlv_stream_parse(b):
+    """the generic rules of fromwire_tlv (wire/tlvstream.c:144-300) with every type accepted: BigSize type and length minimally
+    encoded, lengths inside the stream, types strictly increasing -> [(type, value)] or None"""
+    out, pos, prev = [], 0, None
+    while pos < len(b):
+        r = bigsize_read(b, pos)
+        if r is None:
+            return None
+        t, pos = r
+        if prev is not None and t <= prev:
+            return None
+        prev = t
+        r = bigsize_read(b, pos)
+        if r is None:
+            return None
+        ln, pos = r
+        if ln > len(b) - pos:
+            return None
+        out.append((t, b[pos:pos + ln]))
+        pos += ln
+    return out
+
+
+def bolt12_H(tag, msg):
+    """BOLT #12: H(tag, msg) = SHA256(SHA256(tag) || SHA256(tag) || msg) (bolt12_merkle.c:48-58)"""
+    t = hashlib.sha256(tag).digest()
+    return hashlib.sha256(t + t + msg).digest()
+
+
+def bolt12_merkle(fields):
+    """fields: [(type, value)] in stream order; signature fields (240..1000) are skipped; the nonce tag comes from the first
+    field that becomes a leaf's predecessor exactly as merkle_tlv_full_() does it (:262-286); the tree is the reference's
+    oversized power-of-two with absent nodes passed through (:186-225, :293-296)"""
+    ser = lambda t, v: bigsize(t) + bigsize(len(v)) + v
+    pair = lambda a, b: bolt12_H(b"LnBranch", min(a, b) + max(a, b))
+    leaves, first = [], None
+    for t, v in fields:
+        if not leaves:
+            first = ser(t, v)
+        if 240 <= t <= 1000:
+            continue
+        leaves.append(pair(bolt12_H(b"LnLeaf", ser(t, v)), bolt12_H(b"LnNonce" + first, bigsize(t))))
+    if not leaves:
+        return None
+
+    def rec(arr):
+        if len(arr) == 1:
+            return arr[0]
+        left, right = rec(arr[:len(arr) // 2]), rec(arr[len(arr) // 2:])
+        return left if right is None else pair(left, right)
+    size = 1 << len(leaves).bit_length()          # 1 << ilog64(n)
+    return rec(leaves + [None] * (size - len(leaves)))
+
+
+def bolt12_sighash(messagename, fieldname, merkle):
+    """sighash_from_merkle (bolt12_merkle.c:308-318) with bip340_sighash_init's three-part tag (bitcoin/signature.c:389-405)"""
+    return bolt12_H(b"lightning" + messagename + fieldname, merkle)
+
+
+def bolt12_check_signature(tlv_stream, messagename, fieldname, key33, sig64):
+    """bolt12_check_signature (common/bolt12.c:80-92) on a serialised TLV stream; check_schnorr_sig drops the key's parity byte"""
+    fields = tlv_stream_parse(tlv_stream)
+    if fields is None:
+        return False
+    m = bolt12_merkle(fields)
+    if m is None:
+        return False
+    return schnorr_verify(bolt12_sighash(messagename, fieldname, m), key33[1:], sig64)

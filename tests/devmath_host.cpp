@@ -7,6 +7,7 @@
 #ifndef LAMD_GTABLE_WINDOW_BITS
 #define LAMD_GTABLE_WINDOW_BITS 8
 #endif
+#include <string>
 #include "../lightning_amd/csrc/verify_core.h"
 #include <stdlib.h>
 #include <string.h>
@@ -300,4 +301,39 @@ extern "C" int dm_bip143(u32 version, u32 locktime, const u8 *inputs, u32 n_in, 
   tx_view t;
   t.version = version; t.locktime = locktime; t.inputs = inputs; t.n_in = n_in; t.outputs = outputs; t.outputs_len = outputs_len; t.n_out = n_out;
   return bip143_sighash(t, in_idx, script, script_len, amount, sighash_type, out32);
+}
+
+// ---- BOLT #12 merkle root + signature hash of a TLV stream (bolt12.h)
+extern "C" int dm_bolt12(const u8 *tlv, size_t len, const char *messagename, const char *fieldname, u8 *root32, u8 *sighash32) {
+  bolt12_mids mids;
+  const u8 leaf[6] = {'L', 'n', 'L', 'e', 'a', 'f'}, branch[8] = {'L', 'n', 'B', 'r', 'a', 'n', 'c', 'h'};
+  bolt12_tag_midstate(leaf, 6, leaf, 0, mids.leaf);
+  bolt12_tag_midstate(branch, 8, branch, 0, mids.branch);
+  const std::string t2 = std::string(messagename) + fieldname;
+  bolt12_tag_midstate((const u8 *)"lightning", 9, (const u8 *)t2.data(), t2.size(), mids.sig);
+  if (!bolt12_merkle_root(tlv, len, mids, root32)) return 0;
+  bolt12_sighash(mids, root32, sighash32);
+  return 1;
+}
+
+// ---- 9x29 scalar arithmetic of the ECDSA preparation (scalar.h sc29_*): inputs are arbitrary 256-bit values, outputs canonical
+extern "C" void dm_sc29_mul(const u8 *a, const u8 *b, u8 *out) {
+  u32 x[8], y[8];
+  be_to_words(x, a); be_to_words(y, b);
+  const sc r = sc29_to_sc(sc29_mul(sc29_from_words(x), sc29_from_words(y)));
+  words_to_be(out, r.w);
+}
+extern "C" void dm_sc29_inv(const u8 *a, u8 *out) {
+  u32 x[8];
+  be_to_words(x, a);
+  const sc r = sc29_to_sc(sc29_inv(sc29_from_words(x)));
+  words_to_be(out, r.w);
+}
+extern "C" void dm_sc29_chain(const u8 *a, const u8 *b, int steps, u8 *out) {  // lazy values fed back without canonicalising
+  u32 x[8], y[8];
+  be_to_words(x, a); be_to_words(y, b);
+  sc29 p = sc29_from_words(x), q = sc29_from_words(y);
+  for (int i = 0; i < steps; i++) { const sc29 t = sc29_mul(p, q); p = q; q = t; }
+  const sc r = sc29_to_sc(q);
+  words_to_be(out, r.w);
 }

@@ -282,3 +282,55 @@ def test_cfg1_one_by_one_through_check_signed_hash(shim):
     exp = [e for _, _, _, e in rows]
     assert got == exp, [i for i in range(1024) if got[i] != exp[i]][:10]
     assert got_id == exp
+
+
+class TlvField(ctypes.Structure):
+    _fields_ = [("meta", ctypes.c_void_p), ("numtype", ctypes.c_uint64), ("length", ctypes.c_size_t), ("value", ctypes.c_void_p)]
+
+
+@pytest.mark.gpu
+def test_bolt12_check_signature_through_the_reference_prototype(shim):
+    """bolt12_check_signature(fields, messagename, fieldname, key, sig) / merkle_tlv / sighash_from_merkle (common/bolt12.c:80-92,
+    common/bolt12_merkle.h) on the invoice_request of common/test/run-bolt12_merkle.c:332-361 and the specification's n1 root"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref
+    shim.shim_tal_dup.restype = ctypes.c_void_p
+    shim.shim_tal_dup.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    shim.bolt12_check_signature.restype = ctypes.c_bool
+    shim.bolt12_check_signature.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+    shim.merkle_tlv.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    shim.sighash_from_merkle.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+
+    def tal_fields(fields):
+        arr = (TlvField * len(fields))()
+        keep = []
+        for i, (t, v) in enumerate(fields):
+            buf = ctypes.create_string_buffer(bytes(v), max(1, len(v)))
+            keep.append(buf)
+            arr[i].numtype, arr[i].length, arr[i].value = t, len(v), ctypes.cast(buf, ctypes.c_void_p).value
+        return shim.shim_tal_dup(None, bytes(arr), ctypes.sizeof(arr)), keep
+    out = (ctypes.c_ubyte * 32)()
+    f1, keep1 = tal_fields([(1, (1000).to_bytes(2, "big"))])
+    shim.merkle_tlv(f1, out)
+    assert bytes(out).hex() == "b013756c8fee86503a0b4abdab4cddeb1af5d344ca6fc2fa8b6c08938caa6f93"
+    bob_d = int.from_bytes(b"B" * 32, "big")
+    alice, bob = pyref.pubkey_create(int.from_bytes(b"A" * 32, "big")), pyref.pubkey_create(bob_d)
+    fields = [(0, bytes(8)), (6, b"USD"), (8, b"\x64"), (10, b"A Mathematical Treatise"), (22, pyref.ser33(alice)), (88, pyref.ser33(bob))]
+    root = pyref.bolt12_merkle(fields)
+    sh = (ctypes.c_ubyte * 32)()
+    shim.sighash_from_merkle(b"invoice_request", b"signature", root, sh)
+    assert bytes(sh) == pyref.bolt12_sighash(b"invoice_request", b"signature", root)
+    sig = pyref.schnorr_sign(bytes(sh), bob_d)
+    fa, keep2 = tal_fields(fields + [(240, sig)])
+    shim.merkle_tlv(fa, out)
+    assert bytes(out) == root
+    key = Pubkey()
+    assert shim.pubkey_from_der(pyref.ser33(bob), 33, ctypes.byref(key))
+    assert shim.bolt12_check_signature(fa, b"invoice_request", b"signature", ctypes.byref(key), sig) is True
+    assert shim.bolt12_check_signature(fa, b"invoice", b"signature", ctypes.byref(key), sig) is False
+    bad = sig[:10] + bytes([sig[10] ^ 1]) + sig[11:]
+    assert shim.bolt12_check_signature(fa, b"invoice_request", b"signature", ctypes.byref(key), bad) is False
+    akey = Pubkey()
+    assert shim.pubkey_from_der(pyref.ser33(alice), 33, ctypes.byref(akey))
+    assert shim.bolt12_check_signature(fa, b"invoice_request", b"signature", ctypes.byref(akey), sig) is False

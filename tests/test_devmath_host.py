@@ -583,3 +583,81 @@ def test_bip143_sighash_host_build_vs_pyref_and_reference_kat(dm, kat):
     assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob), 1, 1, script, 1, amount, 1, o) == 0          # input index out of range
     assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob) - 1, 1, 0, script, 1, amount, 1, o) == 0      # truncated outputs
     assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob), 2, 0, script, 1, amount, 1, o) == 0          # fewer outputs than claimed
+
+
+def _tlv(t, v):
+    return pyref.bigsize(t) + pyref.bigsize(len(v)) + v
+
+
+# BOLT #12 signature-test vectors (bolt12/signature-test.json of the specification, the file common/test/run-bolt12_merkle.c prints):
+# recalled offline; the three roots below are reproduced digit for digit by the restatement, which no wrong algorithm would do
+BOLT12_N1 = [((1, (1000).to_bytes(2, "big")),),
+             ((1, (1000).to_bytes(2, "big")), (2, ((1 << 40) | (2 << 16) | 3).to_bytes(8, "big"))),
+             ((1, (1000).to_bytes(2, "big")), (2, ((1 << 40) | (2 << 16) | 3).to_bytes(8, "big")),
+              (3, H("0266e4598d1d3c415f572a8488830b60f7e744ed9235eb0b1ba93283b315c03518") + (1).to_bytes(8, "big") + (2).to_bytes(8, "big")))]
+BOLT12_N1_ROOTS = ["b013756c8fee86503a0b4abdab4cddeb1af5d344ca6fc2fa8b6c08938caa6f93", "c3774abbf4815aa54ccaa026bff6581f01f3be5fe814c620a252534f434bc0d1",
+                   "ab2e79b1283b0b31e0b035258de23782df6b89a38cfa7237bde69aed1a658c5d"]
+
+
+def test_bolt12_merkle_host_build_vs_pyref_and_spec_vectors(dm):
+    """the device's BOLT #12 front end on the host: the specification's n1 vectors (the trees common/test/run-bolt12_merkle.c builds
+    by hand, :150-330), the explicit construction that test asserts against merkle_tlv(), and 6 000 random TLV streams -- 1..70
+    fields, values across the BigSize boundaries, signature fields (240..1000) in between, big types -- against the restatement;
+    malformed streams are refused"""
+    dm.dm_bolt12.restype = ctypes.c_int
+    dm.dm_bolt12.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    root, sh = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    assert _tlv(*BOLT12_N1[0][0]) == H("010203e8")
+    for fields, want in zip(BOLT12_N1, BOLT12_N1_ROOTS):
+        st = b"".join(_tlv(t, v) for t, v in fields)
+        assert pyref.bolt12_merkle(list(fields)).hex() == want
+        assert dm.dm_bolt12(st, len(st), b"invoice_request", b"signature", root, sh) == 1 and root.raw.hex() == want
+        assert sh.raw == pyref.bolt12_sighash(b"invoice_request", b"signature", root.raw)
+    # the three-leaf tree spelled out as the reference's test does (:259-263): H(LnBranch, ordered(H(LnBranch, ordered(l0, l1)), l2))
+    f = BOLT12_N1[2]
+    first = _tlv(*f[0])
+    Hh, order = pyref.bolt12_H, lambda a, b: min(a, b) + max(a, b)
+    leaf = [Hh(b"LnBranch", order(Hh(b"LnLeaf", _tlv(t, v)), Hh(b"LnNonce" + first, pyref.bigsize(t)))) for t, v in f]
+    assert Hh(b"LnBranch", order(Hh(b"LnBranch", order(leaf[0], leaf[1])), leaf[2])).hex() == BOLT12_N1_ROOTS[2]
+    rnd = random.Random(1212)
+    for it in range(6_000):
+        nf = rnd.choice([1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 70])
+        types = sorted(rnd.sample(list(range(0, 240)) + list(range(240, 1001, 7)) + list(range(1001, 1100)) + [0x10000, 0x10001, 1 << 32, (1 << 40) + 5, (1 << 64) - 1], nf))
+        fields = [(t, bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 8, 33, 64, 100, 252, 253, 300])))) for t in types]
+        st = b"".join(_tlv(t, v) for t, v in fields)
+        want = pyref.bolt12_merkle(fields)
+        assert pyref.tlv_stream_parse(st) == fields
+        got = dm.dm_bolt12(st, len(st), b"invoice", b"signature", root, sh)
+        if want is None:
+            assert got == 0
+        else:
+            assert got == 1 and root.raw == want and sh.raw == pyref.bolt12_sighash(b"invoice", b"signature", want), it
+    ok = _tlv(1, b"ab") + _tlv(5, b"c")
+    for bad in (ok[:-1], _tlv(5, b"c") + _tlv(1, b"ab"), _tlv(1, b"a") + _tlv(1, b"b"), b"\xfd\x00\x01\x00", b"\x01\xfd\x00\x01a", b"\x01", _tlv(240, bytes(64)), b""):
+        assert dm.dm_bolt12(bad, len(bad), b"invoice", b"signature", root, sh) == 0, bad.hex()
+        assert pyref.tlv_stream_parse(bad) is None or pyref.bolt12_merkle(pyref.tlv_stream_parse(bad)) is None
+    assert dm.dm_bolt12(ok, len(ok), b"invoice", b"signature", root, sh) == 1
+
+
+def test_sc29_scalar_arithmetic_vs_integers(dm):
+    """the 9x29-limb arithmetic mod n that the ECDSA preparation runs in (prefix products, shared inversion, u1, u2): products of
+    arbitrary 256-bit values (not only residues), chains of lazy values, inversion -- against Python integers; edge operands"""
+    Nn = pyref.N
+    out = ctypes.create_string_buffer(32)
+    rnd = random.Random(2929)
+    edge = [0, 1, 2, Nn - 1, Nn, Nn + 1, (1 << 256) - 1, (1 << 256) - Nn, 1 << 255, (1 << 128) - 1, (1 << 261) % Nn, Nn - 2, (Nn - 1) // 2]
+    vals = edge + [rnd.getrandbits(256) for _ in range(300)]
+    for a in vals:
+        for b in rnd.sample(vals, 12) + edge[:6]:
+            dm.dm_sc29_mul(a.to_bytes(32, "big"), b.to_bytes(32, "big"), out)
+            assert int.from_bytes(out.raw, "big") == a * b % Nn, (hex(a), hex(b))
+    for _ in range(200):
+        a, b, steps = rnd.getrandbits(256), rnd.getrandbits(256), rnd.randrange(1, 40)
+        dm.dm_sc29_chain(a.to_bytes(32, "big"), b.to_bytes(32, "big"), steps, out)
+        p, q = a, b
+        for _ in range(steps):
+            p, q = q, p * q % Nn
+        assert int.from_bytes(out.raw, "big") == q % Nn
+    for a in [1, 2, Nn - 1, Nn + 5, (1 << 256) - 1] + [rnd.getrandbits(256) for _ in range(40)]:
+        dm.dm_sc29_inv(a.to_bytes(32, "big"), out)
+        assert int.from_bytes(out.raw, "big") == pow(a % Nn, -1, Nn), hex(a)

@@ -865,3 +865,68 @@ def test_check_tx_sig_from_transaction_templates_vs_spec_model(eng, orc):
     got = eng.check_tx_sig_tx_batch(txs, _rows(sigs, 64), _rows(pubs, 33))
     assert [bool(g) for g in got] == exp
     assert 1500 < sum(exp) < 2900
+
+
+@pytest.mark.gpu
+def test_bolt12_signatures_device_front_end_vs_spec_model(eng):
+    """BOLT #12 (rest of N4): merkle_tlv + sighash_from_merkle + check_schnorr_sig on the device (lamd_bolt12_check_signature_batch)
+    -- the specification's n1 roots, the invoice_request of common/test/run-bolt12_merkle.c:332-361 (Alice 0x41.., Bob 0x42.. signs),
+    and 1 500 random streams signed with the model's BIP-340 signer, a third damaged (value byte, type, signature, key, tag,
+    a signature field's content -- which must NOT matter --, a stream that breaks the TLV rules)"""
+    def tlv(t, v):
+        return pyref.bigsize(t) + pyref.bigsize(len(v)) + v
+    n1 = [(1, (1000).to_bytes(2, "big")), (2, ((1 << 40) | (2 << 16) | 3).to_bytes(8, "big")),
+          (3, H("0266e4598d1d3c415f572a8488830b60f7e744ed9235eb0b1ba93283b315c03518") + (1).to_bytes(8, "big") + (2).to_bytes(8, "big"))]
+    streams = [b"".join(tlv(t, v) for t, v in n1[:k]) for k in (1, 2, 3)]
+    mk, sh, ok = eng.bolt12_merkle_batch(streams, b"invoice_request", b"signature")
+    assert ok.all() and [bytes(r).hex() for r in mk] == ["b013756c8fee86503a0b4abdab4cddeb1af5d344ca6fc2fa8b6c08938caa6f93",
+                                                         "c3774abbf4815aa54ccaa026bff6581f01f3be5fe814c620a252534f434bc0d1",
+                                                         "ab2e79b1283b0b31e0b035258de23782df6b89a38cfa7237bde69aed1a658c5d"]
+    assert all(bytes(sh[i]) == pyref.bolt12_sighash(b"invoice_request", b"signature", bytes(mk[i])) for i in range(3))
+    # the reference test's invoice_request
+    alice, bob = pyref.pubkey_create(int.from_bytes(b"A" * 32, "big")), pyref.pubkey_create(int.from_bytes(b"B" * 32, "big"))
+    fields = [(0, bytes(8)), (6, b"USD"), (8, b"\x64"), (10, b"A Mathematical Treatise"), (22, pyref.ser33(alice)), (88, pyref.ser33(bob))]
+    root = pyref.bolt12_merkle(fields)
+    sig = pyref.schnorr_sign(pyref.bolt12_sighash(b"invoice_request", b"signature", root), int.from_bytes(b"B" * 32, "big"))
+    st = b"".join(tlv(t, v) for t, v in fields) + tlv(240, sig)
+    assert len(pyref.tlv_stream_parse(st)) == 7                     # as the reference asserts (:363)
+    got = eng.bolt12_check_signature_batch([st, st, st], b"invoice_request", b"signature", _rows([pyref.ser33(bob), pyref.ser33(alice), pyref.ser33(bob)], 33),
+                                           _rows([sig, sig, sig[:63] + bytes([sig[63] ^ 1])], 64))
+    assert list(got) == [True, False, False]
+    assert not eng.bolt12_check_signature_batch([st], b"invoice", b"signature", _rows([pyref.ser33(bob)], 33), _rows([sig], 64))[0]   # the tag is signed too
+    rnd = random.Random(1240)
+    keys = [rnd.randrange(1, pyref.N) for _ in range(9)]
+    pubs = [pyref.ser33(pyref.pubkey_create(d)) for d in keys]
+    streams, ks, sigs, exp = [], [], [], []
+    for it in range(1500):
+        nf = rnd.choice([1, 2, 3, 5, 6, 7, 8, 12, 17, 40])
+        types = sorted(rnd.sample(list(range(0, 240)) + list(range(1001, 1060)) + [0x10000, 1 << 33], nf))
+        fields = [(t, bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 8, 33, 100, 253, 300])))) for t in types]
+        k = rnd.randrange(len(keys))
+        sig = pyref.schnorr_sign(pyref.bolt12_sighash(b"invoice", b"signature", pyref.bolt12_merkle(fields)), keys[k], bytes(rnd.randrange(256) for _ in range(32)))
+        sigfield = (240, sig)
+        key = pubs[k]
+        dmg = rnd.randrange(21)
+        if dmg == 0 and fields[0][1]:
+            fields[0] = (fields[0][0], bytes([fields[0][1][0] ^ 1]) + fields[0][1][1:])
+        elif dmg == 1:
+            fields[-1] = (fields[-1][0] + 2, fields[-1][1])
+        elif dmg == 2:
+            sig = sig[:40] + bytes([sig[40] ^ 0x20]) + sig[41:]
+        elif dmg == 3:
+            key = pubs[(k + 1) % len(pubs)]
+        elif dmg == 4:
+            sigfield = (240, bytes(64))                       # the signature FIELD is no leaf: its content does not matter
+        elif dmg == 5:
+            key = bytes([key[0] ^ 1]) + key[1:]               # the parity byte is dropped: still valid
+        allf = sorted(fields + [sigfield])
+        st = b"".join(tlv(t, v) for t, v in allf)
+        if dmg == 6:
+            st = st[:-1]                                      # truncated: fromwire_tlv fails
+        elif dmg == 7 and len(fields) > 1:
+            st = tlv(*fields[1]) + tlv(*fields[0])            # not ascending
+        streams.append(st); ks.append(key); sigs.append(sig)
+        exp.append(pyref.bolt12_check_signature(st, b"invoice", b"signature", key, sig))
+    got = eng.bolt12_check_signature_batch(streams, b"invoice", b"signature", _rows(ks, 33), _rows(sigs, 64))
+    assert [bool(g) for g in got] == exp
+    assert 1000 < sum(exp) < 1450

@@ -141,3 +141,30 @@ def test_device_field_fuzz_one_million_ops():
         assert ops >= 30_000_000
         bad, ops, rep = eng.fuzz_field(lanes=64, iters=2000, seed=0xBEEF)   # one latency-bound wave
         assert bad == 0, rep
+
+
+@pytest.mark.gpu
+def test_calls_in_flight_may_share_one_verdict_buffer(monkeypatch):
+    """Regression (round 2): the kernels of a call used to keep their inter-kernel state (SCHNORR_PENDING / VERDICT_SUSPECT) in the
+    CALLER's verdict buffer; two calls in flight on different lanes with the same buffer (bench.py's steps) then disturbed each
+    other's BIP-340 parity stage and valid signatures came back rejected -- visible once the scalar preparation was slow enough
+    (few, long-running threads) for calls to overlap widely.  Verdicts now reach the caller's buffer in one final copy."""
+    import numpy as np
+    import torch
+    from lightning_amd import Engine, workload
+    monkeypatch.setenv("LAMD_CACHE", "0")
+    monkeypatch.setenv("LAMD_PREP_BATCH", "64")
+    monkeypatch.setenv("LAMD_PREP_MIN_THREADS", "4096")
+    n = 300_000
+    with Engine(0) as eng:
+        we = workload.make_ecdsa(eng, n, seed=91, nkeys=20000, publen=65)
+        ws = workload.make_schnorr(eng, n, seed=92, nkeys=20000)
+        eng.auto_order = False
+        for rep in range(3):
+            for k in range(10):
+                eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
+                eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            assert int((we.d_ok.cpu().numpy().astype(bool) != we.expect).sum()) == 0, rep
+            assert int((ws.d_ok.cpu().numpy().astype(bool) != ws.expect).sum()) == 0, rep
