@@ -391,6 +391,23 @@ def main():
                 ts.append(time.perf_counter() - t1)
             ts = np.sort(np.array(ts[5:])) * 1e3
             lat["ecdsa65_batch_%d" % bs] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)])}
+        if world == 1:
+            # one commitment_signed as channeld sees it (channeld.c:2171,2224): 1 signature under the funding key + 483 under ONE htlc key
+            # that recurs with every commitment of the channel -- first sight (the key gets its comb table) and afterwards (cache hit)
+            cs = workload.make_commit_storm(eng, 4, device=device)["ecdsa"]
+            hh, ss, pp = [np.ascontiguousarray(x[:484]) for x in cs.cols]
+            t1 = time.perf_counter()
+            first = eng.verify_ecdsa(hh, ss, pp)
+            t_first = time.perf_counter() - t1
+            ts = []
+            for it in range(60):
+                t1 = time.perf_counter()
+                got = eng.verify_ecdsa(hh, ss, pp)
+                ts.append(time.perf_counter() - t1)
+            ts = np.sort(np.array(ts[5:])) * 1e3
+            mism += int((got != cs.expect[:484]).sum() + (first != cs.expect[:484]).sum())
+            lat["commitment_484_one_htlc_key"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
+                                                  "cache_hits_last_call": int(eng.info()["last_cache_hits"])}
         if lat:
             out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
         tp = []
@@ -464,6 +481,54 @@ def main():
                                                     "note": "inputs in host memory: staging memcpy + H2D + verification + D2H inside the clock"}
             mism += sbad
             del st
+            # ---- N2: the same kind of flood through the batched gossip INGEST (lightning_amd/csrc/gossip_ingest.cpp: gossipd's receive
+            # path -- filters, ordering, store -- around one device call per drained queue): 100 k channel_announcements from a
+            # peer, lightningd's txout replies, then 400 k channel_updates for those channels.  Host code + GPU inside the clock.
+            try:
+                import hashlib
+                from lightning_amd.gossipd import GossipIngest
+                g = workload.make_gossip(eng, 100_000, 400_000, n_nodes=15000, corrupt_frac=0.01, device=device)
+                chain = bytes(g.msgs[260:292])
+                peer = bytes(g.ids[g.n_cann])          # some node relays everything
+                cann_blob, cann_off = g.msgs[:int(g.off[g.n_cann]) + 1], g.off[:g.n_cann + 1].copy()
+                cupd_blob = g.msgs[int(g.off[g.n_cann]):]
+                cupd_off = (g.off[g.n_cann:] - g.off[g.n_cann]).copy()
+                spk = []
+                for i in range(g.n_cann):
+                    m = g.msgs[int(g.off[i]):int(g.off[i + 1])]
+                    k1, k2 = sorted([bytes(m[366:399]), bytes(m[399:432])])
+                    spk.append(b"\x00\x20" + hashlib.sha256(b"\x52\x21" + k1 + b"\x21" + k2 + b"\x52\xae").digest())
+                spk_blob = np.frombuffer(b"".join(spk) + b"\x00", dtype=np.uint8)
+                spk_off = (np.arange(g.n_cann + 1, dtype=np.uint64) * 34)
+                scids = np.arange(g.n_cann, dtype=np.uint64)
+                sats = np.full(g.n_cann, 1_000_000, dtype=np.uint64)
+                res = {}
+                for rep in range(2):
+                    with GossipIngest(eng, chain, peer, 700_000, 1 << 32, prune_interval=0xFFFFFFFF, collect_events=False) as ing:
+                        t1 = time.perf_counter()
+                        ing.push_batch(peer, cann_blob, cann_off)
+                        ing.process()
+                        t2 = time.perf_counter()
+                        ing.txout_reply_batch(scids, sats, spk_blob, spk_off)
+                        t3 = time.perf_counter()
+                        ing.push_batch(peer, cupd_blob, cupd_off)
+                        ing.process()
+                        t4 = time.perf_counter()
+                        st_ = ing.stats()
+                    res = {"channel_announcements": g.n_cann, "channel_updates": g.n_cupd,
+                           "announcements_per_s": g.n_cann / (t2 - t1), "txout_replies_per_s": g.n_cann / (t3 - t2), "updates_per_s": g.n_cupd / (t4 - t3),
+                           "messages_per_s_overall": g.n / (t4 - t1), "verified_sigs": int(st_["verified_sigs"]), "device_batches": int(st_["batches"]),
+                           "channels_accepted": int(st_["channels"]), "store_records": int(st_["store_records"]), "late_verifies": int(st_["late_verifies"])}
+                exp_ok_cann = int((g.expect[:g.n_cann] == 0).sum())
+                ibad = 0 if (res["channels_accepted"] == exp_ok_cann and res["late_verifies"] == 0) else 1
+                res["mismatches"] = ibad
+                res["note"] = ("host buffers in -> store events out; accepted channels = announcements with four good signatures by construction; the "
+                               "sequential reference does one libsecp256k1 call per signature here (gossmap_manage.c:687,924)")
+                extra["gossip_ingest_flood"] = res
+                mism += ibad
+                del g
+            except Exception as e:   # the ingest leg must not take the headline down
+                extra["gossip_ingest_flood"] = {"error": repr(e)}
             # onchaind's fee grind with the reference's own transaction (onchaind/test/run-grind_feerate.c):
             # every feerate 0..250 000 at weight 663 for one signature/key, hashing + verification on the device
             try:

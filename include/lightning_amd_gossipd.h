@@ -50,8 +50,7 @@ enum lamd_gossipd_event_kind {
 	LAMD_GEV_QUERY_CHANNEL = 8,  /* query_unknown_channel(peer, scid) (gossmap_manage.c:908) */
 	LAMD_GEV_QUERY_NODE = 9,     /* query_unknown_node(peer, node id in data) (gossmap_manage.c:1232) */
 	LAMD_GEV_GOOD_GOSSIP = 10,   /* peer_supplied_good_gossip(peer, 1) */
-	LAMD_GEV_TXOUT_FAILED = 11,  /* txout_failures_add(scid) (gossmap_manage.c:868-869) */
-	LAMD_GEV_DEBUG = 12          /* status_debug / status_trace lines without a peer */
+	LAMD_GEV_TXOUT_FAILED = 11   /* txout_failures_add(scid) (gossmap_manage.c:868-869) */
 };
 
 typedef struct lamd_gossipd_event {
@@ -94,11 +93,18 @@ void lamd_gossipd_set_backend(lamd_gossipd *g, lamd_gossipd_sigcheck_fn sigcheck
 /* connectd -> gossipd: one raw peer message (type 256/257/258) from source_peer33 (may be NULL: generated locally).
  * Queues only; LAMD_ERR_STATE when more than 500 000 messages are waiting (connectd drops there, multiplex.c:829-833). */
 int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, const uint8_t *msg, size_t len);
+/* n messages at once: message i is msgs + off[i] .. off[i+1] from source_peers33 + peer_stride*i (source_peers33 NULL: no peer;
+ * peer_stride 0: one peer for all) */
+int lamd_gossipd_push_batch(lamd_gossipd *g, size_t n, const uint8_t *source_peers33, size_t peer_stride, const uint8_t *msgs,
+			    const uint64_t *off);
 /* Drains the queue as ONE batch (see above).  Returns the number of messages applied, or a negative LAMD_ERR_*. */
 long lamd_gossipd_process(lamd_gossipd *g);
 /* lightningd's answer to LAMD_GEV_GET_TXOUT (gossmap_manage.c:753-872); script_len 0 = no unspent output.  Channel_updates
  * and node_announcements that were waiting are verified (one batch) and applied once nothing is pending any more. */
 int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const uint8_t *script, size_t script_len);
+/* n replies in order (reply i's script: scripts + script_off[i] .. script_off[i+1]) */
+int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const uint64_t *scids, const uint64_t *sats, const uint8_t *scripts,
+				   const uint64_t *script_off);
 /* gossmap_manage_new_block (:1358-1390): too-early announcements that are now deep enough become pending */
 int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight);
 void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now);

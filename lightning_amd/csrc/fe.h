@@ -349,6 +349,77 @@ LAMD_HD fe fe_sqr(const fe &a) {
 #endif
 }
 
+// ---- fused forms: ONE reduction (fold, carries, tail) for a product plus something else.  The group law is full of
+// "product minus value" and "product minus product" (U2 - X1, S2 - Y1, R^2 - H^3 - 2V, R*(V - X3) - Y1*H^3): as separate
+// operations each costs a lazy negation, an addition and a fe_norm_weak (~48 instructions) or a whole second reduction
+// (~75); here the extra terms join the column accumulators of the multiply -- limb k of the addend as one more multiply-add
+// (times 1) in column k, a second product as 81 more multiply-adds -- and the result comes out exactly carried (magnitude 1).
+// Column budget as for fe_mul: mag(a)*mag(b) [+ mag(c)*mag(d)] <= 7; an addend of magnitude <= 7 is noise against that.
+#define LAMD_FE_ASM_IO9(x) "v"(x.n[0]), "v"(x.n[1]), "v"(x.n[2]), "v"(x.n[3]), "v"(x.n[4]), "v"(x.n[5]), "v"(x.n[6]), "v"(x.n[7]), "v"(x.n[8])
+// r = a*b + e
+LAMD_HD fe fe_mul_add(const fe &a, const fe &b, const fe &ad) {
+  LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7 && FE_MAG(ad) <= 7);
+#if defined(LAMD_FE_ASM_BLOCK) && defined(LAMD_FE_MULADD_ASM)
+  fe r;
+  u64 hi, lo;
+  u32 t0, t1, t2;
+  asm(LAMD_FE_MULADD_ASM
+      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+      : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), "s"(FE_R0), "s"(1u << FE_R1_SHIFT), LAMD_FE_ASM_IO9(ad)
+      : "vcc");
+  LAMD_FE_TAIL
+#else
+#define LAMD_P(k, acc, ch) do { fe_mul_col<ch>(a, b, k, acc); if ((k) < 9) acc += ad.n[(k) < 9 ? (k) : 0]; } while (0)
+  LAMD_FE_CHAINS(LAMD_P)
+  LAMD_FE_TAIL
+#undef LAMD_P
+#endif
+}
+// r = a^2 + e; mag(a) <= 2
+LAMD_HD fe fe_sqr_add(const fe &a, const fe &ad) {
+  LAMD_ASSERT(FE_MAG(a) <= 2 && FE_MAG(ad) <= 7);
+  fe d;
+#pragma unroll
+  for (int i = 0; i < 9; i++) d.n[i] = a.n[i] << 1;
+#if defined(LAMD_FE_ASM_BLOCK) && defined(LAMD_FE_SQRADD_ASM)
+  fe r;
+  u64 hi, lo;
+  u32 t0, t1, t2;
+  asm(LAMD_FE_SQRADD_ASM
+      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+      : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), "s"(FE_R0), "s"(1u << FE_R1_SHIFT), LAMD_FE_ASM_IO9(ad)
+      : "vcc");
+  LAMD_FE_TAIL
+#else
+#define LAMD_P(k, acc, ch) do { fe_sqr_col<ch>(a, d.n, k, acc); if ((k) < 9) acc += ad.n[(k) < 9 ? (k) : 0]; } while (0)
+  LAMD_FE_CHAINS(LAMD_P)
+  LAMD_FE_TAIL
+#undef LAMD_P
+#endif
+}
+// r = a*b + c*d
+LAMD_HD fe fe_mul2(const fe &a, const fe &b, const fe &c, const fe &d) {
+  LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) + FE_MAG(c) * FE_MAG(d) <= 7);
+#if defined(LAMD_FE_ASM_BLOCK) && defined(LAMD_FE_MUL2_ASM)
+  fe r;
+  u64 hi, lo;
+  u32 t0, t1, t2;
+  asm(LAMD_FE_MUL2_ASM
+      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+      : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), "s"(FE_R0), "s"(1u << FE_R1_SHIFT), LAMD_FE_ASM_IO9(c), LAMD_FE_ASM_IO9(d)
+      : "vcc");
+  LAMD_FE_TAIL
+#else
+#define LAMD_P(k, acc, ch) do { fe_mul_col<ch>(a, b, k, acc); fe_mul_col<ch>(c, d, k, acc); } while (0)
+  LAMD_FE_CHAINS(LAMD_P)
+  LAMD_FE_TAIL
+#undef LAMD_P
+#endif
+}
+
 LAMD_HD fe fe_sqr_n(fe a, int n) {
 #pragma unroll 1
   for (int i = 0; i < n; i++) a = fe_sqr(a);

@@ -29,7 +29,7 @@ LAMD_HD void fz_mix(u64 &h, const fe &a) {
 #pragma unroll
   for (int i = 0; i < 9; i++) h = (h ^ a.n[i]) * 0x100000001B3ULL;
 }
-constexpr int FZ_OPS_PER_ITER = 2 + 7 + 11 + 11, FZ_OPS_TAIL = 270;  // mul + sqr | double | add core | complete add; one inversion per lane
+constexpr int FZ_OPS_PER_ITER = 2 + 4 + 7 + 11 + 11 + 11, FZ_OPS_TAIL = 270;  // mul + sqr | fused forms | double | add core | complete add | bare add; one inversion per lane
 LAMD_HD u64 fuzz_lane(u64 seed, u64 lane, int iters) {
   u64 s = seed ^ (lane * 0xD1342543DE82EF95ULL), h = 0xCBF29CE484222325ULL;
   const u32 pa[8] = {1, 1, 7, 2, 3, 1, 2, 4}, pb[8] = {1, 7, 1, 3, 2, 4, 2, 1};
@@ -44,6 +44,14 @@ LAMD_HD u64 fuzz_lane(u64 seed, u64 lane, int iters) {
     const fe c = fz_fe(s, 1 + ((k >> 3) & 1));
     const fe s1 = fe_sqr(c);
     fz_mix(h, m1); fz_mix(h, s1);
+    // the fused forms at their budget: a*b + e (7 + a magnitude-7 addend), c^2 + e, a*b + c*d with the magnitude products adding up to 7
+    const u32 pc[4] = {3, 2, 1, 6}, pd[4] = {2, 3, 6, 1}, pe[4] = {1, 1, 1, 1}, pf[4] = {1, 1, 1, 1};
+    const u32 q = (k >> 9) & 3;
+    const fe ad = fz_fe(s, 1 + ((k >> 11) % 7));
+    const fe f1 = fe_mul_add(a, b, ad), f2 = fe_sqr_add(c, ad);
+    const fe f3 = fe_mul2(fz_fe(s, pc[q]), fz_fe(s, pd[q]), fz_fe(s, pe[q]), fz_fe(s, pf[q]));   // 6 + 1
+    const fe f4 = fe_mul2(fz_fe(s, 2), fz_fe(s, 2), fz_fe(s, 3), fz_fe(s, 1));                   // 4 + 3
+    fz_mix(h, f1); fz_mix(h, f2); fz_mix(h, f3); fz_mix(h, f4);
     const fe t = fe_add(fe_neg(m1, 1), fe_mul_int(s1, 3));  // magnitude 5
     const fe nw = fe_norm_weak(t);
     fz_mix(h, nw); fz_mix(h, fe_carry(t)); fz_mix(h, fe_normalize(t));
@@ -61,6 +69,9 @@ LAMD_HD u64 fuzz_lane(u64 seed, u64 lane, int iters) {
     fz_mix(h, P.x); fz_mix(h, P.y); fz_mix(h, P.z);
     h = (h ^ (u64)degenerate ^ ((u64)P.inf << 1)) * 0x100000001B3ULL;
     P.inf = false;
+    Q.x = f1; Q.y = fe_add(f2, f3);   // the table-driven kernels' form: no tests, a magnitude-2 y
+    P = gej_add_ge_fast(P, Q);
+    fz_mix(h, P.x); fz_mix(h, P.y); fz_mix(h, P.z);
     P.z = fe_norm_weak(P.z);
     keep = fe_select((k >> 8) & 1, m1, s1);
   }

@@ -540,9 +540,13 @@ struct lamd_gossipd {
 
   // ---- reprocess_queued_msgs (:1284-1342): the signatures of every waiting channel_update whose channel now exists go to
   // the device as one batch first
+  void drop_verdicts() {  // (clear() walks the whole bucket array of a map that once held a large batch)
+    if (!verdicts.empty() || verdicts.bucket_count() > 64) std::unordered_map<std::string, int>().swap(verdicts);
+  }
   int reprocess_queued_msgs() {
     const bool pending_empty = pending_ann.empty(), early_empty = early_ann.empty();
     if (!pending_empty && !early_empty) return LAMD_OK;
+    if (pending_cupdates.empty() && early_cupdates.empty() && pending_nannounces.empty()) return LAMD_OK;  // nothing is waiting
     slotlist sl;
     auto plan_list = [&](const std::vector<pending_cupdate> &l) {
       for (const pending_cupdate &u : l) {
@@ -550,7 +554,7 @@ struct lamd_gossipd {
         if (it != chans.end()) sl.add(this, u.update, &it->second.node[u.cflags & 1]);
       }
     };
-    verdicts.clear();
+    drop_verdicts();
     if (pending_empty) plan_list(pending_cupdates);
     if (early_empty) plan_list(early_cupdates);
     const int rc = verify(sl);
@@ -581,7 +585,7 @@ struct lamd_gossipd {
         process_node_announcement(it->second, pn.timestamp, pn.id, pn.msg, pn.has_src, &pn.src);
       }
     }
-    verdicts.clear();
+    drop_verdicts();
     return LAMD_OK;
   }
 
@@ -633,6 +637,18 @@ extern "C" int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, 
   memset(q.src.k, 0, 33);
   if (source_peer33) memcpy(q.src.k, source_peer33, 33);
   g->queue.push_back(std::move(q));
+  return LAMD_OK;
+}
+
+extern "C" int lamd_gossipd_push_batch(lamd_gossipd *g, size_t n, const uint8_t *source_peers33, size_t peer_stride, const uint8_t *msgs,
+                                       const uint64_t *off) {
+  if (!g || (n && (!msgs || !off))) return LAMD_ERR_ARG;
+  if (g->queue.size() + n > 500000 + 1) return LAMD_ERR_STATE;
+  g->queue.reserve(g->queue.size() + n);
+  for (size_t i = 0; i < n; i++) {
+    const int rc = lamd_gossipd_push(g, source_peers33 ? source_peers33 + peer_stride * i : nullptr, msgs + off[i], (size_t)(off[i + 1] - off[i]));
+    if (rc != LAMD_OK) return rc;
+  }
   return LAMD_OK;
 }
 
@@ -688,7 +704,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     }
   }
   // ---- verify: one call for the signatures, one for the keys of announcements that are dropped anyway
-  g->verdicts.clear();
+  g->drop_verdicts();
   int rc = g->verify(sl);
   if (rc != LAMD_OK) { g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
   std::vector<u8> keyok(keyblob.size() / 33, 0);
@@ -706,7 +722,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     // other types never reach gossipd's three handlers (gossipd.c:206-264)
     g->st.messages++;
   }
-  g->verdicts.clear();
+  g->drop_verdicts();
   return (long)n;
 }
 
@@ -745,6 +761,16 @@ extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t
     nd.nchans++;
   }
   return g->reprocess_queued_msgs();  // :864
+}
+
+extern "C" int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const uint64_t *scids, const uint64_t *sats, const uint8_t *scripts,
+                                              const uint64_t *script_off) {
+  if (!g || (n && (!scids || !sats || !scripts || !script_off))) return LAMD_ERR_ARG;
+  for (size_t i = 0; i < n; i++) {
+    const int rc = lamd_gossipd_txout_reply(g, scids[i], sats[i], scripts + script_off[i], (size_t)(script_off[i + 1] - script_off[i]));
+    if (rc != LAMD_OK) return rc;
+  }
+  return LAMD_OK;
 }
 
 extern "C" int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight) {

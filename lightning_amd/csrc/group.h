@@ -46,10 +46,9 @@ LAMD_HD gej gej_double(const gej &a) {
   const fe uu = fe_sqr(u);                         // 4Y^4        (1)
   const fe w = fe_mul(a.x, u);                     // 2XY^2       (1)
   const fe m = fe_norm_weak(fe_mul_int(fe_sqr(a.x), 3));  // 3X^2  (1)
-  const fe mm = fe_sqr(m);
-  r.x = fe_norm_weak(fe_add(mm, fe_neg(fe_mul_int(w, 4), 4)));               // M^2 - 8XY^2
+  r.x = fe_sqr_add(m, fe_neg(fe_mul_int(w, 4), 4));                           // M^2 - 8XY^2: one reduction
   const fe t = fe_add(fe_mul_int(w, 2), fe_neg(r.x, 1));                      // 4XY^2 - X3  (4)
-  r.y = fe_norm_weak(fe_add(fe_mul(m, t), fe_neg(fe_mul_int(uu, 2), 2)));   // M*t - 8Y^4
+  r.y = fe_mul_add(m, t, fe_neg(fe_mul_int(uu, 2), 2));                       // M*t - 8Y^4: one reduction
   r.z = fe_mul_int(fe_mul(a.y, a.z), 2);                                      // 2YZ         (2)
   r.inf = a.inf;
   return r;
@@ -61,17 +60,15 @@ LAMD_HD gej gej_double(const gej &a) {
 LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, bool *degenerate, fe *h_out, fe *rr_out) {
   gej r;
   const fe zz = fe_sqr(a.z);
-  const fe u2 = fe_mul(b.x, zz);
-  const fe s2 = fe_mul(b.y, fe_mul(a.z, zz));
-  const fe h = fe_norm_weak(fe_add(u2, fe_neg(a.x, 1)));
-  const fe rr = fe_norm_weak(fe_add(s2, fe_neg(a.y, 1)));
+  const fe h = fe_mul_add(b.x, zz, fe_neg(a.x, 1));                  // U2 - X1, exactly carried
+  const fe rr = fe_mul_add(b.y, fe_mul(a.z, zz), fe_neg(a.y, 1));    // S2 - Y1
   *degenerate = fe_is_zero(h);
   const fe hh = fe_sqr(h);
   const fe hhh = fe_mul(h, hh);
   const fe v = fe_mul(a.x, hh);
-  r.x = fe_norm_weak(fe_add(fe_sqr(rr), fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3)));
+  r.x = fe_sqr_add(rr, fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3));   // R^2 - H^3 - 2V
   const fe t = fe_add(v, fe_neg(r.x, 1));  // (3)
-  r.y = fe_norm_weak(fe_add(fe_mul(rr, t), fe_neg(fe_mul(a.y, hhh), 1)));
+  r.y = fe_mul2(rr, t, a.y, fe_neg(hhh, 1));                         // R*(V - X3) - Y1*H^3: two products, one reduction
   r.z = fe_mul(a.z, h);
   r.inf = false;
   *h_out = h;
@@ -86,16 +83,14 @@ LAMD_HD gej gej_add_ge_core(const gej &a, const ge &b, bool *degenerate, fe *h_o
 LAMD_HD gej gej_add_ge_fast(const gej &a, const ge &b) {
   gej r;
   const fe zz = fe_sqr(a.z);
-  const fe u2 = fe_mul(b.x, zz);
-  const fe s2 = fe_mul(b.y, fe_mul(a.z, zz));
-  const fe h = fe_norm_weak(fe_add(u2, fe_neg(a.x, 1)));
-  const fe rr = fe_norm_weak(fe_add(s2, fe_neg(a.y, 1)));
+  const fe h = fe_mul_add(b.x, zz, fe_neg(a.x, 1));
+  const fe rr = fe_mul_add(b.y, fe_mul(a.z, zz), fe_neg(a.y, 1));
   const fe hh = fe_sqr(h);
   const fe hhh = fe_mul(h, hh);
   const fe v = fe_mul(a.x, hh);
-  r.x = fe_norm_weak(fe_add(fe_sqr(rr), fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3)));
+  r.x = fe_sqr_add(rr, fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3));
   const fe t = fe_add(v, fe_neg(r.x, 1));  // (3)
-  r.y = fe_norm_weak(fe_add(fe_mul(rr, t), fe_neg(fe_mul(a.y, hhh), 1)));
+  r.y = fe_mul2(rr, t, a.y, fe_neg(hhh, 1));
   r.z = fe_mul(a.z, h);
   r.inf = false;
   return r;

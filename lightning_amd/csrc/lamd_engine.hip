@@ -480,6 +480,13 @@ __global__ void __launch_bounds__(256) k_gen_gossip(size_t n_cann, size_t n_cupd
     const u64 side = splitmix64(seed ^ splitmix64(u + (13ULL << 56))) & 1;
     const sc d = rand_scalar(seed, side ? b : a, 1);
     pubkey33(ids + i * 33, d, gtable);
+    // the direction bit of channel_flags says whether the signer is node_id_1 or node_id_2 of the announcement, i.e. the lesser or
+    // the greater of the two keys (BOLT #7; gossmap_manage.c:920-922 picks the verification key by it)
+    u8 other[33];
+    pubkey33(other, rand_scalar(seed, side ? a : b, 1), gtable);
+    bool signer_greater = false;
+    for (int j = 0; j < 33; j++)
+      if (ids[i * 33 + j] != other[j]) { signer_greater = ids[i * 33 + j] > other[j]; break; }
     m[0] = 0x01; m[1] = 0x02;
     u8 *body = m + 66;
     for (int j = 0; j < 32; j++) body[j] = chain[j];
@@ -488,7 +495,7 @@ __global__ void __launch_bounds__(256) k_gen_gossip(size_t n_cann, size_t n_cupd
     rand_words(rndw, seed, u, 6);
     for (int j = 0; j < 32; j++) body[40 + j] = (u8)(rndw[j >> 2] >> (8 * (j & 3)));
     body[44] = 1;               // message_flags: option_channel_htlc_max
-    body[45] = (u8)side;        // channel_flags: direction
+    body[45] = signer_greater ? 1 : 0;  // channel_flags: direction
     sha256d_bytes(body, CUPD_LEN - 66, h);
     load_words_be(zw, h);
     sign_ecdsa_words(rw, sw, zw, d, rand_scalar(seed, u, 7), gtable);

@@ -41,6 +41,8 @@ def _load():
         L.lamd_gossipd_free.argtypes = [ctypes.c_void_p]
         L.lamd_gossipd_set_backend.argtypes = [ctypes.c_void_p, SIGCHECK_FN, KEYPARSE_FN, ctypes.c_void_p]
         L.lamd_gossipd_push.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
+        L.lamd_gossipd_push_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.lamd_gossipd_txout_reply_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.lamd_gossipd_process.restype = ctypes.c_long
         L.lamd_gossipd_process.argtypes = [ctypes.c_void_p]
         L.lamd_gossipd_txout_reply.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]
@@ -56,14 +58,14 @@ class GossipIngest:
     sigcheck(msgs_blob: bytes, off: list[int], ids: bytes) -> list[int], keyparse(keys: bytes) -> list[int] -- which tests use to
     run the host logic against a CPU checker on a machine without a GPU."""
 
-    def __init__(self, engine, chain_hash, our_id, blockheight, now, prune_interval=0, backend=None):
+    def __init__(self, engine, chain_hash, our_id, blockheight, now, prune_interval=0, backend=None, collect_events=True):
         self._L = _load()
         cfg = Config()
         cfg.chain_hash[:] = chain_hash
         cfg.our_id[:] = our_id
         cfg.blockheight, cfg.now, cfg.prune_interval = blockheight, now, prune_interval
         self.events = []
-        self._cb = EVENT_FN(self._on_event)
+        self._cb = EVENT_FN(self._on_event) if collect_events else ctypes.cast(None, EVENT_FN)
         self._engine = engine
         self._g = self._L.lamd_gossipd_new(engine._ctx if engine is not None else None, ctypes.byref(cfg), self._cb, None)
         if not self._g:
@@ -111,6 +113,17 @@ class GossipIngest:
         rc = self._L.lamd_gossipd_push(self._g, peer, msg, len(msg))
         if rc != 0:
             raise RuntimeError("lamd_gossipd_push: %d" % rc)
+
+    def push_batch(self, peer, msgs, off):
+        """msgs: numpy uint8 blob, off: numpy uint64 [n+1]; every message from `peer` (33 bytes or None)"""
+        rc = self._L.lamd_gossipd_push_batch(self._g, len(off) - 1, peer, 0, msgs.ctypes.data, off.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("lamd_gossipd_push_batch: %d" % rc)
+
+    def txout_reply_batch(self, scids, sats, scripts, script_off):
+        rc = self._L.lamd_gossipd_txout_reply_batch(self._g, len(scids), scids.ctypes.data, sats.ctypes.data, scripts.ctypes.data, script_off.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("lamd_gossipd_txout_reply_batch: %d" % rc)
 
     def process(self):
         n = self._L.lamd_gossipd_process(self._g)

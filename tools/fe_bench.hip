@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <vector>
-#include "../lightning_amd/csrc/fe.h"
+#include "../lightning_amd/csrc/group.h"
 using namespace lamd;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -19,20 +19,18 @@ __global__ void __launch_bounds__(256) k_chain(u32 *out, int iters) {
   for (int it = 0; it < iters; it++) {
     if (MODE == 0) { const fe c = fe_mul(a, b); a = b; b = c; const fe d = fe_mul(a, b); a = b; b = d; }
     else if (MODE == 1) { a = fe_sqr(a); a = fe_sqr(a); }
-    else {  // mixed-addition shaped: 8 mul + 3 sqr with the glue of gej_add_ge_fast
-      const fe zz = fe_sqr(b);
-      const fe u2 = fe_mul(a, zz);
-      const fe s2 = fe_mul(a, fe_mul(b, zz));
-      const fe h = fe_norm_weak(fe_add(u2, fe_neg(a, 1)));
-      const fe rr = fe_norm_weak(fe_add(s2, fe_neg(b, 1)));
-      const fe hh = fe_sqr(h);
-      const fe hhh = fe_mul(h, hh);
-      const fe v = fe_mul(a, hh);
-      const fe x3 = fe_norm_weak(fe_add(fe_sqr(rr), fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3)));
-      const fe tt = fe_add(v, fe_neg(x3, 1));
-      const fe y3 = fe_norm_weak(fe_add(fe_mul(rr, tt), fe_neg(fe_mul(b, hhh), 1)));
-      b = fe_norm_weak(fe_mul(b, h));
-      a = fe_norm_weak(fe_add(x3, y3));
+    else if (MODE == 2) {  // the table-driven kernels' mixed addition (group.h gej_add_ge_fast): 8 multiplications + 3 squarings
+      gej P;
+      P.x = a; P.y = b; P.z = a; P.inf = false;
+      ge Q;
+      Q.x = b; Q.y = a;
+      P = gej_add_ge_fast(P, Q);
+      a = P.x; b = fe_norm_weak(fe_add(P.y, P.z));
+    } else {               // doubling: 3 multiplications + 4 squarings
+      gej P;
+      P.x = a; P.y = b; P.z = a; P.inf = false;
+      P = gej_double(P);
+      a = P.x; b = fe_norm_weak(fe_add(P.y, P.z));
     }
   }
   u32 acc = 0;
@@ -104,13 +102,13 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
-  const char *names[] = {"mul-chain", "sqr-chain", "madd-shape"};
-  kfn fs[] = {k_chain<0>, k_chain<1>, k_chain<2>};
-  const double per_iter[] = {2, 2, 11};
-  for (int m = 0; m < 3; m++) {
+  const char *names[] = {"mul-chain", "sqr-chain", "madd", "double"};
+  kfn fs[] = {k_chain<0>, k_chain<1>, k_chain<2>, k_chain<3>};
+  const double per_iter[] = {2, 2, 1, 1};
+  for (int m = 0; m < 4; m++) {
     printf("%-10s", names[m]);
-    for (int w : W) { const int iters = m == 2 ? 300 : 1500; const double s = run(fs[m], cus * w, iters, dout); printf("  w%d %.3e", w, (double)cus * w * 256 * iters * per_iter[m] / s); }
-    printf("  mul(+sqr)/s\n");
+    for (int w : W) { const int iters = m >= 2 ? 300 : 1500; const double s = run(fs[m], cus * w, iters, dout); printf("  w%d %.3e", w, (double)cus * w * 256 * iters * per_iter[m] / s); }
+    printf(m >= 2 ? "  group operations/s\n" : "  mul(+sqr)/s\n");
   }
   return 0;
 }

@@ -30,10 +30,16 @@ T = lambda k: "%%%d" % (8 + k % 3)   # h[k] lives in rotating temp k mod 3
 A = lambda i: "%%%d" % (13 + NX + i)
 B = lambda i: "%%%d" % (22 + NX + i)
 SR0, S256 = "%%%d" % (31 + NX), "%%%d" % (32 + NX)
-MASK = "%%%d" % (33 + NX) if MASK_SGPR else "0x1fffffff"
+C2 = lambda i: "%%%d" % (33 + NX + i)   # second product's left operand (LAMD_FE_MUL2_ASM) / the addend limbs (..._ADD_ASM)
+D2 = lambda i: "%%%d" % (42 + NX + i)   # second product's right operand
+assert not MASK_SGPR or True
+MASK = "%%%d" % (33 + NX) if MASK_SGPR else "0x1fffffff"   # (--mask=sgpr is only generated for the plain multiply / square)
 CY = {True: "%13" if CARRY_SGPR else "vcc", False: "%14" if CARRY_SGPR else "vcc"}   # keyed by "is the high chain"
 hi, lo = "v[%d:%d]" % (HI, HI + 1), "v[%d:%d]" % (LO, LO + 1)
 hil, lol = "v%d" % HI, "v%d" % LO
+
+
+EXTRA = {"prod2": False, "addend": False}   # set per emitted macro
 
 
 def column(acc, k, square, first):
@@ -47,6 +53,13 @@ def column(acc, k, square, first):
         else:
             x, y = A(i), B(j)
         out.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, CY[acc == hi], x, y, "0" if first and not out else acc))
+    if EXTRA["prod2"]:      # a second full product c*d accumulated into the same columns: one reduction for a*b + c*d
+        for i in range(9):
+            j = k - i
+            if 0 <= j <= 8:
+                out.append("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, CY[acc == hi], C2(i), D2(j), acc))
+    if EXTRA["addend"] and k <= 8:   # + e: limb k of a lazy field element joins column k (times the inline constant 1)
+        out.append("v_mad_u64_u32 %s, %s, %s, 1, %s" % (acc, CY[acc == hi], C2(k), acc))
     return out
 
 
@@ -90,7 +103,8 @@ def body(square):
     return ins
 
 
-def emit(name, square):
+def emit(name, square, prod2=False, addend=False):
+    EXTRA["prod2"], EXTRA["addend"] = prod2, addend
     ins = body(square)
     nm = sum(1 for x in ins if x.startswith("v_mad"))
     print("// %s: %d v_mad_u64_u32 + %d other instructions" % (name, nm, len(ins) - nm))
@@ -110,3 +124,7 @@ print("#define LAMD_FE_ASM_EXTRA_IN %s" % (', "s"(FE_M29)' if MASK_SGPR else "")
 print("#define LAMD_FE_ASM_CLOBBER %s" % ("" if CARRY_SGPR else '"vcc"'))
 emit("LAMD_FE_MUL_ASM", False)
 emit("LAMD_FE_SQR_ASM", True)
+if not MASK_SGPR:
+    emit("LAMD_FE_MULADD_ASM", False, addend=True)   # a*b + e      (%33.. = e[0..8])
+    emit("LAMD_FE_SQRADD_ASM", True, addend=True)    # a^2 + e
+    emit("LAMD_FE_MUL2_ASM", False, prod2=True)      # a*b + c*d    (%33.. = c[0..8], %42.. = d[0..8])

@@ -60,9 +60,11 @@ for k in sorted(vals):
         lines.append("  %-22s %.6g" % (c, d[c]))
     summary[k] = d
     lines.append("")
-hot = next((k for k in summary if k.startswith("k_ecmult_keyed") and "[ecdsa]" in k), None) or next(k for k in summary if k.startswith("k_ecmult") and "[ecdsa]" in k)
+cand = [k for k in summary if k.startswith("k_ecmult_keyed") and "[ecdsa]" in k and summary[k].get("SQ_INSTS_VALU", 0) > 0] or \
+       [k for k in summary if k.startswith("k_ecmult") and "[ecdsa]" in k]
+hot = max(cand, key=lambda k: summary[k].get("SQ_INSTS_VALU", 0))   # the table-driven kernel that does the work (not the empty careful / 10-tooth launches)
 e = summary[hot]
-kname = hot.split(" ")[0]
+kname = hot[:hot.rindex(" [")]
 t = mean(dur[kname][0::2]) * 1e-6 if len(dur[kname]) > 1 else dur[kname][0] * 1e-6
 # counter passes serialise the kernels (no overlap between the engine's lanes): take that pass's own duration for rates
 def pass_t(sub):
