@@ -30,11 +30,12 @@ sys.path.insert(0, ROOT)
 # algorithmic 32x32->64 multiplies per verification (implementation-independent yardstick)
 W_ECDSA65 = 1.32e5
 W_SCHNORR = 1.65e5
-# 32x32->64 multiply-adds the ecmult kernel EXECUTES per verification: field multiplications M (97 mads) and
-# squarings S (61 mads) of: doublings 3M+4S, mixed additions 8M+3S, + 2 tail mads each, + the acceptance test
+# 32x32->64 multiply-adds the ecmult kernel EXECUTES per verification.  A field multiplication is 99
+# v_mad_u64_u32 (97 in the generated block + 2 in the tail), a squaring 63; the fused forms add 9 for an addend and make a*b + c*d
+# 180.  Mixed addition (group.h gej_add_ge_fast): S + (M+9) + M + (M+9) + S + M + M + (S+9) + 180 + M = 990; doubling: 3 S +
+# (S+9) + M + (M+9) + M = 567; acceptance test: 3 M + 1 S.
 def _mads(dbl, add):
-    m, sq = 3 * dbl + 8 * add + 3, 4 * dbl + 3 * add + 1
-    return m * 99 + sq * 63
+    return dbl * 567 + add * 990 + 3 * 99 + 63
 # ladder: 132 doublings (+1 for 2Q), 66 + 6 table additions, 12 G windows; combs: both halves made odd by a lattice vector (no
 # repair additions), the first table point initialises the accumulator: 2D - 1 additions + D - 1 doublings + 12 G windows
 W_EXEC = {0: _mads(132 + 1, 66 + 12 + 6), 7: _mads(18, 37 + 12), 10: _mads(12, 25 + 12)}   # ladder, 7-tooth comb, 10-tooth comb

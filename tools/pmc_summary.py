@@ -21,15 +21,22 @@ def short(name):
 
 # ---- kernel trace: durations per kernel, in launch order; ECDSA launches come before Schnorr launches in every step
 trace = load("trace", "kernel_trace")
-dur = collections.defaultdict(list)
+dur, bigdur = collections.defaultdict(list), collections.defaultdict(list)
 for r in sorted(trace, key=lambda r: int(r["Start_Timestamp"])):
-    dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    dur[short(r["Kernel_Name"])].append(d)
+    if int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) >= 500000:      # the 1 M-row launches of the timed loops / isolated calls
+        bigdur[short(r["Kernel_Name"])].append(d)
 lines = ["# rocprofv3 summary, MI355X, `python bench.py --steps 2 --warmup 1 --cpu-sample 0 --skip-extra` (1 M ECDSA-65 + 1 M BIP-340 per step)",
          "# pass 1: --kernel-trace --stats; passes 2-5: --kernel-trace --pmc ... (FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2), one counter group per run", "",
-         "[kernel trace: calls, mean us, min us]"]
+         "[kernel trace, launches over >= 500 000 work items only (the 1 M-row batches; the bench's latency legs launch the same kernels over a few hundred rows): calls, mean us, min us, max us]"]
+for k, v in sorted(bigdur.items(), key=lambda kv: -sum(kv[1])):
+    if k.startswith("k_") and not k.startswith("k_gen") and not k.startswith("k_gtable"):
+        lines.append("  %-32s %4d %12.1f %12.1f %12.1f" % (k, len(v), sum(v) / len(v), min(v), max(v)))
+lines += ["", "[kernel trace, every launch: calls, mean us, min us]"]
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     if k.startswith("k_"):
-        lines.append("  %-28s %4d %12.1f %12.1f" % (k, len(v), sum(v) / len(v), min(v)))
+        lines.append("  %-32s %4d %12.1f %12.1f" % (k, len(v), sum(v) / len(v), min(v)))
 lines.append("")
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("fetch", "write", "sq", "sq2"):
@@ -65,7 +72,7 @@ cand = [k for k in summary if k.startswith("k_ecmult_keyed") and "[ecdsa]" in k 
 hot = max(cand, key=lambda k: summary[k].get("SQ_INSTS_VALU", 0))   # the table-driven kernel that does the work (not the empty careful / 10-tooth launches)
 e = summary[hot]
 kname = hot[:hot.rindex(" [")]
-t = mean(dur[kname][0::2]) * 1e-6 if len(dur[kname]) > 1 else dur[kname][0] * 1e-6
+t = mean(bigdur[kname][0::2]) * 1e-6 if len(bigdur[kname]) > 1 else mean(dur[kname]) * 1e-6
 # counter passes serialise the kernels (no overlap between the engine's lanes): take that pass's own duration for rates
 def pass_t(sub):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e9 for r in sorted(load(sub, "kernel_trace"), key=lambda r: int(r["Start_Timestamp"]))
