@@ -909,6 +909,7 @@ struct lamd_ctx {
   bool timing = false;
   bool ev_recorded = false;
   int ecmult_waves = 3;
+  unsigned keyed_lds_pad = 0;      // LAMD_KEYED_LDS_PAD: dynamic LDS bytes requested by the table-driven ecmult launches (occupancy limiter: 65536 = two blocks per CU)
   int keyed_waves = 3;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3: no spill; 4: a 5-dword spill, measured 60 % slower)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
   size_t prep_min_threads = 0;  // LAMD_PREP_MIN_THREADS: fewest prep threads of a large batch (0 = 256 per CU)
@@ -1035,6 +1036,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->gtable = root->gtable;
     L->ecmult_waves = root->ecmult_waves;
     L->keyed_waves = root->keyed_waves;
+    L->keyed_lds_pad = root->keyed_lds_pad;
     L->prep_batch = root->prep_batch;
     L->prep_min_threads = root->prep_min_threads;
     L->hash_seed = root->hash_seed;
@@ -1085,6 +1087,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   }
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
+  if (const char *w = getenv("LAMD_KEYED_LDS_PAD")) ctx->keyed_lds_pad = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
   {
@@ -1532,10 +1535,10 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   auto fast10 = ctx->keyed_waves == 3 ? k_ecmult_keyed<10, false, 3> : k_ecmult_keyed<10, false, 4>;
   const bool run7 = thr7 != 0xFFFFFFFFu || use_cache, run10 = thr10 != 0xFFFFFFFFu || use_cache;
   if (run7)
-    hipLaunchKernelGGL(fast7, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs, (const u32 *)row_ent, ents,
+    hipLaunchKernelGGL(fast7, dim3(blocks_for(n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs, (const u32 *)row_ent, ents,
                        (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
   if (run10)
-    hipLaunchKernelGGL(fast10, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs, (const u32 *)row_ent, ents,
+    hipLaunchKernelGGL(fast10, dim3(blocks_for(n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs, (const u32 *)row_ent, ents,
                        (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
   if (run7)

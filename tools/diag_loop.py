@@ -15,6 +15,7 @@ from lightning_amd import Engine, workload  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+idle = Engine(0) if os.environ.get('DIAG_IDLE_ENGINE') == '1' else None
 with Engine(0) as eng:
     we = workload.make_ecdsa(eng, n, seed=workload.SEED_CFG2, nkeys=65536, publen=65)
     ws = workload.make_schnorr(eng, n, seed=workload.SEED_CFG3, nkeys=65536)
@@ -29,7 +30,10 @@ with Engine(0) as eng:
         eng.set_timing(True)
     tstream = torch.cuda.current_stream().cuda_stream
     eng.auto_order = False
+    import time
     for rep in range(3):
+        torch.cuda.synchronize(); eng.synchronize()
+        t0 = time.perf_counter()
         for k in range(steps):
             if poison and k == steps - 1:
                 oke[k].fill_(7); oks[k].fill_(7)
@@ -38,6 +42,7 @@ with Engine(0) as eng:
             eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], oks[k])
         eng.synchronize()
         torch.cuda.synchronize()
+        print("rep %d: %.3f ms per step, %.1f M verifies/s" % (rep, (time.perf_counter() - t0) / steps * 1e3, 2 * n * steps / (time.perf_counter() - t0) / 1e6), flush=True)
         for k in (range(steps) if not shared else [steps - 1]):
             for kind, w, ok in (("ecdsa", we, oke[k]), ("schnorr", ws, oks[k])):
                 got = ok.cpu().numpy()
