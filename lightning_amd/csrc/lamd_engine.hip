@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(256) k_gen_ecdsa(size_t n, u64 seed, u64 nkeys
   gmul_affine(rx, ry, k, gtable);
   const sc r = sc_from_words(rx, nullptr);
   const sc z = sc_from_words(zw, nullptr);
-  sc s = sc_mul(sc_inv(k), sc_add_mod(z, sc_mul(r, d)));
+  sc s = sc_mul(sc_inv_var(k), sc_add_mod(z, sc_mul(r, d)));
   if (sc_is_high(s)) s = sc_neg(s);
   store_words_be(hash32 + 32 * i, zw);
   store_words_be(sig64 + 64 * i, r.w);
@@ -418,7 +418,7 @@ LAMD_HD void sign_ecdsa_words(u32 rw[8], u32 sw[8], const u32 zw[8], const sc &d
   gmul_affine(rx, ry, k, gtable);
   const sc r = sc_from_words(rx, nullptr);
   const sc z = sc_from_words(zw, nullptr);
-  sc s = sc_mul(sc_inv(k), sc_add_mod(z, sc_mul(r, d)));
+  sc s = sc_mul(sc_inv_var(k), sc_add_mod(z, sc_mul(r, d)));
   if (sc_is_high(s)) s = sc_neg(s);
 #pragma unroll
   for (int i = 0; i < 8; i++) { rw[i] = r.w[i]; sw[i] = s.w[i]; }
@@ -551,7 +551,7 @@ constexpr u32 ENT_NONE = 0xFFFFFFFFu;
 enum { C_ENT = 0, C_USED7 = 1, C_USED10 = 2, C_WORDS = 4 };  // cache counters
 // per-call counters ("plan"): everything the host used to read back to size the next launches now stays on the device;
 // launches cover upper bounds and the kernels take their real extent from here
-enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_WORDS = 16 };
+enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_DENSE = 8, P_WORDS = 16 };
 constexpr u8 VERDICT_SUSPECT = 3;  // the bare-formula ecmult met Z = 0: the complete form decides (k_ecmult_keyed_careful)
 
 LAMD_HD void key_words(u32 kw[17], const u8 *p, int len) {
@@ -836,6 +836,53 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, int whic
   }
   out[i] = ok ? 1 : 0;
 }
+// ---- small batches with a key-table cache: one kernel probes the cache for every row and writes the three row lists straight
+// away (cached 7-tooth comb / cached 10-tooth comb / ladder) -- no de-duplication, no table building, so a commitment_signed
+// whose htlc key is cached costs a dozen launches instead of the two dozen of the partitioning path.  Nothing is inserted here;
+// rows whose key missed but equals their neighbour's (a dense batch under a new key) are counted in plan[P_DENSE], and the host
+// sends the NEXT small batch through the table-building path when that count is high.  (One kernel that also ran the comb or
+// the ladder itself was tried: 248 VGPRs and 208 bytes of scratch made it slower than the separate kernels.)
+__global__ void __launch_bounds__(64) k_small_lookup(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride, u64 seed, const u32 *index, u32 mask,
+                                                     const cache_ent *ents, cache_vis vis, u32 *__restrict__ row_ent, u32 *__restrict__ plan,
+                                                     u32 *__restrict__ list7, u32 *__restrict__ list10, u32 *__restrict__ listcold,
+                                                     u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  u32 found = ENT_NONE, T = 255, hash = 0;
+  if (live) {
+    u32 kw[17];
+    key_words(kw, keys + stride * i, keylen);
+    hash = (u32)key_words_hash(kw, seed);
+    u32 slot = hash & mask;
+    for (int probe = 0; probe < 64; probe++) {
+      const u32 id = index[slot];
+      if (id == 0u) break;
+      const cache_ent *e = ents + (id - 1u);
+      const u32 seq = e->seq, meta = e->meta;
+      if (seq != 0u && seq <= vis.seq[(meta >> 8) & 15u]) {
+        bool same = true;
+#pragma unroll 1
+        for (int w = 0; w < 17; w++) same &= e->kw[w] == kw[w];
+        if (same) { found = id - 1u; T = meta & 0xFFu; break; }
+      }
+      slot = (slot + 1u) & mask;
+    }
+    row_ent[i] = found;
+  }
+  const u32 lane = threadIdx.x & 63u;
+  const u32 prev = __shfl_up(hash, 1, 64);
+  const bool miss = live && found == ENT_NONE;
+  const u32 p7 = wave_alloc(&plan[P_L7], T == 7u), p10 = wave_alloc(&plan[P_L10], T == 10u), pc = wave_alloc(&plan[P_COLD], miss);
+  (void)wave_alloc(&plan[P_HITS], live && found != ENT_NONE);
+  (void)wave_alloc(&plan[P_DENSE], miss && lane > 0 && prev == hash);
+  if (T == 7u) list7[p7] = (u32)i;
+  else if (T == 10u) list10[p10] = (u32)i;
+  else if (miss) listcold[pc] = (u32)i;
+  else if (live) {  // T == 0: a key that is known not to parse
+    out[i] = 0;
+    if (keyok_row) keyok_row[i] = 0;
+  }
+}
 __global__ void __launch_bounds__(256) k_schnorr_final_fin(size_t n, u32 *__restrict__ fin, u8 *__restrict__ out) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -897,6 +944,9 @@ struct lamd_ctx {
   hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr;
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
+  bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
+  bool last_small_fused = false;  // the previous small batch of this lane ran k_ecmult_small (its plan holds P_DENSE)
+  size_t last_small_n = 0;
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
   double keyed_dense_uses = 48.0;  // ... and for the 10-tooth comb (512 entries per key)
   int keyed_teeth = 0;             // 0 = choose by re-use, 7 or 10 = force that comb (LAMD_KEYED_TEETH)
@@ -1043,6 +1093,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->chunk = root->chunk;
     L->keyed_mode = root->keyed_mode;
     L->keyed_min_rows = root->keyed_min_rows;
+    L->small_fused = root->small_fused;
     L->keyed_min_uses = root->keyed_min_uses;
     L->keyed_dense_uses = root->keyed_dense_uses;
     L->keyed_teeth = root->keyed_teeth;
@@ -1100,6 +1151,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_DENSE_USES")) ctx->keyed_dense_uses = atof(w);
   if (const char *w = getenv("LAMD_KEYED_TEETH")) ctx->keyed_teeth = atoi(w) == 7 ? 7 : (atoi(w) == 10 ? 10 : 0);
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
+  if (const char *w = getenv("LAMD_SMALL_FUSED")) ctx->small_fused = atoi(w) != 0;
   if (const char *w = getenv("LAMD_CACHE")) ctx->cache_mode = atoi(w) != 0;
   if (const char *w = getenv("LAMD_CACHE_KEYS")) ctx->cache_keys = (size_t)atoll(w) < 64 ? 64 : (size_t)atoll(w);
   if (const char *w = getenv("LAMD_CACHE_KEYS10")) ctx->cache_keys10 = (size_t)atoll(w) < 16 ? 16 : (size_t)atoll(w);
@@ -1417,16 +1469,90 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     return LAMD_OK;
   }
 
+  // small batch with a cache: lookup straight into the row lists (k_small_lookup), cached combs + ladder -- unless the previous
+  // small batch on this lane reported a dense run of rows under a key the cache does not know: then this one takes the
+  // table-building path below and publishes it
+  if (small && use_cache && ctx->small_fused) {
+    const u32 dense_thr = ctx->last_small_n / 8 > 32 ? (u32)(ctx->last_small_n / 8) : 32u;
+    const bool learn = ctx->last_small_fused && ctx->h_plan && ((volatile const u32 *)ctx->h_plan)[P_DENSE] >= dense_thr;
+    ctx->last_small_fused = !learn;
+    ctx->last_small_n = n;
+    if (!learn) {
+      lamd_ctx::key_cache *kcs = &root->cache_store;
+      for (devbuf *b : {&ctx->row_ent, &ctx->list7, &ctx->list10, &ctx->listcold})
+        if ((rc = ensure(ctx, b, n * 4)) != LAMD_OK) return rc;
+      if ((rc = ensure(ctx, &ctx->plan, P_WORDS * 4)) != LAMD_OK) return rc;
+      if (mode == MODE_SCHNORR && (rc = ensure(ctx, &ctx->kt_fin, n * (size_t)FIN_WORDS * 4)) != LAMD_OK) return rc;
+      u32 *plan_s = (u32 *)ctx->plan.p, *fin_s = mode == MODE_SCHNORR ? (u32 *)ctx->kt_fin.p : nullptr;
+      HIPCHK(ctx, hipMemsetAsync(plan_s, 0, P_WORDS * 4, ctx->stream));
+      for (int l = 0; l <= MAX_LANES; l++)
+        if (root->pub_pending[l] && hipEventQuery(root->ev_pub[l]) == hipSuccess) {
+          root->vis_seq[l] = root->pub_seq[l];
+          root->pub_pending[l] = false;
+        }
+      (void)hipGetLastError();
+      cache_vis vis;
+      for (int l = 0; l <= MAX_LANES; l++) vis.seq[l] = root->vis_seq[l];
+      vis.seq[ctx->lane_id] = root->pub_seq[ctx->lane_id];
+      hipLaunchKernelGGL(k_small_lookup, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                         (const u32 *)kcs->index.p, kcs->index_mask, (const cache_ent *)kcs->ents.p, vis, (u32 *)ctx->row_ent.p, plan_s, (u32 *)ctx->list7.p,
+                         (u32 *)ctx->list10.p, (u32 *)ctx->listcold.p, keyok_out, d_ok);
+      if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+      // the ladder for the misses (parses their keys first) on the third stream, the cached combs on this one: one uncached row
+      // (a commitment's funding-key signature) costs a whole ladder latency and must not sit in front of the other 483
+      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+      {
+        hipStream_t main = ctx->stream;
+        ctx->stream = ctx->stream3;
+        rc = launch_direct(ctx, mode, n, (const u32 *)ctx->listcold.p, (const u32 *)(plan_s + P_COLD), recs, d_sig, d_key, keylen, keystride, fin_s, keyok_out,
+                           d_ok, false);
+        ctx->stream = main;
+        if (rc != LAMD_OK) return rc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
+      }
+      if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+      hipLaunchKernelGGL((k_ecmult_keyed<7, false, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
+                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
+                         keyok_out, d_ok);
+      hipLaunchKernelGGL((k_ecmult_keyed<10, false, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
+                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
+                         keyok_out, d_ok);
+      hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
+                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
+                         keyok_out, d_ok);
+      hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
+                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
+                         keyok_out, d_ok);
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
+      if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+      if (mode == MODE_SCHNORR)
+        hipLaunchKernelGGL(k_schnorr_final_fin, dim3(blocks_for(final_threads(ctx, n))), dim3(256), 0, ctx->stream, n, fin_s, d_ok);
+      HIPCHK(ctx, hipMemcpyAsync(d_ok_caller, d_ok, n, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_plan, plan_s, P_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (time_it) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        ctx->ev_recorded = true;
+      }
+      HIPCHK(ctx, hipGetLastError());
+      return LAMD_OK;
+    }
+  }
+
   // thresholds: rows per key that pay for a 7-tooth / a 10-tooth comb
   u32 thr7 = ctx->keyed_mode > 0 ? 2u : (u32)(ctx->keyed_min_uses + 0.5), thr10 = (u32)(ctx->keyed_dense_uses + 0.5);
   if (ctx->keyed_teeth == 7) thr10 = 0xFFFFFFFFu;
   if (ctx->keyed_teeth == 10) { thr10 = thr7; thr7 = 0xFFFFFFFFu; }
-  if (small) {  // only a key that carries a large share of a small batch
-    thr7 = 0xFFFFFFFFu;
-    if (ctx->keyed_teeth != 7) thr10 = (u32)(ctx->keyed_dense_uses + 0.5);
-  }
   if (thr7 < 2) thr7 = 2;
   if (thr10 < 2) thr10 = 2;
+  if (small) {
+    // without a cache: only a key that carries a large share of the batch is worth a table.  With one we are here because the
+    // previous small batch saw a dense run under an unknown key (a channel's htlc key): that key gets the 10-tooth comb and every
+    // other key the batch misses -- the funding key, one signature per commitment but the same one every time -- a 7-tooth comb
+    thr7 = use_cache && ctx->small_fused && ctx->keyed_teeth != 10 ? 1u : 0xFFFFFFFFu;
+    if (ctx->keyed_teeth != 7) thr10 = (u32)(ctx->keyed_dense_uses + 0.5);
+  }
   const size_t hk7_cap = thr7 == 0xFFFFFFFFu ? 1 : n / thr7 + 1, hk10_cap = thr10 == 0xFFFFFFFFu ? 1 : n / thr10 + 1;
   lamd_ctx::key_cache *kc = use_cache ? &root->cache_store : &ctx->cache_store;
   if (!use_cache && (rc = cache_alloc(ctx, kc, hk7_cap, hk10_cap, false)) != LAMD_OK) return rc;

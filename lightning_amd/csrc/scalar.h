@@ -329,6 +329,143 @@ LAMD_HD sc29 sc29_inv(const sc29 &a) {
   return t;
 }
 
+// ---- Modular inversion by division steps (Bernstein-Yang "safegcd", the variable-time form: signatures are public).
+// (delta, f, g) -> g odd and delta > 0: (1 - delta, g, (g - f) / 2); else (1 + delta, f, (g + (g & 1) * f) / 2), starting from
+// (1, n, a).  Thirty steps at a time only look at the low 32 bits and yield a 2x2 integer matrix t with
+// 2^30 * (f', g') = t * (f, g); the 256-bit values are then updated once per batch in signed 30-bit limbs, and so is the pair
+// (d, e) with d * a = f, e * a = g (mod n), whose division by 2^30 is made exact by adding a multiple of n.  When g reaches 0,
+// f = +-1 and a^-1 = +-d.  <= 19 batches on every input tried (bound: 724 steps = 25 batches); ~10^4 instructions against ~1.2 * 10^5
+// for the exponentiation a^(n-2) -- the scalar inversion was what a small batch waited for (0.3 ms of its 0.55).
+struct s30 { int32_t v[9]; };  // limbs 0..7 in [0, 2^30), limb 8 signed
+#define LAMD_S30_N {0x10364141, 0x3F497A33, 0x348A03BB, 0x2BB739AB, 0x3FFFFEBA, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0xFFFF}
+constexpr u32 S30_NINV = 0x2A774EC1u;  // n^-1 mod 2^30
+struct s30_mat { int32_t u, v, q, r; };
+LAMD_HD void s30_update_fg(s30 &f, s30 &g, const s30_mat &t) {
+  const int64_t M = (1 << 30) - 1;
+  int64_t cf = (int64_t)t.u * f.v[0] + (int64_t)t.v * g.v[0], cg = (int64_t)t.q * f.v[0] + (int64_t)t.r * g.v[0];
+  LAMD_ASSERT((cf & M) == 0 && (cg & M) == 0);
+  cf >>= 30; cg >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+    cf += (int64_t)t.u * f.v[i] + (int64_t)t.v * g.v[i];
+    cg += (int64_t)t.q * f.v[i] + (int64_t)t.r * g.v[i];
+    f.v[i - 1] = (int32_t)(cf & M); cf >>= 30;
+    g.v[i - 1] = (int32_t)(cg & M); cg >>= 30;
+  }
+  f.v[8] = (int32_t)cf;
+  g.v[8] = (int32_t)cg;
+}
+LAMD_HD void s30_update_de(s30 &d, s30 &e, const s30_mat &t) {
+  const int32_t nl[9] = LAMD_S30_N;
+  const int64_t M = (1 << 30) - 1;
+  int64_t cd = (int64_t)t.u * d.v[0] + (int64_t)t.v * e.v[0], ce = (int64_t)t.q * d.v[0] + (int64_t)t.r * e.v[0];
+  const int64_t md = (int64_t)((0u - (u32)(cd & M)) * S30_NINV & (u32)M), me = (int64_t)((0u - (u32)(ce & M)) * S30_NINV & (u32)M);
+  cd += md * nl[0]; ce += me * nl[0];
+  LAMD_ASSERT((cd & M) == 0 && (ce & M) == 0);
+  cd >>= 30; ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+    cd += (int64_t)t.u * d.v[i] + (int64_t)t.v * e.v[i] + md * nl[i];
+    ce += (int64_t)t.q * d.v[i] + (int64_t)t.r * e.v[i] + me * nl[i];
+    d.v[i - 1] = (int32_t)(cd & M); cd >>= 30;
+    e.v[i - 1] = (int32_t)(ce & M); ce >>= 30;
+  }
+  d.v[8] = (int32_t)cd;
+  e.v[8] = (int32_t)ce;
+}
+// a in [0, n) -> a^-1 mod n (0 -> 0)
+LAMD_HD sc sc_inv_var(const sc &a) {
+  const int32_t nl[9] = LAMD_S30_N;
+  s30 f, g, d, e;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { f.v[i] = nl[i]; d.v[i] = 0; e.v[i] = i == 0; }
+  {  // 256 bits -> 9 x 30
+    const u32 *w = a.w;
+    g.v[0] = (int32_t)(w[0] & 0x3FFFFFFFu);
+    g.v[1] = (int32_t)(((w[0] >> 30) | (w[1] << 2)) & 0x3FFFFFFFu);
+    g.v[2] = (int32_t)(((w[1] >> 28) | (w[2] << 4)) & 0x3FFFFFFFu);
+    g.v[3] = (int32_t)(((w[2] >> 26) | (w[3] << 6)) & 0x3FFFFFFFu);
+    g.v[4] = (int32_t)(((w[3] >> 24) | (w[4] << 8)) & 0x3FFFFFFFu);
+    g.v[5] = (int32_t)(((w[4] >> 22) | (w[5] << 10)) & 0x3FFFFFFFu);
+    g.v[6] = (int32_t)(((w[5] >> 20) | (w[6] << 12)) & 0x3FFFFFFFu);
+    g.v[7] = (int32_t)(((w[6] >> 18) | (w[7] << 14)) & 0x3FFFFFFFu);
+    g.v[8] = (int32_t)(w[7] >> 16);
+  }
+  int32_t delta = 1;
+#pragma unroll 1
+  for (int batch = 0; batch < 25; batch++) {
+    int32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) nz |= g.v[i];
+    if (nz == 0) break;
+    u32 fl = (u32)f.v[0] | ((u32)f.v[1] << 30), gl = (u32)g.v[0] | ((u32)g.v[1] << 30);
+    s30_mat t = {1, 0, 0, 1};
+#pragma unroll 1
+    for (int i = 0; i < 30; i++) {
+      const bool odd = gl & 1u;
+      u32 x = fl;
+      int32_t y = t.u, z = t.v;
+      if (odd && delta > 0) {
+        fl = gl; t.u = t.q; t.v = t.r;
+        x = 0u - x; y = -y; z = -z;
+        delta = -delta;
+      }
+      if (odd) { gl += x; t.q += y; t.r += z; }
+      gl >>= 1;
+      t.u *= 2; t.v *= 2;
+      delta += 1;
+    }
+    s30_update_fg(f, g, t);
+    s30_update_de(d, e, t);
+  }
+  // f = +-1: the inverse is +-d; d may be negative or exceed n by a few multiples: + 32 n, then reduce as any 262-bit value
+  const bool neg = f.v[8] < 0;
+  const u32 nw[8] = LAMD_SC_N;
+  // t = (neg ? -d : d) as a signed 270-bit integer in 32-bit words, plus 32 * n
+  int64_t c = 0;
+  u32 limb[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    c += neg ? -(int64_t)d.v[i] : (int64_t)d.v[i];
+    limb[i] = (u32)(c & 0x3FFFFFFF);
+    c >>= 30;
+  }
+  // limb[0..8] (30 bits each) + c * 2^270 is the two's-complement value; c is 0 or -1
+  u32 w[9];
+  w[0] = limb[0] | (limb[1] << 30);
+  w[1] = (limb[1] >> 2) | (limb[2] << 28);
+  w[2] = (limb[2] >> 4) | (limb[3] << 26);
+  w[3] = (limb[3] >> 6) | (limb[4] << 24);
+  w[4] = (limb[4] >> 8) | (limb[5] << 22);
+  w[5] = (limb[5] >> 10) | (limb[6] << 20);
+  w[6] = (limb[6] >> 12) | (limb[7] << 18);
+  w[7] = (limb[7] >> 14) | (limb[8] << 16);
+  w[8] = (limb[8] >> 16) | ((u32)c << 14);   // sign-extended top word
+  // + 32 n  (n << 5), modulo 2^288: the sum is in [0, 64 n)
+  u64 cy = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const u32 ni = i < 8 ? ((nw[i] << 5) | (i ? nw[i - 1] >> 27 : 0u)) : (nw[7] >> 27);
+    cy += (u64)w[i] + ni;
+    w[i] = (u32)cy;
+    cy >>= 32;
+  }
+  const u32 nc[5] = LAMD_SC_NC;
+  u32 q = w[8];  // < 64
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    u64 k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      k += (u64)w[i] + (i < 5 ? (u64)q * nc[i] : 0u);
+      w[i] = (u32)k;
+      k >>= 32;
+    }
+    q = (u32)k;
+  }
+  return sc_from_words(w, nullptr);
+}
+
 // ---- GLV endomorphism split: k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128.
 // Lattice basis (a1, b1), (a2, b2) of {(x, y): x + y*lambda = 0 mod n}; g1 = round(2^384*b2/n),
 // g2 = round(2^384*(-b1)/n); c1 = round(k*g1 / 2^384), c2 = round(k*g2 / 2^384);

@@ -139,7 +139,7 @@ LAMD_HD void ecdsa_prep_thread(size_t first, size_t stride, size_t n, const u8 *
     any = true;
   }
   if (!any) return;
-  sc29 inv = sc29_inv(acc);
+  sc29 inv = sc29_from_sc(sc_inv_var(sc29_to_sc(acc)));  // division steps: ~12x fewer instructions than a^(n-2)
 #pragma unroll 1
   for (size_t i = last;; i -= stride) {
     sc r, s;
@@ -1130,7 +1130,7 @@ LAMD_HD void grind_prepare(grind_setup *out, const u8 *sig64, const u8 *pub33, c
   }
   for (int i = 0; i < 8; i++) { g.mid[i] = st[i]; g.sinv[i] = g.rw[i] = g.px[i] = g.py[i] = 0; }
   if (ok) {
-    const sc sinv = sc_inv(s);
+    const sc sinv = sc_inv_var(s);
     const sc u2 = sc_mul(r, sinv);
     glv_half h1, h2;
     glv_split(&h1, &h2, u2);
@@ -1227,7 +1227,7 @@ LAMD_HD void recover_prep_thread(size_t first, size_t stride, size_t n, const u8
     any = true;
   }
   if (!any) return;
-  sc inv = sc_inv(acc);
+  sc inv = sc_inv_var(acc);
 #pragma unroll 1
   for (size_t i = last;; i -= stride) {
     sc r, s, prefix;

@@ -337,3 +337,4 @@ extern "C" void dm_sc29_chain(const u8 *a, const u8 *b, int steps, u8 *out) {  /
   const sc r = sc29_to_sc(q);
   words_to_be(out, r.w);
 }
+extern "C" void dm_sc_inv_var(const u8 *a, u8 *out) { sc x; be_to_words(x.w, a); sc r = sc_inv_var(x); words_to_be(out, r.w); }

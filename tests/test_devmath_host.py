@@ -661,3 +661,19 @@ def test_sc29_scalar_arithmetic_vs_integers(dm):
     for a in [1, 2, Nn - 1, Nn + 5, (1 << 256) - 1] + [rnd.getrandbits(256) for _ in range(40)]:
         dm.dm_sc29_inv(a.to_bytes(32, "big"), out)
         assert int.from_bytes(out.raw, "big") == pow(a % Nn, -1, Nn), hex(a)
+
+
+def test_sc_inv_var_division_steps_vs_integers(dm):
+    """the division-step (safegcd) inversion mod n that the scalar preparation uses: edge values, small and huge operands, 20 000 random
+    residues -- against pow(a, -1, n); 0 maps to 0"""
+    Nn = pyref.N
+    out = ctypes.create_string_buffer(32)
+    rnd = random.Random(590)
+    vals = [1, 2, 3, Nn - 1, Nn - 2, (Nn - 1) // 2, (Nn + 1) // 2, 1 << 255, (1 << 255) - 1, (1 << 128) - 1, 1 << 128, 0x14551231950B75FC4402DA1732FC9BEBF,
+            (1 << 256) - Nn, pow(2, -1, Nn), pow(3, -1, Nn)] + [1 << k for k in range(0, 256, 7)] + [Nn - (1 << k) for k in range(0, 255, 11)]
+    vals += [rnd.randrange(1, Nn) for _ in range(20_000)] + [rnd.randrange(1, 1 << rnd.randrange(1, 256)) for _ in range(2000)]
+    for a in vals:
+        dm.dm_sc_inv_var(a.to_bytes(32, "big"), out)
+        assert int.from_bytes(out.raw, "big") == pow(a, -1, Nn), hex(a)
+    dm.dm_sc_inv_var(bytes(32), out)
+    assert out.raw == bytes(32)

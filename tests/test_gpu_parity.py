@@ -930,3 +930,61 @@ def test_bolt12_signatures_device_front_end_vs_spec_model(eng):
     got = eng.bolt12_check_signature_batch(streams, b"invoice", b"signature", _rows(ks, 33), _rows(sigs, 64))
     assert [bool(g) for g in got] == exp
     assert 1000 < sum(exp) < 1450
+
+
+@pytest.mark.gpu
+def test_small_batches_with_a_cache_take_the_lookup_path(kat, orc):
+    """small batches on an engine with the key-table cache: ONE kernel probes the cache and runs the cached comb or, on a miss, the
+    ladder (k_ecmult_small).  Hits, misses, unparsable keys and damaged signatures in one batch; a commitment-shaped batch under a
+    NEW key is verified by the ladder first, makes the next call build and publish the table, and hits from the third call on;
+    degenerate rows under a cached key fall back to the complete formulas inside the kernel; BIP-340 the same way."""
+    from lightning_amd import Engine, workload
+    with Engine(0) as e:
+        assert e.info()["cache_enabled"]
+        big = workload.make_ecdsa(e, 40000, seed=777, nkeys=600, publen=33)           # 66 rows per key: cached combs
+        e.verify_ecdsa_device(big.dev[0], big.dev[1], big.dev[2], big.d_ok)
+        e.synchronize()
+        assert np.array_equal(big.d_ok.cpu().numpy().astype(bool), big.expect) and e.info()["last_new_tables"] > 500
+        e.verify_ecdsa_device(big.dev[0], big.dev[1], big.dev[2], big.d_ok)           # the host has now seen the publishing call complete
+        e.synchronize()
+        fresh = workload.make_ecdsa(e, 3000, seed=778, nkeys=1 << 40, publen=33)      # keys the cache has never seen
+        for n in (1, 7, 64, 65, 484, 3000):
+            sel = np.arange(n)
+            hs = np.concatenate([big.cols[0][sel], fresh.cols[0][sel]]); sg = np.concatenate([big.cols[1][sel], fresh.cols[1][sel]])
+            pk = np.concatenate([big.cols[2][sel], fresh.cols[2][sel]])
+            exp = np.concatenate([big.expect[sel], fresh.expect[sel]])
+            got = e.verify_ecdsa(hs, sg, pk)
+            assert np.array_equal(got, exp), n
+            assert np.array_equal(got, orc.ecdsa_verify_batch(hs, sg, pk, 33, 2).astype(bool))
+            inf = e.info()
+            assert inf["last_cache_hits"] >= int(0.9 * n) and inf["last_new_tables"] == 0 and inf["last_cold_rows"] >= int(0.9 * n), (n, inf)
+        # a commitment under a new htlc key: ladder, then the table-building path, then cache hits
+        st = workload.make_commit_storm(e, 4, seed=4242)["ecdsa"]
+        hh, ss, pp = [np.ascontiguousarray(x[484:968]) for x in st.cols]
+        seen = []
+        for call in range(4):
+            got = e.verify_ecdsa(hh, ss, pp)
+            assert np.array_equal(got, st.expect[484:968]), call
+            inf = e.info()
+            seen.append((inf["last_cache_hits"], inf["last_new_tables"]))
+        assert seen[0] == (0, 0) and seen[1][1] == 2 and seen[2][0] == 484 and seen[3][0] == 484, seen      # the htlc key AND the funding key get tables
+        # degenerate rows (Z = 0 in the bare formulas) under cached keys
+        vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 130 and any(t in v["name"] for t in ("u1G==u2Q", "R=inf"))]
+        assert len(vs) >= 6
+        reps = 9000 // len(vs) + 1
+        hs, sg, pk = _rows([H(v["hash"]) for v in vs] * reps, 32), _rows([H(v["sig"]) for v in vs] * reps, 64), _rows([H(v["pub"]) for v in vs] * reps, 65)
+        assert [bool(g) for g in e.verify_ecdsa(hs, sg, pk)] == [v["expect"] for v in vs] * reps      # big: tables built and published
+        e.verify_ecdsa(hs, sg, pk)
+        got = e.verify_ecdsa(hs[:len(vs)], sg[:len(vs)], pk[:len(vs)])
+        assert [bool(g) for g in got] == [v["expect"] for v in vs] and e.info()["last_cache_hits"] == len(vs)
+        # BIP-340
+        sb = workload.make_schnorr(e, 30000, seed=779, nkeys=200)
+        e.verify_schnorr_device(sb.dev[0], sb.dev[1], sb.dev[2], sb.d_ok); e.synchronize()
+        e.verify_schnorr_device(sb.dev[0], sb.dev[1], sb.dev[2], sb.d_ok); e.synchronize()
+        sf = workload.make_schnorr(e, 500, seed=780, nkeys=1 << 40)
+        for n in (1, 100, 500):
+            ms = np.concatenate([sb.cols[0][:n], sf.cols[0][:n]]); ks = np.concatenate([sb.cols[1][:n], sf.cols[1][:n]]); ss2 = np.concatenate([sb.cols[2][:n], sf.cols[2][:n]])
+            got = e.verify_schnorr(ms, ks, ss2)
+            assert np.array_equal(got, np.concatenate([sb.expect[:n], sf.expect[:n]])), n
+            assert np.array_equal(got, orc.schnorr_verify_batch(ms, ks, ss2, 2).astype(bool))
+            assert e.info()["last_cache_hits"] >= int(0.9 * n)
