@@ -68,12 +68,15 @@ def test_product_never_touches_oracle():
 
 def test_generated_fe_asm_is_current():
     """lightning_amd/csrc/fe_asm.inc is generated: it must be exactly what tools/gen_fe_asm.py writes, and must hold the
-    multiply-add counts fe.h documents (97 per multiplication, 61 per squaring)"""
+    multiply-add counts fe.h documents (97 per multiplication, 61 per squaring, the fused forms)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.check_output([sys.executable, os.path.join(root, "tools", "gen_fe_asm.py")]).decode()
     cur = open(os.path.join(root, "lightning_amd", "csrc", "fe_asm.inc")).read()
     assert out == cur
-    mul, sqr = cur.split("#define LAMD_FE_SQR_ASM")[0], cur.split("#define LAMD_FE_SQR_ASM")[1]
-    assert mul.count("v_mad_u64_u32 v[") == 97 and sqr.count("v_mad_u64_u32 v[") == 61
+    import re
+    secs = dict(re.findall(r"#define (LAMD_FE_\w+_ASM) \\\n((?:  \".*\n)+)", cur))
+    count = {k: v.count("v_mad_u64_u32 v[") for k, v in secs.items()}
+    # 81 + 16 fold (45 + 16 for a square); + 9 for an addend; two products share one fold
+    assert count == {"LAMD_FE_MUL_ASM": 97, "LAMD_FE_SQR_ASM": 61, "LAMD_FE_MULADD_ASM": 106, "LAMD_FE_SQRADD_ASM": 70, "LAMD_FE_MUL2_ASM": 178}, count
