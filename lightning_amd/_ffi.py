@@ -76,6 +76,15 @@ def load(build_if_needed=True):
     missing: there is no fallback implementation."""
     global _lib
     if _lib is None:
+        alt = os.environ.get("LAMD_LIB_PATH")   # experiments only (tools/variants/*.so built with other constants): same ABI, no fallback either
+        if alt:
+            L = ctypes.CDLL(alt)
+            for name, (res, args) in SYMBOLS.items():
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
+            _lib = L
+            return _lib
         if build_if_needed and os.path.exists("/opt/rocm/bin/hipcc"):
             _build.build()
         if not os.path.exists(_build.LIB):
