@@ -793,48 +793,52 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, int whic
                                                       const cache_ent *__restrict__ ents, const u32 *__restrict__ pool,
                                                       const u8 *__restrict__ sig64, int mode, const u32 *__restrict__ gtable,
                                                       u32 *__restrict__ fin, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
-  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= plan[which]) return;
+  // grid-stride over the list: the launch covers at most a few blocks per CU (the list's length is only known on the device, and a
+  // launch sized for the whole batch costs 20-170 us of block dispatch even when its list is empty -- four such launches per call)
   if (CAREFUL && plan[P_SUSPECT] == 0) return;
-  const size_t i = list[j];
-  if (CAREFUL && out[i] != VERDICT_SUSPECT) return;
-  prep_rec rec;
-  {
-    const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
-    const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
-    rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
-    rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
-    rec.k1[0] = c.x; rec.k1[1] = c.y; rec.k1[2] = c.z; rec.k1[3] = c.w;
-    rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
-    rec.flags = e.x;
-  }
-  const cache_ent *ce = ents + row_ent[i];
-  const u32 *tab = pool + (size_t)ce->tabslot * kc_stride(T);
-  if (!CAREFUL && keyok_row) keyok_row[i] = 1;  // rows on these lists have a parsed key (the others were rejected by lookup / partition)
-  bool ok = (rec.flags & PREP_VALID) != 0;
-  if (ok) {
-    gej R;
-    if (CAREFUL) {
-      R = ecmult_lane_keyed<T>(rec, tab, gtable);
-    } else {
-      bool suspect;
-      R = ecmult_lane_keyed_fast<T>(rec, tab, gtable, &suspect);
-      if (suspect) {
-        out[i] = VERDICT_SUSPECT;
-        atomicAdd(&plan[P_SUSPECT], 1u);
-        return;
+  const size_t total = plan[which], stride = (size_t)gridDim.x * blockDim.x;
+#pragma unroll 1
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+    const size_t i = list[j];
+    if (CAREFUL && out[i] != VERDICT_SUSPECT) continue;
+    prep_rec rec;
+    {
+      const uint4 *src = reinterpret_cast<const uint4 *>(recs + i);
+      const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+      rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
+      rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
+      rec.k1[0] = c.x; rec.k1[1] = c.y; rec.k1[2] = c.z; rec.k1[3] = c.w;
+      rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
+      rec.flags = e.x;
+    }
+    const cache_ent *ce = ents + row_ent[i];
+    const u32 *tab = pool + (size_t)ce->tabslot * kc_stride(T);
+    if (!CAREFUL && keyok_row) keyok_row[i] = 1;  // rows on these lists have a parsed key (the others were rejected by lookup / partition)
+    bool ok = (rec.flags & PREP_VALID) != 0;
+    if (ok) {
+      gej R;
+      if (CAREFUL) {
+        R = ecmult_lane_keyed<T>(rec, tab, gtable);
+      } else {
+        bool suspect;
+        R = ecmult_lane_keyed_fast<T>(rec, tab, gtable, &suspect);
+        if (suspect) {
+          out[i] = VERDICT_SUSPECT;
+          atomicAdd(&plan[P_SUSPECT], 1u);
+          continue;
+        }
+      }
+      u32 rw[8];
+      load_words_be(rw, sig64 + 64 * i);
+      if (mode == MODE_ECDSA) {
+        ok = ecdsa_final(R, rw);
+      } else {
+        out[i] = schnorr_stage1(R, rw, fin + i * FIN_WORDS);
+        continue;
       }
     }
-    u32 rw[8];
-    load_words_be(rw, sig64 + 64 * i);
-    if (mode == MODE_ECDSA) {
-      ok = ecdsa_final(R, rw);
-    } else {
-      out[i] = schnorr_stage1(R, rw, fin + i * FIN_WORDS);
-      return;
-    }
+    out[i] = ok ? 1 : 0;
   }
-  out[i] = ok ? 1 : 0;
 }
 // ---- small batches with a key-table cache: one kernel probes the cache for every row and writes the three row lists straight
 // away (cached 7-tooth comb / cached 10-tooth comb / ladder) -- no de-duplication, no table building, so a commitment_signed
@@ -959,6 +963,8 @@ struct lamd_ctx {
   bool timing = false;
   bool ev_recorded = false;
   int ecmult_waves = 3;
+  unsigned keyed_blocks_per_cu = 0;  // LAMD_KEYED_BLOCKS_PER_CU: grid cap of the table-driven ecmult launches (0 = one thread per row: measured best -- a capped grid
+                                     // leaves a tail of partly filled iterations: 3.19 ms -> 3.9 ms at 4 blocks per CU)
   unsigned keyed_lds_pad = 0;      // LAMD_KEYED_LDS_PAD: dynamic LDS bytes requested by the table-driven ecmult launches (occupancy limiter: 65536 = two blocks per CU)
   int keyed_waves = 3;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3: no spill; 4: a 5-dword spill, measured 60 % slower)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
@@ -1037,6 +1043,18 @@ static void release(devbuf *b) {
 
 
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+// the complete-formula kernels only see rows the bare formulas flagged (crafted scalars): a few blocks walk the list -- unless the
+// lane's previous call reported many such rows (somebody is crafting them): then the launch covers the batch
+static unsigned careful_grid(const lamd_ctx *ctx, size_t n) {
+  const bool flood = ctx->h_plan && ((volatile const u32 *)ctx->h_plan)[P_SUSPECT] > 4096u;
+  return flood || blocks_for(n) < 64u ? blocks_for(n) : 64u;
+}
+
+// blocks of a table-driven ecmult launch (the kernels walk their list with a grid stride)
+static unsigned keyed_grid(const lamd_ctx *ctx, size_t n) {
+  const unsigned full = blocks_for(n), cap = (unsigned)ctx->prop.multiProcessorCount * ctx->keyed_blocks_per_cu;
+  return ctx->keyed_blocks_per_cu && cap < full ? cap : full;
+}
 
 // ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise.  The
 // engine uses up to 9 streams (root + two lanes, each with a prep and a cold-row side stream); with 4 queues one lane's prep
@@ -1087,6 +1105,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->ecmult_waves = root->ecmult_waves;
     L->keyed_waves = root->keyed_waves;
     L->keyed_lds_pad = root->keyed_lds_pad;
+    L->keyed_blocks_per_cu = root->keyed_blocks_per_cu;
     L->prep_batch = root->prep_batch;
     L->prep_min_threads = root->prep_min_threads;
     L->hash_seed = root->hash_seed;
@@ -1139,6 +1158,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
   if (const char *w = getenv("LAMD_KEYED_LDS_PAD")) ctx->keyed_lds_pad = (unsigned)atoi(w);
+  if (const char *w = getenv("LAMD_KEYED_BLOCKS_PER_CU")) ctx->keyed_blocks_per_cu = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
   {
@@ -1513,16 +1533,16 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
       }
       if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-      hipLaunchKernelGGL((k_ecmult_keyed<7, false, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
+      hipLaunchKernelGGL((k_ecmult_keyed<7, false, 3>), dim3(keyed_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
                          (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
                          keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<10, false, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
+      hipLaunchKernelGGL((k_ecmult_keyed<10, false, 3>), dim3(keyed_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
                          (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
                          keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
+      hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
                          (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
                          keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
+      hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
                          (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
                          keyok_out, d_ok);
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
@@ -1661,17 +1681,17 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   auto fast10 = ctx->keyed_waves == 3 ? k_ecmult_keyed<10, false, 3> : k_ecmult_keyed<10, false, 4>;
   const bool run7 = thr7 != 0xFFFFFFFFu || use_cache, run10 = thr10 != 0xFFFFFFFFu || use_cache;
   if (run7)
-    hipLaunchKernelGGL(fast7, dim3(blocks_for(n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs, (const u32 *)row_ent, ents,
+    hipLaunchKernelGGL(fast7, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs, (const u32 *)row_ent, ents,
                        (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
   if (run10)
-    hipLaunchKernelGGL(fast10, dim3(blocks_for(n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs, (const u32 *)row_ent, ents,
+    hipLaunchKernelGGL(fast10, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs, (const u32 *)row_ent, ents,
                        (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
   if (run7)
-    hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs,
+    hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs,
                        (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
   if (run10)
-    hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs,
+    hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs,
                        (const u32 *)row_ent, ents, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
