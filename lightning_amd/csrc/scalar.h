@@ -355,11 +355,10 @@ LAMD_HD void s30_update_fg(s30 &f, s30 &g, const s30_mat &t) {
   f.v[8] = (int32_t)cf;
   g.v[8] = (int32_t)cg;
 }
-LAMD_HD void s30_update_de(s30 &d, s30 &e, const s30_mat &t) {
-  const int32_t nl[9] = LAMD_S30_N;
+LAMD_HD void s30_update_de(s30 &d, s30 &e, const s30_mat &t, const int32_t nl[9], u32 ninv) {
   const int64_t M = (1 << 30) - 1;
   int64_t cd = (int64_t)t.u * d.v[0] + (int64_t)t.v * e.v[0], ce = (int64_t)t.q * d.v[0] + (int64_t)t.r * e.v[0];
-  const int64_t md = (int64_t)((0u - (u32)(cd & M)) * S30_NINV & (u32)M), me = (int64_t)((0u - (u32)(ce & M)) * S30_NINV & (u32)M);
+  const int64_t md = (int64_t)((0u - (u32)(cd & M)) * ninv & (u32)M), me = (int64_t)((0u - (u32)(ce & M)) * ninv & (u32)M);
   cd += md * nl[0]; ce += me * nl[0];
   LAMD_ASSERT((cd & M) == 0 && (ce & M) == 0);
   cd >>= 30; ce >>= 30;
@@ -373,24 +372,21 @@ LAMD_HD void s30_update_de(s30 &d, s30 &e, const s30_mat &t) {
   d.v[8] = (int32_t)cd;
   e.v[8] = (int32_t)ce;
 }
-// a in [0, n) -> a^-1 mod n (0 -> 0)
-LAMD_HD sc sc_inv_var(const sc &a) {
-  const int32_t nl[9] = LAMD_S30_N;
+// x with x * a = 1 (mod m) for an odd 256-bit modulus m (30-bit limbs ml, minv = m^-1 mod 2^30) and a in [0, m): a two's-complement
+// integer in (-26 m, 26 m), nine 32-bit words (a = 0 gives 0).  The caller adds a multiple of m and reduces.
+LAMD_HD void s30_inverse(u32 out[9], const u32 a[8], const int32_t ml[9], u32 minv) {
   s30 f, g, d, e;
 #pragma unroll
-  for (int i = 0; i < 9; i++) { f.v[i] = nl[i]; d.v[i] = 0; e.v[i] = i == 0; }
-  {  // 256 bits -> 9 x 30
-    const u32 *w = a.w;
-    g.v[0] = (int32_t)(w[0] & 0x3FFFFFFFu);
-    g.v[1] = (int32_t)(((w[0] >> 30) | (w[1] << 2)) & 0x3FFFFFFFu);
-    g.v[2] = (int32_t)(((w[1] >> 28) | (w[2] << 4)) & 0x3FFFFFFFu);
-    g.v[3] = (int32_t)(((w[2] >> 26) | (w[3] << 6)) & 0x3FFFFFFFu);
-    g.v[4] = (int32_t)(((w[3] >> 24) | (w[4] << 8)) & 0x3FFFFFFFu);
-    g.v[5] = (int32_t)(((w[4] >> 22) | (w[5] << 10)) & 0x3FFFFFFFu);
-    g.v[6] = (int32_t)(((w[5] >> 20) | (w[6] << 12)) & 0x3FFFFFFFu);
-    g.v[7] = (int32_t)(((w[6] >> 18) | (w[7] << 14)) & 0x3FFFFFFFu);
-    g.v[8] = (int32_t)(w[7] >> 16);
-  }
+  for (int i = 0; i < 9; i++) { f.v[i] = ml[i]; d.v[i] = 0; e.v[i] = i == 0; }
+  g.v[0] = (int32_t)(a[0] & 0x3FFFFFFFu);
+  g.v[1] = (int32_t)(((a[0] >> 30) | (a[1] << 2)) & 0x3FFFFFFFu);
+  g.v[2] = (int32_t)(((a[1] >> 28) | (a[2] << 4)) & 0x3FFFFFFFu);
+  g.v[3] = (int32_t)(((a[2] >> 26) | (a[3] << 6)) & 0x3FFFFFFFu);
+  g.v[4] = (int32_t)(((a[3] >> 24) | (a[4] << 8)) & 0x3FFFFFFFu);
+  g.v[5] = (int32_t)(((a[4] >> 22) | (a[5] << 10)) & 0x3FFFFFFFu);
+  g.v[6] = (int32_t)(((a[5] >> 20) | (a[6] << 12)) & 0x3FFFFFFFu);
+  g.v[7] = (int32_t)(((a[6] >> 18) | (a[7] << 14)) & 0x3FFFFFFFu);
+  g.v[8] = (int32_t)(a[7] >> 16);
   int32_t delta = 1;
 #pragma unroll 1
   for (int batch = 0; batch < 25; batch++) {
@@ -416,12 +412,10 @@ LAMD_HD sc sc_inv_var(const sc &a) {
       delta += 1;
     }
     s30_update_fg(f, g, t);
-    s30_update_de(d, e, t);
+    s30_update_de(d, e, t, ml, minv);
   }
-  // f = +-1: the inverse is +-d; d may be negative or exceed n by a few multiples: + 32 n, then reduce as any 262-bit value
+  // f = +-1: the inverse is +-d
   const bool neg = f.v[8] < 0;
-  const u32 nw[8] = LAMD_SC_N;
-  // t = (neg ? -d : d) as a signed 270-bit integer in 32-bit words, plus 32 * n
   int64_t c = 0;
   u32 limb[9];
 #pragma unroll
@@ -431,16 +425,22 @@ LAMD_HD sc sc_inv_var(const sc &a) {
     c >>= 30;
   }
   // limb[0..8] (30 bits each) + c * 2^270 is the two's-complement value; c is 0 or -1
+  out[0] = limb[0] | (limb[1] << 30);
+  out[1] = (limb[1] >> 2) | (limb[2] << 28);
+  out[2] = (limb[2] >> 4) | (limb[3] << 26);
+  out[3] = (limb[3] >> 6) | (limb[4] << 24);
+  out[4] = (limb[4] >> 8) | (limb[5] << 22);
+  out[5] = (limb[5] >> 10) | (limb[6] << 20);
+  out[6] = (limb[6] >> 12) | (limb[7] << 18);
+  out[7] = (limb[7] >> 14) | (limb[8] << 16);
+  out[8] = (limb[8] >> 16) | ((u32)c << 14);   // sign-extended top word
+}
+// a in [0, n) -> a^-1 mod n (0 -> 0)
+LAMD_HD sc sc_inv_var(const sc &a) {
+  const int32_t nl[9] = LAMD_S30_N;
   u32 w[9];
-  w[0] = limb[0] | (limb[1] << 30);
-  w[1] = (limb[1] >> 2) | (limb[2] << 28);
-  w[2] = (limb[2] >> 4) | (limb[3] << 26);
-  w[3] = (limb[3] >> 6) | (limb[4] << 24);
-  w[4] = (limb[4] >> 8) | (limb[5] << 22);
-  w[5] = (limb[5] >> 10) | (limb[6] << 20);
-  w[6] = (limb[6] >> 12) | (limb[7] << 18);
-  w[7] = (limb[7] >> 14) | (limb[8] << 16);
-  w[8] = (limb[8] >> 16) | ((u32)c << 14);   // sign-extended top word
+  s30_inverse(w, a.w, nl, S30_NINV);
+  const u32 nw[8] = LAMD_SC_N;
   // + 32 n  (n << 5), modulo 2^288: the sum is in [0, 64 n)
   u64 cy = 0;
 #pragma unroll

@@ -22,6 +22,44 @@ namespace lamd {
 
 enum { MODE_ECDSA = 0, MODE_SCHNORR = 1, MODE_RECOVER = 2 };
 
+// ---- field inversion by division steps (scalar.h s30_inverse with the modulus p): ~10^4 instructions against the 255 squarings +
+// 15 multiplications of fe_inv.  Used where ONE inversion is shared by a group of rows (BIP-340 parity stage, key recovery) or sits
+// on a small batch's latency path; variable time (public data).
+#define LAMD_S30_P {0x3FFFFC2F, 0x3FFFFFFB, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0x3FFFFFFF, 0xFFFF}
+LAMD_HD fe fe_inv_var(const fe &a) {
+  const int32_t pl[9] = LAMD_S30_P;
+  u32 aw[8], w[9];
+  fe_to_words(aw, fe_normalize(a));
+  s30_inverse(w, aw, pl, 0x2DDACACFu);  // p^-1 mod 2^30
+  // + 32 p = 2^261 - 2^37 - 32 * 977, modulo 2^288: the sum is in [0, 64 p)
+  const u32 p32[9] = {0xFFFF85E0u, 0xFFFFFFDFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x1Fu};
+  u64 cy = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    cy += (u64)w[i] + p32[i];
+    w[i] = (u32)cy;
+    cy >>= 32;
+  }
+  // fold the bits above 2^256 (2^256 = 2^32 + 977 mod p), twice: q < 64 first, then the carry of that addition
+  u32 q = w[8];
+#pragma unroll
+  for (int round = 0; round < 2; round++) {
+    u64 k = (u64)w[0] + (u64)q * 977u;
+    w[0] = (u32)k;
+    k = (k >> 32) + (u64)w[1] + q;
+    w[1] = (u32)k;
+    k >>= 32;
+#pragma unroll
+    for (int i = 2; i < 8; i++) {
+      k += w[i];
+      w[i] = (u32)k;
+      k >>= 32;
+    }
+    q = (u32)k;
+  }
+  return fe_from_words(w);  // any value below 2^256 is a magnitude-1 element
+}
+
 // ---- per-signature record produced by prep, consumed by ecmult (80 bytes, 16-byte aligned)
 struct prep_rec {
   u32 u1[8];   // scalar for G (little-endian words)
@@ -338,7 +376,7 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
     acc = gej_double(acc);
     acc = gej_add_ge(acc, b, ((d >> bit) & 1u) == 0);
   }
-  const fe zi = fe_inv(fe_norm_weak(acc.z));
+  const fe zi = fe_inv_var(acc.z);
   const fe zi2 = fe_sqr(zi);
   fe_to_words(out, fe_normalize(fe_mul(acc.x, zi2)));
   fe_to_words(out + 8, fe_normalize(fe_mul(acc.y, fe_mul(zi2, zi))));
@@ -820,7 +858,7 @@ LAMD_HD void schnorr_final_thread(size_t first, size_t stride, size_t n, u32 *sl
     any = true;
   }
   if (!any) return;
-  fe inv = fe_inv(acc);
+  fe inv = fe_inv_var(acc);
 #pragma unroll 1
   for (size_t i = last;; i -= stride) {
     if (out[i] == SCHNORR_PENDING) {
@@ -1142,7 +1180,7 @@ LAMD_HD void grind_prepare(grind_setup *out, const u8 *sig64, const u8 *pub33, c
     if (P.inf) {
       g.valid = 0;  // unreachable: r/s != 0 and Q has prime order
     } else {
-      const fe zi = fe_inv(fe_norm_weak(P.z)), zi2 = fe_sqr(zi);
+      const fe zi = fe_inv_var(P.z), zi2 = fe_sqr(zi);
       fe_to_words(g.px, fe_normalize(fe_mul(P.x, zi2)));
       fe_to_words(g.py, fe_normalize(fe_mul(P.y, fe_mul(zi2, zi))));
       for (int i = 0; i < 8; i++) { g.sinv[i] = sinv.w[i]; g.rw[i] = r.w[i]; }
@@ -1304,7 +1342,7 @@ LAMD_HD void recover_final_thread(size_t first, size_t stride, size_t n, u32 *sl
     acc = fe_mul(acc, slot_load_raw(slot + SLOT_REC_Z));
   }
   if (!any) return;
-  fe inv = fe_inv(acc);
+  fe inv = fe_inv_var(acc);
 #pragma unroll 1
   for (size_t i = last;; i -= stride) {
     u8 *key = pub33 + 33 * i;
@@ -1336,7 +1374,7 @@ LAMD_HD bool schnorr_final(const gej &R, const u32 rw[8]) {
   const fe z2 = fe_sqr(R.z);
   const fe rf = fe_from_words(rw);  // r < p checked in prep
   if (!fe_equal(fe_mul(rf, z2), R.x, 1)) return false;
-  const fe zi = fe_inv(fe_norm_weak(R.z));
+  const fe zi = fe_inv_var(R.z);
   const fe y = fe_normalize(fe_mul(R.y, fe_mul(fe_sqr(zi), zi)));
   return (y.n[0] & 1) == 0;
 }

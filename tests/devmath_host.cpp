@@ -338,3 +338,11 @@ extern "C" void dm_sc29_chain(const u8 *a, const u8 *b, int steps, u8 *out) {  /
   words_to_be(out, r.w);
 }
 extern "C" void dm_sc_inv_var(const u8 *a, u8 *out) { sc x; be_to_words(x.w, a); sc r = sc_inv_var(x); words_to_be(out, r.w); }
+extern "C" void dm_fe_inv_var(const u8 *a, u8 *out) {
+  u32 w[8];
+  be_to_words(w, a);
+  const fe r = fe_inv_var(fe_from_words(w));
+  u32 o[8];
+  fe_to_words(o, fe_normalize(r));
+  words_to_be(out, o);
+}

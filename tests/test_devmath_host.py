@@ -677,3 +677,20 @@ def test_sc_inv_var_division_steps_vs_integers(dm):
         assert int.from_bytes(out.raw, "big") == pow(a, -1, Nn), hex(a)
     dm.dm_sc_inv_var(bytes(32), out)
     assert out.raw == bytes(32)
+
+
+def test_fe_inv_var_division_steps_vs_integers(dm):
+    """the division-step inversion mod p (BIP-340 parity stage, key recovery, the G table build): edge values and 20 000 random
+    elements, non-canonical inputs (>= p) included -- against pow(a, -1, p)"""
+    Pp = pyref.P
+    out = ctypes.create_string_buffer(32)
+    rnd = random.Random(977)
+    vals = [1, 2, 3, Pp - 1, Pp - 2, (Pp - 1) // 2, 1 << 255, (1 << 255) - 1, 977, (1 << 32) + 977, Pp + 1, Pp + 5, (1 << 256) - 1]
+    vals += [1 << k for k in range(0, 256, 5)] + [Pp - (1 << k) for k in range(0, 255, 13)] + [rnd.getrandbits(256) for _ in range(20_000)]
+    for a in vals:
+        dm.dm_fe_inv_var(a.to_bytes(32, "big"), out)
+        assert int.from_bytes(out.raw, "big") == pow(a % Pp, -1, Pp), hex(a)
+    dm.dm_fe_inv_var(bytes(32), out)
+    assert out.raw == bytes(32)
+    dm.dm_fe_inv_var(Pp.to_bytes(32, "big"), out)
+    assert out.raw == bytes(32)
