@@ -69,23 +69,17 @@ constexpr int FIN_WORDS = 32;  // BIP-340 stage-1 parking space per row (Y, Z, p
 __global__ void __launch_bounds__(256) k_keys(size_t n, const u8 *__restrict__ pub, int publen, size_t stride,
                                               const u32 *__restrict__ idx, u32 *__restrict__ qwords, u8 *__restrict__ keyok,
                                               const u32 *__restrict__ count) {
-  // work items walk with a grid stride: a launch may cover fewer threads than items (the cold rows of a partitioned chunk are
-  // counted on the device; their launches are sized from the previous call's count)
-  size_t total = n;
-  if (count && *count < total) total = *count;
-  const size_t stride_t = (size_t)gridDim.x * blockDim.x;
-#pragma unroll 1
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride_t) {
-    const size_t row = idx ? idx[i] : i;
-    u32 qx[8], qy[8];
-    const bool ok = parse_pubkey(pub + stride * row, publen, qx, qy);
-    uint4 *dst = reinterpret_cast<uint4 *>(qwords + i * 16);
-    dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
-    dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
-    dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
-    dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
-    keyok[i] = ok;
-  }
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (count && i >= *count)) return;
+  const size_t row = idx ? idx[i] : i;
+  u32 qx[8], qy[8];
+  const bool ok = parse_pubkey(pub + stride * row, publen, qx, qy);
+  uint4 *dst = reinterpret_cast<uint4 *>(qwords + i * 16);
+  dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+  dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
+  dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
+  dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
+  keyok[i] = ok;
 }
 
 // ---- the hot kernel: R = u1*G + u2*Q and the acceptance test.  WAVES = minimum waves per SIMD the register
@@ -96,50 +90,43 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
                                                 const u32 *__restrict__ gtable, u32 *__restrict__ slots,
                                                 const u32 *__restrict__ idx, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
                                                 u8 *__restrict__ out, const u32 *__restrict__ count) {
-  // idx != nullptr (cold rows of a partitioned chunk): work item i verifies input row idx[i]; its key data live at position i,
-  // the prep record / signature / verdict / BIP-340 parking space (fin) at the row.  The table slot belongs to the THREAD: items
-  // walk with a grid stride (a launch may cover fewer threads than items); callers that park BIP-340 / recovery state in the
-  // slots (fin == nullptr) launch one thread per item, so that thread and item coincide.
-  size_t total = n;
-  if (count && *count < total) total = *count;
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride_t = (size_t)gridDim.x * blockDim.x;
-  u32 *slot = slots + tid * SLOT_WORDS;
-#pragma unroll 1
-  for (size_t i = tid; i < total; i += stride_t) {
-    const size_t row = idx ? idx[i] : i;
-    prep_rec rec;
-    {
-      const uint4 *src = reinterpret_cast<const uint4 *>(recs + row);
-      const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
-      rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
-      rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
-      rec.k1[0] = c.x; rec.k1[1] = c.y; rec.k1[2] = c.z; rec.k1[3] = c.w;
-      rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
-      rec.flags = e.x;
-    }
-    if (keyok_row) keyok_row[row] = keyok[i];
-    bool ok = (rec.flags & PREP_VALID) && keyok[i];
-    if (ok) {  // whole waves of rejected inputs skip the ladder (s_cbranch_execz)
-      u32 qx[8], qy[8];
-      const uint4 *src = reinterpret_cast<const uint4 *>(qwords + i * 16);
-      const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-      qx[0] = a.x; qx[1] = a.y; qx[2] = a.z; qx[3] = a.w; qx[4] = b.x; qx[5] = b.y; qx[6] = b.z; qx[7] = b.w;
-      qy[0] = c.x; qy[1] = c.y; qy[2] = c.z; qy[3] = c.w; qy[4] = d.x; qy[5] = d.y; qy[6] = d.z; qy[7] = d.w;
-      const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slot, gtable);
-      u32 rw[8];
-      load_words_be(rw, sig64 + 64 * row);
-      if (mode == MODE_ECDSA) {
-        ok = ecdsa_final(R, rw);
-      } else if (mode == MODE_RECOVER) {  // 0 or SCHNORR_PENDING with the Jacobian key parked in the slot (k_recover_final)
-        out[row] = recover_stage1(R, slot);
-        continue;
-      } else {  // 0 or SCHNORR_PENDING (parity decided by k_schnorr_final[_fin])
-        out[row] = schnorr_stage1(R, rw, fin ? fin + row * FIN_WORDS : slot);
-        continue;
-      }
-    }
-    out[row] = ok ? 1 : 0;
+  // idx != nullptr (cold rows of a partitioned chunk): work item i verifies input row idx[i]; key data and the table
+  // slot live at position i, the prep record / signature / verdict / BIP-340 parking space (fin) at the row
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (count && i >= *count)) return;
+  const size_t row = idx ? idx[i] : i;
+  prep_rec rec;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(recs + row);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    rec.u1[0] = a.x; rec.u1[1] = a.y; rec.u1[2] = a.z; rec.u1[3] = a.w;
+    rec.u1[4] = b.x; rec.u1[5] = b.y; rec.u1[6] = b.z; rec.u1[7] = b.w;
+    rec.k1[0] = c.x; rec.k1[1] = c.y; rec.k1[2] = c.z; rec.k1[3] = c.w;
+    rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
+    rec.flags = e.x;
   }
+  if (keyok_row) keyok_row[row] = keyok[i];
+  bool ok = (rec.flags & PREP_VALID) && keyok[i];
+  if (ok) {  // whole waves of rejected inputs skip the ladder (s_cbranch_execz)
+    u32 qx[8], qy[8];
+    const uint4 *src = reinterpret_cast<const uint4 *>(qwords + i * 16);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    qx[0] = a.x; qx[1] = a.y; qx[2] = a.z; qx[3] = a.w; qx[4] = b.x; qx[5] = b.y; qx[6] = b.z; qx[7] = b.w;
+    qy[0] = c.x; qy[1] = c.y; qy[2] = c.z; qy[3] = c.w; qy[4] = d.x; qy[5] = d.y; qy[6] = d.z; qy[7] = d.w;
+    const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slots + i * SLOT_WORDS, gtable);
+    u32 rw[8];
+    load_words_be(rw, sig64 + 64 * row);
+    if (mode == MODE_ECDSA) {
+      ok = ecdsa_final(R, rw);
+    } else if (mode == MODE_RECOVER) {  // 0 or SCHNORR_PENDING with the Jacobian key parked in the slot (k_recover_final)
+      out[row] = recover_stage1(R, slots + i * SLOT_WORDS);
+      return;
+    } else {  // 0 or SCHNORR_PENDING (parity decided by k_schnorr_final[_fin])
+      out[row] = schnorr_stage1(R, rw, fin ? fin + row * FIN_WORDS : slots + i * SLOT_WORDS);
+      return;
+    }
+  }
+  out[row] = ok ? 1 : 0;
 }
 
 // ---- BIP-340 stage 2: shared inversion for the y-parity test
@@ -962,8 +949,6 @@ struct lamd_ctx {
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
-  u32 cold_seen = 0;              // cold rows the previous partitioned call of this lane counted (sizes the next cold-row launches)
-  bool last_partitioned = false;
   bool last_small_fused = false;  // the previous small batch of this lane ran k_ecmult_small (its plan holds P_DENSE)
   size_t last_small_n = 0;
   double keyed_min_uses = 6.0;   // average signatures per distinct key that pays for a (comb) table
@@ -1088,15 +1073,9 @@ static int cache_reset(lamd_ctx *root);
 static int cache_maybe_reset(lamd_ctx *root);
 
 static int create_streams(lamd_ctx *ctx) {
-  // the side streams run short, latency-bound work (scalar prep; key parse + ladder of the few cold rows) beside a kernel that fills
-  // the chip: with equal priority their blocks queue behind the ecmult kernel's 3 900 (measured on an isolated 1 M-row call: the
-  // cold-row key parse took 2.7 ms and the call ended 1.9 ms after its main kernel), so they get the highest stream priority
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  const bool side_prio = !getenv("LAMD_SIDE_PRIORITY") || atoi(getenv("LAMD_SIDE_PRIORITY")) != 0;
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, side_prio ? prio_hi : prio_lo));
-  HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, side_prio ? prio_hi : prio_lo));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
@@ -1391,20 +1370,17 @@ static size_t final_threads(lamd_ctx *ctx, size_t n) {
 // real number of items is *count, on the device): keys -> ladder.  Prep records (indexed by row) must already be queued
 // on stream2 / finished (ev_prep).
 static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, const u32 *count, const prep_rec *recs, const u8 *d_sig,
-                         const u8 *d_key, int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it, size_t threads = 0) {
-  // threads: how many threads the two launches cover (0 = one per item).  Fewer is only allowed when the BIP-340 state is parked
-  // per row (fin != nullptr): the kernels then walk the items with a grid stride and the table slots belong to the threads.
-  if (threads == 0 || threads > m || (!fin && mode != MODE_ECDSA)) threads = m;
+                         const u8 *d_key, int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it) {
   int rc;
   if ((rc = ensure(ctx, &ctx->qwords, m * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->keyok, m)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->slots, (size_t)blocks_for(threads) * 256 * SLOT_WORDS * 4)) != LAMD_OK) return rc;
-  hipLaunchKernelGGL(k_keys, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, m, d_key, keylen, keystride, idx, (u32 *)ctx->qwords.p,
+  if ((rc = ensure(ctx, &ctx->slots, m * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_keys, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, d_key, keylen, keystride, idx, (u32 *)ctx->qwords.p,
                      (u8 *)ctx->keyok.p, count);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
   auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
-  hipLaunchKernelGGL(kern, dim3(blocks_for(threads)), dim3(256), 0, ctx->stream, m, recs, (const u32 *)ctx->qwords.p, (const u8 *)ctx->keyok.p, d_sig,
+  hipLaunchKernelGGL(kern, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, recs, (const u32 *)ctx->qwords.p, (const u8 *)ctx->keyok.p, d_sig,
                      mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, idx, fin, keyok_row, d_ok, count);
   return LAMD_OK;
 }
@@ -1692,14 +1668,8 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   {
     hipStream_t main = ctx->stream;
     ctx->stream = ctx->stream3;
-    // sized from what this lane's previous partitioned call counted (twice that, at least 16 384 threads): a launch over all n rows
-    // whose blocks nearly all exit at once still queues 3 900 blocks behind the table-driven kernel's (measured: 2.7 ms for the
-    // key parse of 13 000 cold rows, the call ending 1.9 ms after its main kernel)
-    if (ctx->h_plan && ctx->last_partitioned) ctx->cold_seen = ((volatile const u32 *)ctx->h_plan)[P_COLD];
-    const size_t cold_threads = (ctx->last_partitioned ? 2 * (size_t)ctx->cold_seen : n / 8) + 16384;
     rc = launch_direct(ctx, mode, n, (const u32 *)listcold, (const u32 *)(plan + P_COLD), recs, d_sig, d_key, keylen, keystride, fin, keyok_out,
-                       d_ok, false, mode == MODE_ECDSA || fin ? cold_threads : 0);
-    ctx->last_partitioned = true;
+                       d_ok, false);
     ctx->stream = main;
     if (rc != LAMD_OK) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
