@@ -409,6 +409,39 @@ def main():
             mism += int((got != cs.expect[:484]).sum() + (first != cs.expect[:484]).sum())
             lat["commitment_484_one_htlc_key"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
                                                   "cache_hits_last_call": int(eng.info()["last_cache_hits"])}
+        if world == 1:
+            # BASELINE configs[0]: the committed 1 024 triples (tests/golden/cfg1.bin), ONE call per
+            # signature through the reference's own prototype check_signed_hash(hash, sig, key) (bitcoin/signature.c:174-192)
+            # in the C++ mirror -- what an unmodified caller sees; ns per call as onchaind/test/run-grind_feerate.c reports
+            try:
+                import ctypes
+                from lightning_amd import _build
+                shim = ctypes.CDLL(_build.build_shim())
+                shim.lamd_shim_use_context.argtypes = [ctypes.c_void_p]
+                shim.lamd_shim_use_context(eng._ctx)
+                shim.check_signed_hash.restype = ctypes.c_bool
+                shim.fromwire_secp256k1_ecdsa_signature.restype = ctypes.c_bool
+                shim.pubkey_from_der.restype = ctypes.c_bool
+                blob = open(os.path.join(ROOT, "tests", "golden", "cfg1.bin"), "rb").read()
+                rows = [(blob[o:o + 32], blob[o + 32:o + 96], blob[o + 96:o + 129], bool(blob[o + 129])) for o in range(0, len(blob), 130)]
+                parsed = []
+                for h, s, p, e in rows:
+                    hh, sg, pk = ctypes.create_string_buffer(h, 32), ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+                    okp = bool(shim.fromwire_secp256k1_ecdsa_signature(s, sg)) and bool(shim.pubkey_from_der(p, 33, pk))
+                    parsed.append((hh, sg, pk, okp, e))
+                c1 = []
+                for rep in range(3):
+                    bad1 = 0
+                    t1 = time.perf_counter()
+                    for hh, sg, pk, okp, e in parsed:
+                        bad1 += (okp and bool(shim.check_signed_hash(hh, sg, pk))) != e
+                    c1.append(time.perf_counter() - t1)
+                lat["cfg1_one_by_one_check_signed_hash"] = {"rows": len(rows), "ns_per_call": min(c1) / len(rows) * 1e9, "mismatches": int(bad1),
+                                                            "note": "1 024 calls of one signature each through the shim's check_signed_hash (host structs in, bool out)"}
+                mism += int(bad1)
+                shim.lamd_shim_use_context(None)
+            except (OSError, FileNotFoundError) as e:
+                lat["cfg1_one_by_one_check_signed_hash"] = {"error": repr(e)}
         if lat:
             out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
         tp = []
@@ -419,6 +452,36 @@ def main():
         out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / min(tp[1:]), "first_call_verifies_per_s": n / tp[0], "rows": n,
                                  "note": "pageable host buffers in, verdicts out, one synchronous call (best of two after a warm-up call); not the headline value"}
         mism += int((hv != we.expect).sum())
+        if world == 1:
+            # SURVEY 8(d)'s own definition of the metric on the headline MIX: both batches of a step start in (pageable) host memory
+            # and their verdicts end in host memory, through the streaming queue (lamd_queue_*_batch -> pinned staging set, lamd_flush,
+            # lamd_wait): while the device works on one flush the host fills the next staging set and its H2D copies run under the
+            # kernels of the flushes before it (three in flight).  Staging memcpy + H2D + verification + D2H inside the clock.
+            def host_mix(e, reps):
+                pend, bad = [], 0
+                t1 = time.perf_counter()
+                for r in range(reps):
+                    for wl in (we, ws):
+                        if wl is we:
+                            e.queue_ecdsa_batch(wl.cols[0], wl.cols[1], wl.cols[2])
+                        else:
+                            e.queue_schnorr_batch(wl.cols[0], wl.cols[1], wl.cols[2])
+                        e.flush()
+                        pend.append(wl)
+                        if len(pend) == 3:
+                            bad += int((e.wait(cap=n) != pend.pop(0).expect).sum())
+                while pend:
+                    bad += int((e.wait(cap=n) != pend.pop(0).expect).sum())
+                return time.perf_counter() - t1, bad
+            hm = {}
+            for name, e in (("cold_tables_rebuilt_every_flush", eng_cold), ("key_table_cache_on", eng)):
+                host_mix(e, 3)                    # staging sets and per-lane workspaces are allocated on first use
+                dtm, badm = host_mix(e, 10)       # 10 steps incl. filling and draining the pipeline
+                hm[name] = {"verifies_per_s": 20 * n / dtm, "ms_per_2M_step": dtm / 10 * 1e3, "steps": 10, "mismatches": badm}
+                mism += badm
+            out["pcie_inclusive"]["mix_streaming"] = dict(hm, rows_per_flush=n, flushes_in_flight=3,
+                                                          note="1 M ECDSA-65 + 1 M BIP-340 per step from host memory to verdicts in host memory "
+                                                               "(289 MB in per step); compare with `value` (inputs resident in HBM)")
         # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
         # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
         # configs[4] commit_tx storm (484-signature groups sharing a key) as one super-batch
@@ -452,35 +515,37 @@ def main():
             # the same storm as STREAMING batches from host memory: commitments (484 signatures each) are appended to the pinned
             # staging queue, every 256 commitments are flushed as one batch, three flushes stay in flight while the next staging
             # set is being filled (lamd_queue_*_batch / lamd_flush / lamd_wait) -- H2D, verification and D2H all inside the clock
-            per, grp = st["per"], 256 * st["per"]
-            ts, sbad = [], 0
-            for it in range(3):
-                jobs = []
-                for kind in ("ecdsa", "schnorr"):
-                    wl = st[kind]
-                    for o in range(0, wl.n, grp):
-                        jobs.append((kind, wl, o, min(wl.n, o + grp)))
-                jobs.sort(key=lambda j: j[2])                     # interleave the two kinds as the channels would arrive
-                pend, sbad = [], 0
-                t1 = time.perf_counter()
-                for kind, wl, a, b in jobs:
-                    if kind == "ecdsa":
-                        eng.queue_ecdsa_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
-                    else:
-                        eng.queue_schnorr_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
-                    eng.flush()
-                    pend.append((wl, a, b))
-                    if len(pend) == 3:
+            streaming = {}
+            for cpf in (256, 1024):
+                per, grp = st["per"], cpf * st["per"]
+                ts, sbad = [], 0
+                for it in range(3):
+                    jobs = []
+                    for kind in ("ecdsa", "schnorr"):
+                        wl = st[kind]
+                        for o in range(0, wl.n, grp):
+                            jobs.append((kind, wl, o, min(wl.n, o + grp)))
+                    jobs.sort(key=lambda j: j[2])                     # interleave the two kinds as the channels would arrive
+                    pend, sbad = [], 0
+                    t1 = time.perf_counter()
+                    for kind, wl, a, b in jobs:
+                        if kind == "ecdsa":
+                            eng.queue_ecdsa_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
+                        else:
+                            eng.queue_schnorr_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
+                        eng.flush()
+                        pend.append((wl, a, b))
+                        if len(pend) == 3:
+                            wl0, a0, b0 = pend.pop(0)
+                            sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
+                    while pend:
                         wl0, a0, b0 = pend.pop(0)
                         sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
-                while pend:
-                    wl0, a0, b0 = pend.pop(0)
-                    sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
-                ts.append(time.perf_counter() - t1)
-            extra["cfg5_commit_storm_streaming"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[1:]), "mismatches": sbad,
-                                                    "batch": "256 commitments (123 904 signatures) per flush, 3 flushes in flight",
-                                                    "note": "inputs in host memory: staging memcpy + H2D + verification + D2H inside the clock"}
-            mism += sbad
+                    ts.append(time.perf_counter() - t1)
+                streaming["%d_commitments_per_flush" % cpf] = {"verifies_per_s": nv / min(ts[1:]), "signatures_per_flush": grp, "mismatches": sbad}
+                mism += sbad
+            extra["cfg5_commit_storm_streaming"] = dict(streaming, channels=10_000, verifies=nv, flushes_in_flight=3,
+                                                        note="inputs in host memory: staging memcpy + H2D + verification + D2H inside the clock")
             del st
             # ---- N2: the same kind of flood through the batched gossip INGEST (lightning_amd/csrc/gossip_ingest.cpp: gossipd's receive
             # path -- filters, ordering, store -- around one device call per drained queue): 100 k channel_announcements from a

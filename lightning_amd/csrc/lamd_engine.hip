@@ -784,22 +784,26 @@ static void launch_keytables(hipStream_t st, const u32 *plan, int which, size_t 
                      (const u32 *)scratch);
 }
 
-// work item j verifies row list[j] against the comb table of its key (plan[which] rows; the launch covers an upper bound).
-// The hot form: bare addition formulas, one Z == 0 test at the end; a lane that meets it reports VERDICT_SUSPECT and
-// k_ecmult_keyed_careful decides that row with the complete formulas.
-template <int T, bool CAREFUL, int WAVES>
-__global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, int which, const u32 *__restrict__ list,
+// work item j verifies one row against the comb table of its key: items [0, plan[P_L7]) are the rows of list7 (7-tooth combs),
+// the plan[P_L10] items after them the rows of list10.  ONE launch covers both shapes: the lists' lengths are only known on the
+// device, and a launch of its own for a list that turns out empty still has to get its blocks dispatched -- behind another lane's
+// ecmult kernel that holds every wave slot that took up to 2.8 ms (rocprofv3 timeline of the streaming queue), all of it added to
+// the batch's latency.  A wave that straddles the boundary runs both bodies; every other wave runs one.
+// The hot form: bare addition formulas, one Z == 0 test at the end; a lane that meets it reports VERDICT_SUSPECT and the
+// CAREFUL launch decides that row with the complete formulas.
+template <bool CAREFUL, int WAVES>
+__global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, const u32 *__restrict__ list7, const u32 *__restrict__ list10,
                                                       const prep_rec *__restrict__ recs, const u32 *__restrict__ row_ent,
-                                                      const cache_ent *__restrict__ ents, const u32 *__restrict__ pool,
-                                                      const u8 *__restrict__ sig64, int mode, const u32 *__restrict__ gtable,
-                                                      u32 *__restrict__ fin, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
-  // grid-stride over the list: the launch covers at most a few blocks per CU (the list's length is only known on the device, and a
-  // launch sized for the whole batch costs 20-170 us of block dispatch even when its list is empty -- four such launches per call)
+                                                      const cache_ent *__restrict__ ents, const u32 *__restrict__ pool7,
+                                                      const u32 *__restrict__ pool10, const u8 *__restrict__ sig64, int mode,
+                                                      const u32 *__restrict__ gtable, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
+                                                      u8 *__restrict__ out) {
   if (CAREFUL && plan[P_SUSPECT] == 0) return;
-  const size_t total = plan[which], stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t7 = plan[P_L7], total = t7 + plan[P_L10], stride = (size_t)gridDim.x * blockDim.x;
 #pragma unroll 1
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
-    const size_t i = list[j];
+    const bool ten = j >= t7;
+    const size_t i = ten ? list10[j - t7] : list7[j];
     if (CAREFUL && out[i] != VERDICT_SUSPECT) continue;
     prep_rec rec;
     {
@@ -811,22 +815,25 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, int whic
       rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
       rec.flags = e.x;
     }
-    const cache_ent *ce = ents + row_ent[i];
-    const u32 *tab = pool + (size_t)ce->tabslot * kc_stride(T);
+    const size_t tabslot = ents[row_ent[i]].tabslot;
     if (!CAREFUL && keyok_row) keyok_row[i] = 1;  // rows on these lists have a parsed key (the others were rejected by lookup / partition)
     bool ok = (rec.flags & PREP_VALID) != 0;
     if (ok) {
       gej R;
-      if (CAREFUL) {
-        R = ecmult_lane_keyed<T>(rec, tab, gtable);
+      bool suspect = false;
+      if (ten) {
+        const u32 *tab = pool10 + tabslot * kc_stride(10);
+        if (CAREFUL) R = ecmult_lane_keyed<10>(rec, tab, gtable);
+        else R = ecmult_lane_keyed_fast<10>(rec, tab, gtable, &suspect);
       } else {
-        bool suspect;
-        R = ecmult_lane_keyed_fast<T>(rec, tab, gtable, &suspect);
-        if (suspect) {
-          out[i] = VERDICT_SUSPECT;
-          atomicAdd(&plan[P_SUSPECT], 1u);
-          continue;
-        }
+        const u32 *tab = pool7 + tabslot * kc_stride(7);
+        if (CAREFUL) R = ecmult_lane_keyed<7>(rec, tab, gtable);
+        else R = ecmult_lane_keyed_fast<7>(rec, tab, gtable, &suspect);
+      }
+      if (suspect) {
+        out[i] = VERDICT_SUSPECT;
+        atomicAdd(&plan[P_SUSPECT], 1u);
+        continue;
       }
       u32 rw[8];
       load_words_be(rw, sig64 + 64 * i);
@@ -945,7 +952,7 @@ struct lamd_ctx {
   devbuf keyok_row;
   hipStream_t stream2 = nullptr;   // scalar prep runs here, concurrently with the key work on `stream`
   hipStream_t stream3 = nullptr;   // cold rows of a partitioned chunk
-  hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr, ev_keys = nullptr;
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
@@ -1077,6 +1084,7 @@ static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_keys, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_plan, (P_WORDS + C_WORDS) * 4, hipHostMallocDefault));
@@ -1235,6 +1243,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
   if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
   if (ctx->ev_cold) (void)hipEventDestroy(ctx->ev_cold);
+  if (ctx->ev_keys) (void)hipEventDestroy(ctx->ev_keys);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->vbuf, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
@@ -1533,18 +1542,12 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
       }
       if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-      hipLaunchKernelGGL((k_ecmult_keyed<7, false, 3>), dim3(keyed_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
-                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
-                         keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<10, false, 3>), dim3(keyed_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
-                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
-                         keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L7, (const u32 *)ctx->list7.p, recs,
-                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
-                         keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (int)P_L10, (const u32 *)ctx->list10.p, recs,
-                         (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s,
-                         keyok_out, d_ok);
+      hipLaunchKernelGGL((k_ecmult_keyed<false, 3>), dim3(keyed_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (const u32 *)ctx->list7.p,
+                         (const u32 *)ctx->list10.p, recs, (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p,
+                         (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s, keyok_out, d_ok);
+      hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (const u32 *)ctx->list7.p,
+                         (const u32 *)ctx->list10.p, recs, (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p,
+                         (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s, keyok_out, d_ok);
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
       if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
       if (mode == MODE_SCHNORR)
@@ -1676,23 +1679,15 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   }
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-  // (the bare-formula kernels fit 4 waves per SIMD with a 5-dword spill, or 3 without: LAMD_KEYED_WAVES)
-  auto fast7 = ctx->keyed_waves == 3 ? k_ecmult_keyed<7, false, 3> : k_ecmult_keyed<7, false, 4>;
-  auto fast10 = ctx->keyed_waves == 3 ? k_ecmult_keyed<10, false, 3> : k_ecmult_keyed<10, false, 4>;
-  const bool run7 = thr7 != 0xFFFFFFFFu || use_cache, run10 = thr10 != 0xFFFFFFFFu || use_cache;
-  if (run7)
-    hipLaunchKernelGGL(fast7, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs, (const u32 *)row_ent, ents,
-                       (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
-  if (run10)
-    hipLaunchKernelGGL(fast10, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs, (const u32 *)row_ent, ents,
-                       (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
+  // (the bare-formula kernel fits 4 waves per SIMD with a spill, or 3 without: LAMD_KEYED_WAVES)
+  auto fast = ctx->keyed_waves == 3 ? k_ecmult_keyed<false, 3> : k_ecmult_keyed<false, 4>;
+  hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
+                     (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
+                     keyok_out, d_ok);
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
-  if (run7)
-    hipLaunchKernelGGL((k_ecmult_keyed<7, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (int)P_L7, (const u32 *)list7, recs,
-                       (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
-  if (run10)
-    hipLaunchKernelGGL((k_ecmult_keyed<10, true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (int)P_L10, (const u32 *)list10, recs,
-                       (const u32 *)row_ent, ents, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin, keyok_out, d_ok);
+  hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
+                     (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
+                     keyok_out, d_ok);
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   if (mode == MODE_SCHNORR)
@@ -2307,9 +2302,10 @@ static void par_copy(const copy_job *jobs, int njobs) {
   work();
   for (auto &t : th) t.join();
 }
-static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes) {
-  if (q.n < q.cap) return LAMD_OK;
-  const size_t ncap = q.cap ? q.cap * 2 : 1024;
+static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, size_t want = 0) {
+  if (q.n < q.cap && want <= q.cap) return LAMD_OK;
+  size_t ncap = q.cap ? q.cap * 2 : 1024;
+  if (ncap < want) ncap = want;  // a large push sizes the set in one allocation (pinned allocations are slow)
   u8 *na = nullptr, *nb = nullptr, *nc = nullptr, *nk = nullptr;
   HIPCHK(ctx, hipHostMalloc((void **)&na, ncap * 32, hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void **)&nb, ncap * 64, hipHostMallocDefault));
@@ -2329,13 +2325,7 @@ static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes) {
 static const size_t Q_KEYBYTES[Q_KINDS] = {33, 65, 32};
 
 static int queue_reserve_n(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, size_t extra) {
-  while (q.n + extra > q.cap) {
-    const size_t keep = q.n;
-    q.n = q.cap;  // make queue_reserve grow
-    const int rc = queue_reserve(ctx, q, keybytes);
-    q.n = keep;
-    if (rc != LAMD_OK) return rc;
-  }
+  if (q.n + extra > q.cap) return queue_reserve(ctx, q, keybytes, q.n + extra);
   return LAMD_OK;
 }
 // appends n triples (row strides 32 / 64 / keystride); returns the ticket of the first one
@@ -2421,16 +2411,25 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     if ((rc = ensure(ctx, &q.d_b, q.n * 64)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_c, q.n * kb + 16)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_ok, q.n)) != LAMD_OK) return rc;
-    // keys first (main stream: de-duplication / tables can start), hashes + signatures on the lane's prep stream (see run_host)
+    // The keys first: de-duplication and table building (main stream) only need them and start while the hashes and signatures
+    // are still on the bus.  All three copies go down the lane's PREP stream back to back and the main stream waits for the
+    // keys' event: a copy that itself waits for another stream's copy starts 0.5-1 ms late (rocprofv3 timeline of the pipelined
+    // loop, tools/host_path_trace.py: the dependency is resolved by the runtime's host thread), a kernel that waits for a copy
+    // does not.
     const bool split = q.n <= L->chunk;
-    hipStream_t s_as = split ? L->stream2 : L->stream;
-    HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
     if (split) {
-      HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));
+      HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));  // after whatever the lane's main stream still holds
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream2));
+      HIPCHK(ctx, hipEventRecord(L->ev_keys, L->stream2));
+      HIPCHK(ctx, hipStreamWaitEvent(L->stream, L->ev_keys, 0));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream2));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream2));
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream));
     }
-    HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, s_as));
-    HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, s_as));
     rc = run_device(L, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
                     (const u8 *)q.d_c.p, (int)kb, kb, (u8 *)q.d_ok.p);
     if (rc != LAMD_OK) {
