@@ -239,6 +239,8 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
+    launch_ms = {}
+
     def timed(eng):
         eng.auto_order = False   # the inputs were generated and synchronised before the loop: no per-call ordering after torch's stream
         stepno[0] = 0
@@ -247,12 +249,16 @@ def main():
         for _ in range(args.warmup):
             step(eng)
         fence(eng)
+        eng.set_timing(True)     # restart the per-launch duration sums of the dominant kernel: they cover exactly the timed steps
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(eng, poison=(k == args.steps - 1))
         fence(eng)
         dt = time.perf_counter() - t0
         eng.auto_order = True
+        # HIP events right around every table-driven ecmult launch of the timed steps, on the lane stream that launched it
+        launch_ms[id(eng)] = [[sum(eng.info(l)["keyed_ecmult_ms_sum"][m] for l in range(eng.info()["lanes"])),
+                               sum(eng.info(l)["keyed_ecmult_launches"][m] for l in range(eng.info()["lanes"]))] for m in (0, 1)]
         if multi:
             t = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -269,6 +275,7 @@ def main():
     eng_default, eng = eng, eng_cold      # the isolated launch durations below are the cold engine's too
     # the same kernels once more, one call at a time (nothing else on the GPU): the isolated durations
     isolated = {"ecdsa": [], "schnorr": []}
+    eng.set_timing(True)
     for _ in range(2):
         eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
         eng.synchronize()
@@ -276,6 +283,8 @@ def main():
         eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
         eng.synchronize()
         isolated["schnorr"].append(eng.info()["last_kernel_ms"])
+    iso_launch = [sum(eng.info(l)["keyed_ecmult_ms_sum"][m] for l in range(eng.info()["lanes"])) /
+                  max(1, sum(eng.info(l)["keyed_ecmult_launches"][m] for l in range(eng.info()["lanes"]))) for m in (0, 1)]
     eng = eng_default                     # latency, PCIe-inclusive and the other configs run on the default engine (cache on)
     for k in isolated:
         if not kernel_ms[k]:          # LAMD_LANES=1: only the last call's events survive the timed region
@@ -308,7 +317,12 @@ def main():
         value = total / dt
         ke = np.mean(np.array(kernel_ms["ecdsa"]), axis=0)      # prep, keys, ecmult [ms]
         ks = np.mean(np.array(kernel_ms["schnorr"]), axis=0)
-        t_ecmult = ke[2] * 1e-3
+        # the dominant kernel's average launch duration over the timed (cold) region: event pair right around each launch
+        lm = launch_ms[id(eng_cold)]
+        if lm[0][1]:
+            t_ecmult = lm[0][0] / lm[0][1] * 1e-3
+        else:                       # no table-driven launch (LAMD_KEYED=0): the wide bracket of the last step
+            t_ecmult = ke[2] * 1e-3
         traffic, traffic_src = None, None
         try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_ecmult_ecdsa_1M"]
@@ -318,6 +332,7 @@ def main():
             pass
         teeth = int(keyed.get("ecdsa", (0, 0))[0])
         w_exec = W_EXEC.get(teeth, W_EXEC[0])
+        iso_ms = iso_launch[0] or float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2])
         achieved = w_exec * n / t_ecmult
         algo_bytes = BYTES_ECDSA65 * n
         valu_issue = None
@@ -340,8 +355,9 @@ def main():
             "rates": {"ecdsa65_verifies_per_s_1gpu": n / (ke.sum() * 1e-3), "schnorr_verifies_per_s_1gpu": n / (ks.sum() * 1e-3),
                       "kernel_ms_ecdsa": {"prep": ke[0], "keys_and_tables": ke[1], "ecmult": ke[2], "parity_stage": ke[3]},
                       "kernel_ms_schnorr": {"prep": ks[0], "keys_and_tables": ks[1], "ecmult": ks[2], "parity_stage": ks[3]},
-                      "kernel_ms_note": "HIP events on each lane's stream in the last timed step: the two batches of a step overlap on the GPU, "
-                                        "so these durations include the other lane's share of the chip; *_isolated = one call at a time",
+                      "kernel_ms_note": "stage brackets (HIP events on each lane's stream, last timed step): a stage's interval includes its waits for the "
+                                        "lane's side streams and the other lanes' share of the chip -- the dominant kernel's own launch duration is roofline.avg_launch_ms; "
+                                        "*_isolated = one call at a time",
                       "kernel_ms_ecdsa_isolated": dict(zip(("prep", "keys_and_tables", "ecmult", "parity_stage"), np.mean(np.array(isolated["ecdsa"]), axis=0).tolist())),
                       "kernel_ms_schnorr_isolated": dict(zip(("prep", "keys_and_tables", "ecmult", "parity_stage"), np.mean(np.array(isolated["schnorr"]), axis=0).tolist())),
                       "keyed_path": {k: {"per_key_tables": bool(v[0]), "distinct_keys": int(v[1])} for k, v in keyed.items()}},
@@ -349,13 +365,16 @@ def main():
                          "bound": "valu-int32-mul (not hbm, not mfma)",
                          # achieved = multiply-adds this kernel's algorithm executes per launch / its HIP-event duration in the timed region
                          "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
-                         "executed_mul32_per_verify": w_exec, "avg_launch_ms": ke[2], "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                         "executed_mul32_per_verify": w_exec, "avg_launch_ms": t_ecmult * 1e3, "launches_timed": int(lm[0][1]),
+                         "avg_launch_ms_schnorr": (lm[1][0] / lm[1][1]) if lm[1][1] else None,
+                         "timing": "HIP event pair recorded on the launching lane's stream right before and after every k_ecmult_keyed launch of the "
+                                   "timed steps (other lanes' kernels share the chip during the interval)",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,
                          # in the timed region the kernel shares the chip with the other lane's front end (de-duplication, table building,
                          # scalar prep), which stretches its launch; alone (one call at a time, measured right after the timed region):
-                         "isolated": {"launch_ms": float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2]),
-                                      "achieved": w_exec * n / (float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2]) * 1e-3) / 1e12,
-                                      "frac": w_exec * n / (float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2]) * 1e-3) / P_MUL32},
+                         "isolated": {"launch_ms": iso_ms, "launch_ms_schnorr": iso_launch[1] or None,
+                                      "achieved": w_exec * n / (iso_ms * 1e-3) / 1e12, "frac": w_exec * n / (iso_ms * 1e-3) / P_MUL32},
                          # the multiplier instructions are about half of the kernel's VALU instructions and the VALU issue port is the limit
                          "valu_issue": valu_issue,
                          # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time:

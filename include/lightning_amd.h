@@ -262,10 +262,14 @@ typedef struct {
 	int cache_enabled;        /* LAMD_CACHE (default 1): comb tables persist across calls */
 	size_t cache_entries, cache_capacity; /* keys with a cached table (as last read back) / LAMD_CACHE_KEYS + LAMD_CACHE_KEYS10 */
 	size_t cache_resets;      /* how often the bounded cache was emptied because it filled up */
+	/* the dominant kernel by itself: HIP events right around every large table-driven ecmult launch ([0] ECDSA, [1] BIP-340)
+	 * of this lane since lamd_set_timing(ctx, 1); summed by lamd_synchronize() */
+	double keyed_ecmult_ms_sum[2];
+	size_t keyed_ecmult_launches[2];
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 .. lanes-1 */
-int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel */
+int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each kernel group; (re)starts the keyed_ecmult_* sums */
 /* Empties the key-table cache (drains the device first).  The cache is bounded (LAMD_CACHE_KEYS 7-tooth tables, 2^20 by
  * default = 6.3 GB of HBM; LAMD_CACHE_KEYS10 10-tooth tables, 2^16 = 3.2 GB) and empties itself when it fills up;
  * benchmarks call this to measure the cold path. */

@@ -980,6 +980,15 @@ struct lamd_ctx {
   size_t chunk = CHUNK_DEFAULT;  // LAMD_CHUNK_ROWS (tests force small chunks to exercise the splitting)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double last_ms[4] = {0, 0, 0, 0};
+  // the dominant kernel alone: an event pair right around every large table-driven ecmult launch while timing is on (the
+  // start event sits AFTER the waits for the prep / cold streams, so the interval is the launch itself, as rocprofv3 sees it);
+  // read and summed per mode (ECDSA / BIP-340) by lamd_synchronize(), reset by lamd_set_timing()
+  static const int KEV = 64;
+  hipEvent_t kev[KEV][2] = {};
+  int kev_mode[KEV] = {};
+  int kev_n = 0;
+  double keyed_ms_sum[2] = {0, 0};
+  size_t keyed_launches[2] = {0, 0};
   // streaming queues (pinned host staging): QUEUE_SETS sets, one being filled while up to QUEUE_SETS - 1 flushed ones are
   // in flight (each on the lane picked at its flush), collected oldest first
   struct queue {
@@ -1264,6 +1273,9 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto &pair : ctx->kev)
+    for (auto &e : pair)
+      if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1285,6 +1297,15 @@ extern "C" int lamd_synchronize(lamd_ctx *ctx) {
     }
     (void)hipGetLastError();
   }
+  for (int i = 0; i < ctx->kev_n; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->kev[i][0], ctx->kev[i][1]) == hipSuccess) {
+      ctx->keyed_ms_sum[ctx->kev_mode[i]] += ms;
+      ctx->keyed_launches[ctx->kev_mode[i]]++;
+    }
+  }
+  (void)hipGetLastError();
+  ctx->kev_n = 0;
   return LAMD_OK;
 }
 
@@ -1312,6 +1333,14 @@ extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
   ctx->timing = enable != 0;
   for (lamd_ctx *L : ctx->lane)
     if (L) L->timing = ctx->timing;
+  // a new measurement interval: forget the launch durations summed so far (event pairs still pending are dropped)
+  for (int i = 0; i <= MAX_LANES; i++) {
+    lamd_ctx *L = i < MAX_LANES ? ctx->lane[i] : ctx;
+    if (!L) continue;
+    L->kev_n = 0;
+    L->keyed_ms_sum[0] = L->keyed_ms_sum[1] = 0;
+    L->keyed_launches[0] = L->keyed_launches[1] = 0;
+  }
   return LAMD_OK;
 }
 
@@ -1331,6 +1360,7 @@ extern "C" int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info) {
 }
 static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   lamd_ctx *root = ctx->root ? ctx->root : ctx;
+  const lamd_ctx *self = ctx;  // the launch-duration sums are this lane's own (a sum over the lanes counts every launch once)
   if (ctx->last_chunk_lane) ctx = ctx->last_chunk_lane;
   memset(info, 0, sizeof(*info));
   info->device = ctx->device;
@@ -1338,6 +1368,10 @@ static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   strncpy(info->arch, ctx->prop.gcnArchName, sizeof(info->arch) - 1);
   info->gtable_bytes = GTABLE_BYTES;
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
+  for (int i = 0; i < 2; i++) {
+    info->keyed_ecmult_ms_sum[i] = self->keyed_ms_sum[i];
+    info->keyed_ecmult_launches[i] = self->keyed_launches[i];
+  }
   info->last_mode = ctx->last_mode;
   // the counts of the last keyed call come from the pinned copy its stream wrote at the end: exact after lamd_synchronize()
   if (ctx->last_keyed_call && ctx->h_plan) {
@@ -1681,9 +1715,22 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
   // (the bare-formula kernel fits 4 waves per SIMD with a spill, or 3 without: LAMD_KEYED_WAVES)
   auto fast = ctx->keyed_waves == 3 ? k_ecmult_keyed<false, 3> : k_ecmult_keyed<false, 4>;
+  const bool time_kernel = time_it && ctx->kev_n < lamd_ctx::KEV;
+  if (time_kernel) {
+    hipEvent_t *pair = ctx->kev[ctx->kev_n];
+    if (!pair[0]) {
+      HIPCHK(ctx, hipEventCreate(&pair[0]));
+      HIPCHK(ctx, hipEventCreate(&pair[1]));
+    }
+    HIPCHK(ctx, hipEventRecord(pair[0], ctx->stream));
+  }
   hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
                      keyok_out, d_ok);
+  if (time_kernel) {
+    HIPCHK(ctx, hipEventRecord(ctx->kev[ctx->kev_n][1], ctx->stream));
+    ctx->kev_mode[ctx->kev_n++] = mode == MODE_SCHNORR ? 1 : 0;
+  }
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
   hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,

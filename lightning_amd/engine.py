@@ -340,7 +340,8 @@ class Engine:
                     last_kernel_ms=list(inf.last_kernel_ms), last_unique_keys=inf.last_unique_keys, last_hot_rows=inf.last_hot_rows, last_keyed=int(inf.last_keyed), last_mode=int(inf.last_mode), lanes=int(inf.lanes),
                     last_cache_hits=inf.last_cache_hits, last_cold_rows=inf.last_cold_rows, last_new_tables=inf.last_new_tables,
                     last_suspect_rows=inf.last_suspect_rows, cache_enabled=bool(inf.cache_enabled), cache_entries=inf.cache_entries,
-                    cache_capacity=inf.cache_capacity, cache_resets=inf.cache_resets)
+                    cache_capacity=inf.cache_capacity, cache_resets=inf.cache_resets,
+                    keyed_ecmult_ms_sum=list(inf.keyed_ecmult_ms_sum), keyed_ecmult_launches=list(inf.keyed_ecmult_launches))
 
     def cache_clear(self):
         """empty the key-table cache (cold-path measurements)"""
