@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows per kind timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--skip-extra", action="store_true", help="skip the cfg4/cfg5 single-GPU data points")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the cold timed loop and the isolated calls: every k_ecmult_keyed launch of the process covers a full batch, so the "
+                         "average of `rocprofv3 --kernel-trace --stats` over this command is directly comparable with roofline.avg_launch_ms")
     args = ap.parse_args()
     # stdout carries exactly ONE line, the JSON: everything libraries print there (RCCL's version banner on the first
     # collective) goes to stderr instead
@@ -187,6 +190,7 @@ def main():
     n = args.n
     we = workload.make_ecdsa(eng, n, seed=workload.SEED_CFG2 + rank, nkeys=65536, publen=65, device=device)
     ws = workload.make_schnorr(eng, n, seed=workload.SEED_CFG3 + rank, nkeys=65536, device=device)
+    # collective path: one all-gather per batch kind and step, issued one step late (after the calls of the next step: see step())
     ok_all_e = torch.zeros(world * n, dtype=torch.uint8, device=device) if multi else None
     ok_all_s = torch.zeros(world * n, dtype=torch.uint8, device=device) if multi else None
 
@@ -195,34 +199,50 @@ def main():
 
     tstream = torch.cuda.current_stream().cuda_stream
 
-    # multi-rank: verdicts alternate between two buffer pairs so that the all-gather of step k (on torch's stream, ordered
-    # after step k by a device-side event) can still be reading pair k%2 while step k+1 already writes the other pair; a
-    # pair is reused only after the gather that read it has finished (side stream + event, no host synchronisation)
+    # multi-rank: verdicts alternate between two buffers per kind so that the all-gather of a step's batch (on torch's stream, ordered
+    # after that call by device-side events) can still be reading buffer k%2 while step k+1 already writes the other one.  Every
+    # dependency is per call, by events, with no host synchronisation:
+    #   * a buffer is written again only after the gather that read it (lamd_wait_event on that gather's event, just before the call);
+    #   * a gather waits for "everything submitted up to its call" (lamd_results_mark right after the call, lamd_stream_wait_mark later);
+    #   * the gathers of step k are issued AFTER the calls of step k+1, when step k is (nearly) done: torch's stream then never carries a
+    #     wait that lasts a whole step.
+    # Coupling the two calls of a step instead (one gather per step, the next-but-one step waiting for it) held the ECDSA lane back until
+    # the BIP-340 call of the same step had finished: a 3-4 ms bubble every other step in the rocprofv3 timeline, -12 % (profiles/r02m_*).
     ok_e = [we.d_ok, torch.zeros_like(we.d_ok)] if multi else [we.d_ok]
     ok_s = [ws.d_ok, torch.zeros_like(ws.d_ok)] if multi else [ws.d_ok]
-    gathered = [None, None]
-    side = torch.cuda.Stream() if multi else None
+    gathered = {"e": [None, None], "s": [None, None]}
+    pending = [None]
     stepno = [0]
     def step(eng, poison=False):
         # no host synchronisation inside a step: successive calls rotate over the engine's lanes, so the front end (key
         # de-duplication, table building) of one batch runs under the ecmult kernels of the batches before it
         b = stepno[0] % len(ok_e)
         stepno[0] += 1
-        if multi and gathered[b] is not None:
-            side.wait_event(gathered[b])
-            eng.wait_stream(side.cuda_stream)
         if poison:   # the LAST timed step writes into poisoned verdict buffers: a launch that wrote nothing cannot pass the parity check
             ok_e[b].fill_(7)
             ok_s[b].fill_(7)
             eng.wait_stream(tstream)
+        if multi and gathered["e"][b] is not None:
+            eng.wait_event(gathered["e"][b].cuda_event)
         eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], ok_e[b])
+        if multi:
+            eng.results_mark(2 * b)
+            if gathered["s"][b] is not None:
+                eng.wait_event(gathered["s"][b].cuda_event)
         eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ok_s[b])
-        if multi:  # RCCL all-gather of the boolean result vectors over xGMI
-            eng.stream_wait_results(tstream)
-            dist.all_gather_into_tensor(ok_all_e, ok_e[b])
-            dist.all_gather_into_tensor(ok_all_s, ok_s[b])
-            gathered[b] = torch.cuda.Event()
-            gathered[b].record()
+        if multi:
+            eng.results_mark(2 * b + 1)
+            if pending[0] is not None:
+                gather(eng, pending[0])
+            pending[0] = b
+
+    def gather(eng, b):  # RCCL all-gathers of the verdict bytes over xGMI
+        for kind, slot, dst, src in (("e", 2 * b, ok_all_e, ok_e[b]), ("s", 2 * b + 1, ok_all_s, ok_s[b])):
+            eng.stream_wait_mark(slot, tstream)
+            dist.all_gather_into_tensor(dst, src)
+            ev = torch.cuda.Event()
+            ev.record()
+            gathered[kind][b] = ev
 
     def record_kernel_times(eng):
         # HIP events recorded on the lanes' own streams around each kernel group of the LAST step inside the timed region
@@ -235,6 +255,9 @@ def main():
 
     def fence(eng):
         if multi:
+            if pending[0] is not None:     # the last step's all-gather belongs to the timed region
+                gather(eng, pending[0])
+                pending[0] = None
             dist.barrier()
         torch.cuda.synchronize()
         eng.synchronize()
@@ -244,8 +267,8 @@ def main():
     def timed(eng):
         eng.auto_order = False   # the inputs were generated and synchronised before the loop: no per-call ordering after torch's stream
         stepno[0] = 0
-        for b in range(len(gathered)):
-            gathered[b] = None
+        for k in gathered:
+            gathered[k] = [None, None]
         for _ in range(args.warmup):
             step(eng)
         fence(eng)
@@ -268,8 +291,12 @@ def main():
         return dt, bad
 
     # warm first (its steady state is all cache hits), then the headline: cold, every table rebuilt in every call
-    dt_warm, mism_warm = timed(eng)
-    warm_info = [eng.info(k) for k in range(eng.info()["lanes"])]
+    full = not args.roofline_only
+    if full:
+        dt_warm, mism_warm = timed(eng)
+        warm_info = [eng.info(k) for k in range(eng.info()["lanes"])]
+    else:
+        dt_warm, mism_warm, warm_info = float("nan"), 0, []
     dt, mism_cold = timed(eng_cold)
     record_kernel_times(eng_cold)
     eng_default, eng = eng, eng_cold      # the isolated launch durations below are the cold engine's too
@@ -299,14 +326,14 @@ def main():
     if multi:
         # every rank must hold every other rank's verdicts after the all-gather
         sl = slice(rank * n, (rank + 1) * n)
-        mism += int((ok_all_e[sl].cpu().numpy().astype(bool) != we.expect).sum())
+        mism += int((ok_all_e[sl].cpu().numpy().astype(bool) != we.expect).sum() + (ok_all_s[sl].cpu().numpy().astype(bool) != ws.expect).sum())
         m = torch.tensor([mism], dtype=torch.int64, device=device)
         dist.all_reduce(m)
         mism = int(m.item())
 
     # ---- the two "8 GPUs" configs of BASELINE.json as ONE job split over the ranks (all ranks take part in the collectives)
     sharded = None
-    if multi and not args.skip_extra:
+    if multi and not args.skip_extra and full:
         sharded = sharded_configs(eng, rank, world, device, tstream)
         for v in sharded.values():
             mism += v["mismatches"] if rank == 0 else 0
@@ -367,6 +394,7 @@ def main():
                          "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
                          "executed_mul32_per_verify": w_exec, "avg_launch_ms": t_ecmult * 1e3, "launches_timed": int(lm[0][1]),
                          "avg_launch_ms_schnorr": (lm[1][0] / lm[1][1]) if lm[1][1] else None,
+                         "avg_launch_ms_both_kinds": ((lm[0][0] + lm[1][0]) / (lm[0][1] + lm[1][1])) if lm[0][1] + lm[1][1] else None,
                          "timing": "HIP event pair recorded on the launching lane's stream right before and after every k_ecmult_keyed launch of the "
                                    "timed steps (other lanes' kernels share the chip during the interval)",
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch",
@@ -397,12 +425,14 @@ def main():
                            "cache_hits_last_call": [int(i["last_cache_hits"]) for i in warm_info], "new_tables_last_call": [int(i["last_new_tables"]) for i in warm_info],
                            "comb_teeth_last_call": [int(i["last_keyed"]) for i in warm_info]},
         }
+        if not full:
+            out["warm_cache"] = None
         if sharded is not None:
             out["sharded_configs"] = sharded
         # ---- batch latency (the metric's second half) and the PCIe-inclusive rate: host buffers in -> verdicts in
         # host memory out, through lamd_verify_ecdsa_batch (pageable numpy memory; never `value`)
         lat = {}
-        for bs in ((1, 484, 4096) if world == 1 else ()):
+        for bs in ((1, 484, 4096) if world == 1 and full else ()):
             hh, ss, pp = [np.ascontiguousarray(x[:bs]) for x in we.cols]
             ts = []
             for it in range(60 if bs > 1 else 120):
@@ -411,7 +441,7 @@ def main():
                 ts.append(time.perf_counter() - t1)
             ts = np.sort(np.array(ts[5:])) * 1e3
             lat["ecdsa65_batch_%d" % bs] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)])}
-        if world == 1:
+        if world == 1 and full:
             # one commitment_signed as channeld sees it (channeld.c:2171,2224): 1 signature under the funding key + 483 under ONE htlc key
             # that recurs with every commitment of the channel -- first sight (the key gets its comb table) and afterwards (cache hit)
             cs = workload.make_commit_storm(eng, 4, device=device)["ecdsa"]
@@ -428,7 +458,7 @@ def main():
             mism += int((got != cs.expect[:484]).sum() + (first != cs.expect[:484]).sum())
             lat["commitment_484_one_htlc_key"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
                                                   "cache_hits_last_call": int(eng.info()["last_cache_hits"])}
-        if world == 1:
+        if world == 1 and full:
             # BASELINE configs[0]: the committed 1 024 triples (tests/golden/cfg1.bin), ONE call per
             # signature through the reference's own prototype check_signed_hash(hash, sig, key) (bitcoin/signature.c:174-192)
             # in the C++ mirror -- what an unmodified caller sees; ns per call as onchaind/test/run-grind_feerate.c reports
@@ -464,14 +494,15 @@ def main():
         if lat:
             out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
         tp = []
-        for _ in range(3):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
+        for _ in range(3 if full else 0):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
             t1 = time.perf_counter()
             hv = eng.verify_ecdsa(we.cols[0], we.cols[1], we.cols[2])
             tp.append(time.perf_counter() - t1)
-        out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / min(tp[1:]), "first_call_verifies_per_s": n / tp[0], "rows": n,
-                                 "note": "pageable host buffers in, verdicts out, one synchronous call (best of two after a warm-up call); not the headline value"}
-        mism += int((hv != we.expect).sum())
-        if world == 1:
+        if full:
+            out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / min(tp[1:]), "first_call_verifies_per_s": n / tp[0], "rows": n,
+                                     "note": "pageable host buffers in, verdicts out, one synchronous call (best of two after a warm-up call); not the headline value"}
+            mism += int((hv != we.expect).sum())
+        if world == 1 and full:
             # SURVEY 8(d)'s own definition of the metric on the headline MIX: both batches of a step start in (pageable) host memory
             # and their verdicts end in host memory, through the streaming queue (lamd_queue_*_batch -> pinned staging set, lamd_flush,
             # lamd_wait): while the device works on one flush the host fills the next staging set and its H2D copies run under the
@@ -504,7 +535,7 @@ def main():
         # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
         # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
         # configs[4] commit_tx storm (484-signature groups sharing a key) as one super-batch
-        if not args.skip_extra and world == 1:
+        if not args.skip_extra and world == 1 and full:
             extra = {}
             g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
             ts = []
@@ -659,7 +690,7 @@ def main():
             mism += rbad
             out["other_configs_1gpu"] = extra
             mism += gm + sm
-        if args.cpu_sample > 0 and world == 1:   # the CPU baseline is a rank-0, N=1 leg
+        if args.cpu_sample > 0 and world == 1 and full:   # the CPU baseline is a rank-0, N=1 leg
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # test infrastructure: the checker / CPU baseline only
             m = min(args.cpu_sample, n)

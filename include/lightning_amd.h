@@ -88,8 +88,17 @@ void *lamd_stream(lamd_ctx *ctx); /* hipStream_t */
 int lamd_synchronize(lamd_ctx *ctx);
 /* `stream` (hipStream_t) waits, on the device, for every verification submitted so far */
 int lamd_stream_wait_results(lamd_ctx *ctx, void *stream);
+/* The same in two phases: lamd_results_mark() remembers "everything submitted so far" in slot 0..3 (events on the lanes' streams,
+ * nothing waits); lamd_stream_wait_mark() later makes `stream` wait for exactly that work.  A consumer that joins late -- after
+ * the next batch has been submitted -- keeps its stream's wait short: a wait that sits in a hardware queue for a whole batch
+ * holds up every other stream that shares the queue (bench.py's collective path: the all-gather of step k is issued after the
+ * calls of step k+1). */
+int lamd_results_mark(lamd_ctx *ctx, int slot);
+int lamd_stream_wait_mark(lamd_ctx *ctx, int slot, void *stream);
 /* verification submitted from now on waits, on the device, for what `stream` holds at this moment */
 int lamd_wait_stream(lamd_ctx *ctx, void *stream);
+/* the same for one event (hipEvent_t) the caller recorded: verification submitted from now on waits, on the device, for it */
+int lamd_wait_event(lamd_ctx *ctx, void *event);
 
 /* ---- single-item veneers with the reference's exact boolean semantics (1 = true, 0 = false,
  * < 0 = engine error: treat as failure).  They run a batch of one: correct but latency-bound;

@@ -67,6 +67,9 @@ SYMBOLS = {
     "lamd_get_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LamdInfo)]),
     "lamd_stream_wait_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_wait_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "lamd_wait_event": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "lamd_results_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }
 
 _lib = None

@@ -983,6 +983,9 @@ struct lamd_ctx {
   // the dominant kernel alone: an event pair right around every large table-driven ecmult launch while timing is on (the
   // start event sits AFTER the waits for the prep / cold streams, so the interval is the launch itself, as rocprofv3 sees it);
   // read and summed per mode (ECDSA / BIP-340) by lamd_synchronize(), reset by lamd_set_timing()
+  static const int MARK_SLOTS = 4;
+  hipEvent_t ev_mark[MARK_SLOTS][MAX_LANES + 1] = {};  // lamd_results_mark(): one event per lane stream (+ the context's own)
+  bool mark_set[MARK_SLOTS] = {};
   static const int KEV = 64;
   hipEvent_t kev[KEV][2] = {};
   int kev_mode[KEV] = {};
@@ -1276,6 +1279,9 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   for (auto &pair : ctx->kev)
     for (auto &e : pair)
       if (e) (void)hipEventDestroy(e);
+  for (auto &slot : ctx->ev_mark)
+    for (auto &e : slot)
+      if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1321,6 +1327,35 @@ extern "C" int lamd_stream_wait_results(lamd_ctx *ctx, void *stream) {
   return LAMD_OK;
 }
 // verification submitted from now on waits for what `stream` holds at this moment (e.g. a consumer of an earlier result buffer)
+extern "C" int lamd_wait_event(lamd_ctx *ctx, void *event) {
+  if (!ctx || !event) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+  return LAMD_OK;
+}
+extern "C" int lamd_results_mark(lamd_ctx *ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= lamd_ctx::MARK_SLOTS) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i <= MAX_LANES; i++) {
+    lamd_ctx *L = i < MAX_LANES ? ctx->lane[i] : ctx;
+    hipEvent_t &e = ctx->ev_mark[slot][i];
+    if (!L) continue;
+    if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(e, L->stream));
+  }
+  ctx->mark_set[slot] = true;
+  return LAMD_OK;
+}
+extern "C" int lamd_stream_wait_mark(lamd_ctx *ctx, int slot, void *stream) {
+  if (!ctx || slot < 0 || slot >= lamd_ctx::MARK_SLOTS) return LAMD_ERR_ARG;
+  if (!ctx->mark_set[slot]) {
+    ctx->err = "lamd_stream_wait_mark: slot was never marked";
+    return LAMD_ERR_STATE;
+  }
+  for (int i = 0; i <= MAX_LANES; i++)
+    if (ctx->ev_mark[slot][i]) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_mark[slot][i], 0));
+  return LAMD_OK;
+}
+
 extern "C" int lamd_wait_stream(lamd_ctx *ctx, void *stream) {
   if (!ctx) return LAMD_ERR_ARG;
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, (hipStream_t)stream));

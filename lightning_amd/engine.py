@@ -326,6 +326,18 @@ class Engine:
         """make a caller's HIP stream wait (on the device) for every verification submitted so far"""
         self._chk(self._lib.lamd_stream_wait_results(self._ctx, ctypes.c_void_p(stream_ptr)))
 
+    def wait_event(self, event_ptr):
+        """verification submitted from now on waits (on the device) for a hipEvent_t the caller recorded"""
+        self._chk(self._lib.lamd_wait_event(self._ctx, ctypes.c_void_p(event_ptr)))
+
+    def results_mark(self, slot):
+        """remember "everything submitted so far" in slot 0..3 (no waiting); see stream_wait_mark"""
+        self._chk(self._lib.lamd_results_mark(self._ctx, int(slot)))
+
+    def stream_wait_mark(self, slot, stream_ptr):
+        """make a caller's HIP stream wait (on the device) for the work remembered by results_mark(slot)"""
+        self._chk(self._lib.lamd_stream_wait_mark(self._ctx, int(slot), ctypes.c_void_p(stream_ptr)))
+
     def wait_stream(self, stream_ptr):
         """verification submitted from now on waits (on the device) for what the caller's stream holds now"""
         self._chk(self._lib.lamd_wait_stream(self._ctx, ctypes.c_void_p(stream_ptr)))
