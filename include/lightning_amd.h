@@ -224,6 +224,11 @@ int lamd_queue_schnorr(lamd_ctx *ctx, const uint8_t msg32[32], const uint8_t xon
 int lamd_queue_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey,
 			   size_t publen, size_t pubstride);
 int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64);
+/* Zero-copy producer form: queues n triples (keylen 33 / 65: ECDSA with compressed / uncompressed keys; 32: BIP-340 with x-only keys) and
+ * returns WHERE their rows live in the pinned staging set -- n rows of 32, 64 and keylen bytes, contiguous -- instead of copying them from
+ * a caller-owned buffer.  The caller writes the rows before lamd_flush(); the pointers are valid until the next lamd_queue_* / lamd_flush call
+ * on this context (a later push may move the set).  Returns the first ticket like the batch forms. */
+int lamd_queue_reserve(lamd_ctx *ctx, size_t n, size_t keylen, uint8_t **hash32, uint8_t **sig64, uint8_t **key);
 int lamd_flush(lamd_ctx *ctx);
 /* 1 = finished (ok[0..*n) filled, tickets in submission order), 0 = still running, < 0 error */
 int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);

@@ -68,6 +68,7 @@ SYMBOLS = {
     "lamd_stream_wait_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_wait_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_wait_event": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "lamd_queue_reserve": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz] + [ctypes.POINTER(ctypes.c_void_p)] * 3),
     "lamd_results_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }

@@ -912,7 +912,10 @@ struct devbuf {
 };
 
 enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
-constexpr int QUEUE_SETS = 5;
+#ifndef LAMD_QUEUE_SETS
+#define LAMD_QUEUE_SETS 5
+#endif
+constexpr int QUEUE_SETS = LAMD_QUEUE_SETS;  // staging sets of the streaming queue: one open + up to QUEUE_SETS - 1 flushes in flight
 
 struct lamd_ctx {
   int device = 0;
@@ -2410,10 +2413,9 @@ static int queue_reserve_n(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, s
   if (q.n + extra > q.cap) return queue_reserve(ctx, q, keybytes, q.n + extra);
   return LAMD_OK;
 }
-// appends n triples (row strides 32 / 64 / keystride); returns the ticket of the first one
-static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *sig, const u8 *key, size_t keystride) {
-  if (!ctx) return LAMD_ERR_ARG;
-  if (!a || !sig || !key || n == 0 || n > (size_t)0x3FFFFFFF || keystride < Q_KEYBYTES[kind]) {
+// room for n more triples of one kind in the open staging set: where their rows go (pinned host memory) and the ticket of the first
+static int queue_take(lamd_ctx *ctx, int kind, size_t n, u8 **pa, u8 **pb, u8 **pc) {
+  if (n == 0 || n > (size_t)0x3FFFFFFF) {
     ctx->err = "bad argument";
     return LAMD_ERR_ARG;
   }
@@ -2432,14 +2434,9 @@ static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *
   }
   const int rc = queue_reserve_n(ctx, q, kb, n);
   if (rc != LAMD_OK) return rc;
-  if (keystride == kb) {
-    const copy_job jobs[3] = {{q.h_a + 32 * q.n, a, 32 * n}, {q.h_b + 64 * q.n, sig, 64 * n}, {q.h_c + kb * q.n, key, kb * n}};
-    par_copy(jobs, 3);
-  } else {
-    const copy_job jobs[2] = {{q.h_a + 32 * q.n, a, 32 * n}, {q.h_b + 64 * q.n, sig, 64 * n}};
-    par_copy(jobs, 2);
-    for (size_t i = 0; i < n; i++) memcpy(q.h_c + kb * (q.n + i), key + keystride * i, kb);
-  }
+  *pa = q.h_a + 32 * q.n;
+  *pb = q.h_b + 64 * q.n;
+  *pc = q.h_c + kb * q.n;
   const size_t first = set.rows;
   if (!q.tickets.empty() && q.tickets.back().row0 + q.tickets.back().count == q.n && q.tickets.back().ticket0 + q.tickets.back().count == first)
     q.tickets.back().count += n;  // consecutive pushes of one kind: one span
@@ -2448,6 +2445,38 @@ static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *
   q.n += n;
   set.rows += n;
   return (int)first;
+}
+// appends n triples (row strides 32 / 64 / keystride); returns the ticket of the first one
+static int queue_push(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *sig, const u8 *key, size_t keystride) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!a || !sig || !key || keystride < Q_KEYBYTES[kind]) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  const size_t kb = Q_KEYBYTES[kind];
+  u8 *da, *db, *dc;
+  const int first = queue_take(ctx, kind, n, &da, &db, &dc);
+  if (first < 0) return first;
+  if (keystride == kb) {
+    const copy_job jobs[3] = {{da, a, 32 * n}, {db, sig, 64 * n}, {dc, key, kb * n}};
+    par_copy(jobs, 3);
+  } else {
+    const copy_job jobs[2] = {{da, a, 32 * n}, {db, sig, 64 * n}};
+    par_copy(jobs, 2);
+    for (size_t i = 0; i < n; i++) memcpy(dc + kb * i, key + keystride * i, kb);
+  }
+  return first;
+}
+// The producer's form: the rows are written straight into the staging set (a sidecar reads its callers' triples from a socket or
+// shared memory into these pointers), so no copy from a caller-owned buffer is made at all -- the host-side copy into pinned memory
+// is what bounds lamd_queue_*_batch() on large batches (~25 GB/s with four threads against 31 GB/s of triples at the device's rate).
+extern "C" int lamd_queue_reserve(lamd_ctx *ctx, size_t n, size_t keylen, uint8_t **hash32, uint8_t **sig64, uint8_t **key) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!hash32 || !sig64 || !key || (keylen != 33 && keylen != 65 && keylen != 32)) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  return queue_take(ctx, keylen == 33 ? Q_ECDSA33 : keylen == 65 ? Q_ECDSA65 : Q_SCHNORR, n, hash32, sig64, key);
 }
 extern "C" int lamd_queue_ecdsa(lamd_ctx *ctx, const uint8_t hash32[32], const uint8_t sig64[64], const uint8_t *pubkey,
                                 size_t publen) {

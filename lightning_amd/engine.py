@@ -242,6 +242,14 @@ class Engine:
         msg32, xonly32, sig64 = _u8(msg32, 32), _u8(xonly32, 32), _u8(sig64, 64)
         return self._chk(self._lib.lamd_queue_schnorr_batch(self._ctx, msg32.shape[0], msg32.ctypes.data, xonly32.ctypes.data, sig64.ctypes.data))
 
+    def queue_reserve(self, n, keylen):
+        """zero-copy producer form: (first ticket, hash/msg [n,32], sig [n,64], key [n,keylen]) -- numpy views of the pinned staging
+        set, to be filled before flush() and not kept beyond the next queue_* / flush call"""
+        ptr = [ctypes.c_void_p() for _ in range(3)]
+        first = self._chk(self._lib.lamd_queue_reserve(self._ctx, int(n), int(keylen), *[ctypes.byref(p) for p in ptr]))
+        views = [np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(n), w)) for p, w in zip(ptr, (32, 64, int(keylen)))]
+        return (first, *views)
+
     def flush(self):
         self._chk(self._lib.lamd_flush(self._ctx))
 

@@ -738,6 +738,35 @@ def test_streaming_pipelined_flushes(eng, orc):
         assert np.array_equal(np.asarray(got, dtype=bool), exp)
 
 
+def test_streaming_zero_copy_reserve_mixed_with_copies(eng, orc):
+    """lamd_queue_reserve(): the producer writes its rows straight into the pinned staging set; mixed with the copying forms inside
+    one flush (tickets keep counting across them), three kinds, several flushes in flight -- verdicts equal the oracle's"""
+    rnd = random.Random(777)
+    outstanding = []
+    for b in range(6):
+        n1, n2, n3 = rnd.choice((1, 64, 700)), rnd.choice((3, 484)), rnd.choice((5, 129))
+        hs, sg, pk = _random_ecdsa(orc, rnd, n1 + n2, 33)
+        sg = sg.copy(); sg[::4, 9] ^= 0x01
+        e33 = orc.ecdsa_verify_batch(hs, sg, pk, 33, 4).astype(bool)
+        hs65, sg65, pk65 = _random_ecdsa(orc, rnd, n3, 65)
+        hs65 = hs65.copy(); hs65[::3, 0] ^= 0x80
+        e65 = orc.ecdsa_verify_batch(hs65, sg65, pk65, 65, 4).astype(bool)
+        t0, a, s_, k = eng.queue_reserve(n1, 33)                 # rows 0..n1 of the 33-byte-key queue, in place
+        a[:], s_[:], k[:] = hs[:n1], sg[:n1], pk[:n1]
+        t1 = eng.queue_ecdsa_batch(hs[n1:], sg[n1:], pk[n1:])   # the copying form continues the same queue
+        t2, a, s_, k = eng.queue_reserve(n3, 65)
+        a[:], s_[:], k[:] = hs65, sg65, pk65
+        assert (t0, t1, t2) == (0, n1, n1 + n2)
+        eng.flush()
+        outstanding.append(np.concatenate([e33, e65]))
+        if len(outstanding) == 3:
+            assert np.array_equal(eng.wait(), outstanding.pop(0))
+    while outstanding:
+        assert np.array_equal(eng.wait(), outstanding.pop(0))
+    with pytest.raises(Exception):
+        eng.queue_reserve(4, 40)                                 # not a key length
+
+
 def test_key_table_cache_warm_cold_and_bounded(orc):
     """the key-table cache: a second call over the same keys builds no table and verifies every row from cached combs (same
     verdicts); keys that do not parse are cached as such; a cache too small for the traffic empties itself and carries on;
