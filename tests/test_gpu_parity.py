@@ -516,6 +516,43 @@ def test_lanes_back_to_back_calls_without_host_sync(eng, orc):
     eng.synchronize()
 
 
+def test_two_phase_join_and_event_ordering(eng):
+    """lamd_results_mark / lamd_stream_wait_mark: a consumer stream joins exactly the work that was marked, after later calls were
+    submitted; lamd_wait_event: a verdict buffer is rewritten only after the consumer's copy of it.  The pattern of bench.py's
+    collective path, checked against verdicts known by construction"""
+    from lightning_amd import LamdError, workload
+    wa = workload.make_ecdsa(eng, 50000, seed=4401, nkeys=700, publen=65)
+    wb = workload.make_schnorr(eng, 45000, seed=4402, nkeys=600)
+    eng.synchronize()
+    consumer = torch.cuda.Stream()
+    with pytest.raises(LamdError):
+        eng.stream_wait_mark(3, consumer.cuda_stream)        # never marked
+    with pytest.raises(LamdError):
+        eng.results_mark(4)                                  # slots are 0..3
+    copies, last_ev = [], [None, None]
+    for rep in range(4):
+        for slot, (w, call) in enumerate(((wa, eng.verify_ecdsa_device), (wb, eng.verify_schnorr_device))):
+            if last_ev[slot] is not None:
+                eng.wait_event(last_ev[slot].cuda_event)     # the consumer's copy of this buffer (previous round) comes first
+            if rep == 2:                                     # poison through torch's stream: after the consumer's copy, before the call
+                torch.cuda.current_stream().wait_event(last_ev[slot])
+                w.d_ok.fill_(5)
+                eng.wait_stream(torch.cuda.current_stream().cuda_stream)
+            call(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+            eng.results_mark(slot)
+        for slot, w in enumerate((wa, wb)):                  # joined late: both calls of the round are already queued
+            eng.stream_wait_mark(slot, consumer.cuda_stream)
+            with torch.cuda.stream(consumer):
+                copies.append((w, w.d_ok.clone()))
+                ev = torch.cuda.Event()
+                ev.record()
+            last_ev[slot] = ev
+    consumer.synchronize()
+    eng.synchronize()
+    for w, got in copies:
+        assert np.array_equal(got.cpu().numpy().astype(bool), w.expect), w.kind
+
+
 def test_single_lane_mode_matches(orc):
     import os
     from lightning_amd import Engine, LamdError, workload
