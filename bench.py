@@ -171,7 +171,7 @@ def main():
     device = "cuda:%d" % local_rank
     # launched by torch.distributed.run (RANK set): the collective path runs even with one rank, so that a 1-GPU box can test it
     multi = world > 1 or ("RANK" in os.environ and os.environ.get("LAMD_BENCH_GATHER", "0") == "1")
-    from lightning_amd import Engine, workload
+    from lightning_amd import Engine, sharding, workload
     # the engine first: its streams take their hardware queues before RCCL creates its own (the other order costs ~8 %:
     # measured with one rank forced through the collective path, 180 vs 196 M verifies/s)
     # two engines: `eng_cold` rebuilds every key's comb table in every call (LAMD_CACHE=0: what a stateless library does, and
@@ -210,39 +210,38 @@ def main():
     # the BIP-340 call of the same step had finished: a 3-4 ms bubble every other step in the rocprofv3 timeline, -12 % (profiles/r02m_*).
     ok_e = [we.d_ok, torch.zeros_like(we.d_ok)] if multi else [we.d_ok]
     ok_s = [ws.d_ok, torch.zeros_like(ws.d_ok)] if multi else [ws.d_ok]
-    gathered = {"e": [None, None], "s": [None, None]}
-    pending = [None]
+
+    def new_event():
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+    lg = {}      # per engine: sharding.LateGather (the marks are the engine's)
+    def late_gather(eng):
+        if id(eng) not in lg:
+            lg[id(eng)] = sharding.LateGather(eng, ("e", "s"), {"e": ok_e, "s": ok_s}, {"e": ok_all_e, "s": ok_all_s}, tstream,
+                                              dist.all_gather_into_tensor, new_event)
+        return lg[id(eng)]
     stepno = [0]
     def step(eng, poison=False):
         # no host synchronisation inside a step: successive calls rotate over the engine's lanes, so the front end (key
         # de-duplication, table building) of one batch runs under the ecmult kernels of the batches before it
         b = stepno[0] % len(ok_e)
         stepno[0] += 1
+        g = late_gather(eng) if multi else None
         if poison:   # the LAST timed step writes into poisoned verdict buffers: a launch that wrote nothing cannot pass the parity check
             ok_e[b].fill_(7)
             ok_s[b].fill_(7)
             eng.wait_stream(tstream)
-        if multi and gathered["e"][b] is not None:
-            eng.wait_event(gathered["e"][b].cuda_event)
+        if multi:
+            g.before_call("e", b)
         eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], ok_e[b])
         if multi:
-            eng.results_mark(2 * b)
-            if gathered["s"][b] is not None:
-                eng.wait_event(gathered["s"][b].cuda_event)
+            g.after_call("e", b)
+            g.before_call("s", b)
         eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ok_s[b])
         if multi:
-            eng.results_mark(2 * b + 1)
-            if pending[0] is not None:
-                gather(eng, pending[0])
-            pending[0] = b
-
-    def gather(eng, b):  # RCCL all-gathers of the verdict bytes over xGMI
-        for kind, slot, dst, src in (("e", 2 * b, ok_all_e, ok_e[b]), ("s", 2 * b + 1, ok_all_s, ok_s[b])):
-            eng.stream_wait_mark(slot, tstream)
-            dist.all_gather_into_tensor(dst, src)
-            ev = torch.cuda.Event()
-            ev.record()
-            gathered[kind][b] = ev
+            g.after_call("s", b)
+            g.end_step(b)      # issues the RCCL all-gathers of the PREVIOUS step
 
     def record_kernel_times(eng):
         # HIP events recorded on the lanes' own streams around each kernel group of the LAST step inside the timed region
@@ -255,9 +254,7 @@ def main():
 
     def fence(eng):
         if multi:
-            if pending[0] is not None:     # the last step's all-gather belongs to the timed region
-                gather(eng, pending[0])
-                pending[0] = None
+            late_gather(eng).flush()       # the last step's all-gathers belong to the timed region
             dist.barrier()
         torch.cuda.synchronize()
         eng.synchronize()
@@ -267,8 +264,8 @@ def main():
     def timed(eng):
         eng.auto_order = False   # the inputs were generated and synchronised before the loop: no per-call ordering after torch's stream
         stepno[0] = 0
-        for k in gathered:
-            gathered[k] = [None, None]
+        if multi:
+            late_gather(eng).reset()
         for _ in range(args.warmup):
             step(eng)
         fence(eng)
