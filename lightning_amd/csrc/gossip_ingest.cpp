@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <map>
+#include <random>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -37,6 +38,54 @@ struct nodeid {
   bool operator<(const nodeid &o) const { return memcmp(k, o.k, 33) < 0; }
   bool operator==(const nodeid &o) const { return memcmp(k, o.k, 33) == 0; }
 };
+
+// ---- hashing for the maps.  Keyed (the key is drawn per ingest, as gossipd seeds its siphash tables): a peer that chooses
+// short_channel_ids, node ids or whole messages cannot aim at one bucket.  Equality is always decided on the full content.
+static inline u64 mix64(u64 h) {
+  h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
+  h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull;
+  h ^= h >> 32;
+  return h;
+}
+static u64 content_hash(u64 seed, const u8 *p, size_t n) {
+  u64 h = seed ^ ((u64)n * 0x9E3779B97F4A7C15ull);
+  while (n >= 8) {
+    u64 w;
+    memcpy(&w, p, 8);
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    p += 8; n -= 8;
+  }
+  u64 w = 0;
+  memcpy(&w, p, n);
+  h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+  return mix64(h);
+}
+struct scid_hash {
+  u64 seed;
+  size_t operator()(u64 x) const { return (size_t)mix64(x ^ seed); }
+};
+struct nodeid_hash {
+  u64 seed;
+  size_t operator()(const nodeid &n) const { return (size_t)content_hash(seed, n.k, 33); }
+};
+// a (message, signer) pair by reference: the bytes live in the batch / the waiting lists for as long as a map holds the key
+struct msgkey {
+  const u8 *m;
+  size_t len;
+  const u8 *signer;  // 33 bytes or nullptr
+  u64 h;
+};
+struct msgkey_hash {
+  size_t operator()(const msgkey &k) const { return (size_t)k.h; }
+};
+struct msgkey_eq {
+  bool operator()(const msgkey &a, const msgkey &b) const {
+    return a.h == b.h && a.len == b.len && (a.signer != nullptr) == (b.signer != nullptr) && memcmp(a.m, b.m, a.len) == 0 &&
+           (!a.signer || memcmp(a.signer, b.signer, 33) == 0);
+  }
+};
+typedef std::unordered_map<msgkey, int, msgkey_hash, msgkey_eq> verdict_map;
 
 std::string hexs(const u8 *p, size_t n) {
   static const char *d = "0123456789abcdef";
@@ -177,17 +226,23 @@ struct lamd_gossipd {
   void *be_user = nullptr;
   lamd_gossipd_stats st;
 
+  const u64 seed = ((u64)std::random_device{}() << 32) ^ std::random_device{}() ^ 0x6C616D6467737064ull;
   std::vector<queued> queue;
-  std::map<u64, chan> chans;
-  std::map<nodeid, node> nodes;
-  std::map<u64, pending_cannounce> pending_ann, early_ann;  // ordered: new_block walks early_ann by ascending scid
+  std::unordered_map<u64, chan, scid_hash> chans{16, scid_hash{seed}};
+  std::unordered_map<nodeid, node, nodeid_hash> nodes{16, nodeid_hash{seed}};
+  std::unordered_map<u64, pending_cannounce, scid_hash> pending_ann{16, scid_hash{seed}};
+  std::map<u64, pending_cannounce> early_ann;  // ordered: new_block walks early_ann by ascending scid
   std::vector<pending_cupdate> pending_cupdates, early_cupdates;
   std::vector<pending_nannounce> pending_nannounces;
-  std::map<u64, bool> txout_failures;
+  std::unordered_map<u64, bool, scid_hash> txout_failures{16, scid_hash{seed}};
   std::vector<record> store;
 
-  // verdicts of the batch being applied: (message bytes + signer) -> verdict
-  std::unordered_map<std::string, int> verdicts;
+  // verdicts of the batch being applied: (message bytes, signer) -> verdict.  The keys refer to the bytes, they do not own them:
+  // the map is emptied (drop_verdicts) before the batch / the lists it was filled from go away
+  verdict_map verdicts;
+  struct slotlist;
+  const slotlist *cur_sl = nullptr;
+  std::vector<int8_t> cur_v;
 
   u64 now() const { return cfg.now ? cfg.now : (u64)time(nullptr); }
 
@@ -213,7 +268,7 @@ struct lamd_gossipd {
   }
   void warning(bool has_peer, const nodeid *peer, const std::string &text) { ev_text(LAMD_GEV_WARNING, has_peer, peer, text); }
   // gossmap_manage.c:576-579
-  void bad_gossip(bool has_peer, const nodeid *peer, const std::string &text) { ev_text(LAMD_GEV_TRACE, has_peer, peer, "Bad gossip order: " + text); }
+  void bad_gossip(bool has_peer, const nodeid *peer, const std::string &text) { if (on_event) ev_text(LAMD_GEV_TRACE, has_peer, peer, "Bad gossip order: " + text); }
   // :582-597
   void peer_warning(bool has_peer, const nodeid *peer, const std::string &text) {
     bad_gossip(has_peer, peer, text);
@@ -281,14 +336,20 @@ struct lamd_gossipd {
     if (!ctx) return LAMD_ERR_ARG;
     return lamd_pubkey_parse_batch(ctx, n, pub33, 33, 33, nullptr, ok);
   }
-  static std::string vkey(const bytes &m, const nodeid *signer) {
-    std::string k((const char *)m.data(), m.size());
-    if (signer) k.append((const char *)signer->k, 33);
+  msgkey vkey(const bytes &m, const nodeid *signer) const {
+    msgkey k{m.data(), m.size(), signer ? signer->k : nullptr, 0};
+    k.h = content_hash(seed, k.m, k.len);
+    if (signer) k.h = content_hash(k.h, signer->k, 33);
     return k;
   }
-  // verdict of (message, signer); verifies on the spot if the plan did not foresee the pair
+  // verdict of (message, signer): the planned pairs answer from the slot list that went to the device (cur_sl / cur_v, set by
+  // verify()); a pair the plan did not foresee is verified on the spot and remembered in `verdicts`
   int verdict_of(const bytes &m, const nodeid *signer) {
-    const std::string k = vkey(m, signer);
+    const msgkey k = vkey(m, signer);
+    if (cur_sl) {
+      auto its = cur_sl->index.find(k);
+      if (its != cur_sl->index.end()) return cur_v[its->second];
+    }
     auto it = verdicts.find(k);
     if (it != verdicts.end()) return it->second;
     st.late_verifies++;
@@ -303,13 +364,12 @@ struct lamd_gossipd {
   struct slotlist {
     std::vector<const bytes *> msg;
     std::vector<const nodeid *> signer;
-    std::unordered_map<std::string, int> index;
+    verdict_map index;
     int add(lamd_gossipd *g, const bytes &m, const nodeid *signer_) {
-      const std::string k = vkey(m, signer_);
-      auto it = index.find(k);
-      if (it != index.end()) { g->st.duplicates++; return it->second; }
+      const msgkey k = g->vkey(m, signer_);
       const int s = (int)msg.size();
-      index.emplace(k, s);
+      const auto ins = index.try_emplace(k, s);
+      if (!ins.second) { g->st.duplicates++; return ins.first->second; }
       msg.push_back(&m);
       signer.push_back(signer_);
       return s;
@@ -333,7 +393,8 @@ struct lamd_gossipd {
     std::vector<int8_t> v(n, -2);
     const int rc = backend_sigcheck(n, blob.data(), off.data(), ids.data(), v.data());
     if (rc != LAMD_OK) return rc;
-    for (auto &kv : sl.index) verdicts[kv.first] = v[kv.second];
+    cur_sl = &sl;  // until drop_verdicts(): the caller keeps `sl` alive that long
+    cur_v.swap(v);
     st.batches++;
     st.verified_messages += n;
     return LAMD_OK;
@@ -415,26 +476,27 @@ struct lamd_gossipd {
   }
 
   // ---- process_channel_update (:878-998); returns the error text ("" = none)
-  std::string process_channel_update(const pending_cupdate &u) {
+  // (`upd` = the message bytes: u.update for an update that waited in a list, the batch's own copy otherwise)
+  std::string process_channel_update(const pending_cupdate &u, const bytes &upd) {
     const int dir = u.cflags & 1;
     auto it = chans.find(u.scid);
     if (it == chans.end()) {
       if (txout_failures.count(u.scid)) return "";  // :901-905
       ev_scid(LAMD_GEV_QUERY_CHANNEL, u.has_src, &u.src, u.scid);
-      bad_gossip(u.has_src, &u.src, "Unknown channel " + fmt_scid(u.scid));
+      if (on_event) bad_gossip(u.has_src, &u.src, "Unknown channel " + fmt_scid(u.scid));
       return "";
     }
     chan &c = it->second;
-    const int v = verdict_of(u.update, &c.node[dir]);  // :920-926
+    const int v = verdict_of(upd, &c.node[dir]);  // :920-926
     if (v == -2) return "engine error";
-    if (v != 0) return sigcheck_text(GOSSIP_CUPD, 1, u.update);
+    if (v != 0) return sigcheck_text(GOSSIP_CUPD, 1, upd);
     if (u.mflags & 2) return "Do not set DONT_FORWARD on public channel_updates (" + fmt_scid(u.scid) + ")";  // :929-932
     if (c.set[dir]) {  // :935-946
       if (store[c.cupd_rec[dir]].timestamp >= u.timestamp) return "";
     } else if (!c.set[!dir]) {
       store_set_ts(c.cann_rec, u.timestamp);  // :950-951
     }
-    const u64 rec = store_add(GOSSIP_CUPD, u.timestamp, u.update.data(), u.update.size());  // :955
+    const u64 rec = store_add(GOSSIP_CUPD, u.timestamp, upd.data(), upd.size());  // :955
     if (c.set[dir]) store_del(c.cupd_rec[dir]);                                             // :966-967
     c.set[dir] = true;
     c.cupd_rec[dir] = rec;
@@ -442,9 +504,11 @@ struct lamd_gossipd {
     memcpy(ours.k, cfg.our_id, 33);
     if (c.node[!dir] == ours) peer_update(u.has_src, &u.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);  // :970-980
     good_gossip(u.has_src, &u.src);
-    char b[16];
-    snprintf(b, sizeof b, "/%d now ", dir);
-    ev_text(LAMD_GEV_TRACE, u.has_src, &u.src, "Received channel_update for channel " + fmt_scid(u.scid) + b + ((u.cflags & 2) ? "DISABLED" : "ACTIVE"));
+    if (on_event) {  // (the text is only built for a listener: it is a debug-level line in the reference)
+      char b[16];
+      snprintf(b, sizeof b, "/%d now ", dir);
+      ev_text(LAMD_GEV_TRACE, u.has_src, &u.src, "Received channel_update for channel " + fmt_scid(u.scid) + b + ((u.cflags & 2) ? "DISABLED" : "ACTIVE"));
+    }
     return "";
   }
 
@@ -460,8 +524,7 @@ struct lamd_gossipd {
     u.fee_base = be32(&m[122]);
     u.fee_ppm = be32(&m[126]);
     u.hmax = be64(&m[130]);
-    u.update = m;
-    u.has_src = q.has_src;
+    u.has_src = q.has_src;  // (u.update stays empty: only an update that has to wait keeps its own copy of the bytes)
     u.src = q.src;
     return u;
   }
@@ -474,13 +537,13 @@ struct lamd_gossipd {
       if (memcmp(&m[66], cfg.chain_hash, 32) != 0) return;                       // :1054-1057
       pending_cupdate u = parse_cupdate(q);
       if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
-      if (pending_ann.count(u.scid)) { pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
-      if (early_ann.count(u.scid)) { early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
+      if (pending_ann.count(u.scid)) { u.update = m; pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
+      if (early_ann.count(u.scid)) { u.update = m; early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
       if (!chans.count(u.scid) && q.has_src && verdict_of(m, &q.src) == 0) {                // :1107-1116
         peer_update(true, &q.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);
         return;
       }
-      err = process_channel_update(u);
+      err = process_channel_update(u, m);
     } while (0);
     if (!err.empty()) warning(q.has_src, &q.src, err);
   }
@@ -493,7 +556,7 @@ struct lamd_gossipd {
     n.announced = true;
     n.nann_rec = rec;
     good_gossip(has_src, src);
-    ev_text(LAMD_GEV_TRACE, has_src, src, "Received node_announcement for node " + hexs(id.k, 33));
+    if (on_event) ev_text(LAMD_GEV_TRACE, has_src, src, "Received node_announcement for node " + hexs(id.k, 33));
   }
   void unknown_node(bool has_src, const nodeid *src, const nodeid &id) {  // :1231-1238
     lamd_gossipd_event ev;
@@ -504,7 +567,7 @@ struct lamd_gossipd {
     ev.data = id.k;
     ev.len = 33;
     emit(ev);
-    bad_gossip(has_src, src, "node_announcement: unknown node " + hexs(id.k, 33));
+    if (on_event) bad_gossip(has_src, src, "node_announcement: unknown node " + hexs(id.k, 33));
   }
   // ---- gossmap_manage_node_announcement (:1162-1243)
   void apply_nann(const queued &q, const planned &p) {
@@ -541,7 +604,9 @@ struct lamd_gossipd {
   // ---- reprocess_queued_msgs (:1284-1342): the signatures of every waiting channel_update whose channel now exists go to
   // the device as one batch first
   void drop_verdicts() {  // (clear() walks the whole bucket array of a map that once held a large batch)
-    if (!verdicts.empty() || verdicts.bucket_count() > 64) std::unordered_map<std::string, int>().swap(verdicts);
+    cur_sl = nullptr;
+    cur_v.clear();
+    if (!verdicts.empty() || verdicts.bucket_count() > 64) verdict_map().swap(verdicts);
   }
   int reprocess_queued_msgs() {
     const bool pending_empty = pending_ann.empty(), early_empty = early_ann.empty();
@@ -560,26 +625,26 @@ struct lamd_gossipd {
     const int rc = verify(sl);
     if (rc != LAMD_OK) return rc;
     auto process_pending = [&](const pending_cupdate &u) {  // :1245-1268
-      const std::string err = process_channel_update(u);
+      const std::string err = process_channel_update(u, u.update);
       if (!err.empty()) peer_warning(u.has_src, &u.src, "channel_update: " + err);
     };
+    // (the lists outlive the verdict map: its keys refer to their messages)
+    std::vector<pending_cupdate> lp, le;
+    std::vector<pending_nannounce> ln;
     if (pending_empty) {
-      std::vector<pending_cupdate> l;
-      l.swap(pending_cupdates);
-      for (const pending_cupdate &u : l) process_pending(u);
+      lp.swap(pending_cupdates);
+      for (const pending_cupdate &u : lp) process_pending(u);
     }
     if (early_empty) {
-      std::vector<pending_cupdate> l;
-      l.swap(early_cupdates);
-      for (pending_cupdate &u : l) {
-        if (pending_ann.count(u.scid)) { pending_cupdates.push_back(std::move(u)); continue; }
+      le.swap(early_cupdates);
+      for (pending_cupdate &u : le) {
+        if (pending_ann.count(u.scid)) { pending_cupdates.push_back(u); continue; }
         process_pending(u);
       }
     }
     if (early_empty && pending_empty) {
-      std::vector<pending_nannounce> l;
-      l.swap(pending_nannounces);
-      for (const pending_nannounce &pn : l) {
+      ln.swap(pending_nannounces);
+      for (const pending_nannounce &pn : ln) {
         auto it = nodes.find(pn.id);
         if (it == nodes.end()) { unknown_node(pn.has_src, &pn.src, pn.id); continue; }
         process_node_announcement(it->second, pn.timestamp, pn.id, pn.msg, pn.has_src, &pn.src);
@@ -710,7 +775,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   std::vector<u8> keyok(keyblob.size() / 33, 0);
   if (!keyok.empty()) {
     rc = g->backend_keyparse(keyok.size(), keyblob.data(), keyok.data());
-    if (rc != LAMD_OK) { g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
+    if (rc != LAMD_OK) { g->drop_verdicts(); g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
   }
   // ---- apply in arrival order
   for (size_t i = 0; i < n; i++) {
