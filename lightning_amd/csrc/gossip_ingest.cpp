@@ -726,6 +726,10 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   // ---- plan: which (message, signer) pairs can reach a sigcheck_*() call, judged from the state before the batch
   std::vector<planned> plan(n);
   lamd_gossipd::slotlist sl;
+  sl.index.reserve(n);  // (growing a hash table rehashes it log2(n) times)
+  g->pending_ann.reserve(g->pending_ann.size() + n / 2);
+  sl.msg.reserve(n);
+  sl.signer.reserve(n);
   bytes keyblob;
   for (size_t i = 0; i < n; i++) {
     const queued &q = batch[i];
@@ -831,6 +835,8 @@ extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t
 extern "C" int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const uint64_t *scids, const uint64_t *sats, const uint8_t *scripts,
                                               const uint64_t *script_off) {
   if (!g || (n && (!scids || !sats || !scripts || !script_off))) return LAMD_ERR_ARG;
+  g->chans.reserve(g->chans.size() + n);
+  g->store.reserve(g->store.size() + 2 * n);
   for (size_t i = 0; i < n; i++) {
     const int rc = lamd_gossipd_txout_reply(g, scids[i], sats[i], scripts + script_off[i], (size_t)(script_off[i + 1] - script_off[i]));
     if (rc != LAMD_OK) return rc;
