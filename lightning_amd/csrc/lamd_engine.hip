@@ -791,8 +791,12 @@ static void launch_keytables(hipStream_t st, const u32 *plan, int which, size_t 
 // the batch's latency.  A wave that straddles the boundary runs both bodies; every other wave runs one.
 // The hot form: bare addition formulas, one Z == 0 test at the end; a lane that meets it reports VERDICT_SUSPECT and the
 // CAREFUL launch decides that row with the complete formulas.
+// (LAMD_KEYED_THREADS: block size of the table-driven ecmult launches -- a build knob for experiments, 256 is what ships)
+#ifndef LAMD_KEYED_THREADS
+#define LAMD_KEYED_THREADS 256
+#endif
 template <bool CAREFUL, int WAVES>
-__global__ void __launch_bounds__(256, WAVES) k_ecmult_keyed(u32 *plan, const u32 *__restrict__ list7, const u32 *__restrict__ list10,
+__global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 *plan, const u32 *__restrict__ list7, const u32 *__restrict__ list10,
                                                       const prep_rec *__restrict__ recs, const u32 *__restrict__ row_ent,
                                                       const cache_ent *__restrict__ ents, const u32 *__restrict__ pool7,
                                                       const u32 *__restrict__ pool10, const u8 *__restrict__ sig64, int mode,
@@ -1074,7 +1078,7 @@ static unsigned careful_grid(const lamd_ctx *ctx, size_t n) {
 
 // blocks of a table-driven ecmult launch (the kernels walk their list with a grid stride)
 static unsigned keyed_grid(const lamd_ctx *ctx, size_t n) {
-  const unsigned full = blocks_for(n), cap = (unsigned)ctx->prop.multiProcessorCount * ctx->keyed_blocks_per_cu;
+  const unsigned full = (unsigned)((n + LAMD_KEYED_THREADS - 1) / LAMD_KEYED_THREADS), cap = (unsigned)ctx->prop.multiProcessorCount * ctx->keyed_blocks_per_cu;
   return ctx->keyed_blocks_per_cu && cap < full ? cap : full;
 }
 
@@ -1614,10 +1618,10 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
       }
       if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-      hipLaunchKernelGGL((k_ecmult_keyed<false, 3>), dim3(keyed_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (const u32 *)ctx->list7.p,
+      hipLaunchKernelGGL((k_ecmult_keyed<false, 3>), dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), 0, ctx->stream, plan_s, (const u32 *)ctx->list7.p,
                          (const u32 *)ctx->list10.p, recs, (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p,
                          (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s, keyok_out, d_ok);
-      hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan_s, (const u32 *)ctx->list7.p,
+      hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), 0, ctx->stream, plan_s, (const u32 *)ctx->list7.p,
                          (const u32 *)ctx->list10.p, recs, (const u32 *)ctx->row_ent.p, (const cache_ent *)kcs->ents.p, (const u32 *)kcs->pool7.p,
                          (const u32 *)kcs->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin_s, keyok_out, d_ok);
       HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));
@@ -1762,7 +1766,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     }
     HIPCHK(ctx, hipEventRecord(pair[0], ctx->stream));
   }
-  hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(256), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
+  hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
                      keyok_out, d_ok);
   if (time_kernel) {
@@ -1770,7 +1774,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     ctx->kev_mode[ctx->kev_n++] = mode == MODE_SCHNORR ? 1 : 0;
   }
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
-  hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(256), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
+  hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
                      keyok_out, d_ok);
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_cold, 0));

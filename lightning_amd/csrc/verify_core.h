@@ -713,6 +713,20 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
       pt.x = slot_load_fe(e + (half ? 8 : 0));
       pt.y = slot_load_fe(e + 16);
       pt = ge_neg_if_lazy(pt, top == (half ? cp.n2 : cp.n1));
+#if defined(LAMD_TOUCH_NEXT) && defined(__HIP_DEVICE_COMPILE__)
+      // experiment (not in the shipped build): touch the table entry of the NEXT addition before this one starts, so that its cache
+      // lines are on their way from HBM while the ~1000 multiply-adds of this addition issue.  One dword per coordinate, result unused.
+      if (half == 0 || j > 0) {
+        const int nj = half ? j - 1 : j, nh = half ? 0 : 1;
+        u32 nm = 0;
+#pragma unroll
+        for (int i = 0; i < T; i++) nm |= (((nh ? cp.tooth2[i] : cp.tooth1[i]) >> nj) & 1u) << i;
+        const u32 nidx = (((nm >> (T - 1)) & 1u) ? nm : ~nm) & (u32)(NE - 1);
+        const volatile u32 *ne_ = tab + nidx * SLOT_ENTRY_WORDS;
+        (void)ne_[nh ? 8 : 0];
+        (void)ne_[16];
+      }
+#endif
       if (j == D - 1 && half == 0) {  // uniform across the wave: the first point is the accumulator
         acc.x = pt.x;
         acc.y = fe_norm_weak(pt.y);
