@@ -123,6 +123,103 @@ BIP340 = [  # (index, seckey|None, pubkey, aux|None, msg, sig, expected, comment
 ]
 
 
+BECH32_CHARSET = "qpzry9x8gf2tvdw0s3jn54khce6mua7l"
+
+
+def bech32_nochecksum_decode(s):
+    """from_bech32_charset + bech32_pull_bits (common/bech32_util.c:15-116): hrp, payload bytes; a partial trailing byte is dropped"""
+    hrp, data = s.split("1", 1)
+    acc = bits = 0
+    out = bytearray()
+    for c in data:
+        acc = (acc << 5) | BECH32_CHARSET.index(c)
+        bits += 5
+        while bits >= 8:
+            bits -= 8
+            out.append((acc >> bits) & 0xFF)
+    return hrp, bytes(out)
+
+
+def harvest_bolt12(schnorr_rows, ref="/root/reference", fuzz_sample=24):
+    import re
+    rx = re.compile(r"(?<![a-z0-9])(ln[ir]1[%s]{150,})" % BECH32_CHARSET)
+    seen = {}
+    for root, dirs, files in os.walk(ref):
+        dirs.sort()
+        for f in sorted(files):
+            p = os.path.join(root, f)
+            if os.path.getsize(p) > 8 << 20:
+                continue
+            try:
+                txt = open(p, "r", errors="ignore").read()
+            except OSError:
+                continue
+            for ln, line in enumerate(txt.split("\n"), 1):
+                for m in rx.finditer(line):
+                    seen.setdefault(m.group(1), []).append("%s:%d" % (os.path.relpath(p, ref), ln))
+    rows, n_true, n_rej, n_bad = [], 0, 0, 0
+    for s, src in sorted(seen.items(), key=lambda kv: (("fuzz" in kv[1][0]), kv[1][0], kv[0])):
+        hrp, stream = bech32_nochecksum_decode(s)
+        mn = b"invoice" if hrp == "lni" else b"invoice_request"
+        keyt = 176 if hrp == "lni" else 88
+        fields = R.tlv_stream_parse(stream)
+        d = dict(fields) if fields is not None else {}
+        from_fuzz = "fuzz" in src[0]
+        if fields is None:
+            # a stream the generic TLV rules reject: the merkle front end must reject it as well (key / sig are dummies)
+            if n_bad >= fuzz_sample or len(stream) > 600:
+                continue
+            n_bad += 1
+            rows.append(dict(name="bolt12/ref-corpus/malformed/%d" % n_bad, stream=stream.hex(), messagename=mn.decode(), key="02" + "11" * 32,
+                             sig="22" * 64, expect=False, sighash=None, source=src[0]))
+            continue
+        if 240 not in d or keyt not in d or len(d[240]) != 64 or len(d[keyt]) != 33:
+            continue
+        got = R.bolt12_check_signature(stream, mn, b"signature", d[keyt], d[240])
+        if from_fuzz:
+            assert not got, src
+            if n_rej >= fuzz_sample or len(stream) > 600:
+                continue
+            n_rej += 1
+            name = "bolt12/ref-corpus/reject/%d" % n_rej
+        else:
+            assert got, ("a reference-held BOLT12 string does not verify", src)
+            n_true += 1
+            name = "bolt12/ref/%s/%d" % (hrp, n_true)
+        sighash = R.bolt12_sighash(mn, b"signature", R.bolt12_merkle(fields))
+        rows.append(dict(name=name, stream=stream.hex(), messagename=mn.decode(), key=d[keyt].hex(), sig=d[240].hex(), expect=got,
+                         sighash=sighash.hex(), source=", ".join(src[:4])))
+        # the derived BIP-340 triple (check_schnorr_sig drops the key's parity byte, bitcoin/signature.c:417-422)
+        schnorr_rows.append(dict(name=name, msg=sighash.hex(), pk=d[keyt][1:].hex(), sig=d[240].hex(), expect=got, source=", ".join(src[:4])))
+        if got:
+            # one-bit-flipped twins: in the signature's r, in its s, in a signed field, and the wrong message name
+            for what, pos in (("r", 0), ("s", 32 + 31)):
+                sg = bytearray(d[240])
+                sg[pos] ^= 0x04
+                st2 = stream.replace(d[240], bytes(sg))
+                assert not R.bolt12_check_signature(st2, mn, b"signature", d[keyt], bytes(sg))
+                rows.append(dict(name=name + "/flip-" + what, stream=st2.hex(), messagename=mn.decode(), key=d[keyt].hex(), sig=bytes(sg).hex(),
+                                 expect=False, sighash=sighash.hex(), source=src[0] + " (one bit flipped)"))
+                schnorr_rows.append(dict(name=name + "/flip-" + what, msg=sighash.hex(), pk=d[keyt][1:].hex(), sig=bytes(sg).hex(), expect=False,
+                                         source=src[0] + " (one bit flipped)"))
+            t0, v0 = fields[0]
+            if len(v0):
+                hdr = R.bigsize(t0) + R.bigsize(len(v0))
+                st2 = bytearray(stream)
+                st2[len(hdr)] ^= 0x01
+                st2 = bytes(st2)
+                assert not R.bolt12_check_signature(st2, mn, b"signature", d[keyt], d[240])
+                rows.append(dict(name=name + "/flip-field", stream=st2.hex(), messagename=mn.decode(), key=d[keyt].hex(), sig=d[240].hex(),
+                                 expect=False, sighash=None, source=src[0] + " (one bit of the first field flipped)"))
+            other = b"invoice_request" if mn == b"invoice" else b"invoice"
+            assert not R.bolt12_check_signature(stream, other, b"signature", d[keyt], d[240])
+            rows.append(dict(name=name + "/wrong-messagename", stream=stream.hex(), messagename=other.decode(), key=d[keyt].hex(), sig=d[240].hex(),
+                             expect=False, sighash=None, source=src[0]))
+    assert n_true >= 9, n_true
+    return rows
+
+
+
 def ecdsa_row(name, h, sig, pub, src, expect=None):
     got = R.ecdsa_verify(h, sig, pub)
     if expect is not None:
@@ -566,6 +663,21 @@ def main():
             e = R.ecdsa_recover(hh, sg, recid)
             out["recover"].append(dict(name="recover/tiny-r=%d/recid=%d" % (r, recid), hash=hh.hex(), sig=sg.hex(), recid=recid,
                                        expect=R.ser33(e).hex() if e else None, source="synth recover/v1"))
+
+    # ---- BOLT #12 strings the reference tree holds as literals: signed by libsecp256k1 inside lightningd when the reference's
+    # tests / schema examples were recorded (tests/test_misc.py:5254, tests/test_pay.py:7183, tests/test_xpay.py:788, the
+    # doc/schemas and contrib/msggen examples).  bech32 without checksum (common/bech32_util.c:74-116) -> TLV stream ->
+    # bolt12_check_signature(fields, "invoice" | "invoice_request", "signature", key, sig) (common/bolt12.c:80-92,558): key =
+    # invoice_node_id (type 176) for lni1, invreq_payer_id (type 88) for lnr1; sig = type 240.  Every one of them must verify --
+    # the first BIP-340 triples in the goldens that were signed by the reference's own library.  The fuzz corpus
+    # (tests/fuzz/corpora/fuzz-bolt12-invoice-decode) supplies reference-held damaged streams: a bounded sample of those goes in
+    # with pyref's verdict (reject: stream does not parse, or the signature does not verify).
+    if os.path.isdir("/root/reference"):
+        out["bolt12"] = harvest_bolt12(out["schnorr"])
+    else:
+        old = json.load(open(os.path.join(HERE, "kat.json")))
+        out["bolt12"] = old["bolt12"]
+        out["schnorr"] += [v for v in old["schnorr"] if v["name"].startswith("bolt12/")]
 
     path = os.path.join(HERE, "kat.json")
     with open(path, "w") as f:

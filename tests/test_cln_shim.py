@@ -334,3 +334,36 @@ def test_bolt12_check_signature_through_the_reference_prototype(shim):
     akey = Pubkey()
     assert shim.pubkey_from_der(pyref.ser33(alice), 33, ctypes.byref(akey))
     assert shim.bolt12_check_signature(fa, b"invoice_request", b"signature", ctypes.byref(akey), sig) is False
+
+
+@pytest.mark.gpu
+def test_bolt12_reference_held_strings_through_the_mirror(shim, kat):
+    """bolt12_check_signature() of the mirror (common/bolt12.c:80-92) on the lni1 / lnr1 literals the reference tree holds
+    (kat.json "bolt12"): the strings signed by the reference's libsecp256k1 verify, their damaged twins do not"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref
+    shim.shim_tal_dup.restype = ctypes.c_void_p
+    shim.shim_tal_dup.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    shim.bolt12_check_signature.restype = ctypes.c_bool
+    shim.bolt12_check_signature.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p]
+    n_true = 0
+    for v in kat["bolt12"]:
+        fields = pyref.tlv_stream_parse(bytes.fromhex(v["stream"]))
+        if fields is None:
+            continue                                   # fromwire_tlv already failed in the caller: the prototype takes parsed fields
+        arr = (TlvField * len(fields))()
+        keep = []
+        for i, (t, val) in enumerate(fields):
+            buf = ctypes.create_string_buffer(bytes(val), max(1, len(val)))
+            keep.append(buf)
+            arr[i].numtype, arr[i].length, arr[i].value = t, len(val), ctypes.cast(buf, ctypes.c_void_p).value
+        fa = shim.shim_tal_dup(None, bytes(arr), ctypes.sizeof(arr))
+        key = Pubkey()
+        if not shim.pubkey_from_der(bytes.fromhex(v["key"]), 33, ctypes.byref(key)):
+            assert not v["expect"]
+            continue
+        got = shim.bolt12_check_signature(fa, v["messagename"].encode(), b"signature", ctypes.byref(key), bytes.fromhex(v["sig"]))
+        assert got is v["expect"], v["name"]
+        n_true += got
+    assert n_true >= 9

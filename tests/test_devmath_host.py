@@ -639,6 +639,29 @@ def test_bolt12_merkle_host_build_vs_pyref_and_spec_vectors(dm):
     assert dm.dm_bolt12(ok, len(ok), b"invoice", b"signature", root, sh) == 1
 
 
+def test_bolt12_reference_held_strings_host_build(dm, kat):
+    """the device's BOLT #12 front end (host build) + its BIP-340 pipeline on the reference-held lni1 / lnr1 strings (kat.json "bolt12")"""
+    dm.dm_bolt12.restype = ctypes.c_int
+    dm.dm_bolt12.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    root, sh = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    msgs, pks, sigs, exp = [], [], [], []
+    for v in kat["bolt12"]:
+        st = H(v["stream"])
+        ok = dm.dm_bolt12(st, len(st), v["messagename"].encode(), b"signature", root, sh)
+        fields = pyref.tlv_stream_parse(st)
+        m = pyref.bolt12_merkle(fields) if fields is not None else None
+        assert (ok == 1) == (m is not None), v["name"]
+        if not ok:
+            assert not v["expect"]
+            continue
+        assert root.raw == m and sh.raw == pyref.bolt12_sighash(v["messagename"].encode(), b"signature", m), v["name"]
+        msgs.append(sh.raw); pks.append(H(v["key"])[1:]); sigs.append(H(v["sig"])); exp.append(v["expect"])
+    n = len(msgs)
+    out = ctypes.create_string_buffer(n)
+    dm.dm_schnorr_verify_batch(ctypes.c_size_t(n), b"".join(msgs), b"".join(pks), b"".join(sigs), out)
+    assert [bool(x) for x in out.raw] == exp and sum(exp) >= 9
+
+
 def test_sc29_scalar_arithmetic_vs_integers(dm):
     """the 9x29-limb arithmetic mod n that the ECDSA preparation runs in (prefix products, shared inversion, u1, u2): products of
     arbitrary 256-bit values (not only residues), chains of lazy values, inversion -- against Python integers; edge operands"""

@@ -934,6 +934,36 @@ def test_check_tx_sig_from_transaction_templates_vs_spec_model(eng, orc):
 
 
 @pytest.mark.gpu
+def test_bolt12_reference_held_strings_on_device(eng, kat):
+    """The lni1 / lnr1 literals of the reference tree (tests/test_misc.py:5254, tests/test_pay.py:7183, tests/test_xpay.py:788,
+    doc/schemas -- signed by the reference's libsecp256k1; kat.json "bolt12"): lamd_bolt12_check_signature_batch must accept every
+    one, reject their one-bit twins and the fuzz corpus' damaged streams; the sighash the device derives is the recorded one; and
+    the derived (sighash, x-only key, signature) triples agree through lamd_verify_schnorr_batch"""
+    rows = kat["bolt12"]
+    assert sum(1 for v in rows if v["expect"]) >= 9
+    for mn in (b"invoice", b"invoice_request"):
+        grp = [v for v in rows if v["messagename"].encode() == mn]
+        assert grp
+        streams = [H(v["stream"]) for v in grp]
+        got = eng.bolt12_check_signature_batch(streams, mn, b"signature", _rows([H(v["key"]) for v in grp], 33), _rows([H(v["sig"]) for v in grp], 64))
+        bad = [v["name"] for v, g in zip(grp, got) if bool(g) != v["expect"]]
+        assert not bad, bad
+        mk, sh, ok = eng.bolt12_merkle_batch(streams, mn, b"signature")
+        for i, v in enumerate(grp):
+            fields = pyref.tlv_stream_parse(streams[i])
+            m = pyref.bolt12_merkle(fields) if fields is not None else None
+            assert bool(ok[i]) == (m is not None), v["name"]
+            if m is not None:
+                assert bytes(mk[i]) == m and bytes(sh[i]) == pyref.bolt12_sighash(mn, b"signature", m), v["name"]
+                if v["sighash"] is not None and "flip-field" not in v["name"]:
+                    assert bytes(sh[i]).hex() == v["sighash"]
+    tri = [v for v in kat["schnorr"] if v["name"].startswith("bolt12/")]
+    assert sum(1 for v in tri if v["expect"]) >= 9
+    got = eng.verify_schnorr(_rows([H(v["msg"]) for v in tri], 32), _rows([H(v["pk"]) for v in tri], 32), _rows([H(v["sig"]) for v in tri], 64))
+    assert [bool(g) for g in got] == [v["expect"] for v in tri]
+
+
+@pytest.mark.gpu
 def test_bolt12_signatures_device_front_end_vs_spec_model(eng):
     """BOLT #12 (rest of N4): merkle_tlv + sighash_from_merkle + check_schnorr_sig on the device (lamd_bolt12_check_signature_batch)
     -- the specification's n1 roots, the invoice_request of common/test/run-bolt12_merkle.c:332-361 (Alice 0x41.., Bob 0x42.. signs),

@@ -37,6 +37,32 @@ def test_kat_schnorr(kat, orc):
         assert orc.schnorr_verify(H(v["msg"]), H(v["pk"]), H(v["sig"])) == v["expect"], v["name"]
 
 
+def test_kat_bolt12_reference_held_strings(kat, orc):
+    """The BOLT #12 strings the reference tree holds as literals (tests/test_misc.py:5254, tests/test_pay.py:7183,
+    tests/test_xpay.py:788, doc/schemas/*.json ...; decoded by tests/golden/make_golden.py harvest_bolt12): signed by the
+    reference's own libsecp256k1, so every one must verify -- merkle_tlv + sighash_from_merkle + BIP-340 in the spec model AND the C
+    oracle; their one-bit-flipped twins and the fuzz corpus' damaged streams must not."""
+    rows = kat["bolt12"]
+    ref = [v for v in rows if v["name"].startswith("bolt12/ref/") and v["name"].count("/") == 3]
+    assert len(ref) >= 9 and all(v["expect"] for v in ref)
+    assert any("tests/test_misc.py:5254" in v["source"] for v in ref) and any("tests/test_pay.py:7183" in v["source"] for v in ref)
+    assert sum(1 for v in rows if not v["expect"]) >= 60
+    for v in rows:
+        st, key, sig, mn = H(v["stream"]), H(v["key"]), H(v["sig"]), v["messagename"].encode()
+        assert pyref.bolt12_check_signature(st, mn, b"signature", key, sig) == v["expect"], v["name"]
+        fields = pyref.tlv_stream_parse(st)
+        m = pyref.bolt12_merkle(fields) if fields is not None else None
+        if m is None:
+            assert not v["expect"]
+            continue
+        sh = pyref.bolt12_sighash(mn, b"signature", m)
+        if v["sighash"] is not None and "flip-field" not in v["name"]:
+            assert sh.hex() == v["sighash"], v["name"]
+        assert orc.schnorr_verify(sh, key[1:], sig) == v["expect"], v["name"]          # the C oracle on the derived triple
+    # the derived triples are ordinary schnorr goldens too (every schnorr test of the suite runs them)
+    assert sum(1 for v in kat["schnorr"] if v["name"].startswith("bolt12/ref/") and v["expect"]) >= 9
+
+
 def test_kat_gossip(kat, orc):
     for v in kat["gossip"]:
         m = H(v["msg"])
