@@ -24,7 +24,7 @@
  *  - check_tx_sig() has the reference's prototype (bitcoin/signature.h:120-124).  `struct bitcoin_tx` here is a plain
  *    mirror of what that path reads from the reference's libwally-backed one (version, locktime, inputs with the amounts
  *    the PSBT carries, outputs); the two script arguments are tal-style arrays whose length travels with the pointer
- *    (tal_bytelen(), as in the reference) -- make them with shim_tal_dup().  The BIP143 hash of
+ *    (shim_tal_bytelen(); tal_bytelen() in the reference) -- make them with shim_tal_dup().  The BIP143 hash of
  *    bitcoin_tx_hash_for_sig() (:120-151) is computed on the device.
  *  - all elliptic-curve work (key decompression, verification) runs on the GPU through
  *    lamd_*; hashing and DER/compact parsing are host code.  Without a device every check
@@ -78,9 +78,13 @@ bool check_signed_hash(const struct sha256_double *hash, const secp256k1_ecdsa_s
 bool check_signed_hash_nodeid(const struct sha256_double *hash, const secp256k1_ecdsa_signature *signature,
 			      const struct node_id *id);
 bool check_schnorr_sig(const struct sha256 *hash, const secp256k1_pubkey *pubkey, const struct bip340sig *sig);
-/* tal-style byte arrays: the length is stored in front of the data, tal_bytelen() reads it (ccan/tal in the reference) */
+/* tal-style byte arrays: the length is stored in front of the data; shim_tal_bytelen() reads it (the role of ccan/tal's
+ * tal_bytelen() in the reference -- deliberately NOT that name, so that the mirror can be linked next to the real ccan/tal;
+ * built with -DLAMD_SHIM_WITH_CCAN_TAL it forwards to ccan's).  A pointer that did not come from shim_tal_dup() gives
+ * SHIM_TAL_FOREIGN and the check that was handed it fails closed (false), it does not abort(). */
+#define SHIM_TAL_FOREIGN ((size_t)-1)
 u8 *shim_tal_dup(const tal_t *ctx, const u8 *src, size_t len);
-size_t tal_bytelen(const void *ptr);
+size_t shim_tal_bytelen(const void *ptr);
 void shim_tal_free(const void *ptr);
 
 /* what check_tx_sig()/bitcoin_tx_hash_for_sig() read from the reference's struct bitcoin_tx (bitcoin/tx.h: wtx + psbt) */
@@ -109,7 +113,7 @@ bool check_tx_sig_preimage(const u8 *bip143_preimage, size_t preimage_len, const
 			   const struct pubkey *key, const struct bitcoin_signature *sig);
 
 /* BOLT #12 (common/bolt12.c:80-92, common/bolt12_merkle.h:8-12,70-79).  `fields` is a tal-style array of struct tlv_field
- * (wire/tlvstream.h:16-26; make it with shim_tal_dup(): tal_count = tal_bytelen / sizeof) in stream order; the merkle tree and the tagged
+ * (wire/tlvstream.h:16-26; make it with shim_tal_dup(): tal_count = shim_tal_bytelen / sizeof) in stream order; the merkle tree and the tagged
  * hash are computed on the device from the re-serialised fields, the verification is check_schnorr_sig()'s. */
 struct tlv_field {
 	const void *meta;   /* const struct tlv_record_type *: unused here */

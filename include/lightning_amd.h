@@ -48,9 +48,10 @@ enum {
  * (secp256k1_ctx = wally_get_secp_context(), common/utils.c:16): the one-time work here is the
  * upload/build of the static table of G multiples in HBM.
  * Hardware queues: the context runs its calls on several HIP streams ("lanes", LAMD_LANES) that only overlap when each has a
- * hardware queue of its own.  ROCm reads GPU_MAX_HW_QUEUES (default 4) at the runtime's FIRST call: this library sets it to 16
- * from a load-time constructor unless the host already set it -- a host that initialises HIP before loading the library should
- * export GPU_MAX_HW_QUEUES=16 itself.  Create the context BEFORE an RCCL communicator (ncclCommInitRank / torch.distributed
+ * hardware queue of its own.  ROCm reads GPU_MAX_HW_QUEUES (default 4) at the runtime's FIRST call.  PRECONDITION for full
+ * throughput: the host process exports GPU_MAX_HW_QUEUES=16 (or setenv()s it) BEFORE its first HIP call -- the library does not
+ * touch the process environment.  lamd_init() records what it found (lamd_info.hw_queues_env; 0 = unset, i.e. the runtime's 4:
+ * the lanes then share queues and the pipelined loop runs ~7 % slower, nothing else changes).  Create the context BEFORE an RCCL communicator (ncclCommInitRank / torch.distributed
  * init_process_group): RCCL's own streams otherwise take hardware queues first and the lanes end up sharing one (measured:
  * -8 % on the 2 M-row step).  Correctness does not depend on either (tests run at 4, 16 and 32 queues). */
 int lamd_init(lamd_ctx **ctx, int device);
@@ -234,24 +235,8 @@ int lamd_flush(lamd_ctx *ctx);
 int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
 int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
 
-/* ---- synthetic workload generation ON THE DEVICE (role of devtools/mkgossip.c:131-147,235-322
- * in the reference: producing signed test traffic).  Keys and nonces are derived from the seed
- * with splitmix64; outputs are device buffers.  Not a signing API: secrets are public by
- * construction. */
-/* group: rows are cut into groups of `group` consecutive rows sharing one key (the 483 HTLC
- * signatures of a commitment share remote_htlckey, channeld/channeld.c:2224-2225); 0 = every row
- * draws its key independently from the nkeys identities. */
-int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group, size_t publen,
-			  void *d_hash32, void *d_sig64, void *d_pub);
-int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group,
-			    void *d_msg32, void *d_xonly32, void *d_sig64);
-/* n_cann channel_announcements (432 bytes each, no features, 4 signatures, node keys drawn from
- * n_nodes identities, bitcoin keys unique) followed by n_cupd channel_updates (138 bytes) signed by
- * one of the referenced channel's nodes -- built and signed like devtools/mkgossip.c:131-147,235-322.
- * d_msgs: n_cann*432 + n_cupd*138 bytes; d_node_ids33: (n_cann+n_cupd)*33 bytes (the update's signer;
- * zero for announcements). */
-int lamd_gen_gossip_device(lamd_ctx *ctx, size_t n_cann, size_t n_cupd, uint64_t seed, size_t n_nodes,
-			   void *d_msgs, void *d_node_ids33);
+/* Synthetic signed test traffic (the signer kernels tests/ and bench.py use) is NOT in this library: see
+ * include/lightning_amd_testgen.h -> liblightning_amd_testgen.so. */
 
 /* Diagnostics (device self-test, arithmetic fuzzers, work-buffer peeks) live in lightning_amd_debug.h: they are exported by the
  * same library but are not part of the drop-in boundary. */
@@ -280,6 +265,7 @@ typedef struct {
 	 * of this lane since lamd_set_timing(ctx, 1); summed by lamd_synchronize() */
 	double keyed_ecmult_ms_sum[2];
 	size_t keyed_ecmult_launches[2];
+	int hw_queues_env;        /* GPU_MAX_HW_QUEUES as lamd_init() found it (0 = unset: the runtime's default of 4; < 16 costs overlap between the lanes) */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 .. lanes-1 */

@@ -31,6 +31,10 @@ int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 i
  * validity, 7 distinct-key affine words, 8 key tables) to host memory.  Tests only. */
 int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out);
 
+/* The static G table in device memory (12 windows x 2^22 affine entries): read by the test-traffic signer kernels of
+ * liblightning_amd_testgen.so.  NULL without a context. */
+const void *lamd_debug_gtable(lamd_ctx *ctx);
+
 /* Randomised arithmetic fuzz ON THE DEVICE: `lanes` lanes x `iters` iterations; every iteration draws operands at the
  * magnitude limits the group law uses (limbs up to 7 x 2^29, a fifth of them exactly at the bound) and runs fe_mul in
  * every legal magnitude pairing, fe_sqr, the lazy add/neg/normalisations, gej_double and the mixed addition with live

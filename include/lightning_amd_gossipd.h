@@ -97,14 +97,21 @@ int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, const uint8
  * peer_stride 0: one peer for all) */
 int lamd_gossipd_push_batch(lamd_gossipd *g, size_t n, const uint8_t *source_peers33, size_t peer_stride, const uint8_t *msgs,
 			    const uint64_t *off);
-/* Drains the queue as ONE batch (see above).  Returns the number of messages applied, or a negative LAMD_ERR_*. */
+/* Drains the queue as ONE batch (see above).  Returns the number of messages applied, or a negative LAMD_ERR_*: after an
+ * engine error nothing is lost -- the messages that were not applied are back at the head of the queue, in order, and no peer
+ * has been sent a warning because of it.
+ * NOT re-entrant: the event callback runs inside this call and must not call lamd_gossipd_process / _txout_reply[_batch] /
+ * _new_block (they return LAMD_ERR_STATE); collect the LAMD_GEV_GET_TXOUT requests and answer them after it returns.
+ * lamd_gossipd_push[_batch] from the callback is fine. */
 long lamd_gossipd_process(lamd_gossipd *g);
 /* lightningd's answer to LAMD_GEV_GET_TXOUT (gossmap_manage.c:753-872); script_len 0 = no unspent output.  Channel_updates
  * and node_announcements that were waiting are verified (one batch) and applied once nothing is pending any more. */
 int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const uint8_t *script, size_t script_len);
-/* n replies in order (reply i's script: scripts + script_off[i] .. script_off[i+1]) */
+/* n replies in order (reply i's script: scripts + script_off[i] .. script_off[i+1]).  *applied (may be NULL) = how many
+ * replies took effect; on an error return the caller resumes with reply *applied + 1 (reply *applied itself registered its
+ * channel; the updates that waited for it stay queued until the next successful reply or process()). */
 int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const uint64_t *scids, const uint64_t *sats, const uint8_t *scripts,
-				   const uint64_t *script_off);
+				   const uint64_t *script_off, size_t *applied);
 /* gossmap_manage_new_block (:1358-1390): too-early announcements that are now deep enough become pending */
 int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight);
 void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now);

@@ -7,13 +7,18 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "liblightning_amd.so")
 SOURCES = [os.path.join(CSRC, f) for f in ("lamd_engine.hip", "verify_core.h", "group.h", "fe.h", "fe_asm.inc", "fuzz.h", "scalar.h", "sha256.h",
-                                           "lamd_common.h")] + [
+                                           "lamd_common.h", "bolt12.h")] + [
     os.path.join(ROOT, "include", "lightning_amd.h"), os.path.join(ROOT, "include", "lightning_amd_debug.h")]
 
 
+# test / bench infrastructure: the synthetic-workload signer kernels (include/lightning_amd_testgen.h)
+TESTGEN = os.path.join(PKG, "liblightning_amd_testgen.so")
+TESTGEN_SOURCES = [os.path.join(CSRC, f) for f in ("lamd_testgen.hip", "verify_core.h", "group.h", "fe.h", "fe_asm.inc", "scalar.h", "sha256.h", "lamd_common.h")] + [
+    os.path.join(ROOT, "include", "lightning_amd_testgen.h")]
+
 SHIM = os.path.join(PKG, "liblightning_amd_cln.so")
 SHIM_CPP = [os.path.join(CSRC, "cln_shim.cpp"), os.path.join(CSRC, "gossip_ingest.cpp")]
-SHIM_SOURCES = SHIM_CPP + [os.path.join(CSRC, "cln_shim.h"), os.path.join(CSRC, "verify_core.h"), os.path.join(ROOT, "include", "lightning_amd_gossipd.h")]
+SHIM_SOURCES = SHIM_CPP + [os.path.join(ROOT, "include", "cln_shim.h"), os.path.join(CSRC, "verify_core.h"), os.path.join(ROOT, "include", "lightning_amd_gossipd.h")]
 
 
 def build_shim(force=False):
@@ -25,6 +30,17 @@ def build_shim(force=False):
                           ["-L" + PKG, "-llightning_amd", "-Wl,-rpath,$ORIGIN"])
     os.replace(SHIM + ".tmp", SHIM)
     return SHIM
+
+
+def build_testgen(force=False):
+    if not force and os.path.exists(TESTGEN) and all(os.path.getmtime(x) <= os.path.getmtime(TESTGEN) for x in TESTGEN_SOURCES):
+        return TESTGEN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                           "-mllvm", "-amdgpu-codegenprepare-mul24=false", "-o", TESTGEN + ".tmp", os.path.join(CSRC, "lamd_testgen.hip"),
+                           "-L" + PKG, "-llightning_amd", "-Wl,-rpath,$ORIGIN"])
+    os.replace(TESTGEN + ".tmp", TESTGEN)
+    return TESTGEN
 
 
 def is_stale():
@@ -40,6 +56,7 @@ EXTRA = os.environ.get("LAMD_BUILD_FLAGS", "").split()
 def build(force=False, verbose=False):
     if not (force or is_stale()):
         build_shim()
+        build_testgen()
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-codegenprepare-mul24=false: ROCm 7.2's AMDGPUCodeGenPrepare mul24 rewrite miscompiles the fused
@@ -54,4 +71,5 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     build_shim(force=True)
+    build_testgen()
     return LIB

@@ -15,7 +15,7 @@ class LamdInfo(ctypes.Structure):
                 ("last_cache_hits", ctypes.c_size_t), ("last_cold_rows", ctypes.c_size_t), ("last_new_tables", ctypes.c_size_t),
                 ("last_suspect_rows", ctypes.c_size_t), ("cache_enabled", ctypes.c_int), ("cache_entries", ctypes.c_size_t),
                 ("cache_capacity", ctypes.c_size_t), ("cache_resets", ctypes.c_size_t),
-                ("keyed_ecmult_ms_sum", ctypes.c_double * 2), ("keyed_ecmult_launches", ctypes.c_size_t * 2)]
+                ("keyed_ecmult_ms_sum", ctypes.c_double * 2), ("keyed_ecmult_launches", ctypes.c_size_t * 2), ("hw_queues_env", ctypes.c_int)]
 
 
 # name -> (restype, argtypes); every symbol of include/lightning_amd.h and include/lightning_amd_debug.h
@@ -51,15 +51,13 @@ SYMBOLS = {
     "lamd_flush": (ctypes.c_int, [ctypes.c_void_p]),
     "lamd_poll": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
     "lamd_wait": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
-    "lamd_gen_ecdsa_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
-    "lamd_gen_schnorr_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
-    "lamd_gen_gossip_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz, ctypes.c_uint64, c_sz, c_u8p, c_u8p]),
     "lamd_sigcheck_gossip_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_u8p]),
     "lamd_selftest": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, ctypes.c_char_p, c_sz]),
     "lamd_chain_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, c_sz]),
     "lamd_inv_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_x2_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_debug_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_sz, c_sz, c_u8p]),
+    "lamd_debug_gtable": (ctypes.c_void_p, [ctypes.c_void_p]),
     "lamd_fuzz_field": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, c_sz]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -73,7 +71,15 @@ SYMBOLS = {
     "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
 }
 
+# include/lightning_amd_testgen.h -> liblightning_amd_testgen.so (test / bench infrastructure: the signer kernels)
+TESTGEN_SYMBOLS = {
+    "lamd_gen_ecdsa_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_gen_schnorr_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_uint64, c_sz, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_gen_gossip_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz, ctypes.c_uint64, c_sz, c_u8p, c_u8p]),
+}
+
 _lib = None
+_testgen = None
 
 
 def load(build_if_needed=True):
@@ -102,3 +108,18 @@ def load(build_if_needed=True):
             f.argtypes = args
         _lib = L
     return _lib
+
+
+def load_testgen():
+    """dlopen liblightning_amd_testgen.so (synthetic signed workloads for tests/ and bench.py; not part of the product)"""
+    global _testgen
+    if _testgen is None:
+        load()
+        path = _build.build_testgen() if os.path.exists("/opt/rocm/bin/hipcc") else _build.TESTGEN
+        L = ctypes.CDLL(path)
+        for name, (res, args) in TESTGEN_SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _testgen = L
+    return _testgen

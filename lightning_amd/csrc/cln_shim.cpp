@@ -1,7 +1,7 @@
 // Host mirror of the reference's prototypes over the C ABI (see cln_shim.h).  Host code here is
 // framing only: SHA-256 of message tails / preimages, DER and compact parsing, error strings.
 // Every elliptic-curve decision is made by the HIP kernels behind lamd_*.
-#include "cln_shim.h"
+#include "../../include/cln_shim.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,12 +50,21 @@ extern "C" u8 *shim_tal_dup(const tal_t *, const u8 *src, size_t len) {
   if (len) memcpy(h + 1, src, len);
   return (u8 *)(h + 1);
 }
-extern "C" size_t tal_bytelen(const void *ptr) {
+// Named shim_tal_bytelen, NOT tal_bytelen: linked next to the real ccan/tal inside lightningd a second global `tal_bytelen` would
+// either be a duplicate definition or interpose ccan's (which would then read this header layout on genuine tal arrays, or the
+// other way round).  In-tree build: compile with -DLAMD_SHIM_WITH_CCAN_TAL and the lengths come from ccan's own tal_bytelen().
+// A pointer that is not one of shim_tal_dup()'s fails closed: SHIM_TAL_FOREIGN, and the caller reports "does not verify".
+#if defined(LAMD_SHIM_WITH_CCAN_TAL)
+extern "C" size_t tal_bytelen(const void *ptr);  // ccan/tal/tal.h
+extern "C" size_t shim_tal_bytelen(const void *ptr) { return ptr ? tal_bytelen(ptr) : 0; }
+#else
+extern "C" size_t shim_tal_bytelen(const void *ptr) {
   if (!ptr) return 0;
   const tal_hdr *h = (const tal_hdr *)ptr - 1;
-  if (h->magic != TAL_MAGIC) abort();  // not a tal array: the reference would read garbage too
+  if (h->magic != TAL_MAGIC) return SHIM_TAL_FOREIGN;
   return h->len;
 }
+#endif
 extern "C" void shim_tal_free(const void *ptr) {
   if (ptr) free((tal_hdr *)ptr - 1);
 }
@@ -247,12 +256,15 @@ extern "C" bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, cons
   }
   for (size_t i = 0; i < tx->num_outputs; i++) {
     for (int b = 0; b < 8; b++) out.push_back((char)(tx->outputs[i].amount_sat >> (8 * b)));
-    const size_t sl = tal_bytelen(tx->outputs[i].script);
+    const size_t sl = shim_tal_bytelen(tx->outputs[i].script);
+    if (sl == SHIM_TAL_FOREIGN) { g_err = "check_tx_sig: output script is not a tal array"; return false; }
     put_compact_size(out, sl);
     out.append((const char *)tx->outputs[i].script, sl);
   }
   const uint32_t version = tx->version, locktime = tx->locktime, inum = (uint32_t)input_num, nout = (uint32_t)tx->num_outputs;
-  const uint64_t in_off[2] = {0, tx->num_inputs}, out_off[2] = {0, out.size()}, sc_off[2] = {0, tal_bytelen(script)};
+  const size_t script_len = shim_tal_bytelen(script);
+  if (script_len == SHIM_TAL_FOREIGN) { g_err = "check_tx_sig: script is not a tal array"; return false; }
+  const uint64_t in_off[2] = {0, tx->num_inputs}, out_off[2] = {0, out.size()}, sc_off[2] = {0, script_len};
   const uint64_t amount = tx->inputs[input_num].amount_sat;
   const u8 type = (u8)sig->sighash_type, wit = use_segwit ? 1 : 0;
   u8 pub65[65], ok = 0;
@@ -273,19 +285,21 @@ static void put_bigsize(std::string &o, uint64_t v) {
   else if (v <= 0xffffffffull) { o.push_back((char)0xfe); for (int i = 3; i >= 0; i--) o.push_back((char)(v >> (8 * i))); }
   else { o.push_back((char)0xff); for (int i = 7; i >= 0; i--) o.push_back((char)(v >> (8 * i))); }
 }
-static std::string serialise_fields(const struct tlv_field *fields) {
-  std::string o;
-  const size_t n = tal_bytelen(fields) / sizeof(struct tlv_field);
+static bool serialise_fields(const struct tlv_field *fields, std::string &o) {
+  const size_t bytes = shim_tal_bytelen(fields);
+  if (bytes == SHIM_TAL_FOREIGN) { g_err = "bolt12: fields is not a tal array"; return false; }
+  const size_t n = bytes / sizeof(struct tlv_field);
   for (size_t i = 0; i < n; i++) {
     put_bigsize(o, fields[i].numtype);
     put_bigsize(o, fields[i].length);
     o.append((const char *)fields[i].value, fields[i].length);
   }
-  return o;
+  return true;
 }
 static bool bolt12_hashes(const struct tlv_field *fields, const char *messagename, const char *fieldname, u8 *merkle32, u8 *sighash32) {
   if (!g_ctx && !lamd_shim_setup()) return false;
-  const std::string st = serialise_fields(fields);
+  std::string st;
+  if (!serialise_fields(fields, st)) return false;
   const uint64_t off[2] = {0, st.size()};
   u8 ok = 0, dummy = 0;
   const int rc = lamd_bolt12_merkle_batch(g_ctx, 1, st.empty() ? &dummy : (const u8 *)st.data(), off, messagename, fieldname, merkle32, sighash32, &ok);
@@ -306,7 +320,8 @@ extern "C" void sighash_from_merkle(const char *messagename, const char *fieldna
 extern "C" bool bolt12_check_signature(const struct tlv_field *fields, const char *messagename, const char *fieldname, const struct pubkey *key,
                                        const struct bip340sig *sig) {
   if (!g_ctx && !lamd_shim_setup()) return false;
-  const std::string st = serialise_fields(fields);
+  std::string st;
+  if (!serialise_fields(fields, st)) return false;
   const uint64_t off[2] = {0, st.size()};
   u8 der[PUBKEY_CMPR_LEN], ok = 0, dummy = 0;
   pubkey_to_der(der, key);

@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "../../include/lightning_amd_gossipd.h"
-#include "cln_shim.h"
+#include "../../include/cln_shim.h"
 #include "verify_core.h"  // gossip_parse_frame(): the same framing rules the device applies
 
 namespace {
@@ -356,10 +356,15 @@ struct lamd_gossipd {
     const uint64_t off[2] = {0, m.size()};
     int8_t v = -2;
     const int rc = backend_sigcheck(1, m.data(), off, signer ? signer->k : nullptr, &v);
-    const int out = rc == LAMD_OK ? v : -2;
-    verdicts[k] = out;
-    return out;
+    if (rc != LAMD_OK || v == -2) {  // a back-end failure is NOT a verdict: nothing is remembered, the caller leaves the message
+      fault_rc = rc != LAMD_OK ? rc : LAMD_ERR_HIP;  // unapplied and lamd_gossipd_process() / txout_reply() return this code
+      return -2;
+    }
+    verdicts[k] = v;
+    return v;
   }
+  int fault_rc = LAMD_OK;     // set by verdict_of(): an engine error during the ordered replay (never a peer-visible warning)
+  bool in_process = false;    // lamd_gossipd_process() is applying a batch: callbacks must not re-enter the state-changing entry points
 
   struct slotlist {
     std::vector<const bytes *> msg;
@@ -418,7 +423,7 @@ struct lamd_gossipd {
       if (p.keyslot < 0) {
         v = verdict_of(m, nullptr);
         if (v == -1) { err = "Malformed channel_announcement " + hexs(m); break; }  // an invalid bitcoin key: fromwire_pubkey
-        if (v == -2) { err = "engine error"; break; }
+        if (v == -2) return;  // engine fault: not consumed (fault_rc)
       }
       const gossip_frame f = gossip_parse_frame(m.data(), m.size());
       const size_t flen = be16(&m[258]);
@@ -435,7 +440,7 @@ struct lamd_gossipd {
       if (known_scid(scid)) return;                                   // :684-687
       if (p.keyslot >= 0) {  // the plan expected one of the drops above: verify now (never seen in practice)
         v = verdict_of(m, nullptr);
-        if (v == -2) { err = "engine error"; break; }
+        if (v == -2) return;
       }
       if (v > 0) { err = sigcheck_text(GOSSIP_CANN, v, m); break; }   // :689-696
       pending_cannounce pca;
@@ -488,7 +493,7 @@ struct lamd_gossipd {
     }
     chan &c = it->second;
     const int v = verdict_of(upd, &c.node[dir]);  // :920-926
-    if (v == -2) return "engine error";
+    if (v == -2) return "";  // engine fault (fault_rc): the caller keeps the update
     if (v != 0) return sigcheck_text(GOSSIP_CUPD, 1, upd);
     if (u.mflags & 2) return "Do not set DONT_FORWARD on public channel_updates (" + fmt_scid(u.scid) + ")";  // :929-932
     if (c.set[dir]) {  // :935-946
@@ -539,9 +544,13 @@ struct lamd_gossipd {
       if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
       if (pending_ann.count(u.scid)) { u.update = m; pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
       if (early_ann.count(u.scid)) { u.update = m; early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
-      if (!chans.count(u.scid) && q.has_src && verdict_of(m, &q.src) == 0) {                // :1107-1116
-        peer_update(true, &q.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);
-        return;
+      if (!chans.count(u.scid) && q.has_src) {                                             // :1107-1116
+        const int pv = verdict_of(m, &q.src);
+        if (pv == -2) return;
+        if (pv == 0) {
+          peer_update(true, &q.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);
+          return;
+        }
       }
       err = process_channel_update(u, m);
     } while (0);
@@ -577,7 +586,7 @@ struct lamd_gossipd {
       if (p.malformed) { err = "node_announcement: malformed " + hexs(m); break; }  // :1197-1198
       if (p.addrs_bad) { err = "node_announcement: malformed wireaddrs  in " + hexs(m); break; }  // :1210-1213 (tal_hex(NULL) is "")
       const int v = verdict_of(m, nullptr);
-      if (v == -2) { err = "engine error"; break; }
+      if (v == -2) return;
       if (v == -1) { err = "node_announcement: malformed " + hexs(m); break; }
       if (v != 0) { err = sigcheck_text(GOSSIP_NANN, 1, m); break; }  // :1216-1219
       const gossip_frame f = gossip_parse_frame(m.data(), m.size());
@@ -625,7 +634,9 @@ struct lamd_gossipd {
     const int rc = verify(sl);
     if (rc != LAMD_OK) return rc;
     auto process_pending = [&](const pending_cupdate &u) {  // :1245-1268
+      if (fault_rc != LAMD_OK) { pending_cupdates.push_back(u); return; }  // after an engine fault the rest keeps waiting, in order
       const std::string err = process_channel_update(u, u.update);
+      if (fault_rc != LAMD_OK) { pending_cupdates.push_back(u); return; }
       if (!err.empty()) peer_warning(u.has_src, &u.src, "channel_update: " + err);
     };
     // (the lists outlive the verdict map: its keys refer to their messages)
@@ -642,7 +653,7 @@ struct lamd_gossipd {
         process_pending(u);
       }
     }
-    if (early_empty && pending_empty) {
+    if (early_empty && pending_empty && fault_rc == LAMD_OK) {
       ln.swap(pending_nannounces);
       for (const pending_nannounce &pn : ln) {
         auto it = nodes.find(pn.id);
@@ -651,7 +662,9 @@ struct lamd_gossipd {
       }
     }
     drop_verdicts();
-    return LAMD_OK;
+    const int frc = fault_rc;
+    fault_rc = LAMD_OK;
+    return frc;
   }
 
   static void sha256_single(const u8 *p, size_t len, u8 out[32]);
@@ -719,6 +732,7 @@ extern "C" int lamd_gossipd_push_batch(lamd_gossipd *g, size_t n, const uint8_t 
 
 extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   if (!g) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;
   std::vector<queued> batch;
   batch.swap(g->queue);
   const size_t n = batch.size();
@@ -781,7 +795,10 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     rc = g->backend_keyparse(keyok.size(), keyblob.data(), keyok.data());
     if (rc != LAMD_OK) { g->drop_verdicts(); g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
   }
-  // ---- apply in arrival order
+  // ---- apply in arrival order.  Event callbacks fire from here: they must not re-enter lamd_gossipd_process / _txout_reply /
+  // _new_block (those return LAMD_ERR_STATE while in_process is set -- answer LAMD_GEV_GET_TXOUT after process() returns; _push is fine).
+  g->in_process = true;
+  g->fault_rc = LAMD_OK;
   for (size_t i = 0; i < n; i++) {
     const queued &q = batch[i];
     const planned &p = plan[i];
@@ -789,14 +806,24 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     else if (p.type == GOSSIP_CUPD) g->apply_cupd(q, p);
     else if (p.type == GOSSIP_NANN) g->apply_nann(q, p);
     // other types never reach gossipd's three handlers (gossipd.c:206-264)
+    if (g->fault_rc != LAMD_OK) {  // an engine error in a late verify: message i and everything after it go back to the queue, unapplied
+      const int frc = g->fault_rc;
+      g->fault_rc = LAMD_OK;
+      g->drop_verdicts();
+      g->queue.insert(g->queue.begin(), std::make_move_iterator(batch.begin() + i), std::make_move_iterator(batch.end()));
+      g->in_process = false;
+      return frc;
+    }
     g->st.messages++;
   }
   g->drop_verdicts();
+  g->in_process = false;
   return (long)n;
 }
 
 extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const uint8_t *script, size_t script_len) {
   if (!g) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;  // called from an event callback: the batch being applied assumes chans / the verdict slots stay put
   auto it = g->pending_ann.find(scid);
   if (it == g->pending_ann.end()) return LAMD_OK;  // :770-780
   pending_cannounce pca = std::move(it->second);
@@ -833,19 +860,23 @@ extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t
 }
 
 extern "C" int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const uint64_t *scids, const uint64_t *sats, const uint8_t *scripts,
-                                              const uint64_t *script_off) {
+                                              const uint64_t *script_off, size_t *applied) {
+  if (applied) *applied = 0;
   if (!g || (n && (!scids || !sats || !scripts || !script_off))) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;
   g->chans.reserve(g->chans.size() + n);
   g->store.reserve(g->store.size() + 2 * n);
   for (size_t i = 0; i < n; i++) {
     const int rc = lamd_gossipd_txout_reply(g, scids[i], sats[i], scripts + script_off[i], (size_t)(script_off[i + 1] - script_off[i]));
-    if (rc != LAMD_OK) return rc;
+    if (rc != LAMD_OK) return rc;  // replies [0, *applied) took effect (reply i's channel is in the map as well; its waiting updates still wait)
+    if (applied) *applied = i + 1;
   }
   return LAMD_OK;
 }
 
 extern "C" int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight) {
   if (!g) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;
   g->cfg.blockheight = blockheight;
   for (auto it = g->early_ann.begin(); it != g->early_ann.end();) {  // :1362-1387, ascending scid
     const u64 scid = it->first;

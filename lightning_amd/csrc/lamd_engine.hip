@@ -287,223 +287,8 @@ __global__ void __launch_bounds__(256) k_gossip_reduce(size_t n, const u8 *__res
   verdict[i] = (int8_t)v;
 }
 
-// ---- synthetic workload generation (keys, nonces and messages from splitmix64)
-LAMD_HD u64 splitmix64(u64 x) {
-  x += 0x9E3779B97F4A7C15ULL;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
-  return x ^ (x >> 31);
-}
-LAMD_HD void rand_words(u32 w[8], u64 seed, u64 idx, u64 stream) {
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u64 v = splitmix64(seed ^ splitmix64(idx * 4 + j + (stream << 56)));
-    w[2 * j] = (u32)v;
-    w[2 * j + 1] = (u32)(v >> 32);
-  }
-}
-LAMD_HD sc rand_scalar(u64 seed, u64 idx, u64 stream) {
-  u32 w[8];
-  rand_words(w, seed, idx, stream);
-  sc s = sc_from_words(w, nullptr);
-  if (sc_is_zero(s)) s.w[0] = 1;
-  return s;
-}
-LAMD_HD void store_words_be(u8 *dst, const u32 w[8]) {
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const u32 v = w[7 - i];
-    dst[4 * i] = (u8)(v >> 24); dst[4 * i + 1] = (u8)(v >> 16); dst[4 * i + 2] = (u8)(v >> 8); dst[4 * i + 3] = (u8)v;
-  }
-}
-// k*G as canonical affine words
-LAMD_HD void gmul_affine(u32 xw[8], u32 yw[8], const sc &k, const u32 *gtable) {
-  gej acc = gej_infinity();
-#pragma unroll 1
-  for (int w = 0; w < GTABLE_WINDOWS; w++) {
-    const u32 d = gtable_digit(k.w, w);
-    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
-    ge pt;
-    pt.x = slot_load_fe(e);
-    pt.y = slot_load_fe(e + 8);
-    acc = gej_add_ge(acc, pt, d == 0);
-  }
-  const fe zi = fe_inv(fe_norm_weak(acc.z));
-  const fe zi2 = fe_sqr(zi);
-  fe_to_words(xw, fe_normalize(fe_mul(acc.x, zi2)));
-  fe_to_words(yw, fe_normalize(fe_mul(acc.y, fe_mul(zi2, zi))));
-}
-LAMD_HD sc sc_add_mod(const sc &a, const sc &b) {
-  u32 t[8];
-  u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) { c += (u64)a.w[i] + b.w[i]; t[i] = (u32)c; c >>= 32; }
-  u32 d[8];
-  words_sub_n(d, t);
-  const bool ge = (c != 0) | words_ge_n(t);
-  sc r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.w[i] = ge ? d[i] : t[i];
-  return r;
-}
-
-// key of row i: rows are cut into groups of `group` consecutive rows that share one key (group = 0: every row draws its
-// key independently); the group's key index is a seeded hash modulo nkeys
-LAMD_HD u64 gen_key_index(u64 seed, u64 i, u64 nkeys, u64 group) {
-  const u64 g = group ? i / group : i;
-  return splitmix64(seed ^ splitmix64(g + (7ULL << 56))) % nkeys;
-}
-__global__ void __launch_bounds__(256) k_gen_ecdsa(size_t n, u64 seed, u64 nkeys, u64 group, int publen, const u32 *__restrict__ gtable,
-                                                   u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 ki = gen_key_index(seed, i, nkeys, group);
-  const sc d = rand_scalar(seed, ki, 1);
-  const sc k = rand_scalar(seed, i, 2);
-  u32 zw[8];
-  rand_words(zw, seed, i, 3);
-  u32 qx[8], qy[8], rx[8], ry[8];
-  gmul_affine(qx, qy, d, gtable);
-  gmul_affine(rx, ry, k, gtable);
-  const sc r = sc_from_words(rx, nullptr);
-  const sc z = sc_from_words(zw, nullptr);
-  sc s = sc_mul(sc_inv_var(k), sc_add_mod(z, sc_mul(r, d)));
-  if (sc_is_high(s)) s = sc_neg(s);
-  store_words_be(hash32 + 32 * i, zw);
-  store_words_be(sig64 + 64 * i, r.w);
-  store_words_be(sig64 + 64 * i + 32, s.w);
-  u8 *p = pub + (size_t)publen * i;
-  if (publen == 65) {
-    p[0] = 4;
-    store_words_be(p + 1, qx);
-    store_words_be(p + 33, qy);
-  } else {
-    p[0] = 2 + (qy[0] & 1);
-    store_words_be(p + 1, qx);
-  }
-}
-
-__global__ void __launch_bounds__(256) k_gen_schnorr(size_t n, u64 seed, u64 nkeys, u64 group, const u32 *__restrict__ gtable,
-                                                     u8 *__restrict__ msg32, u8 *__restrict__ pk32, u8 *__restrict__ sig64) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 ki = gen_key_index(seed, i, nkeys, group);
-  sc d = rand_scalar(seed, ki, 1);
-  sc k = rand_scalar(seed, i, 2);
-  u32 mw[8];
-  rand_words(mw, seed, i, 3);
-  u32 px[8], py[8], rx[8], ry[8];
-  gmul_affine(px, py, d, gtable);
-  gmul_affine(rx, ry, k, gtable);
-  if (py[0] & 1) d = sc_neg(d);
-  if (ry[0] & 1) k = sc_neg(k);
-  u32 rb[8], pb[8], mb[8], eh[8], ew[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) { rb[j] = rx[7 - j]; pb[j] = px[7 - j]; mb[j] = mw[7 - j]; }
-  bip340_challenge(eh, rb, pb, mb);
-#pragma unroll
-  for (int j = 0; j < 8; j++) ew[j] = eh[7 - j];
-  const sc e = sc_from_words(ew, nullptr);
-  const sc s = sc_add_mod(k, sc_mul(e, d));
-  store_words_be(msg32 + 32 * i, mw);
-  store_words_be(pk32 + 32 * i, px);
-  store_words_be(sig64 + 64 * i, rx);
-  store_words_be(sig64 + 64 * i + 32, s.w);
-}
-
-// ---- synthetic gossip (shape of devtools/mkgossip.c:131-147,235-322): n_cann channel_announcements (432 B, no
-// features) followed by n_cupd channel_updates (138 B) signed by one of the referenced channel's nodes
-LAMD_HD void sign_ecdsa_words(u32 rw[8], u32 sw[8], const u32 zw[8], const sc &d, const sc &k, const u32 *gtable) {
-  u32 rx[8], ry[8];
-  gmul_affine(rx, ry, k, gtable);
-  const sc r = sc_from_words(rx, nullptr);
-  const sc z = sc_from_words(zw, nullptr);
-  sc s = sc_mul(sc_inv_var(k), sc_add_mod(z, sc_mul(r, d)));
-  if (sc_is_high(s)) s = sc_neg(s);
-#pragma unroll
-  for (int i = 0; i < 8; i++) { rw[i] = r.w[i]; sw[i] = s.w[i]; }
-}
-LAMD_HD void pubkey33(u8 out[33], const sc &d, const u32 *gtable) {
-  u32 qx[8], qy[8];
-  gmul_affine(qx, qy, d, gtable);
-  out[0] = 2 + (qy[0] & 1);
-  store_words_be(out + 1, qx);
-}
-LAMD_HD void gossip_chan_nodes(u64 seed, u64 c, u64 n_nodes, u64 *a, u64 *b) {
-  *a = splitmix64(seed ^ splitmix64(c + (10ULL << 56))) % n_nodes;
-  *b = splitmix64(seed ^ splitmix64(c + (11ULL << 56))) % n_nodes;
-  if (*b == *a) *b = (*a + 1) % n_nodes;
-}
-constexpr size_t CANN_LEN = 432, CUPD_LEN = 138;
-__global__ void __launch_bounds__(256) k_gen_gossip(size_t n_cann, size_t n_cupd, u64 seed, u64 n_nodes, const u32 *__restrict__ gtable,
-                                                    u8 *__restrict__ msgs, u8 *__restrict__ ids) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_cann + n_cupd) return;
-  const u8 chain[32] = {0x6f, 0xe2, 0x8c, 0x0a, 0xb6, 0xf1, 0xb3, 0x72, 0xc1, 0xa6, 0xa2, 0x46, 0xae, 0x63, 0xf7, 0x4f,
-                        0x93, 0x1e, 0x83, 0x65, 0xe1, 0x5a, 0x08, 0x9c, 0x68, 0xd6, 0x19, 0x00, 0x00, 0x00, 0x00, 0x00};
-  u8 h[32];
-  u32 zw[8], rw[8], sw[8];
-  if (i < n_cann) {
-    u8 *m = msgs + i * CANN_LEN;
-    u64 a, b;
-    gossip_chan_nodes(seed, i, n_nodes, &a, &b);
-    sc d[4] = {rand_scalar(seed, a, 1), rand_scalar(seed, b, 1), rand_scalar(seed, 2 * i, 4), rand_scalar(seed, 2 * i + 1, 4)};
-    u8 k0[33], k1[33];
-    pubkey33(k0, d[0], gtable);
-    pubkey33(k1, d[1], gtable);
-    bool swap = false;  // BOLT #7: node_id_1 is the lexicographically lesser
-    for (int j = 0; j < 33; j++)
-      if (k0[j] != k1[j]) { swap = k0[j] > k1[j]; break; }
-    if (swap) { const sc t = d[0]; d[0] = d[1]; d[1] = t; }
-    m[0] = 0x01; m[1] = 0x00;
-    u8 *tail = m + 258;
-    tail[0] = 0; tail[1] = 0;
-    for (int j = 0; j < 32; j++) tail[2 + j] = chain[j];
-    for (int j = 0; j < 8; j++) tail[34 + j] = (u8)((u64)i >> (8 * (7 - j)));
-    for (int j = 0; j < 33; j++) { tail[42 + j] = swap ? k1[j] : k0[j]; tail[75 + j] = swap ? k0[j] : k1[j]; }
-    pubkey33(tail + 108, d[2], gtable);
-    pubkey33(tail + 141, d[3], gtable);
-    sha256d_bytes(tail, CANN_LEN - 258, h);
-    load_words_be(zw, h);
-    for (int j = 0; j < 4; j++) {
-      sign_ecdsa_words(rw, sw, zw, d[j], rand_scalar(seed, 4 * i + j, 5), gtable);
-      store_words_be(m + 2 + 64 * j, rw);
-      store_words_be(m + 2 + 64 * j + 32, sw);
-    }
-    for (int j = 0; j < 33; j++) ids[i * 33 + j] = 0;
-  } else {
-    const size_t u = i - n_cann;
-    u8 *m = msgs + n_cann * CANN_LEN + u * CUPD_LEN;
-    const u64 c = splitmix64(seed ^ splitmix64(u + (12ULL << 56))) % (n_cann ? n_cann : 1);
-    u64 a, b;
-    gossip_chan_nodes(seed, c, n_nodes, &a, &b);
-    const u64 side = splitmix64(seed ^ splitmix64(u + (13ULL << 56))) & 1;
-    const sc d = rand_scalar(seed, side ? b : a, 1);
-    pubkey33(ids + i * 33, d, gtable);
-    // the direction bit of channel_flags says whether the signer is node_id_1 or node_id_2 of the announcement, i.e. the lesser or
-    // the greater of the two keys (BOLT #7; gossmap_manage.c:920-922 picks the verification key by it)
-    u8 other[33];
-    pubkey33(other, rand_scalar(seed, side ? a : b, 1), gtable);
-    bool signer_greater = false;
-    for (int j = 0; j < 33; j++)
-      if (ids[i * 33 + j] != other[j]) { signer_greater = ids[i * 33 + j] > other[j]; break; }
-    m[0] = 0x01; m[1] = 0x02;
-    u8 *body = m + 66;
-    for (int j = 0; j < 32; j++) body[j] = chain[j];
-    for (int j = 0; j < 8; j++) body[32 + j] = (u8)(c >> (8 * (7 - j)));
-    u32 rndw[8];
-    rand_words(rndw, seed, u, 6);
-    for (int j = 0; j < 32; j++) body[40 + j] = (u8)(rndw[j >> 2] >> (8 * (j & 3)));
-    body[44] = 1;               // message_flags: option_channel_htlc_max
-    body[45] = signer_greater ? 1 : 0;  // channel_flags: direction
-    sha256d_bytes(body, CUPD_LEN - 66, h);
-    load_words_be(zw, h);
-    sign_ecdsa_words(rw, sw, zw, d, rand_scalar(seed, u, 7), gtable);
-    store_words_be(m + 2, rw);
-    store_words_be(m + 34, sw);
-  }
-}
-
+// (the synthetic-workload signer kernels live in lamd_testgen.hip -> liblightning_amd_testgen.so: test / bench infrastructure,
+// not part of the product library)
 // ---- keyed path kernels (see verify_core.h "Keyed path")
 // seeded per context (std::random_device at lamd_init): public keys come from the network, and a fixed hash would let a
 // peer craft keys that all probe the same slots
@@ -1086,8 +871,13 @@ static unsigned keyed_grid(const lamd_ctx *ctx, size_t n) {
 // engine uses up to 9 streams (root + two lanes, each with a prep and a cold-row side stream); with 4 queues one lane's prep
 // kernel lands behind the other lane's ecmult kernel and the lanes stop overlapping (measured: two 484-row flushes in flight
 // 880 -> 1 640 batches/s, the 2 M-row step 170 -> 182 M verifies/s with >= 8 queues).  The runtime reads the variable once,
-// at its first API call, so it is set when this library is loaded -- unless the host application has set it already.
-__attribute__((constructor)) static void lamd_runtime_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// at its first API call: exporting GPU_MAX_HW_QUEUES=16 before that is the HOST's job (documented precondition of lamd_init in
+// include/lightning_amd.h -- a drop-in linked into somebody else's daemon does not edit the process environment);
+// lamd_info.hw_queues_env reports what lamd_init() found.
+static int hw_queues_from_env(void) {
+  const char *v = getenv("GPU_MAX_HW_QUEUES");
+  return v && *v ? atoi(v) : 0;
+}
 
 extern "C" const char *lamd_version(void) { return "lightning_amd 0.1 (gfx950)"; }
 
@@ -1409,6 +1199,7 @@ static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   info->compute_units = ctx->prop.multiProcessorCount;
   strncpy(info->arch, ctx->prop.gcnArchName, sizeof(info->arch) - 1);
   info->gtable_bytes = GTABLE_BYTES;
+  info->hw_queues_env = hw_queues_from_env();
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
   for (int i = 0; i < 2; i++) {
     info->keyed_ecmult_ms_sum[i] = self->keyed_ms_sum[i];
@@ -2396,10 +2187,18 @@ static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, siz
   size_t ncap = q.cap ? q.cap * 2 : 1024;
   if (ncap < want) ncap = want;  // a large push sizes the set in one allocation (pinned allocations are slow)
   u8 *na = nullptr, *nb = nullptr, *nc = nullptr, *nk = nullptr;
-  HIPCHK(ctx, hipHostMalloc((void **)&na, ncap * 32, hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void **)&nb, ncap * 64, hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void **)&nc, ncap * keybytes, hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void **)&nk, ncap, hipHostMallocDefault));
+  {  // all four or none: a failure (pinned memory is scarce exactly when this path is hit) must not leak the blocks already taken
+    hipError_t e = hipHostMalloc((void **)&na, ncap * 32, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&nb, ncap * 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&nc, ncap * keybytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&nk, ncap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      for (u8 *h : {na, nb, nc, nk})
+        if (h) (void)hipHostFree(h);
+      ctx->err = std::string("hipHostMalloc (staging set): ") + hipGetErrorString(e);
+      return e == hipErrorOutOfMemory ? LAMD_ERR_NOMEM : LAMD_ERR_HIP;
+    }
+  }
   if (q.n) {
     memcpy(na, q.h_a, q.n * 32);
     memcpy(nb, q.h_b, q.n * 64);
@@ -2981,6 +2780,7 @@ extern "C" int lamd_fuzz_field(lamd_ctx *ctx, size_t lanes, int iters, uint64_t 
 }
 
 // ---- diagnostic peek into the engine's device work buffers (tests / debugging only)
+extern "C" const void *lamd_debug_gtable(lamd_ctx *ctx) { return ctx ? (const void *)ctx->gtable : nullptr; }
 extern "C" int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out) {
   if (!ctx || !out) return LAMD_ERR_ARG;
   devbuf *bufs[] = {&ctx->recs, &ctx->keyok, &ctx->kd_rep, &ctx->kd_uid, &ctx->row_ent, &ctx->kd_uniq, &ctx->hk7_keyok, &ctx->hk7_qwords, &ctx->cache_store.pool7};
@@ -2991,49 +2791,5 @@ extern "C" int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t n
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipMemcpy(out, (const u8 *)bufs[which]->p + offset, nbytes, hipMemcpyDeviceToHost));
-  return LAMD_OK;
-}
-
-// ---- synthetic workloads
-extern "C" int lamd_gen_ecdsa_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group, size_t publen, void *d_hash32,
-                                     void *d_sig64, void *d_pub) {
-  if (!ctx) return LAMD_ERR_ARG;
-  if (!d_hash32 || !d_sig64 || !d_pub || (publen != 33 && publen != 65) || nkeys == 0) {
-    ctx->err = "bad argument";
-    return LAMD_ERR_ARG;
-  }
-  if (n == 0) return LAMD_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_gen_ecdsa, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys, (u64)group,
-                     (int)publen, (const u32 *)ctx->gtable, (u8 *)d_hash32, (u8 *)d_sig64, (u8 *)d_pub);
-  HIPCHK(ctx, hipGetLastError());
-  return LAMD_OK;
-}
-extern "C" int lamd_gen_schnorr_device(lamd_ctx *ctx, size_t n, uint64_t seed, size_t nkeys, size_t group, void *d_msg32,
-                                       void *d_xonly32, void *d_sig64) {
-  if (!ctx) return LAMD_ERR_ARG;
-  if (!d_msg32 || !d_xonly32 || !d_sig64 || nkeys == 0) {
-    ctx->err = "bad argument";
-    return LAMD_ERR_ARG;
-  }
-  if (n == 0) return LAMD_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_gen_schnorr, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (u64)seed, (u64)nkeys, (u64)group,
-                     (const u32 *)ctx->gtable, (u8 *)d_msg32, (u8 *)d_xonly32, (u8 *)d_sig64);
-  HIPCHK(ctx, hipGetLastError());
-  return LAMD_OK;
-}
-extern "C" int lamd_gen_gossip_device(lamd_ctx *ctx, size_t n_cann, size_t n_cupd, uint64_t seed, size_t n_nodes, void *d_msgs,
-                                      void *d_node_ids33) {
-  if (!ctx) return LAMD_ERR_ARG;
-  if (!d_msgs || !d_node_ids33 || n_nodes < 2 || (n_cupd && !n_cann)) {
-    ctx->err = "bad argument";
-    return LAMD_ERR_ARG;
-  }
-  if (n_cann + n_cupd == 0) return LAMD_OK;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_gen_gossip, dim3(blocks_for(n_cann + n_cupd)), dim3(256), 0, ctx->stream, n_cann, n_cupd, (u64)seed, (u64)n_nodes,
-                     (const u32 *)ctx->gtable, (u8 *)d_msgs, (u8 *)d_node_ids33);
-  HIPCHK(ctx, hipGetLastError());
   return LAMD_OK;
 }

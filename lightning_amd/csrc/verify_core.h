@@ -109,6 +109,22 @@ LAMD_HD void load_words_be(u32 w[8], const u8 *p) {
   }
 }
 
+// ---- seeded mixing (hash-table probes of the key de-duplication / cache, synthetic test data)
+LAMD_HD u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+// 8 little-endian words -> 32 big-endian bytes
+LAMD_HD void store_words_be(u8 *dst, const u32 w[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const u32 v = w[7 - i];
+    dst[4 * i] = (u8)(v >> 24); dst[4 * i + 1] = (u8)(v >> 16); dst[4 * i + 2] = (u8)(v >> 8); dst[4 * i + 3] = (u8)v;
+  }
+}
+
 // ---- public keys.  len: 33 / 65 (SEC1) or 32 (BIP-340 x-only, lifted to even y).
 // Writes canonical affine words; returns validity.
 LAMD_HD bool parse_pubkey(const u8 *p, int len, u32 qx[8], u32 qy[8]) {

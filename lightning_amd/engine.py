@@ -281,16 +281,16 @@ class Engine:
     def gen_ecdsa_device(self, seed, nkeys, d_hash, d_sig, d_pub, group=0):
         n, publen = d_pub.shape
         self._after_torch()   # the output tensors may still be being filled on torch's stream (torch.zeros)
-        self._chk(self._lib.lamd_gen_ecdsa_device(self._ctx, n, seed, nkeys, group, publen, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr()))
+        self._chk(_ffi.load_testgen().lamd_gen_ecdsa_device(self._ctx, n, seed, nkeys, group, publen, d_hash.data_ptr(), d_sig.data_ptr(), d_pub.data_ptr()))
 
     def gen_schnorr_device(self, seed, nkeys, d_msg, d_xonly, d_sig, group=0):
         n = d_msg.shape[0]
         self._after_torch()
-        self._chk(self._lib.lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, group, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
+        self._chk(_ffi.load_testgen().lamd_gen_schnorr_device(self._ctx, n, seed, nkeys, group, d_msg.data_ptr(), d_xonly.data_ptr(), d_sig.data_ptr()))
 
     def gen_gossip_device(self, seed, n_cann, n_cupd, n_nodes, d_msgs, d_ids):
         self._after_torch()
-        self._chk(self._lib.lamd_gen_gossip_device(self._ctx, n_cann, n_cupd, seed, n_nodes, d_msgs.data_ptr(), d_ids.data_ptr()))
+        self._chk(_ffi.load_testgen().lamd_gen_gossip_device(self._ctx, n_cann, n_cupd, seed, n_nodes, d_msgs.data_ptr(), d_ids.data_ptr()))
 
     def sigcheck_gossip_device(self, n, d_msgs, d_off, d_ids, d_rowbase, rows, d_verdict):
         self._after_torch()
@@ -361,7 +361,7 @@ class Engine:
                     last_cache_hits=inf.last_cache_hits, last_cold_rows=inf.last_cold_rows, last_new_tables=inf.last_new_tables,
                     last_suspect_rows=inf.last_suspect_rows, cache_enabled=bool(inf.cache_enabled), cache_entries=inf.cache_entries,
                     cache_capacity=inf.cache_capacity, cache_resets=inf.cache_resets,
-                    keyed_ecmult_ms_sum=list(inf.keyed_ecmult_ms_sum), keyed_ecmult_launches=list(inf.keyed_ecmult_launches))
+                    keyed_ecmult_ms_sum=list(inf.keyed_ecmult_ms_sum), keyed_ecmult_launches=list(inf.keyed_ecmult_launches), hw_queues_env=int(inf.hw_queues_env))
 
     def cache_clear(self):
         """empty the key-table cache (cold-path measurements)"""

@@ -42,7 +42,7 @@ def _load():
         L.lamd_gossipd_set_backend.argtypes = [ctypes.c_void_p, SIGCHECK_FN, KEYPARSE_FN, ctypes.c_void_p]
         L.lamd_gossipd_push.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t]
         L.lamd_gossipd_push_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
-        L.lamd_gossipd_txout_reply_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.lamd_gossipd_txout_reply_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
         L.lamd_gossipd_process.restype = ctypes.c_long
         L.lamd_gossipd_process.argtypes = [ctypes.c_void_p]
         L.lamd_gossipd_txout_reply.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]
@@ -76,7 +76,7 @@ class GossipIngest:
             def c_sig(_user, n, msgs, off, ids, verdict):
                 offs = (ctypes.c_uint64 * (n + 1)).from_address(off)
                 blob = ctypes.string_at(msgs, offs[n])
-                out = sig(blob, list(offs), ctypes.string_at(ids, 33 * n))
+                out = sig(blob, list(offs), ctypes.string_at(ids, 33 * n) if ids else bytes(33 * n))   # NULL for announcement-only late verifies
                 (ctypes.c_int8 * n).from_address(verdict)[:] = out
                 return 0
 
@@ -121,9 +121,10 @@ class GossipIngest:
             raise RuntimeError("lamd_gossipd_push_batch: %d" % rc)
 
     def txout_reply_batch(self, scids, sats, scripts, script_off):
-        rc = self._L.lamd_gossipd_txout_reply_batch(self._g, len(scids), scids.ctypes.data, sats.ctypes.data, scripts.ctypes.data, script_off.ctypes.data)
+        applied = ctypes.c_size_t(0)
+        rc = self._L.lamd_gossipd_txout_reply_batch(self._g, len(scids), scids.ctypes.data, sats.ctypes.data, scripts.ctypes.data, script_off.ctypes.data, ctypes.byref(applied))
         if rc != 0:
-            raise RuntimeError("lamd_gossipd_txout_reply_batch: %d" % rc)
+            raise RuntimeError("lamd_gossipd_txout_reply_batch: %d after %d replies" % (rc, applied.value))
 
     def process(self):
         n = self._L.lamd_gossipd_process(self._g)

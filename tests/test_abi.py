@@ -28,6 +28,35 @@ def test_header_symbols_exported_and_bound():
         assert n in _ffi.SYMBOLS, "ctypes binding missing for %s" % n
     assert set(_ffi.SYMBOLS) == set(names)
     assert b"gfx950" in lib.lamd_version()
+    # no signing code in the product library: the synthetic-workload signer kernels live in liblightning_amd_testgen.so
+    assert not [n for n in names if n.startswith("lamd_gen_")]
+    assert not [n for n in ("lamd_gen_ecdsa_device", "lamd_gen_schnorr_device", "lamd_gen_gossip_device") if hasattr(lib, n)]
+
+
+def test_testgen_header_symbols_exported():
+    """include/lightning_amd_testgen.h (test / bench infrastructure) -> liblightning_amd_testgen.so"""
+    from lightning_amd import _ffi
+    names = _declared("lightning_amd_testgen.h")
+    assert names == sorted(_ffi.TESTGEN_SYMBOLS) and len(names) == 3
+    tg = _ffi.load_testgen()
+    for n in names:
+        assert hasattr(tg, n)
+
+
+def test_mirror_header_is_installed_and_exported():
+    """include/cln_shim.h: every prototype with one of the reference's names is exported by liblightning_amd_cln.so"""
+    from lightning_amd import _build
+    src = open(os.path.join(ROOT, "include", "cln_shim.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    lib = ctypes.CDLL(_build.build_shim())
+    want = ["check_signed_hash", "check_signed_hash_nodeid", "check_schnorr_sig", "check_tx_sig", "sigcheck_channel_update",
+            "sigcheck_channel_announcement", "sigcheck_node_announcement", "signature_from_der", "pubkey_from_der",
+            "fromwire_secp256k1_ecdsa_signature", "sha256_double", "bolt12_check_signature", "merkle_tlv", "sighash_from_merkle",
+            "shim_tal_dup", "shim_tal_bytelen"]
+    for n in want:
+        assert re.search(r"\b%s\s*\(" % n, src), n
+        assert hasattr(lib, n), n
+    assert not hasattr(lib, "tal_bytelen")
 
 
 def test_gossipd_header_symbols_exported():

@@ -70,8 +70,8 @@ def shim():
     L.check_tx_sig_preimage.restype = ctypes.c_bool
     L.shim_tal_dup.restype = ctypes.c_void_p
     L.shim_tal_dup.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
-    L.tal_bytelen.restype = ctypes.c_size_t
-    L.tal_bytelen.argtypes = [ctypes.c_void_p]
+    L.shim_tal_bytelen.restype = ctypes.c_size_t
+    L.shim_tal_bytelen.argtypes = [ctypes.c_void_p]
     L.check_tx_sig.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return L
 
@@ -115,7 +115,10 @@ def test_check_tx_sig_sighash_gate_needs_no_device(shim):
     key = Pubkey()
     tx, keep = make_tx(shim, 2, 0, [(bytes(32), 0, 0, 1000)], [(900, b"\x00\x14" + bytes(20))])
     sub = shim.shim_tal_dup(None, b"\x76\xa9", 2)
-    assert shim.tal_bytelen(sub) == 2
+    assert shim.shim_tal_bytelen(sub) == 2
+    assert not hasattr(shim, "tal_bytelen")                 # the mirror must not define ccan/tal's symbol (it links next to it in-tree)
+    foreign = ctypes.create_string_buffer(64)                # a pointer shim_tal_dup() did not make: fails closed, no abort()
+    assert shim.shim_tal_bytelen(ctypes.byref(foreign, 32)) == ctypes.c_size_t(-1).value
     for t, wit, reaches_verify in ((2, b"\x51", False), (0x83, None, False), (0x81, b"\x51", False), (3, b"\x51", False)):
         sig.sighash_type = t
         assert shim.check_tx_sig_preimage(b"\x00" * 10, 10, wit, ctypes.byref(key), ctypes.byref(sig)) is False
