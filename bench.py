@@ -177,12 +177,19 @@ def main():
     # two engines: `eng_cold` rebuilds every key's comb table in every call (LAMD_CACHE=0: what a stateless library does, and
     # what `value` is measured on); `eng` keeps tables in its key-table cache across calls, so from the second step on a repeated
     # batch is all cache hits ("warm": reported beside the headline, never as it)
+    # With more than one rank ONLY the cold engine exists: one engine = one 3 GiB G table and one set of 16 hardware-queue-backed
+    # streams per rank.  Two engines plus RCCL's own streams is the many-queues regime in which the collective path lost up to 45 %
+    # on one rank (profiles/r02n_collective_path_and_queues.txt); the warm-cache leg is a single-GPU data point anyway.
     os.environ["LAMD_CACHE"] = "0"
     eng_cold = Engine(local_rank)
     del os.environ["LAMD_CACHE"]
-    eng = Engine(local_rank)
+    eng = Engine(local_rank) if not multi else eng_cold
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the only collective is an all-gather of <= 1 MB of verdict bytes per rank: one or two RCCL channels carry it, and every
+        # channel RCCL opens beyond that is a stream competing with the engine's lanes for hardware queues
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
         dist.init_process_group("nccl", device_id=torch.device(device))
     eng.set_timing(True)
     eng_cold.set_timing(True)
@@ -289,7 +296,7 @@ def main():
 
     # warm first (its steady state is all cache hits), then the headline: cold, every table rebuilt in every call
     full = not args.roofline_only
-    if full:
+    if full and eng is not eng_cold:
         dt_warm, mism_warm = timed(eng)
         warm_info = [eng.info(k) for k in range(eng.info()["lanes"])]
     else:
@@ -393,7 +400,11 @@ def main():
                          "avg_launch_ms_schnorr": (lm[1][0] / lm[1][1]) if lm[1][1] else None,
                          "avg_launch_ms_both_kinds": ((lm[0][0] + lm[1][0]) / (lm[0][1] + lm[1][1])) if lm[0][1] + lm[1][1] else None,
                          "timing": "HIP event pair recorded on the launching lane's stream right before and after every k_ecmult_keyed launch of the "
-                                   "timed steps (other lanes' kernels share the chip during the interval)",
+                                   "timed steps.  These in-loop brackets OVERLAP: 1.1-1.5 such launches are in flight at any time plus the other lanes' "
+                                   "front ends, so sum(launch durations) > step time and `frac` understates what the kernel does with the chip to itself; "
+                                   "`frac_isolated` (one call at a time, same process) and `pipeline.frac` (both launches' work / step time) are the clean figures",
+                         "frac_isolated": w_exec * n / (iso_ms * 1e-3) / P_MUL32,
+                         "sum_of_launch_ms_per_step": ((lm[0][0] + lm[1][0]) / args.steps) if args.steps else None,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                          "traffic_source": traffic_src,
                          # in the timed region the kernel shares the chip with the other lane's front end (de-duplication, table building,
@@ -404,7 +415,10 @@ def main():
                          "valu_issue": valu_issue,
                          # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time:
                          # exceeds the executed figure because the comb tables and the 22-bit G windows need fewer multiplications
-                         "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "achieved": W_ECDSA65 * n / t_ecmult / 1e12, "frac": W_ECDSA65 * n / t_ecmult / P_MUL32},
+                         # NOT a utilisation figure (the kernel executes 2.2x fewer multiplies than the yardstick's generic algorithm, so the
+                         # ratio to peak would exceed 1 on the isolated launch): reported as a rate only
+                         "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "yardstick_Tmul32_per_s_in_loop": W_ECDSA65 * n / t_ecmult / 1e12,
+                                              "note": "rate at which SURVEY 8(d)'s generic-algorithm multiplies would have to run to finish in the same time; not a fraction of peak"},
                          # whole timed step: the ecmult work of both batches against the step time (the rest of the step builds key tables,
                          # prepares scalars and de-duplicates keys)
                          "pipeline": {"ms": dt / args.steps * 1e3, "achieved": 2 * w_exec * n / (dt / args.steps) / 1e12,
@@ -422,7 +436,7 @@ def main():
                            "cache_hits_last_call": [int(i["last_cache_hits"]) for i in warm_info], "new_tables_last_call": [int(i["last_new_tables"]) for i in warm_info],
                            "comb_teeth_last_call": [int(i["last_keyed"]) for i in warm_info]},
         }
-        if not full:
+        if not full or eng_default is eng_cold:
             out["warm_cache"] = None
         if sharded is not None:
             out["sharded_configs"] = sharded
@@ -715,6 +729,29 @@ def main():
             extra["ecdsa_recover"] = {"recoveries": 2 * n, "recoveries_per_s": 2 * n / min(ts[1:]), "mismatches": rbad,
                                       "check": "signer's key from exactly one recovery id on every valid row"}
             mism += rbad
+            # ---- key-reuse sweep (cold engine: every call builds its tables again): 1 M ECDSA-65 rows under K distinct keys.  K = 65 536 is
+            # configs[1]; K = 1 and 256 put every row on a 10-tooth comb; "all distinct" puts every row on the per-signature GLV ladder
+            # (k_ecmult) -- the floor of the engine.  Eight calls back to back over the lanes, every verdict checked by construction.
+            sweep = {}
+            del d_keys, d_oks, d_rids
+            for label, nk, grp in (("K=1", 1, 0), ("K=256", 256, 0), ("K=65536", 65536, 0), ("K=1000000_all_distinct", 1 << 40, 1)):
+                wk = workload.make_ecdsa(eng_cold, n, seed=workload.SEED_CFG2 ^ (0x5EED0000 + nk % 65521), nkeys=nk, publen=65, device=device, group=grp)
+                for _ in range(eng_cold.info()["lanes"]):          # every lane allocates its workspaces for this shape once
+                    eng_cold.verify_ecdsa_device(wk.dev[0], wk.dev[1], wk.dev[2], wk.d_ok)
+                torch.cuda.synchronize(); eng_cold.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(8):
+                    eng_cold.verify_ecdsa_device(wk.dev[0], wk.dev[1], wk.dev[2], wk.d_ok)
+                eng_cold.synchronize()
+                dts = time.perf_counter() - t1
+                inf = eng_cold.info()
+                kbad = int((wk.d_ok.cpu().numpy().astype(bool) != wk.expect).sum())
+                sweep[label] = {"verifies_per_s": 8 * n / dts, "ms_per_call": dts / 8 * 1e3, "mismatches": kbad, "distinct_keys_seen": int(inf["last_unique_keys"]),
+                                "rows_on_comb_tables": int(inf["last_hot_rows"]), "rows_on_ladder": int(inf["last_cold_rows"]), "comb_teeth": int(inf["last_keyed"])}
+                mism += kbad
+                del wk
+            extra["key_reuse_sweep"] = dict(sweep, rows=n, calls=8, note="1 M ECDSA-65 rows per call, key-table cache off, 8 calls pipelined over the lanes; "
+                                            "K = number of distinct public keys the rows draw from")
             out["other_configs_1gpu"] = extra
             mism += gm + sm
         if args.cpu_sample > 0 and world == 1 and full:   # the CPU baseline is a rank-0, N=1 leg
@@ -747,7 +784,8 @@ def main():
             mism += cm
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
-    eng_cold.close()
+    if eng_cold is not eng:
+        eng_cold.close()
     if multi:
         dist.destroy_process_group()
     if not args.no_parity and rank == 0 and mism:

@@ -20,9 +20,10 @@
  *      earlier copy was accepted, :673-676) resolves exactly as it does one message at a time.
  * What is kept: the announce/update/node maps, the pending and too-early announcement maps with their queued
  * channel_updates and node_announcements, the txout-failure set, and an append-only store (records with timestamps,
- * deletions marked).  What is not: pruning, dying/spent channels, compaction, the seeker, local (known_amount)
- * announcements, the gossip_store file format -- events tell the host daemon what the reference would have done
- * (send a warning, ask lightningd for a txout, append to / delete from the store) and it does the I/O.
+ * deletions marked) together with the byte image of the gossip_store FILE those records make (common/gossip_store.h:15-59), pruning
+ * (prune_network) and dying / spent channels (channel_spent, new_block).  What is not: compaction, the seeker, local (known_amount)
+ * announcements -- events tell the host daemon what the reference would have done (send a warning, ask lightningd for a txout,
+ * append to / delete from / re-flag the store) and it does the I/O.
  *
  * Everything observable is reported through the event callback, in the order the reference would produce it; texts
  * (warnings, traces) are the reference's own format strings. */
@@ -50,7 +51,10 @@ enum lamd_gossipd_event_kind {
 	LAMD_GEV_QUERY_CHANNEL = 8,  /* query_unknown_channel(peer, scid) (gossmap_manage.c:908) */
 	LAMD_GEV_QUERY_NODE = 9,     /* query_unknown_node(peer, node id in data) (gossmap_manage.c:1232) */
 	LAMD_GEV_GOOD_GOSSIP = 10,   /* peer_supplied_good_gossip(peer, 1) */
-	LAMD_GEV_TXOUT_FAILED = 11   /* txout_failures_add(scid) (gossmap_manage.c:868-869) */
+	LAMD_GEV_TXOUT_FAILED = 11,  /* txout_failures_add(scid) (gossmap_manage.c:868-869) */
+	LAMD_GEV_STORE_FLAG = 12,    /* gossip_store_set_flag(record `index`, values[1] = GOSSIP_STORE_DYING_BIT) (gossmap_manage.c:367-372,1472-1495) */
+	LAMD_GEV_STORE_WRITE = 13    /* only with config.emit_store_writes: pwrite(gossip_store, data, len, offset = values[0]) -- applying these in
+	                              * order to a file reproduces lamd_gossipd_store_image() byte for byte */
 };
 
 typedef struct lamd_gossipd_event {
@@ -75,6 +79,10 @@ typedef struct lamd_gossipd_config {
 	uint32_t blockheight;     /* daemon->current_blockheight (0 = unknown) */
 	uint64_t now;             /* seconds since the epoch; 0 = read the clock at every lamd_gossipd_process() */
 	uint32_t prune_interval;  /* GOSSIP_PRUNE_INTERVAL: 1209600 (0 = that default) */
+	uint8_t store_version;    /* first byte of the gossip_store image: 0 = GOSSIP_STORE_VER (0 << 5 | 16, gossip_store.c:24); a minor version
+	                           * below 16 writes no uuid record (the fixtures under contrib/pyln-client/tests/data are v15) */
+	uint8_t emit_store_writes; /* 1 = report every write to the image as a LAMD_GEV_STORE_WRITE event */
+	uint8_t store_uuid[32];   /* the uuid record's content (the reference draws it at random, gossip_store.c:186-197) */
 } lamd_gossipd_config;
 
 /* A verification back end with the signature of lamd_sigcheck_gossip_batch / lamd_pubkey_parse_batch.  The product uses
@@ -112,8 +120,23 @@ int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const
  * channel; the updates that waited for it stay queued until the next successful reply or process()). */
 int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const uint64_t *scids, const uint64_t *sats, const uint8_t *scripts,
 				   const uint64_t *script_off, size_t *applied);
-/* gossmap_manage_new_block (:1358-1390): too-early announcements that are now deep enough become pending */
+/* gossmap_manage_new_block (:1389-1437): too-early announcements that are now deep enough become pending; dying channels whose
+ * deadline has come are removed (kill_spent_channel -> remove_channel, :296-387) */
 int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight);
+/* gossmap_manage_channel_spent (:1439-1497): lightningd saw the funding output of `scid` spent at `blockheight`: the channel is
+ * marked dying in the store (chan_dying record, DYING flag on its announcement, updates and -- if every channel of a node is dying
+ * -- that node's announcement) and removed 72 blocks later by lamd_gossipd_new_block(). */
+int lamd_gossipd_channel_spent(lamd_gossipd *g, uint32_t blockheight, uint64_t scid);
+/* prune_network (:398-470): removes every channel one of whose directions has no channel_update newer than now - prune_interval
+ * (delete_chan tombstone, records marked deleted, node_announcements deleted / moved behind a surviving channel_announcement).
+ * The reference runs it from a timer every prune_interval / 4; here the host daemon owns the timer.  Returns the number of
+ * channels pruned. */
+long lamd_gossipd_prune(lamd_gossipd *g);
+/* The gossip_store file as the reference's gossip_store.c would hold it after the same operations (common/gossip_store.h:15-59:
+ * version byte, then struct gossip_hdr {flags, len, crc32c seeded with the timestamp, timestamp} + message per record; a v16
+ * store starts with the uuid record).  Store events carry the record's offset in values[0] (the offset gossip_store_add()
+ * returns: of the message, after its header).  Valid until the next call that changes the ingest. */
+size_t lamd_gossipd_store_image(const lamd_gossipd *g, const uint8_t **data);
 void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now);
 
 typedef struct lamd_gossipd_stats {

@@ -115,7 +115,8 @@ def load_testgen():
     global _testgen
     if _testgen is None:
         load()
-        path = _build.build_testgen() if os.path.exists("/opt/rocm/bin/hipcc") else _build.TESTGEN
+        alt = os.environ.get("LAMD_TESTGEN_LIB_PATH")   # experiments only: a variant engine built with another table layout needs its own signer library
+        path = alt if alt else (_build.build_testgen() if os.path.exists("/opt/rocm/bin/hipcc") else _build.TESTGEN)
         L = ctypes.CDLL(path)
         for name, (res, args) in TESTGEN_SYMBOLS.items():
             f = getattr(L, name)

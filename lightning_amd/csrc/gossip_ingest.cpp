@@ -194,13 +194,77 @@ struct chan {
   u64 cann_rec;
   bool set[2];
   u64 cupd_rec[2];
+  bool dying = false;   // GOSSIP_STORE_DYING_BIT on its announcement (gossmap_chan_is_dying)
 };
 struct node {
   u32 nchans;
   bool announced;
   u64 nann_rec;
+  std::vector<u64> scids;  // its channels (gossmap_nth_chan): remove_channel() walks them
 };
-struct record { u32 type, timestamp; bool deleted; };
+// one record of the store; `off` = offset of its MESSAGE in the gossip_store image (header at off - 12): what gossip_store_add()
+// returns in the reference (gossipd/gossip_store.c:481-511, "by gossmap convention, offset is *after* hdr")
+struct record { u32 type, timestamp; bool deleted; u64 off; u32 len; };
+struct chan_dying { u64 scid; u32 deadline; u64 rec; };  // gossmap_manage.c struct chan_dying
+
+// ---- gossip_store file format (common/gossip_store.h:15-59, gossipd/gossip_store.c:49-81)
+constexpr u32 GS_DELETED = 0x8000, GS_COMPLETED = 0x2000, GS_DYING = 0x0800;
+constexpr u32 WIRE_GS_CHANNEL_AMOUNT = 4101, WIRE_GS_DELETE_CHAN = 4103, WIRE_GS_CHAN_DYING = 4106, WIRE_GS_UUID = 4107;
+// ccan/crc32c: CRC-32C (Castagnoli), `crc` = the CRC so far (the store seeds it with the record's timestamp)
+static u32 crc32c_table[8][256];
+static bool crc32c_ready = false;
+static void crc32c_init() {
+  for (u32 n = 0; n < 256; n++) {
+    u32 c = n;
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    crc32c_table[0][n] = c;
+  }
+  for (u32 n = 0; n < 256; n++) {
+    u32 c = crc32c_table[0][n];
+    for (int k = 1; k < 8; k++) {
+      c = crc32c_table[0][c & 0xFF] ^ (c >> 8);
+      crc32c_table[k][n] = c;
+    }
+  }
+  crc32c_ready = true;
+}
+static u32 crc32c_sw(u32 crc, const u8 *p, size_t len) {
+  if (!crc32c_ready) crc32c_init();
+  crc = ~crc;
+  while (len >= 8) {
+    u64 w;
+    memcpy(&w, p, 8);
+    w ^= crc;
+    crc = crc32c_table[7][w & 0xFF] ^ crc32c_table[6][(w >> 8) & 0xFF] ^ crc32c_table[5][(w >> 16) & 0xFF] ^ crc32c_table[4][(w >> 24) & 0xFF] ^
+          crc32c_table[3][(w >> 32) & 0xFF] ^ crc32c_table[2][(w >> 40) & 0xFF] ^ crc32c_table[1][(w >> 48) & 0xFF] ^ crc32c_table[0][w >> 56];
+    p += 8; len -= 8;
+  }
+  while (len--) crc = crc32c_table[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+  return ~crc;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static u32 crc32c_hw(u32 crc, const u8 *p, size_t len) {
+  u64 c = (u32)~crc;
+  while (len >= 8) {
+    u64 w;
+    memcpy(&w, p, 8);
+    c = __builtin_ia32_crc32di(c, w);
+    p += 8; len -= 8;
+  }
+  u32 c32 = (u32)c;
+  while (len--) c32 = __builtin_ia32_crc32qi(c32, *p++);
+  return ~c32;
+}
+static u32 crc32c(u32 crc, const u8 *p, size_t len) {
+  static const bool hw = __builtin_cpu_supports("sse4.2");
+  return hw ? crc32c_hw(crc, p, len) : crc32c_sw(crc, p, len);
+}
+#else
+static u32 crc32c(u32 crc, const u8 *p, size_t len) { return crc32c_sw(crc, p, len); }
+#endif
+void put_be16(u8 *p, u32 v) { p[0] = (u8)(v >> 8); p[1] = (u8)v; }
+void put_be32(u8 *p, u32 v) { p[0] = (u8)(v >> 24); p[1] = (u8)(v >> 16); p[2] = (u8)(v >> 8); p[3] = (u8)v; }
+void put_be64(u8 *p, u64 v) { for (int i = 0; i < 8; i++) p[i] = (u8)(v >> (56 - 8 * i)); }
 
 struct queued { bytes msg; bool has_src; nodeid src; };
 
@@ -236,6 +300,10 @@ struct lamd_gossipd {
   std::vector<pending_nannounce> pending_nannounces;
   std::unordered_map<u64, bool, scid_hash> txout_failures{16, scid_hash{seed}};
   std::vector<record> store;
+  // the gossip_store file as gossip_store.c would hold it: version byte, (v16: the uuid record), then gossip_hdr + message per
+  // record -- flags / crc / timestamp rewritten in place by del / set_timestamp / set_flag exactly as the reference pwrite()s them
+  bytes image;
+  std::vector<chan_dying> dying_channels;
 
   // verdicts of the batch being applied: (message bytes, signer) -> verdict.  The keys refer to the bytes, they do not own them:
   // the map is emptied (drop_verdicts) before the batch / the lists it was filled from go away
@@ -283,35 +351,97 @@ struct lamd_gossipd {
     memcpy(ev.peer, peer->k, 33);
     emit(ev);
   }
+  // ---- store: records + the byte image of the file (append_msg, gossip_store.c:49-81)
+  void store_write_event(u64 off, size_t len) {
+    if (!cfg.emit_store_writes || !on_event) return;
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_STORE_WRITE;
+    ev.values[0] = off;
+    ev.data = image.data() + off;
+    ev.len = len;
+    emit(ev);
+  }
+  u64 store_append(u32 type, u32 timestamp, const u8 *data, size_t len) {
+    const u64 hdr = image.size();
+    image.resize(hdr + 12 + len);
+    u8 *h = image.data() + hdr;
+    put_be16(h, GS_COMPLETED);  // (the reference writes flags = 0 and then the completed bit as a one-byte pwrite: same bytes)
+    put_be16(h + 2, (u32)len);
+    put_be32(h + 4, crc32c(timestamp, data, len));
+    put_be32(h + 8, timestamp);
+    memcpy(h + 12, data, len);
+    store.push_back(record{type, timestamp, false, hdr + 12, (u32)len});
+    store_write_event(hdr, 12 + len);
+    return store.size() - 1;
+  }
+  void store_init() {
+    const u8 ver = cfg.store_version ? cfg.store_version : 16;  // GOSSIP_STORE_VER, gossip_store.c:24
+    image.assign(1, ver);
+    if ((ver & 0x1F) >= 16) {  // "v16 add uuid field" (:98): new_uuid_record, :186-197
+      u8 m[34];
+      put_be16(m, WIRE_GS_UUID);
+      memcpy(m + 2, cfg.store_uuid, 32);
+      store_append(WIRE_GS_UUID, 0, m, sizeof m);
+    }
+  }
   u64 store_add(u32 type, u32 timestamp, const u8 *data, size_t len) {
-    store.push_back(record{type, timestamp, false});
+    const u64 idx = store_append(type, timestamp, data, len);
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_ADD;
-    ev.index = store.size() - 1;
+    ev.index = idx;
     ev.type = type;
     ev.timestamp = timestamp;
+    ev.values[0] = store[idx].off;
     ev.data = data;
     ev.len = len;
     emit(ev);
-    return store.size() - 1;
+    return idx;
   }
-  void store_del(u64 idx) {
+  void store_or_flag(u64 idx, u32 flag) {  // gossip_store_set_flag, :572-593
+    u8 *h = image.data() + store[idx].off - 12;
+    put_be16(h, (((u32)h[0] << 8) | h[1]) | flag);
+    store_write_event(store[idx].off - 12, 12);
+  }
+  void store_del(u64 idx) {  // gossip_store_del, :622-638: a channel_announcement takes its amount record (the next one) with it
     store[idx].deleted = true;
+    store_or_flag(idx, GS_DELETED);
+    if (store[idx].type == GOSSIP_CANN && idx + 1 < store.size() && store[idx + 1].type == WIRE_GS_CHANNEL_AMOUNT) {
+      store[idx + 1].deleted = true;
+      store_or_flag(idx + 1, GS_DELETED);
+    }
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_DEL;
     ev.index = idx;
     ev.type = store[idx].type;
+    ev.values[0] = store[idx].off;
     emit(ev);
   }
-  void store_set_ts(u64 idx, u32 ts) {
+  void store_set_ts(u64 idx, u32 ts) {  // gossip_store_set_timestamp, :655-670: timestamp AND crc change
     store[idx].timestamp = ts;
+    u8 *h = image.data() + store[idx].off - 12;
+    put_be32(h + 4, crc32c(ts, image.data() + store[idx].off, store[idx].len));
+    put_be32(h + 8, ts);
+    store_write_event(store[idx].off - 12, 12);
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_SET_TS;
     ev.index = idx;
     ev.timestamp = ts;
+    ev.values[0] = store[idx].off;
+    emit(ev);
+  }
+  void store_set_dying(u64 idx) {
+    store_or_flag(idx, GS_DYING);
+    lamd_gossipd_event ev;
+    memset(&ev, 0, sizeof ev);
+    ev.kind = LAMD_GEV_STORE_FLAG;
+    ev.index = idx;
+    ev.type = store[idx].type;
+    ev.values[0] = store[idx].off;
+    ev.values[1] = GS_DYING;
     emit(ev);
   }
   void peer_update(bool has_peer, const nodeid *peer, u64 scid, u32 fee_base, u32 fee_ppm, u32 cltv, u64 hmin, u64 hmax) {
@@ -667,6 +797,150 @@ struct lamd_gossipd {
     return frc;
   }
 
+  // ---- remove_channel (gossmap_manage.c:296-375) and what leads to it: pruning (:398-470), spent / dying channels (:1369-1497)
+  bool channel_already_dying(u64 scid) const {
+    for (const chan_dying &d : dying_channels)
+      if (d.scid == scid) return true;
+    return false;
+  }
+  // any_cannounce_preceeds_offset (:267-286): does another, not dying, channel of the node sit before `off` in the store?
+  bool any_cannounce_precedes(const node &n, u64 exclude_scid, u64 off) const {
+    for (u64 sc : n.scids) {
+      if (sc == exclude_scid) continue;
+      const chan &c = chans.find(sc)->second;
+      if (store[c.cann_rec].off > off) continue;
+      if (c.dying) continue;
+      return true;
+    }
+    return false;
+  }
+  bool all_node_channels_dying(const node &n, u64 ignore_scid) const {  // :289-298
+    for (u64 sc : n.scids)
+      if (sc != ignore_scid && !chans.find(sc)->second.dying) return false;
+    return true;
+  }
+  void remove_channel(u64 scid) {
+    auto it = chans.find(scid);
+    if (it == chans.end()) return;
+    const chan c = it->second;
+    txout_failures[scid] = true;   // :309 suppress any now-obsolete updates / announcements
+    pending_ann.erase(scid);       // :312-313
+    early_ann.erase(scid);
+    u8 tomb[10];
+    put_be16(tomb, WIRE_GS_DELETE_CHAN);
+    put_be64(tomb + 2, scid);
+    store_add(WIRE_GS_DELETE_CHAN, 0, tomb, sizeof tomb);  // :316-318
+    store_del(c.cann_rec);                                  // :321
+    for (int dir = 0; dir < 2; dir++)
+      if (c.set[dir]) store_del(c.cupd_rec[dir]);
+    for (int dir = 0; dir < 2; dir++) {                     // :328-373 node_announcements that should no longer be there
+      if (dir == 1 && c.node[1] == c.node[0]) continue;
+      auto nit = nodes.find(c.node[dir]);
+      if (nit == nodes.end()) continue;
+      node &n = nit->second;
+      if (!n.announced) continue;
+      if (n.nchans == 1) {  // last channel: delete the node_announcement
+        store_del(n.nann_rec);
+        n.announced = false;
+        continue;
+      }
+      u64 rec;
+      if (store[c.cann_rec].off < store[n.nann_rec].off && !any_cannounce_precedes(n, scid, store[n.nann_rec].off)) {
+        // this was the last channel_announcement in front of the node_announcement: delete and re-add it to keep the order
+        const record r = store[n.nann_rec];
+        const bytes copy(image.begin() + r.off, image.begin() + r.off + r.len);
+        store_del(n.nann_rec);
+        rec = store_add(GOSSIP_NANN, r.timestamp, copy.data(), copy.size());
+        n.nann_rec = rec;
+      } else {
+        if (c.dying) continue;
+        rec = n.nann_rec;
+      }
+      if (all_node_channels_dying(n, scid)) store_set_dying(rec);
+    }
+    // what the reference's next gossmap refresh does: the channel is gone, and so is a node left without channels
+    for (int dir = 0; dir < 2; dir++) {
+      if (dir == 1 && c.node[1] == c.node[0]) continue;
+      auto nit = nodes.find(c.node[dir]);
+      if (nit == nodes.end()) continue;
+      node &n = nit->second;
+      n.scids.erase(std::remove(n.scids.begin(), n.scids.end(), scid), n.scids.end());
+      if (--n.nchans == 0) nodes.erase(nit);
+    }
+    chans.erase(scid);
+  }
+  void channel_spent(u32 blockheight, u64 scid) {  // gossmap_manage_channel_spent, :1439-1497
+    auto it = chans.find(scid);
+    if (it == chans.end()) return;
+    if (channel_already_dying(scid)) return;
+    chan &c = it->second;
+    chan_dying cd;
+    cd.scid = scid;
+    cd.deadline = blockheight + 72;  // BOLT #7: SHOULD forget a channel after a 72-block delay
+    if (on_event) ev_text(LAMD_GEV_TRACE, false, nullptr, "channel " + fmt_scid(scid) + " closing soon due to the funding outpoint being spent");
+    u8 m[14];
+    put_be16(m, WIRE_GS_CHAN_DYING);
+    put_be64(m + 2, scid);
+    put_be32(m + 10, cd.deadline);
+    cd.rec = store_add(WIRE_GS_CHAN_DYING, 0, m, sizeof m);
+    dying_channels.push_back(cd);
+    store_set_dying(c.cann_rec);
+    c.dying = true;
+    for (int dir = 0; dir < 2; dir++)
+      if (c.set[dir]) store_set_dying(c.cupd_rec[dir]);
+    for (int dir = 0; dir < 2; dir++) {
+      if (dir == 1 && c.node[1] == c.node[0]) continue;
+      auto nit = nodes.find(c.node[dir]);
+      if (nit == nodes.end() || !nit->second.announced) continue;
+      if (all_node_channels_dying(nit->second, scid)) store_set_dying(nit->second.nann_rec);
+    }
+  }
+  void kill_dying(u32 new_blockheight) {  // second loop of gossmap_manage_new_block, :1419-1436
+    for (size_t i = 0; i < dying_channels.size(); i++) {
+      if (dying_channels[i].deadline > new_blockheight) continue;
+      const chan_dying cd = dying_channels[i];
+      if (chans.count(cd.scid)) {  // kill_spent_channel, :1369-1387
+        if (on_event) ev_text(LAMD_GEV_TRACE, false, nullptr, "Deleting channel " + fmt_scid(cd.scid) + " due to the funding outpoint being spent");
+        remove_channel(cd.scid);
+      }
+      store_del(cd.rec);
+      dying_channels.erase(dying_channels.begin() + i);
+      i--;
+    }
+  }
+  size_t prune_network() {  // :398-470; the caller owns the timer (GOSSIP_PRUNE_INTERVAL / 4)
+    const int64_t highwater = (int64_t)now() - (int64_t)(cfg.prune_interval ? cfg.prune_interval : 1209600u);
+    // gossmap's channel index order is the order of the announcements in the store
+    std::vector<std::pair<u64, u64>> order;
+    order.reserve(chans.size());
+    for (const auto &kv : chans) order.emplace_back(kv.second.cann_rec, kv.first);
+    std::sort(order.begin(), order.end());
+    nodeid ours;
+    memcpy(ours.k, cfg.our_id, 33);
+    size_t pruned = 0;
+    for (const auto &o : order) {
+      auto it = chans.find(o.second);
+      if (it == chans.end()) continue;
+      const chan &c = it->second;
+      const u32 ts0 = c.set[0] ? store[c.cupd_rec[0]].timestamp : 0xFFFFFFFFu, ts1 = c.set[1] ? store[c.cupd_rec[1]].timestamp : 0xFFFFFFFFu;  // get_timestamp: unknown = good
+      if ((int64_t)ts0 >= highwater && (int64_t)ts1 >= highwater) continue;  // "both ends must refresh!"
+      if (channel_already_dying(o.second)) continue;
+      char b[96];
+      if (on_event && (c.node[0] == ours || c.node[1] == ours)) {
+        const int local = c.node[1] == ours;
+        snprintf(b, sizeof b, ": local channel_update time %u, remote %u", local ? ts1 : ts0, local ? ts0 : ts1);
+        ev_text(LAMD_GEV_TRACE, false, nullptr, "Pruning local channel " + fmt_scid(o.second) + " from gossip_store" + b);
+      }
+      if (on_event) {
+        snprintf(b, sizeof b, " from network view (ages %u and %u)", ts0, ts1);
+        ev_text(LAMD_GEV_TRACE, false, nullptr, "Pruning channel " + fmt_scid(o.second) + b);
+      }
+      remove_channel(o.second);
+      pruned++;
+    }
+    return pruned;
+  }
+
   static void sha256_single(const u8 *p, size_t len, u8 out[32]);
 };
 
@@ -695,6 +969,7 @@ extern "C" lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_conf
   g->on_event = on_event;
   g->user = user;
   memset(&g->st, 0, sizeof g->st);
+  g->store_init();
   return g;
 }
 extern "C" void lamd_gossipd_free(lamd_gossipd *g) { delete g; }
@@ -853,8 +1128,10 @@ extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t
   g->store_add(4101, 0, amt, sizeof amt);
   g->chans.emplace(scid, c);
   for (int i = 0; i < 2; i++) {
+    if (i == 1 && pca.node[1] == pca.node[0]) continue;  // a channel with itself is one entry of that node's list
     node &nd = g->nodes[pca.node[i]];  // value-initialised on first sight
     nd.nchans++;
+    nd.scids.push_back(scid);
   }
   return g->reprocess_queued_msgs();  // :864
 }
@@ -886,7 +1163,27 @@ extern "C" int lamd_gossipd_new_block(lamd_gossipd *g, uint32_t blockheight) {
     if (!g->pending_ann.emplace(scid, std::move(pca)).second) continue;
     g->ev_scid(LAMD_GEV_GET_TXOUT, false, nullptr, scid);
   }
+  g->kill_dying(blockheight);  // :1419-1436 channels whose funding output was spent 72 blocks ago
   return LAMD_OK;
+}
+
+extern "C" int lamd_gossipd_channel_spent(lamd_gossipd *g, uint32_t blockheight, uint64_t scid) {
+  if (!g) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;
+  g->channel_spent(blockheight, scid);
+  return LAMD_OK;
+}
+
+extern "C" long lamd_gossipd_prune(lamd_gossipd *g) {
+  if (!g) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;
+  return (long)g->prune_network();
+}
+
+extern "C" size_t lamd_gossipd_store_image(const lamd_gossipd *g, const uint8_t **data) {
+  if (!g) return 0;
+  if (data) *data = g->image.data();
+  return g->image.size();
 }
 
 extern "C" void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats *out) {

@@ -30,19 +30,19 @@ __global__ void __launch_bounds__(256) k_gtable_build(u32 *__restrict__ gtable, 
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= GTABLE_ENTRIES) return;
   const u32 w = (u32)(idx >> GTABLE_WINDOW_BITS), d = (u32)(idx & ((1u << GTABLE_WINDOW_BITS) - 1u));
-  u32 out[16];
+  u32 out[GT_ENTRY_WORDS];
   if (d == 0) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (int i = 0; i < GT_ENTRY_WORDS; i++) out[i] = 0;
   } else {
     u32 base[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) base[i] = bases[w * 16 + i];
     gtable_compute_entry(out, base, d);
   }
-  uint4 *dst = reinterpret_cast<uint4 *>(gtable + idx * 16);
+  uint2 *dst = reinterpret_cast<uint2 *>(gtable + idx * GT_ENTRY_WORDS);  // entries are 8-byte aligned in both layouts
 #pragma unroll
-  for (int i = 0; i < 4; i++) dst[i] = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+  for (int i = 0; i < GT_ENTRY_WORDS / 2; i++) dst[i] = make_uint2(out[2 * i], out[2 * i + 1]);
 }
 
 // ---- ECDSA scalar preparation: each thread owns signatures tid, tid+T, ... and inverts their
@@ -82,6 +82,35 @@ __global__ void __launch_bounds__(256) k_keys(size_t n, const u8 *__restrict__ p
   keyok[i] = ok;
 }
 
+// ---- the keys of the cold rows (keys seen too rarely for a table; the list and its length live on the device).  A row whose key
+// does not parse is decided HERE (verdict 0) and only the others are compacted onto the ladder's work list: in the configs[1]/[2]
+// workloads nearly every cold row is a damaged key (1.25 % of the rows: unique by construction, so never worth a table), and a
+// ladder wave with one live lane costs as much as a full one -- the ladder kernel's VALU work drops from ~2 % of the rows to the
+// few hundred rows under genuinely rare keys.
+__device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight = 0, u32 *wsum = nullptr);
+__global__ void __launch_bounds__(256) k_keys_cold(size_t n, const u8 *__restrict__ pub, int publen, size_t stride, const u32 *__restrict__ idx,
+                                                   const u32 *__restrict__ count, u32 *__restrict__ counter_ok, u32 *__restrict__ idx_ok,
+                                                   u32 *__restrict__ qwords, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n && i < *count;
+  const size_t row = live ? idx[i] : 0;
+  u32 qx[8], qy[8];
+  const bool ok = live && parse_pubkey(pub + stride * row, publen, qx, qy);
+  const u32 pos = wave_alloc(counter_ok, ok, 0, nullptr);
+  if (!live) return;
+  if (keyok_row) keyok_row[row] = ok;
+  if (!ok) {
+    out[row] = 0;
+    return;
+  }
+  idx_ok[pos] = (u32)row;
+  uint4 *dst = reinterpret_cast<uint4 *>(qwords + (size_t)pos * 16);
+  dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+  dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
+  dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
+  dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
+}
+
 // ---- the hot kernel: R = u1*G + u2*Q and the acceptance test.  WAVES = minimum waves per SIMD the register
 // allocator must leave room for (2nd __launch_bounds__ argument); the engine picks the instantiation (LAMD_ECMULT_WAVES).
 template <int WAVES>
@@ -105,8 +134,9 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
     rec.k2[0] = d.x; rec.k2[1] = d.y; rec.k2[2] = d.z; rec.k2[3] = d.w;
     rec.flags = e.x;
   }
-  if (keyok_row) keyok_row[row] = keyok[i];
-  bool ok = (rec.flags & PREP_VALID) && keyok[i];
+  const bool key_good = keyok ? keyok[i] != 0 : true;  // keyok == nullptr: a compacted list (k_keys_cold), every listed row has a parsed key
+  if (keyok_row && keyok) keyok_row[row] = key_good;
+  bool ok = (rec.flags & PREP_VALID) && key_good;
   if (ok) {  // whole waves of rejected inputs skip the ladder (s_cbranch_execz)
     u32 qx[8], qy[8];
     const uint4 *src = reinterpret_cast<const uint4 *>(qwords + i * 16);
@@ -304,7 +334,7 @@ LAMD_HD u64 key_hash(const u8 *p, int len, u64 seed) {
 // Wave-aggregated allocation from a global counter: ONE atomic per wavefront (an uncontended device atomic costs
 // ~10 ns; a million lane-level atomics on one word serialise into >10 ms -- measured).  Every lane of the wave must call
 // it; lanes with pred get consecutive indices.  `weight` (optional) is summed over the pred lanes into *wsum.
-__device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight = 0, u32 *wsum = nullptr) {
+__device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight, u32 *wsum) {
   const u64 mask = __ballot(pred);
   const u32 lane = threadIdx.x & 63u;
   const u32 prefix = (u32)__popcll(mask & ((1ull << lane) - 1ull));
@@ -336,7 +366,7 @@ constexpr u32 ENT_NONE = 0xFFFFFFFFu;
 enum { C_ENT = 0, C_USED7 = 1, C_USED10 = 2, C_WORDS = 4 };  // cache counters
 // per-call counters ("plan"): everything the host used to read back to size the next launches now stays on the device;
 // launches cover upper bounds and the kernels take their real extent from here
-enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_DENSE = 8, P_WORDS = 16 };
+enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_DENSE = 8, P_COLDOK = 9, P_EARLY = 10, P_WORDS = 16 };
 constexpr u8 VERDICT_SUSPECT = 3;  // the bare-formula ecmult met Z = 0: the complete form decides (k_ecmult_keyed_careful)
 
 LAMD_HD void key_words(u32 kw[17], const u8 *p, int len) {
@@ -362,7 +392,8 @@ LAMD_HD u64 key_words_hash(const u32 kw[17], u64 seed) {
 __global__ void __launch_bounds__(256) k_cache_lookup(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride, u64 seed,
                                                       const u32 *index, u32 mask, const cache_ent *ents, cache_vis vis,
                                                       u32 *__restrict__ row_ent, u32 *__restrict__ plan, u32 *__restrict__ list7,
-                                                      u32 *__restrict__ list10, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+                                                      u32 *__restrict__ list10, u8 *__restrict__ keyok_row, u8 *__restrict__ out,
+                                                      const u8 *__restrict__ sig64, int mode) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   u32 found = ENT_NONE, T = 255;
@@ -385,8 +416,17 @@ __global__ void __launch_bounds__(256) k_cache_lookup(size_t n, const u8 *__rest
     }
     row_ent[i] = found;
   }
+  // early reject: a row whose signature scalars are certain to fail the preparation (range, low-S) gets its verdict here and no
+  // lane of an ecmult wave; its key has a table, i.e. it parsed
+  const bool dead = (T == 7u || T == 10u) && sig_certain_reject(sig64 + 64 * i, mode);
+  if (dead) {
+    out[i] = 0;
+    if (keyok_row) keyok_row[i] = 1;
+    T = 254;
+  }
   const u32 p7 = wave_alloc(&plan[P_L7], T == 7u), p10 = wave_alloc(&plan[P_L10], T == 10u);
   (void)wave_alloc(&plan[P_HITS], found != ENT_NONE);
+  (void)wave_alloc(&plan[P_EARLY], dead);
   if (T == 7u) list7[p7] = (u32)i;
   else if (T == 10u) list10[p10] = (u32)i;
   else if (T == 0u) {  // a key that does not parse
@@ -493,7 +533,7 @@ __global__ void __launch_bounds__(256) k_cache_publish(const u32 *__restrict__ p
 __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ row_ent, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
                                                    const u32 *__restrict__ newent, const cache_ent *__restrict__ ents, u32 *__restrict__ plan,
                                                    u32 *__restrict__ list7, u32 *__restrict__ list10, u32 *__restrict__ listcold,
-                                                   u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+                                                   u8 *__restrict__ keyok_row, u8 *__restrict__ out, const u8 *__restrict__ sig64, int mode) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool miss = i < n && rep[i] != ENT_NONE;
   u32 T = 255;
@@ -504,9 +544,16 @@ __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ r
       T = ents[e].meta & 0xFFu;
     }
   }
+  const bool dead = miss && (T == 7u || T == 10u) && sig_certain_reject(sig64 + 64 * i, mode);  // early reject (see k_cache_lookup)
+  if (dead) {
+    out[i] = 0;
+    if (keyok_row) keyok_row[i] = 1;
+    T = 254;
+  }
   const u32 p7 = wave_alloc(&plan[P_L7], miss && T == 7u), p10 = wave_alloc(&plan[P_L10], miss && T == 10u);
   const u32 pc = wave_alloc(&plan[P_COLD], miss && T == 255u);
-  if (!miss) return;
+  (void)wave_alloc(&plan[P_EARLY], dead);
+  if (!miss || dead) return;
   if (T == 7u) list7[p7] = (u32)i;
   else if (T == 10u) list10[p10] = (u32)i;
   else if (T == 0u) {
@@ -718,7 +765,7 @@ struct lamd_ctx {
   // representative row, cache entry, table slot; parsed key, validity, build scratch), row lists per shape + cold rows
   devbuf row_ent, kd_table, kd_rep, kd_uid, kd_uniq, kd_count, kd_newent, plan, kt_fin;
   devbuf hk7_row, hk7_ent, hk7_slot, hk7_qwords, hk7_keyok, hk7_scratch, hk10_row, hk10_ent, hk10_slot, hk10_qwords, hk10_keyok, hk10_scratch;
-  devbuf list7, list10, listcold;
+  devbuf list7, list10, listcold, listcold_ok;
   u32 *h_plan = nullptr;   // pinned read-back of the last call's plan + cache counters (statistics only: nothing waits for it)
   // Key-table cache.  The root context owns the shared one (LAMD_CACHE=1, default): entries + index + one table pool per
   // comb shape, filled by whichever lane meets a key often enough, looked up by every later call.  With LAMD_CACHE=0 every
@@ -744,7 +791,8 @@ struct lamd_ctx {
   devbuf keyok_row;
   hipStream_t stream2 = nullptr;   // scalar prep runs here, concurrently with the key work on `stream`
   hipStream_t stream3 = nullptr;   // cold rows of a partitioned chunk
-  hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr, ev_keys = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr, ev_keys = nullptr, ev_sigs = nullptr;
+  bool sigs_pending = false;  // lamd_flush put the signature copy on the prep stream: the first kernel of the main stream that reads signatures waits for ev_sigs
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
@@ -894,6 +942,7 @@ static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_keys, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sigs, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
   HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_plan, (P_WORDS + C_WORDS) * 4, hipHostMallocDefault));
@@ -1044,7 +1093,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   for (devbuf *b : {&ctx->row_ent, &ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->plan,
                     &ctx->kt_fin, &ctx->hk7_row, &ctx->hk7_ent, &ctx->hk7_slot, &ctx->hk7_qwords, &ctx->hk7_keyok, &ctx->hk7_scratch,
                     &ctx->hk10_row, &ctx->hk10_ent, &ctx->hk10_slot, &ctx->hk10_qwords, &ctx->hk10_keyok, &ctx->hk10_scratch, &ctx->list7,
-                    &ctx->list10, &ctx->listcold, &ctx->keyok_row, &ctx->cache_store.ents, &ctx->cache_store.index, &ctx->cache_store.pool7,
+                    &ctx->list10, &ctx->listcold, &ctx->listcold_ok, &ctx->keyok_row, &ctx->cache_store.ents, &ctx->cache_store.index, &ctx->cache_store.pool7,
                     &ctx->cache_store.pool10, &ctx->cache_store.counters})
     release(b);
   for (auto &e : ctx->ev_pub)
@@ -1053,6 +1102,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
   if (ctx->ev_cold) (void)hipEventDestroy(ctx->ev_cold);
   if (ctx->ev_keys) (void)hipEventDestroy(ctx->ev_keys);
+  if (ctx->ev_sigs) (void)hipEventDestroy(ctx->ev_sigs);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->vbuf, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
@@ -1246,16 +1296,26 @@ static size_t final_threads(lamd_ctx *ctx, size_t n) {
 // real number of items is *count, on the device): keys -> ladder.  Prep records (indexed by row) must already be queued
 // on stream2 / finished (ev_prep).
 static int launch_direct(lamd_ctx *ctx, int mode, size_t m, const u32 *idx, const u32 *count, const prep_rec *recs, const u8 *d_sig,
-                         const u8 *d_key, int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it) {
+                         const u8 *d_key, int keylen, size_t keystride, u32 *fin, u8 *keyok_row, u8 *d_ok, bool time_it, u32 *plan = nullptr) {
   int rc;
   if ((rc = ensure(ctx, &ctx->qwords, m * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->keyok, m)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->slots, m * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
+  if (idx && count && plan) {
+    // cold rows of a partitioned call: parse, reject the rows whose key does not parse, compact the rest (k_keys_cold)
+    if ((rc = ensure(ctx, &ctx->listcold_ok, m * 4)) != LAMD_OK) return rc;
+    hipLaunchKernelGGL(k_keys_cold, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, d_key, keylen, keystride, idx, count, plan + P_COLDOK,
+                       (u32 *)ctx->listcold_ok.p, (u32 *)ctx->qwords.p, keyok_row, d_ok);
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
+    hipLaunchKernelGGL(kern, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, recs, (const u32 *)ctx->qwords.p, (const u8 *)nullptr, d_sig, mode,
+                       (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, (const u32 *)ctx->listcold_ok.p, fin, keyok_row, d_ok, (const u32 *)(plan + P_COLDOK));
+    return LAMD_OK;
+  }
   hipLaunchKernelGGL(k_keys, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, d_key, keylen, keystride, idx, (u32 *)ctx->qwords.p,
                      (u8 *)ctx->keyok.p, count);
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
-  auto kern = ctx->ecmult_waves == 2 ? k_ecmult<2> : ctx->ecmult_waves == 4 ? k_ecmult<4> : k_ecmult<3>;
   hipLaunchKernelGGL(kern, dim3(blocks_for(m)), dim3(256), 0, ctx->stream, m, recs, (const u32 *)ctx->qwords.p, (const u8 *)ctx->keyok.p, d_sig,
                      mode, (const u32 *)ctx->gtable, (u32 *)ctx->slots.p, idx, fin, keyok_row, d_ok, count);
   return LAMD_OK;
@@ -1402,7 +1462,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
         hipStream_t main = ctx->stream;
         ctx->stream = ctx->stream3;
         rc = launch_direct(ctx, mode, n, (const u32 *)ctx->listcold.p, (const u32 *)(plan_s + P_COLD), recs, d_sig, d_key, keylen, keystride, fin_s, keyok_out,
-                           d_ok, false);
+                           d_ok, false, plan_s);
         ctx->stream = main;
         if (rc != LAMD_OK) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
@@ -1485,8 +1545,9 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     for (int l = 0; l <= MAX_LANES; l++) vis.seq[l] = root->vis_seq[l];
     vis.seq[ctx->lane_id] = root->pub_seq[ctx->lane_id];
     seq = ++root->call_seq;
+    if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs, 0)); ctx->sigs_pending = false; }
     hipLaunchKernelGGL(k_cache_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
-                       (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok);
+                       (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok, d_sig, mode);
   } else {
     HIPCHK(ctx, hipMemsetAsync(row_ent, 0xFF, n * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(cc, 0, C_WORDS * 4, ctx->stream));
@@ -1529,8 +1590,9 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     root->pub_seq[ctx->lane_id] = seq;
     root->pub_pending[ctx->lane_id] = true;
   }
+  if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs, 0)); ctx->sigs_pending = false; }
   hipLaunchKernelGGL(k_partition, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
-                     (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok);
+                     (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok, d_sig, mode);
   // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few rows, i.e.
   // a latency-bound launch that should hide behind the table-driven kernels instead of serialising with them
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
@@ -1539,7 +1601,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     hipStream_t main = ctx->stream;
     ctx->stream = ctx->stream3;
     rc = launch_direct(ctx, mode, n, (const u32 *)listcold, (const u32 *)(plan + P_COLD), recs, d_sig, d_key, keylen, keystride, fin, keyok_out,
-                       d_ok, false);
+                       d_ok, false, plan);
     ctx->stream = main;
     if (rc != LAMD_OK) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
@@ -2329,7 +2391,9 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     // are still on the bus.  All three copies go down the lane's PREP stream back to back and the main stream waits for the
     // keys' event: a copy that itself waits for another stream's copy starts 0.5-1 ms late (rocprofv3 timeline of the pipelined
     // loop, tools/host_path_trace.py: the dependency is resolved by the runtime's host thread), a kernel that waits for a copy
-    // does not.
+    // does not.  (Round 3 tried pulling the rows over PCIe with a KERNEL on the lane's streams instead -- no SDMA queue, every
+    // dependency in order on compute queues: 119-137 M verifies/s against 168-185 M/s for these copies, profiles/r03_ab_variants.txt:
+    // device-initiated reads of host memory reach a fraction of the SDMA engines' 57 GB/s.  Dropped.)
     const bool split = q.n <= L->chunk;
     if (split) {
       HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));  // after whatever the lane's main stream still holds
@@ -2337,8 +2401,12 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream2));
       HIPCHK(ctx, hipEventRecord(L->ev_keys, L->stream2));
       HIPCHK(ctx, hipStreamWaitEvent(L->stream, L->ev_keys, 0));
-      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream2));
+      // signatures before hashes: the row-list builders on the main stream read r and s (early reject) long before the
+      // preparation needs the hashes
       HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream2));
+      HIPCHK(ctx, hipEventRecord(L->ev_sigs, L->stream2));
+      L->sigs_pending = true;
+      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream2));
     } else {
       HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
       HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream));
@@ -2446,7 +2514,11 @@ LAMD_HD void selftest_lane(const st_in &in, const u32 *gtable, u32 *slot, u32 *o
   const ge q = ge_from_words(qx, qy);
   const fe zg = build_q_table(slot, q);
   fe_to_words(w, fe_normalize(zg)); for (int i = 0; i < 8; i++) o[k++] = w[i];                              // 102 zg
-  for (int i = 0; i < 8 * SLOT_ENTRY_WORDS; i++) o[k++] = slot[i];                                            // 110..301 table
+  for (int e = 0; e < 8; e++)                                                                                  // 110..301 table (canonical words)
+    for (int c = 0; c < 3; c++) {
+      fe_to_words(w, fe_normalize(slot_load_fe(slot + e * SLOT_ENTRY_WORDS + c * TW)));
+      for (int i = 0; i < 8; i++) o[k++] = w[i];
+    }
   const gej R = ecmult_lane(rec, q, slot, gtable);
   fe_to_words(w, fe_normalize(R.x)); for (int i = 0; i < 8; i++) o[k++] = w[i];
   fe_to_words(w, fe_normalize(R.y)); for (int i = 0; i < 8; i++) o[k++] = w[i];
@@ -2520,18 +2592,18 @@ extern "C" int lamd_selftest(lamd_ctx *ctx, const uint8_t *hash32, const uint8_t
     memcpy(base, gx, 32); memcpy(base + 8, gy, 32);
     const u32 ds[] = {1, 2, 3, 255, 256, 4097, 65535};
     for (u32 d : ds) {
-      u32 e[16];
+      u32 e[GT_ENTRY_WORDS];
       gtable_compute_entry(e, base, d);
-      if (memcmp(e, &gt[(size_t)d * 16], 64)) { fails |= 1 << 20; rep += "gtable w0 d=" + std::to_string(d) + " differs; "; }
+      if (memcmp(e, &gt[(size_t)d * GT_ENTRY_WORDS], GT_ENTRY_WORDS * 4)) { fails |= 1 << 20; rep += "gtable w0 d=" + std::to_string(d) + " differs; "; }
     }
     // window 1 entry 1 must equal 65536*G = window 0 ... (2^16)G: check via doubling
     gej bb = gej_from_ge(ge_from_words(base, base + 8));
     for (int i = 0; i < GTABLE_WINDOW_BITS; i++) bb = gej_double(bb);
     const fe zi = fe_inv(fe_norm_weak(bb.z)); const fe zi2 = fe_sqr(zi);
-    u32 e[16];
-    fe_to_words(e, fe_normalize(fe_mul(bb.x, zi2)));
-    fe_to_words(e + 8, fe_normalize(fe_mul(bb.y, fe_mul(zi2, zi))));
-    if (memcmp(e, &gt[(((size_t)1 << GTABLE_WINDOW_BITS) + 1) * 16], 64)) { fails |= 1 << 21; rep += "gtable w1 d=1 differs; "; }
+    u32 e[GT_ENTRY_WORDS];
+    slot_store_fe(e, fe_mul(bb.x, zi2));
+    slot_store_fe(e + TW, fe_mul(bb.y, fe_mul(zi2, zi)));
+    if (memcmp(e, &gt[(((size_t)1 << GTABLE_WINDOW_BITS) + 1) * GT_ENTRY_WORDS], GT_ENTRY_WORDS * 4)) { fails |= 1 << 21; rep += "gtable w1 d=1 differs; "; }
   }
   if (report && cap) { strncpy(report, rep.c_str(), cap - 1); report[cap - 1] = 0; }
   return fails;

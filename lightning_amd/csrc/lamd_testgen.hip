@@ -43,10 +43,10 @@ LAMD_HD void gmul_affine(u32 xw[8], u32 yw[8], const sc &k, const u32 *gtable) {
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = gtable_digit(k.w, w);
-    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
     ge pt;
     pt.x = slot_load_fe(e);
-    pt.y = slot_load_fe(e + 8);
+    pt.y = slot_load_fe(e + TW);
     acc = gej_add_ge(acc, pt, d == 0);
   }
   const fe zi = fe_inv(fe_norm_weak(acc.z));

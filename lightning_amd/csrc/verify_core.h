@@ -70,10 +70,22 @@ struct prep_rec {
 };
 enum { PREP_VALID = 1, PREP_K1NEG = 2, PREP_K2NEG = 4, PREP_K1TOP = 8, PREP_K2TOP = 16 };
 
-// scratch slot owned by one ecmult lane (u32 words)
-constexpr int SLOT_WORDS = 256;        // 1 KiB
-constexpr int SLOT_ENTRY_WORDS = 24;   // x[8] | beta*x[8] | y[8]
-constexpr int SLOT_H_OFF = 8 * SLOT_ENTRY_WORDS;  // 6 x 8 words of H_2..H_7
+// Table entries (the ladder's per-lane table, the per-key combs, the static G table) hold their coordinates as 8 x 32-bit words
+// (canonical) and the loads re-pack them into the nine 29-bit limbs the field arithmetic computes in: ~16 VALU instructions per
+// coordinate, 98 coordinates per signature = 1.5 % of the table-driven kernel's instructions.  LAMD_TABLE_LIMBS=1 stores the nine
+// limbs instead (one dword more per coordinate, no re-packing).  Measured on MI355X (round 3, tools/runs/next_ab_variants.sh,
+// profiles/r03_ab_variants.txt): the limb layout is NOT faster -- isolated 1 M-row launch 3.31 / 3.37 ms against 3.29 / 3.28 ms for
+// words: 72-byte G entries straddle 128-byte lines, 112-byte comb entries move 17 % more bytes, and memory waits (10 % of the wave
+// cycles) grow by as much as the VALU work shrinks.  Words ship; the limb layout stays buildable and tested (host build).
+#ifndef LAMD_TABLE_LIMBS
+#define LAMD_TABLE_LIMBS 0
+#endif
+constexpr int TW = LAMD_TABLE_LIMBS ? 9 : 8;                         // words per stored coordinate
+constexpr int SLOT_ENTRY_WORDS = LAMD_TABLE_LIMBS ? 28 : 24;         // x | beta*x | y (+ 1 word of padding: 16-byte aligned entries)
+constexpr int ENT_X = 0, ENT_BX = TW, ENT_Y = 2 * TW;                // word offsets inside an entry
+constexpr int GT_ENTRY_WORDS = 2 * TW;                               // static G table: x | y
+constexpr int SLOT_H_OFF = 8 * SLOT_ENTRY_WORDS;                     // 6 x TW words of H_2..H_7
+constexpr int SLOT_WORDS = LAMD_TABLE_LIMBS ? 288 : 256;             // scratch slot owned by one ladder lane
 
 // Static table of G: window w, digit d -> d * 2^(BITS*w) * G as 64-byte affine words (d = 0 unused).
 // 22-bit windows (12 windows, 3 GiB in HBM) make u1*G twelve mixed additions; measured against 16-bit windows (64 MiB,
@@ -85,7 +97,7 @@ constexpr int SLOT_H_OFF = 8 * SLOT_ENTRY_WORDS;  // 6 x 8 words of H_2..H_7
 constexpr int GTABLE_WINDOW_BITS = LAMD_GTABLE_WINDOW_BITS;
 constexpr int GTABLE_WINDOWS = (256 + GTABLE_WINDOW_BITS - 1) / GTABLE_WINDOW_BITS;
 constexpr size_t GTABLE_ENTRIES = (size_t)GTABLE_WINDOWS << GTABLE_WINDOW_BITS;
-constexpr size_t GTABLE_BYTES = GTABLE_ENTRIES * 64;
+constexpr size_t GTABLE_BYTES = GTABLE_ENTRIES * GT_ENTRY_WORDS * 4;
 // window w of a 256-bit scalar (8 little-endian words); windows may straddle a word and run past bit 255
 LAMD_HD u32 gtable_digit(const u32 k[8], int w) {
   const int bit = w * GTABLE_WINDOW_BITS, i = bit >> 5, sh = bit & 31;
@@ -171,6 +183,23 @@ LAMD_HD void ecdsa_load_rs(const u8 *sig64, sc *r, sc *s, bool *ok) {
   v &= !sc_is_zero(*r) & !sc_is_zero(*s);      // secp256k1_ecdsa_verify: r, s in [1, n-1]
   v &= !sc_is_high(*s);                        // ... and low-S
   *ok = v;
+}
+
+// Cheap pre-test of a signature's two scalars, used by the row-list builders (early reject): true = the preparation kernel is
+// certain to reject this row (ECDSA: r or s outside [1, n-1], or s > n/2 -- secp256k1_ecdsa_signature_parse_compact + low-S rule;
+// BIP-340: r >= p or s >= n), so it needs no lane of an ecmult wave.  Says nothing about rows it lets through.
+LAMD_HD bool sig_certain_reject(const u8 *sig64, int mode) {
+  u32 rw[8], sw[8];
+  load_words_be(rw, sig64);
+  load_words_be(sw, sig64 + 32);
+  if (mode == MODE_SCHNORR) return words_ge_p(rw) | words_ge_n(sw);
+  u32 rz = 0, sz = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { rz |= rw[i]; sz |= sw[i]; }
+  sc s;
+#pragma unroll
+  for (int i = 0; i < 8; i++) s.w[i] = sw[i];
+  return words_ge_n(rw) | words_ge_n(sw) | (rz == 0) | (sz == 0) | sc_is_high(s);
 }
 
 LAMD_HD void ecdsa_prep_thread(size_t first, size_t stride, size_t n, const u8 *hash32, const u8 *sig64,
@@ -268,10 +297,16 @@ LAMD_HD void schnorr_prep_one(const u8 *msg32, const u8 *pk32, const u8 *sig64, 
 
 // ---- table slot helpers
 LAMD_HD void slot_store_fe(u32 *dst, const fe &a) {
-  u32 w[8];
-  fe_to_words(w, fe_normalize(a));
+  const fe n = fe_normalize(a);
+  if (LAMD_TABLE_LIMBS) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) dst[i] = w[i];
+    for (int i = 0; i < 9; i++) dst[i] = n.n[i];
+  } else {
+    u32 w[8];
+    fe_to_words(w, n);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i] = w[i];
+  }
 }
 LAMD_HD fe slot_load_raw(const u32 *src) {
   fe r;
@@ -281,6 +316,7 @@ LAMD_HD fe slot_load_raw(const u32 *src) {
   return r;
 }
 LAMD_HD fe slot_load_fe(const u32 *src) {
+  if (LAMD_TABLE_LIMBS) return slot_load_raw(src);
   u32 w[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) w[i] = src[i];
@@ -294,18 +330,18 @@ template <int NE>
 LAMD_HD fe build_multiples(u32 *slot, u32 *hbuf, const ge &q) {
   gej p = gej_from_ge(q);
   slot_store_fe(slot + 0, p.x);
-  slot_store_fe(slot + 16, p.y);
+  slot_store_fe(slot + ENT_Y, p.y);
   p = gej_double(p);
   slot_store_fe(slot + SLOT_ENTRY_WORDS + 0, p.x);
-  slot_store_fe(slot + SLOT_ENTRY_WORDS + 16, p.y);
+  slot_store_fe(slot + SLOT_ENTRY_WORDS + ENT_Y, p.y);
 #pragma unroll 1
   for (int i = 2; i < NE; i++) {  // entry i = (i+1)Q = entry(i-1) + Q
     bool degenerate;
     fe h, rr;
     p = gej_add_ge_core(p, q, &degenerate, &h, &rr);  // (i)Q = +-Q is impossible for i in 2..NE: no degenerate case
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, p.x);
-    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, p.y);
-    slot_store_fe(hbuf + (i - 2) * 8, h);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + ENT_Y, p.y);
+    slot_store_fe(hbuf + (i - 2) * TW, h);
   }
   const fe zg = fe_norm_weak(p.z);
   const u32 betaw[8] = LAMD_BETA;
@@ -313,22 +349,22 @@ LAMD_HD fe build_multiples(u32 *slot, u32 *hbuf, const ge &q) {
   // the last entry already has Z = Zg
   {
     const fe x = slot_load_fe(slot + (NE - 1) * SLOT_ENTRY_WORDS);
-    slot_store_fe(slot + (NE - 1) * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
+    slot_store_fe(slot + (NE - 1) * SLOT_ENTRY_WORDS + ENT_BX, fe_mul(x, beta));
   }
   fe rho = fe_set_int(1);
 #pragma unroll 1
   for (int i = NE - 2; i >= 0; i--) {
     // rho = Zg / Z_entry(i): entry i+1 = entry i + Q had Z_{i+1} = Z_i * H (H stored at index i-1 for i >= 1),
     // and entry 1 = 2Q has Z = Z_2, entry 0 = Q has Z = 1 so its ratio is Zg itself.
-    if (i >= 1) rho = fe_mul(rho, slot_load_fe(hbuf + (i - 1) * 8));
+    if (i >= 1) rho = fe_mul(rho, slot_load_fe(hbuf + (i - 1) * TW));
     else rho = zg;
     const fe r2 = fe_sqr(rho);
     const fe r3 = fe_mul(r2, rho);
     const fe x = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + 0), r2);
-    const fe y = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + 16), r3);
+    const fe y = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + ENT_Y), r3);
     slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, x);
-    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
-    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 16, y);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + ENT_BX, fe_mul(x, beta));
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + ENT_Y, y);
   }
   return zg;
 }
@@ -361,8 +397,8 @@ LAMD_HD gej ecmult_lane(const prep_rec &rec, const ge &q, u32 *slot, const u32 *
       const int a = d < 0 ? -d : d;
       const u32 *e = slot + (skip ? 0 : a - 1) * SLOT_ENTRY_WORDS;
       ge pt;
-      pt.x = slot_load_fe(e + (half ? 8 : 0));
-      pt.y = slot_load_fe(e + 16);
+      pt.x = slot_load_fe(e + (half ? ENT_BX : ENT_X));
+      pt.y = slot_load_fe(e + ENT_Y);
       pt = ge_neg_if(pt, d < 0);
       acc = gej_add_ge(acc, pt, skip);
     }
@@ -374,17 +410,17 @@ LAMD_HD gej ecmult_lane(const prep_rec &rec, const ge &q, u32 *slot, const u32 *
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = gtable_digit(rec.u1, w);
     const bool skip = d == 0;
-    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
     ge pt;
     pt.x = slot_load_fe(e);
-    pt.y = slot_load_fe(e + 8);
+    pt.y = slot_load_fe(e + TW);
     acc = gej_add_ge(acc, pt, skip);
   }
   return acc;
 }
 
 // One entry of the static G table: out = d * B (B = 2^(BITS*w) * G given as affine words), d >= 1.
-LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
+LAMD_HD void gtable_compute_entry(u32 out[GT_ENTRY_WORDS], const u32 base[16], u32 d) {
   const ge b = ge_from_words(base, base + 8);
   gej acc = gej_infinity();
 #pragma unroll 1
@@ -394,8 +430,8 @@ LAMD_HD void gtable_compute_entry(u32 out[16], const u32 base[16], u32 d) {
   }
   const fe zi = fe_inv_var(acc.z);
   const fe zi2 = fe_sqr(zi);
-  fe_to_words(out, fe_normalize(fe_mul(acc.x, zi2)));
-  fe_to_words(out + 8, fe_normalize(fe_mul(acc.y, fe_mul(zi2, zi))));
+  slot_store_fe(out, fe_mul(acc.x, zi2));
+  slot_store_fe(out + TW, fe_mul(acc.y, fe_mul(zi2, zi)));
 }
 
 // ================================================================================================
@@ -418,7 +454,7 @@ constexpr int kc_ne(int T) { return 1 << (T - 1); }
 constexpr int KC_SUB_LOG = 4, KC_SUB = 1 << KC_SUB_LOG;            // entries built by one thread (a Gray-code chain)
 constexpr int kc_nsub(int T) { return kc_ne(T) / KC_SUB; }
 constexpr int kc_words(int T) { return (kc_ne(T) + 1) * SLOT_ENTRY_WORDS; }
-constexpr int kc_stride(int T) { return kc_words(T) + 16; }        // + Zc (8 words), keeps 16-byte alignment
+constexpr int kc_stride(int T) { return kc_words(T) + 16; }        // + Zc (TW words), keeps 16-byte alignment
 // scratch per key (words): P0 = entry 0 as a Jacobian point (27) | Zb (9) | C_i = 2*B_i, i < T-1, affine (18 each) |
 // per chain: Z_chain (9), unify ratio (9), the 15 H values of its additions (9 each).  Stage 1 parks its 2T-1
 // Jacobian points (36 words each) in the per-chain area before any chain uses it.
@@ -517,7 +553,7 @@ LAMD_HD void kc_chain_fwd(u32 *tab, u32 *scratch, int sub) {
     }
   }
   slot_store_fe(ent + 0, p.x);
-  slot_store_fe(ent + 16, p.y);
+  slot_store_fe(ent + ENT_Y, p.y);
 #pragma unroll 1
   for (int g = 1; g < KC_SUB; g++) {
     const int c = __builtin_ctz((unsigned)g), gr = g ^ (g >> 1);
@@ -527,7 +563,7 @@ LAMD_HD void kc_chain_fwd(u32 *tab, u32 *scratch, int sub) {
     pt = ge_neg_if(pt, ((gr >> c) & 1) == 0);  // tooth c goes - to +: add 2*B_c; + to -: subtract it
     p = gej_add_ge_core(p, pt, &degenerate, &h, &rr);
     slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 0, p.x);
-    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 16, p.y);
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + ENT_Y, p.y);
     store_raw(sp + 18 + (g - 1) * 9, h);
   }
   store_raw(sp + 0, fe_norm_weak(p.z));
@@ -556,8 +592,8 @@ LAMD_HD void kc_prefix(u32 *tab, u32 *scratch, const ge &q) {
   const fe x = fe_mul(q.x, z2);
   u32 *e = tab + NE * SLOT_ENTRY_WORDS;
   slot_store_fe(e + 0, x);
-  slot_store_fe(e + 8, fe_mul(x, fe_from_words(betaw)));
-  slot_store_fe(e + 16, fe_mul(q.y, fe_mul(z2, zc)));
+  slot_store_fe(e + ENT_BX, fe_mul(x, fe_from_words(betaw)));
+  slot_store_fe(e + ENT_Y, fe_mul(q.y, fe_mul(z2, zc)));
 }
 template <int T>
 LAMD_HD void kc_chain_bwd(u32 *tab, const u32 *scratch, int sub) {
@@ -572,10 +608,10 @@ LAMD_HD void kc_chain_bwd(u32 *tab, const u32 *scratch, int sub) {
     const int gr = g ^ (g >> 1);
     const fe r2 = fe_sqr(rho);
     const fe x = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 0), r2);
-    const fe y = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + 16), fe_mul(r2, rho));
+    const fe y = fe_mul(slot_load_fe(ent + gr * SLOT_ENTRY_WORDS + ENT_Y), fe_mul(r2, rho));
     slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 0, x);
-    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 8, fe_mul(x, beta));
-    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + 16, y);
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + ENT_BX, fe_mul(x, beta));
+    slot_store_fe(ent + gr * SLOT_ENTRY_WORDS + ENT_Y, y);
   }
 }
 // sequential composition (CPU test harness; the engine launches the stages as separate kernels)
@@ -726,8 +762,8 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
       const u32 idx = (top ? m : ~m) & (u32)(NE - 1);
       const u32 *e = tab + idx * SLOT_ENTRY_WORDS;
       ge pt;
-      pt.x = slot_load_fe(e + (half ? 8 : 0));
-      pt.y = slot_load_fe(e + 16);
+      pt.x = slot_load_fe(e + (half ? ENT_BX : ENT_X));
+      pt.y = slot_load_fe(e + ENT_Y);
       pt = ge_neg_if_lazy(pt, top == (half ? cp.n2 : cp.n1));
 #if defined(LAMD_TOUCH_NEXT) && defined(__HIP_DEVICE_COMPILE__)
       // experiment (not in the shipped build): touch the table entry of the NEXT addition before this one starts, so that its cache
@@ -739,8 +775,8 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
         for (int i = 0; i < T; i++) nm |= (((nh ? cp.tooth2[i] : cp.tooth1[i]) >> nj) & 1u) << i;
         const u32 nidx = (((nm >> (T - 1)) & 1u) ? nm : ~nm) & (u32)(NE - 1);
         const volatile u32 *ne_ = tab + nidx * SLOT_ENTRY_WORDS;
-        (void)ne_[nh ? 8 : 0];
-        (void)ne_[16];
+        (void)ne_[nh ? ENT_BX : ENT_X];
+        (void)ne_[ENT_Y];
       }
 #endif
       if (j == D - 1 && half == 0) {  // uniform across the wave: the first point is the accumulator
@@ -765,10 +801,10 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
     for (int i = 0; i < 7; i++) uw[i] = (uw[i] >> GTABLE_WINDOW_BITS) | (uw[i + 1] << (32 - GTABLE_WINDOW_BITS));
     uw[7] >>= GTABLE_WINDOW_BITS;
     if (d != 0) {  // a zero digit (2^-22 per window) is a divergent skip, not a select
-      const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+      const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
       ge pt;
       pt.x = slot_load_fe(e);
-      pt.y = slot_load_fe(e + 8);
+      pt.y = slot_load_fe(e + TW);
       acc = gej_add_ge_fast(acc, pt);
     }
   }
@@ -796,8 +832,8 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
       const u32 idx = (top ? m : ~m) & (u32)(NE - 1);
       const u32 *e = tab + idx * SLOT_ENTRY_WORDS;
       ge pt;
-      pt.x = slot_load_fe(e + (half ? 8 : 0));
-      pt.y = slot_load_fe(e + 16);
+      pt.x = slot_load_fe(e + (half ? ENT_BX : ENT_X));
+      pt.y = slot_load_fe(e + ENT_Y);
       pt = ge_neg_if(pt, top == (half ? n2 : n1));  // column value is -entry when the top tooth is -1; times the half's sign
       acc = gej_add_ge(acc, pt, false);
     }
@@ -807,8 +843,8 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
   for (int half = 0; half < 2; half++) {
     const u32 *e = tab + NE * SLOT_ENTRY_WORDS;
     ge pt;
-    pt.x = slot_load_fe(e + (half ? 8 : 0));
-    pt.y = slot_load_fe(e + 16);
+    pt.x = slot_load_fe(e + (half ? ENT_BX : ENT_X));
+    pt.y = slot_load_fe(e + ENT_Y);
     pt = ge_neg_if(pt, !(half ? n2 : n1));
     acc = gej_add_ge(acc, pt, !(half ? h2.even : h1.even));
   }
@@ -818,10 +854,10 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = gtable_digit(rec.u1, w);
     const bool skip = d == 0;
-    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
     ge pt;
     pt.x = slot_load_fe(e);
-    pt.y = slot_load_fe(e + 8);
+    pt.y = slot_load_fe(e + TW);
     acc = gej_add_ge(acc, pt, skip);
   }
   return acc;
@@ -1246,10 +1282,10 @@ LAMD_HD bool grind_candidate(u32 c, u32 min_rate, u64 weight, u64 input_sat, con
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = gtable_digit(u1.w, w);
-    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * 16;
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
     ge pt;
     pt.x = slot_load_fe(e);
-    pt.y = slot_load_fe(e + 8);
+    pt.y = slot_load_fe(e + TW);
     acc = gej_add_ge(acc, pt, d == 0);
   }
   return ecdsa_final(acc, rw);

@@ -14,7 +14,8 @@ class Event(ctypes.Structure):
 
 class Config(ctypes.Structure):
     _fields_ = [("chain_hash", ctypes.c_ubyte * 32), ("our_id", ctypes.c_ubyte * 33), ("blockheight", ctypes.c_uint32), ("now", ctypes.c_uint64),
-                ("prune_interval", ctypes.c_uint32)]
+                ("prune_interval", ctypes.c_uint32), ("store_version", ctypes.c_uint8), ("emit_store_writes", ctypes.c_uint8),
+                ("store_uuid", ctypes.c_ubyte * 32)]
 
 
 class Stats(ctypes.Structure):
@@ -27,7 +28,7 @@ EVENT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(Event))
 SIGCHECK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
 KEYPARSE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p)
 KINDS = {1: "WARNING", 2: "GET_TXOUT", 3: "STORE_ADD", 4: "STORE_DEL", 5: "STORE_SET_TS", 6: "PEER_UPDATE", 7: "TRACE", 8: "QUERY_CHANNEL",
-         9: "QUERY_NODE", 10: "GOOD_GOSSIP", 11: "TXOUT_FAILED"}
+         9: "QUERY_NODE", 10: "GOOD_GOSSIP", 11: "TXOUT_FAILED", 12: "STORE_FLAG", 13: "STORE_WRITE"}
 
 _lib = None
 
@@ -47,6 +48,11 @@ def _load():
         L.lamd_gossipd_process.argtypes = [ctypes.c_void_p]
         L.lamd_gossipd_txout_reply.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t]
         L.lamd_gossipd_new_block.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.lamd_gossipd_channel_spent.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64]
+        L.lamd_gossipd_prune.restype = ctypes.c_long
+        L.lamd_gossipd_prune.argtypes = [ctypes.c_void_p]
+        L.lamd_gossipd_store_image.restype = ctypes.c_size_t
+        L.lamd_gossipd_store_image.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         L.lamd_gossipd_set_time.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         L.lamd_gossipd_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
         _lib = L
@@ -58,13 +64,17 @@ class GossipIngest:
     sigcheck(msgs_blob: bytes, off: list[int], ids: bytes) -> list[int], keyparse(keys: bytes) -> list[int] -- which tests use to
     run the host logic against a CPU checker on a machine without a GPU."""
 
-    def __init__(self, engine, chain_hash, our_id, blockheight, now, prune_interval=0, backend=None, collect_events=True):
+    def __init__(self, engine, chain_hash, our_id, blockheight, now, prune_interval=0, backend=None, collect_events=True, store_version=0,
+                 store_uuid=bytes(32), emit_store_writes=False):
         self._L = _load()
         cfg = Config()
         cfg.chain_hash[:] = chain_hash
         cfg.our_id[:] = our_id
         cfg.blockheight, cfg.now, cfg.prune_interval = blockheight, now, prune_interval
+        cfg.store_version, cfg.emit_store_writes = store_version, 1 if emit_store_writes else 0
+        cfg.store_uuid[:] = store_uuid
         self.events = []
+        self.writes = []     # (offset, bytes) of every LAMD_GEV_STORE_WRITE event (emit_store_writes=True)
         self._cb = EVENT_FN(self._on_event) if collect_events else ctypes.cast(None, EVENT_FN)
         self._engine = engine
         self._g = self._L.lamd_gossipd_new(engine._ctx if engine is not None else None, ctypes.byref(cfg), self._cb, None)
@@ -100,6 +110,10 @@ class GossipIngest:
             self.events.append((k, e.index, e.type))
         elif k == "STORE_SET_TS":
             self.events.append((k, e.index, e.timestamp))
+        elif k == "STORE_FLAG":
+            self.events.append((k, e.index, e.type, int(e.values[1])))
+        elif k == "STORE_WRITE":
+            self.writes.append((int(e.values[0]), ctypes.string_at(e.data, e.len)))
         elif k == "PEER_UPDATE":
             self.events.append((k, peer, e.scid) + tuple(e.values))
         elif k == "QUERY_CHANNEL":
@@ -139,6 +153,26 @@ class GossipIngest:
 
     def new_block(self, height):
         self._L.lamd_gossipd_new_block(self._g, height)
+
+    def set_time(self, now):
+        self._L.lamd_gossipd_set_time(self._g, now)
+
+    def channel_spent(self, blockheight, scid):
+        rc = self._L.lamd_gossipd_channel_spent(self._g, blockheight, scid)
+        if rc != 0:
+            raise RuntimeError("lamd_gossipd_channel_spent: %d" % rc)
+
+    def prune(self):
+        n = self._L.lamd_gossipd_prune(self._g)
+        if n < 0:
+            raise RuntimeError("lamd_gossipd_prune: %d" % n)
+        return n
+
+    def store_image(self):
+        """the gossip_store file the reference would hold after the same operations (bytes)"""
+        p = ctypes.c_void_p()
+        n = self._L.lamd_gossipd_store_image(self._g, ctypes.byref(p))
+        return ctypes.string_at(p, n)
 
     def stats(self):
         s = Stats()

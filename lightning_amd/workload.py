@@ -82,10 +82,15 @@ def make_ecdsa(engine, n, seed=SEED_CFG2, nkeys=65536, publen=65, invalid_frac=0
         elif name == "high_s":
             _put(s[i, 32:], N - _int(s[i, 32:]))
         elif name == "wrong_key":
-            k = (int(i) + 1) % n
-            while np.array_equal(p[k], p[i]):
-                k = (k + 1) % n
-            p[i] = p[k]
+            k, tries = (int(i) + 1) % n, 0
+            while np.array_equal(p[k], p[i]) and tries < 256:
+                k, tries = (k + 1) % n, tries + 1
+            if tries < 256:
+                p[i] = p[k]
+            else:                           # every row carries the same key (nkeys = 1): the signature itself is swapped instead
+                k = (int(i) + 1) % n
+                s[i] = s[k]
+                h[i, 0] ^= 1                # (and the hash is touched, in case the neighbour signed the same message)
         elif name == "r_zero":
             s[i, :32] = 0
         elif name == "s_zero":

@@ -8,8 +8,10 @@ Follows /root/reference/gossipd/gossipd.c:172-286 (handle_recv_gossip) and gossi
 Every signature is checked when the reference checks it, by `sigcheck(msg, signer_or_None)` (default: the C oracle's
 restatement of gossipd/sigcheck.c, one call per message); fromwire_* is restated from wire/peer_wire.csv:344-381 with
 pyref's framing helpers.  Only tests import this: the product's batched ingest (lightning_amd/csrc/gossip_ingest.cpp) is
-compared against it event by event.  Not modelled (neither is it in the product): pruning, dying channels, the seeker's
-internals, local announcements with a known amount, the store's file format.
+compared against it event by event.  Also modelled: remove_channel :296-375, prune_network :398-470, kill_spent_channel /
+the dying loop of new_block :1369-1437, gossmap_manage_channel_spent :1439-1497.  Not modelled (neither is it in the product): the
+seeker's internals, local announcements with a known amount, store compaction.  (The store's FILE FORMAT is not restated here: the
+product's image is compared byte for byte with files the reference's gossipd wrote, tests/test_gossip_ingest.py.)
 
 Events are tuples (kind, peer_hex_or_None, ...) in the vocabulary of include/lightning_amd_gossipd.h."""
 import hashlib
@@ -69,7 +71,7 @@ def wireaddrs_ok(b):  # common/wireaddr.c:30-68, 858-891
 
 
 class Model:
-    def __init__(self, chain_hash, our_id, blockheight, now, sigcheck, key_valid, prune_interval=1209600):
+    def __init__(self, chain_hash, our_id, blockheight, now, sigcheck, key_valid, prune_interval=1209600, store_version=16):
         self.chain_hash, self.our_id, self.blockheight, self.now, self.prune = chain_hash, our_id, blockheight, now, prune_interval
         self.sigcheck = sigcheck      # (msg, signer33 or None) -> 0 ok / k first bad signature / -1 malformed
         self.key_valid = key_valid    # 33 bytes -> bool (fromwire_pubkey)
@@ -77,7 +79,9 @@ class Model:
         self.pending_ann, self.early_ann = {}, {}
         self.pending_cupdates, self.early_cupdates, self.pending_nannounces = [], [], []
         self.txout_failures = set()
-        self.store = []               # [type, timestamp, deleted]
+        # [type, timestamp, deleted, dying]; record numbers grow with the file offset.  A v16 store opens with its uuid record (gossip_store.c:186-197)
+        self.store = [[4107, 0, False, False]] if (store_version & 0x1F) >= 16 else []
+        self.dying = []               # [scid, deadline, record] (struct chan_dying)
         self.events = []
 
     # ---- helpers
@@ -100,13 +104,19 @@ class Model:
             self.warning(peer, text)
 
     def store_add(self, typ, ts, data):
-        self.store.append([typ, ts, False])
+        self.store.append([typ, ts, False, False])
         self.ev("STORE_ADD", len(self.store) - 1, typ, ts, data.hex())
         return len(self.store) - 1
 
-    def store_del(self, idx):
+    def store_del(self, idx):  # gossip_store_del :622-638 (a channel_announcement takes its amount record with it)
         self.store[idx][2] = True
+        if self.store[idx][0] == CANN and idx + 1 < len(self.store) and self.store[idx + 1][0] == 4101:
+            self.store[idx + 1][2] = True
         self.ev("STORE_DEL", idx, self.store[idx][0])
+
+    def store_set_dying(self, idx):  # gossip_store_set_flag(.., GOSSIP_STORE_DYING_BIT, ..)
+        self.store[idx][3] = True
+        self.ev("STORE_FLAG", idx, self.store[idx][0], 0x0800)
 
     def sigcheck_text(self, typ, which, m):  # gossipd/sigcheck.c
         off = 258 if typ == CANN else 66
@@ -187,7 +197,7 @@ class Model:
             return
         rec = self.store_add(CANN, 0, pca["msg"])
         self.store_add(4101, 0, b"\x10\x05" + sat.to_bytes(8, "big"))
-        self.chans[scid] = dict(node=pca["node"], cann=rec, cupd=[None, None])
+        self.chans[scid] = dict(node=pca["node"], cann=rec, cupd=[None, None], dying=False)
         for n in pca["node"]:
             self.nodes.setdefault(n, dict(nann=None))
         self.reprocess_queued_msgs()
@@ -254,6 +264,7 @@ class Model:
         if node["nann"] is not None:
             self.store_del(node["nann"])
         node["nann"] = rec
+        node["msg"] = m
         if peer is not None:
             self.ev("GOOD_GOSSIP", self.ph(peer))
         self.ev("TRACE", self.ph(peer), "Received node_announcement for node " + nid.hex())
@@ -330,3 +341,118 @@ class Model:
                 continue
             self.pending_ann[scid] = pca
             self.ev("GET_TXOUT", scid)
+
+        # :1419-1436 dying channels whose deadline has come
+        i = 0
+        while i < len(self.dying):
+            scid, deadline, rec = self.dying[i]
+            if deadline > height:
+                i += 1
+                continue
+            if scid in self.chans:  # kill_spent_channel :1369-1387
+                self.ev("TRACE", None, "Deleting channel %s due to the funding outpoint being spent" % fmt_scid(scid))
+                self.remove_channel(scid)
+            self.store_del(rec)
+            del self.dying[i]
+
+    # ---- gossmap views the removal code needs
+    def node_chans(self, nid):
+        return [s for s, c in self.chans.items() if nid in c["node"]]
+
+    def any_cannounce_precedes(self, nid, exclude, off):  # :267-286
+        for s in self.node_chans(nid):
+            if s == exclude:
+                continue
+            c = self.chans[s]
+            if c["cann"] > off or c["dying"]:
+                continue
+            return True
+        return False
+
+    def all_node_channels_dying(self, nid, ignore):  # :289-298
+        return all(self.chans[s]["dying"] for s in self.node_chans(nid) if s != ignore)
+
+    # ---- :296-375
+    def remove_channel(self, scid):
+        chan = self.chans[scid]
+        self.txout_failures.add(scid)
+        self.pending_ann.pop(scid, None)
+        self.early_ann.pop(scid, None)
+        self.store_add(4103, 0, b"\x10\x07" + scid.to_bytes(8, "big"))
+        self.store_del(chan["cann"])
+        for d in (0, 1):
+            if chan["cupd"][d] is not None:
+                self.store_del(chan["cupd"][d])
+        for d in (0, 1):
+            nid = chan["node"][d]
+            if d == 1 and nid == chan["node"][0]:
+                continue
+            node = self.nodes.get(nid)
+            if node is None or node["nann"] is None:
+                continue
+            if len(self.node_chans(nid)) == 1:
+                self.store_del(node["nann"])
+                node["nann"] = None
+                continue
+            if chan["cann"] < node["nann"] and not self.any_cannounce_precedes(nid, scid, node["nann"]):
+                ts, msg = self.store[node["nann"]][1], node["msg"]
+                self.store_del(node["nann"])
+                off = self.store_add(NANN, ts, msg)
+                node["nann"] = off
+            else:
+                if chan["dying"]:
+                    continue
+                off = node["nann"]
+            if self.all_node_channels_dying(nid, scid):
+                self.store_set_dying(off)
+        del self.chans[scid]
+        for nid in set(chan["node"]):   # the next gossmap refresh drops nodes without channels
+            if not self.node_chans(nid):
+                self.nodes.pop(nid, None)
+
+    # ---- :1439-1497
+    def channel_spent(self, blockheight, scid):
+        chan = self.chans.get(scid)
+        if chan is None:
+            return
+        if any(d[0] == scid for d in self.dying):
+            return
+        deadline = blockheight + 72
+        self.ev("TRACE", None, "channel %s closing soon due to the funding outpoint being spent" % fmt_scid(scid))
+        rec = self.store_add(4106, 0, b"\x10\x0a" + scid.to_bytes(8, "big") + deadline.to_bytes(4, "big"))
+        self.dying.append([scid, deadline, rec])
+        self.store_set_dying(chan["cann"])
+        chan["dying"] = True
+        for d in (0, 1):
+            if chan["cupd"][d] is not None:
+                self.store_set_dying(chan["cupd"][d])
+        for d in (0, 1):
+            nid = chan["node"][d]
+            if d == 1 and nid == chan["node"][0]:
+                continue
+            node = self.nodes.get(nid)
+            if node is None or node["nann"] is None:
+                continue
+            if self.all_node_channels_dying(nid, scid):
+                self.store_set_dying(node["nann"])
+
+    # ---- :398-470
+    def prune_network(self):
+        highwater = self.now - self.prune
+        pruned = 0
+        for scid in sorted(self.chans, key=lambda s: self.chans[s]["cann"]):   # gossmap's channel index order = store order
+            chan = self.chans.get(scid)
+            if chan is None:
+                continue
+            ts = [self.store[chan["cupd"][d]][1] if chan["cupd"][d] is not None else 0xFFFFFFFF for d in (0, 1)]
+            if ts[0] >= highwater and ts[1] >= highwater:
+                continue
+            if any(d[0] == scid for d in self.dying):
+                continue
+            if self.our_id in chan["node"]:
+                local = 1 if chan["node"][1] == self.our_id else 0
+                self.ev("TRACE", None, "Pruning local channel %s from gossip_store: local channel_update time %u, remote %u" % (fmt_scid(scid), ts[local], ts[1 - local]))
+            self.ev("TRACE", None, "Pruning channel %s from network view (ages %u and %u)" % (fmt_scid(scid), ts[0], ts[1]))
+            self.remove_channel(scid)
+            pruned += 1
+        return pruned

@@ -66,13 +66,13 @@ int dm_parse_pubkey(const u8 *p, int len, u8 *out64) { u32 qx[8], qy[8]; bool ok
 static std::vector<u32> g_table;
 void dm_init(void) {
   if (!g_table.empty()) return;
-  g_table.assign(GTABLE_ENTRIES * 16, 0);
+  g_table.assign(GTABLE_ENTRIES * GT_ENTRY_WORDS, 0);
   const u32 gx[8] = LAMD_GX, gy[8] = LAMD_GY;
   u32 base[16];
   memcpy(base, gx, 32); memcpy(base + 8, gy, 32);
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     for (u32 d = 1; d < (1u << GTABLE_WINDOW_BITS); d++)
-      gtable_compute_entry(&g_table[(((size_t)w << GTABLE_WINDOW_BITS) + d) * 16], base, d);
+      gtable_compute_entry(&g_table[(((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS], base, d);
     // next base = 2^BITS * base
     gej b = gej_from_ge(ge_from_words(base, base + 8));
     for (int i = 0; i < GTABLE_WINDOW_BITS; i++) b = gej_double(b);
@@ -82,7 +82,15 @@ void dm_init(void) {
   }
 }
 // table entry as 64 big-endian bytes
-void dm_gtable_entry(int w, u32 d, u8 *out64) { dm_init(); const u32 *e = &g_table[(((size_t)w << GTABLE_WINDOW_BITS) + d) * 16]; words_to_be(out64, e); words_to_be(out64 + 32, e + 8); }
+void dm_gtable_entry(int w, u32 d, u8 *out64) {
+  dm_init();
+  const u32 *e = &g_table[(((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS];
+  u32 xw[8], yw[8];
+  fe_to_words(xw, fe_normalize(slot_load_fe(e)));
+  fe_to_words(yw, fe_normalize(slot_load_fe(e + TW)));
+  words_to_be(out64, xw);
+  words_to_be(out64 + 32, yw);
+}
 
 // Whole pipeline exactly as the kernels stage it.  threads = how many "prep threads" share the batch
 // (exercises the Montgomery batch inversion with different group sizes).
@@ -142,8 +150,8 @@ static void keytable_entry_t(const u32 *qx, const u32 *qy, int idx, u8 *out96) {
   const u32 *e = &tab[idx * SLOT_ENTRY_WORDS];
   u32 w[8];
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e), zi2))); words_to_be(out96, w);
-  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 16), zi3))); words_to_be(out96 + 32, w);
-  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + 8), zi2))); words_to_be(out96 + 64, w);
+  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + ENT_Y), zi3))); words_to_be(out96 + 32, w);
+  fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + ENT_BX), zi2))); words_to_be(out96 + 64, w);
 }
 extern "C" {
 int dm_comb_spacing(int T) { return kc_spacing(T); }

@@ -89,7 +89,7 @@ def damage(rnd, m, kind):
     return bytes(b)
 
 
-def make_script(orc, seed, n_nodes=12, n_chans=30, n_ops=900):
+def make_script(orc, seed, n_nodes=12, n_chans=30, n_ops=900, lifecycle=False):
     """-> (net, ops): ops is a list of ("push", peer, msg) | ("process",) | ("txout", scid, sat, script) | ("block", height)"""
     net = Net(orc, seed, n_nodes, n_chans)
     rnd = random.Random(seed ^ 0x5EED)
@@ -179,6 +179,26 @@ def make_script(orc, seed, n_nodes=12, n_chans=30, n_ops=900):
     ops.append(("block", height + 30))
     ops.append(("process",))
     ops.append(("txouts", "all", 0.9))
+    if lifecycle:
+        # the channel life cycle after the flood: funding outputs get spent (dying, removed 72 blocks later), time passes and
+        # prune_network runs, more gossip arrives in between (updates for dying / removed channels, node_announcements that move)
+        lr = random.Random(seed ^ 0x11FE)
+        for rnd_round in range(6):
+            for _ in range(lr.randrange(1, 5)):
+                ops.append(("spent", height, lr.randrange(n_chans)))
+            for _ in range(lr.randrange(3, 12)):
+                c, d = lr.randrange(n_chans), lr.randrange(2)
+                ops.append(("push", lr.choice(net.peers), net.cupd(c, d, NOW + 100 + 50 * rnd_round + lr.randrange(40))))
+            for _ in range(lr.randrange(1, 4)):
+                ops.append(("push", lr.choice(net.peers), net.nann(lr.randrange(n_nodes), NOW + 100 + 50 * rnd_round)))
+            ops.append(("process",))
+            height += lr.choice([10, 40, 80])
+            ops.append(("block", height))
+            if rnd_round in (2, 4):
+                ops.append(("time", NOW + (8 + 4 * rnd_round) * 86400))
+                ops.append(("prune",))
+        ops.append(("block", height + 100))
+        ops.append(("process",))
     return net, ops
 
 
@@ -195,6 +215,12 @@ def drive(net, ops, receiver, seed):
             receiver.process()
         elif op[0] == "block":
             receiver.new_block(op[1])
+        elif op[0] == "spent":
+            receiver.channel_spent(op[1], net.chans[op[2]]["scid"])
+        elif op[0] == "time":
+            receiver.set_time(op[1])
+        elif op[0] == "prune":
+            receiver.prune()
         elif op[0] == "txouts":
             ev = receiver.events
             for e in ev[seen:]:

@@ -46,6 +46,15 @@ class ModelReceiver:
     def new_block(self, h):
         self.m.new_block(h)
 
+    def channel_spent(self, bh, scid):
+        self.m.channel_spent(bh, scid)
+
+    def set_time(self, now):
+        self.m.now = now
+
+    def prune(self):
+        return self.m.prune_network()
+
 
 def oracle_backend(orc):
     def sig(blob, off, ids):
@@ -100,6 +109,41 @@ def test_batched_ingest_equals_sequential_model_cpu_backend(orc):
     assert tot["duplicates"] > 0 and tot["keyparse_messages"] > 0
 
 
+def test_channel_life_cycle_spent_dying_pruned_equals_sequential_model(orc):
+    """remove_channel (gossmap_manage.c:296-375) reached through channel_spent -> 72 blocks -> new_block (:1419-1497) and through
+    prune_network (:398-470): tombstones, deleted records, node_announcements deleted with their last channel / moved behind a
+    surviving channel_announcement / flagged dying -- event for event against the sequential model, and the store image stays a
+    well-formed gossip_store (every crc valid, flags as the events say)"""
+    from lightning_amd.gossipd import GossipIngest
+    k = {}
+    for seed in (31, 32, 33):
+        net, ops = gs.make_script(orc, seed, lifecycle=True)
+        model = ModelReceiver(orc, net)
+        gs.drive(net, ops, model, seed)
+        with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc), emit_store_writes=True) as ing:
+            gs.drive(net, ops, ing, seed)
+            _compare(ing.events, model.events)
+            img = ing.store_image()
+            recs = _store_records(img)
+            assert img[0] == 16 and int.from_bytes(recs[0][3][:2], "big") == 4107          # GOSSIP_STORE_VER, the uuid record
+            assert len(recs) == len(model.m.store)
+            for (off, flags, ts, m, crc), (typ, mts, deleted, dying) in zip(recs, model.m.store):
+                assert crc == _crc32c(ts, m) and int.from_bytes(m[:2], "big") == typ and ts == mts
+                assert flags == 0x2000 | (0x8000 if deleted else 0) | (0x0800 if dying else 0), (off, hex(flags), deleted, dying)
+            f = bytearray([img[0]])
+            for off, data in ing.writes:
+                if off + len(data) > len(f):
+                    f.extend(bytes(off + len(data) - len(f)))
+                f[off:off + len(data)] = data
+            assert bytes(f)[1 + 12 + 34:] == img[1 + 12 + 34:]     # (the uuid record is written before the callback exists)
+        for kind, c in _kinds(model.events).items():
+            k[kind] = k.get(kind, 0) + c
+    assert k.get("STORE_FLAG", 0) > 10 and k.get("STORE_DEL", 0) > 30
+    texts = [e[2] for e in model.events if e[0] == "TRACE"]
+    for needle in ("closing soon due to the funding outpoint being spent", "Deleting channel", "Pruning channel"):
+        assert any(needle in t for t in texts), needle
+
+
 def test_ingest_ordering_dependencies_explicit(orc):
     """the dependency VERDICT names: a channel_update is only accepted once its channel_announcement has been accepted AND
     confirmed (gossmap_manage.c:900-924, 1060-1097) -- in one batch, across batches, and when the announcement is bad"""
@@ -141,3 +185,120 @@ def test_batched_ingest_on_the_engine_equals_sequential_model(orc):
             _compare(ing.events, model.events)
             st = ing.stats()
             assert st["late_verifies"] == 0 and st["batches"] > 3 and st["verified_sigs"] > 300
+
+
+# ---- the gossip_store FILE FORMAT, against files written by the reference's own gossipd
+# (contrib/pyln-client/tests/data/gossip_store*.xz, decompressed into tests/golden/ by make_golden.py harvest_gossip_stores)
+def _crc32c(crc, data):
+    crc ^= 0xFFFFFFFF
+    for b in data:
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ 0x82F63B78 if crc & 1 else crc >> 1
+    return crc ^ 0xFFFFFFFF
+
+
+def _store_records(blob):
+    import struct
+    recs, off = [], 1
+    while off + 12 <= len(blob):
+        flags, ln, crc, ts = struct.unpack(">HHII", blob[off:off + 12])
+        recs.append((off + 12, flags, ts, blob[off + 12:off + 12 + ln], crc))
+        off += 12 + ln
+    assert off == len(blob)
+    return recs
+
+
+def _replay_reference_store(blob, make_ingest):
+    """feeds the messages of a reference-written store to the ingest in store order, answering every txout request with the amount
+    the store's channel_amount record holds, and returns (ingest image, events)"""
+    import hashlib
+    recs = _store_records(blob)
+    now = max(ts for _, _, ts, _, _ in recs) + 10
+    peer = bytes.fromhex("02" + "ab" * 32)
+    chain = None
+    for _, _, _, m, _ in recs:
+        if int.from_bytes(m[:2], "big") == 256:
+            flen = int.from_bytes(m[258:260], "big")
+            chain = m[260 + flen:292 + flen]
+            break
+    ing = make_ingest(chain, peer, 1 << 22, now)
+    k = 0
+    while k < len(recs):
+        _, flags, ts, m, _ = recs[k]
+        t = int.from_bytes(m[:2], "big")
+        if t == 256:
+            amt = recs[k + 1][3]
+            assert int.from_bytes(amt[:2], "big") == 4101
+            flen = int.from_bytes(m[258:260], "big")
+            ko = 260 + flen + 32 + 8
+            scid = int.from_bytes(m[260 + flen + 32:ko], "big")
+            k1, k2 = sorted([m[ko + 66:ko + 99], m[ko + 99:ko + 132]])
+            spk = b"\x00\x20" + hashlib.sha256(b"\x52\x21" + k1 + b"\x21" + k2 + b"\x52\xae").digest()
+            ing.push(peer, m)
+            assert ing.process() == 1
+            ing.txout_reply(scid, int.from_bytes(amt[2:10], "big"), spk)
+            k += 2
+        else:
+            assert t in (257, 258), t
+            ing.push(peer, m)
+            assert ing.process() == 1
+            k += 1
+    return ing
+
+
+def _check_store_fixture(name, make_ingest):
+    blob = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+    assert blob[0] == 0x0F                                                       # GOSSIP_STORE_VER of the day: minor 15, no uuid record
+    ing = _replay_reference_store(blob, make_ingest)
+    img = ing.store_image()
+    warn = [e for e in ing.events if e[0] == "WARNING"]
+    assert not warn, warn[:3]                                                    # every message of a reference store is good gossip
+    assert ing.stats()["late_verifies"] == 0
+    want, got = _store_records(blob), _store_records(img)
+    assert len(img) == len(blob) and img[0] == blob[0] and len(want) == len(got)
+    for (o1, f1, t1, m1, c1), (o2, f2, t2, m2, c2) in zip(want, got):
+        # 0x4000 was v15's GOSSIP_STORE_PUSH_BIT (a locally generated message gossipd pushes to its peers): a property of who
+        # created the message, not of the store format -- the current common/gossip_store.h has no such bit
+        assert (o1, f1 & ~0x4000, t1, m1, c1) == (o2, f2, t2, m2, c2), (name, o1, hex(f1), hex(f2), t1, t2)
+        assert c2 == _crc32c(t2, m2)
+    # and byte for byte, once the push bit is masked in the reference file
+    masked = bytearray(blob)
+    for o, f, _, _, _ in want:
+        masked[o - 12] &= 0xBF
+    assert bytes(masked) == img
+    # the write events, applied like pwrite() to an empty file, give the same image
+    f = bytearray([blob[0]])
+    for off, data in ing.writes:
+        if off + len(data) > len(f):
+            f.extend(bytes(off + len(data) - len(f)))
+        f[off:off + len(data)] = data
+    assert bytes(f) == img
+    ing.close()
+    return len(want)
+
+
+@pytest.mark.parametrize("name", ["gossip_store_simple.bin", "gossip_store_mesh_3x3.bin"])
+def test_store_image_equals_the_file_the_reference_gossipd_wrote(orc, name):
+    """N2's store append format, judged by a fixture the builder did not author: the gossip_store files under
+    contrib/pyln-client/tests/data were written by the reference's gossipd (real node keys, libsecp256k1 signatures).  Replaying
+    their messages in store order through the batched ingest -- every signature verified, the txout answered with the recorded
+    amount -- must reproduce the file: record framing (struct gossip_hdr, common/gossip_store.h:44-49), COMPLETED / DELETED flags
+    (a replaced channel_update is marked deleted, gossip_store.c:622-638), the crc32c seeded with the timestamp (:67), the
+    channel_announcement's timestamp rewritten to its first update's (gossmap_manage.c:950-951, gossip_store.c:655-670)."""
+    from lightning_amd.gossipd import GossipIngest
+
+    def make(chain, peer, height, now):
+        return GossipIngest(None, chain, peer, height, now, prune_interval=0xFFFFFFFF, backend=oracle_backend(orc), store_version=0x0F, emit_store_writes=True)
+    assert _check_store_fixture(name, make) >= 6
+
+
+@pytest.mark.gpu
+def test_store_image_of_the_reference_files_with_the_engine(orc):
+    from lightning_amd import Engine
+    from lightning_amd.gossipd import GossipIngest
+    with Engine(0) as eng:
+        def make(chain, peer, height, now):
+            return GossipIngest(eng, chain, peer, height, now, prune_interval=0xFFFFFFFF, store_version=0x0F, emit_store_writes=True)
+        for name in ("gossip_store_simple.bin", "gossip_store_mesh_3x3.bin"):
+            _check_store_fixture(name, make)

@@ -27,7 +27,7 @@ def _rows(rows, w):
 
 def test_native_library_is_what_runs(eng):
     inf = eng.info()
-    assert inf["arch"].startswith("gfx950") and inf["gtable_bytes"] == 12 * (64 << 22)   # 12 windows of 2^22 64-byte entries
+    assert inf["arch"].startswith("gfx950") and inf["gtable_bytes"] in (12 * (64 << 22), 12 * (72 << 22))   # 12 windows of 2^22 entries (8-word / 9-limb coordinates)
     import ctypes
     from lightning_amd import _build
     assert ctypes.CDLL(_build.LIB)  # the in-tree .so is loaded
