@@ -529,7 +529,7 @@ def main():
                             e.queue_schnorr_batch(wl.cols[0], wl.cols[1], wl.cols[2])
                         e.flush()
                         pend.append(wl)
-                        if len(pend) == 3:
+                        if len(pend) == 4:
                             bad += int((e.wait(cap=n) != pend.pop(0).expect).sum())
                 while pend:
                     bad += int((e.wait(cap=n) != pend.pop(0).expect).sum())
@@ -558,7 +558,7 @@ def main():
                                 c[:], b_[:] = wl.cols[1], wl.cols[2]
                         e.flush()
                         pend.append(wl)
-                        if len(pend) == 3:
+                        if len(pend) == 4:
                             bad += int((e.wait(cap=n) != pend.pop(0).expect).sum())
                 while pend:
                     bad += int((e.wait(cap=n) != pend.pop(0).expect).sum())
@@ -570,7 +570,7 @@ def main():
                 hm[name] = {"verifies_per_s": 20 * n / dtm, "ms_per_2M_step": dtm / 10 * 1e3, "steps": 10, "mismatches": badm,
                             "note": "rows written into the pinned staging set by the producer (lamd_queue_reserve): no host-side copy inside the clock"}
                 mism += badm
-            out["pcie_inclusive"]["mix_streaming"] = dict(hm, rows_per_flush=n, flushes_in_flight=3,
+            out["pcie_inclusive"]["mix_streaming"] = dict(hm, rows_per_flush=n, flushes_in_flight=4,
                                                           note="1 M ECDSA-65 + 1 M BIP-340 per step from host memory to verdicts in host memory "
                                                                "(289 MB in per step); compare with `value` (inputs resident in HBM)")
         # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):

@@ -12,6 +12,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <climits>
+#include <thread>
 #include <map>
 #include <random>
 #include <string>
@@ -33,6 +36,19 @@ using lamd::u32;
 using lamd::u64;
 
 typedef std::vector<u8> bytes;
+// a message by reference: bytes of the batch arena (alive until the batch has been applied) or of a waiting list's own copy
+struct mview {
+  const u8 *p;
+  size_t n;
+  mview() : p(nullptr), n(0) {}
+  mview(const u8 *p_, size_t n_) : p(p_), n(n_) {}
+  mview(const bytes &b) : p(b.data()), n(b.size()) {}  // NOLINT: implicit on purpose
+  const u8 *data() const { return p; }
+  size_t size() const { return n; }
+  const u8 &operator[](size_t i) const { return p[i]; }
+  const u8 *begin() const { return p; }
+  const u8 *end() const { return p + n; }
+};
 struct nodeid {
   u8 k[33];
   bool operator<(const nodeid &o) const { return memcmp(k, o.k, 33) < 0; }
@@ -94,7 +110,7 @@ std::string hexs(const u8 *p, size_t n) {
   for (size_t i = 0; i < n; i++) { s.push_back(d[p[i] >> 4]); s.push_back(d[p[i] & 15]); }
   return s;
 }
-std::string hexs(const bytes &b) { return hexs(b.data(), b.size()); }
+std::string hexs(const mview &b) { return hexs(b.data(), b.size()); }
 u64 be64(const u8 *p) { u64 v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | p[i]; return v; }
 u32 be32(const u8 *p) { return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | p[3]; }
 u32 be16(const u8 *p) { return ((u32)p[0] << 8) | p[1]; }
@@ -131,7 +147,7 @@ const u8 ORDER_N[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x
 bool sig_in_range(const u8 *sig64) { return memcmp(sig64, ORDER_N, 32) < 0 && memcmp(sig64 + 32, ORDER_N, 32) < 0; }  // wire/fromwire.c:196
 
 // gossipd/sigcheck.c:21-26,52-113,150-157: the text for "first bad signature = which" (1-based)
-std::string sigcheck_text(u32 type, int which, const bytes &m) {
+std::string sigcheck_text(u32 type, int which, const mview &m) {
   const size_t off = type == GOSSIP_CANN ? 258 : 66;
   struct sha256_double h;
   sha256_double(&h, m.data() + off, m.size() - off);
@@ -164,6 +180,28 @@ bool wireaddrs_ok(const u8 *p, size_t len) {
     p += alen + 2; len -= alen + 2;
   }
   return true;
+}
+
+// splits [0, n) over a few short-lived threads (the planning pass and the staging copy of a large batch: framing, range checks,
+// content hashes, P2WSH script hashes -- per-message work that reads the maps but never writes them)
+static unsigned host_threads() {
+  static const unsigned t = [] {
+    const char *e = getenv("LAMD_INGEST_THREADS");
+    unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+    return v < 1 ? 1u : (v > 16 ? 16u : v);
+  }();
+  return t;
+}
+template <class F>
+static void parallel_for(size_t n, size_t min_per_thread, F f) {
+  unsigned t = host_threads();
+  if (n / (min_per_thread ? min_per_thread : 1) < t) t = (unsigned)(n / (min_per_thread ? min_per_thread : 1));
+  if (t <= 1) { f((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  const size_t step = (n + t - 1) / t;
+  for (unsigned k = 1; k < t; k++) th.emplace_back(f, std::min(n, k * step), std::min(n, (k + 1) * step));
+  f((size_t)0, std::min(n, step));
+  for (auto &x : th) x.join();
 }
 
 struct pending_cannounce {  // gossmap_manage.c:36-45
@@ -266,7 +304,8 @@ void put_be16(u8 *p, u32 v) { p[0] = (u8)(v >> 8); p[1] = (u8)v; }
 void put_be32(u8 *p, u32 v) { p[0] = (u8)(v >> 24); p[1] = (u8)(v >> 16); p[2] = (u8)(v >> 8); p[3] = (u8)v; }
 void put_be64(u8 *p, u64 v) { for (int i = 0; i < 8; i++) p[i] = (u8)(v >> (56 - 8 * i)); }
 
-struct queued { bytes msg; bool has_src; nodeid src; };
+struct queued { mview msg; bool has_src; nodeid src; };
+struct qent { u64 off; u32 len; bool has_src; nodeid src; };  // a queued message inside the arena
 
 // one message of a batch as plan() saw it
 struct planned {
@@ -276,6 +315,12 @@ struct planned {
   int slot;           // verification slot with the signer the plan expects (-1: none)
   int keyslot;        // channel_announcement whose bitcoin keys only are parsed (-1: none)
   u64 scid;
+  // filled by the parallel pass: what the serial pass needs to register the slot without touching the message again
+  bool want_slot, want_keys;
+  const nodeid *signer;   // the signer the plan expects (a channel's node, the relaying peer, or nullptr: the message names its own)
+  u64 h;                  // vkey(message, signer).h
+  u8 spk[32];             // channel_announcement: SHA256 of the 2-of-2 script (the P2WSH program)
+  bool spk_set;
 };
 
 }  // namespace
@@ -291,7 +336,9 @@ struct lamd_gossipd {
   lamd_gossipd_stats st;
 
   const u64 seed = ((u64)std::random_device{}() << 32) ^ std::random_device{}() ^ 0x6C616D6467737064ull;
-  std::vector<queued> queue;
+  // connectd's queue: the messages sit back to back in ONE arena (a push is an append, a batch push one memcpy)
+  bytes qarena;
+  std::vector<qent> queue;
   std::unordered_map<u64, chan, scid_hash> chans{16, scid_hash{seed}};
   std::unordered_map<nodeid, node, nodeid_hash> nodes{16, nodeid_hash{seed}};
   std::unordered_map<u64, pending_cannounce, scid_hash> pending_ann{16, scid_hash{seed}};
@@ -466,7 +513,7 @@ struct lamd_gossipd {
     if (!ctx) return LAMD_ERR_ARG;
     return lamd_pubkey_parse_batch(ctx, n, pub33, 33, 33, nullptr, ok);
   }
-  msgkey vkey(const bytes &m, const nodeid *signer) const {
+  msgkey vkey(const mview &m, const nodeid *signer) const {
     msgkey k{m.data(), m.size(), signer ? signer->k : nullptr, 0};
     k.h = content_hash(seed, k.m, k.len);
     if (signer) k.h = content_hash(k.h, signer->k, 33);
@@ -474,7 +521,7 @@ struct lamd_gossipd {
   }
   // verdict of (message, signer): the planned pairs answer from the slot list that went to the device (cur_sl / cur_v, set by
   // verify()); a pair the plan did not foresee is verified on the spot and remembered in `verdicts`
-  int verdict_of(const bytes &m, const nodeid *signer) {
+  int verdict_of(const mview &m, const nodeid *signer) {
     const msgkey k = vkey(m, signer);
     if (cur_sl) {
       auto its = cur_sl->index.find(k);
@@ -497,15 +544,16 @@ struct lamd_gossipd {
   bool in_process = false;    // lamd_gossipd_process() is applying a batch: callbacks must not re-enter the state-changing entry points
 
   struct slotlist {
-    std::vector<const bytes *> msg;
+    std::vector<mview> msg;
     std::vector<const nodeid *> signer;
     verdict_map index;
-    int add(lamd_gossipd *g, const bytes &m, const nodeid *signer_) {
-      const msgkey k = g->vkey(m, signer_);
+    int add(lamd_gossipd *g, const mview &m, const nodeid *signer_) { return add(g, m, signer_, g->vkey(m, signer_).h); }
+    int add(lamd_gossipd *g, const mview &m, const nodeid *signer_, u64 h) {  // h = vkey(m, signer_).h, computed by the (parallel) plan
+      const msgkey k{m.data(), m.size(), signer_ ? signer_->k : nullptr, h};
       const int s = (int)msg.size();
       const auto ins = index.try_emplace(k, s);
       if (!ins.second) { g->st.duplicates++; return ins.first->second; }
-      msg.push_back(&m);
+      msg.push_back(m);
       signer.push_back(signer_);
       return s;
     }
@@ -517,14 +565,15 @@ struct lamd_gossipd {
     bytes blob, ids(33 * n, 0);
     std::vector<uint64_t> off(n + 1, 0);
     size_t total = 0;
-    for (size_t i = 0; i < n; i++) total += sl.msg[i]->size();
-    blob.reserve(total);
-    for (size_t i = 0; i < n; i++) {
-      blob.insert(blob.end(), sl.msg[i]->begin(), sl.msg[i]->end());
-      off[i + 1] = blob.size();
-      if (sl.signer[i]) memcpy(&ids[33 * i], sl.signer[i]->k, 33);
-      st.verified_sigs += ((*sl.msg[i])[0] == 1 && (*sl.msg[i])[1] == 0) ? 4 : 1;
-    }
+    for (size_t i = 0; i < n; i++) { off[i + 1] = off[i] + sl.msg[i].size(); total += sl.msg[i].size(); }
+    blob.resize(total + 1);
+    parallel_for(n, 4096, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) {
+        memcpy(&blob[off[i]], sl.msg[i].data(), sl.msg[i].size());
+        if (sl.signer[i]) memcpy(&ids[33 * i], sl.signer[i]->k, 33);
+      }
+    });
+    for (size_t i = 0; i < n; i++) st.verified_sigs += (sl.msg[i][0] == 1 && sl.msg[i][1] == 0) ? 4 : 1;
     std::vector<int8_t> v(n, -2);
     const int rc = backend_sigcheck(n, blob.data(), off.data(), ids.data(), v.data());
     if (rc != LAMD_OK) return rc;
@@ -545,13 +594,13 @@ struct lamd_gossipd {
 
   // ---- gossmap_manage_channel_announcement (:620-753) with the sigcheck verdict `v` (or the key-only verdict) known
   void apply_cann(const queued &q, const planned &p, int key_ok) {
-    const bytes &m = q.msg;
+    const mview &m = q.msg;
     std::string err;
     do {
       if (p.malformed || (p.keyslot >= 0 && !key_ok)) { err = "Malformed channel_announcement " + hexs(m); break; }  // :648
       int v = 0;
       if (p.keyslot < 0) {
-        v = verdict_of(m, nullptr);
+        v = p.slot >= 0 ? cur_v[p.slot] : verdict_of(m, nullptr);  // the plan's slot: no second hash of the message
         if (v == -1) { err = "Malformed channel_announcement " + hexs(m); break; }  // an invalid bitcoin key: fromwire_pubkey
         if (v == -2) return;  // engine fault: not consumed (fault_rc)
       }
@@ -574,20 +623,24 @@ struct lamd_gossipd {
       }
       if (v > 0) { err = sigcheck_text(GOSSIP_CANN, v, m); break; }   // :689-696
       pending_cannounce pca;
-      pca.msg = m;
+      pca.msg.assign(m.begin(), m.end());
       pca.has_src = q.has_src;
       pca.src = q.src;
       pca.node[0] = id1;
       pca.node[1] = id2;
       {  // scriptpubkey_p2wsh(bitcoin_redeem_2of2(key1, key2)) (:699-702; bitcoin/script.c:149-165): keys in DER order
-        const u8 *k1 = &m[f.keyoff + 66], *k2 = &m[f.keyoff + 99];
-        if (memcmp(k1, k2, 33) >= 0) std::swap(k1, k2);
-        u8 script[71];
-        script[0] = 0x52; script[1] = 33; memcpy(script + 2, k1, 33);
-        script[35] = 33; memcpy(script + 36, k2, 33);
-        script[69] = 0x52; script[70] = 0xae;
         u8 h[32];
-        sha256_single(script, sizeof script, h);
+        if (p.spk_set) {
+          memcpy(h, p.spk, 32);  // hashed by the parallel planning pass
+        } else {
+          const u8 *k1 = &m[f.keyoff + 66], *k2 = &m[f.keyoff + 99];
+          if (memcmp(k1, k2, 33) >= 0) std::swap(k1, k2);
+          u8 script[71];
+          script[0] = 0x52; script[1] = 33; memcpy(script + 2, k1, 33);
+          script[35] = 33; memcpy(script + 36, k2, 33);
+          script[69] = 0x52; script[70] = 0xae;
+          sha256_single(script, sizeof script, h);
+        }
         pca.spk.resize(34);
         pca.spk[0] = 0x00; pca.spk[1] = 0x20;
         memcpy(&pca.spk[2], h, 32);
@@ -612,7 +665,7 @@ struct lamd_gossipd {
 
   // ---- process_channel_update (:878-998); returns the error text ("" = none)
   // (`upd` = the message bytes: u.update for an update that waited in a list, the batch's own copy otherwise)
-  std::string process_channel_update(const pending_cupdate &u, const bytes &upd) {
+  std::string process_channel_update(const pending_cupdate &u, const mview &upd, int known_verdict = INT32_MIN) {
     const int dir = u.cflags & 1;
     auto it = chans.find(u.scid);
     if (it == chans.end()) {
@@ -622,7 +675,7 @@ struct lamd_gossipd {
       return "";
     }
     chan &c = it->second;
-    const int v = verdict_of(upd, &c.node[dir]);  // :920-926
+    const int v = known_verdict != INT32_MIN ? known_verdict : verdict_of(upd, &c.node[dir]);  // :920-926
     if (v == -2) return "";  // engine fault (fault_rc): the caller keeps the update
     if (v != 0) return sigcheck_text(GOSSIP_CUPD, 1, upd);
     if (u.mflags & 2) return "Do not set DONT_FORWARD on public channel_updates (" + fmt_scid(u.scid) + ")";  // :929-932
@@ -648,7 +701,7 @@ struct lamd_gossipd {
   }
 
   static pending_cupdate parse_cupdate(const queued &q) {
-    const bytes &m = q.msg;
+    const mview &m = q.msg;
     pending_cupdate u;
     u.scid = be64(&m[98]);
     u.timestamp = be32(&m[106]);
@@ -665,15 +718,15 @@ struct lamd_gossipd {
   }
   // ---- gossmap_manage_channel_update (:1014-1120)
   void apply_cupd(const queued &q, const planned &p) {
-    const bytes &m = q.msg;
+    const mview &m = q.msg;
     std::string err;
     do {
       if (p.malformed) { err = "channel_update: malformed " + hexs(m); break; }  // :1044-1046
       if (memcmp(&m[66], cfg.chain_hash, 32) != 0) return;                       // :1054-1057
       pending_cupdate u = parse_cupdate(q);
       if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
-      if (pending_ann.count(u.scid)) { u.update = m; pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
-      if (early_ann.count(u.scid)) { u.update = m; early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
+      if (pending_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
+      if (early_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
       if (!chans.count(u.scid) && q.has_src) {                                             // :1107-1116
         const int pv = verdict_of(m, &q.src);
         if (pv == -2) return;
@@ -682,13 +735,18 @@ struct lamd_gossipd {
           return;
         }
       }
-      err = process_channel_update(u, m);
+      {  // the plan's verdict stands if the signer it expected is the one process_channel_update() will ask for
+        int known = INT32_MIN;
+        auto itc = chans.find(u.scid);
+        if (p.slot >= 0 && p.signer && itc != chans.end() && *p.signer == itc->second.node[u.cflags & 1]) known = cur_v[p.slot];
+        err = process_channel_update(u, m, known);
+      }
     } while (0);
     if (!err.empty()) warning(q.has_src, &q.src, err);
   }
 
   // ---- process_node_announcement (:1122-1160)
-  void process_node_announcement(node &n, u32 timestamp, const nodeid &id, const bytes &m, bool has_src, const nodeid *src) {
+  void process_node_announcement(node &n, u32 timestamp, const nodeid &id, const mview &m, bool has_src, const nodeid *src) {
     if (n.announced && store[n.nann_rec].timestamp >= timestamp) return;
     const u64 rec = store_add(GOSSIP_NANN, timestamp, m.data(), m.size());
     if (n.announced) store_del(n.nann_rec);
@@ -710,12 +768,12 @@ struct lamd_gossipd {
   }
   // ---- gossmap_manage_node_announcement (:1162-1243)
   void apply_nann(const queued &q, const planned &p) {
-    const bytes &m = q.msg;
+    const mview &m = q.msg;
     std::string err;
     do {
       if (p.malformed) { err = "node_announcement: malformed " + hexs(m); break; }  // :1197-1198
       if (p.addrs_bad) { err = "node_announcement: malformed wireaddrs  in " + hexs(m); break; }  // :1210-1213 (tal_hex(NULL) is "")
-      const int v = verdict_of(m, nullptr);
+      const int v = p.slot >= 0 ? cur_v[p.slot] : verdict_of(m, nullptr);
       if (v == -2) return;
       if (v == -1) { err = "node_announcement: malformed " + hexs(m); break; }
       if (v != 0) { err = sigcheck_text(GOSSIP_NANN, 1, m); break; }  // :1216-1219
@@ -727,7 +785,7 @@ struct lamd_gossipd {
       if (it == nodes.end()) {
         if (!pending_ann.empty() || !early_ann.empty()) {  // :1224-1230
           pending_nannounce pn;
-          pn.id = id; pn.timestamp = timestamp; pn.msg = m; pn.has_src = q.has_src; pn.src = q.src;
+          pn.id = id; pn.timestamp = timestamp; pn.msg.assign(m.begin(), m.end()); pn.has_src = q.has_src; pn.src = q.src;
           pending_nannounces.push_back(std::move(pn));
           return;
         }
@@ -982,14 +1040,16 @@ extern "C" void lamd_gossipd_set_backend(lamd_gossipd *g, lamd_gossipd_sigcheck_
 extern "C" void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now) { if (g) g->cfg.now = now; }
 
 extern "C" int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, const uint8_t *msg, size_t len) {
-  if (!g || (!msg && len)) return LAMD_ERR_ARG;
+  if (!g || (!msg && len) || len > 0xFFFFFFFFu) return LAMD_ERR_ARG;
   if (g->queue.size() > 500000) return LAMD_ERR_STATE;  // connectd/multiplex.c:832-833
-  queued q;
-  q.msg.assign(msg, msg + len);
+  qent q;
+  q.off = g->qarena.size();
+  q.len = (u32)len;
+  g->qarena.insert(g->qarena.end(), msg, msg + len);
   q.has_src = source_peer33 != nullptr;
   memset(q.src.k, 0, 33);
   if (source_peer33) memcpy(q.src.k, source_peer33, 33);
-  g->queue.push_back(std::move(q));
+  g->queue.push_back(q);
   return LAMD_OK;
 }
 
@@ -997,23 +1057,118 @@ extern "C" int lamd_gossipd_push_batch(lamd_gossipd *g, size_t n, const uint8_t 
                                        const uint64_t *off) {
   if (!g || (n && (!msgs || !off))) return LAMD_ERR_ARG;
   if (g->queue.size() + n > 500000 + 1) return LAMD_ERR_STATE;
-  g->queue.reserve(g->queue.size() + n);
-  for (size_t i = 0; i < n; i++) {
-    const int rc = lamd_gossipd_push(g, source_peers33 ? source_peers33 + peer_stride * i : nullptr, msgs + off[i], (size_t)(off[i + 1] - off[i]));
-    if (rc != LAMD_OK) return rc;
-  }
+  const size_t base = g->qarena.size(), q0 = g->queue.size();
+  g->qarena.resize(base + (size_t)(off[n] - off[0]));
+  g->queue.resize(q0 + n);
+  parallel_for(n, 8192, [&](size_t lo, size_t hi) {
+    if (lo < hi) memcpy(&g->qarena[base + (size_t)(off[lo] - off[0])], msgs + off[lo], (size_t)(off[hi] - off[lo]));
+    for (size_t i = lo; i < hi; i++) {
+      qent &q = g->queue[q0 + i];
+      q.off = base + (size_t)(off[i] - off[0]);
+      q.len = (u32)(off[i + 1] - off[i]);
+      q.has_src = source_peers33 != nullptr;
+      if (source_peers33) memcpy(q.src.k, source_peers33 + peer_stride * i, 33);
+      else memset(q.src.k, 0, 33);
+    }
+  });
   return LAMD_OK;
+}
+
+// messages [from, end) of a batch that could not be applied go back to the HEAD of the queue, in order (engine error paths)
+static void requeue(lamd_gossipd *g, const bytes &arena, const std::vector<qent> &ents, size_t from) {
+  bytes na;
+  std::vector<qent> nq;
+  nq.reserve(ents.size() - from + g->queue.size());
+  for (size_t i = from; i < ents.size(); i++) {
+    qent q = ents[i];
+    const size_t o = na.size();
+    na.insert(na.end(), arena.begin() + q.off, arena.begin() + q.off + q.len);
+    q.off = o;
+    nq.push_back(q);
+  }
+  for (qent q : g->queue) {  // whatever a callback pushed meanwhile stays behind them
+    const size_t o = na.size();
+    na.insert(na.end(), g->qarena.begin() + q.off, g->qarena.begin() + q.off + q.len);
+    q.off = o;
+    nq.push_back(q);
+  }
+  g->qarena.swap(na);
+  g->queue.swap(nq);
 }
 
 extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   if (!g) return LAMD_ERR_ARG;
   if (g->in_process) return LAMD_ERR_STATE;
-  std::vector<queued> batch;
-  batch.swap(g->queue);
-  const size_t n = batch.size();
+  bytes arena;
+  std::vector<qent> ents;
+  arena.swap(g->qarena);
+  ents.swap(g->queue);
+  const size_t n = ents.size();
   if (!n) return 0;
-  // ---- plan: which (message, signer) pairs can reach a sigcheck_*() call, judged from the state before the batch
+  std::vector<queued> batch(n);
+  // ---- plan: which (message, signer) pairs can reach a sigcheck_*() call, judged from the state before the batch.
+  // Pass 1 (parallel over the messages; reads the maps, writes nothing shared): framing, r/s range, the filters that need no
+  // curve arithmetic, the expected signer, the content hash that keys the verdict, the P2WSH program of an announcement.
   std::vector<planned> plan(n);
+  parallel_for(n, 2048, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      queued &q = batch[i];
+      q.msg = mview(arena.data() + ents[i].off, ents[i].len);
+      q.has_src = ents[i].has_src;
+      q.src = ents[i].src;
+      const mview &m = q.msg;
+      planned &p = plan[i];
+      const gossip_frame f = gossip_parse_frame(m.data(), m.size());
+      p.type = f.type;
+      p.malformed = f.bad;
+      p.addrs_bad = false;
+      p.slot = p.keyslot = -1;
+      p.scid = 0;
+      p.want_slot = p.want_keys = p.spk_set = false;
+      p.signer = nullptr;
+      p.h = 0;
+      if (f.type == GOSSIP_CANN) {
+        if (!p.malformed)
+          for (int s = 0; s < 4; s++) p.malformed |= !sig_in_range(&m[2 + 64 * s]);
+        if (p.malformed) continue;
+        const size_t flen = be16(&m[258]);
+        p.scid = be64(&m[260 + flen + 32]);
+        const bool order_bad = memcmp(&m[f.keyoff], &m[f.keyoff + 33], 33) >= 0;
+        const bool drop = order_bad || memcmp(&m[260 + flen], g->cfg.chain_hash, 32) != 0 || g->txout_failures.count(p.scid) || g->known_scid(p.scid);
+        if (drop) {  // fromwire_pubkey still decides between "Malformed" and the silent drop / the node-order warning
+          p.want_keys = true;
+        } else {
+          p.want_slot = true;
+          // scriptpubkey_p2wsh(bitcoin_redeem_2of2(key1, key2)) (:699-702; bitcoin/script.c:149-165): keys in DER order
+          const u8 *k1 = &m[f.keyoff + 66], *k2 = &m[f.keyoff + 99];
+          if (memcmp(k1, k2, 33) >= 0) std::swap(k1, k2);
+          u8 script[71];
+          script[0] = 0x52; script[1] = 33; memcpy(script + 2, k1, 33);
+          script[35] = 33; memcpy(script + 36, k2, 33);
+          script[69] = 0x52; script[70] = 0xae;
+          lamd_gossipd::sha256_single(script, sizeof script, p.spk);
+          p.spk_set = true;
+        }
+      } else if (f.type == GOSSIP_CUPD) {
+        if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
+        if (p.malformed) continue;
+        p.scid = be64(&m[98]);
+        if (memcmp(&m[66], g->cfg.chain_hash, 32) != 0 || !g->timestamp_reasonable(be32(&m[106]))) continue;
+        auto it = g->chans.find(p.scid);
+        if (it != g->chans.end()) { p.want_slot = true; p.signer = &it->second.node[m[111] & 1]; }
+        else if (q.has_src) { p.want_slot = true; p.signer = &q.src; }  // the private-update probe of :1107-1109 (unused if the channel turns out to be pending)
+      } else if (f.type == GOSSIP_NANN) {
+        if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
+        if (p.malformed) continue;
+        const size_t alen = be16(&m[f.keyoff + 68]);
+        p.addrs_bad = !wireaddrs_ok(&m[f.keyoff + 70], alen);
+        p.want_slot = !p.addrs_bad;
+      }
+      if (p.want_slot) p.h = g->vkey(m, p.signer).h;
+    }
+  });
+  // Pass 2 (serial, in arrival order): slots -- identical (message, signer) pairs relayed by several peers share one -- and the
+  // key-only list
   lamd_gossipd::slotlist sl;
   sl.index.reserve(n);  // (growing a hash table rehashes it log2(n) times)
   g->pending_ann.reserve(g->pending_ann.size() + n / 2);
@@ -1021,54 +1176,25 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   sl.signer.reserve(n);
   bytes keyblob;
   for (size_t i = 0; i < n; i++) {
-    const queued &q = batch[i];
-    const bytes &m = q.msg;
     planned &p = plan[i];
-    const gossip_frame f = gossip_parse_frame(m.data(), m.size());
-    p.type = f.type;
-    p.malformed = f.bad;
-    p.addrs_bad = false;
-    p.slot = p.keyslot = -1;
-    p.scid = 0;
-    if (f.type == GOSSIP_CANN) {
-      if (!p.malformed)
-        for (int s = 0; s < 4; s++) p.malformed |= !sig_in_range(&m[2 + 64 * s]);
-      if (p.malformed) continue;
-      const size_t flen = be16(&m[258]);
-      p.scid = be64(&m[260 + flen + 32]);
-      const bool order_bad = memcmp(&m[f.keyoff], &m[f.keyoff + 33], 33) >= 0;
-      const bool drop = order_bad || memcmp(&m[260 + flen], g->cfg.chain_hash, 32) != 0 || g->txout_failures.count(p.scid) || g->known_scid(p.scid);
-      if (drop) {  // fromwire_pubkey still decides between "Malformed" and the silent drop / the node-order warning
-        p.keyslot = (int)(keyblob.size() / 66);
-        keyblob.insert(keyblob.end(), &m[f.keyoff + 66], &m[f.keyoff + 132]);
-        g->st.keyparse_messages++;
-      } else {
-        p.slot = sl.add(g, m, nullptr);
-      }
-    } else if (f.type == GOSSIP_CUPD) {
-      if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
-      if (p.malformed) continue;
-      p.scid = be64(&m[98]);
-      if (memcmp(&m[66], g->cfg.chain_hash, 32) != 0 || !g->timestamp_reasonable(be32(&m[106]))) continue;
-      auto it = g->chans.find(p.scid);
-      if (it != g->chans.end()) p.slot = sl.add(g, m, &it->second.node[m[111] & 1]);
-      else if (q.has_src) p.slot = sl.add(g, m, &q.src);  // the private-update probe of :1107-1109 (unused if the channel turns out to be pending)
-    } else if (f.type == GOSSIP_NANN) {
-      if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
-      if (p.malformed) continue;
-      const size_t alen = be16(&m[f.keyoff + 68]);
-      p.addrs_bad = !wireaddrs_ok(&m[f.keyoff + 70], alen);
-      if (!p.addrs_bad) p.slot = sl.add(g, m, nullptr);
+    if (p.want_slot) {
+      p.slot = sl.add(g, batch[i].msg, p.signer, p.h);
+    } else if (p.want_keys) {
+      const mview &m = batch[i].msg;
+      const gossip_frame f = gossip_parse_frame(m.data(), m.size());
+      p.keyslot = (int)(keyblob.size() / 66);
+      keyblob.insert(keyblob.end(), &m[f.keyoff + 66], &m[f.keyoff + 132]);
+      g->st.keyparse_messages++;
     }
   }
   // ---- verify: one call for the signatures, one for the keys of announcements that are dropped anyway
   g->drop_verdicts();
   int rc = g->verify(sl);
-  if (rc != LAMD_OK) { g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
+  if (rc != LAMD_OK) { requeue(g, arena, ents, 0); return rc; }
   std::vector<u8> keyok(keyblob.size() / 33, 0);
   if (!keyok.empty()) {
     rc = g->backend_keyparse(keyok.size(), keyblob.data(), keyok.data());
-    if (rc != LAMD_OK) { g->drop_verdicts(); g->queue.insert(g->queue.begin(), batch.begin(), batch.end()); return rc; }
+    if (rc != LAMD_OK) { g->drop_verdicts(); requeue(g, arena, ents, 0); return rc; }
   }
   // ---- apply in arrival order.  Event callbacks fire from here: they must not re-enter lamd_gossipd_process / _txout_reply /
   // _new_block (those return LAMD_ERR_STATE while in_process is set -- answer LAMD_GEV_GET_TXOUT after process() returns; _push is fine).
@@ -1085,7 +1211,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
       const int frc = g->fault_rc;
       g->fault_rc = LAMD_OK;
       g->drop_verdicts();
-      g->queue.insert(g->queue.begin(), std::make_move_iterator(batch.begin() + i), std::make_move_iterator(batch.end()));
+      requeue(g, arena, ents, i);
       g->in_process = false;
       return frc;
     }

@@ -123,6 +123,34 @@ LAMD_HD gej gej_add_ge(const gej &a, const ge &b, bool skip) {
   return gej_select(skip, a, r);
 }
 
+// Complete Jacobian + Jacobian addition (12M + 4S), branching on the special cases: for the few places that MERGE partial sums
+// (the latency path splits one verification into tasks run by different waves, verify_core.h "task split").  Inputs as the other
+// gej functions leave them (x, y magnitude 1, z magnitude <= 2); any point may be infinity, equal or opposite to the other.
+LAMD_HD gej gej_add_var(const gej &a, const gej &b) {
+  if (a.inf) return b;
+  if (b.inf) return a;
+  const fe az = fe_norm_weak(a.z), bz = fe_norm_weak(b.z);
+  const fe z12 = fe_sqr(az), z22 = fe_sqr(bz);
+  const fe u1 = fe_mul(a.x, z22), u2 = fe_mul(b.x, z12);
+  const fe s1 = fe_mul(a.y, fe_mul(z22, bz)), s2 = fe_mul(b.y, fe_mul(z12, az));
+  const fe h = fe_norm_weak(fe_add(u2, fe_neg(u1, 1)));
+  const fe rr = fe_norm_weak(fe_add(s2, fe_neg(s1, 1)));
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) return gej_double(a);
+    return gej_infinity();
+  }
+  const fe hh = fe_sqr(h);
+  const fe hhh = fe_mul(h, hh);
+  const fe v = fe_mul(u1, hh);
+  gej r;
+  r.x = fe_norm_weak(fe_add(fe_add(fe_sqr(rr), fe_neg(hhh, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // R^2 - H^3 - 2V  (1 + 2 + 3)
+  const fe t = fe_norm_weak(fe_add(v, fe_neg(r.x, 1)));
+  r.y = fe_norm_weak(fe_add(fe_mul(rr, t), fe_neg(fe_mul(s1, hhh), 1)));                          // R*(V - X3) - S1*H^3
+  r.z = fe_mul(fe_mul(az, bz), h);
+  r.inf = false;
+  return r;
+}
+
 LAMD_HD ge ge_neg_if(const ge &a, bool neg) {
   ge r;
   r.x = a.x;

@@ -445,7 +445,11 @@ __global__ void __launch_bounds__(256) k_dedupe_insert(size_t n, const u8 *__res
   const u8 *k = keys + stride * i;
   u32 slot = (u32)key_hash(k, keylen, seed) & mask;
   for (;;) {
-    const u32 old = atomicCAS(&table[slot], 0u, (u32)i + 1u);
+    // look before claiming: once a key's first row has landed, its other rows only read the slot.  (With the CAS alone every row
+    // of a batch under ONE key -- a key-reuse sweep's K = 1, a hot node's gossip -- hammered the same word: 1 M serialised atomics,
+    // 10 ms.)  A stale zero just falls through to the CAS.
+    u32 old = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);
+    if (old == 0u) old = atomicCAS(&table[slot], 0u, (u32)i + 1u);
     if (old == 0u) { rep[i] = (u32)i; return; }
     const u8 *o = keys + stride * (size_t)(old - 1u);
     bool same = true;
@@ -730,6 +734,142 @@ __global__ void __launch_bounds__(64) k_small_lookup(size_t n, const u8 *__restr
     if (keyok_row) keyok_row[i] = 0;
   }
 }
+// ---- the latency path: n <= 64 rows in ONE launch, inputs read straight from pinned host memory, verdicts written straight back.
+// One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of ST_TASKS waves on one CU.
+//   phase A   wave 0: scalar preparation of its row (one division-step inversion per lane)
+//             wave 1: the row's key -- probe the key-table cache (comb shape + table), or parse it and build the 8-entry ladder table
+//   phase B   wave 0: u1*G (12 windows of the static table);  waves 1-4: the comb's four partial sums / the ladder's two halves
+//   phase C   wave 0: merge (complete Jacobian additions), acceptance test, verdict byte -> host memory, completion flag
+// Replaces, for such calls, H2D x 3 + a dozen launches + D2H + a stream synchronise (0.38 ms for one row) and the ~10^5-instruction
+// dependent chain on one lane.  Everything uses the complete addition formulas: no suspect rows, no second pass.
+struct small_part { u32 w[27]; u32 inf; };  // a Jacobian point in LDS
+struct small_args {
+  const u8 *a32, *sig64, *key;   // pinned host memory (device-mapped)
+  int keylen, mode;
+  u32 n;
+  u64 seed;
+  const u32 *index;              // key-table cache (nullptr: none)
+  u32 mask;
+  const cache_ent *ents;
+  cache_vis vis;
+  const u32 *pool7, *pool10, *gtable;
+  u32 *slots;                    // ladder tables, SLOT_WORDS per row
+  u8 *out;                       // pinned host memory: n verdict bytes
+  u32 *flag;                     // ... and the completion word (set to `ticket` last)
+  u32 ticket;
+};
+__device__ __forceinline__ void small_store(small_part *p, const gej &g) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) { p->w[i] = g.x.n[i]; p->w[9 + i] = g.y.n[i]; }
+  const fe z = fe_norm_weak(g.z);
+#pragma unroll
+  for (int i = 0; i < 9; i++) p->w[18 + i] = z.n[i];
+  p->inf = g.inf;
+}
+__device__ __forceinline__ gej small_load(const small_part *p) {
+  gej g;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { g.x.n[i] = p->w[i]; g.y.n[i] = p->w[9 + i]; g.z.n[i] = p->w[18 + i]; }
+  FE_SETMAG(g.x, 1); FE_SETMAG(g.y, 1); FE_SETMAG(g.z, 1);
+  g.inf = p->inf != 0;
+  return g;
+}
+__global__ void __launch_bounds__(64 * ST_TASKS) k_small_verify(small_args A) {
+  __shared__ prep_rec s_rec[64];
+  __shared__ u32 s_shape[64];          // 7 / 10: comb teeth; 255: ladder; 0: rejected (key does not parse)
+  __shared__ u32 s_tab[64];            // table slot in the pool of its shape
+  __shared__ u32 s_zscale[64][9];      // ladder: Zg of the lane's table
+  __shared__ small_part s_part[ST_TASKS][64];
+  const u32 lane = threadIdx.x & 63u, task = threadIdx.x >> 6;
+  const bool live = lane < A.n;
+  // ---- phase A
+  if (task == 0 && live) {
+    if (A.mode == MODE_ECDSA) ecdsa_prep_thread(lane, 64, lane + 1, A.a32, A.sig64, s_rec);   // this lane's row only
+    else schnorr_prep_one(A.a32 + 32 * lane, A.key + (size_t)A.keylen * lane, A.sig64 + 64 * lane, &s_rec[lane]);
+  }
+  if (task == 1 && live) {
+    u32 T = 255, tabslot = 0;
+    const u8 *kp = A.key + (size_t)A.keylen * lane;
+    if (A.index) {
+      u32 kw[17];
+      key_words(kw, kp, A.keylen);
+      u32 slot = (u32)key_words_hash(kw, A.seed) & A.mask;
+      for (int probe = 0; probe < 64; probe++) {
+        const u32 id = A.index[slot];
+        if (id == 0u) break;
+        const cache_ent *e = A.ents + (id - 1u);
+        const u32 seq = e->seq, meta = e->meta;
+        if (seq != 0u && seq <= A.vis.seq[(meta >> 8) & 15u]) {
+          bool same = true;
+#pragma unroll 1
+          for (int w = 0; w < 17; w++) same &= e->kw[w] == kw[w];
+          if (same) { T = meta & 0xFFu; tabslot = e->tabslot; break; }
+        }
+        slot = (slot + 1u) & A.mask;
+      }
+    }
+    if (T == 255u) {  // no table: parse the key, build the ladder's 8-entry table in the lane's slot
+      u32 qx[8], qy[8];
+      if (parse_pubkey(kp, A.keylen, qx, qy)) {
+        const fe zg = fe_norm_weak(build_q_table(A.slots + (size_t)lane * SLOT_WORDS, ge_from_words(qx, qy)));
+#pragma unroll
+        for (int i = 0; i < 9; i++) s_zscale[lane][i] = zg.n[i];
+        __threadfence_block();  // the table (global memory) is read by the ladder waves after the barrier
+      } else {
+        T = 0;
+      }
+    }
+    s_shape[lane] = T;
+    s_tab[lane] = tabslot;
+  }
+  __syncthreads();
+  // ---- phase B
+  const u32 shape = live ? s_shape[lane] : 0u;
+  const bool work = live && shape != 0u && (s_rec[lane].flags & PREP_VALID);
+  if (work) {
+    prep_rec rec = s_rec[lane];
+    gej part = gej_infinity();
+    if (task == ST_G) {
+      part = small_task_g(rec, A.gtable);
+    } else if (shape == 7u) {
+      part = small_task_comb<7>(rec, A.pool7 + (size_t)s_tab[lane] * kc_stride(7), (int)task);
+    } else if (shape == 10u) {
+      part = small_task_comb<10>(rec, A.pool10 + (size_t)s_tab[lane] * kc_stride(10), (int)task);
+    } else if (task == ST_H1LO || task == ST_H2LO) {
+      part = small_task_ladder(rec, A.slots + (size_t)lane * SLOT_WORDS, task == ST_H2LO);
+    }
+    small_store(&s_part[task][lane], part);
+  }
+  __syncthreads();
+  // ---- phase C
+  if (task == 0 && live) {
+    bool ok = false;
+    if (work) {
+      gej parts[ST_TASKS];
+#pragma unroll
+      for (int t = 0; t < ST_TASKS; t++) parts[t] = small_load(&s_part[t][lane]);
+      fe zscale;
+      if (shape == 255u) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) zscale.n[i] = s_zscale[lane][i];
+        FE_SETMAG(zscale, 1);
+      } else {
+        zscale = slot_load_fe((shape == 7u ? A.pool7 + (size_t)s_tab[lane] * kc_stride(7) + kc_words(7) : A.pool10 + (size_t)s_tab[lane] * kc_stride(10) + kc_words(10)));
+      }
+      const gej R = small_merge(parts, zscale);
+      u32 rw[8];
+      load_words_be(rw, A.sig64 + 64 * lane);
+      ok = A.mode == MODE_ECDSA ? ecdsa_final(R, rw) : schnorr_accept_one(R, rw);
+    }
+    A.out[lane] = ok ? 1 : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(A.flag, A.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_schnorr_final_fin(size_t n, u32 *__restrict__ fin, u8 *__restrict__ out) {
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -766,6 +906,10 @@ struct lamd_ctx {
   devbuf row_ent, kd_table, kd_rep, kd_uid, kd_uniq, kd_count, kd_newent, plan, kt_fin;
   devbuf hk7_row, hk7_ent, hk7_slot, hk7_qwords, hk7_keyok, hk7_scratch, hk10_row, hk10_ent, hk10_slot, hk10_qwords, hk10_keyok, hk10_scratch;
   devbuf list7, list10, listcold, listcold_ok;
+  // latency path (k_small_verify): pinned, device-mapped staging for up to SMALL_MAX rows, the verdict bytes and the completion word
+  u8 *h_small = nullptr;
+  u32 small_ticket = 0;
+  bool small_kernel = true;   // LAMD_SMALL_KERNEL=0: such calls take the general path
   u32 *h_plan = nullptr;   // pinned read-back of the last call's plan + cache counters (statistics only: nothing waits for it)
   // Key-table cache.  The root context owns the shared one (LAMD_CACHE=1, default): entries + index + one table pool per
   // comb shape, filled by whichever lane meets a key often enough, looked up by every later call.  With LAMD_CACHE=0 every
@@ -1039,6 +1183,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_MIN_ROWS")) ctx->keyed_min_rows = (size_t)atoll(w);
   if (const char *w = getenv("LAMD_SMALL_FUSED")) ctx->small_fused = atoi(w) != 0;
   if (const char *w = getenv("LAMD_CACHE")) ctx->cache_mode = atoi(w) != 0;
+  if (const char *w = getenv("LAMD_SMALL_KERNEL")) ctx->small_kernel = atoi(w) != 0;
   if (const char *w = getenv("LAMD_CACHE_KEYS")) ctx->cache_keys = (size_t)atoll(w) < 64 ? 64 : (size_t)atoll(w);
   if (const char *w = getenv("LAMD_CACHE_KEYS10")) ctx->cache_keys10 = (size_t)atoll(w) < 16 ? 16 : (size_t)atoll(w);
   int rc = create_streams(ctx);
@@ -1119,6 +1264,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   }
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
   if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
+  if (ctx->h_small) (void)hipHostFree(ctx->h_small);
   if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
@@ -1726,11 +1872,74 @@ extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const v
   return rc;
 }
 
+// n <= SMALL_MAX rows from host memory: one launch of k_small_verify, inputs and verdicts through pinned device-mapped memory, the
+// host waits on the completion word the kernel's last instruction writes
+constexpr size_t SMALL_MAX = 64;
+constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG + SMALL_MAX * 64, SMALL_OFF_OUT = SMALL_OFF_KEY + SMALL_MAX * 65 + 64,
+                 SMALL_OFF_FLAG = SMALL_OFF_OUT + SMALL_MAX, SMALL_BYTES = SMALL_OFF_FLAG + 64;
+static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok) {
+  int rc;
+  if (!ctx->h_small) {
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_small, SMALL_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_small, 0, SMALL_BYTES);
+  }
+  if ((rc = ensure(ctx, &ctx->slots, SMALL_MAX * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  u8 *h = ctx->h_small;
+  memcpy(h, a, n * 32);
+  memcpy(h + SMALL_OFF_SIG, sig, n * 64);
+  if (keystride == (size_t)keylen) memcpy(h + SMALL_OFF_KEY, key, n * keylen);
+  else
+    for (size_t i = 0; i < n; i++) memcpy(h + SMALL_OFF_KEY + i * keylen, key + i * keystride, keylen);
+  small_args A;
+  memset(&A, 0, sizeof A);
+  A.a32 = h; A.sig64 = h + SMALL_OFF_SIG; A.key = h + SMALL_OFF_KEY;
+  A.keylen = keylen; A.mode = mode; A.n = (u32)n;
+  A.seed = ctx->hash_seed;
+  if (ctx->cache_mode != 0 && ctx->cache_store.shared) {
+    lamd_ctx::key_cache *kc = &ctx->cache_store;
+    for (int l = 0; l <= MAX_LANES; l++)
+      if (ctx->pub_pending[l] && hipEventQuery(ctx->ev_pub[l]) == hipSuccess) {
+        ctx->vis_seq[l] = ctx->pub_seq[l];
+        ctx->pub_pending[l] = false;
+      }
+    (void)hipGetLastError();
+    for (int l = 0; l <= MAX_LANES; l++) A.vis.seq[l] = ctx->vis_seq[l];
+    A.vis.seq[ctx->lane_id] = ctx->pub_seq[ctx->lane_id];
+    A.index = (const u32 *)kc->index.p; A.mask = kc->index_mask; A.ents = (const cache_ent *)kc->ents.p;
+    A.pool7 = (const u32 *)kc->pool7.p; A.pool10 = (const u32 *)kc->pool10.p;
+  }
+  A.gtable = (const u32 *)ctx->gtable;
+  A.slots = (u32 *)ctx->slots.p;
+  A.out = h + SMALL_OFF_OUT;
+  A.flag = (u32 *)(h + SMALL_OFF_FLAG);
+  A.ticket = ++ctx->small_ticket ? ctx->small_ticket : ++ctx->small_ticket;
+  hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(64 * ST_TASKS), 0, ctx->stream, A);
+  HIPCHK(ctx, hipGetLastError());
+  // spin on the completion word (the kernel's last store, system scope); fall back to the stream if it does not show up
+  volatile u32 *flag = (volatile u32 *)(h + SMALL_OFF_FLAG);
+  bool seen = false;
+  for (u32 spins = 0; spins < (1u << 22); spins++) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == A.ticket) { seen = true; break; }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (!seen) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != A.ticket) { ctx->err = "k_small_verify: completion word not written"; return LAMD_ERR_HIP; }
+  }
+  memcpy(ok, h + SMALL_OFF_OUT, n);
+  ctx->last_mode = mode;
+  ctx->last_n = n;
+  return LAMD_OK;
+}
+
 static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride,
                     u8 *ok) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+  if (n <= SMALL_MAX && ctx->small_kernel) return run_small(ctx, mode, n, a, sig, key, keylen, keystride, ok);
   if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_c, n * keystride)) != LAMD_OK) return rc;

@@ -863,6 +863,105 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
   return acc;
 }
 
+// ================================================================================================
+// Task split (latency path, n <= 64 rows: k_small_verify).  One row per LANE and one TASK per WAVE: a lone signature on one
+// lane is a chain of ~10^5 dependent instructions, and a wave issues one instruction every ~4.3 cycles however few lanes are
+// live -- so the verification is cut into independent partial sums that different waves (different SIMDs) compute at the same
+// time, and one wave merges them with complete Jacobian additions:
+//     R = u1*G  +  [ (H1lo + H1hi) + (H2lo + H2hi) ] * (Z scale of the table's isomorphic curve)
+//   comb of T teeth, D columns, split at column J:  Hxlo = sum_{j<J} 2^j C_j,  Hxhi = 2^J * sum_{j>=J} 2^(j-J) C_j   (x = GLV half)
+//   ladder (key without a table):                   H1lo = k1*Q, H2lo = k2*lambda*Q, H1hi = H2hi = infinity
+// Every addition here is the COMPLETE mixed addition (gej_add_ge): no suspect rows, no second pass.
+enum { ST_G = 0, ST_H1LO = 1, ST_H1HI = 2, ST_H2LO = 3, ST_H2HI = 4, ST_TASKS = 5 };
+constexpr int kc_split_col(int T) { return T == 7 ? 12 : T == 10 ? 8 : (kc_spacing(T) * 5) / 8; }  // balances doublings + additions of the two parts
+
+LAMD_HD gej small_task_g(const prep_rec &rec, const u32 *gtable) {
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+    const u32 d = gtable_digit(rec.u1, w);
+    const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
+    ge pt;
+    pt.x = slot_load_fe(e);
+    pt.y = slot_load_fe(e + TW);
+    acc = gej_add_ge(acc, pt, d == 0);
+  }
+  return acc;
+}
+// task in ST_H1LO..ST_H2HI; the result lives on the table's isomorphic curve
+template <int T>
+LAMD_HD gej small_task_comb(const prep_rec &rec, const u32 *tab, int task) {
+  constexpr int D = kc_spacing(T), NE = kc_ne(T), J = kc_split_col(T);
+  const comb_pair<T> cp = comb_from_rec_odd<T>(rec);
+  const bool second = task >= ST_H2LO, hi = task == ST_H1HI || task == ST_H2HI;
+  u32 tooth[T];
+#pragma unroll
+  for (int i = 0; i < T; i++) tooth[i] = second ? cp.tooth2[i] : cp.tooth1[i];
+  const bool neg = second ? cp.n2 : cp.n1;
+  const int jtop = hi ? D - 1 : J - 1, jbot = hi ? J : 0;
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int j = jtop; j >= jbot; j--) {
+    if (j != jtop) acc = gej_double(acc);
+    u32 m = 0;
+#pragma unroll
+    for (int i = 0; i < T; i++) m |= ((tooth[i] >> j) & 1u) << i;
+    const bool top = (m >> (T - 1)) & 1u;
+    const u32 idx = (top ? m : ~m) & (u32)(NE - 1);
+    const u32 *e = tab + idx * SLOT_ENTRY_WORDS;
+    ge pt;
+    pt.x = slot_load_fe(e + (second ? ENT_BX : ENT_X));
+    pt.y = slot_load_fe(e + ENT_Y);
+    pt = ge_neg_if(pt, top == neg);  // the column is -entry when the top tooth is -1; times the sign of the (adjusted) half
+    acc = gej_add_ge(acc, pt, false);
+  }
+  if (hi) {
+#pragma unroll 1
+    for (int k = 0; k < J; k++) acc = gej_double(acc);
+  }
+  return acc;
+}
+// one GLV half over the lane's own 8-entry table (build_q_table): k1*Q (second = false) or k2*lambda*Q
+LAMD_HD gej small_task_ladder(const prep_rec &rec, const u32 *slot, bool second) {
+  const bool neg = rec.flags & (second ? PREP_K2NEG : PREP_K1NEG);
+  const u32 top = (rec.flags & (second ? PREP_K2TOP : PREP_K1TOP)) ? 1u : 0u;
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int i = 32; i >= 0; i--) {
+    if (i != 32) {
+#pragma unroll 1
+      for (int j = 0; j < 4; j++) acc = gej_double(acc);
+    }
+    int d = second ? glv_digit(rec.k2, top, i) : glv_digit(rec.k1, top, i);
+    if (neg) d = -d;
+    const bool skip = d == 0;
+    const int a = d < 0 ? -d : d;
+    const u32 *e = slot + (skip ? 0 : a - 1) * SLOT_ENTRY_WORDS;
+    ge pt;
+    pt.x = slot_load_fe(e + (second ? ENT_BX : ENT_X));
+    pt.y = slot_load_fe(e + ENT_Y);
+    pt = ge_neg_if(pt, d < 0);
+    acc = gej_add_ge(acc, pt, skip);
+  }
+  return acc;
+}
+// parts[ST_TASKS]; zscale = Zc of the comb table / Zg of the ladder table
+LAMD_HD gej small_merge(const gej *parts, const fe &zscale) {
+  gej s = gej_add_var(gej_add_var(parts[ST_H1LO], parts[ST_H1HI]), gej_add_var(parts[ST_H2LO], parts[ST_H2HI]));
+  if (!s.inf) s.z = fe_mul(fe_norm_weak(s.z), zscale);  // back from the isomorphic curve: (X, Y, Z) -> (X, Y, Z * zscale)
+  return gej_add_var(s, parts[ST_G]);
+}
+// BIP-340 acceptance for one row (the batched form shares the inversion over 16 rows: schnorr_stage1 / schnorr_final_thread)
+LAMD_HD bool schnorr_accept_one(const gej &R, const u32 rw[8]) {
+  if (R.inf) return false;
+  const fe z = fe_norm_weak(R.z);
+  const fe z2 = fe_sqr(z);
+  if (!fe_equal(fe_mul(fe_from_words(rw), z2), R.x, 1)) return false;
+  const fe zi = fe_inv_var(z);
+  const fe y = fe_normalize(fe_mul(R.y, fe_mul(fe_sqr(zi), zi)));
+  return (y.n[0] & 1) == 0;
+}
+
 // p - n (129 bits): r + n < p  <=>  r < p - n
 #define LAMD_P_MINUS_N {0x2FC9BAEEu, 0x402DA172u, 0x50B75FC4u, 0x45512319u, 1u, 0u, 0u, 0u}
 

@@ -153,6 +153,44 @@ static void keytable_entry_t(const u32 *qx, const u32 *qy, int idx, u8 *out96) {
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + ENT_Y), zi3))); words_to_be(out96 + 32, w);
   fe_to_words(w, fe_normalize(fe_mul(slot_load_fe(e + ENT_BX), zi2))); words_to_be(out96 + 64, w);
 }
+// The latency path's task split (verify_core.h "Task split"): every task evaluated on its own, merged with complete additions --
+// T = 7 / 10: comb tasks over the key's table; T = 0: the two ladder halves over the lane's own 8-entry table
+template <int T>
+static void verify_split_t(int mode, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  dm_init();
+  std::vector<u32> tab(kc_stride(T ? T : 7)), scratch(kc_scratch_words(T ? T : 7)), slot(SLOT_WORDS);
+  std::vector<prep_rec> recs(n);
+  for (size_t i = 0; i < n; i++) {
+    if (mode == MODE_ECDSA) ecdsa_prep_thread(i, n, n, a32, sig64, recs.data());   // one row per "lane", as k_small_verify runs it
+    else schnorr_prep_one(a32 + 32 * i, key + (size_t)keylen * i, sig64 + 64 * i, &recs[i]);
+    u32 qx[8], qy[8], rw[8];
+    bool ok = parse_pubkey(key + (size_t)keylen * i, keylen, qx, qy);
+    ok &= (recs[i].flags & PREP_VALID) != 0;
+    out[i] = 0;
+    if (!ok) continue;
+    gej parts[ST_TASKS];
+    fe zscale;
+    parts[ST_G] = small_task_g(recs[i], g_table.data());
+    if (T) {
+      keytable_build<(T ? T : 7)>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+      for (int t = ST_H1LO; t <= ST_H2HI; t++) parts[t] = small_task_comb<(T ? T : 7)>(recs[i], tab.data(), t);
+      zscale = slot_load_fe(&tab[kc_words(T ? T : 7)]);
+    } else {
+      zscale = build_q_table(slot.data(), ge_from_words(qx, qy));
+      parts[ST_H1LO] = small_task_ladder(recs[i], slot.data(), false);
+      parts[ST_H2LO] = small_task_ladder(recs[i], slot.data(), true);
+      parts[ST_H1HI] = parts[ST_H2HI] = gej_infinity();
+    }
+    const gej R = small_merge(parts, zscale);
+    be_to_words(rw, sig64 + 64 * i);
+    out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : (u8)schnorr_accept_one(R, rw);
+  }
+}
+extern "C" void dm_verify_split(int mode, int T, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  if (T == 7) verify_split_t<7>(mode, n, a32, sig64, key, keylen, out);
+  else if (T == 10) verify_split_t<10>(mode, n, a32, sig64, key, keylen, out);
+  else verify_split_t<0>(mode, n, a32, sig64, key, keylen, out);
+}
 extern "C" {
 int dm_comb_spacing(int T) { return kc_spacing(T); }
 void dm_verify_keyed(int mode, int T, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {

@@ -300,6 +300,27 @@ def test_keyed_path_tables_and_verdicts(dm, kat):
         assert not bad, (T, bad[:10])
 
 
+def test_task_split_of_the_latency_path_gives_the_golden_verdicts(dm, kat):
+    """k_small_verify's arithmetic on the host: one verification cut into five independent partial sums (u1*G; the comb's two
+    GLV halves, each split at a column -- or the two ladder halves for a key without a table) merged with complete Jacobian
+    additions (gej_add_var).  Every ECDSA golden (reference KATs, all edge classes: R = infinity, u1*G = +-u2*Q, Q = G, Q = lambda*G,
+    lattice-vector scalars, x(R) = r + n) and every BIP-340 golden through all three shapes."""
+    for T in (7, 10, 0):
+        for publen in (33, 65):
+            rows = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
+            out = ctypes.create_string_buffer(len(rows))
+            dm.dm_verify_split(0, T, ctypes.c_size_t(len(rows)), b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+                               b"".join(H(v["pub"]) for v in rows), publen, out)
+            bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
+            assert not bad, (T, publen, bad[:10])
+        rows = kat["schnorr"]
+        out = ctypes.create_string_buffer(len(rows))
+        dm.dm_verify_split(1, T, ctypes.c_size_t(len(rows)), b"".join(H(v["msg"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+                           b"".join(H(v["pk"]) for v in rows), 32, out)
+        bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
+        assert not bad, (T, bad[:10])
+
+
 def test_keyed_ecmult_special_scalars(dm):
     """u1*G + u2*Q through the comb for scalars that stress the recoding: zero / even / tiny GLV halves, halves that cancel,
     u2 = +-lambda^i (one half exactly +-1), the partial sums that meet -u1*G, and seeded random ones"""

@@ -879,7 +879,10 @@ def test_keyed_fast_path_degenerate_rows_take_the_complete_formulas(eng_keyed, k
     for publen, tags in ((65, ("u1G==u2Q", "R=inf")), (33, ("Q=G", "Q=lamG"))):
         vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen and any(t in v["name"] for t in tags)]
         assert len(vs) >= 6
-        reps = 4                                    # each key several times: forced onto per-key tables (LAMD_KEYED=1)
+        # the same rows ONCE: <= 64 rows from host memory take the fused latency path (k_small_verify: complete formulas throughout)
+        one = e.verify_ecdsa(_rows([H(v["hash"]) for v in vs], 32), _rows([H(v["sig"]) for v in vs], 64), _rows([H(v["pub"]) for v in vs], publen))
+        assert [bool(g) for g in one] == [v["expect"] for v in vs]
+        reps = 16                                   # each key several times, more than 64 rows: forced onto per-key tables (LAMD_KEYED=1)
         hs = _rows([H(v["hash"]) for v in vs] * reps, 32)
         sg = _rows([H(v["sig"]) for v in vs] * reps, 64)
         pk = _rows([H(v["pub"]) for v in vs] * reps, publen)
