@@ -524,8 +524,8 @@ struct lamd_gossipd {
   int verdict_of(const mview &m, const nodeid *signer) {
     const msgkey k = vkey(m, signer);
     if (cur_sl) {
-      auto its = cur_sl->index.find(k);
-      if (its != cur_sl->index.end()) return cur_v[its->second];
+      const int slot = cur_sl->find(k);
+      if (slot >= 0) return cur_v[slot];
     }
     auto it = verdicts.find(k);
     if (it != verdicts.end()) return it->second;
@@ -546,15 +546,45 @@ struct lamd_gossipd {
   struct slotlist {
     std::vector<mview> msg;
     std::vector<const nodeid *> signer;
-    verdict_map index;
+    std::vector<u64> hs;      // vkey hash per slot
+    // (message, signer) -> slot: open addressing over the precomputed content hashes, no allocation per entry (a node-based
+    // unordered_map cost ~0.2 us per message of a flood here)
+    std::vector<u32> tab;     // slot + 1, 0 = empty
+    u32 mask = 0;
+    void reserve(size_t n) {
+      size_t m = 64;
+      while (m < 2 * n + 2) m <<= 1;
+      if (m <= tab.size()) return;
+      tab.assign(m, 0);
+      mask = (u32)(m - 1);
+      for (size_t s = 0; s < msg.size(); s++) {
+        u32 pos = (u32)hs[s] & mask;
+        while (tab[pos]) pos = (pos + 1) & mask;
+        tab[pos] = (u32)s + 1;
+      }
+    }
+    int find(const msgkey &k) const {
+      if (tab.empty()) return -1;
+      for (u32 pos = (u32)k.h & mask;; pos = (pos + 1) & mask) {
+        const u32 v = tab[pos];
+        if (!v) return -1;
+        const size_t s = v - 1;
+        if (hs[s] == k.h && msgkey_eq()(k, msgkey{msg[s].data(), msg[s].size(), signer[s] ? signer[s]->k : nullptr, hs[s]})) return (int)s;
+      }
+    }
     int add(lamd_gossipd *g, const mview &m, const nodeid *signer_) { return add(g, m, signer_, g->vkey(m, signer_).h); }
     int add(lamd_gossipd *g, const mview &m, const nodeid *signer_, u64 h) {  // h = vkey(m, signer_).h, computed by the (parallel) plan
       const msgkey k{m.data(), m.size(), signer_ ? signer_->k : nullptr, h};
+      const int have = find(k);
+      if (have >= 0) { g->st.duplicates++; return have; }
+      if (2 * (msg.size() + 1) + 2 > tab.size()) reserve(2 * (msg.size() + 1));
       const int s = (int)msg.size();
-      const auto ins = index.try_emplace(k, s);
-      if (!ins.second) { g->st.duplicates++; return ins.first->second; }
       msg.push_back(m);
       signer.push_back(signer_);
+      hs.push_back(h);
+      u32 pos = (u32)h & mask;
+      while (tab[pos]) pos = (pos + 1) & mask;
+      tab[pos] = (u32)s + 1;
       return s;
     }
   };
@@ -727,8 +757,9 @@ struct lamd_gossipd {
       if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
       if (pending_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
       if (early_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
-      if (!chans.count(u.scid) && q.has_src) {                                             // :1107-1116
-        const int pv = verdict_of(m, &q.src);
+      auto itc = chans.find(u.scid);
+      if (itc == chans.end() && q.has_src) {                                               // :1107-1116
+        const int pv = (p.slot >= 0 && p.signer == &q.src) ? cur_v[p.slot] : verdict_of(m, &q.src);
         if (pv == -2) return;
         if (pv == 0) {
           peer_update(true, &q.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);
@@ -737,7 +768,6 @@ struct lamd_gossipd {
       }
       {  // the plan's verdict stands if the signer it expected is the one process_channel_update() will ask for
         int known = INT32_MIN;
-        auto itc = chans.find(u.scid);
         if (p.slot >= 0 && p.signer && itc != chans.end() && *p.signer == itc->second.node[u.cflags & 1]) known = cur_v[p.slot];
         err = process_channel_update(u, m, known);
       }
@@ -1002,20 +1032,26 @@ struct lamd_gossipd {
   static void sha256_single(const u8 *p, size_t len, u8 out[32]);
 };
 
-// single SHA-256 through the device header's host build (sha256.h): only P2WSH scripts use it
+// single SHA-256 through the device header's host build (sha256.h): P2WSH scripts (71 bytes: two blocks, padded in place)
 void lamd_gossipd::sha256_single(const u8 *p, size_t len, u8 out[32]) {
-  lamd::sha_stream s;
-  lamd::shs_init(&s);
-  lamd::shs_update(&s, p, len);
-  // finish a single hash: pad, length, output the state
-  const u64 bits = s.total * 8;
-  const u8 pad = 0x80, zero = 0;
-  lamd::shs_update(&s, &pad, 1);
-  while (s.fill != 56) lamd::shs_update(&s, &zero, 1);
-  s.w[14] = (u32)(bits >> 32);
-  s.w[15] = (u32)bits;
-  lamd::sha256_compress(s.st, s.w);
-  for (int i = 0; i < 8; i++) { out[4 * i] = (u8)(s.st[i] >> 24); out[4 * i + 1] = (u8)(s.st[i] >> 16); out[4 * i + 2] = (u8)(s.st[i] >> 8); out[4 * i + 3] = (u8)s.st[i]; }
+  u32 st[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+  u32 w[16];
+  size_t off = 0;
+  for (; off + 64 <= len; off += 64) {
+    for (int i = 0; i < 16; i++) w[i] = be32(p + off + 4 * i);
+    lamd::sha256_compress(st, w);
+  }
+  u8 tail[128];
+  const size_t rem = len - off, padded = rem < 56 ? 64 : 128;
+  memset(tail, 0, sizeof tail);
+  memcpy(tail, p + off, rem);
+  tail[rem] = 0x80;
+  put_be64(tail + padded - 8, (u64)len * 8);
+  for (size_t b = 0; b < padded; b += 64) {
+    for (int i = 0; i < 16; i++) w[i] = be32(tail + b + 4 * i);
+    lamd::sha256_compress(st, w);
+  }
+  for (int i = 0; i < 8; i++) put_be32(out + 4 * i, st[i]);
 }
 
 extern "C" lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_config *cfg, lamd_gossipd_event_fn on_event, void *user) {
@@ -1106,6 +1142,9 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   const size_t n = ents.size();
   if (!n) return 0;
   std::vector<queued> batch(n);
+  static const bool prof = getenv("LAMD_INGEST_PROFILE") != nullptr;
+  auto tnow = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+  const double t0 = prof ? tnow() : 0;
   // ---- plan: which (message, signer) pairs can reach a sigcheck_*() call, judged from the state before the batch.
   // Pass 1 (parallel over the messages; reads the maps, writes nothing shared): framing, r/s range, the filters that need no
   // curve arithmetic, the expected signer, the content hash that keys the verdict, the P2WSH program of an announcement.
@@ -1167,13 +1206,15 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
       if (p.want_slot) p.h = g->vkey(m, p.signer).h;
     }
   });
+  const double t1 = prof ? tnow() : 0;
   // Pass 2 (serial, in arrival order): slots -- identical (message, signer) pairs relayed by several peers share one -- and the
   // key-only list
   lamd_gossipd::slotlist sl;
-  sl.index.reserve(n);  // (growing a hash table rehashes it log2(n) times)
+  sl.reserve(n);
   g->pending_ann.reserve(g->pending_ann.size() + n / 2);
   sl.msg.reserve(n);
   sl.signer.reserve(n);
+  sl.hs.reserve(n);
   bytes keyblob;
   for (size_t i = 0; i < n; i++) {
     planned &p = plan[i];
@@ -1188,9 +1229,11 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     }
   }
   // ---- verify: one call for the signatures, one for the keys of announcements that are dropped anyway
+  const double t2 = prof ? tnow() : 0;
   g->drop_verdicts();
   int rc = g->verify(sl);
   if (rc != LAMD_OK) { requeue(g, arena, ents, 0); return rc; }
+  const double t3 = prof ? tnow() : 0;
   std::vector<u8> keyok(keyblob.size() / 33, 0);
   if (!keyok.empty()) {
     rc = g->backend_keyparse(keyok.size(), keyblob.data(), keyok.data());
@@ -1217,8 +1260,11 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     }
     g->st.messages++;
   }
+  const double t4 = prof ? tnow() : 0;
   g->drop_verdicts();
   g->in_process = false;
+  if (prof) fprintf(stderr, "[ingest] n=%zu plan(parallel) %.1f ms, slots %.1f ms, verify %.1f ms, apply %.1f ms, drop %.1f ms\n", n, (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                    (t3 - t2) * 1e3, (t4 - t3) * 1e3, (tnow() - t4) * 1e3);
   return (long)n;
 }
 

@@ -97,6 +97,13 @@ def _worker(rank, world, port, q):
     gfull, gb = sharding.run_sharded(len(msgs), rank, world, gossip_range)
     gref = orc.sigcheck_gossip_batch(blob, off, idarr, 1)
     ok = ok and gfull.dtype == torch.int8 and bool(np.array_equal(gfull.numpy(), gref)) and int((gref > 0).sum()) >= 5 and int((gref == 0).sum()) >= 15
+    # a job smaller than the world (three commitments of 4 rows on up to 8 ranks): most shards are EMPTY, the gather is still exact
+    def tiny_range(a, z):
+        if a == z:
+            return torch.zeros(0, dtype=torch.uint8)
+        return torch.from_numpy(orc.ecdsa_verify_batch(np.ascontiguousarray(hs[a:z]), np.ascontiguousarray(sg[a:z]), np.ascontiguousarray(pk[a:z]), 33, 1))
+    tfull, tb = sharding.run_sharded(12, rank, world, tiny_range, [4, 4, 4])
+    ok = ok and bool(np.array_equal(tfull.numpy(), ref[:12])) and all(int(x) % 4 == 0 for x in tb) and len(tb) == world + 1
     q.put((rank, ok, int(ref.sum()), lo, hi))
     dist.destroy_process_group()
 
@@ -202,3 +209,25 @@ def test_two_rank_late_gather_protocol_and_payload():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
+
+
+def test_eight_rank_ragged_and_empty_shards():
+    """the same worker at world 8 (the size the driver scales to): 101 rows in groups of 4 and 1 -> ragged shards cut on group
+    boundaries, 32 gossip messages over 8 ranks, and a 12-row job that leaves most ranks with an empty shard; every rank must end
+    with the single-process verdict vector"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    ranges = sorted((r[3], r[4]) for r in res)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 101 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    assert len({hi - lo for lo, hi in ranges}) > 1          # ragged
