@@ -755,6 +755,7 @@ struct small_args {
   const u32 *pool7, *pool10, *gtable;
   u32 *slots;                    // ladder tables, SLOT_WORDS per row
   u8 *out;                       // pinned host memory: n verdict bytes
+  u32 *counts;                   // ... rows per shape, for lamd_get_info: [0] 7-tooth combs, [1] 10-tooth combs, [2] ladder, [3] rejected keys
   u32 *flag;                     // ... and the completion word (set to `ticket` last)
   u32 ticket;
 };
@@ -821,6 +822,11 @@ __global__ void __launch_bounds__(64 * ST_TASKS) k_small_verify(small_args A) {
     }
     s_shape[lane] = T;
     s_tab[lane] = tabslot;
+  }
+  if (task == 1) {  // whole wave: statistics for lamd_get_info
+    const u32 T = live ? s_shape[lane] : 1u;
+    const u64 b7 = __ballot(T == 7u), b10 = __ballot(T == 10u), bl = __ballot(T == 255u), b0 = __ballot(T == 0u);
+    if (lane == 0) { A.counts[0] = (u32)__popcll(b7); A.counts[1] = (u32)__popcll(b10); A.counts[2] = (u32)__popcll(bl); A.counts[3] = (u32)__popcll(b0); }
   }
   __syncthreads();
   // ---- phase B
@@ -1876,7 +1882,7 @@ extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const v
 // host waits on the completion word the kernel's last instruction writes
 constexpr size_t SMALL_MAX = 64;
 constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG + SMALL_MAX * 64, SMALL_OFF_OUT = SMALL_OFF_KEY + SMALL_MAX * 65 + 64,
-                 SMALL_OFF_FLAG = SMALL_OFF_OUT + SMALL_MAX, SMALL_BYTES = SMALL_OFF_FLAG + 64;
+                 SMALL_OFF_COUNTS = SMALL_OFF_OUT + SMALL_MAX, SMALL_OFF_FLAG = SMALL_OFF_COUNTS + 64, SMALL_BYTES = SMALL_OFF_FLAG + 64;
 static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok) {
   int rc;
   if (!ctx->h_small) {
@@ -1911,6 +1917,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   A.gtable = (const u32 *)ctx->gtable;
   A.slots = (u32 *)ctx->slots.p;
   A.out = h + SMALL_OFF_OUT;
+  A.counts = (u32 *)(h + SMALL_OFF_COUNTS);
   A.flag = (u32 *)(h + SMALL_OFF_FLAG);
   A.ticket = ++ctx->small_ticket ? ctx->small_ticket : ++ctx->small_ticket;
   hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(64 * ST_TASKS), 0, ctx->stream, A);
@@ -1931,6 +1938,15 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   memcpy(ok, h + SMALL_OFF_OUT, n);
   ctx->last_mode = mode;
   ctx->last_n = n;
+  {  // what lamd_get_info() reports about the last call
+    const u32 *c = (const u32 *)(h + SMALL_OFF_COUNTS);
+    u32 *hp = ctx->h_plan;
+    memset(hp, 0, P_WORDS * 4);
+    hp[P_L7] = c[0]; hp[P_L10] = c[1]; hp[P_COLD] = c[2]; hp[P_HITS] = c[0] + c[1] + c[3];
+    ctx->last_keyed_call = true;
+    ctx->last_lane = nullptr;
+    ctx->last_chunk_lane = nullptr;
+  }
   return LAMD_OK;
 }
 
