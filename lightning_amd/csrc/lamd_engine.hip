@@ -637,8 +637,20 @@ __global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 
                                                       const cache_ent *__restrict__ ents, const u32 *__restrict__ pool7,
                                                       const u32 *__restrict__ pool10, const u8 *__restrict__ sig64, int mode,
                                                       const u32 *__restrict__ gtable, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
-                                                      u8 *__restrict__ out) {
+                                                      u8 *__restrict__ out, const u32 *__restrict__ gtable5 = nullptr) {
   if (CAREFUL && plan[P_SUSPECT] == 0) return;
+#if defined(LAMD_G_LDS)
+  extern __shared__ u32 s_g5[];
+  const u32 *glds = nullptr;
+  if (!CAREFUL && gtable5) {  // stage the 5-bit-window table of G into this block's LDS (104 KB)
+    for (int i = threadIdx.x; i < GLDS_WORDS / 4; i += blockDim.x) reinterpret_cast<uint4 *>(s_g5)[i] = reinterpret_cast<const uint4 *>(gtable5)[i];
+    __syncthreads();
+    glds = s_g5;
+  }
+#else
+  const u32 *glds = nullptr;
+  (void)gtable5;
+#endif
   const size_t t7 = plan[P_L7], total = t7 + plan[P_L10], stride = (size_t)gridDim.x * blockDim.x;
 #pragma unroll 1
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
@@ -664,11 +676,11 @@ __global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 
       if (ten) {
         const u32 *tab = pool10 + tabslot * kc_stride(10);
         if (CAREFUL) R = ecmult_lane_keyed<10>(rec, tab, gtable);
-        else R = ecmult_lane_keyed_fast<10>(rec, tab, gtable, &suspect);
+        else R = ecmult_lane_keyed_fast<10>(rec, tab, gtable, &suspect, glds);
       } else {
         const u32 *tab = pool7 + tabslot * kc_stride(7);
         if (CAREFUL) R = ecmult_lane_keyed<7>(rec, tab, gtable);
-        else R = ecmult_lane_keyed_fast<7>(rec, tab, gtable, &suspect);
+        else R = ecmult_lane_keyed_fast<7>(rec, tab, gtable, &suspect, glds);
       }
       if (suspect) {
         out[i] = VERDICT_SUSPECT;
@@ -962,6 +974,7 @@ struct lamd_ctx {
   int ecmult_waves = 3;
   unsigned keyed_blocks_per_cu = 0;  // LAMD_KEYED_BLOCKS_PER_CU: grid cap of the table-driven ecmult launches (0 = one thread per row: measured best -- a capped grid
                                      // leaves a tail of partly filled iterations: 3.19 ms -> 3.9 ms at 4 blocks per CU)
+  u32 *gtable5 = nullptr;          // -DLAMD_G_LDS experiment: 52 x 32 entries of 5-bit windows of G, staged into LDS by the kernel
   unsigned keyed_lds_pad = 0;      // LAMD_KEYED_LDS_PAD: dynamic LDS bytes requested by the table-driven ecmult launches (occupancy limiter: 65536 = two blocks per CU)
   int keyed_waves = 3;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3: no spill; 4: a 5-dword spill, measured 60 % slower)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
@@ -1118,6 +1131,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->device = root->device;
     L->prop = root->prop;
     L->gtable = root->gtable;
+    L->gtable5 = root->gtable5;
     L->ecmult_waves = root->ecmult_waves;
     L->keyed_waves = root->keyed_waves;
     L->keyed_lds_pad = root->keyed_lds_pad;
@@ -1219,6 +1233,33 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipFree(d_bases));
+#if defined(LAMD_G_LDS)
+  {  // experiment: the 5-bit-window table the kernel stages into LDS (computed on the host: 1 664 entries)
+    std::vector<u32> t5(GLDS_WORDS, 0);
+    const u32 gx[8] = LAMD_GX, gy[8] = LAMD_GY;
+    gej b = gej_from_ge(ge_from_words(gx, gy));
+    for (int w = 0; w < GLDS_WINDOWS; w++) {
+      const fe zi = fe_inv(fe_norm_weak(b.z));
+      const fe zi2 = fe_sqr(zi);
+      ge base;
+      base.x = fe_normalize(fe_mul(b.x, zi2));
+      base.y = fe_normalize(fe_mul(b.y, fe_mul(zi2, zi)));
+      gej acc = gej_infinity();
+      for (u32 d = 1; d < (1u << GLDS_BITS); d++) {
+        acc = gej_add_ge(acc, base, false);
+        const fe ai = fe_inv(fe_norm_weak(acc.z));
+        const fe ai2 = fe_sqr(ai);
+        fe_to_words(&t5[((w << GLDS_BITS) + d) * 16], fe_normalize(fe_mul(acc.x, ai2)));
+        fe_to_words(&t5[((w << GLDS_BITS) + d) * 16 + 8], fe_normalize(fe_mul(acc.y, fe_mul(ai2, ai))));
+      }
+      for (int i = 0; i < GLDS_BITS; i++) b = gej_double(b);
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->gtable5, GLDS_WORDS * 4));
+    HIPCHK(ctx, hipMemcpy(ctx->gtable5, t5.data(), GLDS_WORDS * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)k_ecmult_keyed<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_WORDS * 4));
+    ctx->keyed_lds_pad = GLDS_WORDS * 4;
+  }
+#endif
   if (ctx->cache_mode) {  // the shared key-table cache: entries, index, one table pool per comb shape
     if ((rc = cache_alloc(ctx, &ctx->cache_store, ctx->cache_keys, ctx->cache_keys10, true)) != LAMD_OK) return rc;
     if ((rc = cache_reset(ctx)) != LAMD_OK) return rc;
@@ -1773,7 +1814,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   }
   hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
-                     keyok_out, d_ok);
+                     keyok_out, d_ok, (const u32 *)ctx->gtable5);
   if (time_kernel) {
     HIPCHK(ctx, hipEventRecord(ctx->kev[ctx->kev_n][1], ctx->stream));
     ctx->kev_mode[ctx->kev_n++] = mode == MODE_SCHNORR ? 1 : 0;

@@ -745,8 +745,12 @@ LAMD_HD comb_pair<T> comb_from_rec_odd(const prep_rec &rec) {
 // accumulator (no infinity handling), every addition is the bare formula (gej_add_ge_fast) and the G windows skip a zero
 // digit by branching.  Degenerate events (an addition meeting +-its operand: adversarial scalars only, or the result being
 // infinity) leave Z = 0, which the caller tests ONCE: *suspect = true means "verdict unknown, run ecmult_lane_keyed".
+// (glds: experiment only, -DLAMD_G_LDS -- the north star's "LDS-staged precomputed G table": 52 windows x 32 entries x 64 B = 104 KB
+// staged into the block's LDS by the kernel; u1*G then takes 52 additions from LDS instead of 12 from the 3 GiB table in HBM.
+// Measured A/B in profiles/r03_ab_variants.txt; the shipped build has no such code.)
+constexpr int GLDS_BITS = 5, GLDS_WINDOWS = (256 + GLDS_BITS - 1) / GLDS_BITS, GLDS_WORDS = GLDS_WINDOWS * (1 << GLDS_BITS) * 16;
 template <int T>
-LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u32 *gtable, bool *suspect) {
+LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u32 *gtable, bool *suspect, const u32 *glds = nullptr) {
   constexpr int D = kc_spacing(T), NE = kc_ne(T);
   const comb_pair<T> cp = comb_from_rec_odd<T>(rec);
   gej acc = gej_infinity();
@@ -794,6 +798,29 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
   u32 uw[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) uw[i] = rec.u1[i];
+#if defined(LAMD_G_LDS)
+  if (glds) {
+#pragma unroll 1
+    for (int w = 0; w < GLDS_WINDOWS; w++) {
+      const u32 d = uw[0] & ((1u << GLDS_BITS) - 1u);
+#pragma unroll
+      for (int i = 0; i < 7; i++) uw[i] = (uw[i] >> GLDS_BITS) | (uw[i + 1] << (32 - GLDS_BITS));
+      uw[7] >>= GLDS_BITS;
+      if (d != 0) {
+        const u32 *e = glds + ((w << GLDS_BITS) + d) * 16;
+        u32 xw[8], yw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { xw[i] = e[i]; yw[i] = e[8 + i]; }
+        ge pt;
+        pt.x = fe_from_words(xw);
+        pt.y = fe_from_words(yw);
+        acc = gej_add_ge_fast(acc, pt);
+      }
+    }
+    *suspect = fe_is_zero(acc.z);
+    return acc;
+  }
+#endif
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
     const u32 d = uw[0] & ((1u << GTABLE_WINDOW_BITS) - 1u);
