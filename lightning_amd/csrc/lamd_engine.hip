@@ -768,6 +768,7 @@ struct small_args {
   u32 *slots;                    // ladder tables, SLOT_WORDS per row
   u8 *out;                       // pinned host memory: n verdict bytes
   u32 *counts;                   // ... rows per shape, for lamd_get_info: [0] 7-tooth combs, [1] 10-tooth combs, [2] ladder, [3] rejected keys
+  u8 *shapes;                    // ... and each row's shape (7 / 10 / 255 = ladder / 0): the host remembers the keys that missed
   u32 *flag;                     // ... and the completion word (set to `ticket` last)
   u32 ticket;
 };
@@ -839,6 +840,7 @@ __global__ void __launch_bounds__(64 * ST_TASKS) k_small_verify(small_args A) {
     const u32 T = live ? s_shape[lane] : 1u;
     const u64 b7 = __ballot(T == 7u), b10 = __ballot(T == 10u), bl = __ballot(T == 255u), b0 = __ballot(T == 0u);
     if (lane == 0) { A.counts[0] = (u32)__popcll(b7); A.counts[1] = (u32)__popcll(b10); A.counts[2] = (u32)__popcll(bl); A.counts[3] = (u32)__popcll(b0); }
+    if (live) A.shapes[lane] = (u8)T;
   }
   __syncthreads();
   // ---- phase B
@@ -926,6 +928,8 @@ struct lamd_ctx {
   devbuf list7, list10, listcold, listcold_ok;
   // latency path (k_small_verify): pinned, device-mapped staging for up to SMALL_MAX rows, the verdict bytes and the completion word
   u8 *h_small = nullptr;
+  std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, direct-mapped)
+  bool force_learn = false;         // the next small call on this context builds tables for every key the cache misses
   u32 small_ticket = 0;
   bool small_kernel = true;   // LAMD_SMALL_KERNEL=0: such calls take the general path
   u32 *h_plan = nullptr;   // pinned read-back of the last call's plan + cache counters (statistics only: nothing waits for it)
@@ -1623,7 +1627,11 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   // table-building path below and publishes it
   if (small && use_cache && ctx->small_fused) {
     const u32 dense_thr = ctx->last_small_n / 8 > 32 ? (u32)(ctx->last_small_n / 8) : 32u;
-    const bool learn = ctx->last_small_fused && ctx->h_plan && ((volatile const u32 *)ctx->h_plan)[P_DENSE] >= dense_thr;
+    const bool learn = ctx->force_learn || (ctx->last_small_fused && ctx->h_plan && ((volatile const u32 *)ctx->h_plan)[P_DENSE] >= dense_thr);
+    if (ctx->force_learn) {
+      ctx->force_learn = false;
+      std::fill(ctx->small_missed.begin(), ctx->small_missed.end(), 0);  // their keys have tables after this call
+    }
     ctx->last_small_fused = !learn;
     ctx->last_small_n = n;
     if (!learn) {
@@ -1923,7 +1931,22 @@ extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const v
 // host waits on the completion word the kernel's last instruction writes
 constexpr size_t SMALL_MAX = 64;
 constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG + SMALL_MAX * 64, SMALL_OFF_OUT = SMALL_OFF_KEY + SMALL_MAX * 65 + 64,
-                 SMALL_OFF_COUNTS = SMALL_OFF_OUT + SMALL_MAX, SMALL_OFF_FLAG = SMALL_OFF_COUNTS + 64, SMALL_BYTES = SMALL_OFF_FLAG + 64;
+                 SMALL_OFF_COUNTS = SMALL_OFF_OUT + SMALL_MAX, SMALL_OFF_SHAPES = SMALL_OFF_COUNTS + 64, SMALL_OFF_FLAG = SMALL_OFF_SHAPES + SMALL_MAX,
+                 SMALL_BYTES = SMALL_OFF_FLAG + 64;
+// Keys that the latency path had to take down the ladder are remembered by fingerprint (host side, direct-mapped): the SECOND small
+// call that brings such a key takes the table-building path once (every key the cache misses gets a comb and is published), and
+// from then on the key is a cache hit -- a peer's node id or a channel's keys recur with every single check_signed_hash() call.
+constexpr size_t MISS_SLOTS = 4096;
+static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen) {
+  u64 h = seed ^ 0x6D697373ull;
+  for (int o = 0; o < keylen; o += 8) {
+    u64 c = 0;
+    memcpy(&c, key + o, keylen - o < 8 ? keylen - o : 8);
+    h = (h ^ c) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+  }
+  return h | 1;
+}
 static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok) {
   int rc;
   if (!ctx->h_small) {
@@ -1932,6 +1955,14 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   }
   if ((rc = ensure(ctx, &ctx->slots, SMALL_MAX * SLOT_WORDS * 4)) != LAMD_OK) return rc;
   u8 *h = ctx->h_small;
+  const bool have_cache = ctx->cache_mode != 0 && ctx->cache_store.shared;
+  if (have_cache) {
+    if (ctx->small_missed.empty()) ctx->small_missed.assign(MISS_SLOTS, 0);
+    for (size_t i = 0; i < n; i++) {
+      const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
+      if (ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp) return 1;  // seen before without a table: the caller takes the learning path
+    }
+  }
   memcpy(h, a, n * 32);
   memcpy(h + SMALL_OFF_SIG, sig, n * 64);
   if (keystride == (size_t)keylen) memcpy(h + SMALL_OFF_KEY, key, n * keylen);
@@ -1959,6 +1990,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   A.slots = (u32 *)ctx->slots.p;
   A.out = h + SMALL_OFF_OUT;
   A.counts = (u32 *)(h + SMALL_OFF_COUNTS);
+  A.shapes = h + SMALL_OFF_SHAPES;
   A.flag = (u32 *)(h + SMALL_OFF_FLAG);
   A.ticket = ++ctx->small_ticket ? ctx->small_ticket : ++ctx->small_ticket;
   hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(64 * ST_TASKS), 0, ctx->stream, A);
@@ -1979,6 +2011,13 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   memcpy(ok, h + SMALL_OFF_OUT, n);
   ctx->last_mode = mode;
   ctx->last_n = n;
+  if (have_cache && ((const u32 *)(h + SMALL_OFF_COUNTS))[2]) {  // remember the keys that went down the ladder
+    for (size_t i = 0; i < n; i++)
+      if (h[SMALL_OFF_SHAPES + i] == 255) {
+        const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
+        ctx->small_missed[(fp >> 1) % MISS_SLOTS] = fp;
+      }
+  }
   {  // what lamd_get_info() reports about the last call
     const u32 *c = (const u32 *)(h + SMALL_OFF_COUNTS);
     u32 *hp = ctx->h_plan;
@@ -1996,7 +2035,11 @@ static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *si
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
-  if (n <= SMALL_MAX && ctx->small_kernel) return run_small(ctx, mode, n, a, sig, key, keylen, keystride, ok);
+  if (n <= SMALL_MAX && ctx->small_kernel) {
+    rc = run_small(ctx, mode, n, a, sig, key, keylen, keystride, ok);
+    if (rc != 1) return rc;
+    ctx->force_learn = true;  // a key that missed before is back: this call builds and publishes the missing tables (general path below)
+  }
   if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_c, n * keystride)) != LAMD_OK) return rc;

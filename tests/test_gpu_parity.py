@@ -1047,6 +1047,33 @@ def test_bolt12_signatures_device_front_end_vs_spec_model(eng):
 
 
 @pytest.mark.gpu
+def test_single_calls_learn_a_recurring_key(orc):
+    """one check_signed_hash()-sized call at a time (the fused launch k_small_verify): a key the cache does not know is verified by
+    the ladder the first time, gets its comb table built and published the second time it shows up, and is a cache hit from the
+    third call on; verdicts equal the oracle's throughout, for valid and damaged rows, ECDSA and BIP-340"""
+    from lightning_amd import Engine, workload
+    with Engine(0) as e:
+        w = workload.make_ecdsa(e, 64, seed=9091, nkeys=1, publen=33, invalid_frac=0.25)     # ONE key, 64 signatures
+        s = workload.make_schnorr(e, 64, seed=9092, nkeys=1, invalid_frac=0.25)
+        for wl, fn, ref in ((w, e.verify_ecdsa, lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 33, 1)), (s, e.verify_schnorr, lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], 1))):
+            seen = []
+            for call in range(6):
+                cols = [np.ascontiguousarray(c[call:call + 1]) for c in wl.cols]
+                got = fn(*cols)
+                assert bool(got[0]) == bool(wl.expect[call]) == bool(ref(cols)[0]), call
+                inf = e.info()
+                seen.append((inf["last_cache_hits"], inf["last_cold_rows"], inf["last_new_tables"]))
+            assert seen[0] == (0, 1, 0), seen            # first sight: the ladder
+            assert seen[1][2] == 1, seen                 # second sight: the table is built and published
+            assert all(x == (1, 0, 0) for x in seen[2:]), seen   # afterwards: a cache hit in the fused launch
+        # a batch of unknown keys next to a learnt one: verdicts stay exact while the fingerprints accumulate
+        f = workload.make_ecdsa(e, 40, seed=9093, nkeys=1 << 40, publen=65, group=1, invalid_frac=0.2)
+        for rep in range(3):
+            got = e.verify_ecdsa(*f.cols)
+            assert np.array_equal(got, f.expect) and np.array_equal(got, orc.ecdsa_verify_batch(f.cols[0], f.cols[1], f.cols[2], 65, 1).astype(bool)), rep
+
+
+@pytest.mark.gpu
 def test_small_batches_with_a_cache_take_the_lookup_path(kat, orc):
     """small batches on an engine with the key-table cache: ONE kernel probes the cache and runs the cached comb or, on a miss, the
     ladder (k_ecmult_small).  Hits, misses, unparsable keys and damaged signatures in one batch; a commitment-shaped batch under a
@@ -1061,12 +1088,14 @@ def test_small_batches_with_a_cache_take_the_lookup_path(kat, orc):
         assert np.array_equal(big.d_ok.cpu().numpy().astype(bool), big.expect) and e.info()["last_new_tables"] > 500
         e.verify_ecdsa_device(big.dev[0], big.dev[1], big.dev[2], big.d_ok)           # the host has now seen the publishing call complete
         e.synchronize()
-        fresh = workload.make_ecdsa(e, 3000, seed=778, nkeys=1 << 40, publen=33)      # keys the cache has never seen
-        for n in (1, 7, 64, 65, 484, 3000):
-            sel = np.arange(n)
-            hs = np.concatenate([big.cols[0][sel], fresh.cols[0][sel]]); sg = np.concatenate([big.cols[1][sel], fresh.cols[1][sel]])
-            pk = np.concatenate([big.cols[2][sel], fresh.cols[2][sel]])
-            exp = np.concatenate([big.expect[sel], fresh.expect[sel]])
+        fresh = workload.make_ecdsa(e, 4000, seed=778, nkeys=1 << 40, publen=33, group=1)      # keys the cache has never seen, every row its own
+        o = 0
+        for n in (1, 7, 32, 65, 484, 3000):
+            sel, fsel = np.arange(n), np.arange(o, o + n)     # fresh keys never recur here (a recurring one would be learnt: test_single_calls_learn_a_recurring_key)
+            o += n
+            hs = np.concatenate([big.cols[0][sel], fresh.cols[0][fsel]]); sg = np.concatenate([big.cols[1][sel], fresh.cols[1][fsel]])
+            pk = np.concatenate([big.cols[2][sel], fresh.cols[2][fsel]])
+            exp = np.concatenate([big.expect[sel], fresh.expect[fsel]])
             got = e.verify_ecdsa(hs, sg, pk)
             assert np.array_equal(got, exp), n
             assert np.array_equal(got, orc.ecdsa_verify_batch(hs, sg, pk, 33, 2).astype(bool))
