@@ -747,11 +747,12 @@ __global__ void __launch_bounds__(64) k_small_lookup(size_t n, const u8 *__restr
   }
 }
 // ---- the latency path: n <= 64 rows in ONE launch, inputs read straight from pinned host memory, verdicts written straight back.
-// One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of ST_TASKS waves on one CU.
+// One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of four waves, one per SIMD of a CU.
 //   phase A   wave 0: scalar preparation of its row (one division-step inversion per lane)
 //             wave 1: the row's key -- probe the key-table cache (comb shape + table), or parse it and build the 8-entry ladder table
-//   phase B   wave 0: u1*G (12 windows of the static table);  waves 1-4: the comb's four partial sums / the ladder's two halves
-//   phase C   wave 0: merge (complete Jacobian additions), acceptance test, verdict byte -> host memory, completion flag
+//   phase B   wave t: part t+1 of the comb's four partial sums (or its ladder half) and its share of the 12 windows of u1*G
+//   phase C   three-level merge with complete Jacobian additions (two sums per level, on different waves), acceptance test on wave 0,
+//             verdict byte -> host memory, completion word
 // Replaces, for such calls, H2D x 3 + a dozen launches + D2H + a stream synchronise (0.38 ms for one row) and the ~10^5-instruction
 // dependent chain on one lane.  Everything uses the complete addition formulas: no suspect rows, no second pass.
 struct small_part { u32 w[27]; u32 inf; };  // a Jacobian point in LDS
@@ -788,12 +789,15 @@ __device__ __forceinline__ gej small_load(const small_part *p) {
   g.inf = p->inf != 0;
   return g;
 }
-__global__ void __launch_bounds__(64 * ST_TASKS) k_small_verify(small_args A) {
+__global__ void __launch_bounds__(256) k_small_verify(small_args A) {
+  // FOUR task waves = one per SIMD of the CU (a fifth would share a SIMD with another and stretch both: the first version of this
+  // kernel ran u1*G on a wave of its own next to one of the comb parts, 276 us for one row; profiles/r03_latency.txt).
   __shared__ prep_rec s_rec[64];
   __shared__ u32 s_shape[64];          // 7 / 10: comb teeth; 255: ladder; 0: rejected (key does not parse)
   __shared__ u32 s_tab[64];            // table slot in the pool of its shape
   __shared__ u32 s_zscale[64][9];      // ladder: Zg of the lane's table
-  __shared__ small_part s_part[ST_TASKS][64];
+  __shared__ small_part s_part[4][64]; // comb / ladder parts (on the table's isomorphic curve)
+  __shared__ small_part s_g[4][64];    // parts of u1*G
   const u32 lane = threadIdx.x & 63u, task = threadIdx.x >> 6;
   const bool live = lane < A.n;
   // ---- phase A
@@ -836,47 +840,59 @@ __global__ void __launch_bounds__(64 * ST_TASKS) k_small_verify(small_args A) {
     s_shape[lane] = T;
     s_tab[lane] = tabslot;
   }
-  if (task == 1) {  // whole wave: statistics for lamd_get_info
+  if (task == 1) {  // whole wave: statistics for lamd_get_info, the shapes for the host's learning of recurring keys
     const u32 T = live ? s_shape[lane] : 1u;
     const u64 b7 = __ballot(T == 7u), b10 = __ballot(T == 10u), bl = __ballot(T == 255u), b0 = __ballot(T == 0u);
     if (lane == 0) { A.counts[0] = (u32)__popcll(b7); A.counts[1] = (u32)__popcll(b10); A.counts[2] = (u32)__popcll(bl); A.counts[3] = (u32)__popcll(b0); }
     if (live) A.shapes[lane] = (u8)T;
   }
   __syncthreads();
-  // ---- phase B
+  // ---- phase B: wave t computes part t+1 of the comb (ST_H1LO .. ST_H2HI) / its ladder half, and its share of the windows of u1*G
   const u32 shape = live ? s_shape[lane] : 0u;
   const bool work = live && shape != 0u && (s_rec[lane].flags & PREP_VALID);
   if (work) {
     prep_rec rec = s_rec[lane];
     gej part = gej_infinity();
-    if (task == ST_G) {
-      part = small_task_g(rec, A.gtable);
-    } else if (shape == 7u) {
-      part = small_task_comb<7>(rec, A.pool7 + (size_t)s_tab[lane] * kc_stride(7), (int)task);
-    } else if (shape == 10u) {
-      part = small_task_comb<10>(rec, A.pool10 + (size_t)s_tab[lane] * kc_stride(10), (int)task);
-    } else if (task == ST_H1LO || task == ST_H2LO) {
-      part = small_task_ladder(rec, A.slots + (size_t)lane * SLOT_WORDS, task == ST_H2LO);
-    }
+    const int ct = (int)task + 1;
+    if (shape == 7u) part = small_task_comb<7>(rec, A.pool7 + (size_t)s_tab[lane] * kc_stride(7), ct);
+    else if (shape == 10u) part = small_task_comb<10>(rec, A.pool10 + (size_t)s_tab[lane] * kc_stride(10), ct);
+    else if (ct == ST_H1LO || ct == ST_H2LO) part = small_task_ladder(rec, A.slots + (size_t)lane * SLOT_WORDS, ct == ST_H2LO);
     small_store(&s_part[task][lane], part);
+    int w_lo, w_hi;
+    small_g_windows((int)task, shape == 255u, &w_lo, &w_hi);
+    small_store(&s_g[task][lane], small_task_g(rec, A.gtable, w_lo, w_hi));
   }
   __syncthreads();
-  // ---- phase C
-  if (task == 0 && live) {
+  // ---- phase C: three-level merge (verify_core.h small_merge4), the two sums of a level on different waves
+  if (work) {  // level 1: wave 0: P0 + P1, wave 2: P2 + P3, wave 1: G0 + G1, wave 3: G2 + G3
+    if (task == 0 || task == 2) small_store(&s_part[task][lane], gej_add_var(small_load(&s_part[task][lane]), small_load(&s_part[task + 1][lane])));
+    else small_store(&s_g[task][lane], gej_add_var(small_load(&s_g[task - 1][lane]), small_load(&s_g[task][lane])));
+  }
+  __syncthreads();
+  if (work) {  // level 2: wave 0: S = (P01 + P23) * zscale, wave 1: G = G01 + G23
+    if (task == 0) {
+      gej sum = gej_add_var(small_load(&s_part[0][lane]), small_load(&s_part[2][lane]));
+      if (!sum.inf) {
+        fe zscale;
+        if (shape == 255u) {
+#pragma unroll
+          for (int i = 0; i < 9; i++) zscale.n[i] = s_zscale[lane][i];
+          FE_SETMAG(zscale, 1);
+        } else {
+          zscale = slot_load_fe(shape == 7u ? A.pool7 + (size_t)s_tab[lane] * kc_stride(7) + kc_words(7) : A.pool10 + (size_t)s_tab[lane] * kc_stride(10) + kc_words(10));
+        }
+        sum.z = fe_mul(fe_norm_weak(sum.z), zscale);  // back from the isomorphic curve
+      }
+      small_store(&s_part[0][lane], sum);
+    } else if (task == 1) {
+      small_store(&s_g[1][lane], gej_add_var(small_load(&s_g[1][lane]), small_load(&s_g[3][lane])));
+    }
+  }
+  __syncthreads();
+  if (task == 0 && live) {  // level 3 and the acceptance test
     bool ok = false;
     if (work) {
-      gej parts[ST_TASKS];
-#pragma unroll
-      for (int t = 0; t < ST_TASKS; t++) parts[t] = small_load(&s_part[t][lane]);
-      fe zscale;
-      if (shape == 255u) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) zscale.n[i] = s_zscale[lane][i];
-        FE_SETMAG(zscale, 1);
-      } else {
-        zscale = slot_load_fe((shape == 7u ? A.pool7 + (size_t)s_tab[lane] * kc_stride(7) + kc_words(7) : A.pool10 + (size_t)s_tab[lane] * kc_stride(10) + kc_words(10)));
-      }
-      const gej R = small_merge(parts, zscale);
+      const gej R = gej_add_var(small_load(&s_part[0][lane]), small_load(&s_g[1][lane]));
       u32 rw[8];
       load_words_be(rw, A.sig64 + 64 * lane);
       ok = A.mode == MODE_ECDSA ? ecdsa_final(R, rw) : schnorr_accept_one(R, rw);
@@ -1993,7 +2009,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   A.shapes = h + SMALL_OFF_SHAPES;
   A.flag = (u32 *)(h + SMALL_OFF_FLAG);
   A.ticket = ++ctx->small_ticket ? ctx->small_ticket : ++ctx->small_ticket;
-  hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(64 * ST_TASKS), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(256), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   // spin on the completion word (the kernel's last store, system scope); fall back to the stream if it does not show up
   volatile u32 *flag = (volatile u32 *)(h + SMALL_OFF_FLAG);

@@ -902,10 +902,10 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
 enum { ST_G = 0, ST_H1LO = 1, ST_H1HI = 2, ST_H2LO = 3, ST_H2HI = 4, ST_TASKS = 5 };
 constexpr int kc_split_col(int T) { return T == 7 ? 12 : T == 10 ? 8 : (kc_spacing(T) * 5) / 8; }  // balances doublings + additions of the two parts
 
-LAMD_HD gej small_task_g(const prep_rec &rec, const u32 *gtable) {
+LAMD_HD gej small_task_g(const prep_rec &rec, const u32 *gtable, int w_lo = 0, int w_hi = GTABLE_WINDOWS) {
   gej acc = gej_infinity();
 #pragma unroll 1
-  for (int w = 0; w < GTABLE_WINDOWS; w++) {
+  for (int w = w_lo; w < w_hi; w++) {
     const u32 d = gtable_digit(rec.u1, w);
     const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
     ge pt;
@@ -971,6 +971,25 @@ LAMD_HD gej small_task_ladder(const prep_rec &rec, const u32 *slot, bool second)
     acc = gej_add_ge(acc, pt, skip);
   }
   return acc;
+}
+// Which windows of u1*G a task wave adds up next to its comb / ladder part (k_small_verify runs FOUR task waves, one per SIMD of
+// the CU -- a fifth wave would share a SIMD with another and stretch both): a row with a comb table spreads the 12 windows evenly,
+// a ladder row gives them to the two waves that have no ladder half to compute.
+LAMD_HD void small_g_windows(int task /*0..3*/, bool ladder, int *w_lo, int *w_hi) {
+  constexpr int Q = (GTABLE_WINDOWS + 3) / 4, H = (GTABLE_WINDOWS + 1) / 2;
+  if (!ladder) { *w_lo = task * Q; *w_hi = (task + 1) * Q; }
+  else if (task == 1) { *w_lo = 0; *w_hi = H; }
+  else if (task == 3) { *w_lo = H; *w_hi = GTABLE_WINDOWS; }
+  else { *w_lo = *w_hi = 0; }
+  if (*w_hi > GTABLE_WINDOWS) *w_hi = GTABLE_WINDOWS;
+  if (*w_lo > *w_hi) *w_lo = *w_hi;
+}
+// the merge as the kernel stages it (three levels, the two sums of a level on different waves):
+//   level 1  P01 = P0 + P1, P23 = P2 + P3, G01 = G0 + G1, G23 = G2 + G3      level 2  S = (P01 + P23) * zscale, G = G01 + G23      level 3  R = S + G
+LAMD_HD gej small_merge4(const gej *p /*[4] comb / ladder parts (isomorphic curve)*/, const gej *g /*[4] parts of u1*G*/, const fe &zscale) {
+  gej s = gej_add_var(gej_add_var(p[0], p[1]), gej_add_var(p[2], p[3]));
+  if (!s.inf) s.z = fe_mul(fe_norm_weak(s.z), zscale);
+  return gej_add_var(s, gej_add_var(gej_add_var(g[0], g[1]), gej_add_var(g[2], g[3])));
 }
 // parts[ST_TASKS]; zscale = Zc of the comb table / Zg of the ladder table
 LAMD_HD gej small_merge(const gej *parts, const fe &zscale) {
