@@ -747,10 +747,10 @@ __global__ void __launch_bounds__(64) k_small_lookup(size_t n, const u8 *__restr
   }
 }
 // ---- the latency path: n <= 64 rows in ONE launch, inputs read straight from pinned host memory, verdicts written straight back.
-// One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of four waves, one per SIMD of a CU.
+// One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of eight waves, two per SIMD of a CU.
 //   phase A   wave 0: scalar preparation of its row (one division-step inversion per lane)
 //             wave 1: the row's key -- probe the key-table cache (comb shape + table), or parse it and build the 8-entry ladder table
-//   phase B   wave t: part t+1 of the comb's four partial sums (or its ladder half) and its share of the 12 windows of u1*G
+//   phase B   waves 0-3: the comb's four partial sums (or the two ladder halves); waves 4-7: three of the 12 windows of u1*G each
 //   phase C   three-level merge with complete Jacobian additions (two sums per level, on different waves), acceptance test on wave 0,
 //             verdict byte -> host memory, completion word
 // Replaces, for such calls, H2D x 3 + a dozen launches + D2H + a stream synchronise (0.38 ms for one row) and the ~10^5-instruction
@@ -789,9 +789,10 @@ __device__ __forceinline__ gej small_load(const small_part *p) {
   g.inf = p->inf != 0;
   return g;
 }
-__global__ void __launch_bounds__(256) k_small_verify(small_args A) {
-  // FOUR task waves = one per SIMD of the CU (a fifth would share a SIMD with another and stretch both: the first version of this
-  // kernel ran u1*G on a wave of its own next to one of the comb parts, 276 us for one row; profiles/r03_latency.txt).
+__global__ void __launch_bounds__(512) k_small_verify(small_args A) {
+  // EIGHT waves, two per SIMD: waves 0-3 compute the four comb parts (or the ladder halves), waves 4-7 three windows of u1*G each.
+  // A lone wave is bound by the dependent-issue latency of its instruction stream (~8.7 cycles per instruction measured, against an
+  // issue cost of ~4.3), so a second wave on the same SIMD runs in the gaps: profiles/r03_latency.txt.
   __shared__ prep_rec s_rec[64];
   __shared__ u32 s_shape[64];          // 7 / 10: comb teeth; 255: ladder; 0: rejected (key does not parse)
   __shared__ u32 s_tab[64];            // table slot in the pool of its shape
@@ -850,7 +851,7 @@ __global__ void __launch_bounds__(256) k_small_verify(small_args A) {
   // ---- phase B: wave t computes part t+1 of the comb (ST_H1LO .. ST_H2HI) / its ladder half, and its share of the windows of u1*G
   const u32 shape = live ? s_shape[lane] : 0u;
   const bool work = live && shape != 0u && (s_rec[lane].flags & PREP_VALID);
-  if (work) {
+  if (work && task < 4) {
     prep_rec rec = s_rec[lane];
     gej part = gej_infinity();
     const int ct = (int)task + 1;
@@ -858,18 +859,19 @@ __global__ void __launch_bounds__(256) k_small_verify(small_args A) {
     else if (shape == 10u) part = small_task_comb<10>(rec, A.pool10 + (size_t)s_tab[lane] * kc_stride(10), ct);
     else if (ct == ST_H1LO || ct == ST_H2LO) part = small_task_ladder(rec, A.slots + (size_t)lane * SLOT_WORDS, ct == ST_H2LO);
     small_store(&s_part[task][lane], part);
+  } else if (work) {
     int w_lo, w_hi;
-    small_g_windows((int)task, shape == 255u, &w_lo, &w_hi);
-    small_store(&s_g[task][lane], small_task_g(rec, A.gtable, w_lo, w_hi));
+    small_g_windows((int)task - 4, false, &w_lo, &w_hi);
+    small_store(&s_g[task - 4][lane], small_task_g(s_rec[lane], A.gtable, w_lo, w_hi));
   }
   __syncthreads();
   // ---- phase C: three-level merge (verify_core.h small_merge4), the two sums of a level on different waves
-  if (work) {  // level 1: wave 0: P0 + P1, wave 2: P2 + P3, wave 1: G0 + G1, wave 3: G2 + G3
+  if (work && task < 4) {  // level 1: wave 0: P0 + P1, wave 2: P2 + P3, wave 1: G0 + G1, wave 3: G2 + G3
     if (task == 0 || task == 2) small_store(&s_part[task][lane], gej_add_var(small_load(&s_part[task][lane]), small_load(&s_part[task + 1][lane])));
     else small_store(&s_g[task][lane], gej_add_var(small_load(&s_g[task - 1][lane]), small_load(&s_g[task][lane])));
   }
   __syncthreads();
-  if (work) {  // level 2: wave 0: S = (P01 + P23) * zscale, wave 1: G = G01 + G23
+  if (work && task < 4) {  // level 2: wave 0: S = (P01 + P23) * zscale, wave 1: G = G01 + G23
     if (task == 0) {
       gej sum = gej_add_var(small_load(&s_part[0][lane]), small_load(&s_part[2][lane]));
       if (!sum.inf) {
@@ -2009,7 +2011,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   A.shapes = h + SMALL_OFF_SHAPES;
   A.flag = (u32 *)(h + SMALL_OFF_FLAG);
   A.ticket = ++ctx->small_ticket ? ctx->small_ticket : ++ctx->small_ticket;
-  hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(512), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
   // spin on the completion word (the kernel's last store, system scope); fall back to the stream if it does not show up
   volatile u32 *flag = (volatile u32 *)(h + SMALL_OFF_FLAG);
