@@ -2071,6 +2071,7 @@ static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *si
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig, n * 64, hipMemcpyHostToDevice, ctx->stream));
   rc = run_device(ctx, mode, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, keylen, keystride,
                   (u8 *)ctx->out.p);
+  ctx->force_learn = false;  // (a path that does not look at the flag must not leave it set for an unrelated later call)
   if (rc != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
   return lamd_synchronize(ctx);
