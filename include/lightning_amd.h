@@ -216,8 +216,10 @@ int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg
 /* ---- streaming front end for callers that produce triples one at a time (channeld's
  * commitment_signed loop, channeld/channeld.c:2171,2215-2232; gossip ingest).  Triples are
  * appended to a pinned staging set; flush launches everything queued so far as one batch (asynchronous) and opens the
- * next set, so queueing continues while flushes are in flight: up to 5 flushes may be outstanding (LAMD_ERR_STATE beyond
- * that, until one is collected), successive flushes run on alternating lanes.  poll/wait return the verdicts of the
+ * next set, so queueing continues while flushes are in flight: up to 9 flushes may be outstanding (LAMD_ERR_STATE beyond
+ * that, until one is collected), successive flushes run on alternating lanes.  A flush's three host-to-device copies go down
+ * a copy stream of their own in flush order, so with more flushes outstanding than lanes (4) the rows of the next flush are
+ * already in HBM when its lane comes free.  poll/wait return the verdicts of the
  * OLDEST outstanding flush, in submission (ticket) order. */
 /* A ticket is the position of the triple's verdict in the vector its flush returns: tickets count 0, 1, 2, ... across
  * the kinds inside the open staging set and restart at 0 after every lamd_flush() (fewer than 2^30 triples per flush). */
@@ -270,6 +272,7 @@ typedef struct {
 	double keyed_ecmult_ms_sum[2];
 	size_t keyed_ecmult_launches[2];
 	int hw_queues_env;        /* GPU_MAX_HW_QUEUES as lamd_init() found it (0 = unset: the runtime's default of 4; < 16 costs overlap between the lanes) */
+	int queue_sets;           /* staging sets of the streaming queue = the most flushes that may be outstanding */
 } lamd_info;
 int lamd_get_info(lamd_ctx *ctx, lamd_info *info);
 int lamd_get_lane_info(lamd_ctx *ctx, int lane, lamd_info *info); /* the last call that ran on lane 0 .. lanes-1 */

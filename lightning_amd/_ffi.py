@@ -15,7 +15,7 @@ class LamdInfo(ctypes.Structure):
                 ("last_cache_hits", ctypes.c_size_t), ("last_cold_rows", ctypes.c_size_t), ("last_new_tables", ctypes.c_size_t),
                 ("last_suspect_rows", ctypes.c_size_t), ("cache_enabled", ctypes.c_int), ("cache_entries", ctypes.c_size_t),
                 ("cache_capacity", ctypes.c_size_t), ("cache_resets", ctypes.c_size_t),
-                ("keyed_ecmult_ms_sum", ctypes.c_double * 2), ("keyed_ecmult_launches", ctypes.c_size_t * 2), ("hw_queues_env", ctypes.c_int)]
+                ("keyed_ecmult_ms_sum", ctypes.c_double * 2), ("keyed_ecmult_launches", ctypes.c_size_t * 2), ("hw_queues_env", ctypes.c_int), ("queue_sets", ctypes.c_int)]
 
 
 # name -> (restype, argtypes); every symbol of include/lightning_amd.h and include/lightning_amd_debug.h

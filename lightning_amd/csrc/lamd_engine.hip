@@ -927,7 +927,7 @@ struct devbuf {
 
 enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
 #ifndef LAMD_QUEUE_SETS
-#define LAMD_QUEUE_SETS 5
+#define LAMD_QUEUE_SETS 9
 #endif
 constexpr int QUEUE_SETS = LAMD_QUEUE_SETS;  // staging sets of the streaming queue: one open + up to QUEUE_SETS - 1 flushes in flight
 
@@ -976,7 +976,10 @@ struct lamd_ctx {
   hipStream_t stream2 = nullptr;   // scalar prep runs here, concurrently with the key work on `stream`
   hipStream_t stream3 = nullptr;   // cold rows of a partitioned chunk
   hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr, ev_keys = nullptr, ev_sigs = nullptr;
-  bool sigs_pending = false;  // lamd_flush put the signature copy on the prep stream: the first kernel of the main stream that reads signatures waits for ev_sigs
+  bool sigs_pending = false;  // lamd_flush sent the signature copy down another stream: the first kernel of the main stream that reads signatures waits for ev_sigs_wait
+  hipEvent_t ev_sigs_wait = nullptr;   // the event that copy is followed by (the lane's own ev_sigs, or the staging set's)
+  hipStream_t copy_stream = nullptr;   // root only: the H2D copies of every flush, in flush order, behind nothing but each other (lamd_flush)
+  bool use_copy_stream = true;         // LAMD_COPY_STREAM=0: a flush's copies go down its lane's prep stream (the round-2 form)
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
@@ -1025,6 +1028,7 @@ struct lamd_ctx {
     struct span { size_t row0; u32 ticket0; size_t count; };
     std::vector<span> tickets;  // rows [row0, row0 + count) of this queue return as verdicts [ticket0, ...) of the staging set
     devbuf d_a, d_b, d_c, d_ok;
+    hipEvent_t ev_keys = nullptr, ev_sigs = nullptr, ev_all = nullptr;  // behind the three H2D copies of a flush on the copy stream
   };
   struct queue_set {
     queue q[Q_KINDS];
@@ -1137,8 +1141,15 @@ static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
-  if (!ctx->is_lane)
-    for (auto &qs : ctx->qs) HIPCHK(ctx, hipEventCreateWithFlags(&qs.done, hipEventDisableTiming));
+  if (!ctx->is_lane) {
+    for (auto &qs : ctx->qs) {
+      HIPCHK(ctx, hipEventCreateWithFlags(&qs.done, hipEventDisableTiming));
+      for (auto &q : qs.q)
+        for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (const char *w = getenv("LAMD_COPY_STREAM")) ctx->use_copy_stream = atoi(w) != 0;
+  }
   return LAMD_OK;
 }
 static int make_lanes(lamd_ctx *root, int count) {
@@ -1303,6 +1314,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     if (L) lamd_shutdown(L);
     L = nullptr;
   }
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (devbuf *b : {&ctx->row_ent, &ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->plan,
                     &ctx->kt_fin, &ctx->hk7_row, &ctx->hk7_ent, &ctx->hk7_slot, &ctx->hk7_qwords, &ctx->hk7_keyok, &ctx->hk7_scratch,
@@ -1328,9 +1340,12 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
       for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
         if (*h) (void)hipHostFree(*h);
       for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
+      for (hipEvent_t e : {q.ev_keys, q.ev_sigs, q.ev_all})
+        if (e) (void)hipEventDestroy(e);
     }
     if (qs.done) (void)hipEventDestroy(qs.done);
   }
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
   if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
@@ -1465,6 +1480,7 @@ static int get_info_of(lamd_ctx *ctx, lamd_info *info) {
   strncpy(info->arch, ctx->prop.gcnArchName, sizeof(info->arch) - 1);
   info->gtable_bytes = GTABLE_BYTES;
   info->hw_queues_env = hw_queues_from_env();
+  info->queue_sets = QUEUE_SETS;
   for (int i = 0; i < 4; i++) info->last_kernel_ms[i] = ctx->last_ms[i];
   for (int i = 0; i < 2; i++) {
     info->keyed_ecmult_ms_sum[i] = self->keyed_ms_sum[i];
@@ -1764,7 +1780,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     for (int l = 0; l <= MAX_LANES; l++) vis.seq[l] = root->vis_seq[l];
     vis.seq[ctx->lane_id] = root->pub_seq[ctx->lane_id];
     seq = ++root->call_seq;
-    if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs, 0)); ctx->sigs_pending = false; }
+    if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
     hipLaunchKernelGGL(k_cache_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
                        (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok, d_sig, mode);
   } else {
@@ -1809,7 +1825,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     root->pub_seq[ctx->lane_id] = seq;
     root->pub_pending[ctx->lane_id] = true;
   }
-  if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs, 0)); ctx->sigs_pending = false; }
+  if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
   hipLaunchKernelGGL(k_partition, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
                      (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok, d_sig, mode);
   // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few rows, i.e.
@@ -2723,7 +2739,23 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     // dependency in order on compute queues: 119-137 M verifies/s against 168-185 M/s for these copies, profiles/r03_ab_variants.txt:
     // device-initiated reads of host memory reach a fraction of the SDMA engines' 57 GB/s.  Dropped.)
     const bool split = q.n <= L->chunk;
-    if (split) {
+    if (split && ctx->use_copy_stream) {
+      // Round 3: the copies of EVERY flush go down one stream of their own, in flush order, behind nothing but each other.  On the
+      // lane's prep stream they stood behind the lane's previous call, so with more flushes in flight than lanes the rows of the
+      // next flush still crossed the bus only after the lane had gone idle (1.2 ms for the keys of 1 M rows before its first kernel
+      // could start) -- which is why more staging sets bought nothing.  The device buffers belong to the staging set, and a set is
+      // not refilled before its flush has been collected, so nothing else orders these copies.
+      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, ctx->copy_stream));
+      HIPCHK(ctx, hipEventRecord(q.ev_keys, ctx->copy_stream));
+      HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_keys, 0));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, ctx->copy_stream));
+      HIPCHK(ctx, hipEventRecord(q.ev_sigs, ctx->copy_stream));
+      L->sigs_pending = true;
+      L->ev_sigs_wait = q.ev_sigs;
+      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+      HIPCHK(ctx, hipEventRecord(q.ev_all, ctx->copy_stream));
+      HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));  // the preparation reads all three
+    } else if (split) {
       HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));  // after whatever the lane's main stream still holds
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
       HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream2));
@@ -2734,6 +2766,7 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream2));
       HIPCHK(ctx, hipEventRecord(L->ev_sigs, L->stream2));
       L->sigs_pending = true;
+      L->ev_sigs_wait = L->ev_sigs;
       HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream2));
     } else {
       HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));

@@ -361,7 +361,7 @@ class Engine:
                     last_cache_hits=inf.last_cache_hits, last_cold_rows=inf.last_cold_rows, last_new_tables=inf.last_new_tables,
                     last_suspect_rows=inf.last_suspect_rows, cache_enabled=bool(inf.cache_enabled), cache_entries=inf.cache_entries,
                     cache_capacity=inf.cache_capacity, cache_resets=inf.cache_resets,
-                    keyed_ecmult_ms_sum=list(inf.keyed_ecmult_ms_sum), keyed_ecmult_launches=list(inf.keyed_ecmult_launches), hw_queues_env=int(inf.hw_queues_env))
+                    keyed_ecmult_ms_sum=list(inf.keyed_ecmult_ms_sum), keyed_ecmult_launches=list(inf.keyed_ecmult_launches), hw_queues_env=int(inf.hw_queues_env), queue_sets=int(inf.queue_sets))
 
     def cache_clear(self):
         """empty the key-table cache (cold-path measurements)"""

@@ -42,9 +42,34 @@ loop(12, max(int(x) for x in os.environ.get("PROBE_INFLIGHT", "4").split(",")), 
 for inflight in [int(x) for x in os.environ.get("PROBE_INFLIGHT", "2,3,4,3,4").split(",")]:
     dt, bad = loop(10, inflight, seen)
     print("in flight %d: %.1f M verifies/s (%.2f ms per 2 M-row step), mismatches %d" % (inflight, 20 * n / dt / 1e6, dt / 10 * 1e3, bad))
+
+
+def loop_copying(reps, inflight):
+    """the copying form: caller-owned (pageable) rows -> lamd_queue_*_batch -> staging set (LAMD_COPY_THREADS threads)"""
+    pend, bad = [], 0
+    t1 = time.perf_counter()
+    for r in range(reps):
+        for wl in (we, ws):
+            if wl is we:
+                eng.queue_ecdsa_batch(wl.cols[0], wl.cols[1], wl.cols[2])
+            else:
+                eng.queue_schnorr_batch(wl.cols[0], wl.cols[1], wl.cols[2])
+            eng.flush()
+            pend.append(wl)
+            if len(pend) == inflight:
+                bad += int((eng.wait(cap=n) != pend.pop(0).expect).sum())
+    while pend:
+        bad += int((eng.wait(cap=n) != pend.pop(0).expect).sum())
+    return time.perf_counter() - t1, bad
+
+
+for inflight in [int(x) for x in os.environ.get("PROBE_COPYING", "").split(",") if x]:
+    loop_copying(3, inflight)
+    dt, bad = loop_copying(10, inflight)
+    print("copying form, in flight %d: %.1f M verifies/s (%.2f ms per 2 M-row step), mismatches %d" % (inflight, 20 * n / dt / 1e6, dt / 10 * 1e3, bad))
 # the same calls with the inputs resident in HBM and at most `inflight` calls outstanding (host waits for the oldest)
 import torch
-for inflight in (3, 4, 100):
+for inflight in [int(x) for x in os.environ.get("PROBE_RESIDENT", "3,4,100").split(",") if x]:
     eng.synchronize()
     t1 = time.perf_counter()
     k = 0
