@@ -485,9 +485,72 @@ __global__ void __launch_bounds__(256) k_dedupe_map(size_t n, const u32 *__restr
     todo &= ~same;
   }
 }
+// ---- the fused front end (LAMD_FUSED_FRONT=1, the default).  Every kernel of a call's front end stands in ONE dependent chain on
+// the lane's main stream, and inside the pipelined loop each link of that chain waits for wave slots behind the other lanes' ecmult
+// kernels: a launch that does nothing still cost 0.14 ms there (rocprofv3 trace of the cold loop, r03: 19 launches and 5 fills in
+// front of the ecmult kernel, 8.9 ms of chain for 1.1 ms of VALU work).  The fused chain is six launches: k_call_init (every fill),
+// k_dedupe_insert_count (insert + numbering + use counts), k_dedupe_classify, k_keys_bases_both (parse + doubling chain, both comb
+// shapes in one grid), k_kc_finish_both (Gray-code chains, Z products, rescale, cache entry -- a key's chains are neighbouring lanes
+// of one block), k_partition.
+__global__ void __launch_bounds__(256) k_call_init(u32 *__restrict__ plan, u32 *__restrict__ table, size_t m, u32 *__restrict__ count, size_t n,
+                                                   u32 *__restrict__ row_ent, u32 *__restrict__ cc) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (t < P_WORDS) plan[t] = 0;
+  if (cc && t < C_WORDS) cc[t] = 0;
+  const uint4 z = make_uint4(0, 0, 0, 0), f = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (size_t i = t; i < m / 4; i += stride) reinterpret_cast<uint4 *>(table)[i] = z;   // m is a power of two >= 4
+  for (size_t i = t; i < n / 4; i += stride) {
+    reinterpret_cast<uint4 *>(count)[i] = z;
+    if (row_ent) reinterpret_cast<uint4 *>(row_ent)[i] = f;
+  }
+  if (t < (n & 3)) {
+    count[(n & ~(size_t)3) + t] = 0;
+    if (row_ent) row_ent[(n & ~(size_t)3) + t] = 0xFFFFFFFFu;
+  }
+}
+// insert + numbering + use counts in one pass: the row that claims a slot represents its key and takes the next place on the list
+// of distinct keys; every row adds one to count[its representative's ROW] (combined per wave and key).  count and newent are
+// indexed by representative row in this form (BYROW below), so no row needs its representative's number.
+__global__ void __launch_bounds__(256) k_dedupe_insert_count(size_t n, const u8 *__restrict__ keys, int keylen, size_t stride, u64 seed,
+                                                             const u32 *__restrict__ row_ent, u32 *__restrict__ table, u32 mask,
+                                                             u32 *__restrict__ rep, u32 *__restrict__ plan, u32 *__restrict__ uniq_row,
+                                                             u32 *__restrict__ count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n && row_ent[i] == ENT_NONE;
+  u32 r = ENT_NONE;
+  if (live) {
+    const u8 *k = keys + stride * i;
+    u32 slot = (u32)key_hash(k, keylen, seed) & mask;
+    for (;;) {  // (look before claiming: see k_dedupe_insert)
+      u32 old = __atomic_load_n(&table[slot], __ATOMIC_RELAXED);
+      if (old == 0u) old = atomicCAS(&table[slot], 0u, (u32)i + 1u);
+      if (old == 0u) { r = (u32)i; break; }
+      const u8 *o = keys + stride * (size_t)(old - 1u);
+      bool same = true;
+      for (int b = 0; b < keylen; b++) same &= o[b] == k[b];
+      if (same) { r = old - 1u; break; }
+      slot = (slot + 1u) & mask;
+    }
+  }
+  if (i < n) rep[i] = r;
+  const bool is_rep = live && r == (u32)i;
+  const u32 u = wave_alloc(&plan[P_UNIQ], is_rep);
+  if (is_rep) uniq_row[u] = (u32)i;
+  const u32 lane = threadIdx.x & 63u;
+  u64 todo = __ballot(live);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const u32 rr = __shfl(r, leader, 64);
+    const u64 same = __ballot(live && r == rr);
+    if ((int)lane == leader) atomicAdd(&count[rr], (u32)__popcll(same));
+    todo &= ~same;
+  }
+}
 // one thread per distinct new key: keys carried by >= thr7 rows get a 7-tooth comb, by >= thr10 rows a 10-tooth comb (table
 // slot + cache entry allocated here, wave-aggregated; a full pool simply leaves the key without a table)
 struct cache_caps { u32 ent, t7, t10; };
+// (BYROW: count / newent are indexed by the representative's row -- the fused front end -- instead of the key's number)
+template <bool BYROW>
 __global__ void __launch_bounds__(256) k_dedupe_classify(size_t n, const u32 *__restrict__ count, const u32 *__restrict__ uniq_row,
                                                          u32 thr7, u32 thr10, u32 *__restrict__ plan, u32 *cc, cache_caps caps,
                                                          u32 hk7_cap, u32 hk10_cap, u32 *__restrict__ newent, u32 *__restrict__ hk7_row,
@@ -495,7 +558,8 @@ __global__ void __launch_bounds__(256) k_dedupe_classify(size_t n, const u32 *__
                                                          u32 *__restrict__ hk10_ent, u32 *__restrict__ hk10_slot) {
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = u < n && u < plan[P_UNIQ];
-  const u32 c = live ? count[u] : 0u;
+  const size_t ci = BYROW ? (live ? (size_t)uniq_row[u] : 0) : u;
+  const u32 c = live ? count[ci] : 0u;
   const bool want10 = live && c >= thr10;
   const u32 s10 = wave_alloc(&cc[C_USED10], want10);
   const bool ok10 = want10 && s10 < caps.t10;
@@ -508,7 +572,7 @@ __global__ void __launch_bounds__(256) k_dedupe_classify(size_t n, const u32 *__
   bool placed = false;
   if (oke && ok7 && j7 < hk7_cap) { hk7_row[j7] = uniq_row[u]; hk7_ent[j7] = eid; hk7_slot[j7] = s7; placed = true; }
   if (oke && ok10 && j10 < hk10_cap) { hk10_row[j10] = uniq_row[u]; hk10_ent[j10] = eid; hk10_slot[j10] = s10; placed = true; }
-  if (live) newent[u] = placed ? eid : ENT_NONE;
+  if (live) newent[ci] = placed ? eid : ENT_NONE;
 }
 // the new keys' cache entries (after their tables are complete) and, in cache mode, their index slots
 __global__ void __launch_bounds__(256) k_cache_publish(const u32 *__restrict__ plan, int which, u32 cap, const u32 *__restrict__ hk_row,
@@ -534,6 +598,7 @@ __global__ void __launch_bounds__(256) k_cache_publish(const u32 *__restrict__ p
   }
 }
 // rows the cache did not know: those whose key just got a table join the row list of its shape, the rest take the ladder
+template <bool BYROW>
 __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ row_ent, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
                                                    const u32 *__restrict__ newent, const cache_ent *__restrict__ ents, u32 *__restrict__ plan,
                                                    u32 *__restrict__ list7, u32 *__restrict__ list10, u32 *__restrict__ listcold,
@@ -542,7 +607,7 @@ __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ r
   const bool miss = i < n && rep[i] != ENT_NONE;
   u32 T = 255;
   if (miss) {
-    const u32 e = newent[uid[rep[i]]];
+    const u32 e = newent[BYROW ? rep[i] : uid[rep[i]]];
     if (e != ENT_NONE) {
       row_ent[i] = e;
       T = ents[e].meta & 0xFFu;
@@ -618,6 +683,97 @@ static void launch_keytables(hipStream_t st, const u32 *plan, int which, size_t 
   hipLaunchKernelGGL((k_kc_prefix<T>), dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, plan, which, (u32)cap, qwords, keyok, pool, slots, scratch);
   hipLaunchKernelGGL((k_kc_chain_bwd<T>), dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, st, plan, which, (u32)cap, keyok, pool, slots,
                      (const u32 *)scratch);
+}
+
+// ---- the fused front end's two table kernels (see k_call_init).  One grid covers both comb shapes: blocks [0, blocks7) work on the
+// 7-tooth list, the others on the 10-tooth list.
+struct kc_shape_args {
+  u32 cap;                 // capacity of the list of new keys of this shape (nkeys = min(plan[which], cap))
+  const u32 *hk_row;       // representative row per new key
+  const u32 *hk_ent, *hk_slot;
+  u32 *qwords;             // parsed key, 16 words per key
+  u8 *keyok;
+  u32 *scratch;
+  u32 *pool;
+};
+template <int T>
+__device__ __forceinline__ void keys_bases_body(size_t u, const u32 *__restrict__ plan, int which, const kc_shape_args &A, const u8 *__restrict__ keys,
+                                                int keylen, size_t stride) {
+  const u32 nkeys = plan[which] < A.cap ? plan[which] : A.cap;
+  if (u >= nkeys) return;
+  u32 qx[8], qy[8];
+  const bool ok = parse_pubkey(keys + stride * (size_t)A.hk_row[u], keylen, qx, qy);
+  uint4 *dst = reinterpret_cast<uint4 *>(A.qwords + u * 16);
+  dst[0] = make_uint4(qx[0], qx[1], qx[2], qx[3]);
+  dst[1] = make_uint4(qx[4], qx[5], qx[6], qx[7]);
+  dst[2] = make_uint4(qy[0], qy[1], qy[2], qy[3]);
+  dst[3] = make_uint4(qy[4], qy[5], qy[6], qy[7]);
+  A.keyok[u] = ok;
+  if (ok) kc_bases<T>(A.scratch + u * kc_scratch_words(T), ge_from_words(qx, qy));
+}
+__global__ void __launch_bounds__(256) k_keys_bases_both(const u32 *__restrict__ plan, unsigned blocks7, kc_shape_args A7, kc_shape_args A10,
+                                                         const u8 *__restrict__ keys, int keylen, size_t stride) {
+  if (blockIdx.x < blocks7) keys_bases_body<7>((size_t)blockIdx.x * blockDim.x + threadIdx.x, plan, P_HK7, A7, keys, keylen, stride);
+  else keys_bases_body<10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, keys, keylen, stride);
+}
+// chains forward -> Z products (+ the key's cache entry) -> chains backward: the kc_nsub(T) chains of a key are neighbouring threads
+// of one block (256 is a multiple of 4 and of 32), the stages talk through the key's scratch area, a block barrier between them.
+struct publish_args {
+  const u8 *keys;
+  int keylen;
+  size_t stride;
+  u32 lane, seq;
+  u64 seed;
+  cache_ent *ents;
+  u32 *index;
+  u32 mask;
+  int do_index;
+};
+template <int T>
+__device__ __forceinline__ void kc_finish_body(size_t t, const u32 *__restrict__ plan, int which, const kc_shape_args &A, const publish_args &P) {
+  constexpr int NS = kc_nsub(T);
+  static_assert(256 % NS == 0, "a key's chains must not straddle blocks");
+  const size_t u = t / NS;
+  const int sub = (int)(t % NS);
+  const u32 nkeys = plan[which] < A.cap ? plan[which] : A.cap;
+  const bool live = u < nkeys;
+  const bool ok = live && A.keyok[u];
+  u32 *tab = ok ? A.pool + (size_t)A.hk_slot[u] * kc_stride(T) : nullptr;
+  u32 *scr = A.scratch + u * kc_scratch_words(T);
+  if (ok) kc_chain_fwd<T>(tab, scr, sub);
+  // (block scope is all the stages need -- __syncthreads() carries the workgroup-scope release / acquire.  A device-scope __threadfence()
+  // here writes the XCD's L2 back on every wave: the two table kernels took 3.9 ms instead of 1.9, measured in GPU session l.)
+  __syncthreads();
+  if (live && sub == 0) {
+    if (ok) {
+      u32 qx[8], qy[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { qx[i] = A.qwords[u * 16 + i]; qy[i] = A.qwords[u * 16 + 8 + i]; }
+      kc_prefix<T>(tab, scr, ge_from_words(qx, qy));
+    }
+    // the key's cache entry (k_cache_publish): a key that does not parse is entered as such
+    cache_ent e;
+    key_words(e.kw, P.keys + P.stride * (size_t)A.hk_row[u], P.keylen);
+    e.meta = (ok ? (u32)T : 0u) | (P.lane << 8);
+    e.seq = P.seq;
+    e.tabslot = A.hk_slot[u];
+    const u32 id = A.hk_ent[u];
+    P.ents[id] = e;
+    if (P.do_index) {
+      __threadfence();
+      u32 slot = (u32)key_words_hash(e.kw, P.seed) & P.mask;
+      for (;;) {
+        if (atomicCAS(&P.index[slot], 0u, id + 1u) == 0u) break;
+        slot = (slot + 1u) & P.mask;
+      }
+    }
+  }
+  __syncthreads();
+  if (ok) kc_chain_bwd<T>(tab, scr, sub);
+}
+__global__ void __launch_bounds__(256) k_kc_finish_both(const u32 *__restrict__ plan, unsigned blocks7, kc_shape_args A7, kc_shape_args A10, publish_args P) {
+  if (blockIdx.x < blocks7) kc_finish_body<7>((size_t)blockIdx.x * blockDim.x + threadIdx.x, plan, P_HK7, A7, P);
+  else kc_finish_body<10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, P);
 }
 
 // work item j verifies one row against the comb table of its key: items [0, plan[P_L7]) are the rows of list7 (7-tooth combs),
@@ -982,6 +1138,7 @@ struct lamd_ctx {
   bool use_copy_stream = true;         // LAMD_COPY_STREAM=0: a flush's copies go down its lane's prep stream (the round-2 form)
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
+  bool fused_front = true;        // LAMD_FUSED_FRONT=0: the front end of a keyed call as the 19 launches + 5 fills of round 2 (see k_call_init)
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
   bool last_small_fused = false;  // the previous small batch of this lane ran k_ecmult_small (its plan holds P_DENSE)
   size_t last_small_n = 0;
@@ -1128,7 +1285,11 @@ static int cache_maybe_reset(lamd_ctx *root);
 static int create_streams(lamd_ctx *ctx) {
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-  HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+  // The cold-row ladder shares the prep stream (it starts long after the lane's preparation has finished): two streams per lane
+  // instead of three -- 231 against 216-223 M verifies/s in the cold loop (profiles/r03_fused_front.txt; fewer hardware queues in
+  // use, see hw_queues_from_env).  LAMD_MERGE_SIDE=0 gives the ladder its own stream again.
+  if (!getenv("LAMD_MERGE_SIDE") || atoi(getenv("LAMD_MERGE_SIDE")) != 0) ctx->stream3 = ctx->stream2;
+  else HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_keys, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_sigs, hipEventDisableTiming));
@@ -1176,6 +1337,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->keyed_mode = root->keyed_mode;
     L->keyed_min_rows = root->keyed_min_rows;
     L->small_fused = root->small_fused;
+    L->fused_front = root->fused_front;
     L->keyed_min_uses = root->keyed_min_uses;
     L->keyed_dense_uses = root->keyed_dense_uses;
     L->keyed_teeth = root->keyed_teeth;
@@ -1222,6 +1384,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
   if (const char *w = getenv("LAMD_KEYED_LDS_PAD")) ctx->keyed_lds_pad = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_KEYED_BLOCKS_PER_CU")) ctx->keyed_blocks_per_cu = (unsigned)atoi(w);
+  if (const char *w = getenv("LAMD_FUSED_FRONT")) ctx->fused_front = atoi(w) != 0;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
   {
@@ -1325,7 +1488,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   for (auto &e : ctx->ev_pub)
     if (e) (void)hipEventDestroy(e);
   if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
-  if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
+  if (ctx->stream3 && ctx->stream3 != ctx->stream2) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
   if (ctx->ev_cold) (void)hipEventDestroy(ctx->ev_cold);
   if (ctx->ev_keys) (void)hipEventDestroy(ctx->ev_keys);
   if (ctx->ev_sigs) (void)hipEventDestroy(ctx->ev_sigs);
@@ -1741,7 +1904,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   const size_t hk7_cap = thr7 == 0xFFFFFFFFu ? 1 : n / thr7 + 1, hk10_cap = thr10 == 0xFFFFFFFFu ? 1 : n / thr10 + 1;
   lamd_ctx::key_cache *kc = use_cache ? &root->cache_store : &ctx->cache_store;
   if (!use_cache && (rc = cache_alloc(ctx, kc, hk7_cap, hk10_cap, false)) != LAMD_OK) return rc;
-  size_t m = 1;
+  size_t m = 4;  // (k_call_init clears the table four words at a time)
   while (m < 2 * n) m <<= 1;
   if ((rc = ensure(ctx, &ctx->kd_table, m * 4)) != LAMD_OK) return rc;
   for (devbuf *b : {&ctx->row_ent, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->list7, &ctx->list10,
@@ -1764,10 +1927,8 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   u32 *fin = mode == MODE_SCHNORR ? (u32 *)ctx->kt_fin.p : nullptr;
   const cache_ent *ents = (const cache_ent *)kc->ents.p;
 
-  HIPCHK(ctx, hipMemsetAsync(plan, 0, P_WORDS * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->kd_count.p, 0, n * 4, ctx->stream));
   u32 seq = 0;
+  cache_vis vis = {};
   if (use_cache) {
     // what this call may use: entries published by calls the host has seen complete, or earlier on this lane's stream
     for (int l = 0; l <= MAX_LANES; l++)
@@ -1776,58 +1937,105 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
         root->pub_pending[l] = false;
       }
     (void)hipGetLastError();
-    cache_vis vis;
     for (int l = 0; l <= MAX_LANES; l++) vis.seq[l] = root->vis_seq[l];
     vis.seq[ctx->lane_id] = root->pub_seq[ctx->lane_id];
     seq = ++root->call_seq;
+  }
+  const cache_caps caps = {kc->cap_ent, kc->cap7, kc->cap10};
+  if (ctx->fused_front) {
+    // six launches (see k_call_init)
+    {
+      const size_t words = m > n ? m : n;
+      const unsigned ib = blocks_for(words / 4 + 1);
+      hipLaunchKernelGGL(k_call_init, dim3(ib < 2048u ? ib : 2048u), dim3(256), 0, ctx->stream, plan, (u32 *)ctx->kd_table.p, m, (u32 *)ctx->kd_count.p, n,
+                         use_cache ? (u32 *)nullptr : row_ent, use_cache ? (u32 *)nullptr : cc);
+    }
+    if (use_cache) {
+      if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
+      hipLaunchKernelGGL(k_cache_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                         (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok, d_sig, mode);
+    }
+    hipLaunchKernelGGL(k_dedupe_insert_count, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                       (const u32 *)row_ent, (u32 *)ctx->kd_table.p, (u32)(m - 1), (u32 *)ctx->kd_rep.p, plan, (u32 *)ctx->kd_uniq.p, (u32 *)ctx->kd_count.p);
+    hipLaunchKernelGGL((k_dedupe_classify<true>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
+                       (const u32 *)ctx->kd_uniq.p, thr7, thr10, plan, cc, caps, (u32)hk7_cap, (u32)hk10_cap, (u32 *)ctx->kd_newent.p,
+                       (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
+                       (u32 *)ctx->hk10_slot.p);
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    const bool on7 = thr7 != 0xFFFFFFFFu, on10 = thr10 != 0xFFFFFFFFu;
+    if (on7 || on10) {
+      const kc_shape_args A7 = {(u32)(on7 ? hk7_cap : 0), (const u32 *)ctx->hk7_row.p, (const u32 *)ctx->hk7_ent.p, (const u32 *)ctx->hk7_slot.p,
+                                (u32 *)ctx->hk7_qwords.p, (u8 *)ctx->hk7_keyok.p, (u32 *)ctx->hk7_scratch.p, (u32 *)kc->pool7.p};
+      const kc_shape_args A10 = {(u32)(on10 ? hk10_cap : 0), (const u32 *)ctx->hk10_row.p, (const u32 *)ctx->hk10_ent.p, (const u32 *)ctx->hk10_slot.p,
+                                 (u32 *)ctx->hk10_qwords.p, (u8 *)ctx->hk10_keyok.p, (u32 *)ctx->hk10_scratch.p, (u32 *)kc->pool10.p};
+      const unsigned kb7 = on7 ? blocks_for(hk7_cap) : 0u, kb10 = on10 ? blocks_for(hk10_cap) : 0u;
+      hipLaunchKernelGGL(k_keys_bases_both, dim3(kb7 + kb10), dim3(256), 0, ctx->stream, (const u32 *)plan, kb7, A7, A10, d_key, keylen, keystride);
+      const unsigned fb7 = on7 ? blocks_for(hk7_cap * kc_nsub(7)) : 0u, fb10 = on10 ? blocks_for(hk10_cap * kc_nsub(10)) : 0u;
+      const publish_args P = {d_key, keylen, keystride, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
+                              kc->index_mask, (int)use_cache};
+      hipLaunchKernelGGL(k_kc_finish_both, dim3(fb7 + fb10), dim3(256), 0, ctx->stream, (const u32 *)plan, fb7, A7, A10, P);
+    }
+    if (use_cache) {
+      HIPCHK(ctx, hipEventRecord(root->ev_pub[ctx->lane_id], ctx->stream));
+      root->pub_seq[ctx->lane_id] = seq;
+      root->pub_pending[ctx->lane_id] = true;
+    }
     if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
-    hipLaunchKernelGGL(k_cache_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
-                       (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok, d_sig, mode);
+    hipLaunchKernelGGL((k_partition<true>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)nullptr,
+                       (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok, d_sig, mode);
   } else {
-    HIPCHK(ctx, hipMemsetAsync(row_ent, 0xFF, n * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(cc, 0, C_WORDS * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(plan, 0, P_WORDS * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->kd_table.p, 0, m * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->kd_count.p, 0, n * 4, ctx->stream));
+    if (use_cache) {
+      if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
+      hipLaunchKernelGGL(k_cache_lookup, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                         (const u32 *)kc->index.p, kc->index_mask, ents, vis, row_ent, plan, list7, list10, keyok_out, d_ok, d_sig, mode);
+    } else {
+      HIPCHK(ctx, hipMemsetAsync(row_ent, 0xFF, n * 4, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(cc, 0, C_WORDS * 4, ctx->stream));
+    }
+    hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
+                       (const u32 *)row_ent, (u32 *)ctx->kd_table.p, (u32)(m - 1), (u32 *)ctx->kd_rep.p);
+    hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
+                       plan, (u32 *)ctx->kd_uniq.p);
+    hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
+                       (u32 *)ctx->kd_count.p);
+    hipLaunchKernelGGL((k_dedupe_classify<false>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
+                       (const u32 *)ctx->kd_uniq.p, thr7, thr10, plan, cc, caps, (u32)hk7_cap, (u32)hk10_cap, (u32 *)ctx->kd_newent.p,
+                       (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
+                       (u32 *)ctx->hk10_slot.p);
+    if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    // the new keys: parse, build their tables, publish
+    if (thr7 != 0xFFFFFFFFu) {
+      hipLaunchKernelGGL(k_keys, dim3(blocks_for(hk7_cap)), dim3(256), 0, ctx->stream, hk7_cap, d_key, keylen, keystride, (const u32 *)ctx->hk7_row.p,
+                         (u32 *)ctx->hk7_qwords.p, (u8 *)ctx->hk7_keyok.p, (const u32 *)(plan + P_HK7));
+      launch_keytables<7>(ctx->stream, plan, P_HK7, hk7_cap, (const u32 *)ctx->hk7_qwords.p, (const u8 *)ctx->hk7_keyok.p, (u32 *)kc->pool7.p,
+                          (const u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk7_scratch.p);
+      hipLaunchKernelGGL(k_cache_publish, dim3(blocks_for(hk7_cap)), dim3(256), 0, ctx->stream, (const u32 *)plan, (int)P_HK7, (u32)hk7_cap,
+                         (const u32 *)ctx->hk7_row.p, (const u32 *)ctx->hk7_ent.p, (const u32 *)ctx->hk7_slot.p, (const u8 *)ctx->hk7_keyok.p, d_key,
+                         keylen, keystride, 7u, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
+                         kc->index_mask, (int)use_cache);
+    }
+    if (thr10 != 0xFFFFFFFFu) {
+      hipLaunchKernelGGL(k_keys, dim3(blocks_for(hk10_cap)), dim3(256), 0, ctx->stream, hk10_cap, d_key, keylen, keystride, (const u32 *)ctx->hk10_row.p,
+                         (u32 *)ctx->hk10_qwords.p, (u8 *)ctx->hk10_keyok.p, (const u32 *)(plan + P_HK10));
+      launch_keytables<10>(ctx->stream, plan, P_HK10, hk10_cap, (const u32 *)ctx->hk10_qwords.p, (const u8 *)ctx->hk10_keyok.p, (u32 *)kc->pool10.p,
+                           (const u32 *)ctx->hk10_slot.p, (u32 *)ctx->hk10_scratch.p);
+      hipLaunchKernelGGL(k_cache_publish, dim3(blocks_for(hk10_cap)), dim3(256), 0, ctx->stream, (const u32 *)plan, (int)P_HK10, (u32)hk10_cap,
+                         (const u32 *)ctx->hk10_row.p, (const u32 *)ctx->hk10_ent.p, (const u32 *)ctx->hk10_slot.p, (const u8 *)ctx->hk10_keyok.p, d_key,
+                         keylen, keystride, 10u, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
+                         kc->index_mask, (int)use_cache);
+    }
+    if (use_cache) {
+      HIPCHK(ctx, hipEventRecord(root->ev_pub[ctx->lane_id], ctx->stream));
+      root->pub_seq[ctx->lane_id] = seq;
+      root->pub_pending[ctx->lane_id] = true;
+    }
+    if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
+    hipLaunchKernelGGL((k_partition<false>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
+                       (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok, d_sig, mode);
   }
-  hipLaunchKernelGGL(k_dedupe_insert, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_key, keylen, keystride, root->hash_seed,
-                     (const u32 *)row_ent, (u32 *)ctx->kd_table.p, (u32)(m - 1), (u32 *)ctx->kd_rep.p);
-  hipLaunchKernelGGL(k_dedupe_number, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (u32 *)ctx->kd_uid.p,
-                     plan, (u32 *)ctx->kd_uniq.p);
-  hipLaunchKernelGGL(k_dedupe_map, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
-                     (u32 *)ctx->kd_count.p);
-  cache_caps caps = {kc->cap_ent, kc->cap7, kc->cap10};
-  hipLaunchKernelGGL(k_dedupe_classify, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
-                     (const u32 *)ctx->kd_uniq.p, thr7, thr10, plan, cc, caps, (u32)hk7_cap, (u32)hk10_cap, (u32 *)ctx->kd_newent.p,
-                     (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
-                     (u32 *)ctx->hk10_slot.p);
-  if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  // the new keys: parse, build their tables, publish
-  if (thr7 != 0xFFFFFFFFu) {
-    hipLaunchKernelGGL(k_keys, dim3(blocks_for(hk7_cap)), dim3(256), 0, ctx->stream, hk7_cap, d_key, keylen, keystride, (const u32 *)ctx->hk7_row.p,
-                       (u32 *)ctx->hk7_qwords.p, (u8 *)ctx->hk7_keyok.p, (const u32 *)(plan + P_HK7));
-    launch_keytables<7>(ctx->stream, plan, P_HK7, hk7_cap, (const u32 *)ctx->hk7_qwords.p, (const u8 *)ctx->hk7_keyok.p, (u32 *)kc->pool7.p,
-                        (const u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk7_scratch.p);
-    hipLaunchKernelGGL(k_cache_publish, dim3(blocks_for(hk7_cap)), dim3(256), 0, ctx->stream, (const u32 *)plan, (int)P_HK7, (u32)hk7_cap,
-                       (const u32 *)ctx->hk7_row.p, (const u32 *)ctx->hk7_ent.p, (const u32 *)ctx->hk7_slot.p, (const u8 *)ctx->hk7_keyok.p, d_key,
-                       keylen, keystride, 7u, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
-                       kc->index_mask, (int)use_cache);
-  }
-  if (thr10 != 0xFFFFFFFFu) {
-    hipLaunchKernelGGL(k_keys, dim3(blocks_for(hk10_cap)), dim3(256), 0, ctx->stream, hk10_cap, d_key, keylen, keystride, (const u32 *)ctx->hk10_row.p,
-                       (u32 *)ctx->hk10_qwords.p, (u8 *)ctx->hk10_keyok.p, (const u32 *)(plan + P_HK10));
-    launch_keytables<10>(ctx->stream, plan, P_HK10, hk10_cap, (const u32 *)ctx->hk10_qwords.p, (const u8 *)ctx->hk10_keyok.p, (u32 *)kc->pool10.p,
-                         (const u32 *)ctx->hk10_slot.p, (u32 *)ctx->hk10_scratch.p);
-    hipLaunchKernelGGL(k_cache_publish, dim3(blocks_for(hk10_cap)), dim3(256), 0, ctx->stream, (const u32 *)plan, (int)P_HK10, (u32)hk10_cap,
-                       (const u32 *)ctx->hk10_row.p, (const u32 *)ctx->hk10_ent.p, (const u32 *)ctx->hk10_slot.p, (const u8 *)ctx->hk10_keyok.p, d_key,
-                       keylen, keystride, 10u, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
-                       kc->index_mask, (int)use_cache);
-  }
-  if (use_cache) {
-    HIPCHK(ctx, hipEventRecord(root->ev_pub[ctx->lane_id], ctx->stream));
-    root->pub_seq[ctx->lane_id] = seq;
-    root->pub_pending[ctx->lane_id] = true;
-  }
-  if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
-  hipLaunchKernelGGL(k_partition, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_uid.p,
-                     (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok, d_sig, mode);
   // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few rows, i.e.
   // a latency-bound launch that should hide behind the table-driven kernels instead of serialising with them
   HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
