@@ -303,6 +303,17 @@ def main():
         dt_warm, mism_warm, warm_info = float("nan"), 0, []
     dt, mism_cold = timed(eng_cold)
     record_kernel_times(eng_cold)
+    # the same cold loop once more with the large ecmult launches chained one after the other (lamd_set_ecmult_chain): the in-loop launch
+    # duration of the dominant kernel when its only company is the other lanes' front end -- reported as roofline.chained, never as `value`
+    chained = None
+    if not multi:
+        lm_cold = launch_ms[id(eng_cold)]
+        eng_cold.set_ecmult_chain(True)
+        dt_ch, mism_ch = timed(eng_cold)
+        eng_cold.set_ecmult_chain(False)
+        chained = (dt_ch, mism_ch, launch_ms[id(eng_cold)])
+        launch_ms[id(eng_cold)] = lm_cold
+        mism_cold += mism_ch
     eng_default, eng = eng, eng_cold      # the isolated launch durations below are the cold engine's too
     # the same kernels once more, one call at a time (nothing else on the GPU): the isolated durations
     isolated = {"ecdsa": [], "schnorr": []}
@@ -428,6 +439,13 @@ def main():
                                               "note": "rate at which SURVEY 8(d)'s generic-algorithm multiplies would have to run to finish in the same time; not a fraction of peak"},
                          # whole timed step: the ecmult work of both batches against the step time (the rest of the step builds key tables,
                          # prepares scalars and de-duplicates keys)
+                         "chained": None if chained is None or not chained[2][0][1] else {
+                             "avg_launch_ms": chained[2][0][0] / chained[2][0][1], "launches_timed": int(chained[2][0][1]),
+                             "frac": w_exec * rows_in_launch / (chained[2][0][0] / chained[2][0][1] * 1e-3) / P_MUL32,
+                             "verifies_per_s": world * 2 * n * args.steps / chained[0], "ms_per_step": chained[0] / args.steps * 1e3, "mismatches": chained[1],
+                             "note": "the same cold loop with lamd_set_ecmult_chain(1): a large ecmult launch waits for the one submitted before it, so the "
+                                     "in-loop bracket holds ONE such launch plus the other lanes' front-end kernels (the default lets two overlap: higher "
+                                     "throughput, each launch stretched by its neighbour)"},
                          "pipeline": {"ms": dt / args.steps * 1e3, "achieved": 2 * w_exec * rows_in_launch / (dt / args.steps) / 1e12,
                                       "frac": 2 * w_exec * rows_in_launch / (dt / args.steps) / P_MUL32},
                          "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,

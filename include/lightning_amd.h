@@ -281,6 +281,11 @@ int lamd_set_timing(lamd_ctx *ctx, int enable); /* record HIP events around each
  * default = 6.3 GB of HBM; LAMD_CACHE_KEYS10 10-tooth tables, 2^16 = 3.2 GB) and empties itself when it fills up;
  * benchmarks call this to measure the cold path. */
 int lamd_cache_clear(lamd_ctx *ctx);
+/* Scheduling of the large (>= 65 536 rows) table-driven ecmult launches of successive calls.  0 (default; LAMD_ECMULT_CHAIN): they overlap
+ * whenever the lanes let them -- highest throughput (230 against 224 M verifies/s in the pipelined loop), each launch stretched by its
+ * neighbour (6.9 ms against 3.1 ms by itself).  1: a launch waits for the one submitted before it -- the kernel saturates the VALU issue
+ * port by itself, so what runs under it is only the other lanes' front end (3.9 ms in the loop). */
+int lamd_set_ecmult_chain(lamd_ctx *ctx, int enable);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ SYMBOLS = {
     "lamd_fuzz_field": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, c_sz]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_set_ecmult_chain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_cache_clear": (ctypes.c_int, [ctypes.c_void_p]),
     "lamd_get_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LamdInfo)]),
     "lamd_stream_wait_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

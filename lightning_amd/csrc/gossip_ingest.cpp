@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <sys/resource.h>
 #include <thread>
 #include <map>
 #include <random>
@@ -1263,8 +1264,12 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   const double t4 = prof ? tnow() : 0;
   g->drop_verdicts();
   g->in_process = false;
-  if (prof) fprintf(stderr, "[ingest] n=%zu plan(parallel) %.1f ms, slots %.1f ms, verify %.1f ms, apply %.1f ms, drop %.1f ms\n", n, (t1 - t0) * 1e3, (t2 - t1) * 1e3,
-                    (t3 - t2) * 1e3, (t4 - t3) * 1e3, (tnow() - t4) * 1e3);
+  if (prof) {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    fprintf(stderr, "[ingest] n=%zu plan(parallel) %.1f ms, slots %.1f ms, verify %.1f ms, apply %.1f ms, drop %.1f ms; minor faults so far %ld\n", n, (t1 - t0) * 1e3,
+            (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (tnow() - t4) * 1e3, ru.ru_minflt);
+  }
   return (long)n;
 }
 

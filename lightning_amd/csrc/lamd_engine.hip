@@ -1207,6 +1207,11 @@ struct lamd_ctx {
   bool is_lane = false;
   int next_lane = 0;
   hipEvent_t ev_lane = nullptr, ev_join = nullptr;
+  // root: the large table-driven ecmult launches of successive calls run one after the other (LAMD_ECMULT_CHAIN, see run_chunk)
+  hipEvent_t ev_ecm[MAX_LANES + 1] = {};
+  int ecm_last = -1;
+  int ecm_chain = 0;
+  size_t ecm_chain_min = 65536;
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -1309,6 +1314,8 @@ static int create_streams(lamd_ctx *ctx) {
         for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (auto &e : ctx->ev_ecm) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (const char *w = getenv("LAMD_ECMULT_CHAIN")) ctx->ecm_chain = atoi(w);
     if (const char *w = getenv("LAMD_COPY_STREAM")) ctx->use_copy_stream = atoi(w) != 0;
   }
   return LAMD_OK;
@@ -1509,6 +1516,8 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     if (qs.done) (void)hipEventDestroy(qs.done);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  for (auto &e : ctx->ev_ecm)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
   if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
@@ -1616,6 +1625,14 @@ extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
     L->keyed_ms_sum[0] = L->keyed_ms_sum[1] = 0;
     L->keyed_launches[0] = L->keyed_launches[1] = 0;
   }
+  return LAMD_OK;
+}
+
+// scheduling of the large table-driven ecmult launches (include/lightning_amd.h); takes effect with the next call
+extern "C" int lamd_set_ecmult_chain(lamd_ctx *ctx, int enable) {
+  if (!ctx) return LAMD_ERR_ARG;
+  ctx->ecm_chain = enable != 0;
+  ctx->ecm_last = -1;
   return LAMD_OK;
 }
 
@@ -2053,6 +2070,11 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
   // (the bare-formula kernel fits 4 waves per SIMD with a spill, or 3 without: LAMD_KEYED_WAVES)
   auto fast = ctx->keyed_waves == 3 ? k_ecmult_keyed<false, 3> : k_ecmult_keyed<false, 4>;
+  // LAMD_ECMULT_CHAIN=1: a large table-driven ecmult launch waits for the one submitted before it (on another lane).  The kernel
+  // saturates the VALU issue port by itself (0.235 of 0.25 wave-instructions per SIMD and cycle), so two of them in flight only
+  // stretch each other; what gains from running under it is the other lanes' latency-bound front end.
+  const bool chain = root->ecm_chain != 0 && n >= root->ecm_chain_min;
+  if (chain && root->ecm_last >= 0 && root->ecm_last != ctx->lane_id) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, root->ev_ecm[root->ecm_last], 0));
   const bool time_kernel = time_it && ctx->kev_n < lamd_ctx::KEV;
   if (time_kernel) {
     hipEvent_t *pair = ctx->kev[ctx->kev_n];
@@ -2068,6 +2090,10 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   if (time_kernel) {
     HIPCHK(ctx, hipEventRecord(ctx->kev[ctx->kev_n][1], ctx->stream));
     ctx->kev_mode[ctx->kev_n++] = mode == MODE_SCHNORR ? 1 : 0;
+  }
+  if (chain) {
+    HIPCHK(ctx, hipEventRecord(root->ev_ecm[ctx->lane_id], ctx->stream));
+    root->ecm_last = ctx->lane_id;
   }
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
   hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,

@@ -330,6 +330,10 @@ class Engine:
     def set_timing(self, on=True):
         self._chk(self._lib.lamd_set_timing(self._ctx, int(on)))
 
+    def set_ecmult_chain(self, on):
+        """large table-driven ecmult launches one after the other (True) or overlapping (False, default): lamd_set_ecmult_chain"""
+        self._chk(self._lib.lamd_set_ecmult_chain(self._ctx, int(on)))
+
     def stream_wait_results(self, stream_ptr):
         """make a caller's HIP stream wait (on the device) for every verification submitted so far"""
         self._chk(self._lib.lamd_stream_wait_results(self._ctx, ctypes.c_void_p(stream_ptr)))
