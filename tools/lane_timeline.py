@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Lane timeline of the timed loops from a rocprofv3 kernel trace (CSV, optionally .gz) of
-`bench.py --steps K --warmup W --cpu-sample 0 --skip-extra`: for each loop (warm engine first, then cold) the window between its
-first and last 1 M-row table-driven ecmult launch, how busy each kernel class was inside it and how the launches overlap.
+`bench.py --steps K --warmup W --cpu-sample 0 --skip-extra`: for each loop (warm engine first, then cold, then cold with the large ecmult
+launches chained) the window between its first and last 1 M-row table-driven ecmult launch, how busy each kernel class was inside it and
+how the launches overlap.
 usage: lane_timeline.py trace.csv[.gz] [steps] [warmup]"""
 import collections
 import csv
@@ -20,7 +21,7 @@ def short(n):
 
 
 CLASS = (("k_ecmult_keyed<false", "table-driven ecmult"), ("k_ecmult_keyed<true", "complete-formula ecmult"), ("k_ecmult<", "cold-row ladder"),
-         ("k_kc_", "table building"), ("k_keys", "key parse"), ("k_cache_", "cache lookup/publish"), ("k_dedupe", "de-duplication"),
+         ("k_kc_", "table building"), ("k_keys_bases", "table building"), ("k_keys", "key parse"), ("k_call_init", "de-duplication"), ("k_cache_", "cache lookup/publish"), ("k_dedupe", "de-duplication"),
          ("k_partition", "partition"), ("k_ecdsa_prep", "scalar prep"), ("k_schnorr_prep", "scalar prep"), ("k_schnorr_final", "BIP-340 parity stage"))
 
 
@@ -32,12 +33,15 @@ def cls(name):
 
 
 big = [r for r in rows if short(r["Kernel_Name"]).startswith("k_ecmult_keyed<false") and int(r["Grid_Size_X"]) >= 500000]
-# launch order of bench.py: warm loop (W warm-up + K timed steps, two launches per step), cold loop (same), then 2 x 2 isolated calls
+# launch order of bench.py: warm loop (W warm-up + K timed steps, two launches per step), cold loop (same), cold loop with chained
+# launches (same), then 2 x 2 isolated calls
 K, W = steps, warmup
-legs = [big[2 * W:2 * W + 2 * K], big[4 * W + 2 * K:4 * W + 4 * K]]
-iso = big[4 * W + 4 * K:4 * W + 4 * K + 4]
+per = 2 * W + 2 * K
+legs = [big[2 * W:per], big[per + 2 * W:2 * per], big[2 * per + 2 * W:3 * per]]
+iso = big[3 * per:3 * per + 4]
 print("isolated calls (one at a time): %s ms" % ", ".join("%.3f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in iso))
-for name, leg in zip(("warm loop (key-table cache on)", "cold loop (tables rebuilt every call: `value`)"), legs):
+for name, leg in zip(("warm loop (key-table cache on)", "cold loop (tables rebuilt every call: `value`)",
+                      "cold loop, large ecmult launches chained (lamd_set_ecmult_chain(1): roofline.chained)"), legs):
     t0, t1 = int(leg[0]["Start_Timestamp"]), int(leg[-1]["End_Timestamp"])
     span = (t1 - t0) / 1e6
     print("== %s: %d launches, window %.2f ms (%.2f ms per 2-launch step)" % (name, len(leg), span, span / (len(leg) / 2)))
