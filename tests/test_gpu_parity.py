@@ -592,6 +592,59 @@ def test_single_lane_mode_matches(orc):
         e.close()
 
 
+@pytest.mark.parametrize("env", [{"LAMD_FUSED_FRONT": "0"}, {"LAMD_MERGE_SIDE": "0"}, {"LAMD_ECMULT_CHAIN": "1"}, {"LAMD_COPY_STREAM": "0"},
+                                 {"LAMD_FUSED_FRONT": "0", "LAMD_CACHE": "0"}, {"LAMD_CACHE": "0"}])
+def test_scheduling_variants_give_the_same_verdicts(orc, env):
+    """the round-2 front end (19 launches), the ladder on a stream of its own, chained ecmult launches, flush copies on the lane's prep
+    stream: every scheduling variant the engine still carries must produce the verdicts of the default one -- against the C oracle on a
+    sample and by construction on every row; calls back to back over all lanes, the streaming queue with more flushes in flight than lanes"""
+    import os
+    from lightning_amd import Engine, workload
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    try:
+        w = workload.make_ecdsa(e, 120000, seed=41, nkeys=3000, publen=33)
+        s = workload.make_schnorr(e, 90000, seed=42, nkeys=900)
+        x = workload.make_ecdsa(e, 70000, seed=43, nkeys=1 << 40, publen=65, group=1)      # every row its own key: all on the ladder
+        for rep in range(3):
+            for wl in (w, s, x):
+                wl.d_ok.fill_(9)
+            torch.cuda.synchronize()
+            e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+            e.verify_schnorr_device(s.dev[0], s.dev[1], s.dev[2], s.d_ok)
+            e.verify_ecdsa_device(x.dev[0], x.dev[1], x.dev[2], x.d_ok)
+            e.synchronize()
+            for wl in (w, s, x):
+                assert np.array_equal(wl.d_ok.cpu().numpy().astype(bool), wl.expect), (env, rep, wl.kind)
+        sample = slice(0, 3000)
+        assert np.array_equal(orc.ecdsa_verify_batch(*[np.ascontiguousarray(c[sample]) for c in w.cols], 33, 4).astype(bool), w.expect[sample])
+        assert np.array_equal(orc.schnorr_verify_batch(*[np.ascontiguousarray(c[sample]) for c in s.cols], 4).astype(bool), s.expect[sample])
+        # streaming: six flushes outstanding on four lanes
+        pend = []
+        for rep in range(8):
+            wl = (w, s)[rep & 1]
+            if wl is w:
+                e.queue_ecdsa_batch(*wl.cols)
+            else:
+                e.queue_schnorr_batch(*wl.cols)
+            e.flush()
+            pend.append(wl)
+            if len(pend) == 6:
+                assert np.array_equal(e.wait(cap=pend[0].n).astype(bool), pend.pop(0).expect), env
+        while pend:
+            assert np.array_equal(e.wait(cap=pend[0].n).astype(bool), pend.pop(0).expect), env
+    finally:
+        e.close()
+
+
 def test_device_self_diagnostics(eng, kat):
     """the diagnostic entry points (every arithmetic stage evaluated on the device and, with the same inline functions, on
     the host) must report no difference -- they are how a code-generation problem is localised on a new toolchain"""
