@@ -60,10 +60,10 @@ const char *lamd_last_error(const lamd_ctx *ctx);
 const char *lamd_version(void);
 
 /* ---- batch verification, host buffers in, host verdicts out (H2D + kernels + D2H, synchronous).
- * A call of <= 64 rows is ONE kernel launch (k_small_verify): the rows travel through pinned device-mapped memory, each
- * verification is split over eight waves, the verdict bytes come back the same way (LAMD_SMALL_KERNEL=0 sends such calls down
- * the general path).  A key such calls bring for the second time gets its comb table built and cached, so recurring keys
- * (a peer's node id, a channel's keys) are cache hits from their third sight on.
+ * A call of <= 4096 rows is ONE kernel launch (k_small_verify, a grid of 64-row blocks): the rows travel through pinned device-mapped
+ * memory, each verification is split over eight waves, the verdict bytes come back the same way (LAMD_SMALL_KERNEL=0 sends such calls
+ * down the general path).  A key such calls bring for the second time gets its comb table built and cached, so recurring keys (a peer's
+ * node id, a channel's htlc key) are cache hits from their third sight on.
  *
  * lamd_verify_ecdsa_batch: n independent check_signed_hash() calls (bitcoin/signature.c:174-192,
  * decl bitcoin/signature.h:85-87).  publen is 33 or 65 for every key of the batch; key i is at

@@ -924,8 +924,8 @@ struct small_args {
   const u32 *pool7, *pool10, *gtable;
   u32 *slots;                    // ladder tables, SLOT_WORDS per row
   u8 *out;                       // pinned host memory: n verdict bytes
-  u32 *counts;                   // ... rows per shape, for lamd_get_info: [0] 7-tooth combs, [1] 10-tooth combs, [2] ladder, [3] rejected keys
-  u8 *shapes;                    // ... and each row's shape (7 / 10 / 255 = ladder / 0): the host remembers the keys that missed
+  u8 *shapes;                    // ... each row's shape (7 / 10: comb teeth, 255: ladder, 0: rejected key): statistics, and the host remembers the keys that missed
+  u32 *done;                     // device memory: blocks finished (grids of more than one block)
   u32 *flag;                     // ... and the completion word (set to `ticket` last)
   u32 ticket;
 };
@@ -955,16 +955,20 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
   __shared__ u32 s_zscale[64][9];      // ladder: Zg of the lane's table
   __shared__ small_part s_part[4][64]; // comb / ladder parts (on the table's isomorphic curve)
   __shared__ small_part s_g[4][64];    // parts of u1*G
+  // (a call of more than 64 rows is a grid of such blocks: block b owns rows [64 b, 64 b + 64); the LAST block to finish -- a counter in
+  // device memory -- writes the completion word)
   const u32 lane = threadIdx.x & 63u, task = threadIdx.x >> 6;
-  const bool live = lane < A.n;
+  const size_t row = (size_t)blockIdx.x * 64 + lane;
+  const bool live = row < A.n;
   // ---- phase A
   if (task == 0 && live) {
-    if (A.mode == MODE_ECDSA) ecdsa_prep_thread(lane, 64, lane + 1, A.a32, A.sig64, s_rec);   // this lane's row only
-    else schnorr_prep_one(A.a32 + 32 * lane, A.key + (size_t)A.keylen * lane, A.sig64 + 64 * lane, &s_rec[lane]);
+    const size_t base = (size_t)blockIdx.x * 64;
+    if (A.mode == MODE_ECDSA) ecdsa_prep_thread(lane, 64, lane + 1, A.a32 + 32 * base, A.sig64 + 64 * base, s_rec);   // this lane's row only
+    else schnorr_prep_one(A.a32 + 32 * row, A.key + (size_t)A.keylen * row, A.sig64 + 64 * row, &s_rec[lane]);
   }
   if (task == 1 && live) {
     u32 T = 255, tabslot = 0;
-    const u8 *kp = A.key + (size_t)A.keylen * lane;
+    const u8 *kp = A.key + (size_t)A.keylen * row;
     if (A.index) {
       u32 kw[17];
       key_words(kw, kp, A.keylen);
@@ -986,7 +990,7 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
     if (T == 255u) {  // no table: parse the key, build the ladder's 8-entry table in the lane's slot
       u32 qx[8], qy[8];
       if (parse_pubkey(kp, A.keylen, qx, qy)) {
-        const fe zg = fe_norm_weak(build_q_table(A.slots + (size_t)lane * SLOT_WORDS, ge_from_words(qx, qy)));
+        const fe zg = fe_norm_weak(build_q_table(A.slots + row * SLOT_WORDS, ge_from_words(qx, qy)));
 #pragma unroll
         for (int i = 0; i < 9; i++) s_zscale[lane][i] = zg.n[i];
         __threadfence_block();  // the table (global memory) is read by the ladder waves after the barrier
@@ -997,12 +1001,7 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
     s_shape[lane] = T;
     s_tab[lane] = tabslot;
   }
-  if (task == 1) {  // whole wave: statistics for lamd_get_info, the shapes for the host's learning of recurring keys
-    const u32 T = live ? s_shape[lane] : 1u;
-    const u64 b7 = __ballot(T == 7u), b10 = __ballot(T == 10u), bl = __ballot(T == 255u), b0 = __ballot(T == 0u);
-    if (lane == 0) { A.counts[0] = (u32)__popcll(b7); A.counts[1] = (u32)__popcll(b10); A.counts[2] = (u32)__popcll(bl); A.counts[3] = (u32)__popcll(b0); }
-    if (live) A.shapes[lane] = (u8)T;
-  }
+  if (task == 1 && live) A.shapes[row] = (u8)s_shape[lane];  // for lamd_get_info and the host's learning of recurring keys
   __syncthreads();
   // ---- phase B: wave t computes part t+1 of the comb (ST_H1LO .. ST_H2HI) / its ladder half, and its share of the windows of u1*G
   const u32 shape = live ? s_shape[lane] : 0u;
@@ -1013,7 +1012,7 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
     const int ct = (int)task + 1;
     if (shape == 7u) part = small_task_comb<7>(rec, A.pool7 + (size_t)s_tab[lane] * kc_stride(7), ct);
     else if (shape == 10u) part = small_task_comb<10>(rec, A.pool10 + (size_t)s_tab[lane] * kc_stride(10), ct);
-    else if (ct == ST_H1LO || ct == ST_H2LO) part = small_task_ladder(rec, A.slots + (size_t)lane * SLOT_WORDS, ct == ST_H2LO);
+    else if (ct == ST_H1LO || ct == ST_H2LO) part = small_task_ladder(rec, A.slots + row * SLOT_WORDS, ct == ST_H2LO);
     small_store(&s_part[task][lane], part);
   } else if (work) {
     int w_lo, w_hi;
@@ -1052,15 +1051,19 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
     if (work) {
       const gej R = gej_add_var(small_load(&s_part[0][lane]), small_load(&s_g[1][lane]));
       u32 rw[8];
-      load_words_be(rw, A.sig64 + 64 * lane);
+      load_words_be(rw, A.sig64 + 64 * row);
       ok = A.mode == MODE_ECDSA ? ecdsa_final(R, rw) : schnorr_accept_one(R, rw);
     }
-    A.out[lane] = ok ? 1 : 0;
+    A.out[row] = ok ? 1 : 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence_system();
-    __hip_atomic_store(A.flag, A.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();  // this block's verdict and shape bytes are on their way to host memory before it counts itself done
+    const bool last = gridDim.x == 1u || __hip_atomic_fetch_add(A.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    if (last) {
+      if (gridDim.x != 1u) __hip_atomic_store(A.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch (same stream: ordered)
+      __hip_atomic_store(A.flag, A.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1102,6 +1105,7 @@ struct lamd_ctx {
   devbuf list7, list10, listcold, listcold_ok;
   // latency path (k_small_verify): pinned, device-mapped staging for up to SMALL_MAX rows, the verdict bytes and the completion word
   u8 *h_small = nullptr;
+  devbuf small_done;          // block counter of k_small_verify grids (device memory)
   std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, direct-mapped)
   bool force_learn = false;         // the next small call on this context builds tables for every key the cache misses
   u32 small_ticket = 0;
@@ -1501,7 +1505,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (ctx->ev_sigs) (void)hipEventDestroy(ctx->ev_sigs);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
-  for (devbuf *b : {&ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->vbuf, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
+  for (devbuf *b : {&ctx->small_done, &ctx->recs, &ctx->qwords, &ctx->keyok, &ctx->slots, &ctx->vbuf, &ctx->in_a, &ctx->in_b, &ctx->in_c, &ctx->out,
                     &ctx->g_msgs, &ctx->g_off, &ctx->g_ids, &ctx->g_rowbase, &ctx->g_hash, &ctx->g_sig, &ctx->g_pub,
                     &ctx->g_malformed, &ctx->g_ok, &ctx->g_verdict})
     release(b);
@@ -2197,10 +2201,9 @@ extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const v
 
 // n <= SMALL_MAX rows from host memory: one launch of k_small_verify, inputs and verdicts through pinned device-mapped memory, the
 // host waits on the completion word the kernel's last instruction writes
-constexpr size_t SMALL_MAX = 64;
+constexpr size_t SMALL_MAX = 4096;  // rows of a call that takes the one-launch path (a grid of 64-row blocks)
 constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG + SMALL_MAX * 64, SMALL_OFF_OUT = SMALL_OFF_KEY + SMALL_MAX * 65 + 64,
-                 SMALL_OFF_COUNTS = SMALL_OFF_OUT + SMALL_MAX, SMALL_OFF_SHAPES = SMALL_OFF_COUNTS + 64, SMALL_OFF_FLAG = SMALL_OFF_SHAPES + SMALL_MAX,
-                 SMALL_BYTES = SMALL_OFF_FLAG + 64;
+                 SMALL_OFF_SHAPES = SMALL_OFF_OUT + SMALL_MAX, SMALL_OFF_FLAG = SMALL_OFF_SHAPES + SMALL_MAX, SMALL_BYTES = SMALL_OFF_FLAG + 64;
 // Keys that the latency path had to take down the ladder are remembered by fingerprint (host side, direct-mapped): the SECOND small
 // call that brings such a key takes the table-building path once (every key the cache misses gets a comb and is published), and
 // from then on the key is a cache hit -- a peer's node id or a channel's keys recur with every single check_signed_hash() call.
@@ -2221,12 +2224,17 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_small, SMALL_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
     memset(ctx->h_small, 0, SMALL_BYTES);
   }
-  if ((rc = ensure(ctx, &ctx->slots, SMALL_MAX * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->slots, ((n + 63) & ~(size_t)63) * SLOT_WORDS * 4)) != LAMD_OK) return rc;
+  if (!ctx->small_done.p) {
+    if ((rc = ensure(ctx, &ctx->small_done, 64)) != LAMD_OK) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->small_done.p, 0, 64, ctx->stream));
+  }
   u8 *h = ctx->h_small;
   const bool have_cache = ctx->cache_mode != 0 && ctx->cache_store.shared;
   if (have_cache) {
     if (ctx->small_missed.empty()) ctx->small_missed.assign(MISS_SLOTS, 0);
     for (size_t i = 0; i < n; i++) {
+      if (i && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0) continue;  // a commitment's rows share their key
       const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
       if (ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp) return 1;  // seen before without a table: the caller takes the learning path
     }
@@ -2236,6 +2244,10 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   if (keystride == (size_t)keylen) memcpy(h + SMALL_OFF_KEY, key, n * keylen);
   else
     for (size_t i = 0; i < n; i++) memcpy(h + SMALL_OFF_KEY + i * keylen, key + i * keystride, keylen);
+  // every verdict / shape byte is written exactly once by the kernel (0 / 1; 0 / 7 / 10 / 255): 0xEE marks "not written yet", so that the
+  // host can tell whether the bytes of EVERY block have arrived when it sees the completion word (written by the last block)
+  memset(h + SMALL_OFF_OUT, 0xEE, n);
+  memset(h + SMALL_OFF_SHAPES, 0xEE, n);
   small_args A;
   memset(&A, 0, sizeof A);
   A.a32 = h; A.sig64 = h + SMALL_OFF_SIG; A.key = h + SMALL_OFF_KEY;
@@ -2257,37 +2269,47 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   A.gtable = (const u32 *)ctx->gtable;
   A.slots = (u32 *)ctx->slots.p;
   A.out = h + SMALL_OFF_OUT;
-  A.counts = (u32 *)(h + SMALL_OFF_COUNTS);
   A.shapes = h + SMALL_OFF_SHAPES;
+  A.done = (u32 *)ctx->small_done.p;
   A.flag = (u32 *)(h + SMALL_OFF_FLAG);
   A.ticket = ++ctx->small_ticket ? ctx->small_ticket : ++ctx->small_ticket;
-  hipLaunchKernelGGL(k_small_verify, dim3(1), dim3(512), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_small_verify, dim3((unsigned)((n + 63) / 64)), dim3(512), 0, ctx->stream, A);
   HIPCHK(ctx, hipGetLastError());
-  // spin on the completion word (the kernel's last store, system scope); fall back to the stream if it does not show up
+  // spin on the completion word (the last block's last store, system scope), then make sure every block's bytes are in; fall back to
+  // the stream if either does not show up
   volatile u32 *flag = (volatile u32 *)(h + SMALL_OFF_FLAG);
+  auto all_in = [&] {
+    for (size_t i = 0; i < n; i++)
+      if (((volatile u8 *)h)[SMALL_OFF_OUT + i] == 0xEE || ((volatile u8 *)h)[SMALL_OFF_SHAPES + i] == 0xEE) return false;
+    return true;
+  };
   bool seen = false;
   for (u32 spins = 0; spins < (1u << 22); spins++) {
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == A.ticket) { seen = true; break; }
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == A.ticket && all_in()) { seen = true; break; }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
   }
   if (!seen) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != A.ticket) { ctx->err = "k_small_verify: completion word not written"; return LAMD_ERR_HIP; }
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != A.ticket || !all_in()) { ctx->err = "k_small_verify: completion word / verdict bytes not written"; return LAMD_ERR_HIP; }
   }
   memcpy(ok, h + SMALL_OFF_OUT, n);
   ctx->last_mode = mode;
   ctx->last_n = n;
-  if (have_cache && ((const u32 *)(h + SMALL_OFF_COUNTS))[2]) {  // remember the keys that went down the ladder
+  u32 c[4] = {0, 0, 0, 0};  // rows per shape: 7-tooth combs, 10-tooth combs, ladder, rejected keys
+  for (size_t i = 0; i < n; i++) {
+    const u8 T = h[SMALL_OFF_SHAPES + i];
+    c[T == 7 ? 0 : T == 10 ? 1 : T == 255 ? 2 : 3]++;
+  }
+  if (have_cache && c[2]) {  // remember the keys that went down the ladder
     for (size_t i = 0; i < n; i++)
-      if (h[SMALL_OFF_SHAPES + i] == 255) {
+      if (h[SMALL_OFF_SHAPES + i] == 255 && !(i && h[SMALL_OFF_SHAPES + i - 1] == 255 && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0)) {
         const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
         ctx->small_missed[(fp >> 1) % MISS_SLOTS] = fp;
       }
   }
   {  // what lamd_get_info() reports about the last call
-    const u32 *c = (const u32 *)(h + SMALL_OFF_COUNTS);
     u32 *hp = ctx->h_plan;
     memset(hp, 0, P_WORDS * 4);
     hp[P_L7] = c[0]; hp[P_L10] = c[1]; hp[P_COLD] = c[2]; hp[P_HITS] = c[0] + c[1] + c[3];
@@ -2303,7 +2325,8 @@ static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *si
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
-  if (n <= SMALL_MAX && ctx->small_kernel) {
+  // (LAMD_KEYED=1 -- tests forcing the table-building path -- keeps calls of more than one block on the general path)
+  if (n <= SMALL_MAX && ctx->small_kernel && (ctx->keyed_mode <= 0 || n <= 64)) {
     rc = run_small(ctx, mode, n, a, sig, key, keylen, keystride, ok);
     if (rc != 1) return rc;
     ctx->force_learn = true;  // a key that missed before is back: this call builds and publishes the missing tables (general path below)
