@@ -1010,7 +1010,12 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
     prep_rec rec = s_rec[lane];
     gej part = gej_infinity();
     const int ct = (int)task + 1;
-    if (shape == 7u) part = small_task_comb<7>(rec, A.pool7 + (size_t)s_tab[lane] * kc_stride(7), ct);
+    // (ONE body for both comb shapes where a wave's lanes hold 7- and 10-tooth keys -- a commitment's funding + htlc rows: two template
+    // instantiations would run one after the other; a wave that holds one shape only takes that shape's own, faster, body)
+    const bool mixed = __ballot(shape == 7u) != 0 && __ballot(shape == 10u) != 0;
+    if (mixed && (shape == 7u || shape == 10u))
+      part = small_task_comb_rt(rec, shape == 7u ? A.pool7 + (size_t)s_tab[lane] * kc_stride(7) : A.pool10 + (size_t)s_tab[lane] * kc_stride(10), ct, (int)shape);
+    else if (shape == 7u) part = small_task_comb<7>(rec, A.pool7 + (size_t)s_tab[lane] * kc_stride(7), ct);
     else if (shape == 10u) part = small_task_comb<10>(rec, A.pool10 + (size_t)s_tab[lane] * kc_stride(10), ct);
     else if (ct == ST_H1LO || ct == ST_H2LO) part = small_task_ladder(rec, A.slots + row * SLOT_WORDS, ct == ST_H2LO);
     small_store(&s_part[task][lane], part);

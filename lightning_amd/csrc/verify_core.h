@@ -948,6 +948,47 @@ LAMD_HD gej small_task_comb(const prep_rec &rec, const u32 *tab, int task) {
   }
   return acc;
 }
+// The same comb part with the shape known only at run time (T = 7 or 10).  k_small_verify keeps one row per lane, and the lanes of a wave
+// may hold keys with 7-tooth and keys with 10-tooth tables -- a commitment_signed is one signature under the funding key (7 teeth) and 483
+// under the htlc key (10): with one instantiation per shape the wave runs both bodies one after the other (0.33 ms for that batch against
+// 0.14 ms for its 483 htlc rows alone); with run-time bounds it runs the longer of the two loops once.
+LAMD_HD gej small_task_comb_rt(const prep_rec &rec, const u32 *tab, int task, int T) {
+  const comb_pair<7> c7 = comb_from_rec_odd<7>(rec);
+  const comb_pair<10> c10 = comb_from_rec_odd<10>(rec);
+  const bool ten = T == 10, second = task >= ST_H2LO, hi = task == ST_H1HI || task == ST_H2HI;
+  u32 tooth[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    const u32 t10 = second ? c10.tooth2[i] : c10.tooth1[i];
+    const u32 t7 = i < 7 ? (second ? c7.tooth2[i < 7 ? i : 0] : c7.tooth1[i < 7 ? i : 0]) : 0u;
+    tooth[i] = ten ? t10 : t7;
+  }
+  const bool neg = ten ? (second ? c10.n2 : c10.n1) : (second ? c7.n2 : c7.n1);
+  const int D = ten ? kc_spacing(10) : kc_spacing(7), J = ten ? kc_split_col(10) : kc_split_col(7), topbit = ten ? 9 : 6;
+  const u32 ne_mask = ten ? (u32)(kc_ne(10) - 1) : (u32)(kc_ne(7) - 1);
+  const int jtop = hi ? D - 1 : J - 1, jbot = hi ? J : 0;
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int j = jtop; j >= jbot; j--) {
+    if (j != jtop) acc = gej_double(acc);
+    u32 m = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) m |= ((tooth[i] >> j) & 1u) << i;
+    const bool top = (m >> topbit) & 1u;
+    const u32 idx = (top ? m : ~m) & ne_mask;
+    const u32 *e = tab + idx * SLOT_ENTRY_WORDS;
+    ge pt;
+    pt.x = slot_load_fe(e + (second ? ENT_BX : ENT_X));
+    pt.y = slot_load_fe(e + ENT_Y);
+    pt = ge_neg_if(pt, top == neg);
+    acc = gej_add_ge(acc, pt, false);
+  }
+  if (hi) {
+#pragma unroll 1
+    for (int k = 0; k < J; k++) acc = gej_double(acc);
+  }
+  return acc;
+}
 // one GLV half over the lane's own 8-entry table (build_q_table): k1*Q (second = false) or k2*lambda*Q
 LAMD_HD gej small_task_ladder(const prep_rec &rec, const u32 *slot, bool second) {
   const bool neg = rec.flags & (second ? PREP_K2NEG : PREP_K1NEG);

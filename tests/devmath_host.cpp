@@ -173,7 +173,18 @@ static void verify_split_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
     parts[ST_G] = small_task_g(recs[i], g_table.data());
     if (T) {
       keytable_build<(T ? T : 7)>(tab.data(), scratch.data(), ge_from_words(qx, qy));
-      for (int t = ST_H1LO; t <= ST_H2HI; t++) parts[t] = small_task_comb<(T ? T : 7)>(recs[i], tab.data(), t);
+      bool rt_same = true;
+      for (int t = ST_H1LO; t <= ST_H2HI; t++) {
+        parts[t] = small_task_comb<(T ? T : 7)>(recs[i], tab.data(), t);
+        // the form k_small_verify runs (shape known at run time) must give the same part, coordinate for coordinate
+        const gej q = small_task_comb_rt(recs[i], tab.data(), t, T ? T : 7);
+        rt_same &= q.inf == parts[t].inf;
+        if (!q.inf && !parts[t].inf)
+          rt_same &= fe_equal(fe_norm_weak(q.x), fe_norm_weak(parts[t].x), 1) && fe_equal(fe_norm_weak(q.y), fe_norm_weak(parts[t].y), 1) &&
+                     fe_equal(fe_norm_weak(q.z), fe_norm_weak(parts[t].z), 1);
+        parts[t] = q;
+      }
+      if (!rt_same) { out[i] = 0xEF; continue; }   // a verdict no test expects
       zscale = slot_load_fe(&tab[kc_words(T ? T : 7)]);
     } else {
       zscale = build_q_table(slot.data(), ge_from_words(qx, qy));
