@@ -1848,9 +1848,11 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   // small batch with a cache: lookup straight into the row lists (k_small_lookup), cached combs + ladder -- unless the previous
   // small batch on this lane reported a dense run of rows under a key the cache does not know: then this one takes the
   // table-building path below and publishes it
+  bool latency_learn = false;  // this call builds the tables of keys the LATENCY path (k_small_verify) met for the second time
   if (small && use_cache && ctx->small_fused) {
     const u32 dense_thr = ctx->last_small_n / 8 > 32 ? (u32)(ctx->last_small_n / 8) : 32u;
     const bool learn = ctx->force_learn || (ctx->last_small_fused && ctx->h_plan && ((volatile const u32 *)ctx->h_plan)[P_DENSE] >= dense_thr);
+    latency_learn = ctx->force_learn;
     if (ctx->force_learn) {
       ctx->force_learn = false;
       std::fill(ctx->small_missed.begin(), ctx->small_missed.end(), 0);  // their keys have tables after this call
@@ -1926,6 +1928,10 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     // other key the batch misses -- the funding key, one signature per commitment but the same one every time -- a 7-tooth comb
     thr7 = use_cache && ctx->small_fused && ctx->keyed_teeth != 10 ? 1u : 0xFFFFFFFFu;
     if (ctx->keyed_teeth != 7) thr10 = (u32)(ctx->keyed_dense_uses + 0.5);
+    // keys learnt for the latency path take the 10-tooth comb while its pool has room (k_dedupe_classify falls back to 7 teeth when it
+    // is full): such a key is about to be met one signature per call, where the comb's dependent chain IS the latency -- 13 columns
+    // instead of 19 (one cached-key call 0.18 -> 0.15 ms); the 48 KB per key are what the 2^16-slot pool is for
+    if (latency_learn && ctx->keyed_teeth != 7) thr10 = 1u;
   }
   const size_t hk7_cap = thr7 == 0xFFFFFFFFu ? 1 : n / thr7 + 1, hk10_cap = thr10 == 0xFFFFFFFFu ? 1 : n / thr10 + 1;
   lamd_ctx::key_cache *kc = use_cache ? &root->cache_store : &ctx->cache_store;

@@ -47,6 +47,19 @@ for bs in [int(x) for x in os.environ.get("PROBE_SIZES", "1,8,64,484,1024,4096")
             continue          # (4096 fresh keys per call: the workload holds 4096 rows)
         a, b = p50(call, 300 if bs <= 64 else 100)
         print("  %4d rows, %-24s p50 %.3f ms  p99 %.3f ms" % (bs, name, a, b))
+# a key the latency path itself learnt (ladder at first sight, table built at the second: such keys take the 10-tooth comb)
+one = workload.make_ecdsa(eng, 256, seed=11, nkeys=1, publen=33, device="cuda:0", invalid_frac=0.0)
+k = [0]
+
+
+def call1():
+    o = k[0] % 256
+    k[0] += 1
+    assert eng.verify_ecdsa(*[c[o:o + 1] for c in one.cols])[0]
+for _ in range(4):
+    call1()
+a, b = p50(call1, 300)
+print("     1 rows, ecdsa33 key learnt one call at a time  p50 %.3f ms  p99 %.3f ms  (comb teeth %s)" % (a, b, eng.info()["last_keyed"]))
 # one commitment_signed: 1 signature under the funding key + 483 under the channel's htlc key (both known to the cache after two sights)
 cs = workload.make_commit_storm(eng, 2, device="cuda:0")["ecdsa"]
 hh, ss, pp = [np.ascontiguousarray(x[:484]) for x in cs.cols]
