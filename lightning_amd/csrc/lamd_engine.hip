@@ -261,16 +261,10 @@ __global__ void __launch_bounds__(256) k_grind(u32 ncand, u32 min_rate, u64 weig
 }
 
 // rowbase[i] = index of message i's first signature row; malformed[i] set here for framing errors
-__global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
-                                                       const u8 *__restrict__ node_ids, const u64 *__restrict__ rowbase,
-                                                       u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub33,
-                                                       u8 *__restrict__ malformed) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u8 *m = msgs + off[i];
-  const size_t len = off[i + 1] - off[i];
-  const size_t row = rowbase[i];
-  const size_t nrows = rowbase[i + 1] - row;
+// one message -> its signature rows (hash of the signed tail, signature k, signer k; strides 32 / 64 / 33) and whether it is malformed
+// (framing, or a signature whose r or s is out of range: fromwire_secp256k1_ecdsa_signature fails).  Shared by the kernel below and by the
+// host-side latency path of lamd_sigcheck_gossip_batch (a handful of messages: the rows go through k_small_verify).
+LAMD_HD bool gossip_expand_one(const u8 *m, size_t len, const u8 *node_id33, size_t nrows, u8 *hash32, u8 *sig64, u8 *pub33) {
   const gossip_frame fr = gossip_parse_frame(m, len);
   bool bad = fr.bad;
   const u32 type = fr.type;
@@ -278,7 +272,7 @@ __global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__res
   u8 h[32];
   if (!bad) sha256d_bytes(m + signed_off, len - signed_off, h);
   for (size_t k = 0; k < nrows; k++) {
-    u8 *hd = hash32 + 32 * (row + k), *sd = sig64 + 64 * (row + k), *pd = pub33 + 33 * (row + k);
+    u8 *hd = hash32 + 32 * k, *sd = sig64 + 64 * k, *pd = pub33 + 33 * k;
     if (bad) {
       for (int b = 0; b < 32; b++) hd[b] = 0;
       for (int b = 0; b < 64; b++) sd[b] = 0;
@@ -286,7 +280,7 @@ __global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__res
       continue;
     }
     const u8 *sp = m + 2 + 64 * k;
-    const u8 *kp = (type == GOSSIP_CUPD) ? node_ids + 33 * i : m + keyoff + 33 * k;
+    const u8 *kp = (type == GOSSIP_CUPD) ? node_id33 : m + keyoff + 33 * k;
     u32 rw[8], sw[8];
     load_words_be(rw, sp);
     load_words_be(sw, sp + 32);
@@ -295,7 +289,27 @@ __global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__res
     for (int b = 0; b < 64; b++) sd[b] = sp[b];
     for (int b = 0; b < 33; b++) pd[b] = kp[b];
   }
-  malformed[i] = bad;
+  return bad;
+}
+// verdicts of a message's rows -> the message's verdict: -1 malformed (incl. a bitcoin key that does not parse: fromwire_pubkey),
+// 0 all signatures good, k = the FIRST failing signature (sigcheck.c:78-113 order)
+LAMD_HD int gossip_reduce_one(size_t nrows, const u8 *ok, const u8 *keyok, bool malformed) {
+  bool bad = malformed;
+  if (!bad && nrows == 4) bad = !keyok[2] | !keyok[3];  // fromwire_pubkey on bitcoin_key_1/2
+  if (bad) return -1;
+  int v = 0;
+  for (size_t k = nrows; k-- > 0;)
+    if (!ok[k]) v = (int)k + 1;
+  return v;
+}
+__global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
+                                                       const u8 *__restrict__ node_ids, const u64 *__restrict__ rowbase,
+                                                       u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub33,
+                                                       u8 *__restrict__ malformed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t row = rowbase[i];
+  malformed[i] = gossip_expand_one(msgs + off[i], off[i + 1] - off[i], node_ids + 33 * i, rowbase[i + 1] - row, hash32 + 32 * row, sig64 + 64 * row, pub33 + 33 * row);
 }
 
 __global__ void __launch_bounds__(256) k_gossip_reduce(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
@@ -304,17 +318,8 @@ __global__ void __launch_bounds__(256) k_gossip_reduce(size_t n, const u8 *__res
                                                        int8_t *__restrict__ verdict) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const size_t row = rowbase[i], nrows = rowbase[i + 1] - row;
-  int v = 0;
-  bool bad = malformed[i];
-  if (!bad && nrows == 4) bad = !keyok[row + 2] | !keyok[row + 3];  // fromwire_pubkey on bitcoin_key_1/2
-  if (bad) {
-    v = -1;
-  } else {
-    for (size_t k = nrows; k-- > 0;)
-      if (!ok[row + k]) v = (int)k + 1;  // ends on the FIRST failing signature (sigcheck.c:78-113 order)
-  }
-  verdict[i] = (int8_t)v;
+  const size_t row = rowbase[i];
+  verdict[i] = (int8_t)gossip_reduce_one(rowbase[i + 1] - row, ok + row, keyok + row, malformed[i]);
 }
 
 // (the synthetic-workload signer kernels live in lamd_testgen.hip -> liblightning_amd_testgen.so: test / bench infrastructure,
@@ -2804,8 +2809,29 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
     ctx->err = "channel_update in batch but node_ids33 is NULL";
     return LAMD_ERR_ARG;
   }
-  const size_t total = off[n] - off[0];
   int rc;
+  // a handful of messages (an unmodified gossipd checks ONE per sigcheck_*() call, gossmap_manage.c:687,924,1217): framing and the
+  // double SHA-256 of the signed tail on the host -- the same inline functions the kernels run -- and the rows through the one-launch
+  // latency path; the first-bad reduction on the host.  (A key that comes back without a table sends the call down the general path
+  // below once: that call builds and publishes the table.)
+  if (rows <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0) {
+    if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+    std::vector<u8> hs(32 * rows), sg(64 * rows), pk(33 * rows), ok(rows), bad(n);
+    for (size_t i = 0; i < n; i++)
+      bad[i] = gossip_expand_one(msgs + off[i], off[i + 1] - off[i], node_ids33 ? node_ids33 + 33 * i : nullptr, rowbase[i + 1] - rowbase[i], &hs[32 * rowbase[i]],
+                                 &sg[64 * rowbase[i]], &pk[33 * rowbase[i]]);
+    rc = run_small(ctx, MODE_ECDSA, rows, hs.data(), sg.data(), pk.data(), 33, 33, ok.data());
+    if (rc == LAMD_OK) {
+      const u8 *shapes = ctx->h_small + SMALL_OFF_SHAPES;
+      std::vector<u8> keyok(rows);
+      for (size_t r = 0; r < rows; r++) keyok[r] = shapes[r] != 0;
+      for (size_t i = 0; i < n; i++) verdict[i] = (int8_t)gossip_reduce_one(rowbase[i + 1] - rowbase[i], &ok[rowbase[i]], &keyok[rowbase[i]], bad[i] != 0);
+      return LAMD_OK;
+    }
+    if (rc != 1) return rc;
+    ctx->force_learn = true;
+  }
+  const size_t total = off[n] - off[0];
   if ((rc = ensure(ctx, &ctx->g_msgs, total + 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_off, (n + 1) * 8)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_ids, n * 33)) != LAMD_OK) return rc;
@@ -2818,6 +2844,7 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
   if (node_ids33) HIPCHK(ctx, hipMemcpyAsync(ctx->g_ids.p, node_ids33, n * 33, hipMemcpyHostToDevice, ctx->stream));
   rc = gossip_device(ctx, n, (const u8 *)ctx->g_msgs.p, (const u64 *)ctx->g_off.p, (const u8 *)ctx->g_ids.p, (const u64 *)ctx->g_rowbase.p,
                      rows, (int8_t *)ctx->g_verdict.p);
+  ctx->force_learn = false;
   if (rc != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(verdict, ctx->g_verdict.p, n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

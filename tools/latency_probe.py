@@ -60,6 +60,21 @@ for _ in range(4):
     call1()
 a, b = p50(call1, 300)
 print("     1 rows, ecdsa33 key learnt one call at a time  p50 %.3f ms  p99 %.3f ms  (comb teeth %s)" % (a, b, eng.info()["last_keyed"]))
+# gossip, one message per call as an unmodified gossipd does it (sigcheck_channel_announcement / _update, gossmap_manage.c:687,924): the nodes recur
+g = workload.make_gossip(eng, 300, 300, n_nodes=20, device="cuda:0", corrupt_frac=0.05)
+gm = [bytes(g.msgs[int(g.off[i]):int(g.off[i + 1])]) for i in range(g.n)]
+gi = [bytes(g.ids[i]) for i in range(g.n)]
+for name, lo in (("channel_announcement (4 signatures)", 0), ("channel_update", g.n_cann)):
+    kk = [0]
+
+    def gcall():
+        i = lo + kk[0] % 300
+        kk[0] += 1
+        assert int(eng.sigcheck_gossip([gm[i]], [gi[i]])[0]) == int(g.expect[i]), i
+    for _ in range(120):
+        gcall()           # node ids learnt (first sight: ladder, second: table); a channel's bitcoin keys never recur
+    a, b = p50(gcall, 300)
+    print("     1 message, %-38s p50 %.3f ms  p99 %.3f ms" % (name, a, b))
 # one commitment_signed: 1 signature under the funding key + 483 under the channel's htlc key (both known to the cache after two sights)
 cs = workload.make_commit_storm(eng, 2, device="cuda:0")["ecdsa"]
 hh, ss, pp = [np.ascontiguousarray(x[:484]) for x in cs.cols]
