@@ -182,30 +182,27 @@ __global__ void __launch_bounds__(256) k_recover_final(size_t n, u32 *__restrict
 // ---- gossip: per message, double-SHA256 of the signed tail and expansion into (hash, sig, key) rows
 // ---- check_tx_sig batches: double-SHA256 of caller-built BIP143 preimages (bitcoin/signature.c:120-151 hashes them
 // through libwally) and the sighash-type gate of bitcoin/signature.c:206-211
+// one row of check_tx_sig: the sighash-type gate (only SIGHASH_ALL, or SINGLE|ANYONECANPAY with a witness script) and the double SHA-256
+// of the caller's preimage; shared by the kernel and the host-side latency path (a few rows: lamd_check_tx_sig_batch)
+LAMD_HD bool txsig_hash_one(const u8 *pre, size_t len, u8 sighash_type, bool has_witness, u8 hash32[32]) {
+  const bool pass = sighash_type == 1 || (sighash_type == 0x83 && has_witness);
+  u8 h[32];
+  if (pass) sha256d_bytes(pre, len, h);
+  for (int b = 0; b < 32; b++) hash32[b] = pass ? h[b] : 0;
+  return pass;
+}
 __global__ void __launch_bounds__(256) k_txsig_hash(size_t n, const u8 *__restrict__ pre, const u64 *__restrict__ off,
                                                     const u8 *__restrict__ sighash_type, const u8 *__restrict__ has_witness,
                                                     u8 *__restrict__ hash32, u8 *__restrict__ gate) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const u8 t = sighash_type[i];
-  // only SIGHASH_ALL, or SINGLE|ANYONECANPAY with a witness script
-  const bool pass = t == 1 || (t == 0x83 && has_witness[i]);
-  gate[i] = pass;
-  u8 h[32];
-  if (pass) sha256d_bytes(pre + off[i], (size_t)(off[i + 1] - off[i]), h);
-  for (int b = 0; b < 32; b++) hash32[32 * i + b] = pass ? h[b] : 0;
+  gate[i] = txsig_hash_one(pre + off[i], (size_t)(off[i + 1] - off[i]), sighash_type[i], has_witness[i] != 0, hash32 + 32 * i);
 }
 // ---- check_tx_sig from transaction templates: the BIP143 hash of bitcoin_tx_hash_for_sig() (bitcoin/signature.c:120-151) computed
 // here from flat template arrays (verify_core.h "BIP143 signature hash on the device"), plus the sighash-type gate of :206-211
-__global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__restrict__ version, const u32 *__restrict__ locktime,
-                                                       const u8 *__restrict__ inputs40, const u64 *__restrict__ in_off,
-                                                       const u32 *__restrict__ input_num, const u64 *__restrict__ amount,
-                                                       const u8 *__restrict__ outputs, const u64 *__restrict__ out_off,
-                                                       const u32 *__restrict__ n_outputs, const u8 *__restrict__ scripts,
-                                                       const u64 *__restrict__ script_off, const u8 *__restrict__ sighash_type,
-                                                       const u8 *__restrict__ has_witness, u8 *__restrict__ hash32, u8 *__restrict__ gate) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+LAMD_HD bool txsig_tx_hash_one(size_t i, const u32 *version, const u32 *locktime, const u8 *inputs40, const u64 *in_off, const u32 *input_num,
+                               const u64 *amount, const u8 *outputs, const u64 *out_off, const u32 *n_outputs, const u8 *scripts,
+                               const u64 *script_off, const u8 *sighash_type, const u8 *has_witness, u8 hash32[32]) {
   const u8 t = sighash_type[i];
   bool pass = t == 1 || (t == 0x83 && has_witness[i]);
   u8 h[32];
@@ -221,8 +218,20 @@ __global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__re
     tv.n_out = n_outputs[i];
     pass = bip143_sighash(tv, input_num[i], scripts + script_off[i], (size_t)(script_off[i + 1] - script_off[i]), amount[i], t, h);
   }
-  gate[i] = pass;
-  for (int b = 0; b < 32; b++) hash32[32 * i + b] = h[b];
+  for (int b = 0; b < 32; b++) hash32[b] = h[b];
+  return pass;
+}
+__global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__restrict__ version, const u32 *__restrict__ locktime,
+                                                       const u8 *__restrict__ inputs40, const u64 *__restrict__ in_off,
+                                                       const u32 *__restrict__ input_num, const u64 *__restrict__ amount,
+                                                       const u8 *__restrict__ outputs, const u64 *__restrict__ out_off,
+                                                       const u32 *__restrict__ n_outputs, const u8 *__restrict__ scripts,
+                                                       const u64 *__restrict__ script_off, const u8 *__restrict__ sighash_type,
+                                                       const u8 *__restrict__ has_witness, u8 *__restrict__ hash32, u8 *__restrict__ gate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  gate[i] = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
+                              has_witness, hash32 + 32 * i);
 }
 // ---- BOLT #12: merkle root + tagged signature hash of one TLV stream per lane (bolt12.h); valid[i] = the stream obeys the TLV rules
 __global__ void __launch_bounds__(64) k_bolt12_hash(size_t n, const u8 *__restrict__ tlvs, const u64 *__restrict__ off, bolt12_mids mids,
@@ -2480,10 +2489,25 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
     return LAMD_ERR_ARG;
   }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  // a few rows (an unmodified channeld checks ONE signature per check_tx_sig() call, channeld.c:2171,2224): gate + double SHA-256 on the
+  // host -- the kernel's own inline function -- and the rows through the one-launch latency path
+  if (n <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0) {
+    if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+    std::vector<u8> hs(32 * n), gate(n);
+    for (size_t i = 0; i < n; i++) gate[i] = txsig_hash_one(preimages + off[i], (size_t)(off[i + 1] - off[i]), sighash_type[i], has_witness[i] != 0, &hs[32 * i]);
+    rc = run_small(ctx, MODE_ECDSA, n, hs.data(), sig64, pub, (int)publen, pubstride, ok);
+    if (rc == LAMD_OK) {
+      for (size_t i = 0; i < n; i++)
+        if (!gate[i]) ok[i] = 0;
+      return LAMD_OK;
+    }
+    if (rc != 1) return rc;
+    ctx->force_learn = true;
+  }
   const size_t total = off[n] - off[0];
   std::vector<u64> rel(n + 1);
   for (size_t i = 0; i <= n; i++) rel[i] = off[i] - off[0];
-  int rc;
   if ((rc = ensure(ctx, &ctx->g_msgs, total + 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_off, (n + 1) * 8)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_ids, 2 * n)) != LAMD_OK) return rc;
@@ -2504,6 +2528,7 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   HIPCHK(ctx, hipGetLastError());
   rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
                   (u8 *)ctx->out.p);
+  ctx->force_learn = false;
   if (rc != LAMD_OK) return rc;
   hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
   HIPCHK(ctx, hipGetLastError());
@@ -2526,6 +2551,20 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+  if (n <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0) {  // a few rows: BIP143 hash on the host, rows through the latency path (see lamd_check_tx_sig_batch)
+    std::vector<u8> hs(32 * n), gate(n);
+    for (size_t i = 0; i < n; i++)
+      gate[i] = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
+                                  has_witness, &hs[32 * i]);
+    rc = run_small(ctx, MODE_ECDSA, n, hs.data(), sig64, pub, (int)publen, pubstride, ok);
+    if (rc == LAMD_OK) {
+      for (size_t i = 0; i < n; i++)
+        if (!gate[i]) ok[i] = 0;
+      return LAMD_OK;
+    }
+    if (rc != 1) return rc;
+    ctx->force_learn = true;
+  }
   // one staging blob: fixed-width columns first (8-byte aligned), then the three byte strings
   const size_t nin = (size_t)(in_off[n] - in_off[0]), nout_b = (size_t)(out_off[n] - out_off[0]), nsc = (size_t)(script_off[n] - script_off[0]);
   size_t o = 0;
@@ -2555,6 +2594,7 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
   HIPCHK(ctx, hipGetLastError());
   rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
                   (u8 *)ctx->out.p);
+  ctx->force_learn = false;
   if (rc != LAMD_OK) return rc;
   hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
   HIPCHK(ctx, hipGetLastError());
@@ -2609,18 +2649,43 @@ extern "C" int lamd_bolt12_check_signature_batch(lamd_ctx *ctx, size_t n, const 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+  // check_schnorr_sig serialises the key compressed and drops the parity byte (bitcoin/signature.c:417-422)
+  std::vector<u8> xonly(n * 32);
+  for (size_t i = 0; i < n; i++) memcpy(&xonly[32 * i], key33 + keystride * i + 1, 32);
+  // a few invoices / offers (one per bolt12_check_signature() call, common/bolt12.c:80-92): merkle root and tagged hash on the host --
+  // the kernel's own inline functions (bolt12.h) -- and the rows through the one-launch latency path
+  if (n <= 256 && ctx->small_kernel && ctx->keyed_mode <= 0) {
+    bolt12_mids mids;
+    const u8 leaf[6] = {'L', 'n', 'L', 'e', 'a', 'f'}, branch[8] = {'L', 'n', 'B', 'r', 'a', 'n', 'c', 'h'};
+    bolt12_tag_midstate(leaf, 6, leaf, 0, mids.leaf);
+    bolt12_tag_midstate(branch, 8, branch, 0, mids.branch);
+    const std::string tag2 = std::string(messagename) + fieldname;
+    bolt12_tag_midstate((const u8 *)"lightning", 9, (const u8 *)tag2.data(), tag2.size(), mids.sig);
+    std::vector<u8> msg(32 * n, 0), valid(n);
+    for (size_t i = 0; i < n; i++) {
+      u8 root[32];
+      valid[i] = bolt12_merkle_root(tlvs + off[i], (size_t)(off[i + 1] - off[i]), mids, root);
+      if (valid[i]) bolt12_sighash(mids, root, &msg[32 * i]);
+    }
+    rc = run_small(ctx, MODE_SCHNORR, n, msg.data(), sig64, xonly.data(), 32, 32, ok);
+    if (rc == LAMD_OK) {
+      for (size_t i = 0; i < n; i++)
+        if (!valid[i]) ok[i] = 0;
+      return LAMD_OK;
+    }
+    if (rc != 1) return rc;
+    ctx->force_learn = true;
+  }
   if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->in_c, n * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
-  // check_schnorr_sig serialises the key compressed and drops the parity byte (bitcoin/signature.c:417-422)
-  std::vector<u8> xonly(n * 32);
-  for (size_t i = 0; i < n; i++) memcpy(&xonly[32 * i], key33 + keystride * i + 1, 32);
   if ((rc = bolt12_hash_device(ctx, n, tlvs, off, messagename, fieldname, nullptr, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, xonly.data(), n * 32, hipMemcpyHostToDevice, ctx->stream));
   rc = run_device(ctx, MODE_SCHNORR, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, 32, 32, (u8 *)ctx->out.p);
+  ctx->force_learn = false;
   if (rc != LAMD_OK) return rc;
   hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
   HIPCHK(ctx, hipGetLastError());
