@@ -593,20 +593,39 @@ struct lamd_gossipd {
   int verify(const slotlist &sl) {
     const size_t n = sl.msg.size();
     if (!n) return LAMD_OK;
-    bytes blob, ids(33 * n, 0);
-    std::vector<uint64_t> off(n + 1, 0);
+    std::vector<uint64_t> &off = vf_off;   // (work buffers kept across calls: a fresh 50 MB vector per flood is 12 000 page faults)
+    off.assign(n + 1, 0);
     size_t total = 0;
-    for (size_t i = 0; i < n; i++) { off[i + 1] = off[i] + sl.msg[i].size(); total += sl.msg[i].size(); }
-    blob.resize(total + 1);
-    parallel_for(n, 4096, [&](size_t lo, size_t hi) {
-      for (size_t i = lo; i < hi; i++) {
-        memcpy(&blob[off[i]], sl.msg[i].data(), sl.msg[i].size());
-        if (sl.signer[i]) memcpy(&ids[33 * i], sl.signer[i]->k, 33);
-      }
-    });
+    bool contiguous = true, any_signer = false;
+    for (size_t i = 0; i < n; i++) {
+      off[i + 1] = off[i] + sl.msg[i].size();
+      total += sl.msg[i].size();
+      contiguous &= sl.msg[i].data() == sl.msg[0].data() + off[i];
+      any_signer |= sl.signer[i] != nullptr;
+    }
+    // a flood's slots are its messages in arrival order, back to back in the queue's arena: the back end reads them where they lie
+    const u8 *blob = sl.msg[0].data();
+    if (!contiguous) {
+      vf_blob.resize(total + 1);
+      parallel_for(n, 4096, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) memcpy(&vf_blob[off[i]], sl.msg[i].data(), sl.msg[i].size());
+      });
+      blob = vf_blob.data();
+    }
+    const u8 *ids = nullptr;
+    if (any_signer) {
+      vf_ids.resize(33 * n);
+      parallel_for(n, 8192, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+          if (sl.signer[i]) memcpy(&vf_ids[33 * i], sl.signer[i]->k, 33);
+          else memset(&vf_ids[33 * i], 0, 33);
+        }
+      });
+      ids = vf_ids.data();
+    }
     for (size_t i = 0; i < n; i++) st.verified_sigs += (sl.msg[i][0] == 1 && sl.msg[i][1] == 0) ? 4 : 1;
     std::vector<int8_t> v(n, -2);
-    const int rc = backend_sigcheck(n, blob.data(), off.data(), ids.data(), v.data());
+    const int rc = backend_sigcheck(n, blob, off.data(), ids, v.data());
     if (rc != LAMD_OK) return rc;
     cur_sl = &sl;  // until drop_verdicts(): the caller keeps `sl` alive that long
     cur_v.swap(v);
@@ -614,6 +633,8 @@ struct lamd_gossipd {
     st.verified_messages += n;
     return LAMD_OK;
   }
+  std::vector<uint64_t> vf_off;
+  bytes vf_blob, vf_ids;
 
   bool known_scid(u64 scid) const { return chans.count(scid) || pending_ann.count(scid) || early_ann.count(scid); }
   bool timestamp_reasonable(u32 ts) const {  // gossmap_manage.c:1001-1012
@@ -696,16 +717,16 @@ struct lamd_gossipd {
 
   // ---- process_channel_update (:878-998); returns the error text ("" = none)
   // (`upd` = the message bytes: u.update for an update that waited in a list, the batch's own copy otherwise)
-  std::string process_channel_update(const pending_cupdate &u, const mview &upd, int known_verdict = INT32_MIN) {
+  std::string process_channel_update(const pending_cupdate &u, const mview &upd, int known_verdict = INT32_MIN, chan *known_chan = nullptr) {
     const int dir = u.cflags & 1;
-    auto it = chans.find(u.scid);
-    if (it == chans.end()) {
+    auto it = known_chan ? chans.end() : chans.find(u.scid);
+    if (!known_chan && it == chans.end()) {
       if (txout_failures.count(u.scid)) return "";  // :901-905
       ev_scid(LAMD_GEV_QUERY_CHANNEL, u.has_src, &u.src, u.scid);
       if (on_event) bad_gossip(u.has_src, &u.src, "Unknown channel " + fmt_scid(u.scid));
       return "";
     }
-    chan &c = it->second;
+    chan &c = known_chan ? *known_chan : it->second;
     const int v = known_verdict != INT32_MIN ? known_verdict : verdict_of(upd, &c.node[dir]);  // :920-926
     if (v == -2) return "";  // engine fault (fault_rc): the caller keeps the update
     if (v != 0) return sigcheck_text(GOSSIP_CUPD, 1, upd);
@@ -756,8 +777,8 @@ struct lamd_gossipd {
       if (memcmp(&m[66], cfg.chain_hash, 32) != 0) return;                       // :1054-1057
       pending_cupdate u = parse_cupdate(q);
       if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
-      if (pending_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
-      if (early_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
+      if (!pending_ann.empty() && pending_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
+      if (!early_ann.empty() && early_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
       auto itc = chans.find(u.scid);
       if (itc == chans.end() && q.has_src) {                                               // :1107-1116
         const int pv = (p.slot >= 0 && p.signer == &q.src) ? cur_v[p.slot] : verdict_of(m, &q.src);
@@ -770,7 +791,7 @@ struct lamd_gossipd {
       {  // the plan's verdict stands if the signer it expected is the one process_channel_update() will ask for
         int known = INT32_MIN;
         if (p.slot >= 0 && p.signer && itc != chans.end() && *p.signer == itc->second.node[u.cflags & 1]) known = cur_v[p.slot];
-        err = process_channel_update(u, m, known);
+        err = process_channel_update(u, m, known, itc != chans.end() ? &itc->second : nullptr);
       }
     } while (0);
     if (!err.empty()) warning(q.has_src, &q.src, err);
