@@ -322,6 +322,9 @@ struct planned {
   u64 h;                  // vkey(message, signer).h
   u8 spk[32];             // channel_announcement: SHA256 of the 2-of-2 script (the P2WSH program)
   bool spk_set;
+  chan *pc;               // channel_update: the channel the plan found (nullptr: none).  chans gains and loses no entry while a batch is applied
+                          // (channels appear in txout_reply, disappear in new_block / prune: none of them runs inside process()), so the
+                          // pointer is what a lookup during the apply pass would return
 };
 
 }  // namespace
@@ -779,8 +782,10 @@ struct lamd_gossipd {
       if (!timestamp_reasonable(u.timestamp)) return;                            // :1060-1063
       if (!pending_ann.empty() && pending_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); pending_cupdates.push_back(std::move(u)); return; }  // :1066-1083
       if (!early_ann.empty() && early_ann.count(u.scid)) { u.update.assign(m.begin(), m.end()); early_cupdates.push_back(std::move(u)); return; }      // :1086-1103
-      auto itc = chans.find(u.scid);
-      if (itc == chans.end() && q.has_src) {                                               // :1107-1116
+      // (the plan looked the channel up when the message passed its filters; a message the plan dropped early is looked up here)
+      chan *pc = p.want_slot || p.pc ? p.pc : nullptr;
+      if (!pc && !p.want_slot) { auto itc = chans.find(u.scid); if (itc != chans.end()) pc = &itc->second; }
+      if (!pc && q.has_src) {                                               // :1107-1116
         const int pv = (p.slot >= 0 && p.signer == &q.src) ? cur_v[p.slot] : verdict_of(m, &q.src);
         if (pv == -2) return;
         if (pv == 0) {
@@ -790,8 +795,8 @@ struct lamd_gossipd {
       }
       {  // the plan's verdict stands if the signer it expected is the one process_channel_update() will ask for
         int known = INT32_MIN;
-        if (p.slot >= 0 && p.signer && itc != chans.end() && *p.signer == itc->second.node[u.cflags & 1]) known = cur_v[p.slot];
-        err = process_channel_update(u, m, known, itc != chans.end() ? &itc->second : nullptr);
+        if (p.slot >= 0 && p.signer && pc && *p.signer == pc->node[u.cflags & 1]) known = cur_v[p.slot];
+        err = process_channel_update(u, m, known, pc);
       }
     } while (0);
     if (!err.empty()) warning(q.has_src, &q.src, err);
@@ -1187,6 +1192,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
       p.scid = 0;
       p.want_slot = p.want_keys = p.spk_set = false;
       p.signer = nullptr;
+      p.pc = nullptr;
       p.h = 0;
       if (f.type == GOSSIP_CANN) {
         if (!p.malformed)
@@ -1216,7 +1222,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
         p.scid = be64(&m[98]);
         if (memcmp(&m[66], g->cfg.chain_hash, 32) != 0 || !g->timestamp_reasonable(be32(&m[106]))) continue;
         auto it = g->chans.find(p.scid);
-        if (it != g->chans.end()) { p.want_slot = true; p.signer = &it->second.node[m[111] & 1]; }
+        if (it != g->chans.end()) { p.want_slot = true; p.pc = &it->second; p.signer = &it->second.node[m[111] & 1]; }
         else if (q.has_src) { p.want_slot = true; p.signer = &q.src; }  // the private-update probe of :1107-1109 (unused if the channel turns out to be pending)
       } else if (f.type == GOSSIP_NANN) {
         if (!p.malformed) p.malformed = !sig_in_range(&m[2]);
@@ -1265,7 +1271,25 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   // _new_block (those return LAMD_ERR_STATE while in_process is set -- answer LAMD_GEV_GET_TXOUT after process() returns; _push is fine).
   g->in_process = true;
   g->fault_rc = LAMD_OK;
+  // (every message of the batch may become a store record: grow the image and the record list once, not by doubling through the pass)
+  if (g->image.capacity() < g->image.size() + arena.size() + 12 * n) g->image.reserve(g->image.size() + arena.size() + 12 * n + (g->image.size() >> 2));
+  if (g->store.capacity() < g->store.size() + n) g->store.reserve(g->store.size() + n + (g->store.size() >> 2));
   for (size_t i = 0; i < n; i++) {
+    // the apply pass is a chain of cache misses (channel -> its store records -> their bytes in the image): fetch ahead what the plan
+    // already knows a channel_update will touch
+    if (i + 16 < n && plan[i + 16].pc) __builtin_prefetch(plan[i + 16].pc);
+    if (i + 8 < n && plan[i + 8].pc) {
+      const chan *c = plan[i + 8].pc;
+      const int dir = batch[i + 8].msg[111] & 1;
+      if (c->set[dir]) { __builtin_prefetch(&g->store[c->cupd_rec[dir]]); }
+      else if (!c->set[!dir]) { __builtin_prefetch(&g->store[c->cann_rec]); }
+    }
+    if (i + 4 < n && plan[i + 4].pc) {
+      const chan *c = plan[i + 4].pc;
+      const int dir = batch[i + 4].msg[111] & 1;
+      if (c->set[dir]) __builtin_prefetch(g->image.data() + g->store[c->cupd_rec[dir]].off - 12);
+      else if (!c->set[!dir]) { const u8 *h = g->image.data() + g->store[c->cann_rec].off - 12; __builtin_prefetch(h); __builtin_prefetch(h + 64); __builtin_prefetch(h + 448 - 64); }
+    }
     const queued &q = batch[i];
     const planned &p = plan[i];
     if (p.type == GOSSIP_CANN) g->apply_cann(q, p, p.keyslot >= 0 ? (keyok[2 * p.keyslot] && keyok[2 * p.keyslot + 1]) : 1);
