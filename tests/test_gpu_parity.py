@@ -1128,6 +1128,58 @@ def test_single_calls_learn_a_recurring_key(orc):
 
 
 @pytest.mark.gpu
+def test_one_launch_path_block_boundaries_and_mixed_shapes(orc):
+    """calls of 1 .. 4096 rows are ONE launch (k_small_verify as a grid of 64-row blocks), 4097 rows take the general path: sizes around the
+    block and path boundaries, every wave holding rows under 7-tooth keys, 10-tooth keys, keys without a table, keys that do not parse and
+    damaged signatures side by side (the run-time comb body for mixed waves); ECDSA (33- and 65-byte keys) and BIP-340; every verdict
+    against the C oracle"""
+    from lightning_amd import Engine, workload
+    with Engine(0) as e:
+        for publen in (33, 65):
+            a = workload.make_ecdsa(e, 30000, seed=5101 + publen, nkeys=2000, publen=publen)          # 15 rows per key: 7-tooth combs
+            b = workload.make_ecdsa(e, 30000, seed=5102 + publen, nkeys=100, publen=publen)           # 300 rows per key: 10-tooth combs
+            c = workload.make_ecdsa(e, 20000, seed=5103 + publen, nkeys=1 << 40, publen=publen, group=1)  # every row its own key (never met twice here): ladder
+            for w in (a, b):
+                for _ in range(2):                                                                    # second call: the host has seen the tables published
+                    e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+                    e.synchronize()
+                assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect)
+            rng = np.random.default_rng(77 + publen)
+            o = 0
+            for n in (1, 63, 64, 65, 127, 128, 129, 1000, 4095, 4096, 4097):
+                src = rng.integers(0, 3, n)
+                src[rng.integers(0, n)] = 2 if n < 4000 else 0                 # (at most a handful of ladder rows in the big calls: they are 0.9 ms each wave)
+                if n >= 4000:
+                    src[src == 2] = rng.integers(0, 2, int((src == 2).sum()))
+                    src[:3] = 2
+                idx = [rng.integers(0, 30000, n), rng.integers(0, 30000, n), (o + np.arange(n)) % 20000]
+                o += n
+                cols = [np.ascontiguousarray(np.where((src == 0)[:, None], a.cols[k][idx[0]], np.where((src == 1)[:, None], b.cols[k][idx[1]], c.cols[k][idx[2]]))) for k in range(3)]
+                exp = np.where(src == 0, a.expect[idx[0]], np.where(src == 1, b.expect[idx[1]], c.expect[idx[2]]))
+                got = e.verify_ecdsa(*cols)
+                assert np.array_equal(got, exp), (publen, n)
+                assert np.array_equal(got, orc.ecdsa_verify_batch(cols[0], cols[1], cols[2], publen, 4).astype(bool)), (publen, n)
+                inf = e.info()
+                if n <= 4096:
+                    assert inf["last_cache_hits"] + inf["last_cold_rows"] == n, (n, inf)              # every row accounted for by the one launch
+        s7 = workload.make_schnorr(e, 30000, seed=5201, nkeys=2000)
+        s10 = workload.make_schnorr(e, 30000, seed=5202, nkeys=100)
+        for w in (s7, s10):
+            for _ in range(2):
+                e.verify_schnorr_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+                e.synchronize()
+        rng = np.random.default_rng(99)
+        for n in (1, 64, 65, 500, 4096):
+            src = rng.integers(0, 2, n)
+            idx = rng.integers(0, 30000, n)
+            cols = [np.ascontiguousarray(np.where((src == 0)[:, None], s7.cols[k][idx], s10.cols[k][idx])) for k in range(3)]
+            exp = np.where(src == 0, s7.expect[idx], s10.expect[idx])
+            got = e.verify_schnorr(*cols)
+            assert np.array_equal(got, exp), n
+            assert np.array_equal(got, orc.schnorr_verify_batch(cols[0], cols[1], cols[2], 4).astype(bool)), n
+
+
+@pytest.mark.gpu
 def test_small_batches_with_a_cache_take_the_lookup_path(kat, orc):
     """small batches on an engine with the key-table cache: ONE kernel probes the cache and runs the cached comb or, on a miss, the
     ladder (k_ecmult_small).  Hits, misses, unparsable keys and damaged signatures in one batch; a commitment-shaped batch under a
