@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Lane timeline of the timed loops from a rocprofv3 kernel trace (CSV, optionally .gz) of
-`bench.py --steps K --warmup W --cpu-sample 0 --skip-extra`: for each loop (warm engine first, then cold, then cold with the large ecmult
-launches chained) the window between its first and last 1 M-row table-driven ecmult launch, how busy each kernel class was inside it and
+`bench.py --steps K --warmup W --cpu-sample 0 --skip-extra`: for each loop (cold, cold with the large ecmult launches
+chained, then the warm engine's) the window between its first and last 1 M-row table-driven ecmult launch, how busy each kernel class was inside it and
 how the launches overlap.
 usage: lane_timeline.py trace.csv[.gz] [steps] [warmup]"""
 import collections
@@ -33,15 +33,17 @@ def cls(name):
 
 
 big = [r for r in rows if short(r["Kernel_Name"]).startswith("k_ecmult_keyed<false") and int(r["Grid_Size_X"]) >= 500000]
-# launch order of bench.py: warm loop (W warm-up + K timed steps, two launches per step), cold loop (same), cold loop with chained
-# launches (same), then 2 x 2 isolated calls
+# launch order of bench.py: cold loop (W warm-up + K timed steps, two launches per step), cold loop with chained launches (same), 2 x 2
+# isolated calls, then -- on the default engine, created only now -- the warm loop
 K, W = steps, warmup
 per = 2 * W + 2 * K
-legs = [big[2 * W:per], big[per + 2 * W:2 * per], big[2 * per + 2 * W:3 * per]]
-iso = big[3 * per:3 * per + 4]
+legs = [big[2 * W:per], big[per + 2 * W:2 * per], big[2 * per + 4 + 2 * W:3 * per + 4]]
+iso = big[2 * per:2 * per + 4]
 print("isolated calls (one at a time): %s ms" % ", ".join("%.3f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in iso))
-for name, leg in zip(("warm loop (key-table cache on)", "cold loop (tables rebuilt every call: `value`)",
-                      "cold loop, large ecmult launches chained (lamd_set_ecmult_chain(1): roofline.chained)"), legs):
+for name, leg in zip(("cold loop (tables rebuilt every call: `value`)", "cold loop, large ecmult launches chained (lamd_set_ecmult_chain(1): roofline.chained)",
+                      "warm loop (key-table cache on)"), legs):
+    if not leg:
+        continue
     t0, t1 = int(leg[0]["Start_Timestamp"]), int(leg[-1]["End_Timestamp"])
     span = (t1 - t0) / 1e6
     print("== %s: %d launches, window %.2f ms (%.2f ms per 2-launch step)" % (name, len(leg), span, span / (len(leg) / 2)))
