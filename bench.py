@@ -116,7 +116,7 @@ def sharded_configs(eng, rank, world, device, tstream):
                         eng.queue_schnorr_batch(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
                     eng.flush()
                     pend.append((o, e))
-                    if len(pend) == 3:
+                    if len(pend) == min(8, eng.info()["queue_sets"] - 1):
                         collect()
                 while pend:
                     collect()
@@ -644,9 +644,10 @@ def main():
             extra["cfg5_commit_storm_superbatch"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[-2:]), "mismatches": sm,
                                                      "keyed_comb_teeth": eng.info()["last_keyed"]}
             # the same storm as STREAMING batches from host memory: commitments (484 signatures each) are appended to the pinned
-            # staging queue, every 256 commitments are flushed as one batch, three flushes stay in flight while the next staging
+            # staging queue, every 256 commitments are flushed as one batch, up to eight flushes stay in flight while the next staging
             # set is being filled (lamd_queue_*_batch / lamd_flush / lamd_wait) -- H2D, verification and D2H all inside the clock
             streaming = {}
+            c5_depth = min(8, eng.info()["queue_sets"] - 1)
             for cpf in (256, 1024):
                 per, grp = st["per"], cpf * st["per"]
                 ts, sbad = [], 0
@@ -666,7 +667,7 @@ def main():
                             eng.queue_schnorr_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
                         eng.flush()
                         pend.append((wl, a, b))
-                        if len(pend) == 3:
+                        if len(pend) == c5_depth:
                             wl0, a0, b0 = pend.pop(0)
                             sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
                     while pend:
@@ -675,7 +676,7 @@ def main():
                     ts.append(time.perf_counter() - t1)
                 streaming["%d_commitments_per_flush" % cpf] = {"verifies_per_s": nv / min(ts[1:]), "signatures_per_flush": grp, "mismatches": sbad}
                 mism += sbad
-            extra["cfg5_commit_storm_streaming"] = dict(streaming, channels=10_000, verifies=nv, flushes_in_flight=3,
+            extra["cfg5_commit_storm_streaming"] = dict(streaming, channels=10_000, verifies=nv, flushes_in_flight=c5_depth,
                                                         note="inputs in host memory: staging memcpy + H2D + verification + D2H inside the clock")
             del st
             # ---- N2: the same kind of flood through the batched gossip INGEST (lightning_amd/csrc/gossip_ingest.cpp: gossipd's receive
