@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
     A.out[row] = ok ? 1 : 0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && A.flag) {  // (a flush of the streaming queue has no completion word: its caller waits for the stream's event)
     __threadfence_system();  // this block's verdict and shape bytes are on their way to host memory before it counts itself done
     const bool last = gridDim.x == 1u || __hip_atomic_fetch_add(A.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
     if (last) {
@@ -1209,6 +1209,7 @@ struct lamd_ctx {
     std::vector<span> tickets;  // rows [row0, row0 + count) of this queue return as verdicts [ticket0, ...) of the staging set
     devbuf d_a, d_b, d_c, d_ok;
     hipEvent_t ev_keys = nullptr, ev_sigs = nullptr, ev_all = nullptr;  // behind the three H2D copies of a flush on the copy stream
+    bool small_flush = false;   // this flush ran as ONE k_small_verify launch over the staging rows themselves (h_ok + cap: the rows' shapes)
   };
   struct queue_set {
     queue q[Q_KINDS];
@@ -1867,10 +1868,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     const u32 dense_thr = ctx->last_small_n / 8 > 32 ? (u32)(ctx->last_small_n / 8) : 32u;
     const bool learn = ctx->force_learn || (ctx->last_small_fused && ctx->h_plan && ((volatile const u32 *)ctx->h_plan)[P_DENSE] >= dense_thr);
     latency_learn = ctx->force_learn;
-    if (ctx->force_learn) {
-      ctx->force_learn = false;
-      std::fill(ctx->small_missed.begin(), ctx->small_missed.end(), 0);  // their keys have tables after this call
-    }
+    ctx->force_learn = false;  // (whoever set it has already forgotten the fingerprints of this call's keys: they have tables after it)
     ctx->last_small_fused = !learn;
     ctx->last_small_n = n;
     if (!learn) {
@@ -2243,6 +2241,16 @@ static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen) {
   }
   return h | 1;
 }
+// the learning call builds a table for EVERY key of its batch the cache misses: forget exactly those fingerprints (other callers' keys that
+// are still waiting for their second sight keep theirs)
+static void small_forget(lamd_ctx *ctx, const u8 *key, size_t keystride, int keylen, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    if (i && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0) continue;
+    const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
+    u64 &slot = ctx->small_missed[(fp >> 1) % MISS_SLOTS];
+    if (slot == fp) slot = 0;
+  }
+}
 static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok) {
   int rc;
   if (!ctx->h_small) {
@@ -2258,10 +2266,15 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   const bool have_cache = ctx->cache_mode != 0 && ctx->cache_store.shared;
   if (have_cache) {
     if (ctx->small_missed.empty()) ctx->small_missed.assign(MISS_SLOTS, 0);
-    for (size_t i = 0; i < n; i++) {
+    bool learn = false;
+    for (size_t i = 0; i < n && !learn; i++) {
       if (i && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0) continue;  // a commitment's rows share their key
       const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
-      if (ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp) return 1;  // seen before without a table: the caller takes the learning path
+      learn = ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp;  // seen before without a table: the caller takes the learning path
+    }
+    if (learn) {
+      small_forget(ctx, key, keystride, keylen, n);
+      return 1;
     }
   }
   memcpy(h, a, n * 32);
@@ -2957,7 +2970,7 @@ static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, siz
     hipError_t e = hipHostMalloc((void **)&na, ncap * 32, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&nb, ncap * 64, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&nc, ncap * keybytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&nk, ncap, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&nk, 2 * ncap, hipHostMallocDefault);  // verdicts | row shapes of a small flush
     if (e != hipSuccess) {
       for (u8 *h : {na, nb, nc, nk})
         if (h) (void)hipHostFree(h);
@@ -3087,6 +3100,50 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     lamd_ctx::queue &q = qs.q[kind];
     if (!q.n) continue;
     const size_t kb = Q_KEYBYTES[kind];
+    q.small_flush = false;
+    // A small flush (one commitment_signed, a handful of gossip messages) is ONE launch of the latency kernel over the pinned staging
+    // rows themselves: no H2D copies, no front end, the verdict bytes written straight into the set's pinned verdict block; the caller's
+    // poll / wait sees it through the flush's event as ever.  A key that was met without a table before sends the flush down the
+    // general path once (that call builds and publishes the table).
+    if (q.n <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0 && ctx->cache_mode != 0 && ctx->cache_store.shared) {
+      if (ctx->small_missed.empty()) ctx->small_missed.assign(MISS_SLOTS, 0);
+      bool learn = false;
+      for (size_t i = 0; i < q.n && !learn; i++) {
+        if (i && memcmp(q.h_c + i * kb, q.h_c + (i - 1) * kb, kb) == 0) continue;
+        const u64 fp = small_fingerprint(ctx->hash_seed, q.h_c + i * kb, (int)kb);
+        learn = ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp;
+      }
+      if (learn) {
+        L->force_learn = true;
+        small_forget(ctx, q.h_c, kb, (int)kb, q.n);
+      } else {
+        if ((rc = ensure(L, &L->slots, ((q.n + 63) & ~(size_t)63) * SLOT_WORDS * 4)) != LAMD_OK) { ctx->err = L->err; return rc; }
+        small_args A;
+        memset(&A, 0, sizeof A);
+        A.a32 = q.h_a; A.sig64 = q.h_b; A.key = q.h_c;
+        A.keylen = (int)kb; A.mode = kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA; A.n = (u32)q.n;
+        A.seed = ctx->hash_seed;
+        lamd_ctx::key_cache *kc = &ctx->cache_store;
+        for (int l = 0; l <= MAX_LANES; l++)
+          if (ctx->pub_pending[l] && hipEventQuery(ctx->ev_pub[l]) == hipSuccess) {
+            ctx->vis_seq[l] = ctx->pub_seq[l];
+            ctx->pub_pending[l] = false;
+          }
+        (void)hipGetLastError();
+        for (int l = 0; l <= MAX_LANES; l++) A.vis.seq[l] = ctx->vis_seq[l];
+        A.vis.seq[L->lane_id] = ctx->pub_seq[L->lane_id];
+        A.index = (const u32 *)kc->index.p; A.mask = kc->index_mask; A.ents = (const cache_ent *)kc->ents.p;
+        A.pool7 = (const u32 *)kc->pool7.p; A.pool10 = (const u32 *)kc->pool10.p;
+        A.gtable = (const u32 *)ctx->gtable;
+        A.slots = (u32 *)L->slots.p;
+        A.out = q.h_ok;
+        A.shapes = q.h_ok + q.cap;
+        hipLaunchKernelGGL(k_small_verify, dim3((unsigned)((q.n + 63) / 64)), dim3(512), 0, L->stream, A);
+        HIPCHK(ctx, hipGetLastError());
+        q.small_flush = true;
+        continue;
+      }
+    }
     if ((rc = ensure(ctx, &q.d_a, q.n * 32)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_b, q.n * 64)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_c, q.n * kb + 16)) != LAMD_OK) return rc;
@@ -3135,6 +3192,7 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     }
     rc = run_device(L, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
                     (const u8 *)q.d_c.p, (int)kb, kb, (u8 *)q.d_ok.p);
+    L->force_learn = false;
     if (rc != LAMD_OK) {
       if (L != ctx) ctx->err = L->err;
       return rc;
@@ -3162,8 +3220,19 @@ static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
     ctx->err = "result buffer too small";
     return LAMD_ERR_ARG;
   }
-  for (auto &q : qs.q) {
+  for (int kind = 0; kind < Q_KINDS; kind++) {
+    lamd_ctx::queue &q = qs.q[kind];
     for (const auto &sp : q.tickets) memcpy(ok + sp.ticket0, q.h_ok + sp.row0, sp.count);
+    if (q.small_flush && !ctx->small_missed.empty()) {  // remember the keys the latency kernel had to take down the ladder (run_small does the same)
+      const size_t kb = Q_KEYBYTES[kind];
+      const u8 *shapes = q.h_ok + q.cap;
+      for (size_t i = 0; i < q.n; i++)
+        if (shapes[i] == 255 && !(i && shapes[i - 1] == 255 && memcmp(q.h_c + i * kb, q.h_c + (i - 1) * kb, kb) == 0)) {
+          const u64 fp = small_fingerprint(ctx->hash_seed, q.h_c + i * kb, (int)kb);
+          ctx->small_missed[(fp >> 1) % MISS_SLOTS] = fp;
+        }
+    }
+    q.small_flush = false;
     q.tickets.clear();
     q.n = 0;
   }
