@@ -219,7 +219,8 @@ int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msg
  * next set, so queueing continues while flushes are in flight: up to 9 flushes may be outstanding (LAMD_ERR_STATE beyond
  * that, until one is collected), successive flushes run on alternating lanes.  A flush's three host-to-device copies go down
  * a copy stream of their own in flush order, so with more flushes outstanding than lanes (4) the rows of the next flush are
- * already in HBM when its lane comes free.  poll/wait return the verdicts of the
+ * already in HBM when its lane comes free.  A flush of <= 4096 rows (one commitment_signed) is ONE launch of the latency kernel over the
+ * pinned staging rows themselves -- no copies at all; its verdicts arrive through lamd_poll / lamd_wait like any other flush's.  poll/wait return the verdicts of the
  * OLDEST outstanding flush, in submission (ticket) order. */
 /* A ticket is the position of the triple's verdict in the vector its flush returns: tickets count 0, 1, 2, ... across
  * the kinds inside the open staging set and restart at 0 after every lamd_flush() (fewer than 2^30 triples per flush). */
