@@ -916,7 +916,8 @@ __global__ void __launch_bounds__(64) k_small_lookup(size_t n, const u8 *__restr
     if (keyok_row) keyok_row[i] = 0;
   }
 }
-// ---- the latency path: n <= 64 rows in ONE launch, inputs read straight from pinned host memory, verdicts written straight back.
+// ---- the latency path: up to SMALL_MAX rows in ONE launch (a grid of 64-row blocks), inputs read straight from pinned host memory, verdicts
+// written straight back (host-buffer calls: run_small; small flushes of the streaming queue: lamd_flush).
 // One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of eight waves, two per SIMD of a CU.
 //   phase A   wave 0: scalar preparation of its row (one division-step inversion per lane)
 //             wave 1: the row's key -- probe the key-table cache (comb shape + table), or parse it and build the 8-entry ladder table

@@ -891,7 +891,7 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
 }
 
 // ================================================================================================
-// Task split (latency path, n <= 64 rows: k_small_verify).  One row per LANE and one TASK per WAVE: a lone signature on one
+// Task split (latency path: k_small_verify, 64 rows per block).  One row per LANE and one TASK per WAVE: a lone signature on one
 // lane is a chain of ~10^5 dependent instructions, and a wave issues one instruction every ~4.3 cycles however few lanes are
 // live -- so the verification is cut into independent partial sums that different waves (different SIMDs) compute at the same
 // time, and one wave merges them with complete Jacobian additions:
