@@ -692,6 +692,43 @@ def main():
             out["recover"].append(dict(name="KAT-B11R/line%d/other-parity" % lineno, hash=h.hex(), sig=sig65[:64].hex(), recid=sig65[64] ^ 1,
                                        expect=R.ser33(other).hex() if other else None, source="derived: same signature, other recovery id"))
         assert len(out["recover"]) >= 10
+        # ---- KAT-SIGNMSG: the checkmessage path (lightningd/signmessage.c:148-198): zbase32 -> 65 bytes, byte 0 - 31 = recovery id,
+        # hash = SHA256d("Lightning Signed Message:" || message), secp256k1_ecdsa_recover == the claimed key.  tests/test_misc.py holds four
+        # literal (message, zbase, pubkey) triples -- three "contributions from LND users" (signed by another implementation's library) and
+        # one of the reference's own -- and asserts exactly this outcome for each (:2604-2613, :4270-4272).
+        zsrc = os.path.join(ref, "tests", "test_misc.py")
+        zchars = "ybndrfg8ejkmcpqxot1uwisza345h769"
+        ztxt = open(zsrc, encoding="utf-8").read()
+        trip = [(m.start(), m.group(1), m.group(2), m.group(3)) for m in
+                re.finditer(r"""\[\s*'@\w+',\s*["']([^"']+)["'],\s*'([%s]{104})',\s*'(0[23][0-9a-f]{64})'\]""" % zchars, ztxt)]
+        m2 = re.search(r'msg = "([^"]+)"\s*\n\s*pubkey = "(0[23][0-9a-f]{64})"\s*\n\s*zbase = "([%s]{104})"' % zchars, ztxt)
+        if m2:
+            trip.append((m2.start(), m2.group(1), m2.group(3), m2.group(2)))
+        assert len(trip) >= 4, len(trip)
+        for pos, msg, zb, pub in trip:
+            lineno = ztxt.count("\n", 0, pos) + 1
+            acc = bits = 0
+            raw = bytearray()
+            for c in zb:
+                acc = (acc << 5) | zchars.index(c)
+                bits += 5
+                while bits >= 8:
+                    bits -= 8
+                    raw.append((acc >> bits) & 0xFF)
+            assert len(raw) == 65 and 31 <= raw[0] <= 34, (lineno, len(raw), raw[0])
+            hh = R.sha256(R.sha256(b"Lightning Signed Message:" + msg.encode()))
+            recid, sig = raw[0] - 31, bytes(raw[1:])
+            rec = R.ecdsa_recover(hh, sig, recid)
+            assert rec is not None and R.ser33(rec).hex() == pub, (lineno, msg)      # what the reference's test asserts
+            out["recover"].append(dict(name="KAT-SIGNMSG/line%d" % lineno, hash=hh.hex(), sig=sig.hex(), recid=recid, expect=pub,
+                                       source="tests/test_misc.py:%d (checkmessage %r)" % (lineno, msg)))
+            hm = R.sha256(R.sha256(b"Lightning Signed Message:" + (msg + "modified").encode()))   # :2614: the modified message does not verify
+            rm = R.ecdsa_recover(hm, sig, recid)
+            assert rm is None or R.ser33(rm).hex() != pub
+            out["recover"].append(dict(name="KAT-SIGNMSG/line%d/modified" % lineno, hash=hm.hex(), sig=sig.hex(), recid=recid,
+                                       expect=R.ser33(rm).hex() if rm else None, source="derived: tests/test_misc.py:%d with the message modified (another key or none)" % lineno))
+            # the same triple as a plain verification under the claimed key (low-S rule of secp256k1_ecdsa_verify applies: expect from the model)
+            out["ecdsa"].append(ecdsa_row("KAT-SIGNMSG/line%d/verify" % lineno, hh, sig, bytes.fromhex(pub), "tests/test_misc.py:%d as (hash, r||s, key)" % lineno))
     else:
         # outside this container keep the committed vectors
         out["recover"] = json.load(open(os.path.join(HERE, "kat.json")))["recover"]
