@@ -729,9 +729,95 @@ def main():
                                        expect=R.ser33(rm).hex() if rm else None, source="derived: tests/test_misc.py:%d with the message modified (another key or none)" % lineno))
             # the same triple as a plain verification under the claimed key (low-S rule of secp256k1_ecdsa_verify applies: expect from the model)
             out["ecdsa"].append(ecdsa_row("KAT-SIGNMSG/line%d/verify" % lineno, hh, sig, bytes.fromhex(pub), "tests/test_misc.py:%d as (hash, r||s, key)" % lineno))
+        # ---- KAT-BOLT3: check_tx_sig on the signed HTLC transactions of BOLT #3 appendix C that channeld/test/run-full_channel.c holds as
+        # raw hex (tx_from_hex(...): the test rebuilds each one -- signatures included -- with the reference's own signer and demands equality).
+        # Witness = 0 <remotehtlcsig> <localhtlcsig> [<preimage>] <wscript>; the two keys stand in the script (remote_htlcpubkey after
+        # OP_CHECKSIG OP_ELSE, local_htlcpubkey after OP_SWAP); BIP143 needs the spent output's amount, which at this vector's feerate (0) is
+        # the transaction's own output amount -- the signatures verifying under that amount is the proof.
+        out["txsig"] = []
+        fsrc = os.path.join(ref, "channeld", "test", "run-full_channel.c")
+
+        def parse_segwit_tx(raw):
+            o = [0]
+
+            def take(n):
+                b = raw[o[0]:o[0] + n]
+                o[0] += n
+                return b
+
+            def cs():
+                v = take(1)[0]
+                return v if v < 0xfd else int.from_bytes(take(2 if v == 0xfd else 4), "little")
+            version = int.from_bytes(take(4), "little")
+            assert take(2) == b"\x00\x01"
+            ins = []
+            for _ in range(cs()):
+                txid, vout = take(32), int.from_bytes(take(4), "little")
+                assert cs() == 0
+                ins.append((txid, vout, int.from_bytes(take(4), "little")))
+            outs = []
+            for _ in range(cs()):
+                amt = int.from_bytes(take(8), "little")
+                outs.append((amt, take(cs())))
+            wit = [[take(cs()) for _ in range(cs())] for _ in ins]
+            lock = int.from_bytes(take(4), "little")
+            assert o[0] == len(raw)
+            return version, ins, outs, wit, lock
+        seen_tx = set()
+        for lineno, line in enumerate(open(fsrc, encoding="utf-8", errors="replace"), 1):
+            m = re.search(r'tx_from_hex\(tmpctx, "(02000000000101[0-9a-f]+)"\)', line)
+            if not m or m.group(1) in seen_tx:
+                continue
+            seen_tx.add(m.group(1))
+            version, ins, outs, wit, lock = parse_segwit_tx(bytes.fromhex(m.group(1)))
+            if len(ins) != 1 or len(wit[0]) < 4 or wit[0][0] != b"":
+                continue
+            ws = wit[0][-1]
+            k = ws.find(bytes.fromhex("ac6721"))
+            k2 = ws.find(bytes.fromhex("7c21"), k + 36)
+            assert k > 0 and k2 > 0, lineno
+            keys = [ws[k + 3:k + 36], ws[k2 + 2:k2 + 35]]                    # remote_htlcpubkey, local_htlcpubkey
+            for which, (der, key) in enumerate(zip(wit[0][1:3], keys)):
+                (r_, s_), sht = R.signature_from_der(der)
+                sig = r_.to_bytes(32, "big") + s_.to_bytes(32, "big")
+                for tag, amount, want in (("", outs[0][0], True), ("/amount+1", outs[0][0] + 1, False)):
+                    hh = R.bip143_sighash(version, ins, outs, lock, 0, ws, amount, sht)[0]
+                    got = R.ecdsa_verify(hh, sig, key)
+                    assert got == want, (lineno, which, tag)
+                    out["txsig"].append(dict(name="KAT-BOLT3/line%d/%s%s" % (lineno, ("remote", "local")[which], tag), version=version, locktime=lock,
+                                             inputs=[[t.hex(), v, q] for t, v, q in ins], outputs=[[a, spk.hex()] for a, spk in outs], input_num=0,
+                                             amount=amount, script=ws.hex(), sighash_type=sht, has_witness=True, sig=sig.hex(), pub=key.hex(), sighash=hh.hex(),
+                                             expect=got, source="channeld/test/run-full_channel.c:%d (BOLT #3 appendix C HTLC transaction, %s signature)%s"
+                                             % (lineno, ("remote_htlc", "local_htlc")[which], " with the spent amount off by one" if tag else "")))
+        assert sum(1 for v in out["txsig"] if v["expect"]) >= 10, len(out["txsig"])
+        # ---- KAT-O2: onchaind/test/run-grind_feerate-bug.c -- one remote HTLC signature, three candidate HTLCs (two cltvs), feerates
+        # 10992..15370: the reference asserts that the THIRD candidate (cltv 586034) is the one whose htlc_timeout_tx the signature fits
+        # (`assert(ret == 2)`, :375).  Transaction as the test's own comment prints it (:3).
+        bsrc = os.path.join(ref, "onchaind", "test", "run-grind_feerate-bug.c")
+        btxt = open(bsrc, encoding="utf-8", errors="replace").read()
+        mb = re.search(r"last tx (0200000001[0-9a-f]+), input (\d+)sat, signature (30[0-9a-f]+01), cltvs (\d+)/(\d+)/(\d+) wscripts ([0-9a-f]+)/", btxt)
+        mk = re.search(r'pubkey_from_hexstr\("(0[23][0-9a-f]{64})"', btxt)
+        assert mb and mk
+        rawb = bytes.fromhex(mb.group(1))
+        assert rawb[4] == 1 and rawb[41] == 0 and rawb[46] == 1                      # one input, empty scriptSig, one output
+        txid_b, vout_b, seq_b = rawb[5:37], int.from_bytes(rawb[37:41], "little"), int.from_bytes(rawb[42:46], "little")
+        spk_b = rawb[56:56 + rawb[55]]
+        in_sat, wsb, keyb = int(mb.group(2)), bytes.fromhex(mb.group(7)), bytes.fromhex(mk.group(1))
+        (rb, sb_), shtb = R.signature_from_der(bytes.fromhex(mb.group(3)))
+        sigb = rb.to_bytes(32, "big") + sb_.to_bytes(32, "big")
+        out["grind"] = []
+        for cltv in sorted({int(mb.group(4)), int(mb.group(5)), int(mb.group(6))}):
+            pre0 = R.bip143_sighash(2, [(txid_b, vout_b, seq_b)], [(in_sat, spk_b)], cltv, 0, wsb, in_sat, shtb)[1]
+            outs0 = in_sat.to_bytes(8, "little") + bytes([len(spk_b)]) + spk_b
+            res = R.grind_htlc_tx_fee(pre0, outs0, in_sat, 663, 10992, 15370, sigb, shtb, True, keyb)
+            out["grind"].append(dict(name="KAT-O2/cltv=%d" % cltv, preimage=pre0.hex(), outputs=outs0.hex(), input_sat=in_sat, weight=663, min_feerate=10992,
+                                     max_feerate=15370, sig=sigb.hex(), sighash_type=shtb, pub=keyb.hex(), expect=list(res) if res else None,
+                                     source="onchaind/test/run-grind_feerate-bug.c (htlc_timeout_tx with locktime %d; the reference asserts the match is the cltv-586034 candidate)" % cltv))
+        assert [v["expect"] is not None for v in out["grind"]] == [False, True], out["grind"]
     else:
         # outside this container keep the committed vectors
-        out["recover"] = json.load(open(os.path.join(HERE, "kat.json")))["recover"]
+        old = json.load(open(os.path.join(HERE, "kat.json")))
+        out["recover"], out["txsig"], out["grind"] = old["recover"], old["txsig"], old["grind"]
     # synthesised failure / edge classes (pyref; the host build of the device code is checked against the same function)
     for i in range(24):
         sk, hh = rng.scalar(), rng.bytes(32)

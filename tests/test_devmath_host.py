@@ -590,6 +590,12 @@ def test_bip143_sighash_host_build_vs_pyref_and_reference_kat(dm, kat):
         assert dm.dm_bip143(2, 109, ib, 1, ob, len(ob), 1, 0, ws, len(ws), 700000, 1, o) == 1
         assert o.raw == H(v["expect"]), v["name"]
     assert any(v["expect"].startswith("45fa7ea15e62277f") for v in kat["bip143"])
+    for v in kat["txsig"]:   # the reference-held BOLT #3 HTLC transactions (channeld/test/run-full_channel.c): template -> the sighash their signatures verify under
+        ib, ob = _tx_flat([(H(t), vout, seq) for t, vout, seq in v["inputs"]], [(a, H(spk)) for a, spk in v["outputs"]])
+        wsx = H(v["script"])
+        assert dm.dm_bip143(v["version"], v["locktime"], ib, len(v["inputs"]), ob, len(ob), len(v["outputs"]), v["input_num"], wsx, len(wsx), v["amount"],
+                            v["sighash_type"], o) == 1
+        assert o.raw == H(v["sighash"]), v["name"]
     rnd = random.Random(143)
     for it in range(100_000):
         version, inputs, outputs, lock, script, amount = _rand_tx(rnd)

@@ -713,6 +713,25 @@ def test_grind_htlc_tx_fee_reference_kat(eng, kat, orc):
     assert eng.grind_htlc_tx_fee(pre, outputs, 165749, 663, 0, 400000, sig, 1, True, key) is None       # input too small for that fee
 
 
+def test_reference_held_transactions_bolt3_htlc_and_second_grind_kat(eng, kat):
+    """check_tx_sig from transaction templates on the signed BOLT #3 HTLC transactions the reference's channeld test holds (both signatures of
+    each; rejected with the spent amount off by one) -- through the one-launch path (20 rows) and, repeated past 4096 rows, through the batch
+    path with the BIP143 hash on the device; the second fee-grind known answer (run-grind_feerate-bug.c: only the cltv-586034 candidate fits)"""
+    rows = kat["txsig"]
+    txs = [dict(version=v["version"], locktime=v["locktime"], inputs=[(H(t), vout, seq) for t, vout, seq in v["inputs"]],
+                outputs=[(a, H(spk)) for a, spk in v["outputs"]], input_num=v["input_num"], amount=v["amount"], script=H(v["script"]),
+                sighash_type=v["sighash_type"], has_witness=v["has_witness"]) for v in rows]
+    sigs, pubs, exp = _rows([H(v["sig"]) for v in rows], 64), _rows([H(v["pub"]) for v in rows], 33), [v["expect"] for v in rows]
+    assert [bool(g) for g in eng.check_tx_sig_tx_batch(txs, sigs, pubs)] == exp
+    reps = 4100 // len(rows) + 1
+    got = eng.check_tx_sig_tx_batch(txs * reps, np.tile(sigs, (reps, 1)), np.tile(pubs, (reps, 1)))
+    assert [bool(g) for g in got] == exp * reps
+    for v in kat["grind"]:
+        got = eng.grind_htlc_tx_fee(H(v["preimage"]), H(v["outputs"]), v["input_sat"], v["weight"], v["min_feerate"], v["max_feerate"], H(v["sig"]),
+                                    v["sighash_type"], True, H(v["pub"]))
+        assert (list(got) if got else None) == v["expect"], v["name"]
+
+
 def test_grind_htlc_tx_fee_random_vs_oracle(eng, orc):
     """seeded synthetic HTLC transactions signed at a hidden feerate: the device grind and the restated reference loop
     (pyref.grind_htlc_tx_fee over the C oracle's ECDSA) must return the same (feerate, fee) -- or both nothing"""

@@ -185,6 +185,29 @@ def test_fee_grind_restatement_reproduces_reference_kat(kat, orc):
     assert pyref.grind_htlc_tx_fee(pre, outputs, 700000, 663, 249001, 250000, sig, 0x83, False, key, verify=ver) is None
 
 
+def test_bolt3_htlc_transactions_and_second_grind_kat(kat, orc):
+    """check_tx_sig on reference-held transactions: the signed BOLT #3 appendix C HTLC transactions of channeld/test/run-full_channel.c (both
+    signatures of each, made by the reference's own signer) -- pyref's BIP143 hash of the template equals the stored one and the C oracle accepts
+    the signature under it, and rejects it with the spent amount off by one; onchaind/test/run-grind_feerate-bug.c -- the remote HTLC signature
+    fits the candidate with cltv 586034 (the reference asserts `ret == 2`) and not the one with cltv 585998, in the reference's feerate range"""
+    H = bytes.fromhex
+    rows = kat["txsig"]
+    assert sum(1 for v in rows if v["expect"]) >= 10 and sum(1 for v in rows if not v["expect"]) >= 10
+    for v in rows:
+        ins = [(H(t), vout, seq) for t, vout, seq in v["inputs"]]
+        outs = [(a, H(spk)) for a, spk in v["outputs"]]
+        h = pyref.bip143_sighash(v["version"], ins, outs, v["locktime"], v["input_num"], H(v["script"]), v["amount"], v["sighash_type"])[0]
+        assert h.hex() == v["sighash"], v["name"]
+        assert pyref.ecdsa_verify(h, H(v["sig"]), H(v["pub"])) == v["expect"], v["name"]
+        assert bool(orc.ecdsa_verify(h, H(v["sig"]), H(v["pub"]))) == v["expect"], v["name"]
+    ver = lambda h, s, k: orc.ecdsa_verify(h, s, k)
+    assert [v["expect"] is not None for v in kat["grind"]] == [False, True]
+    for v in kat["grind"]:
+        got = pyref.grind_htlc_tx_fee(H(v["preimage"]), H(v["outputs"]), v["input_sat"], v["weight"], v["min_feerate"], v["max_feerate"], H(v["sig"]),
+                                      v["sighash_type"], True, H(v["pub"]), verify=ver)
+        assert (list(got) if got else None) == v["expect"], v["name"]
+
+
 def test_recover_goldens(kat, orc):
     """public-key recovery: the reference's own BOLT11 test invoices (common/test/run-bolt11.c) all recover the key the test
     pins (:310); plus the other recovery id and synthesised failure classes"""
