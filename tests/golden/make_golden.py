@@ -790,6 +790,31 @@ def main():
                                              expect=got, source="channeld/test/run-full_channel.c:%d (BOLT #3 appendix C HTLC transaction, %s signature)%s"
                                              % (lineno, ("remote_htlc", "local_htlc")[which], " with the spent amount off by one" if tag else "")))
         assert sum(1 for v in out["txsig"] if v["expect"]) >= 10, len(out["txsig"])
+        # ... and the commitment transaction "taken from BOLT #3" that wallet/test/run-wallet.c stores (:1520): witness = 0 <sig1> <sig2>
+        # <2 <key1> <key2> 2 OP_CHECKMULTISIG>, spending the 10 000 000 sat funding output of that appendix
+        wsrc = os.path.join(ref, "wallet", "test", "run-wallet.c")
+        for lineno, line in enumerate(open(wsrc, encoding="utf-8", errors="replace"), 1):
+            m = re.search(r'bitcoin_tx_from_hex\(w, "(02000000000101[0-9a-f]+)"', line)
+            if not m or m.group(1) in seen_tx:
+                continue
+            seen_tx.add(m.group(1))
+            version, ins, outs, wit, lock = parse_segwit_tx(bytes.fromhex(m.group(1)))
+            ws = wit[0][-1]
+            if len(wit[0]) != 4 or len(ws) != 71 or ws[:2] != b"\x52\x21" or ws[-2:] != b"\x52\xae":
+                continue
+            for which, (der, key) in enumerate(zip(wit[0][1:3], (ws[2:35], ws[36:69]))):
+                (r_, s_), sht = R.signature_from_der(der)
+                sig = r_.to_bytes(32, "big") + s_.to_bytes(32, "big")
+                for tag, amount, want in (("", 10_000_000, True), ("/amount+1", 10_000_001, False)):
+                    hh = R.bip143_sighash(version, ins, outs, lock, 0, ws, amount, sht)[0]
+                    got = R.ecdsa_verify(hh, sig, key)
+                    assert got == want, (lineno, which, tag)
+                    out["txsig"].append(dict(name="KAT-BOLT3/commit/line%d/key%d%s" % (lineno, which + 1, tag), version=version, locktime=lock,
+                                             inputs=[[t.hex(), v, q] for t, v, q in ins], outputs=[[a, spk.hex()] for a, spk in outs], input_num=0,
+                                             amount=amount, script=ws.hex(), sighash_type=sht, has_witness=True, sig=sig.hex(), pub=key.hex(), sighash=hh.hex(),
+                                             expect=got, source="wallet/test/run-wallet.c:%d (BOLT #3 commitment transaction, signature %d of the 2-of-2)%s"
+                                             % (lineno, which + 1, " with the funding amount off by one" if tag else "")))
+        assert sum(1 for v in out["txsig"] if v["expect"]) >= 12
         # ---- KAT-O2: onchaind/test/run-grind_feerate-bug.c -- one remote HTLC signature, three candidate HTLCs (two cltvs), feerates
         # 10992..15370: the reference asserts that the THIRD candidate (cltv 586034) is the one whose htlc_timeout_tx the signature fits
         # (`assert(ret == 2)`, :375).  Transaction as the test's own comment prints it (:3).
