@@ -173,6 +173,17 @@ def test_reference_unit_test_expectations(shim, kat):
         tx, keep = make_tx(shim, 2, 109, [(rawtx[5:37], 0, 0, 700000)], [(700000 - fee, rawtx[56:90])])
         got[fee] = shim.check_tx_sig(ctypes.byref(tx), 0, None, ws, ctypes.byref(key), ctypes.byref(sig))
     assert got == {165749: False, 165750: True, 165751: False, 0: False}
+    # ... the signed BOLT #3 transactions the reference tree holds (channeld/test/run-full_channel.c HTLC transactions, wallet/test/run-wallet.c
+    # commitment transaction) through the same prototype: check_tx_sig(tx, 0, NULL, wscript, &key, &sig)
+    for v in kat["txsig"]:
+        txv, keepv = make_tx(shim, v["version"], v["locktime"], [(H(t), vout, seq, v["amount"]) for t, vout, seq in v["inputs"]],
+                             [(a, H(spk)) for a, spk in v["outputs"]])
+        wsv = shim.shim_tal_dup(None, H(v["script"]), len(v["script"]) // 2)
+        kv, sv = Pubkey(), BitcoinSig()
+        assert shim.pubkey_from_der(H(v["pub"]), 33, ctypes.byref(kv))
+        assert shim.fromwire_secp256k1_ecdsa_signature(H(v["sig"]), ctypes.byref(sv.s))
+        sv.sighash_type = v["sighash_type"]
+        assert shim.check_tx_sig(ctypes.byref(txv), v["input_num"], None, wsv, ctypes.byref(kv), ctypes.byref(sv)) is v["expect"], v["name"]
     # ... and the grind itself as the test runs it: weight 663, max_possible_feerate 250 000, 1000 iterations
     pre = H(next(v for v in kat["bip143"] if v["name"] == "KAT-O/fee=0")["preimage"])
     spk = H("002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d6192743604179")
