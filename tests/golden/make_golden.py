@@ -728,7 +728,7 @@ def main():
             out["recover"].append(dict(name="KAT-SIGNMSG/line%d/modified" % lineno, hash=hm.hex(), sig=sig.hex(), recid=recid,
                                        expect=R.ser33(rm).hex() if rm else None, source="derived: tests/test_misc.py:%d with the message modified (another key or none)" % lineno))
             # the same triple as a plain verification under the claimed key (low-S rule of secp256k1_ecdsa_verify applies: expect from the model)
-            out["ecdsa"].append(ecdsa_row("KAT-SIGNMSG/line%d/verify" % lineno, hh, sig, bytes.fromhex(pub), "tests/test_misc.py:%d as (hash, r||s, key)" % lineno))
+            out["ecdsa"].append(ecdsa_row("checkmessage/line%d/verify" % lineno, hh, sig, bytes.fromhex(pub), "tests/test_misc.py:%d as (hash, r||s, key)" % lineno))
         # ---- KAT-BOLT3: check_tx_sig on the signed HTLC transactions of BOLT #3 appendix C that channeld/test/run-full_channel.c holds as
         # raw hex (tx_from_hex(...): the test rebuilds each one -- signatures included -- with the reference's own signer and demands equality).
         # Witness = 0 <remotehtlcsig> <localhtlcsig> [<preimage>] <wscript>; the two keys stand in the script (remote_htlcpubkey after
