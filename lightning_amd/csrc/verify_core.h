@@ -1631,4 +1631,83 @@ LAMD_HD bool schnorr_final(const gej &R, const u32 rw[8]) {
   return (y.n[0] & 1) == 0;
 }
 
+
+// ================================================================================================
+// Per-row front ends of the callers that hash first -- one source for the kernels (k_txsig_hash, k_txsig_tx_hash, k_gossip_expand,
+// k_gossip_reduce) and for the host-side latency paths of lamd_check_tx_sig_*batch / lamd_sigcheck_gossip_batch (a few rows per call:
+// hashing on the host, the rows through k_small_verify)
+// one row of check_tx_sig: the sighash-type gate (only SIGHASH_ALL, or SINGLE|ANYONECANPAY with a witness script) and the double SHA-256
+// of the caller's preimage; shared by the kernel and the host-side latency path (a few rows: lamd_check_tx_sig_batch)
+LAMD_HD bool txsig_hash_one(const u8 *pre, size_t len, u8 sighash_type, bool has_witness, u8 hash32[32]) {
+  const bool pass = sighash_type == 1 || (sighash_type == 0x83 && has_witness);
+  u8 h[32];
+  if (pass) sha256d_bytes(pre, len, h);
+  for (int b = 0; b < 32; b++) hash32[b] = pass ? h[b] : 0;
+  return pass;
+}
+// ---- check_tx_sig from transaction templates: the BIP143 hash of bitcoin_tx_hash_for_sig() (bitcoin/signature.c:120-151) computed
+// here from flat template arrays (verify_core.h "BIP143 signature hash on the device"), plus the sighash-type gate of :206-211
+LAMD_HD bool txsig_tx_hash_one(size_t i, const u32 *version, const u32 *locktime, const u8 *inputs40, const u64 *in_off, const u32 *input_num,
+                               const u64 *amount, const u8 *outputs, const u64 *out_off, const u32 *n_outputs, const u8 *scripts,
+                               const u64 *script_off, const u8 *sighash_type, const u8 *has_witness, u8 hash32[32]) {
+  const u8 t = sighash_type[i];
+  bool pass = t == 1 || (t == 0x83 && has_witness[i]);
+  u8 h[32];
+  for (int b = 0; b < 32; b++) h[b] = 0;
+  if (pass) {
+    tx_view tv;
+    tv.version = version[i];
+    tv.locktime = locktime[i];
+    tv.inputs = inputs40 + 40 * in_off[i];
+    tv.n_in = (u32)(in_off[i + 1] - in_off[i]);
+    tv.outputs = outputs + out_off[i];
+    tv.outputs_len = (size_t)(out_off[i + 1] - out_off[i]);
+    tv.n_out = n_outputs[i];
+    pass = bip143_sighash(tv, input_num[i], scripts + script_off[i], (size_t)(script_off[i + 1] - script_off[i]), amount[i], t, h);
+  }
+  for (int b = 0; b < 32; b++) hash32[b] = h[b];
+  return pass;
+}
+// one message -> its signature rows (hash of the signed tail, signature k, signer k; strides 32 / 64 / 33) and whether it is malformed
+// (framing, or a signature whose r or s is out of range: fromwire_secp256k1_ecdsa_signature fails).  Shared by the kernel below and by the
+// host-side latency path of lamd_sigcheck_gossip_batch (a handful of messages: the rows go through k_small_verify).
+LAMD_HD bool gossip_expand_one(const u8 *m, size_t len, const u8 *node_id33, size_t nrows, u8 *hash32, u8 *sig64, u8 *pub33) {
+  const gossip_frame fr = gossip_parse_frame(m, len);
+  bool bad = fr.bad;
+  const u32 type = fr.type;
+  const size_t signed_off = fr.signed_off, keyoff = fr.keyoff;
+  u8 h[32];
+  if (!bad) sha256d_bytes(m + signed_off, len - signed_off, h);
+  for (size_t k = 0; k < nrows; k++) {
+    u8 *hd = hash32 + 32 * k, *sd = sig64 + 64 * k, *pd = pub33 + 33 * k;
+    if (bad) {
+      for (int b = 0; b < 32; b++) hd[b] = 0;
+      for (int b = 0; b < 64; b++) sd[b] = 0;
+      for (int b = 0; b < 33; b++) pd[b] = 0;
+      continue;
+    }
+    const u8 *sp = m + 2 + 64 * k;
+    const u8 *kp = (type == GOSSIP_CUPD) ? node_id33 : m + keyoff + 33 * k;
+    u32 rw[8], sw[8];
+    load_words_be(rw, sp);
+    load_words_be(sw, sp + 32);
+    if (words_ge_n(rw) | words_ge_n(sw)) bad = true;  // fromwire_secp256k1_ecdsa_signature fails: malformed
+    for (int b = 0; b < 32; b++) hd[b] = h[b];
+    for (int b = 0; b < 64; b++) sd[b] = sp[b];
+    for (int b = 0; b < 33; b++) pd[b] = kp[b];
+  }
+  return bad;
+}
+// verdicts of a message's rows -> the message's verdict: -1 malformed (incl. a bitcoin key that does not parse: fromwire_pubkey),
+// 0 all signatures good, k = the FIRST failing signature (sigcheck.c:78-113 order)
+LAMD_HD int gossip_reduce_one(size_t nrows, const u8 *ok, const u8 *keyok, bool malformed) {
+  bool bad = malformed;
+  if (!bad && nrows == 4) bad = !keyok[2] | !keyok[3];  // fromwire_pubkey on bitcoin_key_1/2
+  if (bad) return -1;
+  int v = 0;
+  for (size_t k = nrows; k-- > 0;)
+    if (!ok[k]) v = (int)k + 1;
+  return v;
+}
+
 }  // namespace lamd

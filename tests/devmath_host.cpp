@@ -218,6 +218,14 @@ extern "C" void dm_verify_split(int mode, int T, size_t n, const u8 *a32, const 
   else if (T == 10) verify_split_t<10>(mode, n, a32, sig64, key, keylen, out);
   else verify_split_t<0>(mode, n, a32, sig64, key, keylen, out);
 }
+// the per-row front ends the kernels share with the host-side latency paths (verify_core.h, last section)
+extern "C" int dm_gossip_expand(const u8 *m, size_t len, const u8 *node_id33, size_t nrows, u8 *hash32, u8 *sig64, u8 *pub33) {
+  return gossip_expand_one(m, len, node_id33, nrows, hash32, sig64, pub33) ? 1 : 0;
+}
+extern "C" int dm_gossip_reduce(size_t nrows, const u8 *ok, const u8 *keyok, int malformed) { return gossip_reduce_one(nrows, ok, keyok, malformed != 0); }
+extern "C" int dm_txsig_hash(const u8 *pre, size_t len, int sighash_type, int has_witness, u8 *hash32) {
+  return txsig_hash_one(pre, len, (u8)sighash_type, has_witness != 0, hash32) ? 1 : 0;
+}
 extern "C" {
 int dm_comb_spacing(int T) { return kc_spacing(T); }
 void dm_verify_keyed(int mode, int T, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {

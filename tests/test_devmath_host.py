@@ -569,6 +569,40 @@ def _tx_flat(inputs, outputs):
     return ib, ob
 
 
+def test_host_side_front_ends_of_the_latency_paths(dm, kat, orc):
+    """what lamd_sigcheck_gossip_batch / lamd_check_tx_sig_batch do ON THE HOST for a call of a few rows -- the kernels' own inline functions
+    (gossip_expand_one, gossip_reduce_one, txsig_hash_one) compiled for the host: every gossip golden (the reference's KAT-G verdicts, its
+    gossip_store messages, the framing classes) expanded into rows, the rows decided by the C oracle, reduced -- the golden verdict must come
+    out; the sighash-type gate and the double SHA-256 of check_tx_sig on the reference's preimages"""
+    dm.dm_gossip_expand.restype = ctypes.c_int
+    dm.dm_gossip_expand.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    dm.dm_gossip_reduce.restype = ctypes.c_int
+    dm.dm_gossip_reduce.argtypes = [ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    seen = set()
+    for v in kat["gossip"]:
+        m = H(v["msg"])
+        typ = int.from_bytes(m[:2], "big") if len(m) >= 2 else 0
+        nrows = 4 if typ == 256 else 1
+        nid = H(v["node_id"]) if "node_id" in v else bytes(33)
+        hs, sg, pk = ctypes.create_string_buffer(32 * nrows), ctypes.create_string_buffer(64 * nrows), ctypes.create_string_buffer(33 * nrows)
+        bad = dm.dm_gossip_expand(m, len(m), nid, nrows, hs, sg, pk)
+        ok = bytes(1 if orc.ecdsa_verify(hs.raw[32 * k:32 * k + 32], sg.raw[64 * k:64 * k + 64], pk.raw[33 * k:33 * k + 33]) else 0 for k in range(nrows))
+        keyok = bytes(1 if pyref.pubkey_parse(pk.raw[33 * k:33 * k + 33]) is not None else 0 for k in range(nrows))
+        got = dm.dm_gossip_reduce(nrows, ok, keyok, bad)
+        assert got == v["expect"], v["name"]
+        seen.add(got)
+    assert {-1, 0, 1, 2}.issubset(seen)
+    dm.dm_txsig_hash.restype = ctypes.c_int
+    dm.dm_txsig_hash.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    o = ctypes.create_string_buffer(32)
+    for v in kat["bip143"]:
+        pre = H(v["preimage"])
+        assert dm.dm_txsig_hash(pre, len(pre), 1, 0, o) == 1 and o.raw == H(v["expect"]), v["name"]
+        assert dm.dm_txsig_hash(pre, len(pre), 0x83, 1, o) == 1 and o.raw == H(v["expect"])          # the gate only looks at the type; the hash is of the bytes given
+        for t, w in ((0x83, 0), (2, 1), (3, 1), (0x81, 1), (0, 1)):
+            assert dm.dm_txsig_hash(pre, len(pre), t, w, o) == 0 and o.raw == bytes(32)                # outside the gate (bitcoin/signature.c:206-211)
+
+
 def test_bip143_sighash_host_build_vs_pyref_and_reference_kat(dm, kat):
     """the device's BIP143 code (streaming SHA-256 over the template's pieces) on the host: the reference's own transaction
     (onchaind/test/run-grind_feerate.c: 290-byte preimage, sighash 45fa7ea1... at fee 165 750) and 100 000 random templates
