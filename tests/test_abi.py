@@ -33,6 +33,26 @@ def test_header_symbols_exported_and_bound():
     assert not [n for n in ("lamd_gen_ecdsa_device", "lamd_gen_schnorr_device", "lamd_gen_gossip_device") if hasattr(lib, n)]
 
 
+def test_struct_layouts_match_the_headers(tmp_path):
+    """the ctypes mirrors of the structures the C ABI hands over (lamd_info; the gossip ingest's event, config and statistics) have the size and
+    the field offsets a C compiler gives the declarations in include/: a field added on one side only would shift everything behind it"""
+    import subprocess
+    from lightning_amd import _ffi
+    fields = [f[0] for f in _ffi.LamdInfo._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lightning_amd.h"\nint main(void) {\n  printf("%zu\\n", sizeof(lamd_info));\n'
+                   + "".join('  printf("%%zu\\n", offsetof(lamd_info, %s));\n' % f for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_ffi.LamdInfo), (out[0], ctypes.sizeof(_ffi.LamdInfo))
+    assert out[1:] == [getattr(_ffi.LamdInfo, f).offset for f in fields]
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lightning_amd.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct[^{;]*\{([^}]*)\} lamd_info;", hdr, re.S).group(1)
+    declared = re.findall(r"\b([a-z_0-9]+)\s*(?:\[[^\]]*\])?\s*[,;]", body)
+    assert declared == fields, (declared, fields)
+
+
 def test_testgen_header_symbols_exported():
     """include/lightning_amd_testgen.h (test / bench infrastructure) -> liblightning_amd_testgen.so"""
     from lightning_amd import _ffi
