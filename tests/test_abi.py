@@ -47,6 +47,23 @@ def test_struct_layouts_match_the_headers(tmp_path):
     out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert out[0] == ctypes.sizeof(_ffi.LamdInfo), (out[0], ctypes.sizeof(_ffi.LamdInfo))
     assert out[1:] == [getattr(_ffi.LamdInfo, f).offset for f in fields]
+    # ... and the three structures of the gossip ingest's ABI (include/lightning_amd_gossipd.h <-> lightning_amd/gossipd.py)
+    from lightning_amd import gossipd
+    gsrc = tmp_path / "layout_g.c"
+    pairs = [("lamd_gossipd_event", gossipd.Event), ("lamd_gossipd_config", gossipd.Config), ("lamd_gossipd_stats", gossipd.Stats)]
+    lines = []
+    for cname, cls in pairs:
+        lines.append('  printf("%%zu\\n", sizeof(%s));\n' % cname)
+        lines += ['  printf("%%zu\\n", offsetof(%s, %s));\n' % (cname, f[0]) for f in cls._fields_]
+    gsrc.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lightning_amd_gossipd.h"\nint main(void) {\n' + "".join(lines) + "  return 0;\n}\n")
+    gexe = tmp_path / "layout_g"
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), "-o", str(gexe), str(gsrc)])
+    gout = [int(x) for x in subprocess.check_output([str(gexe)]).split()]
+    want = []
+    for cname, cls in pairs:
+        want.append(ctypes.sizeof(cls))
+        want += [getattr(cls, f[0]).offset for f in cls._fields_]
+    assert gout == want, (gout, want)
     hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lightning_amd.h")).read(), flags=re.S)
     body = re.search(r"typedef struct[^{;]*\{([^}]*)\} lamd_info;", hdr, re.S).group(1)
     declared = re.findall(r"\b([a-z_0-9]+)\s*(?:\[[^\]]*\])?\s*[,;]", body)
