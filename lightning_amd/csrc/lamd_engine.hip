@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 
                                                       const cache_ent *__restrict__ ents, const u32 *__restrict__ pool7,
                                                       const u32 *__restrict__ pool10, const u8 *__restrict__ sig64, int mode,
                                                       const u32 *__restrict__ gtable, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
-                                                      u8 *__restrict__ out, const u32 *__restrict__ gtable5 = nullptr) {
+                                                      u8 *__restrict__ out, const u32 *__restrict__ gtable5 = nullptr, int part = 0, u32 tail = 0) {
   if (CAREFUL && plan[P_SUSPECT] == 0) return;
 #if defined(LAMD_G_LDS)
   extern __shared__ u32 s_g5[];
@@ -751,8 +751,10 @@ __global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 
   (void)gtable5;
 #endif
   const size_t t7 = plan[P_L7], total = t7 + plan[P_L10], stride = (size_t)gridDim.x * blockDim.x;
+  // (part 1 / 2 of a launch cut in two, LAMD_ECMULT_CHAIN=2: everything but the last `tail` work items / those last items)
+  const size_t cut = total > tail ? total - tail : 0, begin = part == 2 ? cut : 0, end = part == 1 ? cut : total;
 #pragma unroll 1
-  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+  for (size_t j = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < end; j += stride) {
     const bool ten = j >= t7;
     const size_t i = ten ? list10[j - t7] : list7[j];
     if (CAREFUL && out[i] != VERDICT_SUSPECT) continue;
@@ -1166,6 +1168,9 @@ struct lamd_ctx {
   int ecm_last = -1;
   int ecm_chain = 0;
   size_t ecm_chain_min = 65536;
+  u32 ecm_tail = 131072;             // LAMD_ECMULT_TAIL: work items of the low-priority second part (LAMD_ECMULT_CHAIN=2)
+  hipStream_t stream_lo = nullptr;   // lanes, LAMD_ECMULT_CHAIN=2: lowest-priority stream of that second part
+  hipEvent_t ev_lo_go = nullptr, ev_lo_done = nullptr;
 };
 
 #define HIPCHK(ctx, call)                                                                           \
@@ -1260,6 +1265,13 @@ static int create_streams(lamd_ctx *ctx) {
     for (auto &e : ctx->ev_pub) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  if (getenv("LAMD_ECMULT_CHAIN") && atoi(getenv("LAMD_ECMULT_CHAIN")) == 2) {  // experiment: the tail of a large ecmult launch on a lowest-priority stream
+    int lo = 0, hi = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (numerically greatest)
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_lo, hipStreamNonBlocking, lo));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lo_go, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lo_done, hipEventDisableTiming));
+  }
   for (auto &e : ctx->ev) HIPCHK(ctx, hipEventCreate(&e));
   if (!ctx->is_lane) {
     for (auto &qs : ctx->qs) {
@@ -1270,6 +1282,7 @@ static int create_streams(lamd_ctx *ctx) {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     for (auto &e : ctx->ev_ecm) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *w = getenv("LAMD_ECMULT_CHAIN")) ctx->ecm_chain = atoi(w);
+    if (const char *w = getenv("LAMD_ECMULT_TAIL")) ctx->ecm_tail = (u32)atol(w);
     if (const char *w = getenv("LAMD_COPY_STREAM")) ctx->use_copy_stream = atoi(w) != 0;
   }
   return LAMD_OK;
@@ -1475,6 +1488,9 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
   if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+  if (ctx->stream_lo) { (void)hipStreamSynchronize(ctx->stream_lo); (void)hipStreamDestroy(ctx->stream_lo); }
+  for (hipEvent_t e : {ctx->ev_lo_go, ctx->ev_lo_done})
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto &e : ctx->ev)
@@ -2041,9 +2057,20 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     }
     HIPCHK(ctx, hipEventRecord(pair[0], ctx->stream));
   }
+  const bool two_parts = chain && root->ecm_chain == 2 && ctx->stream_lo;
+  if (two_parts) {
+    // part 2 (the last ecm_tail work items) on the lane's lowest-priority stream, runnable from now on: the dispatcher gives it the wave slots
+    // part 1 leaves free -- at part 1's tail, and under the head of the NEXT call's part 1, which waits for THIS part 1 only
+    HIPCHK(ctx, hipEventRecord(ctx->ev_lo_go, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_lo, ctx->ev_lo_go, 0));
+    hipLaunchKernelGGL(fast, dim3((root->ecm_tail + LAMD_KEYED_THREADS - 1) / LAMD_KEYED_THREADS), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ctx->stream_lo, plan,
+                       (const u32 *)list7, (const u32 *)list10, recs, (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode,
+                       (const u32 *)ctx->gtable, fin, keyok_out, d_ok, (const u32 *)ctx->gtable5, 2, root->ecm_tail);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_lo_done, ctx->stream_lo));
+  }
   hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
-                     keyok_out, d_ok, (const u32 *)ctx->gtable5);
+                     keyok_out, d_ok, (const u32 *)ctx->gtable5, two_parts ? 1 : 0, root->ecm_tail);
   if (time_kernel) {
     HIPCHK(ctx, hipEventRecord(ctx->kev[ctx->kev_n][1], ctx->stream));
     ctx->kev_mode[ctx->kev_n++] = mode == MODE_SCHNORR ? 1 : 0;
@@ -2052,6 +2079,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     HIPCHK(ctx, hipEventRecord(root->ev_ecm[ctx->lane_id], ctx->stream));
     root->ecm_last = ctx->lane_id;
   }
+  if (two_parts) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lo_done, 0));
   // rows whose bare-formula ecmult met Z = 0 (crafted scalars, a result at infinity): the complete formulas decide
   hipLaunchKernelGGL((k_ecmult_keyed<true, 3>), dim3(careful_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,

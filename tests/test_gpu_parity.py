@@ -592,7 +592,7 @@ def test_single_lane_mode_matches(orc):
         e.close()
 
 
-@pytest.mark.parametrize("env", [{"LAMD_FUSED_FRONT": "0"}, {"LAMD_MERGE_SIDE": "0"}, {"LAMD_ECMULT_CHAIN": "1"}, {"LAMD_COPY_STREAM": "0"},
+@pytest.mark.parametrize("env", [{"LAMD_FUSED_FRONT": "0"}, {"LAMD_MERGE_SIDE": "0"}, {"LAMD_ECMULT_CHAIN": "1"}, {"LAMD_ECMULT_CHAIN": "2", "LAMD_ECMULT_TAIL": "50000"}, {"LAMD_COPY_STREAM": "0"},
                                  {"LAMD_FUSED_FRONT": "0", "LAMD_CACHE": "0"}, {"LAMD_CACHE": "0"}])
 def test_scheduling_variants_give_the_same_verdicts(orc, env):
     """the round-2 front end (19 launches), the ladder on a stream of its own, chained ecmult launches, flush copies on the lane's prep
