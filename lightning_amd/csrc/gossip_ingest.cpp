@@ -368,6 +368,7 @@ struct lamd_gossipd {
   // ---- events
   void emit(lamd_gossipd_event &ev) { if (on_event) on_event(user, &ev); }
   void ev_text(int kind, bool has_peer, const nodeid *peer, const std::string &text) {
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = kind;
@@ -377,6 +378,7 @@ struct lamd_gossipd {
     emit(ev);
   }
   void ev_scid(int kind, bool has_peer, const nodeid *peer, u64 scid) {
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = kind;
@@ -395,6 +397,7 @@ struct lamd_gossipd {
   }
   void good_gossip(bool has_peer, const nodeid *peer) {
     if (!has_peer) return;  // gossipd.c:70-71
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_GOOD_GOSSIP;
@@ -438,6 +441,7 @@ struct lamd_gossipd {
   }
   u64 store_add(u32 type, u32 timestamp, const u8 *data, size_t len) {
     const u64 idx = store_append(type, timestamp, data, len);
+    if (!on_event) return idx;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_ADD;
@@ -462,6 +466,7 @@ struct lamd_gossipd {
       store[idx + 1].deleted = true;
       store_or_flag(idx + 1, GS_DELETED);
     }
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_DEL;
@@ -476,6 +481,7 @@ struct lamd_gossipd {
     put_be32(h + 4, crc32c(ts, image.data() + store[idx].off, store[idx].len));
     put_be32(h + 8, ts);
     store_write_event(store[idx].off - 12, 12);
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_SET_TS;
@@ -486,6 +492,7 @@ struct lamd_gossipd {
   }
   void store_set_dying(u64 idx) {
     store_or_flag(idx, GS_DYING);
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_STORE_FLAG;
@@ -496,6 +503,7 @@ struct lamd_gossipd {
     emit(ev);
   }
   void peer_update(bool has_peer, const nodeid *peer, u64 scid, u32 fee_base, u32 fee_ppm, u32 cltv, u64 hmin, u64 hmax) {
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_PEER_UPDATE;
@@ -813,6 +821,7 @@ struct lamd_gossipd {
     if (on_event) ev_text(LAMD_GEV_TRACE, has_src, src, "Received node_announcement for node " + hexs(id.k, 33));
   }
   void unknown_node(bool has_src, const nodeid *src, const nodeid &id) {  // :1231-1238
+    if (!on_event) return;   // (no listener: nothing to build)
     lamd_gossipd_event ev;
     memset(&ev, 0, sizeof ev);
     ev.kind = LAMD_GEV_QUERY_NODE;
