@@ -200,6 +200,7 @@ def test_bolt3_htlc_transactions_and_second_grind_kat(kat, orc):
         assert h.hex() == v["sighash"], v["name"]
         assert pyref.ecdsa_verify(h, H(v["sig"]), H(v["pub"])) == v["expect"], v["name"]
         assert bool(orc.ecdsa_verify(h, H(v["sig"]), H(v["pub"]))) == v["expect"], v["name"]
+        assert bool(orc.ossl_ecdsa_verify(h, H(v["sig"]), H(v["pub"]))) == v["expect"], v["name"]     # OpenSSL as the third opinion (low-S signatures: no extra rule needed)
     ver = lambda h, s, k: orc.ecdsa_verify(h, s, k)
     assert [v["expect"] is not None for v in kat["grind"]] == [False, True]
     for v in kat["grind"]:
