@@ -2316,13 +2316,21 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   return LAMD_OK;
 }
 
+// does a host-buffer call of `rows` signature rows take the one-launch path?  More than one block only where recurring keys have cached
+// tables to hit (LAMD_CACHE=1, the default: without a cache every row would walk the in-kernel ladder, and a batch under ONE new key -- a
+// commitment -- is better served by the general path's per-call table); LAMD_KEYED=1 (tests forcing the table-building path) likewise
+static bool small_path(const lamd_ctx *ctx, size_t rows) {
+  if (!ctx->small_kernel || rows > SMALL_MAX) return false;
+  if (rows <= 64) return true;
+  return ctx->keyed_mode <= 0 && ctx->cache_mode != 0 && ctx->cache_store.shared;
+}
 static int run_host(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride,
                     u8 *ok) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
   // (LAMD_KEYED=1 -- tests forcing the table-building path -- keeps calls of more than one block on the general path)
-  if (n <= SMALL_MAX && ctx->small_kernel && (ctx->keyed_mode <= 0 || n <= 64)) {
+  if (small_path(ctx, n)) {
     rc = run_small(ctx, mode, n, a, sig, key, keylen, keystride, ok);
     if (rc != 1) return rc;
     ctx->force_learn = true;  // a key that missed before is back: this call builds and publishes the missing tables (general path below)
@@ -2463,7 +2471,7 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   int rc;
   // a few rows (an unmodified channeld checks ONE signature per check_tx_sig() call, channeld.c:2171,2224): gate + double SHA-256 on the
   // host -- the kernel's own inline function -- and the rows through the one-launch latency path
-  if (n <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0) {
+  if (small_path(ctx, n) && ctx->keyed_mode <= 0) {
     if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
     std::vector<u8> hs(32 * n), gate(n);
     for (size_t i = 0; i < n; i++) gate[i] = txsig_hash_one(preimages + off[i], (size_t)(off[i + 1] - off[i]), sighash_type[i], has_witness[i] != 0, &hs[32 * i]);
@@ -2522,7 +2530,7 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
-  if (n <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0) {  // a few rows: BIP143 hash on the host, rows through the latency path (see lamd_check_tx_sig_batch)
+  if (small_path(ctx, n) && ctx->keyed_mode <= 0) {  // a few rows: BIP143 hash on the host, rows through the latency path (see lamd_check_tx_sig_batch)
     std::vector<u8> hs(32 * n), gate(n);
     for (size_t i = 0; i < n; i++)
       gate[i] = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
@@ -2625,7 +2633,7 @@ extern "C" int lamd_bolt12_check_signature_batch(lamd_ctx *ctx, size_t n, const 
   for (size_t i = 0; i < n; i++) memcpy(&xonly[32 * i], key33 + keystride * i + 1, 32);
   // a few invoices / offers (one per bolt12_check_signature() call, common/bolt12.c:80-92): merkle root and tagged hash on the host --
   // the kernel's own inline functions (bolt12.h) -- and the rows through the one-launch latency path
-  if (n <= 256 && ctx->small_kernel && ctx->keyed_mode <= 0) {
+  if (n <= 256 && small_path(ctx, n) && ctx->keyed_mode <= 0) {
     bolt12_mids mids;
     const u8 leaf[6] = {'L', 'n', 'L', 'e', 'a', 'f'}, branch[8] = {'L', 'n', 'B', 'r', 'a', 'n', 'c', 'h'};
     bolt12_tag_midstate(leaf, 6, leaf, 0, mids.leaf);
@@ -2850,7 +2858,7 @@ extern "C" int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t
   // double SHA-256 of the signed tail on the host -- the same inline functions the kernels run -- and the rows through the one-launch
   // latency path; the first-bad reduction on the host.  (A key that comes back without a table sends the call down the general path
   // below once: that call builds and publishes the table.)
-  if (rows <= SMALL_MAX && ctx->small_kernel && ctx->keyed_mode <= 0) {
+  if (small_path(ctx, rows) && ctx->keyed_mode <= 0) {
     if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
     std::vector<u8> hs(32 * rows), sg(64 * rows), pk(33 * rows), ok(rows), bad(n);
     for (size_t i = 0; i < n; i++)
