@@ -5,7 +5,8 @@
  *   bitcoin/signature.h:85-87    check_signed_hash()
  *   bitcoin/signature.h:120-124  check_tx_sig()            (see note below)
  *   bitcoin/signature.h:129-131  check_schnorr_sig()
- *   common/bolt11.c:1021-1046    secp256k1_ecdsa_recoverable_signature_parse_compact(), secp256k1_ecdsa_recover()
+ *   common/bolt11.c:1021-1057    secp256k1_ecdsa_recoverable_signature_parse_compact(), _convert(), secp256k1_ecdsa_recover(),
+ *                                secp256k1_ecdsa_verify() (also lightningd/dual_open_control.c:2254)
  *   onchaind/onchaind.c:388-438  grind_htlc_tx_fee()       (static there; its statics become arguments)
  *   bitcoin/signature.h:158-159  signature_from_der()      (bitcoin/signature.c:310-323)
  *   common/node_id.h:72-82       pubkey_from_node_id(), check_signed_hash_nodeid()
@@ -19,8 +20,9 @@
  * secp256k1_pubkey.data = affine X||Y big-endian.
  *
  * Differences a maintainer has to know about (also in INTEGRATION.md):
- *  - tal: the sigcheck_* functions return a malloc()ed string (or NULL); the `ctx` argument is
- *    accepted and ignored.  In-tree one would tal_strdup() it onto ctx.
+ *  - tal: stand-alone, "tal arrays" are shim_tal_dup()'s (length in front of the data) and the sigcheck_* error strings are such
+ *    arrays owned by the caller; built with -DLAMD_SHIM_WITH_CCAN_TAL (in-tree) lengths come from ccan's tal_bytelen() and the
+ *    strings are tal_strdup()ed onto `ctx` -- the reference's ownership exactly.
  *  - check_tx_sig() has the reference's prototype (bitcoin/signature.h:120-124).  `struct bitcoin_tx` here is a plain
  *    mirror of what that path reads from the reference's libwally-backed one (version, locktime, inputs with the amounts
  *    the PSBT carries, outputs); the two script arguments are tal-style arrays whose length travels with the pointer
@@ -104,10 +106,13 @@ struct bitcoin_tx {
 	const struct bitcoin_tx_input *inputs;
 	const struct bitcoin_tx_output *outputs;
 };
-/* bitcoin/signature.h:120-124, same argument order and meaning: witness_script NULL = hash `subscript`, and then only
+/* bitcoin/signature.h:120-124, same prototype, argument order and meaning: witness NULL = hash `subscript`, and then only
  * SIGHASH_ALL is accepted (bitcoin/signature.c:198-211). */
-bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, const u8 *subscript, const u8 *witness_script,
-		  const struct pubkey *key, const struct bitcoin_signature *sig);
+bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num,
+		  const u8 *subscript,
+		  const u8 *witness,
+		  const struct pubkey *key,
+		  const struct bitcoin_signature *sig);
 /* the round-1 form, kept for callers that already hold the serialised BIP143 preimage */
 bool check_tx_sig_preimage(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
 			   const struct pubkey *key, const struct bitcoin_signature *sig);
@@ -134,6 +139,14 @@ int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *ctx, secp256
 							 const unsigned char *input64, int recid);
 int secp256k1_ecdsa_recover(const void *ctx, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
 			    const unsigned char *msghash32);
+/* The two libsecp256k1 calls the reference makes on the BOLT #11 `n`-field path (common/bolt11.c:1026-1027,1055) and in
+ * lightningd/dual_open_control.c:2254, under the library's own names: convert drops the recovery id (returns 1 always, as upstream);
+ * secp256k1_ecdsa_verify() is check_signed_hash() without the struct wrappers -- 1 iff r, s in [1, n-1], s <= n/2 (upstream rejects
+ * high-S: bitcoin/signature.c:185-187) and the signature verifies; msghash32 is used as given (32 bytes, reduced mod n). */
+int secp256k1_ecdsa_recoverable_signature_convert(const void *ctx, secp256k1_ecdsa_signature *sig,
+						  const secp256k1_ecdsa_recoverable_signature *sigin);
+int secp256k1_ecdsa_verify(const void *ctx, const secp256k1_ecdsa_signature *sig, const unsigned char *msghash32,
+			   const secp256k1_pubkey *pubkey);
 void node_id_from_pubkey(struct node_id *id, const struct pubkey *key);   /* common/node_id.c:12-19 */
 
 /* onchaind/onchaind.c:388-438.  The reference's file-scope state becomes arguments (min/max_possible_feerate,
@@ -145,17 +158,41 @@ bool grind_htlc_tx_fee(uint64_t *fee_sat, const u8 *bip143_preimage, size_t prei
 		       uint64_t input_sat, const struct bitcoin_signature *remotesig, const u8 *wscript, uint64_t weight,
 		       uint32_t min_possible_feerate, uint32_t max_possible_feerate, const struct pubkey *other_htlc_key);
 
-/* msg_len replaces tal_count(msg).  NULL = OK, else a malloc()ed message with the reference's
- * exact wording ("Bad node_signature_1 <der-hex> hash <hex> on channel_announcement <hex>", ...). */
-const char *sigcheck_channel_update(const tal_t *ctx, const struct node_id *node_id,
-				    const secp256k1_ecdsa_signature *node_sig, const u8 *update, size_t msg_len);
-const char *sigcheck_channel_announcement(const tal_t *ctx, const struct node_id *node1_id, const struct node_id *node2_id,
-					  const struct pubkey *bitcoin1_key, const struct pubkey *bitcoin2_key,
-					  const secp256k1_ecdsa_signature *node1_sig, const secp256k1_ecdsa_signature *node2_sig,
-					  const secp256k1_ecdsa_signature *bitcoin1_sig, const secp256k1_ecdsa_signature *bitcoin2_sig,
-					  const u8 *announcement, size_t msg_len);
-const char *sigcheck_node_announcement(const tal_t *ctx, const struct node_id *node_id,
-				       const secp256k1_ecdsa_signature *node_sig, const u8 *node_announcement, size_t msg_len);
+/* gossipd/sigcheck.h:7-28 -- the reference's prototypes, token for token (tests/test_abi.py diffs them against the reference header).
+ * The message is a tal array, as everywhere in the reference (sigcheck.c:30-33 hashes tal_count(msg) - 66 bytes): its length is read
+ * with shim_tal_bytelen() -- ccan's tal_bytelen() in a -DLAMD_SHIM_WITH_CCAN_TAL build -- and a pointer whose length cannot be read fails
+ * closed ("... is not a tal array").  NULL = OK, else the reference's exact wording ("Bad node_signature_1 <der-hex> hash <hex> on
+ * channel_announcement <hex>", ...): a tal string -- tal_strdup()ed onto `ctx` in a -DLAMD_SHIM_WITH_CCAN_TAL build (sigcheck.c:36-41
+ * tal_fmt(ctx, ...)); stand-alone a shim_tal_dup()ed one whose owner is the caller (shim_tal_free(); `ctx` has no allocator behind it). */
+const char *sigcheck_channel_update(const tal_t *ctx,
+				    const struct node_id *node_id,
+				    const secp256k1_ecdsa_signature *node_sig,
+				    const u8 *update);
+const char *sigcheck_channel_announcement(const tal_t *ctx,
+					  const struct node_id *node1_id,
+					  const struct node_id *node2_id,
+					  const struct pubkey *bitcoin1_key,
+					  const struct pubkey *bitcoin2_key,
+					  const secp256k1_ecdsa_signature *node1_sig,
+					  const secp256k1_ecdsa_signature *node2_sig,
+					  const secp256k1_ecdsa_signature *bitcoin1_sig,
+					  const secp256k1_ecdsa_signature *bitcoin2_sig,
+					  const u8 *announcement);
+const char *sigcheck_node_announcement(const tal_t *ctx,
+				       const struct node_id *node_id,
+				       const secp256k1_ecdsa_signature *node_sig,
+				       const u8 *node_announcement);
+/* The same for callers that hold a plain (pointer, length) pair -- a message still sitting in a receive buffer: msg_len replaces
+ * tal_count(msg); the string is allocated as above. */
+const char *sigcheck_channel_update_len(const tal_t *ctx, const struct node_id *node_id,
+					const secp256k1_ecdsa_signature *node_sig, const u8 *update, size_t msg_len);
+const char *sigcheck_channel_announcement_len(const tal_t *ctx, const struct node_id *node1_id, const struct node_id *node2_id,
+					      const struct pubkey *bitcoin1_key, const struct pubkey *bitcoin2_key,
+					      const secp256k1_ecdsa_signature *node1_sig, const secp256k1_ecdsa_signature *node2_sig,
+					      const secp256k1_ecdsa_signature *bitcoin1_sig, const secp256k1_ecdsa_signature *bitcoin2_sig,
+					      const u8 *announcement, size_t msg_len);
+const char *sigcheck_node_announcement_len(const tal_t *ctx, const struct node_id *node_id,
+					   const secp256k1_ecdsa_signature *node_sig, const u8 *node_announcement, size_t msg_len);
 
 #ifdef __cplusplus
 }

@@ -350,6 +350,21 @@ extern "C" int secp256k1_ecdsa_recover(const void *, secp256k1_pubkey *pubkey, c
   if (rc != LAMD_OK || !ok) return 0;
   return parse_key(key33, 33, pubkey) ? 1 : 0;
 }
+// common/bolt11.c:1026-1027: drops the recovery id (upstream returns 1 unconditionally)
+extern "C" int secp256k1_ecdsa_recoverable_signature_convert(const void *, secp256k1_ecdsa_signature *sig,
+                                                              const secp256k1_ecdsa_recoverable_signature *sigin) {
+  memcpy(sig->data, sigin->data, 64);
+  return 1;
+}
+// common/bolt11.c:1055, lightningd/dual_open_control.c:2254, bitcoin/signature.c:188: the library call itself
+extern "C" int secp256k1_ecdsa_verify(const void *, const secp256k1_ecdsa_signature *sig, const unsigned char *msghash32,
+                                      const secp256k1_pubkey *pubkey) {
+  struct sha256_double h;
+  memcpy(h.sha.u.u8, msghash32, 32);
+  struct pubkey k;
+  k.pubkey = *pubkey;
+  return check_signed_hash(&h, sig, &k) ? 1 : 0;
+}
 extern "C" void node_id_from_pubkey(struct node_id *id, const struct pubkey *key) { pubkey_to_der(id->k, key); }
 
 extern "C" bool grind_htlc_tx_fee(uint64_t *fee_sat, const u8 *bip143_preimage, size_t preimage_len, const u8 *outputs, size_t outputs_len,
@@ -397,11 +412,14 @@ static std::string der_hex(const secp256k1_ecdsa_signature *sig) {
   out[1] = (u8)(n - 2);
   return hex(out, n);
 }
-static const char *dup(const std::string &s) {
-  char *r = (char *)malloc(s.size() + 1);
-  memcpy(r, s.c_str(), s.size() + 1);
-  return r;
-}
+// The error string is a tal string (the reference: tal_fmt(ctx, ...), gossipd/sigcheck.c:36-41).  In-tree (-DLAMD_SHIM_WITH_CCAN_TAL) it is
+// tal_strdup()ed onto the caller's ctx; stand-alone it is a shim_tal_dup() array the caller owns (shim_tal_free()).
+#if defined(LAMD_SHIM_WITH_CCAN_TAL)
+extern "C" char *tal_strdup_(const tal_t *ctx, const char *p, const char *label);  // ccan/tal/str/str.h:20
+static const char *dup(const tal_t *ctx, const std::string &s) { return tal_strdup_(ctx, s.c_str(), "char[]"); }
+#else
+static const char *dup(const tal_t *ctx, const std::string &s) { return (const char *)shim_tal_dup(ctx, (const u8 *)s.c_str(), s.size() + 1); }
+#endif
 static std::string bad(const char *what, const secp256k1_ecdsa_signature *sig, const u8 *msg, size_t len, size_t off, const char *kind) {
   struct sha256_double h;
   sha256_double(&h, msg + (off < len ? off : len), off < len ? len - off : 0);
@@ -417,31 +435,56 @@ static int device_verdict(const u8 *msg, size_t len, const struct node_id *id) {
   if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return -2; }
   return v;
 }
-extern "C" const char *sigcheck_channel_update(const tal_t *, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
-                                               const u8 *update, size_t len) {
+extern "C" const char *sigcheck_channel_update_len(const tal_t *ctx, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
+                                                   const u8 *update, size_t len) {
   const int v = device_verdict(update, len, node_id);
   if (v == 0) return nullptr;
-  if (v == -2) return dup("engine error: " + g_err);
-  if (v == -1) return dup(std::string("malformed channel_update ") + hex(update, len));  // fromwire_* would have failed earlier
-  return dup(bad("Bad signature for", node_sig, update, len, 66, "channel_update"));
+  if (v == -2) return dup(ctx, "engine error: " + g_err);
+  if (v == -1) return dup(ctx, std::string("malformed channel_update ") + hex(update, len));  // fromwire_* would have failed earlier
+  return dup(ctx, bad("Bad signature for", node_sig, update, len, 66, "channel_update"));
 }
-extern "C" const char *sigcheck_channel_announcement(const tal_t *, const struct node_id *, const struct node_id *, const struct pubkey *,
-                                                     const struct pubkey *, const secp256k1_ecdsa_signature *node1_sig,
-                                                     const secp256k1_ecdsa_signature *node2_sig, const secp256k1_ecdsa_signature *bitcoin1_sig,
-                                                     const secp256k1_ecdsa_signature *bitcoin2_sig, const u8 *announcement, size_t len) {
+extern "C" const char *sigcheck_channel_announcement_len(const tal_t *ctx, const struct node_id *, const struct node_id *, const struct pubkey *,
+                                                         const struct pubkey *, const secp256k1_ecdsa_signature *node1_sig,
+                                                         const secp256k1_ecdsa_signature *node2_sig, const secp256k1_ecdsa_signature *bitcoin1_sig,
+                                                         const secp256k1_ecdsa_signature *bitcoin2_sig, const u8 *announcement, size_t len) {
   const int v = device_verdict(announcement, len, nullptr);
   if (v == 0) return nullptr;
-  if (v == -2) return dup("engine error: " + g_err);
-  if (v == -1) return dup(std::string("malformed channel_announcement ") + hex(announcement, len));  // fromwire_* would have failed earlier
+  if (v == -2) return dup(ctx, "engine error: " + g_err);
+  if (v == -1) return dup(ctx, std::string("malformed channel_announcement ") + hex(announcement, len));  // fromwire_* would have failed earlier
   static const char *names[4] = {"Bad node_signature_1", "Bad node_signature_2", "Bad bitcoin_signature_1", "Bad bitcoin_signature_2"};
   const secp256k1_ecdsa_signature *sigs[4] = {node1_sig, node2_sig, bitcoin1_sig, bitcoin2_sig};
-  return dup(bad(names[v - 1], sigs[v - 1], announcement, len, 258, "channel_announcement"));
+  return dup(ctx, bad(names[v - 1], sigs[v - 1], announcement, len, 258, "channel_announcement"));
 }
-extern "C" const char *sigcheck_node_announcement(const tal_t *, const struct node_id *, const secp256k1_ecdsa_signature *node_sig,
-                                                  const u8 *node_announcement, size_t len) {
+extern "C" const char *sigcheck_node_announcement_len(const tal_t *ctx, const struct node_id *, const secp256k1_ecdsa_signature *node_sig,
+                                                      const u8 *node_announcement, size_t len) {
   const int v = device_verdict(node_announcement, len, nullptr);
   if (v == 0) return nullptr;
-  if (v == -2) return dup("engine error: " + g_err);
-  if (v == -1) return dup(std::string("malformed node_announcement ") + hex(node_announcement, len));
-  return dup(bad("Bad signature for", node_sig, node_announcement, len, 66, "node_announcement"));
+  if (v == -2) return dup(ctx, "engine error: " + g_err);
+  if (v == -1) return dup(ctx, std::string("malformed node_announcement ") + hex(node_announcement, len));
+  return dup(ctx, bad("Bad signature for", node_sig, node_announcement, len, 66, "node_announcement"));
+}
+// ---- the reference's own prototypes (gossipd/sigcheck.h:7-28): the message is a tal array, its length travels with the pointer
+// (tal_count(msg), gossipd/sigcheck.c:30-33,73-76,138-141).  A pointer whose length cannot be read fails closed.
+static const char *not_tal(const tal_t *ctx, const char *kind) { return dup(ctx, std::string("engine error: ") + kind + " is not a tal array"); }
+extern "C" const char *sigcheck_channel_update(const tal_t *ctx, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
+                                               const u8 *update) {
+  const size_t len = shim_tal_bytelen(update);
+  if (len == SHIM_TAL_FOREIGN) return not_tal(ctx, "channel_update");
+  return sigcheck_channel_update_len(ctx, node_id, node_sig, update, len);
+}
+extern "C" const char *sigcheck_channel_announcement(const tal_t *ctx, const struct node_id *node1_id, const struct node_id *node2_id,
+                                                     const struct pubkey *bitcoin1_key, const struct pubkey *bitcoin2_key,
+                                                     const secp256k1_ecdsa_signature *node1_sig, const secp256k1_ecdsa_signature *node2_sig,
+                                                     const secp256k1_ecdsa_signature *bitcoin1_sig, const secp256k1_ecdsa_signature *bitcoin2_sig,
+                                                     const u8 *announcement) {
+  const size_t len = shim_tal_bytelen(announcement);
+  if (len == SHIM_TAL_FOREIGN) return not_tal(ctx, "channel_announcement");
+  return sigcheck_channel_announcement_len(ctx, node1_id, node2_id, bitcoin1_key, bitcoin2_key, node1_sig, node2_sig, bitcoin1_sig, bitcoin2_sig,
+                                           announcement, len);
+}
+extern "C" const char *sigcheck_node_announcement(const tal_t *ctx, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
+                                                  const u8 *node_announcement) {
+  const size_t len = shim_tal_bytelen(node_announcement);
+  if (len == SHIM_TAL_FOREIGN) return not_tal(ctx, "node_announcement");
+  return sigcheck_node_announcement_len(ctx, node_id, node_sig, node_announcement, len);
 }

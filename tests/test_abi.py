@@ -89,11 +89,48 @@ def test_mirror_header_is_installed_and_exported():
     want = ["check_signed_hash", "check_signed_hash_nodeid", "check_schnorr_sig", "check_tx_sig", "sigcheck_channel_update",
             "sigcheck_channel_announcement", "sigcheck_node_announcement", "signature_from_der", "pubkey_from_der",
             "fromwire_secp256k1_ecdsa_signature", "sha256_double", "bolt12_check_signature", "merkle_tlv", "sighash_from_merkle",
-            "shim_tal_dup", "shim_tal_bytelen"]
+            "shim_tal_dup", "shim_tal_bytelen", "sigcheck_channel_update_len", "sigcheck_channel_announcement_len", "sigcheck_node_announcement_len",
+            "secp256k1_ecdsa_verify", "secp256k1_ecdsa_recoverable_signature_convert", "secp256k1_ecdsa_recoverable_signature_parse_compact",
+            "secp256k1_ecdsa_recover"]
     for n in want:
         assert re.search(r"\b%s\s*\(" % n, src), n
         assert hasattr(lib, n), n
     assert not hasattr(lib, "tal_bytelen")
+
+
+def test_mirror_prototypes_equal_the_reference_headers_token_for_token(tmp_path):
+    """the prototypes of the boundary as the reference declares them (harvested into tests/golden/ref_prototypes.json by
+    tests/golden/make_ref_prototypes.py) appear in include/cln_shim.h verbatim modulo white space -- same types, same argument names, no
+    extra argument; with the reference tree present the fixture itself is re-harvested and must be current.  The reference's own
+    unit-test calls compile against the header (tests/c/run_check_channel_announcement.c) and link with the mirror."""
+    import importlib.util
+    import json
+    import subprocess
+    gold = os.path.join(ROOT, "tests", "golden")
+    want = json.load(open(os.path.join(gold, "ref_prototypes.json")))
+    spec = importlib.util.spec_from_file_location("make_ref_prototypes", os.path.join(gold, "make_ref_prototypes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hdr = mod.strip_comments(open(os.path.join(ROOT, "include", "cln_shim.h")).read())
+    for fn in ("check_signed_hash", "check_tx_sig", "check_schnorr_sig", "check_signed_hash_nodeid", "sigcheck_channel_update",
+               "sigcheck_channel_announcement", "sigcheck_node_announcement", "signature_from_der", "pubkey_from_node_id", "sha256_double",
+               "pubkey_from_der", "pubkey_to_der"):
+        assert mod.find(hdr, fn) == want[fn]["prototype"], (fn, mod.find(hdr, fn), want[fn]["prototype"])
+    if os.path.isdir("/root/reference/gossipd"):
+        assert mod.harvest("/root/reference") == want, "tests/golden/ref_prototypes.json is stale: run tests/golden/make_ref_prototypes.py"
+    from lightning_amd import _build
+    _build.build_shim()
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", str(tmp_path / "rcca"),
+                           os.path.join(ROOT, "tests", "c", "run_check_channel_announcement.c"), "-L" + os.path.join(ROOT, "lightning_amd"),
+                           "-llightning_amd_cln", "-llightning_amd", "-Wl,-rpath," + os.path.join(ROOT, "lightning_amd")])
+    if not _have_gpu():   # no device: the mirror fails closed, loudly (exit 3 = lamd_shim_setup() refused), it never says "OK"
+        r = subprocess.run([str(tmp_path / "rcca"), "0100"], capture_output=True, text=True)
+        assert r.returncode == 3 and "no engine" in r.stdout
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
 
 
 def test_gossipd_header_symbols_exported():

@@ -65,8 +65,11 @@ def shim():
     for n in ("pubkey_from_der", "pubkey_from_node_id", "fromwire_secp256k1_ecdsa_signature", "signature_from_der", "check_signed_hash",
               "check_signed_hash_nodeid", "check_schnorr_sig", "check_tx_sig", "lamd_shim_setup"):
         getattr(L, n).restype = ctypes.c_bool
-    for n in ("sigcheck_channel_update", "sigcheck_channel_announcement", "sigcheck_node_announcement", "lamd_shim_last_error"):
-        getattr(L, n).restype = ctypes.c_char_p  # leaks the malloc()ed string; fine in a test
+    for n in ("sigcheck_channel_update", "sigcheck_channel_announcement", "sigcheck_node_announcement", "sigcheck_channel_update_len",
+              "sigcheck_channel_announcement_len", "sigcheck_node_announcement_len", "lamd_shim_last_error"):
+        getattr(L, n).restype = ctypes.c_char_p  # leaks the shim_tal_dup()ed string; fine in a test
+    for n in ("secp256k1_ecdsa_verify", "secp256k1_ecdsa_recoverable_signature_convert"):
+        getattr(L, n).restype = ctypes.c_int
     L.check_tx_sig_preimage.restype = ctypes.c_bool
     L.shim_tal_dup.restype = ctypes.c_void_p
     L.shim_tal_dup.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
@@ -141,9 +144,20 @@ def test_reference_unit_test_expectations(shim, kat):
         keys = [Pubkey() for _ in range(2)]
         for i in range(2):
             assert shim.pubkey_from_der(m[koff + 66 + 33 * i:koff + 99 + 33 * i], 33, ctypes.byref(keys[i]))
-        err = shim.sigcheck_channel_announcement(None, ctypes.byref(ids[0]), ctypes.byref(ids[1]), ctypes.byref(keys[0]), ctypes.byref(keys[1]),
-                                                 ctypes.byref(sigs[0]), ctypes.byref(sigs[1]), ctypes.byref(sigs[2]), ctypes.byref(sigs[3]), m, len(m))
+        err = shim.sigcheck_channel_announcement_len(None, ctypes.byref(ids[0]), ctypes.byref(ids[1]), ctypes.byref(keys[0]), ctypes.byref(keys[1]),
+                                                     ctypes.byref(sigs[0]), ctypes.byref(sigs[1]), ctypes.byref(sigs[2]), ctypes.byref(sigs[3]), m, len(m))
         assert err is not None and needle in err
+        # the reference's own prototype (gossipd/sigcheck.h:15-24): the message is a tal array, no length argument
+        tm = ctypes.c_void_p(shim.shim_tal_dup(None, m, len(m)))
+        err2 = shim.sigcheck_channel_announcement(None, ctypes.byref(ids[0]), ctypes.byref(ids[1]), ctypes.byref(keys[0]), ctypes.byref(keys[1]),
+                                                  ctypes.byref(sigs[0]), ctypes.byref(sigs[1]), ctypes.byref(sigs[2]), ctypes.byref(sigs[3]), tm)
+        assert err2 == err
+        # a pointer that is not a tal array fails closed -- never "OK"
+        foreign = ctypes.create_string_buffer(bytes(32) + m)
+        err3 = shim.sigcheck_channel_announcement(None, ctypes.byref(ids[0]), ctypes.byref(ids[1]), ctypes.byref(keys[0]), ctypes.byref(keys[1]),
+                                                  ctypes.byref(sigs[0]), ctypes.byref(sigs[1]), ctypes.byref(sigs[2]), ctypes.byref(sigs[3]),
+                                                  ctypes.byref(foreign, 32))
+        assert err3 is not None and b"not a tal array" in err3
         if name == "KAT-G/orig":
             # the exact text quoted at the top of the reference's test file
             assert err.startswith(b"Bad node_signature_1 3044022011effc9ed10fceccfae5f9e3fef20d983b06eed030e968fd8d1e6c5905e18f9f02202df6a43f00d7c0ddf52e0467ab1e32394051b72ea6343fb008a4117c265f3d7b "
@@ -227,11 +241,69 @@ def test_reference_unit_test_expectations(shim, kat):
     m = H(cu["msg"])
     sg = Sig()
     assert shim.fromwire_secp256k1_ecdsa_signature(m[2:66], ctypes.byref(sg))
-    err = shim.sigcheck_channel_update(None, ctypes.byref(NodeId.from_buffer_copy(H(cu["node_id"]))), ctypes.byref(sg), m, len(m))
+    err = shim.sigcheck_channel_update_len(None, ctypes.byref(NodeId.from_buffer_copy(H(cu["node_id"]))), ctypes.byref(sg), m, len(m))
     assert err.startswith(b"Bad signature for 30") and b" on channel_update 0102" in err  # tests/test_gossip.py:2001 greps "Bad signature"
+    tm = ctypes.c_void_p(shim.shim_tal_dup(None, m, len(m)))
+    assert shim.sigcheck_channel_update(None, ctypes.byref(NodeId.from_buffer_copy(H(cu["node_id"]))), ctypes.byref(sg), tm) == err
     ok = next(v for v in kat["gossip"] if v["name"] == "nann/ok/0")
     m = H(ok["msg"])
-    assert shim.sigcheck_node_announcement(None, None, ctypes.byref(sg), m, len(m)) is None
+    assert shim.sigcheck_node_announcement_len(None, None, ctypes.byref(sg), m, len(m)) is None
+    assert shim.sigcheck_node_announcement(None, None, ctypes.byref(sg), ctypes.c_void_p(shim.shim_tal_dup(None, m, len(m)))) is None
+
+
+@pytest.mark.gpu
+def test_reference_unit_test_calls_compile_unchanged_and_give_the_reference_strings(kat, tmp_path):
+    """gossipd/test/run-check_channel_announcement.c:77-85,100-108 -- the two call statements as they stand there, compiled against
+    include/cln_shim.h (tests/c/run_check_channel_announcement.c) and linked with the mirror: "Bad node_signature_1" for the message as
+    received, "Bad node_signature_2" once the features are stripped and the message re-serialised (the reference's assertions)"""
+    import subprocess
+    from lightning_amd import _build
+    _build.build_shim()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "rcca"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), "-o", str(exe),
+                           os.path.join(root, "tests", "c", "run_check_channel_announcement.c"), "-L" + os.path.join(root, "lightning_amd"),
+                           "-llightning_amd_cln", "-llightning_amd", "-Wl,-rpath," + os.path.join(root, "lightning_amd")])
+    msg = next(v for v in kat["gossip"] if v["name"] == "KAT-G/orig")["msg"]
+    r = subprocess.run([str(exe), msg], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("Bad node_signature_1 3044022011effc9ed10fceccfae5f9e3fef20d983b06eed030e968fd8d1e6c5905e18f9f02202df6a43f00d7c0ddf52e0467ab1e32394051b72ea6343fb008a4117c265f3d7b "
+                               "hash bb92b8f45b48e65ad2f2cfff2242fa921b4cf46f709a372ca7788537e89d9de1 on channel_announcement 010011effc9ed10f")
+    assert lines[1].startswith("Bad node_signature_2 30440220732bab7df4ee404ac926aef6610f4eb33e31baabfd9afdbf897c8a80057efa14022068362b4d2cc0a5482013e1058c8205717f85c3bc82c3ea89f17cfeac21e2cb2a "
+                               "hash 59e255d34a96fa25dc666ecee7f2d70aefd34cb39170fe4246ba6328fabcc85b on channel_announcement 0100")
+
+
+@pytest.mark.gpu
+def test_libsecp_names_of_the_bolt11_n_field_path(shim, kat):
+    """common/bolt11.c:1021-1057 with an `n` field: parse_compact -> convert -> secp256k1_ecdsa_verify(ctx, &sig, hash, &key) -- the
+    reference's own invoice vectors (common/test/run-bolt11.c): the converted signature verifies under the key recovery yields, and
+    neither under another key nor with one hash bit flipped; lightningd/dual_open_control.c:2254 makes the same raw call"""
+    assert shim.lamd_shim_setup(), shim.lamd_shim_last_error()
+
+    class RecSig(ctypes.Structure):
+        _fields_ = [("data", ctypes.c_ubyte * 65)]
+    HALF_N = 0x7FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF5D576E7357A4501DDFE92F46681B20A0
+    distinct, n_checked = {}, 0
+    for v in kat["recover"]:
+        if not v["expect"] or not (v["name"].startswith("KAT-B11R") or v["name"].startswith("KAT-SIGNMSG")):
+            continue
+        rs, sg, pk = RecSig(), Sig(), Pubkey()
+        assert shim.secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"]) == 1
+        assert shim.secp256k1_ecdsa_recoverable_signature_convert(None, ctypes.byref(sg), ctypes.byref(rs)) == 1
+        assert bytes(sg.data) == H(v["sig"])
+        assert shim.pubkey_from_der(H(v["expect"]), 33, ctypes.byref(pk))
+        h = H(v["hash"])
+        # secp256k1_ecdsa_verify accepts low-S signatures only (bitcoin/signature.c:185-187); recovery has no such rule
+        low_s = int.from_bytes(H(v["sig"])[32:], "big") <= HALF_N
+        assert shim.secp256k1_ecdsa_verify(None, ctypes.byref(sg), h, ctypes.byref(pk)) == (1 if low_s else 0), v["name"]
+        assert shim.secp256k1_ecdsa_verify(None, ctypes.byref(sg), bytes([h[0] ^ 1]) + h[1:], ctypes.byref(pk)) == 0, v["name"]
+        n_checked += low_s
+        distinct.setdefault(bytes(pk.data), (sg, h, pk))
+    assert n_checked >= 12
+    ds = list(distinct.values())
+    for a, b in zip(ds, ds[1:]):      # under another signer's key nothing verifies
+        assert shim.secp256k1_ecdsa_verify(None, ctypes.byref(a[0]), a[1], ctypes.byref(b[2])) == 0
 
 
 @pytest.mark.gpu
