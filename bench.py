@@ -8,9 +8,10 @@ when the timed region starts; every rank processes its own 2 M-row batch (weak s
 data-path collective); with more than one rank the verdict vectors are all-gathered over RCCL
 inside the timed region, as the north star asks.
 
-    python bench.py                       # = --gpus 1 --steps 20 --warmup 3
+    python bench.py                       # = --gpus 1 --steps 250 --warmup 5 (a timed region of ~2 s)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N              # without RANK in the environment: re-executes itself under torch.distributed.run
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (HIP-event
 timing of the dominant kernel, k_ecmult) and `cpu_baseline` (the CPU oracle on a bounded sample
@@ -141,16 +142,28 @@ def sharded_configs(eng, rank, world, device, tstream):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=1_000_000, help="rows per kind per rank (1 M = BASELINE configs[1], [2])")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows per kind timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--skip-extra", action="store_true", help="skip the cfg4/cfg5 single-GPU data points")
     ap.add_argument("--roofline-only", action="store_true",
-                    help="only the cold timed loop and the isolated calls: every k_ecmult_keyed launch of the process covers a full batch, so the "
-                         "average of `rocprofv3 --kernel-trace --stats` over this command is directly comparable with roofline.avg_launch_ms")
+                    help="ONLY the loop `roofline.frac` is computed from (the cold loop with chained ecmult launches, warm-up + steps): every "
+                         "k_ecmult_keyed<false, 3> launch of the process is one of that loop's, so the per-kernel average of `rocprofv3 "
+                         "--kernel-trace --stats` over this command is directly comparable with roofline.avg_launch_ms")
+    ap.add_argument("--steady-steps", type=int, default=250,
+                    help="when --steps gives a timed region under ~1 s: steps of an extra, longer cold loop reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # a plain `python bench.py --gpus N`: become the launcher -- one process per GPU over RCCL, rendezvous on 127.0.0.1
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     # stdout carries exactly ONE line, the JSON: everything libraries print there (RCCL's version banner on the first
     # collective) goes to stderr instead
     json_fd = os.dup(1)
@@ -295,27 +308,54 @@ def main():
         bad = int((got[0] != we.expect.astype(np.uint8)).sum() + (got[1] != ws.expect.astype(np.uint8)).sum())
         return dt, bad
 
+    def rows_per_kind(eng):
+        # rows the table-driven launch of the last call of each kind really carried (rows whose signature scalars are certain to fail the
+        # preparation were rejected by the row-list builders, rows under rare / unparsable keys went to the ladder list)
+        r = {}
+        for lane in range(eng.info()["lanes"]):
+            inf = eng.info(lane)
+            if inf["last_hot_rows"]:
+                r[int(inf["last_mode"])] = int(inf["last_hot_rows"])
+        return r
+
     # the headline first: cold, every table rebuilt in every call
     full = not args.roofline_only
-    dt, mism_cold = timed(eng_cold)
-    record_kernel_times(eng_cold)
-    # the same cold loop once more with the large ecmult launches chained one after the other (lamd_set_ecmult_chain): the in-loop launch
-    # duration of the dominant kernel when its only company is the other lanes' front end -- reported as roofline.chained, never as `value`
+    dt, mism_cold, steady = float("nan"), 0, None
+    if full:
+        dt, mism_cold = timed(eng_cold)
+        record_kernel_times(eng_cold)
+        if args.steady_steps > 0 and dt < 1.0 and not multi:
+            # the driver's --steps 20 is a 0.17 s region: the same loop once more over a region of seconds, reported beside `value`
+            k_steps, args.steps = args.steps, args.steady_steps
+            dt_st, mism_st = timed(eng_cold)
+            args.steps = k_steps
+            steady = {"value": world * 2 * n * args.steady_steps / dt_st, "unit": "verifies/s", "steps": args.steady_steps, "seconds": dt_st,
+                      "ms_per_step": dt_st / args.steady_steps * 1e3, "mismatches": mism_st,
+                      "note": "the timed loop of `value` again over a region of seconds (box-to-box spread of the short region: +-3 %)"}
+            mism_cold += mism_st
+    # THE ROOFLINE LOOP: the same cold loop with the large ecmult launches chained one after the other (lamd_set_ecmult_chain): ONE such launch in
+    # flight at any time, in the company of the other lanes' front-end kernels only, so the HIP-event pair around a launch brackets that launch
+    # (in the default mode two or three of them overlap and every bracket measures its neighbours too).  roofline.frac comes from here; `value`
+    # from the default mode above (2-3 % more throughput: the tail of one launch filled by the head of the next).
     chained = None
     if not multi:
-        lm_cold = launch_ms[id(eng_cold)]
+        lm_cold = launch_ms.get(id(eng_cold))
         eng_cold.set_ecmult_chain(True)
         dt_ch, mism_ch = timed(eng_cold)
+        chained = {"dt": dt_ch, "mismatches": mism_ch, "lm": launch_ms[id(eng_cold)], "rows": rows_per_kind(eng_cold)}
+        if not full:
+            record_kernel_times(eng_cold)
+            dt = dt_ch
         eng_cold.set_ecmult_chain(False)
-        chained = (dt_ch, mism_ch, launch_ms[id(eng_cold)])
-        launch_ms[id(eng_cold)] = lm_cold
+        if lm_cold is not None:
+            launch_ms[id(eng_cold)] = lm_cold
         mism_cold += mism_ch
     eng_default, eng = eng, eng_cold      # the isolated launch durations below are the cold engine's too
     # the same kernels once more, one call at a time (nothing else on the GPU): the isolated durations
     isolated = {"ecdsa": [], "schnorr": []}
     eng.set_timing(True)
     rows_in_launch = n
-    for _ in range(2):
+    for _ in range(2 if full else 0):
         eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
         eng.synchronize()
         isolated["ecdsa"].append(eng.info()["last_kernel_ms"])
@@ -326,7 +366,10 @@ def main():
         eng.synchronize()
         isolated["schnorr"].append(eng.info()["last_kernel_ms"])
     iso_launch = [sum(eng.info(l)["keyed_ecmult_ms_sum"][m] for l in range(eng.info()["lanes"])) /
-                  max(1, sum(eng.info(l)["keyed_ecmult_launches"][m] for l in range(eng.info()["lanes"]))) for m in (0, 1)]
+                  max(1, sum(eng.info(l)["keyed_ecmult_launches"][m] for l in range(eng.info()["lanes"]))) for m in (0, 1)] if full else [0.0, 0.0]
+    if not full:
+        rows_in_launch = (chained or {}).get("rows", {}).get(0, n)
+        isolated = {k: [[float("nan")] * 4] for k in isolated}
     # now the default engine (key-table cache on) and its warm loop: after the warm-up steps every key of the repeated batch is a cache hit
     if full and not multi:
         eng_default = Engine(local_rank)
@@ -344,7 +387,7 @@ def main():
     # the isolated calls just made
     got_e = we.d_ok.cpu().numpy().astype(bool)
     got_s = ws.d_ok.cpu().numpy().astype(bool)
-    mism_iso = int((got_e != we.expect).sum() + (got_s != ws.expect).sum())
+    mism_iso = int((got_e != we.expect).sum() + (got_s != ws.expect).sum()) if full else 0
     mism = mism_iso + mism_cold + mism_warm
     if multi:
         # every rank must hold every other rank's verdicts after the all-gather
@@ -365,34 +408,60 @@ def main():
     if rank == 0:
         total = world * 2 * n * args.steps
         value = total / dt
-        ke = np.mean(np.array(kernel_ms["ecdsa"]), axis=0)      # prep, keys, ecmult [ms]
-        ks = np.mean(np.array(kernel_ms["schnorr"]), axis=0)
-        # the dominant kernel's average launch duration over the timed (cold) region: event pair right around each launch
-        lm = launch_ms[id(eng_cold)]
-        if lm[0][1]:
-            t_ecmult = lm[0][0] / lm[0][1] * 1e-3
-        else:                       # no table-driven launch (LAMD_KEYED=0): the wide bracket of the last step
-            t_ecmult = ke[2] * 1e-3
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch come from separate rocprofv3 --pmc passes of this same command (tools/pmc_run.sh)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_ecmult_ecdsa_1M"]
-            if n == 1_000_000:
-                traffic, traffic_src = pm["hbm_bytes_per_launch"], pm["source"]
-        except Exception:
-            pass
+        # ---- roofline of the dominant kernel, k_ecmult_keyed<false, 3>.  Numerator: the 32x32->64 multiply-adds the kernel's
+        # algorithm EXECUTES per row (W_EXEC) x the rows its launches carried.  Denominator: the average duration of those launches, HIP events
+        # on the launching lane's stream right around every one of them, in the CHAINED loop (one such launch in flight at a time: the brackets do
+        # not overlap, their sum per step is below the step time, and `rocprofv3 --kernel-trace --stats -- python bench.py --roofline-only`
+        # -- the same loop and nothing else -- gives the same per-kernel average: profiles/).  ECDSA and BIP-340 launches are the same kernel
+        # (their acceptance tests differ by two field multiplications of ~650), so the average is over both kinds, as rocprofv3's is.
         teeth = int(keyed.get("ecdsa", (0, 0))[0])
         w_exec = W_EXEC.get(teeth, W_EXEC[0])
-        iso_ms = iso_launch[0] or float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2])
-        achieved = w_exec * rows_in_launch / t_ecmult
-        algo_bytes = BYTES_ECDSA65 * n
+        lm_ov = launch_ms.get(id(eng_cold)) if full else None          # default mode (the launches overlap): reported, never the roofline
+        pipeline = {"ms": dt / args.steps * 1e3, "achieved": 2 * w_exec * rows_in_launch / (dt / args.steps) / 1e12,
+                    "frac": 2 * w_exec * rows_in_launch / (dt / args.steps) / P_MUL32,
+                    "note": "both table-driven launches' executed multiply-adds of a step / the step time of the loop `value` is measured on (everything "
+                            "else a step does -- key tables, scalar preparation, de-duplication -- counts as lost time here)"}
+        if chained is not None and chained["lm"][0][1] + chained["lm"][1][1]:
+            cl = chained["lm"]
+            n_l = int(cl[0][1] + cl[1][1])
+            t_ecmult = (cl[0][0] + cl[1][0]) / n_l * 1e-3                 # seconds per launch, both kinds
+            rows_k = [chained["rows"].get(m, rows_in_launch) for m in (0, 1)]
+            rows_avg = (rows_k[0] * cl[0][1] + rows_k[1] * cl[1][1]) / n_l
+            sum_per_step = (cl[0][0] + cl[1][0]) / args.steps
+            roof_mode = {"mode": "chained", "launches_timed": n_l, "avg_launch_ms": t_ecmult * 1e3,
+                         "avg_launch_ms_ecdsa": cl[0][0] / cl[0][1] if cl[0][1] else None, "avg_launch_ms_schnorr": cl[1][0] / cl[1][1] if cl[1][1] else None,
+                         "rows_in_launch": rows_avg, "rows_in_launch_by_kind": {"ecdsa": rows_k[0], "schnorr": rows_k[1]},
+                         "sum_of_launch_ms_per_step": sum_per_step, "ms_per_step": chained["dt"] / args.steps * 1e3,
+                         "sum_of_launches_le_step": bool(sum_per_step <= chained["dt"] / args.steps * 1e3),
+                         "verifies_per_s": world * 2 * n * args.steps / chained["dt"], "mismatches": chained["mismatches"]}
+            achieved = w_exec * rows_avg / t_ecmult
+        else:
+            # no chained loop (collective path: more than one rank): the pipeline figure, which needs no per-launch bracket
+            t_ecmult, rows_avg = dt / args.steps / 2, rows_in_launch
+            roof_mode = {"mode": "pipeline", "launches_timed": 2 * args.steps, "avg_launch_ms": t_ecmult * 1e3, "rows_in_launch": rows_avg,
+                         "sum_of_launch_ms_per_step": dt / args.steps * 1e3, "ms_per_step": dt / args.steps * 1e3, "sum_of_launches_le_step": True}
+            achieved = w_exec * rows_avg / t_ecmult
+        # HBM traffic per launch: separate rocprofv3 --pmc passes of the roofline loop (tools/pmc_run.sh -> profiles/pmc_latest.json).  FETCH_SIZE on
+        # gfx950 counts memory-side read requests at 64 B each; for this kernel's access pattern (49 random table entries of 64-96 B per row) the
+        # counter is calibrated on a gather of known size (tools/microbench.hip `gather`; factor and source in pmc_latest.json)
+        traffic = traffic_raw = traffic_src = fetch_factor = None
         valu_issue = None
         try:
-            pmk = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_ecmult_ecdsa_1M"]
-            valu_issue = {"wave_instr_per_simd_cycle": pmk["valu_issue_per_simd_cycle"], "saturated_at": 0.25,
-                          "frac": pmk["valu_issue_per_simd_cycle"] / 0.25, "valu_instr_per_verify": pmk["valu_insts_per_verify"],
-                          "source": pmk["source"]}
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_ecmult_ecdsa_1M"]
+            if n == 1_000_000:
+                fetch_factor = float(pm.get("fetch_size_factor", 1.0))
+                traffic_raw = pm["hbm_bytes_per_launch"]
+                traffic = (pm["fetch_kib"] * fetch_factor + pm["write_kib"]) * 1024.0
+                traffic_src = pm["source"]
+            valu_issue = {"wave_instr_per_simd_cycle": pm["valu_issue_per_simd_cycle"], "saturated_at": 0.25,
+                          "frac": pm["valu_issue_per_simd_cycle"] / 0.25, "valu_instr_per_verify": pm["valu_insts_per_verify"],
+                          "source": pm["source"]}
         except Exception:
             pass
+        iso_ms = iso_launch[0] or float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2])
+        algo_bytes = BYTES_ECDSA65 * n
+        ke = np.mean(np.array(kernel_ms["ecdsa"]), axis=0)      # prep, keys, ecmult [ms]
+        ks = np.mean(np.array(kernel_ms["schnorr"]), axis=0)
         out = {
             "metric": "signature verifies/sec (ECDSA+Schnorr mix)", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -401,7 +470,10 @@ def main():
             "config": {"workload": "configs[1]+configs[2]: %d ECDSA (65-byte keys, 65536 distinct) + %d BIP-340 Schnorr per GPU per step, "
                                    "90%% valid / 10%% invalid, inputs resident in HBM" % (n, n),
                        "rows_per_gpu_per_step": 2 * n, "parallelism": "shard-by-row x%d, RCCL all-gather of verdicts" % world,
-                       "key_table_cache": "off for `value` (tables rebuilt every call); on for `warm_cache`"},
+                       "key_table_cache": "off for `value` (tables rebuilt every call); on for `warm_cache`",
+                       "timed_loop": "default scheduling (large ecmult launches of successive calls may overlap)" if full else
+                                     "--roofline-only: the chained loop (this line's `value` is that loop's)"},
+            "steady_state": steady,
             "rates": {"ecdsa65_verifies_per_s_1gpu": n / (ke.sum() * 1e-3), "schnorr_verifies_per_s_1gpu": n / (ks.sum() * 1e-3),
                       "kernel_ms_ecdsa": {"prep": ke[0], "keys_and_tables": ke[1], "ecmult": ke[2], "parity_stage": ke[3]},
                       "kernel_ms_schnorr": {"prep": ks[0], "keys_and_tables": ks[1], "ecmult": ks[2], "parity_stage": ks[3]},
@@ -411,56 +483,49 @@ def main():
                       "kernel_ms_ecdsa_isolated": dict(zip(("prep", "keys_and_tables", "ecmult", "parity_stage"), np.mean(np.array(isolated["ecdsa"]), axis=0).tolist())),
                       "kernel_ms_schnorr_isolated": dict(zip(("prep", "keys_and_tables", "ecmult", "parity_stage"), np.mean(np.array(isolated["schnorr"]), axis=0).tolist())),
                       "keyed_path": {k: {"per_key_tables": bool(v[0]), "distinct_keys": int(v[1])} for k, v in keyed.items()}},
-            "roofline": {"kernel": "%s (ECDSA launch, %d signatures)" % ("k_ecmult_keyed<%d, bare formulas>" % teeth if teeth else "k_ecmult", n),
-                         "bound": "valu-int32-mul (not hbm, not mfma)",
-                         # achieved = multiply-adds this kernel's algorithm executes per launch / its HIP-event duration in the timed region
-                         "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
-                         "executed_mul32_per_verify": w_exec, "rows_in_launch": rows_in_launch,
-                         "rows_note": "of the batch's %d rows: the others were decided before the ecmult (early reject of signatures whose scalars cannot pass "
-                                      "the preparation: r, s range and low-S; keys that do not parse; rows under rare keys take the ladder kernel)" % n,
-                         "avg_launch_ms": t_ecmult * 1e3, "launches_timed": int(lm[0][1]),
-                         "avg_launch_ms_schnorr": (lm[1][0] / lm[1][1]) if lm[1][1] else None,
-                         "avg_launch_ms_both_kinds": ((lm[0][0] + lm[1][0]) / (lm[0][1] + lm[1][1])) if lm[0][1] + lm[1][1] else None,
-                         "timing": "HIP event pair recorded on the launching lane's stream right before and after every k_ecmult_keyed launch of the "
-                                   "timed steps.  These in-loop brackets OVERLAP: 1.1-1.5 such launches are in flight at any time plus the other lanes' "
-                                   "front ends, so sum(launch durations) > step time and `frac` understates what the kernel does with the chip to itself; "
-                                   "`frac_isolated` (one call at a time, same process) and `pipeline.frac` (both launches' work / step time) are the clean figures",
-                         "frac_isolated": w_exec * rows_in_launch / (iso_ms * 1e-3) / P_MUL32,
-                         "sum_of_launch_ms_per_step": ((lm[0][0] + lm[1][0]) / args.steps) if args.steps else None,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                         "traffic_source": traffic_src,
-                         # in the timed region the kernel shares the chip with the other lane's front end (de-duplication, table building,
-                         # scalar prep), which stretches its launch; alone (one call at a time, measured right after the timed region):
-                         "isolated": {"launch_ms": iso_ms, "launch_ms_schnorr": iso_launch[1] or None,
-                                      "achieved": w_exec * rows_in_launch / (iso_ms * 1e-3) / 1e12, "frac": w_exec * rows_in_launch / (iso_ms * 1e-3) / P_MUL32},
-                         # the multiplier instructions are about half of the kernel's VALU instructions and the VALU issue port is the limit
-                         "valu_issue": valu_issue,
-                         # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time:
-                         # exceeds the executed figure because the comb tables and the 22-bit G windows need fewer multiplications
-                         # NOT a utilisation figure (the kernel executes 2.2x fewer multiplies than the yardstick's generic algorithm, so the
-                         # ratio to peak would exceed 1 on the isolated launch): reported as a rate only
-                         "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "yardstick_Tmul32_per_s_in_loop": W_ECDSA65 * n / t_ecmult / 1e12,
-                                              "note": "rate at which SURVEY 8(d)'s generic-algorithm multiplies would have to run to finish in the same time; not a fraction of peak"},
-                         # whole timed step: the ecmult work of both batches against the step time (the rest of the step builds key tables,
-                         # prepares scalars and de-duplicates keys)
-                         "chained": None if chained is None or not chained[2][0][1] else {
-                             "avg_launch_ms": chained[2][0][0] / chained[2][0][1], "launches_timed": int(chained[2][0][1]),
-                             "frac": w_exec * rows_in_launch / (chained[2][0][0] / chained[2][0][1] * 1e-3) / P_MUL32,
-                             "verifies_per_s": world * 2 * n * args.steps / chained[0], "ms_per_step": chained[0] / args.steps * 1e3, "mismatches": chained[1],
-                             "note": "the same cold loop with lamd_set_ecmult_chain(1): a large ecmult launch waits for the one submitted before it, so the "
-                                     "in-loop bracket holds ONE such launch plus the other lanes' front-end kernels (the default lets two overlap: higher "
-                                     "throughput, each launch stretched by its neighbour)"},
-                         "pipeline": {"ms": dt / args.steps * 1e3, "achieved": 2 * w_exec * rows_in_launch / (dt / args.steps) / 1e12,
-                                      "frac": 2 * w_exec * rows_in_launch / (dt / args.steps) / P_MUL32},
-                         "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,
-                                 "peak_GBs": HBM_PEAK_GBS, "frac": algo_bytes / t_ecmult / 1e9 / HBM_PEAK_GBS}},
+            "roofline": dict(roof_mode, **{
+                "kernel": "%s (1 M-row ECDSA-65 / BIP-340 launches)" % ("k_ecmult_keyed<false, 3>: %d-tooth signed comb, bare formulas" % teeth if teeth else "k_ecmult"),
+                "bound": "valu-int32-mul (not hbm, not mfma)",
+                "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
+                "executed_mul32_per_verify": w_exec,
+                "rows_note": "of a batch's %d rows: the others were decided before the ecmult (early reject of signatures whose scalars cannot pass "
+                             "the preparation: r, s range and low-S; keys that do not parse; rows under rare keys take the ladder kernel)" % n,
+                "timing": "HIP event pair on the launching lane's stream right before and after every k_ecmult_keyed<false, 3> launch of the timed "
+                          "steps of the CHAINED cold loop (lamd_set_ecmult_chain(1): a launch waits for the one submitted before it, so ONE is in flight "
+                          "at a time and a bracket holds that launch plus the other lanes' front-end kernels).  `rocprofv3 --kernel-trace --stats -- "
+                          "python bench.py --roofline-only` runs this loop only: its per-kernel average is the same quantity",
+                "frac_isolated": (w_exec * rows_in_launch / (iso_ms * 1e-3) / P_MUL32) if full else None,
+                "isolated": None if not full else {
+                    "launch_ms": iso_ms, "launch_ms_schnorr": iso_launch[1] or None,
+                    "achieved": w_exec * rows_in_launch / (iso_ms * 1e-3) / 1e12, "frac": w_exec * rows_in_launch / (iso_ms * 1e-3) / P_MUL32,
+                    "note": "one call at a time, nothing else on the GPU (measured right after the timed loops)"},
+                "overlapped": None if not (lm_ov and lm_ov[0][1]) else {
+                    "avg_launch_ms": lm_ov[0][0] / lm_ov[0][1], "avg_launch_ms_schnorr": (lm_ov[1][0] / lm_ov[1][1]) if lm_ov[1][1] else None,
+                    "sum_of_launch_ms_per_step": (lm_ov[0][0] + lm_ov[1][0]) / args.steps,
+                    "note": "the same brackets in the DEFAULT mode (the loop `value` is measured on): 1.1-1.5 such launches are in flight at any time, every "
+                            "bracket holds its neighbours' share too and their sum exceeds the step time -- not a kernel duration, kept for comparison with "
+                            "earlier rounds (r03 reported this as roofline.avg_launch_ms)"},
+                "pipeline": pipeline,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                "traffic_detail": None if traffic is None else {"fetch_size_factor": fetch_factor, "uncorrected_bytes": traffic_raw,
+                                                               "achieved_TBs_at_avg_launch": traffic / t_ecmult / 1e12, "hbm_peak_frac": traffic / t_ecmult / 1e9 / HBM_PEAK_GBS},
+                "traffic_source": traffic_src,
+                # the multiplier instructions are 60 % of the kernel's VALU instructions and the VALU issue port is the limit
+                "valu_issue": valu_issue,
+                # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time: NOT a
+                # utilisation figure (the combs execute 2.2x fewer multiplies than the yardstick's generic algorithm)
+                "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "yardstick_Tmul32_per_s_in_loop": W_ECDSA65 * n / t_ecmult / 1e12,
+                                     "note": "rate at which SURVEY 8(d)'s generic-algorithm multiplies would have to run to finish in the same time; not a fraction of peak"},
+                "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,
+                        "peak_GBs": HBM_PEAK_GBS, "frac": algo_bytes / t_ecmult / 1e9 / HBM_PEAK_GBS}}),
             "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "mismatches_by_leg": {"cold_loop": mism_cold, "warm_loop": mism_warm, "isolated_calls": mism_iso},
                        "against": "verdicts known by construction (all rows; the last timed step of "
                        "both loops writes into poisoned verdict buffers)"},
             # `value` above is COLD: every call builds the comb tables of its keys again (LAMD_CACHE=0), as a stateless library
             # would.  With the key-table cache (the default for serving: gossip node ids and channel keys recur) the same loop is
             "warm_cache": {"value": world * 2 * n * args.steps / dt_warm, "unit": "verifies/s", "ms_per_step": dt_warm / args.steps * 1e3,
-                           "note": "same 20-step loop on an engine with the key-table cache on: after the warm-up steps every key of this repeated "
+                           "note": "same timed loop on an engine with the key-table cache on: after the warm-up steps every key of this repeated "
                                    "synthetic batch is a cache hit (no table is built) -- an upper bound for serving, not the headline",
                            "cache_hits_last_call": [int(i["last_cache_hits"]) for i in warm_info], "new_tables_last_call": [int(i["last_new_tables"]) for i in warm_info],
                            "comb_teeth_last_call": [int(i["last_keyed"]) for i in warm_info]},
@@ -837,6 +902,10 @@ def main():
             out["other_configs_1gpu"] = extra
             mism += gm + sm
         if args.cpu_sample > 0 and world == 1 and full:   # the CPU baseline is a rank-0, N=1 leg
+            # C0 = the reference's real CPU path (libsecp256k1 through dlopen, called as bitcoin/signature.c:188,425 call it) if this
+            # machine has the library -- else "unavailable"; C1 = the restated C oracle, 1 thread and all cores; C2 = OpenSSL ECDSA_do_verify +
+            # libsecp256k1's range / low-S rules, 1 thread.  Monotonic clock around each whole batch, verifies/s and ns per verification (the shape
+            # of onchaind/test/run-grind_feerate.c:146-154).  Every leg's verdicts must equal the GPU's on the rows it was given.
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import orc  # test infrastructure: the checker / CPU baseline only
             m = min(args.cpu_sample, n)
@@ -847,19 +916,55 @@ def main():
                     cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
             except Exception:
                 pass
-            c = [np.ascontiguousarray(x[:m]) for x in we.cols]
-            orc.ecdsa_verify_batch(c[0][:64], c[1][:64], c[2][:64], 65, cores)  # table init outside the timed part
-            t1 = time.perf_counter()
-            ce = orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, cores).astype(bool)
-            t2 = time.perf_counter()
-            c = [np.ascontiguousarray(x[:m]) for x in ws.cols]
-            cs = orc.schnorr_verify_batch(c[0], c[1], c[2], cores).astype(bool)
-            t3 = time.perf_counter()
-            cm = int((ce != got_e[:m]).sum() + (cs != got_s[:m]).sum())
-            out["cpu_baseline"] = {"value": 2 * m / (t3 - t1), "unit": "verifies/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d ECDSA + first %d Schnorr rows of rank 0's batch, OpenMP over all host cores; "
-                                             "restated C oracle (oracle/secp256k1_oracle.c), NOT libsecp256k1 (absent from the reference tree)" % (m, m),
-                                   "ecdsa_verifies_per_s": m / (t2 - t1), "schnorr_verifies_per_s": m / (t3 - t2),
+            ce_cols = [np.ascontiguousarray(x[:m]) for x in we.cols]
+            cs_cols = [np.ascontiguousarray(x[:m]) for x in ws.cols]
+
+            def leg(fn_e, fn_s, rows_e, rows_s):
+                """-> (dict, verdict mismatches against the GPU)"""
+                t1 = time.perf_counter()
+                ve = fn_e([c[:rows_e] for c in ce_cols]) if fn_e and rows_e else None
+                t2 = time.perf_counter()
+                vs = fn_s([c[:rows_s] for c in cs_cols]) if fn_s and rows_s else None
+                t3 = time.perf_counter()
+                bad = 0
+                d = {}
+                if ve is not None:
+                    bad += int((ve.astype(bool) != got_e[:rows_e]).sum())
+                    d.update(ecdsa_rows=rows_e, ecdsa_verifies_per_s=rows_e / (t2 - t1), ecdsa_ns_per_verify=(t2 - t1) / rows_e * 1e9)
+                if vs is not None:
+                    bad += int((vs.astype(bool) != got_s[:rows_s]).sum())
+                    d.update(schnorr_rows=rows_s, schnorr_verifies_per_s=rows_s / (t3 - t2), schnorr_ns_per_verify=(t3 - t2) / rows_s * 1e9)
+                rows = (rows_e if ve is not None else 0) + (rows_s if vs is not None else 0)
+                secs = (t2 - t1 if ve is not None else 0) + (t3 - t2 if vs is not None else 0)
+                d.update(value=rows / secs if secs else None, seconds=secs, gpu_vs_cpu_verdict_mismatches=bad)
+                return d, bad
+            orc.ecdsa_verify_batch(ce_cols[0][:64], ce_cols[1][:64], ce_cols[2][:64], 65, cores)  # table init outside the timed part
+            legs = {}
+            one = max(1, min(m, 20_000))
+            legs["C1_oracle_1_thread"], b1 = leg(lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, 1), lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], 1), one, one)
+            legs["C1_oracle_all_cores"], b2 = leg(lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, cores), lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], cores), m, m)
+            legs["C1_oracle_1_thread"]["threads"], legs["C1_oracle_all_cores"]["threads"] = 1, cores
+            ossl_rows = max(1, min(m, 10_000))
+            legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"], b3 = leg(lambda c: orc.ossl_ecdsa_verify_rules_batch(c[0], c[1], c[2], 65), None, ossl_rows, 0)
+            legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"]["threads"] = 1
+            secp = orc.libsecp_available()
+            if secp:
+                legs["C0_libsecp256k1_1_thread"], b0 = leg(lambda c: orc.libsecp_ecdsa_verify_batch(c[0], c[1], c[2], 65),
+                                                           lambda c: orc.libsecp_schnorr_verify_batch(c[0], c[1], c[2]), min(m, 100_000), min(m, 100_000))
+                legs["C0_libsecp256k1_1_thread"].update(threads=1, library=secp)
+            else:
+                legs["C0_libsecp256k1_1_thread"], b0 = "unavailable: no libsecp256k1.so can be dlopen()ed on this node (the reference's copy is an empty submodule)", 0
+            cm = b0 + b1 + b2 + b3
+            ac = legs["C1_oracle_all_cores"]
+            ref = legs["C0_libsecp256k1_1_thread"] if secp else None
+            out["cpu_baseline"] = {"value": ref["value"] if ref else ac["value"], "unit": "verifies/s", "cores": 1 if ref else cores, "kind": "reference" if ref else "port",
+                                   "sample": ("libsecp256k1 (%s) through dlopen, called as bitcoin/signature.c:188,425 do, 1 thread, first %d ECDSA + %d Schnorr rows" % (secp, ref["ecdsa_rows"], ref.get("schnorr_rows", 0))) if ref else
+                                             ("first %d ECDSA + first %d Schnorr rows of rank 0's batch, OpenMP over all %d host cores; restated C oracle "
+                                              "(oracle/secp256k1_oracle.c), NOT libsecp256k1 (absent from the reference tree and from this node)" % (m, m, cores)),
+                                   "ecdsa_verifies_per_s": (ref or ac)["ecdsa_verifies_per_s"], "schnorr_verifies_per_s": (ref or ac).get("schnorr_verifies_per_s"),
+                                   "host_cores": cores, "libsecp256k1_found": secp, "legs": legs,
+                                   "legs_note": "BASELINE.md 3: C0 the reference's library (if present), C1 this repo's restated oracle, C2 OpenSSL's generic secp256k1 + "
+                                                "libsecp256k1's acceptance rules; monotonic clock around each batch; every leg's verdicts compared with the GPU's",
                                    "gpu_vs_cpu_verdict_mismatches": cm}
             out["parity"]["oracle_rows_checked"] = 2 * m
             out["parity"]["oracle_mismatches"] = cm

@@ -127,3 +127,23 @@ out0:
 	BN_CTX_free(bc); EC_GROUP_free(g);
 	return ret;
 }
+
+/* ---- BASELINE.md 3, leg C2: n rows of "OpenSSL ECDSA_do_verify on NID_secp256k1 + libsecp256k1's acceptance rules" (r, s in
+ * [1, n-1], s <= n/2 -- bitcoin/signature.c:185-187 -- checked here, in front of the library call), one thread, rows exactly as
+ * lamd_verify_ecdsa_batch takes them.  bench.py's cpu_baseline times it (a second, independent CPU point: OpenSSL's generic
+ * curve code, no secp256k1-specific tricks); tests compare its verdicts with the oracle's. */
+static const uint8_t ORDER_N[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFE,
+				    0xBA, 0xAE, 0xDC, 0xE6, 0xAF, 0x48, 0xA0, 0x3B, 0xBF, 0xD2, 0x5E, 0x8C, 0xD0, 0x36, 0x41, 0x41};
+static const uint8_t HALF_N[32] = {0x7F, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
+				   0x5D, 0x57, 0x6E, 0x73, 0x57, 0xA4, 0x50, 0x1D, 0xDF, 0xE9, 0x2F, 0x46, 0x68, 0x1B, 0x20, 0xA0};
+static int is_zero32(const uint8_t *a) { uint8_t o = 0; for (int i = 0; i < 32; i++) o |= a[i]; return o == 0; }
+void ossl_ecdsa_verify_rules_batch(size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride,
+				   uint8_t *ok)
+{
+	for (size_t i = 0; i < n; i++) {
+		const uint8_t *sg = sig64 + 64 * i;
+		ok[i] = 0;
+		if (is_zero32(sg) || is_zero32(sg + 32) || memcmp(sg, ORDER_N, 32) >= 0 || memcmp(sg + 32, HALF_N, 32) > 0) continue;
+		ok[i] = ossl_ecdsa_verify(hash32 + 32 * i, sg, pub + pubstride * i, publen) == 1;
+	}
+}

@@ -7,13 +7,14 @@ import subprocess
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_DIR, "liblnamd_oracle.so")
 _OSSL = os.path.join(_DIR, "libossl_xcheck.so")
+_SECPDL = os.path.join(_DIR, "libsecp_dl.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_DIR, f) for f in ("secp256k1_oracle.c", "secp256k1_oracle.h", "openssl_xcheck.c", "Makefile")]
-    stale = force or not (os.path.exists(_LIB) and os.path.exists(_OSSL))
+    srcs = [os.path.join(_DIR, f) for f in ("secp256k1_oracle.c", "secp256k1_oracle.h", "openssl_xcheck.c", "libsecp_dl.c", "Makefile")]
+    stale = force or not (os.path.exists(_LIB) and os.path.exists(_OSSL) and os.path.exists(_SECPDL))
     if not stale:
-        t = min(os.path.getmtime(_LIB), os.path.getmtime(_OSSL))
+        t = min(os.path.getmtime(_LIB), os.path.getmtime(_OSSL), os.path.getmtime(_SECPDL))
         stale = any(os.path.getmtime(s) > t for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _DIR, "-s"])
@@ -79,8 +80,58 @@ def ossl():
         L.ossl_schnorr_verify.restype = ctypes.c_int
         L.ossl_ecdsa_recover.argtypes = [_u8p, _u8p, ctypes.c_int, _u8p]
         L.ossl_ecdsa_recover.restype = ctypes.c_int
+        L.ossl_ecdsa_verify_rules_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                    ctypes.c_void_p]
+        L.ossl_ecdsa_verify_rules_batch.restype = None
         _ossl = L
     return _ossl
+
+
+_secpdl = None
+
+
+def secpdl():
+    """oracle/libsecp_dl.c: a real libsecp256k1 through dlopen, if this machine has one (leg C0)"""
+    global _secpdl
+    if _secpdl is None:
+        build()
+        L = ctypes.CDLL(_SECPDL)
+        L.secpdl_open.argtypes = [ctypes.c_char_p]
+        L.secpdl_path.restype = ctypes.c_char_p
+        L.secpdl_ecdsa_verify_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                ctypes.c_void_p]
+        L.secpdl_schnorr_verify_batch.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _secpdl = L
+    return _secpdl
+
+
+def libsecp_available(path=None):
+    """path of the libsecp256k1 shared object that could be loaded, or None"""
+    L = secpdl()
+    return L.secpdl_path().decode() if L.secpdl_open(path.encode() if path else None) else None
+
+
+def libsecp_ecdsa_verify_batch(hashes, sigs, pubs, publen):
+    """uint8 [n] verdicts of the real library, or None when there is none"""
+    import numpy as np
+    out = np.zeros(hashes.shape[0], dtype=np.uint8)
+    rc = secpdl().secpdl_ecdsa_verify_batch(hashes.shape[0], hashes.ctypes.data, sigs.ctypes.data, pubs.ctypes.data, publen, pubs.strides[0], out.ctypes.data)
+    return out if rc == 0 else None
+
+
+def libsecp_schnorr_verify_batch(msgs, xonly, sigs):
+    import numpy as np
+    out = np.zeros(msgs.shape[0], dtype=np.uint8)
+    rc = secpdl().secpdl_schnorr_verify_batch(msgs.shape[0], msgs.ctypes.data, xonly.ctypes.data, sigs.ctypes.data, out.ctypes.data)
+    return out if rc == 0 else None
+
+
+def ossl_ecdsa_verify_rules_batch(hashes, sigs, pubs, publen):
+    """OpenSSL ECDSA_do_verify + libsecp256k1's range / low-S rules, one thread (leg C2)"""
+    import numpy as np
+    out = np.zeros(hashes.shape[0], dtype=np.uint8)
+    ossl().ossl_ecdsa_verify_rules_batch(hashes.shape[0], hashes.ctypes.data, sigs.ctypes.data, pubs.ctypes.data, publen, pubs.strides[0], out.ctypes.data)
+    return out
 
 
 def sha256(b):

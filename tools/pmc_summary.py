@@ -27,7 +27,7 @@ for r in sorted(trace, key=lambda r: int(r["Start_Timestamp"])):
     dur[short(r["Kernel_Name"])].append(d)
     if int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) >= 500000:      # the 1 M-row launches of the timed loops / isolated calls
         bigdur[short(r["Kernel_Name"])].append(d)
-lines = ["# rocprofv3 summary, MI355X, `python bench.py --steps 2 --warmup 1 --cpu-sample 0 --skip-extra` (1 M ECDSA-65 + 1 M BIP-340 per step)",
+lines = ["# rocprofv3 summary, MI355X, `python bench.py --roofline-only --steps 6 --warmup 2` (the chained cold loop: 1 M ECDSA-65 + 1 M BIP-340 per step)",
          "# pass 1: --kernel-trace --stats; passes 2-5: --kernel-trace --pmc ... (FETCH_SIZE | WRITE_SIZE | SQ set 1 | SQ set 2), one counter group per run", "",
          "[kernel trace, launches over >= 500 000 work items only (the 1 M-row batches; the bench's latency legs launch the same kernels over a few hundred rows): calls, mean us, min us, max us]"]
 for k, v in sorted(bigdur.items(), key=lambda kv: -sum(kv[1])):
@@ -91,10 +91,34 @@ lines += ["[derived: %s, ECDSA launch]" % kname,
               e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8)),
           "  SQ_WAIT_ANY / SQ_WAVE_CYCLES                            %.3f" % (e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]),
           "  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES                       %.3f" % (e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"]), ""]
+# ---- FETCH_SIZE calibration (tools/gather_calib.hip under --pmc FETCH_SIZE): requested bytes of a gather of known size / counter
+import re
+calib = {}
+for E in (64, 96):
+    try:
+        txt = open("%s/calib%d.txt" % (base, E)).read()
+        req = float(re.findall(r"= ([0-9.e+]+) bytes requested", txt)[-1])
+        rows = [r for r in csv.DictReader(open(glob.glob("%s/calib%d/runc/*_counter_collection.csv" % (base, E))[0]))
+                if r["Counter_Name"] == "FETCH_SIZE" and "k_gather" in r["Kernel_Name"]]
+        fs = mean([float(r["Counter_Value"]) for r in rows]) * 1024
+        calib[E] = {"requested_bytes": req, "fetch_size_bytes": fs, "requested_over_counter": req / fs}
+    except Exception as ex:
+        calib[E] = {"error": repr(ex)}
+factor, fsrc = 1.0, "uncalibrated"
+if all("requested_over_counter" in calib[E] for E in (64, 96)):
+    # per row: 12 entries of 64 B and 37 of 96 B -- weight the two calibrations by the bytes each class asks for
+    w64, w96 = 12 * 64.0, 37 * 96.0
+    factor = (w64 * calib[64]["requested_over_counter"] + w96 * calib[96]["requested_over_counter"]) / (w64 + w96)
+    factor = max(1.0, factor)      # a counter that over-counts a gather (whole 128-byte lines fetched for 64-96 bytes asked) is real traffic: keep it
+    fsrc = "gather calibration: requested/FETCH_SIZE = %.3f (64-byte entries), %.3f (96-byte entries)" % (
+        calib[64]["requested_over_counter"], calib[96]["requested_over_counter"])
+lines += ["[FETCH_SIZE calibration on random gathers of known size over a 3 GiB table (tools/gather_calib.hip)]"] + [
+    "  %d-byte entries: %s" % (E, calib[E]) for E in (64, 96)] + ["  factor applied to FETCH_SIZE of the dominant kernel: %.3f (%s)" % (factor, fsrc), ""]
 open(outp + "_pmc_summary.txt", "w").write("\n".join(lines))
 json.dump({"k_ecmult_ecdsa_1M": {"kernel": kname, "hbm_bytes_per_launch": hbm, "fetch_kib": e.get("FETCH_SIZE"), "write_kib": e.get("WRITE_SIZE"),
                                   "valu_insts_per_verify": e["SQ_INSTS_VALU"] / nwaves,
                                   "valu_issue_per_simd_cycle": e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8),
-                                  "source": outp + "_pmc_summary.txt (rocprofv3 --pmc, separate passes; FETCH_SIZE uncorrected)"}},
+                                  "fetch_size_factor": factor, "fetch_size_calibration": calib,
+                                  "source": outp + "_pmc_summary.txt (rocprofv3 --pmc of `bench.py --roofline-only`, separate passes; FETCH_SIZE x %.3f, %s)" % (factor, fsrc)}},
           open("profiles/pmc_latest.json", "w"), indent=1)
 print("\n".join(lines))
