@@ -137,13 +137,27 @@ static const uint8_t ORDER_N[32] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0x
 static const uint8_t HALF_N[32] = {0x7F, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
 				   0x5D, 0x57, 0x6E, 0x73, 0x57, 0xA4, 0x50, 0x1D, 0xDF, 0xE9, 0x2F, 0x46, 0x68, 0x1B, 0x20, 0xA0};
 static int is_zero32(const uint8_t *a) { uint8_t o = 0; for (int i = 0; i < 32; i++) o |= a[i]; return o == 0; }
-void ossl_ecdsa_verify_rules_batch(size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride,
-				   uint8_t *ok)
+void ossl_ecdsa_verify_rules_batch_mt(size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride,
+				      uint8_t *ok, int nthreads)
 {
-	for (size_t i = 0; i < n; i++) {
+	long i;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+	for (i = 0; i < (long)n; i++) {
 		const uint8_t *sg = sig64 + 64 * i;
 		ok[i] = 0;
 		if (is_zero32(sg) || is_zero32(sg + 32) || memcmp(sg, ORDER_N, 32) >= 0 || memcmp(sg + 32, HALF_N, 32) > 0) continue;
 		ok[i] = ossl_ecdsa_verify(hash32 + 32 * i, sg, pub + pubstride * i, publen) == 1;
 	}
+}
+void ossl_ecdsa_verify_rules_batch(size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride,
+				   uint8_t *ok)
+{
+	ossl_ecdsa_verify_rules_batch_mt(n, hash32, sig64, pub, publen, pubstride, ok, 1);
+}
+/* n x BIP-340 through ossl_schnorr_verify() (the protocol spelled out over OpenSSL's generic point arithmetic) */
+void ossl_schnorr_verify_batch_mt(size_t n, const uint8_t *msg32, const uint8_t *pk32, const uint8_t *sig64, uint8_t *ok, int nthreads)
+{
+	long i;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+	for (i = 0; i < (long)n; i++) ok[i] = ossl_schnorr_verify(msg32 + 32 * i, pk32 + 32 * i, sig64 + 64 * i) == 1;
 }

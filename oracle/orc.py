@@ -11,7 +11,7 @@ _SECPDL = os.path.join(_DIR, "libsecp_dl.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_DIR, f) for f in ("secp256k1_oracle.c", "secp256k1_oracle.h", "openssl_xcheck.c", "libsecp_dl.c", "Makefile")]
+    srcs = [os.path.join(_DIR, f) for f in ("secp256k1_oracle.c", "secp256k1_oracle.h", "edge_gen.c", "openssl_xcheck.c", "libsecp_dl.c", "Makefile")]
     stale = force or not (os.path.exists(_LIB) and os.path.exists(_OSSL) and os.path.exists(_SECPDL))
     if not stale:
         t = min(os.path.getmtime(_LIB), os.path.getmtime(_OSSL), os.path.getmtime(_SECPDL))
@@ -126,11 +126,25 @@ def libsecp_schnorr_verify_batch(msgs, xonly, sigs):
     return out if rc == 0 else None
 
 
-def ossl_ecdsa_verify_rules_batch(hashes, sigs, pubs, publen):
-    """OpenSSL ECDSA_do_verify + libsecp256k1's range / low-S rules, one thread (leg C2)"""
+def ossl_ecdsa_verify_rules_batch(hashes, sigs, pubs, publen, nthreads=1):
+    """OpenSSL ECDSA_do_verify + libsecp256k1's range / low-S rules (leg C2: one thread; tests use more)"""
     import numpy as np
     out = np.zeros(hashes.shape[0], dtype=np.uint8)
-    ossl().ossl_ecdsa_verify_rules_batch(hashes.shape[0], hashes.ctypes.data, sigs.ctypes.data, pubs.ctypes.data, publen, pubs.strides[0], out.ctypes.data)
+    L = ossl()
+    L.ossl_ecdsa_verify_rules_batch_mt.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                   ctypes.c_void_p, ctypes.c_int]
+    L.ossl_ecdsa_verify_rules_batch_mt.restype = None
+    L.ossl_ecdsa_verify_rules_batch_mt(hashes.shape[0], hashes.ctypes.data, sigs.ctypes.data, pubs.ctypes.data, publen, pubs.strides[0], out.ctypes.data, nthreads)
+    return out
+
+
+def ossl_schnorr_verify_batch(msgs, xonly, sigs, nthreads=1):
+    import numpy as np
+    out = np.zeros(msgs.shape[0], dtype=np.uint8)
+    L = ossl()
+    L.ossl_schnorr_verify_batch_mt.argtypes = [ctypes.c_size_t] + [ctypes.c_void_p] * 4 + [ctypes.c_int]
+    L.ossl_schnorr_verify_batch_mt.restype = None
+    L.ossl_schnorr_verify_batch_mt(msgs.shape[0], msgs.ctypes.data, xonly.ctypes.data, sigs.ctypes.data, out.ctypes.data, nthreads)
     return out
 
 
@@ -261,3 +275,32 @@ def ecdsa_recover_batch(hashes, sigs, recids, nthreads=1):
     recids = np.ascontiguousarray(recids, dtype=np.uint8)
     lib().orc_ecdsa_recover_batch(n, hashes.ctypes.data, sigs.ctypes.data, recids.ctypes.data, keys.ctypes.data, ok.ctypes.data, nthreads)
     return keys, ok
+
+
+def gen_ecdsa_edge_batch(seed, n, publen, nthreads=1):
+    """oracle/edge_gen.c: n signed rows covering every synthesised ECDSA edge class -> (hash [n,32], sig [n,64], pub [n,publen], cls [n], expect [n])"""
+    import numpy as np
+    L = lib()
+    L.orc_gen_ecdsa_edge_batch.argtypes = [ctypes.c_uint64, ctypes.c_size_t, ctypes.c_size_t] + [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    L.orc_gen_ecdsa_edge_batch.restype = None
+    h, s, p = np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8), np.zeros((n, publen), np.uint8)
+    c, e = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    L.orc_gen_ecdsa_edge_batch(seed, n, publen, h.ctypes.data, s.ctypes.data, p.ctypes.data, c.ctypes.data, e.ctypes.data, nthreads)
+    return h, s, p, c, e
+
+
+def gen_schnorr_edge_batch(seed, n, nthreads=1):
+    """-> (msg [n,32], xonly [n,32], sig [n,64], cls [n], expect [n])"""
+    import numpy as np
+    L = lib()
+    L.orc_gen_schnorr_edge_batch.argtypes = [ctypes.c_uint64, ctypes.c_size_t] + [ctypes.c_void_p] * 5 + [ctypes.c_int]
+    L.orc_gen_schnorr_edge_batch.restype = None
+    m, x, s = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, 64), np.uint8)
+    c, e = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    L.orc_gen_schnorr_edge_batch(seed, n, m.ctypes.data, x.ctypes.data, s.ctypes.data, c.ctypes.data, e.ctypes.data, nthreads)
+    return m, x, s, c, e
+
+
+def edge_classes():
+    L = lib()
+    return L.orc_edge_nclasses_ecdsa(), L.orc_edge_nclasses_schnorr()

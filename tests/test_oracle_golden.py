@@ -4,6 +4,7 @@
 classes: tests/golden/kat.json), (2) the spec-level model oracle/pyref.py on seeded random
 rows, (3) OpenSSL's independent secp256k1 ECDSA with libsecp256k1's extra rules layered on."""
 import hashlib
+import os
 import random
 
 import pytest
@@ -258,3 +259,49 @@ def test_openssl_arithmetic_cross_checks_bip340_and_recovery(kat, orc):
         a = orc.ossl_ecdsa_recover(h, sig, recid)
         b = pyref.ecdsa_recover(h, sig, recid)
         assert a == (pyref.ser33(b) if b else None), i
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def test_million_row_differential_oracle_vs_openssl_every_edge_class(orc):
+    """VERDICT r03 "Next" 7: the restated oracle against the only third-party arithmetic in the image -- OpenSSL's generic secp256k1
+    (ECDSA_do_verify + libsecp256k1's range / low-S rules; BIP-340 spelled out over EC_POINT_mul) -- on >= 10^6 signed rows that cover
+    every synthesised edge class of SURVEY 8(c) (oracle/edge_gen.c: hash >= n, bit flips in hash / r / s, high-S twin, wrong key, r = 0,
+    s = 0, r >= n, s >= n, off-curve / unliftable key, bad prefix, x >= p, wrong parity, hybrid 06/07 keys right and wrong; BIP-340:
+    r >= p, s >= n, unliftable key, negated s, ...).  Three opinions per row: C oracle == OpenSSL == the verdict the class fixes by
+    construction.  pyref (pure Python, ~10 ms per row) joins on a slice."""
+    import numpy as np
+    import pyref
+    cores = _cores()
+    n_e, n_s = 500_000, 100_000
+    total = 0
+    for publen, seed in ((33, 0xC1A00006), (65, 0xC1A00016)):
+        h, s, p, c, e = orc.gen_ecdsa_edge_batch(seed, n_e, publen, cores)
+        assert set(np.unique(c)) == set(range(orc.edge_classes()[0])), "a class is missing from the plan"
+        v = orc.ecdsa_verify_batch(h, s, p, publen, cores)
+        o = orc.ossl_ecdsa_verify_rules_batch(h, s, p, publen, cores)
+        bad = np.nonzero((v != e) | (o != e))[0]
+        assert bad.size == 0, ("publen %d: first disagreeing row %d class %d oracle %d openssl %d expected %d" %
+                               (publen, bad[0], c[bad[0]], v[bad[0]], o[bad[0]], e[bad[0]]))
+        for i in range(0, 400):       # the spec-level model on a slice that holds every class
+            assert pyref.ecdsa_verify(bytes(h[i]), bytes(s[i]), bytes(p[i])) == bool(e[i]), (publen, i, int(c[i]))
+        total += n_e
+    m, x, sg, c, e = orc.gen_schnorr_edge_batch(0xC1A00007, n_s, cores)
+    assert set(np.unique(c)) == set(range(orc.edge_classes()[1]))
+    v = orc.schnorr_verify_batch(m, x, sg, cores)
+    o = orc.ossl_schnorr_verify_batch(m, x, sg, cores)
+    bad = np.nonzero((v != e) | (o != e))[0]
+    assert bad.size == 0, ("BIP-340: first disagreeing row %d class %d oracle %d openssl %d expected %d" % (bad[0], c[bad[0]], v[bad[0]], o[bad[0]], e[bad[0]]))
+    for i in range(0, 200):
+        assert pyref.schnorr_verify(bytes(m[i]), bytes(x[i]), bytes(sg[i])) == bool(e[i]), (i, int(c[i]))
+    total += n_s
+    assert total >= 1_000_000
