@@ -42,7 +42,10 @@ enum {
 	LAMD_ERR_STATE = -5      /* streaming API misuse (poll before flush, queue full, ...) */
 };
 
-/* A context is NOT thread-safe: one per calling thread, or serialise the calls.  Every entry point returns a
+/* A context is NOT thread-safe -- including the single-item veneers and every host-buffer call of <= 4096 rows, which share one pinned block
+ * and one completion word per context: one context per calling thread, or serialise the calls (lamd_multi_* below runs one context per device
+ * behind its own lock).  A latency-path call busy-waits for its completion word for at most LAMD_SPIN_US microseconds (default 2000), then
+ * blocks in the runtime.  Every entry point returns a
  * LAMD_ERR_* code (< 0) or a documented non-negative value; lamd_last_error() describes the last failure. */
 /* ---- lifecycle.  Replaces the process-global secp256k1_ctx set up in common/setup.c:58
  * (secp256k1_ctx = wally_get_secp_context(), common/utils.c:16): the one-time work here is the
@@ -241,6 +244,32 @@ int lamd_flush(lamd_ctx *ctx);
 /* 1 = finished (ok[0..*n) filled, tickets in submission order), 0 = still running, < 0 error */
 int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
 int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
+
+/* ---- several MI355X behind one host process (the sidecar that serves a node's channeld / gossipd processes owns every GPU).
+ * lamd_multi_init(): one engine context and one host thread per device (devices == NULL: 0 .. n_devices-1), then an RCCL communicator over them
+ * (librccl.so is dlopen()ed here, never by a single-GPU process).  A call cuts its rows into n_devices contiguous ranges on GROUP boundaries
+ * (lamd_shard_bounds: a channel_announcement's four signatures / a commitment's 1 + 483 rows stay on one device, so a per-key table is built
+ * once), copies and verifies every range on its device (the ranges' host-to-device copies run side by side, piece k+1 of a range under the
+ * kernels of piece k), all-gathers the verdict bytes ON THE DEVICES (ncclAllGather over xGMI, shards padded to the largest: every device
+ * ends with the whole vector) and copies the vector to the host once, from the first device.  Verdicts are exactly those of the
+ * single-device calls (lamd_verify_ecdsa_batch, lamd_verify_schnorr_batch, lamd_sigcheck_gossip_batch); with n_devices == 1 the same path
+ * runs on one GPU, collective included.  One call at a time per lamd_multi (internally locked); < 0 = LAMD_ERR_*, lamd_multi_last_error(). */
+typedef struct lamd_multi lamd_multi;
+int lamd_multi_init(lamd_multi **m, const int *devices, int n_devices);
+void lamd_multi_shutdown(lamd_multi *m);
+const char *lamd_multi_last_error(const lamd_multi *m);
+int lamd_multi_devices(const lamd_multi *m);
+lamd_ctx *lamd_multi_ctx(lamd_multi *m, int i);   /* device i's engine context (statistics, lamd_get_info); not for concurrent verification calls */
+/* group_rows: rows that must stay together (1 = any row boundary; 484 = one commitment_signed; 4 = the rows of a channel_announcement) */
+int lamd_multi_verify_ecdsa_batch(lamd_multi *m, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub, size_t publen,
+				  size_t pubstride, size_t group_rows, uint8_t *ok);
+int lamd_multi_verify_schnorr_batch(lamd_multi *m, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64, size_t group_rows,
+				    uint8_t *ok);
+/* raw wire messages as for lamd_sigcheck_gossip_batch: sharded by MESSAGE, balanced by signatures (4 per channel_announcement) */
+int lamd_multi_sigcheck_gossip_batch(lamd_multi *m, size_t n, const uint8_t *msgs, const uint64_t *off, const uint8_t *node_ids33, int8_t *verdict);
+/* The partition itself: n_groups groups of group_rows[g] rows each (NULL: one row each) into n_shards contiguous ranges of whole groups,
+ * balanced by rows; bounds_groups[0..n_shards] (and, if not NULL, bounds_rows[0..n_shards]) receive the cut points.  Shards may be empty. */
+int lamd_shard_bounds(size_t n_groups, const uint32_t *group_rows, int n_shards, size_t *bounds_groups, size_t *bounds_rows);
 
 /* Synthetic signed test traffic (the signer kernels tests/ and bench.py use) is NOT in this library: see
  * include/lightning_amd_testgen.h -> liblightning_amd_testgen.so. */

@@ -43,6 +43,31 @@ const void *lamd_debug_gtable(lamd_ctx *ctx);
  * *ops (may be NULL) = field multiplications + squarings executed on the device. */
 int lamd_fuzz_field(lamd_ctx *ctx, size_t lanes, int iters, uint64_t seed, uint64_t *ops, char *report, size_t cap);
 
+/* ---- lamd_multi_* over a caller-supplied device layer.  Everything lamd_multi does to a device goes through this table; lamd_multi_init() binds
+ * it to the engine + HIP + RCCL.  Tests bind it to host memory and a CPU checker, so that the sharding, padding, threading and gather layout
+ * run at 8 "devices" on a machine without a GPU (tests/c/multi_stub.c).  Not part of the drop-in boundary.  All functions return LAMD_OK or
+ * a LAMD_ERR_* code; h2d / verify_* / sigcheck_gossip are called on the device's own host thread, the others on the caller's. */
+typedef struct lamd_multi_backend {
+	void *user;   /* passed back as the first argument (NULL: lamd_multi's own engine state -- only meaningful with lamd_multi_init()) */
+	int (*dev_open)(void *user, int device, void **handle);
+	void (*dev_close)(void *user, void *handle);
+	void *(*dev_alloc)(void *user, void *handle, size_t bytes);
+	void (*dev_free)(void *user, void *handle, void *p);
+	int (*h2d)(void *user, void *handle, void *dst, const void *src, size_t bytes);   /* complete (or ordered before the device's next verification) on return */
+	int (*d2h)(void *user, void *handle, void *dst, const void *src, size_t bytes);   /* after the gather; complete on return */
+	int (*verify_ecdsa)(void *user, void *handle, size_t n, const void *d_hash32, const void *d_sig64, const void *d_pub, size_t publen, size_t pubstride, void *d_ok);
+	int (*verify_schnorr)(void *user, void *handle, size_t n, const void *d_msg32, const void *d_xonly32, const void *d_sig64, void *d_ok);
+	int (*sigcheck_gossip)(void *user, void *handle, size_t n, const void *d_msgs, const void *d_off, const void *d_node_ids33, const void *d_rowbase,
+			       size_t rows, void *d_verdict);
+	int (*gather_open)(void *user, void **handles, int n);
+	/* every device i: d_recv[i] = d_send[0] | d_send[1] | ... (bytes each), ordered after the verifications submitted to device i */
+	int (*all_gather)(void *user, void **handles, int n, void **d_send, void **d_recv, size_t bytes);
+	void (*gather_close)(void *user, void **handles, int n);
+	const char *(*error)(void *user);
+	void *(*engine_ctx)(void *user, void *handle);   /* may be NULL */
+} lamd_multi_backend;
+int lamd_multi_init_backend(lamd_multi **m, const int *devices, int n_devices, const lamd_multi_backend *backend);
+
 #ifdef __cplusplus
 }
 #endif

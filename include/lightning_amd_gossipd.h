@@ -87,7 +87,9 @@ typedef struct lamd_gossipd_config {
 
 /* A verification back end with the signature of lamd_sigcheck_gossip_batch / lamd_pubkey_parse_batch.  The product uses
  * the engine (lamd_gossipd_new with a context); the hook exists so that the host logic can be tested on a machine
- * without a GPU against a sequential model -- the library itself contains no CPU verification. */
+ * without a GPU against a sequential model -- the library itself contains no CPU verification.
+ * node_ids33 is NULL when no message of the batch has an explicit signer (a batch without channel_update, as for
+ * lamd_sigcheck_gossip_batch); a back end must not read it then. */
 typedef int (*lamd_gossipd_sigcheck_fn)(void *user, size_t n, const uint8_t *msgs, const uint64_t *off, const uint8_t *node_ids33,
 					int8_t *verdict);
 typedef int (*lamd_gossipd_keyparse_fn)(void *user, size_t n, const uint8_t *pub33, uint8_t *ok);

@@ -70,6 +70,17 @@ SYMBOLS = {
     "lamd_queue_reserve": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz] + [ctypes.POINTER(ctypes.c_void_p)] * 3),
     "lamd_results_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    # several devices behind one process (lamd_multi.cpp)
+    "lamd_multi_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "lamd_multi_init_backend": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_void_p]),
+    "lamd_multi_shutdown": (None, [ctypes.c_void_p]),
+    "lamd_multi_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "lamd_multi_devices": (ctypes.c_int, [ctypes.c_void_p]),
+    "lamd_multi_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_multi_verify_ecdsa_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_sz, c_u8p]),
+    "lamd_multi_verify_schnorr_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_sz, c_u8p]),
+    "lamd_multi_sigcheck_gossip_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p]),
+    "lamd_shard_bounds": (ctypes.c_int, [c_sz, c_u8p, ctypes.c_int, c_u8p, c_u8p]),
 }
 
 # include/lightning_amd_testgen.h -> liblightning_amd_testgen.so (test / bench infrastructure: the signer kernels)

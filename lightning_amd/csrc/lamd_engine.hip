@@ -21,6 +21,20 @@ using namespace lamd;
 
 constexpr int MAX_LANES = 8;
 
+// Wave priority (s_setprio) of the kernels that run UNDER the big table-driven ecmult launches of the other lanes: a front-end / ladder wave
+// that shares a SIMD with three ecmult waves gets the issue port first, so a call's dependent chain of small launches (and its handful of
+// latency-bound ladder waves) stops being stretched by work that has a whole launch to hide in.  g_prio is a bit mask set once at lamd_init
+// from LAMD_PRIO (default: see lamd_init): 1 front end (init / lookup / dedupe / classify / partition), 2 cold-row ladder + its key parse,
+// 4 scalar preparation, 8 key-table building, 16 BIP-340 parity stage.
+__device__ u32 g_prio;
+#ifndef LAMD_PRIO_DEFAULT
+#define LAMD_PRIO_DEFAULT 0
+#endif
+#define LAMD_PRIO(bit)                                     \
+  do {                                                     \
+    if (g_prio & (bit)) __builtin_amdgcn_s_setprio(3);     \
+  } while (0)
+
 // =====================================================================================
 //                                       kernels
 // =====================================================================================
@@ -49,6 +63,7 @@ __global__ void __launch_bounds__(256) k_gtable_build(u32 *__restrict__ gtable, 
 // s values with one modular inversion (Montgomery's trick)
 __global__ void __launch_bounds__(256) k_ecdsa_prep(size_t n, const u8 *__restrict__ hash32, const u8 *__restrict__ sig64,
                                                     prep_rec *__restrict__ recs) {
+  LAMD_PRIO(4);
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t T = (size_t)gridDim.x * blockDim.x;
   ecdsa_prep_thread(tid, T, n, hash32, sig64, recs);
@@ -56,6 +71,7 @@ __global__ void __launch_bounds__(256) k_ecdsa_prep(size_t n, const u8 *__restri
 
 __global__ void __launch_bounds__(256) k_schnorr_prep(size_t n, const u8 *__restrict__ msg32, const u8 *__restrict__ pk32,
                                                       const u8 *__restrict__ sig64, prep_rec *__restrict__ recs) {
+  LAMD_PRIO(4);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   schnorr_prep_one(msg32 + 32 * i, pk32 + 32 * i, sig64 + 64 * i, &recs[i]);
@@ -91,6 +107,7 @@ __device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight = 
 __global__ void __launch_bounds__(256) k_keys_cold(size_t n, const u8 *__restrict__ pub, int publen, size_t stride, const u32 *__restrict__ idx,
                                                    const u32 *__restrict__ count, u32 *__restrict__ counter_ok, u32 *__restrict__ idx_ok,
                                                    u32 *__restrict__ qwords, u8 *__restrict__ keyok_row, u8 *__restrict__ out) {
+  LAMD_PRIO(2);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n && i < *count;
   const size_t row = live ? idx[i] : 0;
@@ -119,6 +136,7 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
                                                 const u32 *__restrict__ gtable, u32 *__restrict__ slots,
                                                 const u32 *__restrict__ idx, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
                                                 u8 *__restrict__ out, const u32 *__restrict__ count) {
+  LAMD_PRIO(2);
   // idx != nullptr (cold rows of a partitioned chunk): work item i verifies input row idx[i]; key data and the table
   // slot live at position i, the prep record / signature / verdict / BIP-340 parking space (fin) at the row
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,6 +355,7 @@ __global__ void __launch_bounds__(256) k_cache_lookup(size_t n, const u8 *__rest
                                                       u32 *__restrict__ row_ent, u32 *__restrict__ plan, u32 *__restrict__ list7,
                                                       u32 *__restrict__ list10, u8 *__restrict__ keyok_row, u8 *__restrict__ out,
                                                       const u8 *__restrict__ sig64, int mode) {
+  LAMD_PRIO(1);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n;
   u32 found = ENT_NONE, T = 255;
@@ -437,6 +456,7 @@ __global__ void __launch_bounds__(256) k_dedupe_map(size_t n, const u32 *__restr
 // of one block), k_partition.
 __global__ void __launch_bounds__(256) k_call_init(u32 *__restrict__ plan, u32 *__restrict__ table, size_t m, u32 *__restrict__ count, size_t n,
                                                    u32 *__restrict__ row_ent, u32 *__restrict__ cc) {
+  LAMD_PRIO(1);
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   if (t < P_WORDS) plan[t] = 0;
   if (cc && t < C_WORDS) cc[t] = 0;
@@ -458,6 +478,7 @@ __global__ void __launch_bounds__(256) k_dedupe_insert_count(size_t n, const u8 
                                                              const u32 *__restrict__ row_ent, u32 *__restrict__ table, u32 mask,
                                                              u32 *__restrict__ rep, u32 *__restrict__ plan, u32 *__restrict__ uniq_row,
                                                              u32 *__restrict__ count) {
+  LAMD_PRIO(1);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < n && row_ent[i] == ENT_NONE;
   u32 r = ENT_NONE;
@@ -489,6 +510,12 @@ __global__ void __launch_bounds__(256) k_dedupe_insert_count(size_t n, const u8 
     todo &= ~same;
   }
 }
+// A LEARNING call (the latency path met a key for the second time, see run_small) builds tables only for the keys whose fingerprint
+// actually recurred -- `fps` -- not for every key its batch happens to carry (a channel_announcement's one-off bitcoin keys, the keys of
+// messages that fail verification), and only while the learnt tables stay inside their budget (half of each pool: learning alone can
+// then never push the bounded cache into the reset that evicts everybody's tables).  fps == nullptr: no filter.
+__host__ __device__ static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen);
+struct learn_filter { const u64 *fps; u32 n; const u8 *keys; int keylen; size_t stride; u64 seed; u32 budget7, budget10; };
 // one thread per distinct new key: keys carried by >= thr7 rows get a 7-tooth comb, by >= thr10 rows a 10-tooth comb (table
 // slot + cache entry allocated here, wave-aggregated; a full pool simply leaves the key without a table)
 struct cache_caps { u32 ent, t7, t10; };
@@ -498,15 +525,24 @@ __global__ void __launch_bounds__(256) k_dedupe_classify(size_t n, const u32 *__
                                                          u32 thr7, u32 thr10, u32 *__restrict__ plan, u32 *cc, cache_caps caps,
                                                          u32 hk7_cap, u32 hk10_cap, u32 *__restrict__ newent, u32 *__restrict__ hk7_row,
                                                          u32 *__restrict__ hk7_ent, u32 *__restrict__ hk7_slot, u32 *__restrict__ hk10_row,
-                                                         u32 *__restrict__ hk10_ent, u32 *__restrict__ hk10_slot) {
+                                                         u32 *__restrict__ hk10_ent, u32 *__restrict__ hk10_slot, learn_filter lf) {
+  LAMD_PRIO(1);
   const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = u < n && u < plan[P_UNIQ];
   const size_t ci = BYROW ? (live ? (size_t)uniq_row[u] : 0) : u;
   const u32 c = live ? count[ci] : 0u;
-  const bool want10 = live && c >= thr10;
+  bool listed = true;
+  if (lf.fps && live) {
+    const u64 fp = small_fingerprint(lf.seed, lf.keys + lf.stride * (size_t)uniq_row[u], lf.keylen);
+    listed = false;
+    for (u32 k = 0; k < lf.n && !listed; k++) listed = lf.fps[k] == fp;
+  }
+  // (the counters only grow: what this launch reads at its start is a lower bound; a batch of <= 4096 keys may overshoot a budget by that much)
+  const bool room10 = cc[C_USED10] < lf.budget10, room7 = cc[C_USED7] < lf.budget7;
+  const bool want10 = live && listed && room10 && c >= thr10;
   const u32 s10 = wave_alloc(&cc[C_USED10], want10);
   const bool ok10 = want10 && s10 < caps.t10;
-  const bool want7 = live && !ok10 && c >= (thr7 < thr10 ? thr7 : thr10);
+  const bool want7 = live && listed && room7 && !ok10 && c >= (thr7 < thr10 ? thr7 : thr10);
   const u32 s7 = wave_alloc(&cc[C_USED7], want7);
   const bool ok7 = want7 && s7 < caps.t7;
   const u32 eid = wave_alloc(&cc[C_ENT], ok7 | ok10);
@@ -546,6 +582,7 @@ __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ r
                                                    const u32 *__restrict__ newent, const cache_ent *__restrict__ ents, u32 *__restrict__ plan,
                                                    u32 *__restrict__ list7, u32 *__restrict__ list10, u32 *__restrict__ listcold,
                                                    u8 *__restrict__ keyok_row, u8 *__restrict__ out, const u8 *__restrict__ sig64, int mode) {
+  LAMD_PRIO(1);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool miss = i < n && rep[i] != ENT_NONE;
   u32 T = 255;
@@ -656,6 +693,7 @@ __device__ __forceinline__ void keys_bases_body(size_t u, const u32 *__restrict_
 }
 __global__ void __launch_bounds__(256) k_keys_bases_both(const u32 *__restrict__ plan, unsigned blocks7, kc_shape_args A7, kc_shape_args A10,
                                                          const u8 *__restrict__ keys, int keylen, size_t stride) {
+  LAMD_PRIO(8);
   if (blockIdx.x < blocks7) keys_bases_body<7>((size_t)blockIdx.x * blockDim.x + threadIdx.x, plan, P_HK7, A7, keys, keylen, stride);
   else keys_bases_body<10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, keys, keylen, stride);
 }
@@ -715,6 +753,7 @@ __device__ __forceinline__ void kc_finish_body(size_t t, const u32 *__restrict__
   if (ok) kc_chain_bwd<T>(tab, scr, sub);
 }
 __global__ void __launch_bounds__(256) k_kc_finish_both(const u32 *__restrict__ plan, unsigned blocks7, kc_shape_args A7, kc_shape_args A10, publish_args P) {
+  LAMD_PRIO(8);
   if (blockIdx.x < blocks7) kc_finish_body<7>((size_t)blockIdx.x * blockDim.x + threadIdx.x, plan, P_HK7, A7, P);
   else kc_finish_body<10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, P);
 }
@@ -901,6 +940,9 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
   __shared__ u32 s_zscale[64][9];      // ladder: Zg of the lane's table
   __shared__ small_part s_part[4][64]; // comb / ladder parts (on the table's isomorphic curve)
   __shared__ small_part s_g[4][64];    // parts of u1*G
+  // 65 280 of the 65 536 bytes a kernel may declare statically: a field added to prep_rec / small_part must come with a smaller buffer here
+  static_assert(sizeof(prep_rec) * 64 + 2 * 64 * sizeof(u32) + 64 * 9 * sizeof(u32) + 2 * 4 * 64 * sizeof(small_part) <= 65536,
+                "k_small_verify: static LDS over 64 KiB");
   // (a call of more than 64 rows is a grid of such blocks: block b owns rows [64 b, 64 b + 64); the LAST block to finish -- a counter in
   // device memory -- writes the completion word)
   const u32 lane = threadIdx.x & 63u, task = threadIdx.x >> 6;
@@ -1019,6 +1061,7 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
 }
 
 __global__ void __launch_bounds__(256) k_schnorr_final_fin(size_t n, u32 *__restrict__ fin, u8 *__restrict__ out) {
+  LAMD_PRIO(16);
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t T = (size_t)gridDim.x * blockDim.x;
   schnorr_final_thread(tid, T, n, fin, out, FIN_WORDS);
@@ -1058,6 +1101,10 @@ struct lamd_ctx {
   u8 *h_small = nullptr;
   devbuf small_done;          // block counter of k_small_verify grids (device memory)
   std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, direct-mapped)
+  u32 prio_mask = LAMD_PRIO_DEFAULT; // LAMD_PRIO: which kernel classes raise their wave priority (g_prio)
+  unsigned spin_us = 2000;         // LAMD_SPIN_US: longest busy-wait of a latency-path call before it blocks in the runtime
+  std::vector<u64> learn_fps;      // the fingerprints that recurred in the call that set force_learn: only these keys get tables (learn_filter)
+  devbuf learn_dev;
   bool force_learn = false;         // the next small call on this context builds tables for every key the cache misses
   u32 small_ticket = 0;
   bool small_kernel = true;   // LAMD_SMALL_KERNEL=0: such calls take the general path
@@ -1169,6 +1216,7 @@ struct lamd_ctx {
   int ecm_chain = 0;
   size_t ecm_chain_min = 65536;
   u32 ecm_tail = 131072;             // LAMD_ECMULT_TAIL: work items of the low-priority second part (LAMD_ECMULT_CHAIN=2)
+  bool bulk_stream = false;          // LAMD_BULK_STREAM=1 (experiment): every large table-driven ecmult launch runs on the lane's lowest-priority stream
   hipStream_t stream_lo = nullptr;   // lanes, LAMD_ECMULT_CHAIN=2: lowest-priority stream of that second part
   hipEvent_t ev_lo_go = nullptr, ev_lo_done = nullptr;
 };
@@ -1252,6 +1300,8 @@ static int create_streams(lamd_ctx *ctx) {
   // The cold-row ladder shares the prep stream (it starts long after the lane's preparation has finished): two streams per lane
   // instead of three -- 231 against 216-223 M verifies/s in the cold loop (profiles/r03_fused_front.txt; fewer hardware queues in
   // use, see hw_queues_from_env).  LAMD_MERGE_SIDE=0 gives the ladder its own stream again.
+  // NOTE for whoever queues work on stream3: by default it IS stream2.  Every stream3 launch is fenced by ev_fork (before) / ev_cold (after); a
+  // launch that waited on an event recorded LATER on stream2 (ev_prep of the next chunk, say) would wait for itself.
   if (!getenv("LAMD_MERGE_SIDE") || atoi(getenv("LAMD_MERGE_SIDE")) != 0) ctx->stream3 = ctx->stream2;
   else HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_cold, hipEventDisableTiming));
@@ -1265,7 +1315,8 @@ static int create_streams(lamd_ctx *ctx) {
     for (auto &e : ctx->ev_pub) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_lane, hipEventDisableTiming));
   HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-  if (getenv("LAMD_ECMULT_CHAIN") && atoi(getenv("LAMD_ECMULT_CHAIN")) == 2) {  // experiment: the tail of a large ecmult launch on a lowest-priority stream
+  ctx->bulk_stream = getenv("LAMD_BULK_STREAM") && atoi(getenv("LAMD_BULK_STREAM")) != 0;
+  if ((getenv("LAMD_ECMULT_CHAIN") && atoi(getenv("LAMD_ECMULT_CHAIN")) == 2) || ctx->bulk_stream) {  // experiments: (the tail of) a large ecmult launch on a lowest-priority stream
     int lo = 0, hi = 0;
     HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least priority (numerically greatest)
     HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_lo, hipStreamNonBlocking, lo));
@@ -1358,6 +1409,8 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
   if (const char *w = getenv("LAMD_KEYED_LDS_PAD")) ctx->keyed_lds_pad = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_KEYED_BLOCKS_PER_CU")) ctx->keyed_blocks_per_cu = (unsigned)atoi(w);
+  if (const char *w = getenv("LAMD_SPIN_US")) ctx->spin_us = (unsigned)atoi(w);
+  if (const char *w = getenv("LAMD_PRIO")) ctx->prio_mask = (u32)atoi(w);
   if (const char *w = getenv("LAMD_FUSED_FRONT")) ctx->fused_front = atoi(w) != 0;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
@@ -1398,6 +1451,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   u32 *d_bases = nullptr;
   HIPCHK(ctx, hipMalloc(&d_bases, bases.size() * 4));
   HIPCHK(ctx, hipMemcpy(d_bases, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_prio), &ctx->prio_mask, sizeof(u32)));
   HIPCHK(ctx, hipMalloc(&ctx->gtable, GTABLE_BYTES));
   hipLaunchKernelGGL(k_gtable_build, dim3(blocks_for(GTABLE_ENTRIES)), dim3(256), 0, ctx->stream, ctx->gtable, d_bases);
   HIPCHK(ctx, hipGetLastError());
@@ -1932,6 +1986,18 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     seq = ++root->call_seq;
   }
   const cache_caps caps = {kc->cap_ent, kc->cap7, kc->cap10};
+  learn_filter lf = {nullptr, 0, d_key, keylen, keystride, root->hash_seed, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  if (small && use_cache) {  // tables learnt from small calls stay inside half of each pool
+    lf.budget7 = kc->cap7 / 2;
+    lf.budget10 = kc->cap10 / 2;
+    if (latency_learn && !ctx->learn_fps.empty()) {
+      const size_t nf = ctx->learn_fps.size() < 4096 ? ctx->learn_fps.size() : 4096;
+      if ((rc = ensure(ctx, &ctx->learn_dev, nf * 8)) != LAMD_OK) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->learn_dev.p, ctx->learn_fps.data(), nf * 8, hipMemcpyHostToDevice, ctx->stream));  // pageable source: staged before the call returns
+      lf.fps = (const u64 *)ctx->learn_dev.p;
+      lf.n = (u32)nf;
+    }
+  }
   if (ctx->fused_front) {
     // six launches (see k_call_init)
     {
@@ -1950,7 +2016,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     hipLaunchKernelGGL((k_dedupe_classify<true>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
                        (const u32 *)ctx->kd_uniq.p, thr7, thr10, plan, cc, caps, (u32)hk7_cap, (u32)hk10_cap, (u32 *)ctx->kd_newent.p,
                        (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
-                       (u32 *)ctx->hk10_slot.p);
+                       (u32 *)ctx->hk10_slot.p, lf);
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     const bool on7 = thr7 != 0xFFFFFFFFu, on10 = thr10 != 0xFFFFFFFFu;
     if (on7 || on10) {
@@ -1994,7 +2060,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     hipLaunchKernelGGL((k_dedupe_classify<false>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_count.p,
                        (const u32 *)ctx->kd_uniq.p, thr7, thr10, plan, cc, caps, (u32)hk7_cap, (u32)hk10_cap, (u32 *)ctx->kd_newent.p,
                        (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
-                       (u32 *)ctx->hk10_slot.p);
+                       (u32 *)ctx->hk10_slot.p, lf);
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     // the new keys: parse, build their tables, publish
     if (thr7 != 0xFFFFFFFFu) {
@@ -2068,9 +2134,20 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
                        (const u32 *)ctx->gtable, fin, keyok_out, d_ok, (const u32 *)ctx->gtable5, 2, root->ecm_tail);
     HIPCHK(ctx, hipEventRecord(ctx->ev_lo_done, ctx->stream_lo));
   }
-  hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, recs,
+  const bool bulk = ctx->bulk_stream && ctx->stream_lo && !two_parts && n >= root->ecm_chain_min;
+  hipStream_t ks = ctx->stream;
+  if (bulk) {  // the whole launch on the lowest-priority stream: the hardware dispatches the other lanes' (normal-priority) front-end blocks first
+    HIPCHK(ctx, hipEventRecord(ctx->ev_lo_go, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_lo, ctx->ev_lo_go, 0));
+    ks = ctx->stream_lo;
+  }
+  hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ks, plan, (const u32 *)list7, (const u32 *)list10, recs,
                      (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
                      keyok_out, d_ok, (const u32 *)ctx->gtable5, two_parts ? 1 : 0, root->ecm_tail);
+  if (bulk) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_lo_done, ctx->stream_lo));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lo_done, 0));
+  }
   if (time_kernel) {
     HIPCHK(ctx, hipEventRecord(ctx->kev[ctx->kev_n][1], ctx->stream));
     ctx->kev_mode[ctx->kev_n++] = mode == MODE_SCHNORR ? 1 : 0;
@@ -2189,24 +2266,30 @@ constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG +
 // call that brings such a key takes the table-building path once (every key the cache misses gets a comb and is published), and
 // from then on the key is a cache hit -- a peer's node id or a channel's keys recur with every single check_signed_hash() call.
 constexpr size_t MISS_SLOTS = 4096;
-static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen) {
+__host__ __device__ static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen) {
   u64 h = seed ^ 0x6D697373ull;
   for (int o = 0; o < keylen; o += 8) {
     u64 c = 0;
-    memcpy(&c, key + o, keylen - o < 8 ? keylen - o : 8);
+    for (int b = 0; b < 8 && o + b < keylen; b++) c |= (u64)key[o + b] << (8 * b);   // (little-endian word, byte by byte: host and device agree)
     h = (h ^ c) * 0x9E3779B97F4A7C15ull;
     h ^= h >> 29;
   }
   return h | 1;
 }
-// the learning call builds a table for EVERY key of its batch the cache misses: forget exactly those fingerprints (other callers' keys that
-// are still waiting for their second sight keep theirs)
-static void small_forget(lamd_ctx *ctx, const u8 *key, size_t keystride, int keylen, size_t n) {
+// the learning call builds tables for the keys of its batch whose fingerprint recurred: forget exactly those fingerprints (other callers' keys
+// that are still waiting for their second sight keep theirs)
+// ... and hand those fingerprints to the context that will run the learning call (`dst`: the root for a host-buffer call, the lane for a
+// flush): its k_dedupe_classify builds tables for exactly these keys
+static void small_forget(lamd_ctx *ctx, lamd_ctx *dst, const u8 *key, size_t keystride, int keylen, size_t n) {
+  dst->learn_fps.clear();
   for (size_t i = 0; i < n; i++) {
     if (i && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0) continue;
     const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
     u64 &slot = ctx->small_missed[(fp >> 1) % MISS_SLOTS];
-    if (slot == fp) slot = 0;
+    if (slot == fp) {
+      slot = 0;
+      dst->learn_fps.push_back(fp);
+    }
   }
 }
 static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok) {
@@ -2231,7 +2314,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
       learn = ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp;  // seen before without a table: the caller takes the learning path
     }
     if (learn) {
-      small_forget(ctx, key, keystride, keylen, n);
+      small_forget(ctx, ctx, key, keystride, keylen, n);
       return 1;
     }
   }
@@ -2279,12 +2362,16 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
       if (((volatile u8 *)h)[SMALL_OFF_OUT + i] == 0xEE || ((volatile u8 *)h)[SMALL_OFF_SHAPES + i] == 0xEE) return false;
     return true;
   };
+  // (the kernel takes 0.14-0.9 ms; the spin is bounded by TIME -- LAMD_SPIN_US, default 2000 -- so that a daemon whose GPU is busy with other
+  // lanes' work does not burn a core for tens of milliseconds: past the bound the call blocks in hipStreamSynchronize)
   bool seen = false;
-  for (u32 spins = 0; spins < (1u << 22); spins++) {
+  const auto t_spin = std::chrono::steady_clock::now();
+  for (u32 spins = 0;; spins++) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == A.ticket && all_in()) { seen = true; break; }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
+    if ((spins & 255u) == 255u && std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_spin).count() > (long)ctx->spin_us) break;
   }
   if (!seen) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -3080,7 +3167,7 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       }
       if (learn) {
         L->force_learn = true;
-        small_forget(ctx, q.h_c, kb, (int)kb, q.n);
+        small_forget(ctx, L, q.h_c, kb, (int)kb, q.n);
       } else {
         if ((rc = ensure(L, &L->slots, ((q.n + 63) & ~(size_t)63) * SLOT_WORDS * 4)) != LAMD_OK) { ctx->err = L->err; return rc; }
         small_args A;
