@@ -152,6 +152,8 @@ def main():
                     help="ONLY the loop `roofline.frac` is computed from (the cold loop with chained ecmult launches, warm-up + steps): every "
                          "k_ecmult_keyed<false, 3> launch of the process is one of that loop's, so the per-kernel average of `rocprofv3 "
                          "--kernel-trace --stats` over this command is directly comparable with roofline.avg_launch_ms")
+    ap.add_argument("--ab", action="store_true", help="A/B runs: the cold loop, the chained loop and the isolated calls only (no warm engine, latency, PCIe, "
+                                                       "other configs or CPU legs)")
     ap.add_argument("--steady-steps", type=int, default=250,
                     help="when --steps gives a timed region under ~1 s: steps of an extra, longer cold loop reported as `steady_state` (0 = skip)")
     args = ap.parse_args()
@@ -320,6 +322,7 @@ def main():
 
     # the headline first: cold, every table rebuilt in every call
     full = not args.roofline_only
+    extras = full and not args.ab
     dt, mism_cold, steady = float("nan"), 0, None
     if full:
         dt, mism_cold = timed(eng_cold)
@@ -371,7 +374,7 @@ def main():
         rows_in_launch = (chained or {}).get("rows", {}).get(0, n)
         isolated = {k: [[float("nan")] * 4] for k in isolated}
     # now the default engine (key-table cache on) and its warm loop: after the warm-up steps every key of the repeated batch is a cache hit
-    if full and not multi:
+    if extras and not multi:
         eng_default = Engine(local_rank)
         eng_default.set_timing(True)
         dt_warm, mism_warm = timed(eng_default)
@@ -399,7 +402,7 @@ def main():
 
     # ---- the two "8 GPUs" configs of BASELINE.json as ONE job split over the ranks (all ranks take part in the collectives)
     sharded = None
-    if multi and not args.skip_extra and full:
+    if multi and not args.skip_extra and extras:
         sharded = sharded_configs(eng, rank, world, device, tstream)
         for v in sharded.values():
             mism += v["mismatches"] if rank == 0 else 0
@@ -530,14 +533,14 @@ def main():
                            "cache_hits_last_call": [int(i["last_cache_hits"]) for i in warm_info], "new_tables_last_call": [int(i["last_new_tables"]) for i in warm_info],
                            "comb_teeth_last_call": [int(i["last_keyed"]) for i in warm_info]},
         }
-        if not full or eng_default is eng_cold:
+        if not extras or eng_default is eng_cold:
             out["warm_cache"] = None
         if sharded is not None:
             out["sharded_configs"] = sharded
         # ---- batch latency (the metric's second half) and the PCIe-inclusive rate: host buffers in -> verdicts in
         # host memory out, through lamd_verify_ecdsa_batch (pageable numpy memory; never `value`)
         lat = {}
-        for bs in ((1, 484, 4096) if world == 1 and full else ()):
+        for bs in ((1, 484, 4096) if world == 1 and extras else ()):
             hh, ss, pp = [np.ascontiguousarray(x[:bs]) for x in we.cols]
             ts = []
             for it in range(60 if bs > 1 else 120):
@@ -546,7 +549,7 @@ def main():
                 ts.append(time.perf_counter() - t1)
             ts = np.sort(np.array(ts[5:])) * 1e3
             lat["ecdsa65_batch_%d" % bs] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)])}
-        if world == 1 and full:
+        if world == 1 and extras:
             # one commitment_signed as channeld sees it (channeld.c:2171,2224): 1 signature under the funding key + 483 under ONE htlc key
             # that recurs with every commitment of the channel -- first sight (the key gets its comb table) and afterwards (cache hit)
             cs = workload.make_commit_storm(eng, 4, device=device)["ecdsa"]
@@ -563,7 +566,7 @@ def main():
             mism += int((got != cs.expect[:484]).sum() + (first != cs.expect[:484]).sum())
             lat["commitment_484_one_htlc_key"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
                                                   "cache_hits_last_call": int(eng.info()["last_cache_hits"])}
-        if world == 1 and full:
+        if world == 1 and extras:
             # BASELINE configs[0]: the committed 1 024 triples (tests/golden/cfg1.bin), ONE call per
             # signature through the reference's own prototype check_signed_hash(hash, sig, key) (bitcoin/signature.c:174-192)
             # in the C++ mirror -- what an unmodified caller sees; ns per call as onchaind/test/run-grind_feerate.c reports
@@ -603,15 +606,15 @@ def main():
         if lat:
             out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
         tp = []
-        for _ in range(3 if full else 0):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
+        for _ in range(3 if extras else 0):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
             t1 = time.perf_counter()
             hv = eng.verify_ecdsa(we.cols[0], we.cols[1], we.cols[2])
             tp.append(time.perf_counter() - t1)
-        if full:
+        if extras:
             out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / min(tp[1:]), "first_call_verifies_per_s": n / tp[0], "rows": n,
                                      "note": "pageable host buffers in, verdicts out, one synchronous call (best of two after a warm-up call); not the headline value"}
             mism += int((hv != we.expect).sum())
-        if world == 1 and full:
+        if world == 1 and extras:
             # SURVEY 8(d)'s own definition of the metric on the headline MIX: both batches of a step start in (pageable) host memory
             # and their verdicts end in host memory, through the streaming queue (lamd_queue_*_batch -> pinned staging set, lamd_flush,
             # lamd_wait): while the device works on one flush the host fills the next staging set and its H2D copies run under the
@@ -681,7 +684,7 @@ def main():
         # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
         # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
         # configs[4] commit_tx storm (484-signature groups sharing a key) as one super-batch
-        if not args.skip_extra and world == 1 and full:
+        if not args.skip_extra and world == 1 and extras:
             extra = {}
             g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
             ts = []
@@ -901,7 +904,7 @@ def main():
                                             "K = number of distinct public keys the rows draw from")
             out["other_configs_1gpu"] = extra
             mism += gm + sm
-        if args.cpu_sample > 0 and world == 1 and full:   # the CPU baseline is a rank-0, N=1 leg
+        if args.cpu_sample > 0 and world == 1 and extras:   # the CPU baseline is a rank-0, N=1 leg
             # C0 = the reference's real CPU path (libsecp256k1 through dlopen, called as bitcoin/signature.c:188,425 call it) if this
             # machine has the library -- else "unavailable"; C1 = the restated C oracle, 1 thread and all cores; C2 = OpenSSL ECDSA_do_verify +
             # libsecp256k1's range / low-S rules, 1 thread.  Monotonic clock around each whole batch, verifies/s and ns per verification (the shape

@@ -150,6 +150,9 @@ typedef struct lamd_gossipd_stats {
 	uint64_t duplicates;        /* identical (message, signer) pairs verified once */
 	uint64_t late_verifies;     /* sigcheck needed during the ordered replay that the plan had not foreseen (0 expected) */
 	uint64_t channels, nodes, pending, early, queued_updates, queued_nodes, store_records;
+	uint64_t run_updates;       /* channel_updates applied by all cores, as runs of plain updates of known channels (the others are replayed one by one) */
+	uint64_t sub_batches;       /* planning stages run (a drained queue is cut into sub-batches: the next one is planned while one is applied) */
+	uint64_t overlapped_stages; /* of those, planning stages that ran under an apply pass */
 } lamd_gossipd_stats;
 void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats *out);
 

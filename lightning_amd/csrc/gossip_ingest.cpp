@@ -17,6 +17,7 @@
 #include <sys/resource.h>
 #include <thread>
 #include <map>
+#include <mutex>
 #include <random>
 #include <string>
 #include <unordered_map>
@@ -194,8 +195,9 @@ static unsigned host_threads() {
   return t;
 }
 template <class F>
-static void parallel_for(size_t n, size_t min_per_thread, F f) {
+static void parallel_for(size_t n, size_t min_per_thread, F f, unsigned max_threads = 0) {
   unsigned t = host_threads();
+  if (max_threads && max_threads < t) t = max_threads;
   if (n / (min_per_thread ? min_per_thread : 1) < t) t = (unsigned)(n / (min_per_thread ? min_per_thread : 1));
   if (t <= 1) { f((size_t)0, n); return; }
   std::vector<std::thread> th;
@@ -234,6 +236,8 @@ struct chan {
   bool set[2];
   u64 cupd_rec[2];
   bool dying = false;   // GOSSIP_STORE_DYING_BIT on its announcement (gossmap_chan_is_dying)
+  // apply_cupd_run(): the batch index of the last channel_update of the run accepted for each direction (NONE outside a run)
+  u32 run_last[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 };
 struct node {
   u32 nchans;
@@ -329,6 +333,7 @@ struct planned {
 
 }  // namespace
 
+struct ingest_stage;
 struct lamd_gossipd {
   lamd_ctx *ctx = nullptr;
   lamd_gossipd_config cfg;
@@ -516,11 +521,13 @@ struct lamd_gossipd {
 
   // ---- verification back end
   int backend_sigcheck(size_t n, const u8 *msgs, const uint64_t *off, const u8 *ids, int8_t *verdict) {
+    std::lock_guard<std::mutex> lk(be_mu);   // (an engine context serves one call at a time; the planning thread and a late verify of the apply pass may meet here)
     if (be_sig) return be_sig(be_user, n, msgs, off, ids, verdict);
     if (!ctx) return LAMD_ERR_ARG;
     return lamd_sigcheck_gossip_batch(ctx, n, msgs, off, ids, verdict);
   }
   int backend_keyparse(size_t n, const u8 *pub33, u8 *ok) {
+    std::lock_guard<std::mutex> lk(be_mu);
     if (be_key) return be_key(be_user, n, pub33, ok);
     if (!ctx) return LAMD_ERR_ARG;
     return lamd_pubkey_parse_batch(ctx, n, pub33, 33, 33, nullptr, ok);
@@ -563,6 +570,10 @@ struct lamd_gossipd {
     // unordered_map cost ~0.2 us per message of a flood here)
     std::vector<u32> tab;     // slot + 1, 0 = empty
     u32 mask = 0;
+    void clear() {  // keeps the memory
+      msg.clear(); signer.clear(); hs.clear();
+      std::fill(tab.begin(), tab.end(), 0u);
+    }
     void reserve(size_t n) {
       size_t m = 64;
       while (m < 2 * n + 2) m <<= 1;
@@ -584,11 +595,11 @@ struct lamd_gossipd {
         if (hs[s] == k.h && msgkey_eq()(k, msgkey{msg[s].data(), msg[s].size(), signer[s] ? signer[s]->k : nullptr, hs[s]})) return (int)s;
       }
     }
-    int add(lamd_gossipd *g, const mview &m, const nodeid *signer_) { return add(g, m, signer_, g->vkey(m, signer_).h); }
-    int add(lamd_gossipd *g, const mview &m, const nodeid *signer_, u64 h) {  // h = vkey(m, signer_).h, computed by the (parallel) plan
+    int add(lamd_gossipd *g, const mview &m, const nodeid *signer_) { return add(&g->st.duplicates, m, signer_, g->vkey(m, signer_).h); }
+    int add(uint64_t *dups, const mview &m, const nodeid *signer_, u64 h) {  // h = vkey(m, signer_).h, computed by the (parallel) plan
       const msgkey k{m.data(), m.size(), signer_ ? signer_->k : nullptr, h};
       const int have = find(k);
-      if (have >= 0) { g->st.duplicates++; return have; }
+      if (have >= 0) { ++*dups; return have; }
       if (2 * (msg.size() + 1) + 2 > tab.size()) reserve(2 * (msg.size() + 1));
       const int s = (int)msg.size();
       msg.push_back(m);
@@ -600,11 +611,31 @@ struct lamd_gossipd {
       return s;
     }
   };
-  // one device call for the signatures of `sl`; verdicts land in this->verdicts
+  // one device call for the signatures of `sl`.  verify_into() touches nothing of the ingest but the back end (under be_mu) and the
+  // work buffers / counters it is handed: the planning stage of sub-batch k+1 runs it on its own thread while sub-batch k is applied
+  struct vbufs { std::vector<uint64_t> off; bytes blob, ids; };
+  struct vcount { uint64_t sigs = 0, msgs = 0, batches = 0, dups = 0, keyparse = 0; };
+  std::mutex be_mu;
   int verify(const slotlist &sl) {
+    std::vector<int8_t> v;
+    vcount c;
+    const int rc = verify_into(sl, v, vf, c);
+    if (rc != LAMD_OK) return rc;
+    if (sl.msg.empty()) return LAMD_OK;
+    cur_sl = &sl;  // until drop_verdicts(): the caller keeps `sl` alive that long
+    cur_v.swap(v);
+    count(c);
+    return LAMD_OK;
+  }
+  void count(const vcount &c) {
+    st.verified_sigs += c.sigs; st.verified_messages += c.msgs; st.batches += c.batches; st.duplicates += c.dups; st.keyparse_messages += c.keyparse;
+  }
+  int verify_into(const slotlist &sl, std::vector<int8_t> &v, vbufs &wb, vcount &cnt) {
     const size_t n = sl.msg.size();
+    v.clear();
     if (!n) return LAMD_OK;
-    std::vector<uint64_t> &off = vf_off;   // (work buffers kept across calls: a fresh 50 MB vector per flood is 12 000 page faults)
+    std::vector<uint64_t> &off = wb.off;   // (work buffers kept across calls: a fresh 50 MB vector per flood is 12 000 page faults)
+    bytes &vf_blob = wb.blob, &vf_ids = wb.ids;
     off.assign(n + 1, 0);
     size_t total = 0;
     bool contiguous = true, any_signer = false;
@@ -634,18 +665,15 @@ struct lamd_gossipd {
       });
       ids = vf_ids.data();
     }
-    for (size_t i = 0; i < n; i++) st.verified_sigs += (sl.msg[i][0] == 1 && sl.msg[i][1] == 0) ? 4 : 1;
-    std::vector<int8_t> v(n, -2);
+    for (size_t i = 0; i < n; i++) cnt.sigs += (sl.msg[i][0] == 1 && sl.msg[i][1] == 0) ? 4 : 1;
+    v.assign(n, -2);
     const int rc = backend_sigcheck(n, blob, off.data(), ids, v.data());
     if (rc != LAMD_OK) return rc;
-    cur_sl = &sl;  // until drop_verdicts(): the caller keeps `sl` alive that long
-    cur_v.swap(v);
-    st.batches++;
-    st.verified_messages += n;
+    cnt.batches++;
+    cnt.msgs += n;
     return LAMD_OK;
   }
-  std::vector<uint64_t> vf_off;
-  bytes vf_blob, vf_ids;
+  vbufs vf;
 
   bool known_scid(u64 scid) const { return chans.count(scid) || pending_ann.count(scid) || early_ann.count(scid); }
   bool timestamp_reasonable(u32 ts) const {  // gossmap_manage.c:1001-1012
@@ -808,6 +836,164 @@ struct lamd_gossipd {
       }
     } while (0);
     if (!err.empty()) warning(q.has_src, &q.src, err);
+  }
+
+  // ---- A RUN of channel_updates for channels the map already holds, applied by all host cores (VERDICT r03 "Next" 4).
+  // process_channel_update() touches only its channel (flags, record numbers, the timestamps of ITS records) plus two things global to the
+  // store: where the new record lands and its record number.  So a run [a, b) of such updates is applied in four passes that give exactly
+  // what the one-by-one replay gives:
+  //   A  (parallel, sharded by CHANNEL: every update of a channel is seen by one thread, in arrival order)  the reference's decisions --
+  //      signature verdict, DONT_FORWARD, "not newer than what we have" (:935-946, against the update accepted earlier in the run, if any),
+  //      which record the accepted update supersedes, whether it is the channel's first update (set_timestamp on the announcement, :950-951);
+  //   B  (serial, arrival order)  record numbers and file offsets of the accepted updates: a prefix sum;
+  //   C  (parallel over the run)  the bytes: header + message at its offset (an update superseded later in the same run is written with its
+  //      DELETED bit already set: the file's final content), the DELETED bit of the superseded older record, the announcement's timestamp / crc,
+  //      the channel's record numbers;
+  //   D  (serial, arrival order, only with a listener)  the events, each exactly as the one-by-one replay emits it.
+  // A listener that asked for the file's write stream (emit_store_writes) sees intermediate states of the image: such an ingest keeps the
+  // one-by-one path (run_ok()).  Everything that is not a plain update of a known channel also stays on that path.
+  static constexpr u32 RUN_NONE = 0xFFFFFFFFu;
+  size_t run_min = 2048;    // LAMD_INGEST_RUN_MIN: shortest run worth the four passes
+  bool run_ok() const { return run_min != 0 && !(on_event && cfg.emit_store_writes); }
+  bool run_member(const planned &p, const queued &q, const std::vector<int8_t> &v) const {
+    return p.type == GOSSIP_CUPD && !p.malformed && p.pc && p.slot >= 0 && p.signer == &p.pc->node[q.msg[111] & 1] && v[p.slot] != -2;
+  }
+  enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3 };
+  struct run_bufs { std::vector<u8> outcome, dead, touch; std::vector<u32> prev_run; std::vector<u64> prev_rec, rec, off; std::vector<std::vector<u32>> bucket; };
+  run_bufs rb;
+  std::vector<queued> w_batch;
+  std::vector<planned> w_plan;
+  ingest_stage *w_stage = nullptr;   // two planning stages (lamd_gossipd_process), allocated on first use
+  void apply_cupd_run(const std::vector<queued> &batch, const std::vector<planned> &plan, const std::vector<int8_t> &v, size_t a, size_t b) {
+    const size_t m = b - a;
+    const unsigned T = std::max(1u, std::min(host_threads(), (unsigned)(m / 1024 + 1)));
+    rb.outcome.assign(m, RO_DROP); rb.dead.assign(m, 0); rb.touch.assign(m, 0);
+    rb.prev_run.assign(m, RUN_NONE); rb.prev_rec.assign(m, ~0ull); rb.rec.assign(m, 0); rb.off.assign(m, 0);
+    // ---- shard by channel, keeping arrival order inside a shard: range r of the run lists its indices per shard, shard t then reads ranges 0, 1, ...
+    if (rb.bucket.size() < (size_t)T * T) rb.bucket.resize((size_t)T * T);
+    for (auto &bk : rb.bucket) bk.clear();
+    const size_t step = (m + T - 1) / T;
+    auto shard_of = [T](const chan *c) { return (unsigned)((mix64((u64)(uintptr_t)c) >> 32) % T); };
+    auto on_threads = [&](auto f) {
+      if (T == 1) { f(0u); return; }
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < T; t++) th.emplace_back(f, t);
+      f(0u);
+      for (auto &x : th) x.join();
+    };
+    on_threads([&](unsigned r) {
+      const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
+      for (unsigned t = 0; t < T; t++) rb.bucket[(size_t)r * T + t].reserve((hi - lo) / T + 16);
+      for (size_t i = lo; i < hi; i++) rb.bucket[(size_t)r * T + shard_of(plan[a + i].pc)].push_back((u32)i);
+    });
+    // ---- pass A
+    on_threads([&](unsigned t) {
+      for (unsigned r = 0; r < T; r++)
+        for (const u32 i : rb.bucket[(size_t)r * T + t]) {
+          const planned &p = plan[a + i];
+          const mview &msg = batch[a + i].msg;
+          chan &c = *p.pc;
+          const int dir = msg[111] & 1;
+          const u32 ts = be32(&msg[106]);
+          if (v[p.slot] != 0) { rb.outcome[i] = RO_BADSIG; continue; }       // :920-926
+          if (msg[110] & 2) { rb.outcome[i] = RO_DONTFWD; continue; }         // :929-932
+          const u32 pr = c.run_last[dir];
+          const bool have = pr != RUN_NONE || c.set[dir];
+          if (have) {                                                          // :935-946
+            const u32 cur = pr != RUN_NONE ? be32(&batch[a + pr].msg[106]) : store[c.cupd_rec[dir]].timestamp;
+            if (cur >= ts) continue;   // RO_DROP
+          } else if (!c.set[!dir] && c.run_last[!dir] == RUN_NONE) {
+            rb.touch[i] = 1;                                                   // :950-951
+          }
+          rb.outcome[i] = RO_ACCEPT;
+          if (pr != RUN_NONE) { rb.prev_run[i] = pr; rb.dead[pr] = 1; }
+          else if (c.set[dir]) rb.prev_rec[i] = c.cupd_rec[dir];
+          c.run_last[dir] = i;
+        }
+    });
+    // ---- pass B
+    u64 nrec = store.size(), pos = image.size();
+    for (size_t i = 0; i < m; i++)
+      if (rb.outcome[i] == RO_ACCEPT) {
+        rb.rec[i] = nrec++;
+        rb.off[i] = pos + 12;
+        pos += 12 + batch[a + i].msg.size();
+      }
+    store.resize(nrec);
+    image.resize(pos);
+    // ---- pass C
+    on_threads([&](unsigned r) {
+      const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
+      for (size_t i = lo; i < hi; i++) {
+        if (rb.outcome[i] != RO_ACCEPT) continue;
+        const mview &msg = batch[a + i].msg;
+        chan &c = *plan[a + i].pc;
+        const int dir = msg[111] & 1;
+        const u32 ts = be32(&msg[106]);
+        if (rb.touch[i]) {  // gossip_store_set_timestamp on the channel_announcement: timestamp AND crc
+          record &ca = store[c.cann_rec];
+          ca.timestamp = ts;
+          u8 *hc = image.data() + ca.off - 12;
+          put_be32(hc + 4, crc32c(ts, image.data() + ca.off, ca.len));
+          put_be32(hc + 8, ts);
+        }
+        u8 *h = image.data() + rb.off[i] - 12;
+        put_be16(h, GS_COMPLETED | (rb.dead[i] ? GS_DELETED : 0u));
+        put_be16(h + 2, (u32)msg.size());
+        put_be32(h + 4, crc32c(ts, msg.data(), msg.size()));
+        put_be32(h + 8, ts);
+        memcpy(h + 12, msg.data(), msg.size());
+        store[rb.rec[i]] = record{GOSSIP_CUPD, ts, rb.dead[i] != 0, rb.off[i], (u32)msg.size()};
+        if (rb.prev_rec[i] != ~0ull) {  // gossip_store_del of the record this update supersedes
+          record &old = store[rb.prev_rec[i]];
+          old.deleted = true;
+          u8 *ho = image.data() + old.off - 12;
+          put_be16(ho, (((u32)ho[0] << 8) | ho[1]) | GS_DELETED);
+        }
+        if (!rb.dead[i]) {  // the channel's standing update for this direction
+          c.set[dir] = true;
+          c.cupd_rec[dir] = rb.rec[i];
+          c.run_last[dir] = RUN_NONE;
+        }
+      }
+    });
+    st.messages += m;
+    st.run_updates += m;
+    if (!on_event) return;
+    // ---- pass D: the events of the one-by-one replay, in its order
+    nodeid ours;
+    memcpy(ours.k, cfg.our_id, 33);
+    for (size_t i = 0; i < m; i++) {
+      const queued &q = batch[a + i];
+      const mview &msg = q.msg;
+      const chan &c = *plan[a + i].pc;
+      const int dir = msg[111] & 1;
+      if (rb.outcome[i] == RO_BADSIG) { warning(q.has_src, &q.src, sigcheck_text(GOSSIP_CUPD, 1, msg)); continue; }
+      if (rb.outcome[i] == RO_DONTFWD) { warning(q.has_src, &q.src, "Do not set DONT_FORWARD on public channel_updates (" + fmt_scid(be64(&msg[98])) + ")"); continue; }
+      if (rb.outcome[i] != RO_ACCEPT) continue;
+      const pending_cupdate u = parse_cupdate(q);
+      lamd_gossipd_event ev;
+      if (rb.touch[i]) {
+        memset(&ev, 0, sizeof ev);
+        ev.kind = LAMD_GEV_STORE_SET_TS; ev.index = c.cann_rec; ev.timestamp = u.timestamp; ev.values[0] = store[c.cann_rec].off;
+        emit(ev);
+      }
+      memset(&ev, 0, sizeof ev);
+      ev.kind = LAMD_GEV_STORE_ADD; ev.index = rb.rec[i]; ev.type = GOSSIP_CUPD; ev.timestamp = u.timestamp; ev.values[0] = rb.off[i];
+      ev.data = msg.data(); ev.len = msg.size();
+      emit(ev);
+      const u64 old = rb.prev_rec[i] != ~0ull ? rb.prev_rec[i] : (rb.prev_run[i] != RUN_NONE ? rb.rec[rb.prev_run[i]] : ~0ull);
+      if (old != ~0ull) {
+        memset(&ev, 0, sizeof ev);
+        ev.kind = LAMD_GEV_STORE_DEL; ev.index = old; ev.type = GOSSIP_CUPD; ev.values[0] = store[old].off;
+        emit(ev);
+      }
+      if (c.node[!dir] == ours) peer_update(u.has_src, &u.src, u.scid, u.fee_base, u.fee_ppm, u.cltv, u.hmin, u.hmax);
+      good_gossip(u.has_src, &u.src);
+      char bb[16];
+      snprintf(bb, sizeof bb, "/%d now ", dir);
+      ev_text(LAMD_GEV_TRACE, u.has_src, &u.src, "Received channel_update for channel " + fmt_scid(u.scid) + bb + ((u.cflags & 2) ? "DISABLED" : "ACTIVE"));
+    }
   }
 
   // ---- process_node_announcement (:1122-1160)
@@ -1102,7 +1288,12 @@ extern "C" lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_conf
   g->store_init();
   return g;
 }
-extern "C" void lamd_gossipd_free(lamd_gossipd *g) { delete g; }
+static void free_stages(ingest_stage *s);
+extern "C" void lamd_gossipd_free(lamd_gossipd *g) {
+  if (!g) return;
+  free_stages(g->w_stage);
+  delete g;
+}
 extern "C" void lamd_gossipd_set_backend(lamd_gossipd *g, lamd_gossipd_sigcheck_fn sigcheck, lamd_gossipd_keyparse_fn keyparse, void *user) {
   if (!g) return;
   g->be_sig = sigcheck;
@@ -1168,25 +1359,34 @@ static void requeue(lamd_gossipd *g, const bytes &arena, const std::vector<qent>
   g->queue.swap(nq);
 }
 
-extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
-  if (!g) return LAMD_ERR_ARG;
-  if (g->in_process) return LAMD_ERR_STATE;
-  bytes arena;
-  std::vector<qent> ents;
-  arena.swap(g->qarena);
-  ents.swap(g->queue);
-  const size_t n = ents.size();
-  if (!n) return 0;
-  std::vector<queued> batch(n);
-  static const bool prof = getenv("LAMD_INGEST_PROFILE") != nullptr;
-  auto tnow = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
-  const double t0 = prof ? tnow() : 0;
-  // ---- plan: which (message, signer) pairs can reach a sigcheck_*() call, judged from the state before the batch.
+// One sub-batch of a drained queue between its planning stage and its apply pass
+struct ingest_stage {
+  size_t lo = 0, hi = 0;
+  lamd_gossipd::slotlist sl;
+  std::vector<int8_t> v;       // verdict per slot
+  bytes keyblob;
+  std::vector<u8> keyok;
+  lamd_gossipd::vbufs wb;
+  lamd_gossipd::vcount cnt;
+  bool has_cann = false;
+  int rc = LAMD_OK;
+  double t_plan = 0, t_slots = 0, t_verify = 0;
+};
+static void free_stages(ingest_stage *s) { delete[] s; }
+static double ingest_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+// ---- the planning stage of messages [st.lo, st.hi): which (message, signer) pairs can reach a sigcheck_*() call, judged from the maps as they
+// stand, and ONE back-end call for their signatures (+ one for the keys of announcements that are dropped anyway).  Reads the maps, writes
+// nothing of the ingest but `st` (and batch / plan entries of its own range): it may run on its own thread while an earlier sub-batch is applied,
+// as long as that apply pass inserts nothing into the maps this stage reads (see lamd_gossipd_process).
+static void ingest_stage1(lamd_gossipd *g, const bytes &arena, const std::vector<qent> &ents, std::vector<queued> &batch, std::vector<planned> &plan,
+                          ingest_stage &st, unsigned threads) {
+  const size_t lo = st.lo, n = st.hi - st.lo;
+  const double t0 = ingest_now();
   // Pass 1 (parallel over the messages; reads the maps, writes nothing shared): framing, r/s range, the filters that need no
   // curve arithmetic, the expected signer, the content hash that keys the verdict, the P2WSH program of an announcement.
-  std::vector<planned> plan(n);
-  parallel_for(n, 2048, [&](size_t lo, size_t hi) {
-    for (size_t i = lo; i < hi; i++) {
+  parallel_for(n, 2048, [&](size_t l, size_t h) {
+    for (size_t i = lo + l; i < lo + h; i++) {
       queued &q = batch[i];
       q.msg = mview(arena.data() + ents[i].off, ents[i].len);
       q.has_src = ents[i].has_src;
@@ -1242,89 +1442,164 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
       }
       if (p.want_slot) p.h = g->vkey(m, p.signer).h;
     }
-  });
-  const double t1 = prof ? tnow() : 0;
+  }, threads);
+  const double t1 = ingest_now();
   // Pass 2 (serial, in arrival order): slots -- identical (message, signer) pairs relayed by several peers share one -- and the
   // key-only list
-  lamd_gossipd::slotlist sl;
-  sl.reserve(n);
-  g->pending_ann.reserve(g->pending_ann.size() + n / 2);
-  sl.msg.reserve(n);
-  sl.signer.reserve(n);
-  sl.hs.reserve(n);
-  bytes keyblob;
-  for (size_t i = 0; i < n; i++) {
+  st.sl.reserve(n);
+  st.sl.msg.reserve(n);
+  st.sl.signer.reserve(n);
+  st.sl.hs.reserve(n);
+  for (size_t i = lo; i < st.hi; i++) {
     planned &p = plan[i];
+    st.has_cann |= p.type == GOSSIP_CANN;
     if (p.want_slot) {
-      p.slot = sl.add(g, batch[i].msg, p.signer, p.h);
+      p.slot = st.sl.add(&st.cnt.dups, batch[i].msg, p.signer, p.h);
     } else if (p.want_keys) {
       const mview &m = batch[i].msg;
       const gossip_frame f = gossip_parse_frame(m.data(), m.size());
-      p.keyslot = (int)(keyblob.size() / 66);
-      keyblob.insert(keyblob.end(), &m[f.keyoff + 66], &m[f.keyoff + 132]);
-      g->st.keyparse_messages++;
+      p.keyslot = (int)(st.keyblob.size() / 66);
+      st.keyblob.insert(st.keyblob.end(), &m[f.keyoff + 66], &m[f.keyoff + 132]);
+      st.cnt.keyparse++;
     }
   }
+  const double t2 = ingest_now();
   // ---- verify: one call for the signatures, one for the keys of announcements that are dropped anyway
-  const double t2 = prof ? tnow() : 0;
-  g->drop_verdicts();
-  int rc = g->verify(sl);
-  if (rc != LAMD_OK) { requeue(g, arena, ents, 0); return rc; }
-  const double t3 = prof ? tnow() : 0;
-  std::vector<u8> keyok(keyblob.size() / 33, 0);
-  if (!keyok.empty()) {
-    rc = g->backend_keyparse(keyok.size(), keyblob.data(), keyok.data());
-    if (rc != LAMD_OK) { g->drop_verdicts(); requeue(g, arena, ents, 0); return rc; }
+  st.rc = g->verify_into(st.sl, st.v, st.wb, st.cnt);
+  if (st.rc == LAMD_OK) {
+    st.keyok.assign(st.keyblob.size() / 33, 0);
+    if (!st.keyok.empty()) st.rc = g->backend_keyparse(st.keyok.size(), st.keyblob.data(), st.keyok.data());
   }
-  // ---- apply in arrival order.  Event callbacks fire from here: they must not re-enter lamd_gossipd_process / _txout_reply /
-  // _new_block (those return LAMD_ERR_STATE while in_process is set -- answer LAMD_GEV_GET_TXOUT after process() returns; _push is fine).
-  g->in_process = true;
-  g->fault_rc = LAMD_OK;
+  const double t3 = ingest_now();
+  st.t_plan = t1 - t0; st.t_slots = t2 - t1; st.t_verify = t3 - t2;
+}
+
+extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
+  if (!g) return LAMD_ERR_ARG;
+  if (g->in_process) return LAMD_ERR_STATE;
+  bytes arena;
+  std::vector<qent> ents;
+  arena.swap(g->qarena);
+  ents.swap(g->queue);
+  const size_t n = ents.size();
+  if (!n) return 0;
+  // (work buffers live with the ingest and only grow: a drained queue of 400 k messages is ~100 MB of scratch, and first-touch page faults on
+  // fresh memory cost more than the planning pass itself -- 2-20 us each under a hypervisor)
+  std::vector<queued> &batch = g->w_batch;
+  std::vector<planned> &plan = g->w_plan;
+  if (batch.size() < n) batch.resize(n);
+  if (plan.size() < n) plan.resize(n);
+  static const bool prof = getenv("LAMD_INGEST_PROFILE") != nullptr;
+  // The drained queue is ONE batch to the caller and a pipeline inside: sub-batches of `sub` messages, the planning stage (framing, filters,
+  // slots, the device call) of sub-batch k+1 on a second thread UNDER the apply pass of sub-batch k.  The planning stage reads chans /
+  // pending_ann / early_ann / txout_failures; an apply pass inserts into pending_ann / early_ann only through channel_announcements, so the
+  // overlap is taken exactly when sub-batch k holds none (a flood arrives typed: announcements, then updates); otherwise the stages alternate.
+  // Planning from the maps as they stood a sub-batch earlier is what the single-batch form does for the WHOLE queue: the apply pass re-checks
+  // every filter that state can change (known / pending scid), and a pair the plan did not foresee is verified late (stats.late_verifies).
+  size_t sub = 131072;
+  if (const char *e = getenv("LAMD_INGEST_SUB")) sub = (size_t)atoll(e) < 1 ? 1 : (size_t)atoll(e);
+  if (const char *e = getenv("LAMD_INGEST_RUN_MIN")) g->run_min = (size_t)atoll(e);
+  const size_t nsub = (n + sub - 1) / sub;
+  const unsigned T = host_threads();
+  if (!g->w_stage) g->w_stage = new ingest_stage[2];
+  ingest_stage *stage = g->w_stage;
+  auto setup = [&](ingest_stage &s, size_t k) {
+    s.lo = k * sub; s.hi = std::min(n, (k + 1) * sub);
+    s.sl.clear();
+    s.v.clear(); s.keyblob.clear(); s.keyok.clear();
+    s.cnt = lamd_gossipd::vcount();
+    s.has_cann = false; s.rc = LAMD_OK;
+  };
+  setup(stage[0], 0);
+  ingest_stage1(g, arena, ents, batch, plan, stage[0], T);
+  g->st.sub_batches++;
   // (every message of the batch may become a store record: grow the image and the record list once, not by doubling through the pass)
   if (g->image.capacity() < g->image.size() + arena.size() + 12 * n) g->image.reserve(g->image.size() + arena.size() + 12 * n + (g->image.size() >> 2));
   if (g->store.capacity() < g->store.size() + n) g->store.reserve(g->store.size() + n + (g->store.size() >> 2));
-  for (size_t i = 0; i < n; i++) {
-    // the apply pass is a chain of cache misses (channel -> its store records -> their bytes in the image): fetch ahead what the plan
-    // already knows a channel_update will touch
-    if (i + 16 < n && plan[i + 16].pc) __builtin_prefetch(plan[i + 16].pc);
-    if (i + 8 < n && plan[i + 8].pc) {
-      const chan *c = plan[i + 8].pc;
-      const int dir = batch[i + 8].msg[111] & 1;
-      if (c->set[dir]) { __builtin_prefetch(&g->store[c->cupd_rec[dir]]); }
-      else if (!c->set[!dir]) { __builtin_prefetch(&g->store[c->cann_rec]); }
+  g->in_process = true;
+  long ret = (long)n;
+  for (size_t k = 0; k < nsub; k++) {
+    ingest_stage &cur = stage[k & 1], &nxt = stage[(k + 1) & 1];
+    if (cur.rc != LAMD_OK) {  // the device call of this sub-batch failed: it and everything behind it go back to the queue, unapplied
+      g->drop_verdicts();
+      requeue(g, arena, ents, cur.lo);
+      ret = cur.rc;
+      break;
     }
-    if (i + 4 < n && plan[i + 4].pc) {
-      const chan *c = plan[i + 4].pc;
-      const int dir = batch[i + 4].msg[111] & 1;
-      if (c->set[dir]) __builtin_prefetch(g->image.data() + g->store[c->cupd_rec[dir]].off - 12);
-      else if (!c->set[!dir]) { const u8 *h = g->image.data() + g->store[c->cann_rec].off - 12; __builtin_prefetch(h); __builtin_prefetch(h + 64); __builtin_prefetch(h + 448 - 64); }
+    std::thread bg;
+    const bool overlap = k + 1 < nsub && !cur.has_cann;
+    if (k + 1 < nsub) setup(nxt, k + 1);
+    // (the planning thread takes half of the cores while it shares the machine with the apply pass)
+    if (overlap) { bg = std::thread([&] { ingest_stage1(g, arena, ents, batch, plan, nxt, std::max(1u, T / 2)); }); g->st.sub_batches++; g->st.overlapped_stages++; }
+    // ---- apply sub-batch k in arrival order.  Event callbacks fire from here: they must not re-enter lamd_gossipd_process / _txout_reply /
+    // _new_block (those return LAMD_ERR_STATE while in_process is set -- answer LAMD_GEV_GET_TXOUT after process() returns; _push is fine).
+    const double ta = prof ? ingest_now() : 0;
+    g->drop_verdicts();
+    g->cur_sl = &cur.sl;
+    g->cur_v = cur.v;
+    g->count(cur.cnt);
+    g->fault_rc = LAMD_OK;
+    if (cur.has_cann) g->pending_ann.reserve(g->pending_ann.size() + (cur.hi - cur.lo) / 2);
+    const bool runs = g->run_ok();
+    size_t fault_at = SIZE_MAX;
+    for (size_t i = cur.lo; i < cur.hi; i++) {
+      if (runs && g->run_member(plan[i], batch[i], g->cur_v)) {  // a run of plain updates of known channels: all cores (apply_cupd_run)
+        size_t j = i + 1;
+        while (j < cur.hi && g->run_member(plan[j], batch[j], g->cur_v)) j++;
+        if (j - i >= g->run_min) {
+          g->apply_cupd_run(batch, plan, g->cur_v, i, j);
+          i = j - 1;
+          continue;
+        }
+      }
+      // the apply pass is a chain of cache misses (channel -> its store records -> their bytes in the image): fetch ahead what the plan
+      // already knows a channel_update will touch
+      if (i + 16 < cur.hi && plan[i + 16].pc) __builtin_prefetch(plan[i + 16].pc);
+      if (i + 8 < cur.hi && plan[i + 8].pc) {
+        const chan *c = plan[i + 8].pc;
+        const int dir = batch[i + 8].msg[111] & 1;
+        if (c->set[dir]) { __builtin_prefetch(&g->store[c->cupd_rec[dir]]); }
+        else if (!c->set[!dir]) { __builtin_prefetch(&g->store[c->cann_rec]); }
+      }
+      if (i + 4 < cur.hi && plan[i + 4].pc) {
+        const chan *c = plan[i + 4].pc;
+        const int dir = batch[i + 4].msg[111] & 1;
+        if (c->set[dir]) __builtin_prefetch(g->image.data() + g->store[c->cupd_rec[dir]].off - 12);
+        else if (!c->set[!dir]) { const u8 *h = g->image.data() + g->store[c->cann_rec].off - 12; __builtin_prefetch(h); __builtin_prefetch(h + 64); __builtin_prefetch(h + 448 - 64); }
+      }
+      const queued &q = batch[i];
+      const planned &p = plan[i];
+      if (p.type == GOSSIP_CANN) g->apply_cann(q, p, p.keyslot >= 0 ? (cur.keyok[2 * p.keyslot] && cur.keyok[2 * p.keyslot + 1]) : 1);
+      else if (p.type == GOSSIP_CUPD) g->apply_cupd(q, p);
+      else if (p.type == GOSSIP_NANN) g->apply_nann(q, p);
+      // other types never reach gossipd's three handlers (gossipd.c:206-264)
+      if (g->fault_rc != LAMD_OK) { fault_at = i; break; }  // an engine error in a late verify
+      g->st.messages++;
     }
-    const queued &q = batch[i];
-    const planned &p = plan[i];
-    if (p.type == GOSSIP_CANN) g->apply_cann(q, p, p.keyslot >= 0 ? (keyok[2 * p.keyslot] && keyok[2 * p.keyslot + 1]) : 1);
-    else if (p.type == GOSSIP_CUPD) g->apply_cupd(q, p);
-    else if (p.type == GOSSIP_NANN) g->apply_nann(q, p);
-    // other types never reach gossipd's three handlers (gossipd.c:206-264)
-    if (g->fault_rc != LAMD_OK) {  // an engine error in a late verify: message i and everything after it go back to the queue, unapplied
-      const int frc = g->fault_rc;
+    const double tb = prof ? ingest_now() : 0;
+    if (bg.joinable()) bg.join();
+    if (fault_at != SIZE_MAX) {  // message fault_at and everything after it go back to the queue, unapplied
+      ret = g->fault_rc;
       g->fault_rc = LAMD_OK;
       g->drop_verdicts();
-      requeue(g, arena, ents, i);
-      g->in_process = false;
-      return frc;
+      requeue(g, arena, ents, fault_at);
+      break;
     }
-    g->st.messages++;
+    if (k + 1 < nsub && !overlap) { ingest_stage1(g, arena, ents, batch, plan, nxt, T); g->st.sub_batches++; }
+    if (prof)
+      fprintf(stderr, "[ingest] sub-batch %zu/%zu n=%zu plan(parallel) %.1f ms, slots %.1f ms, verify %.1f ms | apply %.1f ms%s\n", k + 1, nsub, cur.hi - cur.lo,
+              cur.t_plan * 1e3, cur.t_slots * 1e3, cur.t_verify * 1e3, (tb - ta) * 1e3, overlap ? " (next sub-batch planned under it)" : "");
   }
-  const double t4 = prof ? tnow() : 0;
   g->drop_verdicts();
   g->in_process = false;
-  if (prof) {
-    struct rusage ru;
-    getrusage(RUSAGE_SELF, &ru);
-    fprintf(stderr, "[ingest] n=%zu plan(parallel) %.1f ms, slots %.1f ms, verify %.1f ms, apply %.1f ms, drop %.1f ms; minor faults so far %ld\n", n, (t1 - t0) * 1e3,
-            (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (tnow() - t4) * 1e3, ru.ru_minflt);
+  // the drained arena's memory serves the next queue (unless a callback or a requeue has already started one)
+  if (g->queue.empty() && g->qarena.empty()) {
+    arena.clear();
+    ents.clear();
+    g->qarena.swap(arena);
+    g->queue.swap(ents);
   }
-  return (long)n;
+  return ret;
 }
 
 extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t sat, const uint8_t *script, size_t script_len) {

@@ -221,6 +221,8 @@ def drive(net, ops, receiver, seed):
             receiver.set_time(op[1])
         elif op[0] == "prune":
             receiver.prune()
+        elif op[0] == "txout":       # an explicit reply (a receiver without a listener emits no GET_TXOUT to answer)
+            receiver.txout_reply(op[1], op[2], op[3])
         elif op[0] == "txouts":
             ev = receiver.events
             for e in ev[seen:]:

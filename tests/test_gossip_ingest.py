@@ -302,3 +302,85 @@ def test_store_image_of_the_reference_files_with_the_engine(orc):
             return GossipIngest(eng, chain, peer, height, now, prune_interval=0xFFFFFFFF, store_version=0x0F, emit_store_writes=True)
         for name in ("gossip_store_simple.bin", "gossip_store_mesh_3x3.bin"):
             _check_store_fixture(name, make)
+
+
+def _update_flood(orc, seed, n_chans=40, n_updates=2500):
+    """announced channels, then ONE queue of channel_updates for them: rising, equal and falling timestamps per direction, exact
+    duplicates relayed by other peers, damaged signatures, DONT_FORWARD, updates of our own channels (PEER_UPDATE), interleaved over
+    the channels -- and a few messages that break the run (a node_announcement, an update of an unknown channel, a malformed one)"""
+    import random
+    net = gs.Net(orc, seed, n_nodes=10, n_chans=n_chans)
+    for ch in net.chans:                      # every channel deep enough to be announceable
+        ch["scid"] = ((net.height - 100) << 40) | (ch["scid"] & 0xFFFFFFFFFF)
+    rnd = random.Random(seed * 7 + 1)
+    ops = []
+    for c in range(n_chans):
+        ops.append(("push", net.peers[c % len(net.peers)], net.cann(c)))
+    ops.append(("process",))
+    for c in range(n_chans):
+        ops.append(("txout", net.chans[c]["scid"], net.chans[c]["sat"], net.spk(c)))
+    last = {}
+    sent = []
+    for k in range(n_updates):
+        c, d = rnd.randrange(n_chans), rnd.randrange(2)
+        x = rnd.random()
+        base = last.get((c, d), gs.NOW - 5000)
+        ts = base + rnd.choice([1, 1, 1, 2, 7, 0, 0, -1, -30])
+        last[(c, d)] = max(base, ts)
+        peer = rnd.choice(net.peers)
+        if x < 0.06 and sent:
+            m = rnd.choice(sent)                                  # the same bytes again (another peer relays it)
+        elif x < 0.10:
+            m = gs.damage(rnd, net.cupd(c, d, ts), "sig")
+        elif x < 0.13:
+            m = net.cupd(c, d, ts, mflags=3)                      # DONT_FORWARD
+        elif x < 0.15:
+            m = net.cupd(c, d, ts, disabled=True)
+        else:
+            m = net.cupd(c, d, ts)
+        sent.append(m)
+        ops.append(("push", peer, m))
+        if k % 600 == 599:                                        # run breakers
+            ops.append(("push", peer, net.nann(rnd.randrange(10), gs.NOW - 100 + k)))
+            ops.append(("push", peer, gs.damage(rnd, net.cupd(c, d, ts + 50), "trunc")))
+            ghost = bytearray(net.cupd(c, d, ts + 60))
+            ghost[98:106] = (net.chans[c]["scid"] ^ 0x55).to_bytes(8, "big")
+            ops.append(("push", peer, bytes(ghost)))
+    ops.append(("process",))
+    return net, ops
+
+
+@pytest.mark.parametrize("listener", [True, False])
+def test_update_runs_on_all_cores_equal_the_one_by_one_replay(orc, listener, monkeypatch):
+    """apply_cupd_run (runs of plain channel_updates of known channels applied by all host cores: decisions sharded by channel, record
+    numbers / offsets by a prefix sum over arrival order, bytes written in parallel) and the pipelined sub-batches against (a) the
+    one-by-one replay of the same ingest and (b) the sequential model of gossmap_manage.c: the same events in the same order and the
+    same gossip_store image, byte for byte -- with a listener (events emitted by the run's serial pass) and without one"""
+    from lightning_amd.gossipd import GossipIngest
+    net, ops = _update_flood(orc, 21)
+    model = ModelReceiver(orc, net)
+    gs.drive(net, ops, model, 21)
+    out = {}
+    for name, env in (("one_by_one", {"LAMD_INGEST_RUN_MIN": "0", "LAMD_INGEST_SUB": "1000000"}),
+                      ("runs", {"LAMD_INGEST_RUN_MIN": "4", "LAMD_INGEST_SUB": "1000000", "LAMD_INGEST_THREADS": "5"}),
+                      ("runs_pipelined", {"LAMD_INGEST_RUN_MIN": "4", "LAMD_INGEST_SUB": "300", "LAMD_INGEST_THREADS": "5"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc), collect_events=listener) as ing:
+            gs.drive(net, ops, ing, 21)
+            out[name] = (list(ing.events) if listener else None, ing.store_image(), ing.stats())
+    st = out["runs"][2]
+    assert out["one_by_one"][2]["run_updates"] == 0
+    assert st["run_updates"] > 1500 and st["late_verifies"] == 0, st
+    assert out["runs_pipelined"][2]["overlapped_stages"] >= 3 and out["runs_pipelined"][2]["run_updates"] > 1000, out["runs_pipelined"][2]
+    for name in ("runs", "runs_pipelined"):
+        assert out[name][1] == out["one_by_one"][1], "%s: the gossip_store image differs from the one-by-one replay's" % name
+        for key in ("messages", "channels", "store_records", "queued_updates", "verified_sigs" if name == "runs" else "messages"):
+            assert out[name][2][key] == out["one_by_one"][2][key], (name, key)
+    if listener:
+        _compare(out["one_by_one"][0], model.events)
+        _compare(out["runs"][0], model.events)
+        _compare(out["runs_pipelined"][0], model.events)
+        kinds = _kinds(model.events)
+        for kind in ("STORE_ADD", "STORE_DEL", "STORE_SET_TS", "WARNING", "PEER_UPDATE", "GOOD_GOSSIP"):
+            assert kinds.get(kind, 0) > 10, (kind, kinds)

@@ -115,10 +115,13 @@ if all("requested_over_counter" in calib[E] for E in (64, 96)):
 lines += ["[FETCH_SIZE calibration on random gathers of known size over a 3 GiB table (tools/gather_calib.hip)]"] + [
     "  %d-byte entries: %s" % (E, calib[E]) for E in (64, 96)] + ["  factor applied to FETCH_SIZE of the dominant kernel: %.3f (%s)" % (factor, fsrc), ""]
 open(outp + "_pmc_summary.txt", "w").write("\n".join(lines))
+import os
+os.makedirs(os.path.dirname(outp) or ".", exist_ok=True)
 json.dump({"k_ecmult_ecdsa_1M": {"kernel": kname, "hbm_bytes_per_launch": hbm, "fetch_kib": e.get("FETCH_SIZE"), "write_kib": e.get("WRITE_SIZE"),
                                   "valu_insts_per_verify": e["SQ_INSTS_VALU"] / nwaves,
                                   "valu_issue_per_simd_cycle": e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8),
                                   "fetch_size_factor": factor, "fetch_size_calibration": calib,
                                   "source": outp + "_pmc_summary.txt (rocprofv3 --pmc of `bench.py --roofline-only`, separate passes; FETCH_SIZE x %.3f, %s)" % (factor, fsrc)}},
-          open("profiles/pmc_latest.json", "w"), indent=1)
+          open(outp + "_pmc_latest.json", "w"), indent=1)
+# (run on the GPU box the output prefix lies under gpurun_out/: copy <prefix>_pmc_latest.json to profiles/pmc_latest.json, which bench.py reads)
 print("\n".join(lines))
