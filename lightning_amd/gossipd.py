@@ -174,6 +174,11 @@ class GossipIngest:
         n = self._L.lamd_gossipd_store_image(self._g, ctypes.byref(p))
         return ctypes.string_at(p, n)
 
+    def store_size(self):
+        """size of that file in bytes (without copying it)"""
+        p = ctypes.c_void_p()
+        return int(self._L.lamd_gossipd_store_image(self._g, ctypes.byref(p)))
+
     def stats(self):
         s = Stats()
         self._L.lamd_gossipd_get_stats(self._g, ctypes.byref(s))

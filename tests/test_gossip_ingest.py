@@ -384,3 +384,58 @@ def test_update_runs_on_all_cores_equal_the_one_by_one_replay(orc, listener, mon
         kinds = _kinds(model.events)
         for kind in ("STORE_ADD", "STORE_DEL", "STORE_SET_TS", "WARNING", "PEER_UPDATE", "GOOD_GOSSIP"):
             assert kinds.get(kind, 0) > 10, (kind, kinds)
+
+
+def test_txout_reply_batch_on_all_cores_equals_reply_by_reply(orc):
+    """lamd_gossipd_txout_reply_batch without a listener updates the maps reply by reply and writes the new channels' store records
+    (channel_announcement + amount) with all cores afterwards: the image, the maps and what later channel_updates do to them must equal
+    what one lamd_gossipd_txout_reply() per channel gives -- with wrong scripts, spent outputs, unknown and repeated scids among the replies"""
+    import random
+    from lightning_amd.gossipd import GossipIngest
+    net = gs.Net(orc, 31, n_nodes=40, n_chans=1300)
+    seen = set()
+    for ch in net.chans:                      # deep enough, distinct scids
+        while True:
+            scid = ((net.height - 100 - len(seen) % 500) << 40) | (random.Random(len(seen)).randrange(1, 3000) << 16) | (len(seen) % 3)
+            if scid not in seen:
+                break
+        seen.add(scid)
+        ch["scid"] = scid
+    rnd = random.Random(5)
+    canns = [net.cann(c) for c in range(len(net.chans))]
+    replies = []
+    for c in range(len(net.chans)):
+        x = rnd.random()
+        scid, sat = net.chans[c]["scid"], net.chans[c]["sat"]
+        if x < 0.04:
+            replies.append((scid, 0, b""))                                       # spent / unknown output
+        elif x < 0.08:
+            replies.append((scid, sat, b"\x00\x20" + bytes(32)))               # not the 2-of-2 we expect
+        elif x < 0.10:
+            replies.append((scid ^ 0x77, sat, net.spk(c)))                         # nobody asked for this one
+        else:
+            replies.append((scid, sat, net.spk(c)))
+            if x > 0.97:
+                replies.append((scid, sat, net.spk(c)))                            # answered twice
+    updates = [net.cupd(c, d, gs.NOW - 500 + d) for c in range(0, len(net.chans), 3) for d in (0, 1)]
+    images = {}
+    for mode in ("batch", "single"):
+        with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc), collect_events=False) as ing:
+            for i, m in enumerate(canns):
+                ing.push(net.peers[i % len(net.peers)], m)
+            ing.process()
+            if mode == "batch":
+                blob = np.frombuffer(b"".join(r[2] for r in replies) + b"\x00", dtype=np.uint8)
+                off = np.concatenate([[0], np.cumsum([len(r[2]) for r in replies])]).astype(np.uint64)
+                ing.txout_reply_batch(np.array([r[0] for r in replies], dtype=np.uint64), np.array([r[1] for r in replies], dtype=np.uint64), blob, off)
+            else:
+                for scid, sat, script in replies:
+                    ing.txout_reply(scid, sat, script)
+            for i, m in enumerate(updates):
+                ing.push(net.peers[i % len(net.peers)], m)
+            ing.process()
+            images[mode] = (ing.store_image(), ing.stats())
+    assert images["batch"][0] == images["single"][0]
+    for key in ("channels", "nodes", "pending", "store_records", "messages"):
+        assert images["batch"][1][key] == images["single"][1][key], key
+    assert images["batch"][1]["channels"] > 1100 and 0 < images["batch"][1]["pending"] < 100   # (the channels whose reply went to another scid still wait)
