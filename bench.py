@@ -826,8 +826,11 @@ def main():
                         t2 = time.perf_counter()
                         ing.txout_reply_batch(scids, sats, spk_blob, spk_off)
                         t3 = time.perf_counter()
-                        ing.push_batch(peer, cupd_blob, cupd_off)
-                        ing.process()
+                        QMAX = 500_000          # connectd's queue bound (lamd_gossipd_push_batch refuses more): the updates arrive as four queues
+                        for o in range(0, g.n_cupd, QMAX):
+                            e_ = min(g.n_cupd, o + QMAX)
+                            ing.push_batch(peer, cupd_blob[int(cupd_off[o]):int(cupd_off[e_]) + 1], (cupd_off[o:e_ + 1] - cupd_off[o]).copy())
+                            ing.process()
                         t4 = time.perf_counter()
                         st_ = ing.stats()
                         store_bytes = ing.store_size()
