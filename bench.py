@@ -37,9 +37,18 @@ W_SCHNORR = 1.65e5
 # (S+9) + M + (M+9) + M = 567; acceptance test: 3 M + 1 S.
 def _mads(dbl, add):
     return dbl * 567 + add * 990 + 3 * 99 + 63
-# ladder: 132 doublings (+1 for 2Q), 66 + 6 table additions, 12 G windows; combs: both halves made odd by a lattice vector (no
-# repair additions), the first table point initialises the accumulator: 2D - 1 additions + D - 1 doublings + 12 G windows
-W_EXEC = {0: _mads(132 + 1, 66 + 12 + 6), 7: _mads(18, 37 + 12), 10: _mads(12, 25 + 12)}   # ladder, 7-tooth comb, 10-tooth comb
+# ladder: 132 doublings (+1 for 2Q), 66 + 6 table additions, G windows; combs: both halves made odd by a lattice vector (no
+# repair additions), the first table point initialises the accumulator: 2D - 1 additions + D - 1 doublings + G windows.  G windows: one
+# mixed addition per window of the static table -- 11 with the 24-bit windows that ship from round 4 on (12 with 22 bits: rounds 1-3)
+def w_exec_table(g_windows):
+    return {0: _mads(132 + 1, 66 + g_windows + 6), 7: _mads(18, 37 + g_windows), 10: _mads(12, 25 + g_windows)}   # ladder, 7-tooth comb, 10-tooth comb
+def g_windows_of(gtable_bytes):
+    for bits in (16, 22, 24, 26):
+        w = (256 + bits - 1) // bits
+        if gtable_bytes in (w * (64 << bits), w * (72 << bits)):
+            return w
+    return 11
+W_EXEC = w_exec_table(11)
 # measured dependent-free v_mad_u64_u32 issue rate of one MI355X (profiles/r01_microbench_valu_rates.txt)
 P_MUL32 = 3.69e13
 HBM_PEAK_GBS = 8000.0
@@ -192,7 +201,7 @@ def main():
     # two engines: `eng_cold` rebuilds every key's comb table in every call (LAMD_CACHE=0: what a stateless library does, and
     # what `value` is measured on); `eng` keeps tables in its key-table cache across calls, so from the second step on a repeated
     # batch is all cache hits ("warm": reported beside the headline, never as it)
-    # With more than one rank ONLY the cold engine exists: one engine = one 3 GiB G table and one set of 16 hardware-queue-backed
+    # With more than one rank ONLY the cold engine exists: one engine = one 11 GiB G table and one set of 16 hardware-queue-backed
     # streams per rank.  Two engines plus RCCL's own streams is the many-queues regime in which the collective path lost up to 45 %
     # on one rank (profiles/r02n_collective_path_and_queues.txt); the warm-cache leg is a single-GPU data point anyway.
     # The cold engine is ALONE in the process while `value` is measured (a serving process holds one engine): the default engine is created
@@ -418,7 +427,9 @@ def main():
         # -- the same loop and nothing else -- gives the same per-kernel average: profiles/).  ECDSA and BIP-340 launches are the same kernel
         # (their acceptance tests differ by two field multiplications of ~650), so the average is over both kinds, as rocprofv3's is.
         teeth = int(keyed.get("ecdsa", (0, 0))[0])
-        w_exec = W_EXEC.get(teeth, W_EXEC[0])
+        g_windows = g_windows_of(int(eng_cold.info()["gtable_bytes"]))
+        w_exec_t = w_exec_table(g_windows)
+        w_exec = w_exec_t.get(teeth, w_exec_t[0])
         lm_ov = launch_ms.get(id(eng_cold)) if full else None          # default mode (the launches overlap): reported, never the roofline
         pipeline = {"ms": dt / args.steps * 1e3, "achieved": 2 * w_exec * rows_in_launch / (dt / args.steps) / 1e12,
                     "frac": 2 * w_exec * rows_in_launch / (dt / args.steps) / P_MUL32,
@@ -430,7 +441,9 @@ def main():
             t_ecmult = (cl[0][0] + cl[1][0]) / n_l * 1e-3                 # seconds per launch, both kinds
             rows_k = [chained["rows"].get(m, rows_in_launch) for m in (0, 1)]
             rows_avg = (rows_k[0] * cl[0][1] + rows_k[1] * cl[1][1]) / n_l
-            sum_per_step = (cl[0][0] + cl[1][0]) / args.steps
+            # (a lane keeps at most lamd_ctx::KEV event pairs per interval: over a long loop fewer launches are timed than run -- the step holds one
+            # launch of each kind, so its launches sum to the two averages)
+            sum_per_step = (cl[0][0] / cl[0][1] if cl[0][1] else 0.0) + (cl[1][0] / cl[1][1] if cl[1][1] else 0.0)
             roof_mode = {"mode": "chained", "launches_timed": n_l, "avg_launch_ms": t_ecmult * 1e3,
                          "avg_launch_ms_ecdsa": cl[0][0] / cl[0][1] if cl[0][1] else None, "avg_launch_ms_schnorr": cl[1][0] / cl[1][1] if cl[1][1] else None,
                          "rows_in_launch": rows_avg, "rows_in_launch_by_kind": {"ecdsa": rows_k[0], "schnorr": rows_k[1]},
@@ -490,7 +503,7 @@ def main():
                 "kernel": "%s (1 M-row ECDSA-65 / BIP-340 launches)" % ("k_ecmult_keyed<false, 3>: %d-tooth signed comb, bare formulas" % teeth if teeth else "k_ecmult"),
                 "bound": "valu-int32-mul (not hbm, not mfma)",
                 "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
-                "executed_mul32_per_verify": w_exec,
+                "executed_mul32_per_verify": w_exec, "g_table_windows": g_windows,
                 "rows_note": "of a batch's %d rows: the others were decided before the ecmult (early reject of signatures whose scalars cannot pass "
                              "the preparation: r, s range and low-S; keys that do not parse; rows under rare keys take the ladder kernel)" % n,
                 "timing": "HIP event pair on the launching lane's stream right before and after every k_ecmult_keyed<false, 3> launch of the timed "
@@ -504,7 +517,7 @@ def main():
                     "note": "one call at a time, nothing else on the GPU (measured right after the timed loops)"},
                 "overlapped": None if not (lm_ov and lm_ov[0][1]) else {
                     "avg_launch_ms": lm_ov[0][0] / lm_ov[0][1], "avg_launch_ms_schnorr": (lm_ov[1][0] / lm_ov[1][1]) if lm_ov[1][1] else None,
-                    "sum_of_launch_ms_per_step": (lm_ov[0][0] + lm_ov[1][0]) / args.steps,
+                    "sum_of_launch_ms_per_step": (lm_ov[0][0] / lm_ov[0][1]) + ((lm_ov[1][0] / lm_ov[1][1]) if lm_ov[1][1] else 0.0),
                     "note": "the same brackets in the DEFAULT mode (the loop `value` is measured on): 1.1-1.5 such launches are in flight at any time, every "
                             "bracket holds its neighbours' share too and their sum exceeds the step time -- not a kernel duration, kept for comparison with "
                             "earlier rounds (r03 reported this as roofline.avg_launch_ms)"},

@@ -31,7 +31,7 @@ int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 i
  * validity, 7 distinct-key affine words, 8 key tables) to host memory.  Tests only. */
 int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out);
 
-/* The static G table in device memory (12 windows x 2^22 affine entries): read by the test-traffic signer kernels of
+/* The static G table in device memory (11 windows x 2^24 affine entries): read by the test-traffic signer kernels of
  * liblightning_amd_testgen.so.  NULL without a context. */
 const void *lamd_debug_gtable(lamd_ctx *ctx);
 

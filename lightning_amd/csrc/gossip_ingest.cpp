@@ -948,7 +948,15 @@ struct lamd_gossipd {
   bool run_member(const planned &p, const queued &q, const std::vector<int8_t> &v) const {
     return p.type == GOSSIP_CUPD && !p.malformed && p.pc && p.slot >= 0 && p.signer == &p.pc->node[q.msg[111] & 1] && v[p.slot] != -2;
   }
-  enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3 };
+  // Without a listener a run also swallows INERT channel_updates -- malformed ones, and updates of channels the map does not hold (unknown or
+  // on another chain, too old, too far in the future: the plan found no channel) -- whose replay changes nothing a run reads or writes: no store
+  // record, no channel state; at most an entry in the lists of updates waiting for a pending announcement.  They are replayed one by one after
+  // the run's passes, in arrival order among themselves.  (With a listener their warnings and traces are events whose order matters: they end
+  // the run, as every other kind of message does.)  One damaged message in a hundred would otherwise cut a flood into runs too short to take.
+  bool run_side(const planned &p, const std::vector<int8_t> &v) const {
+    return !on_event && p.type == GOSSIP_CUPD && (p.malformed || !p.pc) && !(p.slot >= 0 && v[p.slot] == -2);
+  }
+  enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3, RO_SIDE = 4 };
   // (what pass A decides about one update.  One array PER SHARD, in the shard's arrival order: the thread that owns a channel writes only
   // its own array -- verdict bytes of neighbouring messages in one shared array ping-pong their cache lines between the cores, which made the
   // 16-thread run slower per update than the one-by-one replay)
@@ -986,6 +994,7 @@ struct lamd_gossipd {
       const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
       for (unsigned t = 0; t < T; t++) { auto &bk = rb.bucket[(size_t)r * T + t]; bk.clear(); bk.reserve((hi - lo) / T + 16); }
       for (size_t i = lo; i < hi; i++) {
+        if (!run_member(plan[a + i], batch[a + i], v)) { rb.shard[i] = 0xFF; continue; }   // an inert message inside the run (run_side)
         const unsigned t = shard_of(plan[a + i].pc);
         rb.shard[i] = (u8)t;
         rb.bucket[(size_t)r * T + t].push_back((u32)i);
@@ -1037,7 +1046,7 @@ struct lamd_gossipd {
       const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
       size_t nr = 0, nb = 0;
       for (size_t i = lo; i < hi; i++)
-        if (rb.res[rb.shard[i]][rb.where[i]].outcome == RO_ACCEPT) { nr++; nb += 12 + batch[a + i].msg.size(); }
+        if (rb.shard[i] != 0xFF && rb.res[rb.shard[i]][rb.where[i]].outcome == RO_ACCEPT) { nr++; nb += 12 + batch[a + i].msg.size(); }
       rb.cnt_rec[r] = nr;
       rb.cnt_bytes[r] = nb;
     });
@@ -1051,6 +1060,7 @@ struct lamd_gossipd {
       const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
       u64 rn = rec0[r], ps = pos0[r];
       for (size_t i = lo; i < hi; i++) {
+        if (rb.shard[i] == 0xFF) continue;
         run_res &R = rb.res[rb.shard[i]][rb.where[i]];
         if (R.outcome != RO_ACCEPT) continue;
         const mview &msg = batch[a + i].msg;
@@ -1089,7 +1099,11 @@ struct lamd_gossipd {
     });
     st.messages += m;
     st.run_updates += m;
-    if (!on_event) return;
+    if (!on_event) {  // the inert messages of the run, one by one (no listener: run_side() admits none otherwise)
+      for (size_t i = 0; i < m; i++)
+        if (rb.shard[i] == 0xFF) { apply_cupd(batch[a + i], plan[a + i]); st.run_updates--; }
+      return;
+    }
     // ---- pass D: the events of the one-by-one replay, in its order
     nodeid ours;
     memcpy(ours.k, cfg.our_id, 33);
@@ -1691,9 +1705,13 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     size_t fault_at = SIZE_MAX;
     for (size_t i = cur.lo; i < cur.hi; i++) {
       if (runs && g->run_member(plan[i], batch[i], g->cur_v)) {  // a run of plain updates of known channels: all cores (apply_cupd_run)
-        size_t j = i + 1;
-        while (j < cur.hi && g->run_member(plan[j], batch[j], g->cur_v)) j++;
-        if (j - i >= g->run_min) {
+        size_t j = i + 1, members = 1;
+        for (; j < cur.hi; j++) {
+          if (g->run_member(plan[j], batch[j], g->cur_v)) members++;
+          else if (!g->run_side(plan[j], g->cur_v)) break;
+        }
+        while (!g->run_member(plan[j - 1], batch[j - 1], g->cur_v)) j--;   // a run ends with a member
+        if (members >= g->run_min) {
           g->apply_cupd_run(batch, plan, g->cur_v, i, j);
           i = j - 1;
           continue;

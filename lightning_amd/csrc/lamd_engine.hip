@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(64) k_small_lookup(size_t n, const u8 *__restr
 // One row per LANE, one TASK per WAVE (verify_core.h "Task split"): a block of eight waves, two per SIMD of a CU.
 //   phase A   wave 0: scalar preparation of its row (one division-step inversion per lane)
 //             wave 1: the row's key -- probe the key-table cache (comb shape + table), or parse it and build the 8-entry ladder table
-//   phase B   waves 0-3: the comb's four partial sums (or the two ladder halves); waves 4-7: three of the 12 windows of u1*G each
+//   phase B   waves 0-3: the comb's four partial sums (or the two ladder halves); waves 4-7: three of the 11 windows of u1*G each
 //   phase C   three-level merge with complete Jacobian additions (two sums per level, on different waves), acceptance test on wave 0,
 //             verdict byte -> host memory, completion word
 // Replaces, for such calls, H2D x 3 + a dozen launches + D2H + a stream synchronise (0.38 ms for one row) and the ~10^5-instruction
@@ -3395,7 +3395,7 @@ extern "C" int lamd_selftest(lamd_ctx *ctx, const uint8_t *hash32, const uint8_t
   hipLaunchKernelGGL(k_selftest, dim3(1), dim3(ST_LANES), 0, ctx->stream, d_in, (const u32 *)ctx->gtable, d_slots, d_out);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  // the host re-runs the whole lane, G additions included: it needs the device's table (a diagnostic: 3 GiB over PCIe is fine)
+  // the host re-runs the whole lane, G additions included: it needs the device's table (a diagnostic: 11 GiB over PCIe is fine)
   std::vector<u32> got((size_t)ST_LANES * ST_WORDS);
   struct host_table {
     u32 *p = (u32 *)malloc(GTABLE_BYTES);

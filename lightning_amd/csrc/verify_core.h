@@ -8,7 +8,7 @@
 //   keys     SEC1 33/65-byte or x-only 32-byte public key -> validated affine point
 //   ecmult   R = u1*G + u2*Q: per-lane 8-entry table of Q (shared-Z / isomorphic-curve trick so
 //            the ladder only does mixed additions), 33 signed 4-bit windows x 2 half-scalars,
-//            then 12 lookups in the 22-bit-window table of G; final x (and y-parity) check
+//            then 11 lookups in the 24-bit-window table of G; final x (and y-parity) check
 //
 // Reference semantics: secp256k1_ecdsa_verify / secp256k1_schnorrsig_verify /
 // secp256k1_ec_pubkey_parse / secp256k1_xonly_pubkey_parse as called from
@@ -88,11 +88,15 @@ constexpr int SLOT_H_OFF = 8 * SLOT_ENTRY_WORDS;                     // 6 x TW w
 constexpr int SLOT_WORDS = LAMD_TABLE_LIMBS ? 288 : 256;             // scratch slot owned by one ladder lane
 
 // Static table of G: window w, digit d -> d * 2^(BITS*w) * G as 64-byte affine words (d = 0 unused).
-// 22-bit windows (12 windows, 3 GiB in HBM) make u1*G twelve mixed additions; measured against 16-bit windows (64 MiB,
-// Infinity-Cache resident, 16 additions) the whole step is 4 % faster: one random 64-byte read per ~1 400 instructions hides.
+// 24-bit windows (11 windows, 11 GiB of the card's 288 GB of HBM) make u1*G eleven mixed additions.  Rounds 1-3 shipped 22 bits (12 windows,
+// 3 GiB); the step is VALU instruction issue end to end, so one addition less (1 of 67 group operations) is 1.5 % of the dominant kernel:
+// three alternating pairs of bench.py --ab on one box, 24 against 22 bits: cold 239.5 / 236.8 / 236.2 against 233.8 / 231.3 / 235.4 M verifies/s,
+// chained launch 4.07 against 4.10-4.14 ms (profiles/r04_ab_variants.txt), and one random 64-byte read less per signature.  26 bits
+// (10 windows, 43 GB) measured another 1 % in round 2 -- not worth 4x the memory.  16-bit windows (64 MiB, Infinity-Cache resident, 16 additions)
+// are 4 % slower than 22: one random 64-byte read per ~1 400 instructions hides.
 // The CPU test harness builds the same code with 8-bit windows to keep its table small.
 #ifndef LAMD_GTABLE_WINDOW_BITS
-#define LAMD_GTABLE_WINDOW_BITS 22
+#define LAMD_GTABLE_WINDOW_BITS 24
 #endif
 constexpr int GTABLE_WINDOW_BITS = LAMD_GTABLE_WINDOW_BITS;
 constexpr int GTABLE_WINDOWS = (256 + GTABLE_WINDOW_BITS - 1) / GTABLE_WINDOW_BITS;
@@ -1014,7 +1018,7 @@ LAMD_HD gej small_task_ladder(const prep_rec &rec, const u32 *slot, bool second)
   return acc;
 }
 // Which windows of u1*G a task wave adds up next to its comb / ladder part (k_small_verify runs FOUR task waves, one per SIMD of
-// the CU -- a fifth wave would share a SIMD with another and stretch both): a row with a comb table spreads the 12 windows evenly,
+// the CU -- a fifth wave would share a SIMD with another and stretch both): a row with a comb table spreads the 11 windows over the four waves (3 + 3 + 3 + 2),
 // a ladder row gives them to the two waves that have no ladder half to compute.
 LAMD_HD void small_g_windows(int task /*0..3*/, bool ladder, int *w_lo, int *w_hi) {
   constexpr int Q = (GTABLE_WINDOWS + 3) / 4, H = (GTABLE_WINDOWS + 1) / 2;

@@ -358,7 +358,7 @@ def test_keyed_ecmult_special_scalars(dm):
 
 
 def test_gtable_windows_that_straddle_words(kat):
-    """the shipped G table uses 22-bit windows (12 windows, the last one runs past bit 255, most straddle a 32-bit word);
+    """the shipped G table uses 24-bit windows (11 windows, the last one runs past bit 255, two of three straddle a 32-bit word);
     the same digit extraction and table code built for the host with 11-bit windows must give the golden verdicts"""
     so = os.path.join(HERE, "libdevmath_host_w11.so")
     src = os.path.join(HERE, "devmath_host.cpp")

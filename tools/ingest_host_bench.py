@@ -13,8 +13,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightning_amd import gossipd
 
-n_cann = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-per = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_cann = int(args[0]) if len(args) > 0 else 100_000
+per = int(args[1]) if len(args) > 1 else 4
+if "--with-engine" in sys.argv:   # the same host logic inside a process that holds a GPU context (pinned memory, the runtime's threads)
+    from lightning_amd import Engine
+    _eng = Engine(0)
 rng = np.random.default_rng(0xC1A00004)
 chain = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
 n_nodes = 15000
