@@ -2,7 +2,8 @@
 //
 // Representation: 9 limbs of 29 bits in u32 registers, LAZY: limbs may exceed 29 bits.
 // A value of "magnitude" m has limbs[0..7] <= m*LIM29 and limb[8] <= m*LIM24 (m <= 7 so
-// nothing overflows a u32).  Why this shape (measured, profiles/r01_microbench_valu_rates.txt):
+// nothing overflows a u32; LIM29 = 2^29 + 2^21: a product leaves its last wrap-around on limb 0
+// unpropagated, see LAMD_FE_CHAINS).  Why this shape (measured, profiles/r01_microbench_valu_rates.txt):
 // on gfx950 v_mad_u64_u32 runs at the same half rate as v_add_co/v_addc (and carry chains
 // additionally pay the VALU-writes-VCC -> VALU-reads-VCC 2-wait-state hazard), so the cheap
 // resource is the 64-bit accumulate inside the multiplier, not the adder.  29-bit limbs let a
@@ -34,7 +35,7 @@ struct fe {
 
 constexpr u32 FE_M29 = 0x1FFFFFFFu;
 constexpr u32 FE_M24 = 0x00FFFFFFu;
-constexpr u32 FE_LIM29 = (1u << 29) + (1u << 13);
+constexpr u32 FE_LIM29 = (1u << 29) + (1u << 21);
 constexpr u32 FE_LIM24 = (1u << 24) + (1u << 13);
 // p in 29-bit limbs
 constexpr u32 FE_P0 = 0x1FFFFC2Fu, FE_P1 = 0x1FFFFFF7u, FE_PM = 0x1FFFFFFFu, FE_P8 = 0x00FFFFFFu;
@@ -226,54 +227,70 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
 
 // Multiplication / squaring with RUNNING carries: a column's 64-bit sum, shifted right by 29, is the addend of
 // the next column's first multiply-add, so a carry costs one 64-bit shift and one mask per column and no
-// additions.  Two chains run skewed by one column so they can overlap:
-//   high chain  columns 9..16 -> limbs H[9..16] (29 bit each); its last carry is H[17] (<= 2^35)
-//   low chain   columns 0..8; limb H[p] (weight 2^(29p) = 2^(29(p-9)) * 2^261, and 2^261 = R0 + 2^8 * 2^29 mod p)
-//               joins column p-9 as R0*H[p] and column p-8 as 2^8*H[p] -- two more multiply-adds in those chains
-//   tail        H[17] is only known when the high chain ends: its column-8 term (R0*H[17]) joins the last low
-//               column; its column-9 term 2^8*H[17]*2^261 folds once more into limbs 0 and 1 together with the
-//               bits >= 2^256 of column 8 (2^256 = 977 + 8 * 2^29), followed by a three-limb carry
+// additions.  Two chains, one after the other (round 4: the wrap-around of the top is known BEFORE the low columns run,
+// so nothing has to be carried through finished limbs afterwards):
+//   high chain  columns 8..16 -> h[0..8] (29 bits each; h[j] has weight 2^(29(8+j))); its last carry is H17 (< 2^22).
+//               Column 8 heads this chain, so its overflow (the largest of all: ~2^33 beyond its 29 bits) rides into
+//               column 9 like any other carry
+//   fold        2^261 = R0 + 2^8 * 2^29 (mod p): h[j] (j >= 1) joins column j-1 as R0*h[j] and column j as 2^8*h[j].
+//               H17 would join column 8 as R0*H17 and column 9 as 2^8*H17 -- the latter simply makes h[1] (weight
+//               2^261) larger: h[1] += H17 << 8.  What column 8 holds before the low chain reaches it,
+//               P8 = R0*H17 + 2^8*h[8] + h[0] (< 2^38), is split at bit 32: P8.hi * 2^32 * 2^232 = 8*P8.hi * 2^261
+//               also joins h[1] (now < 2^31, still a 32-bit factor); P8.lo waits for the end
+//   low chain   columns 0..7 with the folds -> r[0..7]; its last carry c7 (< 2^35)
+//   end         column 8 = c7 + P8.lo (< 2^36): r[8] = its low 24 bits, the rest e2 (<= 2064) is a multiple of
+//               2^256 = 977 + 8 * 2^29: r[0] += 977*e2 (< 2^21: stays on the limb, hence FE_LIM29), r[1] += 8*e2
 // PROD(k, acc, ch) must add the partial products of column k into acc with fe_mac<ch>().
-// On the device the chains run as one hand-ordered asm statement per multiply (LAMD_FE_ASM_BLOCK, generated into
-// fe_asm.inc by tools/gen_fe_asm.py from exactly this schedule); the C form below is what the host build checks and what
+// On the device the whole operation is one hand-ordered asm statement (LAMD_FE_ASM_BLOCK, generated into fe_asm.inc by
+// tools/gen_fe_asm.py from exactly this schedule); the C form below is what the host build checks and what
 // -DLAMD_FE_NO_ASM_BLOCK falls back to.
+// Column budget (magnitude products summing to M <= 7, L = FE_LIM29): a column is at most 8 full products + one with a
+// 24-bit limb < 8.04 * M * L^2 < 56.8 * 2^58, the folds (< 2^47) and carries (< 2^35) are noise: < 2^64.
 #define LAMD_FE_CHAINS(PROD)                                                                        \
-  u32 h[8];                                                                                         \
+  u32 h[9];                                                                                         \
   fe r;                                                                                             \
   u64 hi = 0, lo = 0;                                                                               \
-  PROD(9, hi, 1);                                                                                   \
-  h[0] = (u32)hi & FE_M29;                                                                          \
-  hi >>= 29;                                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 9; j++) {                                                   \
+    PROD(8 + j, hi, 1);                                                                             \
+    h[j] = (u32)hi & FE_M29;                                                                        \
+    hi >>= 29;                                                                                      \
+  }                                                                                                 \
+  LAMD_ASSERT((hi >> 22) == 0);                           /* column 16 is one product of 24-bit limbs */ \
+  h[1] += (u32)hi << FE_R1_SHIFT;                                                                   \
+  u64 p8 = (u64)(u32)hi * FE_R0;                                                                    \
+  p8 += (u64)h[8] << FE_R1_SHIFT;                                                                   \
+  p8 += h[0];                                                                                       \
+  LAMD_ASSERT((p8 >> 38) == 0);                                                                     \
+  h[1] += (u32)(p8 >> 32) << 3;                                                                     \
   _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                   \
-    if (k < 7) {                                                                                    \
-      PROD(10 + k, hi, 1);                                                                          \
-      h[k + 1] = (u32)hi & FE_M29;                                                                  \
-      hi >>= 29;                                                                                    \
-    }                                                                                               \
     PROD(k, lo, 0);                                                                                 \
-    fe_mac_k(lo, h[k], FE_R0);                                                                      \
-    if (k > 0) fe_mac_k(lo, h[k - 1], 1u << FE_R1_SHIFT);                                           \
+    fe_mac_k(lo, h[k + 1], FE_R0);                                                                  \
+    if (k > 0) fe_mac_k(lo, h[k], 1u << FE_R1_SHIFT);                                               \
     r.n[k] = (u32)lo & FE_M29;                                                                      \
     lo >>= 29;                                                                                      \
   }                                                                                                 \
-  PROD(8, lo, 0);                                                                                   \
-  fe_mac_k(lo, h[7], 1u << FE_R1_SHIFT);
-// r.n[0..7], lo (column 8 so far) and hi (= H[17], <= 2^35) -> the finished product
-#define LAMD_FE_TAIL                                                                                \
-  LAMD_ASSERT((hi >> 32) == 0);                           /* column 16 is one product: H[17] < 2^26 */ \
-  const u32 h17 = (u32)hi;                                                                          \
-  lo += (u64)h17 * FE_R0;                                                                           \
+  lo += (u32)p8;                                                                                    \
   r.n[8] = (u32)lo & FE_M24;                                                                        \
-  const u64 e = lo >> 24;                                 /* <= 2^40 */                             \
-  u64 t = (u64)r.n[0] + e * 977u + (u64)h17 * (FE_R0 << FE_R1_SHIFT);                               \
-  r.n[0] = (u32)t & FE_M29;                                                                         \
-  t = (t >> 29) + (u64)r.n[1] + (e << 3) + ((u64)h17 << (2 * FE_R1_SHIFT));                          \
-  r.n[1] = (u32)t & FE_M29;                                                                         \
-  t = (t >> 29) + (u64)r.n[2];                                                                      \
-  r.n[2] = (u32)t & FE_M29;                                                                         \
-  r.n[3] += (u32)(t >> 29);                                                                         \
+  const u32 e2 = (u32)(lo >> 24);                                                                   \
+  LAMD_ASSERT((lo >> 24) <= 2064);                                                                  \
+  r.n[0] += e2 * 977u;                                                                              \
+  r.n[1] += e2 << 3;                                                                                \
   FE_SETMAG(r, 1);                                                                                  \
   fe_verify(r);                                                                                     \
+  return r;
+
+// the asm statements' operand lists (tools/gen_fe_asm.py: operand map) and what follows them
+#define LAMD_FE_ASM_DECL                                                                            \
+  fe r;                                                                                             \
+  u64 hi, lo;                                                                                       \
+  u32 e2;
+#define LAMD_FE_ASM_OUT                                                                             \
+  "=&v"(r.n[0]), "=&v"(e2), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]),       \
+      "=&v"(r.n[7]), "=&v"(r.n[8]), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+#define LAMD_FE_ASM_K "s"(FE_R0), "s"(1u << FE_R1_SHIFT), "s"(977u)
+#define LAMD_FE_ASM_DONE                                                                            \
+  (void)e2;                                                                                         \
+  FE_SETMAG(r, 1);                                                                                  \
   return r;
 
 template <int CH>
@@ -295,28 +312,19 @@ LAMD_HD void fe_sqr_col(const fe &a, const u32 d[9], int k, u64 &acc) {
   }
 }
 
+#define LAMD_FE_ASM_IO9(x) "v"(x.n[0]), "v"(x.n[1]), "v"(x.n[2]), "v"(x.n[3]), "v"(x.n[4]), "v"(x.n[5]), "v"(x.n[6]), "v"(x.n[7]), "v"(x.n[8])
+
 // r = a*b; requires mag(a)*mag(b) <= 7
 LAMD_HD fe fe_mul(const fe &a, const fe &b) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7);
 #if defined(LAMD_FE_ASM_BLOCK)
-  // the chains as ONE asm statement (fe_asm.inc): no compiler-inserted s_nop between the dependent multiply-adds
-  fe r;
-  u64 hi, lo;
-  u32 t0, t1, t2;
-  u64 cy0, cy1;  // dead carry-outs of the two chains (SGPR pairs; unused when the schedule sends them to VCC)
-  (void)cy0; (void)cy1;
-  asm(LAMD_FE_MUL_ASM
-      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo) LAMD_FE_ASM_EXTRA_OUT
-      : "v"(a.n[0]), "v"(a.n[1]), "v"(a.n[2]), "v"(a.n[3]), "v"(a.n[4]), "v"(a.n[5]), "v"(a.n[6]), "v"(a.n[7]), "v"(a.n[8]),
-        "v"(b.n[0]), "v"(b.n[1]), "v"(b.n[2]), "v"(b.n[3]), "v"(b.n[4]), "v"(b.n[5]), "v"(b.n[6]), "v"(b.n[7]), "v"(b.n[8]),
-        "s"(FE_R0), "s"(1u << FE_R1_SHIFT) LAMD_FE_ASM_EXTRA_IN
-      : LAMD_FE_ASM_CLOBBER);
-  LAMD_FE_TAIL
+  // the whole multiplication as ONE asm statement (fe_asm.inc): no compiler-inserted s_nop between the dependent multiply-adds
+  LAMD_FE_ASM_DECL
+  asm(LAMD_FE_MUL_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K : "vcc");
+  LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) fe_mul_col<ch>(a, b, k, acc)
   LAMD_FE_CHAINS(LAMD_P)
-  LAMD_FE_TAIL
 #undef LAMD_P
 #endif
 }
@@ -324,55 +332,36 @@ LAMD_HD fe fe_mul(const fe &a, const fe &b) {
 // r = a^2; requires mag(a) <= 2
 LAMD_HD fe fe_sqr(const fe &a) {
   LAMD_ASSERT(FE_MAG(a) <= 2);
-  u32 d[9];
+  fe d;
 #pragma unroll
-  for (int i = 0; i < 9; i++) d[i] = a.n[i] << 1;
+  for (int i = 0; i < 9; i++) d.n[i] = a.n[i] << 1;
 #if defined(LAMD_FE_ASM_BLOCK)
-  fe r;
-  u64 hi, lo;
-  u32 t0, t1, t2;
-  u64 cy0, cy1;  // dead carry-outs of the two chains (SGPR pairs; unused when the schedule sends them to VCC)
-  (void)cy0; (void)cy1;
-  asm(LAMD_FE_SQR_ASM
-      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo) LAMD_FE_ASM_EXTRA_OUT
-      : "v"(a.n[0]), "v"(a.n[1]), "v"(a.n[2]), "v"(a.n[3]), "v"(a.n[4]), "v"(a.n[5]), "v"(a.n[6]), "v"(a.n[7]), "v"(a.n[8]),
-        "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(d[4]), "v"(d[5]), "v"(d[6]), "v"(d[7]), "v"(d[8]),
-        "s"(FE_R0), "s"(1u << FE_R1_SHIFT) LAMD_FE_ASM_EXTRA_IN
-      : LAMD_FE_ASM_CLOBBER);
-  LAMD_FE_TAIL
+  LAMD_FE_ASM_DECL
+  asm(LAMD_FE_SQR_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), LAMD_FE_ASM_K : "vcc");
+  LAMD_FE_ASM_DONE
 #else
-#define LAMD_P(k, acc, ch) fe_sqr_col<ch>(a, d, k, acc)
+#define LAMD_P(k, acc, ch) fe_sqr_col<ch>(a, d.n, k, acc)
   LAMD_FE_CHAINS(LAMD_P)
-  LAMD_FE_TAIL
 #undef LAMD_P
 #endif
 }
 
-// ---- fused forms: ONE reduction (fold, carries, tail) for a product plus something else.  The group law is full of
+// ---- fused forms: ONE reduction (fold, carries, wrap-around) for a product plus something else.  The group law is full of
 // "product minus value" and "product minus product" (U2 - X1, S2 - Y1, R^2 - H^3 - 2V, R*(V - X3) - Y1*H^3): as separate
 // operations each costs a lazy negation, an addition and a fe_norm_weak (~48 instructions) or a whole second reduction
 // (~75); here the extra terms join the column accumulators of the multiply -- limb k of the addend as one more multiply-add
-// (times 1) in column k, a second product as 81 more multiply-adds -- and the result comes out exactly carried (magnitude 1).
+// (times 1) in column k, a second product as 81 more multiply-adds -- and the result comes out carried (magnitude 1).
 // Column budget as for fe_mul: mag(a)*mag(b) [+ mag(c)*mag(d)] <= 7; an addend of magnitude <= 7 is noise against that.
-#define LAMD_FE_ASM_IO9(x) "v"(x.n[0]), "v"(x.n[1]), "v"(x.n[2]), "v"(x.n[3]), "v"(x.n[4]), "v"(x.n[5]), "v"(x.n[6]), "v"(x.n[7]), "v"(x.n[8])
 // r = a*b + e
 LAMD_HD fe fe_mul_add(const fe &a, const fe &b, const fe &ad) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7 && FE_MAG(ad) <= 7);
-#if defined(LAMD_FE_ASM_BLOCK) && defined(LAMD_FE_MULADD_ASM)
-  fe r;
-  u64 hi, lo;
-  u32 t0, t1, t2;
-  asm(LAMD_FE_MULADD_ASM
-      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
-      : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), "s"(FE_R0), "s"(1u << FE_R1_SHIFT), LAMD_FE_ASM_IO9(ad)
-      : "vcc");
-  LAMD_FE_TAIL
+#if defined(LAMD_FE_ASM_BLOCK)
+  LAMD_FE_ASM_DECL
+  asm(LAMD_FE_MULADD_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(ad) : "vcc");
+  LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) do { fe_mul_col<ch>(a, b, k, acc); if ((k) < 9) acc += ad.n[(k) < 9 ? (k) : 0]; } while (0)
   LAMD_FE_CHAINS(LAMD_P)
-  LAMD_FE_TAIL
 #undef LAMD_P
 #endif
 }
@@ -382,40 +371,26 @@ LAMD_HD fe fe_sqr_add(const fe &a, const fe &ad) {
   fe d;
 #pragma unroll
   for (int i = 0; i < 9; i++) d.n[i] = a.n[i] << 1;
-#if defined(LAMD_FE_ASM_BLOCK) && defined(LAMD_FE_SQRADD_ASM)
-  fe r;
-  u64 hi, lo;
-  u32 t0, t1, t2;
-  asm(LAMD_FE_SQRADD_ASM
-      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
-      : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), "s"(FE_R0), "s"(1u << FE_R1_SHIFT), LAMD_FE_ASM_IO9(ad)
-      : "vcc");
-  LAMD_FE_TAIL
+#if defined(LAMD_FE_ASM_BLOCK)
+  LAMD_FE_ASM_DECL
+  asm(LAMD_FE_SQRADD_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(ad) : "vcc");
+  LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) do { fe_sqr_col<ch>(a, d.n, k, acc); if ((k) < 9) acc += ad.n[(k) < 9 ? (k) : 0]; } while (0)
   LAMD_FE_CHAINS(LAMD_P)
-  LAMD_FE_TAIL
 #undef LAMD_P
 #endif
 }
 // r = a*b + c*d
 LAMD_HD fe fe_mul2(const fe &a, const fe &b, const fe &c, const fe &d) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) + FE_MAG(c) * FE_MAG(d) <= 7);
-#if defined(LAMD_FE_ASM_BLOCK) && defined(LAMD_FE_MUL2_ASM)
-  fe r;
-  u64 hi, lo;
-  u32 t0, t1, t2;
-  asm(LAMD_FE_MUL2_ASM
-      : "=&v"(r.n[0]), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]), "=&v"(r.n[7]),
-        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
-      : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), "s"(FE_R0), "s"(1u << FE_R1_SHIFT), LAMD_FE_ASM_IO9(c), LAMD_FE_ASM_IO9(d)
-      : "vcc");
-  LAMD_FE_TAIL
+#if defined(LAMD_FE_ASM_BLOCK)
+  LAMD_FE_ASM_DECL
+  asm(LAMD_FE_MUL2_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(c), LAMD_FE_ASM_IO9(d) : "vcc");
+  LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) do { fe_mul_col<ch>(a, b, k, acc); fe_mul_col<ch>(c, d, k, acc); } while (0)
   LAMD_FE_CHAINS(LAMD_P)
-  LAMD_FE_TAIL
 #undef LAMD_P
 #endif
 }
