@@ -32,15 +32,26 @@ sys.path.insert(0, ROOT)
 W_ECDSA65 = 1.32e5
 W_SCHNORR = 1.65e5
 # 32x32->64 multiply-adds the ecmult kernel EXECUTES per verification.  A field multiplication is 99
-# v_mad_u64_u32 (97 in the generated block + 2 in the tail), a squaring 63; the fused forms add 9 for an addend and make a*b + c*d
+# v_mad_u64_u32 (one generated block, wrap-around included), a squaring 63; the fused forms add 9 for an addend and make a*b + c*d
 # 180.  Mixed addition (group.h gej_add_ge_fast): S + (M+9) + M + (M+9) + S + M + M + (S+9) + 180 + M = 990; doubling: 3 S +
 # (S+9) + M + (M+9) + M = 567; acceptance test: 3 M + 1 S.
+M_MUL, M_SQR, M_ADD, M_DBL = 99, 63, 990, 567
 def _mads(dbl, add):
-    return dbl * 567 + add * 990 + 3 * 99 + 63
+    return dbl * M_DBL + add * M_ADD + 3 * M_MUL + M_SQR
+# pairs first (verify_core.h "Pairs first", k_ecmult_keyed_pairs): the two comb entries of a column, and two G windows, are summed as affine
+# points first -- pass 1 one multiplication per pair (the prefix product), pass 2 M + M + M + (S+9) + (M+9) = 482 per pair -- and enter the
+# accumulator by ONE mixed addition; the inversion by division steps is ~1 840 32-bit multiplies (20 batches x 92), shared by the rows of a lane's batch
+M_PAIR, M_INV = M_MUL + 3 * M_MUL + (M_SQR + 9) + (M_MUL + 9), 1840
+def _mads_pairs(cols, g_windows, rows_per_inversion):
+    pairs = cols + g_windows // 2
+    adds = (cols - 1) + g_windows // 2 + (g_windows & 1)
+    return pairs * M_PAIR + adds * M_ADD + (cols - 1) * M_DBL + M_MUL + 3 * M_MUL + M_SQR + M_INV / max(1.0, rows_per_inversion)
 # ladder: 132 doublings (+1 for 2Q), 66 + 6 table additions, G windows; combs: both halves made odd by a lattice vector (no
 # repair additions), the first table point initialises the accumulator: 2D - 1 additions + D - 1 doublings + G windows.  G windows: one
 # mixed addition per window of the static table -- 11 with the 24-bit windows that ship from round 4 on (12 with 22 bits: rounds 1-3)
-def w_exec_table(g_windows):
+def w_exec_table(g_windows, pairs=False, rows_per_inversion=4.8):
+    if pairs:
+        return {0: _mads(132 + 1, 66 + g_windows + 6), 7: _mads_pairs(19, g_windows, rows_per_inversion), 10: _mads_pairs(13, g_windows, rows_per_inversion)}
     return {0: _mads(132 + 1, 66 + g_windows + 6), 7: _mads(18, 37 + g_windows), 10: _mads(12, 25 + g_windows)}   # ladder, 7-tooth comb, 10-tooth comb
 def g_windows_of(gtable_bytes):
     for bits in (16, 22, 24, 26):
@@ -428,8 +439,11 @@ def main():
         # (their acceptance tests differ by two field multiplications of ~650), so the average is over both kinds, as rocprofv3's is.
         teeth = int(keyed.get("ecdsa", (0, 0))[0])
         g_windows = g_windows_of(int(eng_cold.info()["gtable_bytes"]))
-        w_exec_t = w_exec_table(g_windows)
+        pairs_first = os.environ.get("LAMD_PAIRS", "0") == "1"          # experiment knob: k_ecmult_keyed_pairs for large calls (the default is k_ecmult_keyed<false, 3>)
+        resident_lanes = int(eng_cold.info()["compute_units"]) * 3 * 4 * 64
+        w_exec_t = w_exec_table(g_windows, pairs_first, min(6.0, max(1.0, rows_in_launch / resident_lanes)))
         w_exec = w_exec_t.get(teeth, w_exec_t[0])
+        kernel_name = "k_ecmult_keyed_pairs<3>" if pairs_first and teeth else ("k_ecmult_keyed<false, 3>" if teeth else "k_ecmult<3>")
         lm_ov = launch_ms.get(id(eng_cold)) if full else None          # default mode (the launches overlap): reported, never the roofline
         pipeline = {"ms": dt / args.steps * 1e3, "achieved": 2 * w_exec * rows_in_launch / (dt / args.steps) / 1e12,
                     "frac": 2 * w_exec * rows_in_launch / (dt / args.steps) / P_MUL32,
@@ -500,13 +514,13 @@ def main():
                       "kernel_ms_schnorr_isolated": dict(zip(("prep", "keys_and_tables", "ecmult", "parity_stage"), np.mean(np.array(isolated["schnorr"]), axis=0).tolist())),
                       "keyed_path": {k: {"per_key_tables": bool(v[0]), "distinct_keys": int(v[1])} for k, v in keyed.items()}},
             "roofline": dict(roof_mode, **{
-                "kernel": "%s (1 M-row ECDSA-65 / BIP-340 launches)" % ("k_ecmult_keyed<false, 3>: %d-tooth signed comb, bare formulas" % teeth if teeth else "k_ecmult"),
+                "kernel": "%s (1 M-row ECDSA-65 / BIP-340 launches)" % ("%s: %d-tooth signed comb, bare formulas%s" % (kernel_name, teeth, ", pairs first" if pairs_first else "") if teeth else "k_ecmult"),
                 "bound": "valu-int32-mul (not hbm, not mfma)",
                 "achieved": achieved / 1e12, "peak": P_MUL32 / 1e12, "unit": "Tmul32/s", "frac": achieved / P_MUL32,
                 "executed_mul32_per_verify": w_exec, "g_table_windows": g_windows,
                 "rows_note": "of a batch's %d rows: the others were decided before the ecmult (early reject of signatures whose scalars cannot pass "
                              "the preparation: r, s range and low-S; keys that do not parse; rows under rare keys take the ladder kernel)" % n,
-                "timing": "HIP event pair on the launching lane's stream right before and after every k_ecmult_keyed<false, 3> launch of the timed "
+                "timing": "HIP event pair on the launching lane's stream right before and after every " + kernel_name + " launch of the timed "
                           "steps of the CHAINED cold loop (lamd_set_ecmult_chain(1): a launch waits for the one submitted before it, so ONE is in flight "
                           "at a time and a bracket holds that launch plus the other lanes' front-end kernels).  `rocprofv3 --kernel-trace --stats -- "
                           "python bench.py --roofline-only` runs this loop only: its per-kernel average is the same quantity",

@@ -229,14 +229,14 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
 // the next column's first multiply-add, so a carry costs one 64-bit shift and one mask per column and no
 // additions.  Two chains, one after the other (round 4: the wrap-around of the top is known BEFORE the low columns run,
 // so nothing has to be carried through finished limbs afterwards):
-//   high chain  columns 8..16 -> h[0..8] (29 bits each; h[j] has weight 2^(29(8+j))); its last carry is H17 (< 2^22).
-//               Column 8 heads this chain, so its overflow (the largest of all: ~2^33 beyond its 29 bits) rides into
-//               column 9 like any other carry
-//   fold        2^261 = R0 + 2^8 * 2^29 (mod p): h[j] (j >= 1) joins column j-1 as R0*h[j] and column j as 2^8*h[j].
-//               H17 would join column 8 as R0*H17 and column 9 as 2^8*H17 -- the latter simply makes h[1] (weight
-//               2^261) larger: h[1] += H17 << 8.  What column 8 holds before the low chain reaches it,
-//               P8 = R0*H17 + 2^8*h[8] + h[0] (< 2^38), is split at bit 32: P8.hi * 2^32 * 2^232 = 8*P8.hi * 2^261
-//               also joins h[1] (now < 2^31, still a 32-bit factor); P8.lo waits for the end
+//   column 8    first; its low 29 bits h8 are set aside, its overflow (the largest of all: ~2^33) is the high chain's first carry
+//   high chain  columns 9..15 -> h[1..7] (29 bits each; h[j] has weight 2^(29(8+j))); column 16 is not cut: V = Vlo + 2^32 * Vhi
+//               (Vlo a full 32-bit word, Vhi < 2^19 -- the two registers of the accumulator as they are)
+//   fold        2^261 = R0 + 2^8 * 2^29 (mod p): h[j] joins column j-1 as R0*h[j] and column j as 2^8*h[j]; Vlo does the same
+//               from position 16.  Vhi * 2^32 * 2^(29*16) = (8*Vhi) * 2^(29*17) would join column 8 as R0*8*Vhi and column 9 as
+//               2^8*8*Vhi -- the latter simply makes h[1] (weight 2^261) larger: h[1] += Vhi << 11.  What column 8 holds before
+//               the low chain reaches it, P8 = 8*R0*Vhi + 2^8*Vlo + h8 (< 2^41), is split at bit 32: P8.hi * 2^32 * 2^232 =
+//               8*P8.hi * 2^261 also joins h[1] (now < 2^31, still a 32-bit factor); P8.lo waits for the end
 //   low chain   columns 0..7 with the folds -> r[0..7]; its last carry c7 (< 2^35)
 //   end         column 8 = c7 + P8.lo (< 2^36): r[8] = its low 24 bits, the rest e2 (<= 2064) is a multiple of
 //               2^256 = 977 + 8 * 2^29: r[0] += 977*e2 (< 2^21: stays on the limb, hence FE_LIM29), r[1] += 8*e2
@@ -247,24 +247,28 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
 // Column budget (magnitude products summing to M <= 7, L = FE_LIM29): a column is at most 8 full products + one with a
 // 24-bit limb < 8.04 * M * L^2 < 56.8 * 2^58, the folds (< 2^47) and carries (< 2^35) are noise: < 2^64.
 #define LAMD_FE_CHAINS(PROD)                                                                        \
-  u32 h[9];                                                                                         \
+  u32 h[8];                                                                                         \
   fe r;                                                                                             \
   u64 hi = 0, lo = 0;                                                                               \
-  _Pragma("unroll") for (int j = 0; j < 9; j++) {                                                   \
+  PROD(8, hi, 1);                                                                                   \
+  const u32 h8 = (u32)hi & FE_M29;                                                                  \
+  hi >>= 29;                                                                                        \
+  _Pragma("unroll") for (int j = 1; j < 8; j++) {                                                   \
     PROD(8 + j, hi, 1);                                                                             \
     h[j] = (u32)hi & FE_M29;                                                                        \
     hi >>= 29;                                                                                      \
   }                                                                                                 \
-  LAMD_ASSERT((hi >> 22) == 0);                           /* column 16 is one product of 24-bit limbs */ \
-  h[1] += (u32)hi << FE_R1_SHIFT;                                                                   \
-  u64 p8 = (u64)(u32)hi * FE_R0;                                                                    \
-  p8 += (u64)h[8] << FE_R1_SHIFT;                                                                   \
-  p8 += h[0];                                                                                       \
-  LAMD_ASSERT((p8 >> 38) == 0);                                                                     \
+  PROD(16, hi, 1);                                                                                  \
+  const u32 vlo = (u32)hi, vhi = (u32)(hi >> 32);                                                   \
+  LAMD_ASSERT(vhi < (1u << 19));                          /* column 16 is one product of 24-bit limbs */ \
+  h[1] += vhi << (3 + FE_R1_SHIFT);                                                                 \
+  u64 p8 = (u64)vhi * (8u * FE_R0) + h8;                                                            \
+  p8 += (u64)vlo << FE_R1_SHIFT;                                                                    \
+  LAMD_ASSERT((p8 >> 41) == 0);                                                                     \
   h[1] += (u32)(p8 >> 32) << 3;                                                                     \
   _Pragma("unroll") for (int k = 0; k < 8; k++) {                                                   \
     PROD(k, lo, 0);                                                                                 \
-    fe_mac_k(lo, h[k + 1], FE_R0);                                                                  \
+    fe_mac_k(lo, k < 7 ? h[k < 7 ? k + 1 : 1] : vlo, FE_R0);                                        \
     if (k > 0) fe_mac_k(lo, h[k], 1u << FE_R1_SHIFT);                                               \
     r.n[k] = (u32)lo & FE_M29;                                                                      \
     lo >>= 29;                                                                                      \
@@ -287,7 +291,7 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
 #define LAMD_FE_ASM_OUT                                                                             \
   "=&v"(r.n[0]), "=&v"(e2), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]),       \
       "=&v"(r.n[7]), "=&v"(r.n[8]), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
-#define LAMD_FE_ASM_K "s"(FE_R0), "s"(1u << FE_R1_SHIFT), "s"(977u)
+#define LAMD_FE_ASM_K "s"(FE_R0), "s"(1u << FE_R1_SHIFT), "s"(977u), "s"(8u * FE_R0)
 #define LAMD_FE_ASM_DONE                                                                            \
   (void)e2;                                                                                         \
   FE_SETMAG(r, 1);                                                                                  \

@@ -327,7 +327,7 @@ constexpr u32 ENT_NONE = 0xFFFFFFFFu;
 enum { C_ENT = 0, C_USED7 = 1, C_USED10 = 2, C_WORDS = 4 };  // cache counters
 // per-call counters ("plan"): everything the host used to read back to size the next launches now stays on the device;
 // launches cover upper bounds and the kernels take their real extent from here
-enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_DENSE = 8, P_COLDOK = 9, P_EARLY = 10, P_WORDS = 16 };
+enum { P_UNIQ = 0, P_HK7 = 1, P_HK10 = 2, P_L7 = 3, P_L10 = 4, P_COLD = 5, P_HITS = 6, P_SUSPECT = 7, P_DENSE = 8, P_COLDOK = 9, P_EARLY = 10, P_TOUCHED = 11, P_G7 = 12, P_G10 = 13, P_WORDS = 16 };
 constexpr u8 VERDICT_SUSPECT = 3;  // the bare-formula ecmult met Z = 0: the complete form decides (k_ecmult_keyed_careful)
 
 LAMD_HD void key_words(u32 kw[17], const u8 *p, int len) {
@@ -758,6 +758,77 @@ __global__ void __launch_bounds__(256) k_kc_finish_both(const u32 *__restrict__ 
   else kc_finish_body<10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, P);
 }
 
+// ---- rows of one key next to each other (round 4).  The row lists come out of the list builders in arrival order, so the 64 lanes of an ecmult
+// wave read 64 different keys' tables: every comb entry a cache miss, 4 KB of random HBM traffic per verification (25x the algorithmic bytes).
+// Three small kernels regroup the lists by key (cache entry) -- a counting sort whose histogram lives in a per-lane array over the entry ids:
+//   k_group_count    every listed row takes its rank among its key's rows (one atomic per distinct key and WAVE: a batch under one key would
+//                    otherwise serialise a million atomics on one word); the first row of a key notes the entry as touched
+//   k_group_alloc    every touched entry gets a contiguous range of its shape's grouped list (wave-level scan + one atomic per wave) and its
+//                    counter goes back to zero for the next call
+//   k_group_scatter  row -> range base + rank
+// After it a wave's lanes share a handful of tables (6 KB / 48 KB each, L1 / L2 resident) and HBM sees each table about once.
+__device__ __forceinline__ u32 wave_alloc_range(u32 *counter, bool pred, u32 count) {
+  const u32 lane = threadIdx.x & 63u;
+  u32 incl = pred ? count : 0u;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const u32 up = __shfl_up(incl, o, 64);
+    if (lane >= (u32)o) incl += up;
+  }
+  const u32 total = __shfl(incl, 63, 64);
+  u32 base = 0;
+  if (lane == 63u && total) base = atomicAdd(counter, total);
+  base = __shfl(base, 63, 64);
+  return base + incl - (pred ? count : 0u);
+}
+__global__ void __launch_bounds__(256) k_group_count(u32 *__restrict__ plan, const u32 *__restrict__ list7, const u32 *__restrict__ list10,
+                                                     const u32 *__restrict__ row_ent, u32 *__restrict__ ent_cnt, u32 *__restrict__ rank,
+                                                     u32 *__restrict__ touched) {
+  LAMD_PRIO(1);
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t7 = plan[P_L7], total = t7 + plan[P_L10];
+  const bool live = j < total;
+  const u32 lane = threadIdx.x & 63u;
+  const u32 ent = live ? row_ent[j < t7 ? list7[j] : list10[j - t7]] : ENT_NONE;
+  u32 r = 0;
+  u64 todo = __ballot(live);
+  while (todo) {  // one round per distinct entry among the wave's rows
+    const int leader = __ffsll((long long)todo) - 1;
+    const u32 e = __shfl(ent, leader, 64);
+    const bool mine = live && ent == e;
+    const u64 same = __ballot(mine);
+    u32 base = 0;
+    if ((int)lane == leader) base = atomicAdd(&ent_cnt[e], (u32)__popcll(same));
+    base = __shfl(base, leader, 64);
+    if (mine) r = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (live) rank[j] = r;
+  const bool first = live && r == 0;
+  const u32 p = wave_alloc(&plan[P_TOUCHED], first, 0, nullptr);
+  if (first) touched[p] = ent;
+}
+__global__ void __launch_bounds__(256) k_group_alloc(u32 *__restrict__ plan, const u32 *__restrict__ touched, const cache_ent *__restrict__ ents,
+                                                     u32 *__restrict__ ent_cnt, u32 *__restrict__ ent_base) {
+  LAMD_PRIO(1);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = t < plan[P_TOUCHED];
+  const u32 ent = live ? touched[t] : 0u, c = live ? ent_cnt[ent] : 0u;
+  const bool ten = live && (ents[ent].meta & 0xFFu) == 10u;
+  const u32 b7 = wave_alloc_range(&plan[P_G7], live && !ten, c), b10 = wave_alloc_range(&plan[P_G10], ten, c);
+  if (live) {
+    ent_base[ent] = ten ? b10 : b7;
+    ent_cnt[ent] = 0;
+  }
+}
+__global__ void __launch_bounds__(256) k_group_scatter(const u32 *__restrict__ plan, const u32 *__restrict__ list7, const u32 *__restrict__ list10,
+                                                       const u32 *__restrict__ row_ent, const u32 *__restrict__ ent_base, const u32 *__restrict__ rank,
+                                                       u32 *__restrict__ glist7, u32 *__restrict__ glist10) {
+  LAMD_PRIO(1);
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t7 = plan[P_L7], total = t7 + plan[P_L10];
+  if (j >= total) return;
+  const u32 i = j < t7 ? list7[j] : list10[j - t7];
+  (j < t7 ? glist7 : glist10)[ent_base[row_ent[i]] + rank[j]] = i;
+}
 // work item j verifies one row against the comb table of its key: items [0, plan[P_L7]) are the rows of list7 (7-tooth combs),
 // the plan[P_L10] items after them the rows of list10.  ONE launch covers both shapes: the lists' lengths are only known on the
 // device, and a launch of its own for a list that turns out empty still has to get its blocks dispatched -- behind another lane's
@@ -839,6 +910,71 @@ __global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 
     out[i] = ok ? 1 : 0;
   }
 }
+// The table-driven ecmult, pairs first (verify_core.h "Pairs first"): a PERSISTENT grid -- at most as many blocks as the chip holds -- in
+// which a lane owns rows tid, tid + nthreads, ... of a list and takes them in batches of <= PAIRS_BMAX rows per field inversion (1 M rows
+// on 196 608 lanes: 4 or 5 rows each, one batch).  ws: PAIRS_SLOTS parking slots per lane, slot s of lane tid at
+// ws[(s * nthreads + tid) * PAIRS_WS_WORDS] (a wave's 64 slots are contiguous).  Verdicts, suspects and the BIP-340 parity stage's
+// input as k_ecmult_keyed<false> writes them; the CAREFUL launch of that kernel follows this one unchanged.
+template <int T>
+__device__ __forceinline__ void keyed_pairs_list(u32 *plan, size_t cnt, const u32 *__restrict__ list, const prep_rec *__restrict__ recs,
+                                                 const u32 *__restrict__ row_ent, const cache_ent *__restrict__ ents, const u32 *__restrict__ pool,
+                                                 const u8 *__restrict__ sig64, int mode, const u32 *__restrict__ gtable, u32 *__restrict__ fin,
+                                                 u8 *__restrict__ keyok_row, u8 *__restrict__ out, u32 *myws, size_t nthreads, size_t tid) {
+#pragma unroll 1
+  for (size_t base = tid; base < cnt; base += nthreads * PAIRS_BMAX) {
+    const size_t left = (cnt - base + nthreads - 1) / nthreads;  // rows of this lane from `base` on
+    const int nb = left < (size_t)PAIRS_BMAX ? (int)left : PAIRS_BMAX;
+    pairs_batch<T>(
+        nb, gtable, myws, nthreads * PAIRS_WS_WORDS,
+        [&](int b, bool first, const prep_rec **rec, const u32 **tab) {
+          const size_t i = list[base + (size_t)b * nthreads];
+          *rec = recs + i;
+          *tab = pool + (size_t)ents[row_ent[i]].tabslot * kc_stride(T);
+          if (first) {
+            if (keyok_row) keyok_row[i] = 1;  // rows on these lists have a parsed key
+            if (!(recs[i].flags & PREP_VALID)) {
+              out[i] = 0;
+              return false;
+            }
+          }
+          return true;
+        },
+        [&](int b, const gej &R, bool suspect) {
+          const size_t i = list[base + (size_t)b * nthreads];
+          if (suspect) {
+            out[i] = VERDICT_SUSPECT;
+            atomicAdd(&plan[P_SUSPECT], 1u);
+            return;
+          }
+          u32 rw[8];
+          load_words_be(rw, sig64 + 64 * i);
+          if (mode == MODE_ECDSA) out[i] = ecdsa_final(R, rw) ? 1 : 0;
+          else out[i] = schnorr_stage1(R, rw, fin + i * FIN_WORDS);
+        });
+  }
+}
+// (one wave per workgroup: the grid is sized to fill the chip exactly once, and a free wave slot must be able to take any waiting workgroup -- with
+// four-wave workgroups a quarter of them found no CU with four free slots on four SIMDs and ran as a second round: 4.0 ms instead of 3.0)
+constexpr unsigned PAIRS_THREADS = 64;
+template <int WAVES>
+__global__ void __launch_bounds__(PAIRS_THREADS, WAVES) k_ecmult_keyed_pairs(u32 *plan, const u32 *__restrict__ list7, const u32 *__restrict__ list10,
+                                                      const prep_rec *__restrict__ recs, const u32 *__restrict__ row_ent,
+                                                      const cache_ent *__restrict__ ents, const u32 *__restrict__ pool7,
+                                                      const u32 *__restrict__ pool10, const u8 *__restrict__ sig64, int mode,
+                                                      const u32 *__restrict__ gtable, u32 *__restrict__ fin, u8 *__restrict__ keyok_row,
+                                                      u8 *__restrict__ out, u32 *__restrict__ ws) {
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  u32 *myws = ws + tid * PAIRS_WS_WORDS;
+  keyed_pairs_list<7>(plan, plan[P_L7], list7, recs, row_ent, ents, pool7, sig64, mode, gtable, fin, keyok_row, out, myws, nthreads, tid);
+  keyed_pairs_list<10>(plan, plan[P_L10], list10, recs, row_ent, ents, pool10, sig64, mode, gtable, fin, keyok_row, out, myws, nthreads, tid);
+}
+#if defined(LAMD_PAIRS_CLOCK)
+extern "C" int lamd_debug_pairs_clock(unsigned long long out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lamd::g_pairs_clk), 64) != hipSuccess) return -1;
+  if (reset) { const unsigned long long z[8] = {0, 0, 0, 0, ~0ULL, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lamd::g_pairs_clk), z, 64) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 // ---- small batches with a key-table cache: one kernel probes the cache for every row and writes the three row lists straight
 // away (cached 7-tooth comb / cached 10-tooth comb / ladder) -- no de-duplication, no table building, so a commitment_signed
 // whose htlc key is cached costs a dozen launches instead of the two dozen of the partitioning path.  Nothing is inserted here;
@@ -1160,6 +1296,11 @@ struct lamd_ctx {
                                      // leaves a tail of partly filled iterations: 3.19 ms -> 3.9 ms at 4 blocks per CU)
   u32 *gtable5 = nullptr;          // -DLAMD_G_LDS experiment: 52 x 32 entries of 5-bit windows of G, staged into LDS by the kernel
   unsigned keyed_lds_pad = 0;      // LAMD_KEYED_LDS_PAD: dynamic LDS bytes requested by the table-driven ecmult launches (occupancy limiter: 65536 = two blocks per CU)
+  bool pairs = false;              // LAMD_PAIRS=1 (experiment, parity-green, measured slower: DESIGN.md 4): the table-driven ecmult of a large call pairs first (k_ecmult_keyed_pairs)
+                                   // instead of one mixed addition per table entry (k_ecmult_keyed<false>)
+  bool group_rows = true;          // LAMD_GROUP=0: the row lists of a large call stay in arrival order (no k_group_*)
+  devbuf g_cnt, g_base, g_rank, g_touched, g_list7, g_list10;   // k_group_*: histogram / range bases over the cache's entry ids, rank per listed row, touched entries, grouped lists
+  devbuf pairs_ws;                 // parking slots of k_ecmult_keyed_pairs (PAIRS_SLOTS x 48 bytes per resident lane)
   int keyed_waves = 3;             // LAMD_KEYED_WAVES: occupancy the bare-formula keyed kernels are compiled for (3: no spill; 4: a 5-dword spill, measured 60 % slower)
   size_t prep_batch = 16;  // signatures sharing one scalar inversion in the ECDSA prep (LAMD_PREP_BATCH)
   size_t prep_min_threads = 0;  // LAMD_PREP_MIN_THREADS: fewest prep threads of a large batch (0 = 256 per CU)
@@ -1353,6 +1494,8 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->gtable5 = root->gtable5;
     L->ecmult_waves = root->ecmult_waves;
     L->keyed_waves = root->keyed_waves;
+    L->pairs = root->pairs;
+    L->group_rows = root->group_rows;
     L->keyed_lds_pad = root->keyed_lds_pad;
     L->keyed_blocks_per_cu = root->keyed_blocks_per_cu;
     L->prep_batch = root->prep_batch;
@@ -1408,6 +1551,8 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_ECMULT_WAVES")) ctx->ecmult_waves = atoi(w);
   if (const char *w = getenv("LAMD_KEYED_WAVES")) ctx->keyed_waves = atoi(w) == 4 ? 4 : 3;
   if (const char *w = getenv("LAMD_KEYED_LDS_PAD")) ctx->keyed_lds_pad = (unsigned)atoi(w);
+  if (const char *w = getenv("LAMD_PAIRS")) ctx->pairs = atoi(w) != 0;
+  if (const char *w = getenv("LAMD_GROUP")) ctx->group_rows = atoi(w) != 0;
   if (const char *w = getenv("LAMD_KEYED_BLOCKS_PER_CU")) ctx->keyed_blocks_per_cu = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_SPIN_US")) ctx->spin_us = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_PRIO")) ctx->prio_mask = (u32)atoi(w);
@@ -1510,7 +1655,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   for (devbuf *b : {&ctx->row_ent, &ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->plan,
                     &ctx->kt_fin, &ctx->hk7_row, &ctx->hk7_ent, &ctx->hk7_slot, &ctx->hk7_qwords, &ctx->hk7_keyok, &ctx->hk7_scratch,
                     &ctx->hk10_row, &ctx->hk10_ent, &ctx->hk10_slot, &ctx->hk10_qwords, &ctx->hk10_keyok, &ctx->hk10_scratch, &ctx->list7,
-                    &ctx->list10, &ctx->listcold, &ctx->listcold_ok, &ctx->keyok_row, &ctx->cache_store.ents, &ctx->cache_store.index, &ctx->cache_store.pool7,
+                    &ctx->list10, &ctx->listcold, &ctx->listcold_ok, &ctx->keyok_row, &ctx->pairs_ws, &ctx->g_cnt, &ctx->g_base, &ctx->g_rank, &ctx->g_touched, &ctx->g_list7, &ctx->g_list10, &ctx->cache_store.ents, &ctx->cache_store.index, &ctx->cache_store.pool7,
                     &ctx->cache_store.pool10, &ctx->cache_store.counters})
     release(b);
   for (auto &e : ctx->ev_pub)
@@ -2105,6 +2250,25 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     if (rc != LAMD_OK) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
   }
+  if (ctx->group_rows && n >= 4096) {
+    // rows of one key next to each other (k_group_*): from here on list7 / list10 are the grouped lists
+    const size_t ent_words = kc->cap_ent;
+    if (ctx->g_cnt.cap < ent_words * 4) {  // the histogram must start out zeroed (k_group_alloc leaves it so)
+      if ((rc = ensure(ctx, &ctx->g_cnt, ent_words * 4)) != LAMD_OK) return rc;
+      HIPCHK(ctx, hipMemsetAsync(ctx->g_cnt.p, 0, ctx->g_cnt.cap, ctx->stream));
+    }
+    if ((rc = ensure(ctx, &ctx->g_base, ent_words * 4)) != LAMD_OK) return rc;
+    for (devbuf *b : {&ctx->g_rank, &ctx->g_touched, &ctx->g_list7, &ctx->g_list10})
+      if ((rc = ensure(ctx, b, n * 4)) != LAMD_OK) return rc;
+    hipLaunchKernelGGL(k_group_count, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (const u32 *)list7, (const u32 *)list10, (const u32 *)row_ent,
+                       (u32 *)ctx->g_cnt.p, (u32 *)ctx->g_rank.p, (u32 *)ctx->g_touched.p);
+    hipLaunchKernelGGL(k_group_alloc, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, plan, (const u32 *)ctx->g_touched.p, ents, (u32 *)ctx->g_cnt.p,
+                       (u32 *)ctx->g_base.p);
+    hipLaunchKernelGGL(k_group_scatter, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, (const u32 *)plan, (const u32 *)list7, (const u32 *)list10,
+                       (const u32 *)row_ent, (const u32 *)ctx->g_base.p, (const u32 *)ctx->g_rank.p, (u32 *)ctx->g_list7.p, (u32 *)ctx->g_list10.p);
+    list7 = (u32 *)ctx->g_list7.p;
+    list10 = (u32 *)ctx->g_list10.p;
+  }
   if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
   // (the bare-formula kernel fits 4 waves per SIMD with a spill, or 3 without: LAMD_KEYED_WAVES)
@@ -2141,9 +2305,19 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream_lo, ctx->ev_lo_go, 0));
     ks = ctx->stream_lo;
   }
-  hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ks, plan, (const u32 *)list7, (const u32 *)list10, recs,
-                     (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
-                     keyok_out, d_ok, (const u32 *)ctx->gtable5, two_parts ? 1 : 0, root->ecm_tail);
+  if (ctx->pairs && ctx->keyed_waves == 3 && !two_parts && !ctx->gtable5) {
+    // pairs first: a persistent grid (what the chip holds at three waves per SIMD), every lane its share of the rows in batches per inversion
+    const unsigned resident = (unsigned)ctx->prop.multiProcessorCount * 3u * 4u, full = (unsigned)((n + PAIRS_THREADS - 1) / PAIRS_THREADS);
+    const unsigned grid = full < resident ? full : resident;
+    if ((rc = ensure(ctx, &ctx->pairs_ws, (size_t)PAIRS_SLOTS * PAIRS_WS_WORDS * 4 * grid * PAIRS_THREADS)) != LAMD_OK) return rc;
+    hipLaunchKernelGGL((k_ecmult_keyed_pairs<3>), dim3(grid), dim3(PAIRS_THREADS), ctx->keyed_lds_pad, ks, plan, (const u32 *)list7, (const u32 *)list10, recs,
+                       (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
+                       keyok_out, d_ok, (u32 *)ctx->pairs_ws.p);
+  } else {
+    hipLaunchKernelGGL(fast, dim3(keyed_grid(ctx, n)), dim3(LAMD_KEYED_THREADS), ctx->keyed_lds_pad, ks, plan, (const u32 *)list7, (const u32 *)list10, recs,
+                       (const u32 *)row_ent, ents, (const u32 *)kc->pool7.p, (const u32 *)kc->pool10.p, d_sig, mode, (const u32 *)ctx->gtable, fin,
+                       keyok_out, d_ok, (const u32 *)ctx->gtable5, two_parts ? 1 : 0, root->ecm_tail);
+  }
   if (bulk) {
     HIPCHK(ctx, hipEventRecord(ctx->ev_lo_done, ctx->stream_lo));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lo_done, 0));

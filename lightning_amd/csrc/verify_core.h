@@ -895,6 +895,221 @@ LAMD_HD gej ecmult_lane_keyed(const prep_rec &rec, const u32 *tab, const u32 *gt
 }
 
 // ================================================================================================
+// Pairs first (round 4): the table-driven ecmult with HALF its mixed additions replaced by affine + affine additions that share
+// one field inversion.  The ~49 points a verification sums are all affine table entries, and they come in natural pairs that sit
+// at the same doubling level: the two GLV halves' entries of one comb column, and two windows of u1*G.  A pair (x1, y1) + (x2, y2)
+// with the inverse of H = x2 - x1 at hand costs 2M + 1S (lambda = (y2 - y1)/H, x3 = lambda^2 - x1 - x2, y3 = lambda*(x1 - x3) - y1)
+// and the sum is affine again, so it enters the accumulator by ONE mixed addition (8M + 3S) where the two points took two.
+// The inverses come from Montgomery's trick over every pair of every row a lane owns in one batch (<= PAIRS_BMAX rows):
+//   pass 1  (pairs_prefix_row)  walks the pairs in ascending order multiplying the H values up; every prefix product is parked
+//           in a per-lane workspace in HBM (48 bytes each; the entries are only read for their x here);
+//   invert  ONE variable-time inversion (division steps, fe_inv_var) per batch;
+//   pass 2  (pairs_sum_row)  walks the pairs in DESCENDING order -- which is the Horner order of the comb: highest column first,
+//           then the G windows -- peeling 1/H off the running inverse with two multiplications per pair.
+// Per pair 1M + store (pass 1) and 4M + 1S + load (pass 2) against the 8M + 3S it removes; the inversion (~10^4 instructions)
+// is shared by the batch.  T = 7: 24 pairs of a row's 49 points; T = 10: 18 of 37.
+// Degenerate pairs (H = 0: the two entries equal or opposite -- no honest and, for the comb columns, no crafted scalar reaches
+// that: entry multipliers are below 2^115, the GLV lattice has no vector that short) would zero the whole product: pass 1 tests
+// the product after every ROW and hands such a row to the complete formulas (VERDICT_SUSPECT), leaving the batch intact.  A G
+// window whose digit is zero (2^-24) has no entry: its pair is not formed, the other window's entry is added on its own.
+constexpr int PAIRS_BMAX = 6;                                  // rows per lane and inversion
+constexpr int PAIRS_WS_WORDS = 12;                             // a parked prefix product: 9 limbs in 48 bytes
+constexpr int GT_PAIRS = GTABLE_WINDOWS / 2, GT_SINGLE = GTABLE_WINDOWS & 1;
+constexpr int pairs_per_row(int T) { return GT_PAIRS + kc_spacing(T); }
+constexpr int PAIRS_SLOTS = 1 + PAIRS_BMAX * pairs_per_row(7);  // slot 0 holds 1; T = 7 has the most pairs per row
+static_assert(pairs_per_row(7) >= pairs_per_row(8) && pairs_per_row(7) >= pairs_per_row(10), "workspace sized for the 7-tooth comb");
+
+LAMD_HD void pairs_ws_store(u32 *p, const fe &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint4 *q = reinterpret_cast<uint4 *>(p);
+  q[0] = make_uint4(a.n[0], a.n[1], a.n[2], a.n[3]);
+  q[1] = make_uint4(a.n[4], a.n[5], a.n[6], a.n[7]);
+  q[2] = make_uint4(a.n[8], 0u, 0u, 0u);
+#else
+  for (int i = 0; i < 9; i++) p[i] = a.n[i];
+#endif
+}
+LAMD_HD fe pairs_ws_load(const u32 *p) {
+  fe r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+  const uint4 a = q[0], b = q[1];
+  r.n[0] = a.x; r.n[1] = a.y; r.n[2] = a.z; r.n[3] = a.w;
+  r.n[4] = b.x; r.n[5] = b.y; r.n[6] = b.z; r.n[7] = b.w;
+  r.n[8] = p[8];
+#else
+  for (int i = 0; i < 9; i++) r.n[i] = p[i];
+#endif
+  FE_SETMAG(r, 1);
+  return r;
+}
+
+template <int T>
+LAMD_HD u32 comb_column(const u32 *tooth, int j) {
+  u32 m = 0;
+#pragma unroll
+  for (int i = 0; i < T; i++) m |= ((tooth[i] >> j) & 1u) << i;
+  return m;
+}
+
+// (x1, y1) + (x2, y2) with 1/(x2 - x1) = inv * pprev, where inv is the inverse of the product of the H values of this pair and
+// every pair before it; inv becomes the inverse of the product before this pair.  y1, y2 magnitude <= 2 (ge_neg_if_lazy).
+LAMD_HD ge pair_add_affine(const fe &x1, const fe &y1, const fe &x2, const fe &y2, const fe &pprev, fe &inv) {
+  const fe h = fe_sub(x2, x1, 1);                                  // (3)
+  const fe ih = fe_mul(inv, pprev);
+  inv = fe_mul(inv, h);
+  const fe lam = fe_mul(fe_sub(y2, y1, 2), ih);                    // (5) * (1)
+  ge r;
+  r.x = fe_sqr_add(lam, fe_neg(fe_add(x1, x2), 2));                // lambda^2 - x1 - x2
+  r.y = fe_mul_add(lam, fe_sub(x1, r.x, 1), fe_neg(y1, 2));        // lambda*(x1 - x3) - y1
+  return r;
+}
+
+// pass 1 over one row: multiplies the H values of its pairs (G pairs first, then the comb's columns in ascending order) onto P
+// and parks every prefix product: pair k of the row at ws + k * ws_stride (words)
+template <int T>
+LAMD_HD fe pairs_prefix_row(const prep_rec &rec, const u32 *tab, const u32 *gtable, fe P, u32 *ws, size_t ws_stride) {
+  constexpr int D = kc_spacing(T), NE = kc_ne(T);
+#pragma unroll 1
+  for (int p = 0; p < GT_PAIRS; p++) {
+    const u32 d0 = gtable_digit(rec.u1, 2 * p), d1 = gtable_digit(rec.u1, 2 * p + 1);
+    if (d0 != 0 && d1 != 0) {
+      const u32 *e0 = gtable + (((size_t)(2 * p) << GTABLE_WINDOW_BITS) + d0) * GT_ENTRY_WORDS;
+      const u32 *e1 = gtable + (((size_t)(2 * p + 1) << GTABLE_WINDOW_BITS) + d1) * GT_ENTRY_WORDS;
+      P = fe_mul(P, fe_sub(slot_load_fe(e1), slot_load_fe(e0), 1));
+    }
+    pairs_ws_store(ws + (size_t)p * ws_stride, P);
+  }
+  const comb_pair<T> cp = comb_from_rec_odd<T>(rec);
+#pragma unroll 1
+  for (int j = 0; j < D; j++) {
+    const u32 m1 = comb_column<T>(cp.tooth1, j), m2 = comb_column<T>(cp.tooth2, j);
+    const u32 i1 = (((m1 >> (T - 1)) & 1u) ? m1 : ~m1) & (u32)(NE - 1), i2 = (((m2 >> (T - 1)) & 1u) ? m2 : ~m2) & (u32)(NE - 1);
+    const fe x1 = slot_load_fe(tab + i1 * SLOT_ENTRY_WORDS + ENT_X), x2 = slot_load_fe(tab + i2 * SLOT_ENTRY_WORDS + ENT_BX);
+    P = fe_mul(P, fe_sub(x2, x1, 1));
+    pairs_ws_store(ws + (size_t)(GT_PAIRS + j) * ws_stride, P);
+  }
+  return P;
+}
+
+// pass 2 over one row: R = u1*G + (k1 + k2*lambda)*Q.  ws as in pass 1 (the slot before the row's first holds the product
+// before the row); inv: in, the inverse of the product through this row's last pair; out, of the product before its first.
+// Bare formulas throughout, *suspect as ecmult_lane_keyed_fast.
+template <int T>
+LAMD_HD gej pairs_sum_row(const prep_rec &rec, const u32 *tab, const u32 *gtable, fe &inv, const u32 *ws, size_t ws_stride, bool *suspect) {
+  constexpr int D = kc_spacing(T), NE = kc_ne(T);
+  const comb_pair<T> cp = comb_from_rec_odd<T>(rec);
+  gej acc = gej_infinity();
+#pragma unroll 1
+  for (int j = D - 1; j >= 0; j--) {
+    const u32 m1 = comb_column<T>(cp.tooth1, j), m2 = comb_column<T>(cp.tooth2, j);
+    const bool t1 = (m1 >> (T - 1)) & 1u, t2 = (m2 >> (T - 1)) & 1u;
+    const u32 *e1 = tab + ((t1 ? m1 : ~m1) & (u32)(NE - 1)) * SLOT_ENTRY_WORDS, *e2 = tab + ((t2 ? m2 : ~m2) & (u32)(NE - 1)) * SLOT_ENTRY_WORDS;
+    ge a, b;
+    a.x = slot_load_fe(e1 + ENT_X);
+    a.y = slot_load_fe(e1 + ENT_Y);
+    b.x = slot_load_fe(e2 + ENT_BX);
+    b.y = slot_load_fe(e2 + ENT_Y);
+    a = ge_neg_if_lazy(a, t1 == cp.n1);
+    b = ge_neg_if_lazy(b, t2 == cp.n2);
+    const fe pprev = pairs_ws_load(ws + ((ptrdiff_t)(GT_PAIRS + j) - 1) * (ptrdiff_t)ws_stride);
+    const ge s = pair_add_affine(a.x, a.y, b.x, b.y, pprev, inv);
+    if (j == D - 1) {  // uniform across the wave: the first sum is the accumulator
+      acc.x = s.x;
+      acc.y = s.y;
+      acc.z = fe_set_int(1);
+      acc.inf = false;
+    } else {
+      acc = gej_add_ge_fast(gej_double(acc), s);
+    }
+  }
+  acc.z = fe_mul(acc.z, slot_load_fe(tab + kc_words(T)));  // back from the table's isomorphic curve
+#pragma unroll 1
+  for (int p = GT_PAIRS - 1; p >= 0; p--) {
+    const u32 d0 = gtable_digit(rec.u1, 2 * p), d1 = gtable_digit(rec.u1, 2 * p + 1);
+    const u32 *e0 = gtable + (((size_t)(2 * p) << GTABLE_WINDOW_BITS) + d0) * GT_ENTRY_WORDS;
+    const u32 *e1 = gtable + (((size_t)(2 * p + 1) << GTABLE_WINDOW_BITS) + d1) * GT_ENTRY_WORDS;
+    if (d0 != 0 && d1 != 0) {
+      const fe pprev = pairs_ws_load(ws + ((ptrdiff_t)p - 1) * (ptrdiff_t)ws_stride);
+      const ge s = pair_add_affine(slot_load_fe(e0), slot_load_fe(e0 + TW), slot_load_fe(e1), slot_load_fe(e1 + TW), pprev, inv);
+      acc = gej_add_ge_fast(acc, s);
+    } else {  // a window without an entry: no pair was formed in pass 1
+      if (d0 != 0) { ge pt; pt.x = slot_load_fe(e0); pt.y = slot_load_fe(e0 + TW); acc = gej_add_ge_fast(acc, pt); }
+      if (d1 != 0) { ge pt; pt.x = slot_load_fe(e1); pt.y = slot_load_fe(e1 + TW); acc = gej_add_ge_fast(acc, pt); }
+    }
+  }
+  if (GT_SINGLE) {
+    const u32 d = gtable_digit(rec.u1, GTABLE_WINDOWS - 1);
+    if (d != 0) {
+      const u32 *e = gtable + (((size_t)(GTABLE_WINDOWS - 1) << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
+      ge pt;
+      pt.x = slot_load_fe(e);
+      pt.y = slot_load_fe(e + TW);
+      acc = gej_add_ge_fast(acc, pt);
+    }
+  }
+  *suspect = fe_is_zero(acc.z);
+  return acc;
+}
+
+// One lane's batch of nb <= PAIRS_BMAX rows through the three stages.  row(b, first, &rec, &tab): the row's scalars and its key's
+// table, false when row b has no work (past the end of the list, scalars that failed the preparation); `first` tells the pass-1
+// call from the pass-2 call.  done(b, R, suspect): the row's result; suspect as ecmult_lane_keyed_fast (R is garbage then).
+// ws: the lane's PAIRS_SLOTS parking slots, ws_stride words apart.
+#if defined(LAMD_PAIRS_CLOCK) && defined(__HIPCC__)
+// experiment build: where a lane's time goes (pass 1 | inversion | pass 2), summed over all lanes in 100 MHz ticks (tools/pairs_clock_probe.py)
+__device__ unsigned long long g_pairs_clk[8];   // [0..2] phase sums | [3] max lane total | [4] min start | [5] max end | [6] max pass 1 | [7] max pass 2
+#endif
+#if defined(LAMD_PAIRS_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
+#define LAMD_PCLK(k) do { const unsigned long long now_ = wall_clock64(); atomicAdd(&g_pairs_clk[k], now_ - pclk_); if ((k) == 0) atomicMax(&g_pairs_clk[6], now_ - pclk_); \
+    if ((k) == 2) { atomicMax(&g_pairs_clk[7], now_ - pclk_); atomicMax(&g_pairs_clk[3], now_ - pclk0_); atomicMax(&g_pairs_clk[5], now_); } pclk_ = now_; } while (0)
+#define LAMD_PCLK_START unsigned long long pclk_ = wall_clock64(); const unsigned long long pclk0_ = pclk_; atomicMin(&g_pairs_clk[4], pclk_);
+#else
+#define LAMD_PCLK(k) ((void)0)
+#define LAMD_PCLK_START
+#endif
+template <int T, class RowF, class DoneF>
+LAMD_HD void pairs_batch(int nb, const u32 *gtable, u32 *ws, size_t ws_stride, RowF row, DoneF done) {
+  constexpr int NP = pairs_per_row(T);
+  LAMD_PCLK_START
+  fe P = fe_set_int(1);
+  pairs_ws_store(ws, P);
+  u32 good = 0;
+  int ng = 0;
+#pragma unroll 1
+  for (int b = 0; b < nb; b++) {
+    const prep_rec *rec;
+    const u32 *tab;
+    if (!row(b, true, &rec, &tab)) continue;
+    const fe before = P;
+    P = pairs_prefix_row<T>(*rec, tab, gtable, P, ws + (size_t)(1 + ng * NP) * ws_stride, ws_stride);
+    if (fe_is_zero(P)) {  // a pair of equal or opposite entries: this row is not for the bare formulas
+      P = before;
+      done(b, gej_infinity(), true);
+      continue;
+    }
+    good |= 1u << b;
+    ng++;
+  }
+  if (ng == 0) return;
+  LAMD_PCLK(0);
+  fe inv = fe_inv_var(P);
+  LAMD_PCLK(1);
+#pragma unroll 1
+  for (int b = nb - 1; b >= 0; b--) {
+    if (!((good >> b) & 1u)) continue;
+    ng--;
+    const prep_rec *rec;
+    const u32 *tab;
+    row(b, false, &rec, &tab);
+    bool suspect;
+    const gej R = pairs_sum_row<T>(*rec, tab, gtable, inv, ws + (size_t)(1 + ng * NP) * ws_stride, ws_stride, &suspect);
+    done(b, R, suspect);
+  }
+  LAMD_PCLK(2);
+}
+
+// ================================================================================================
 // Task split (latency path: k_small_verify, 64 rows per block).  One row per LANE and one TASK per WAVE: a lone signature on one
 // lane is a chain of ~10^5 dependent instructions, and a wave issues one instruction every ~4.3 cycles however few lanes are
 // live -- so the verification is cut into independent partial sums that different waves (different SIMDs) compute at the same

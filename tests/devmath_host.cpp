@@ -140,6 +140,42 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
   }
   if (mode == MODE_SCHNORR) schnorr_final_thread(0, 1, n, fin.data(), out, 32);
 }
+// the pairs-first form (verify_core.h "Pairs first"): rows in batches of `batch` <= PAIRS_BMAX per inversion, every row's key with a table of its own
+template <int T>
+static void verify_pairs_t(int mode, size_t n, int batch, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  dm_init();
+  std::vector<u32> tabs((size_t)PAIRS_BMAX * kc_stride(T)), scratch(kc_scratch_words(T)), fin(n * 32), ws((size_t)PAIRS_SLOTS * PAIRS_WS_WORDS);
+  std::vector<prep_rec> recs(n);
+  if (mode == MODE_ECDSA) ecdsa_prep_thread(0, 1, n, a32, sig64, recs.data());
+  else for (size_t i = 0; i < n; i++) schnorr_prep_one(a32 + 32 * i, key + (size_t)keylen * i, sig64 + 64 * i, &recs[i]);
+  if (batch < 1) batch = 1;
+  if (batch > PAIRS_BMAX) batch = PAIRS_BMAX;
+  for (size_t base = 0; base < n; base += batch) {
+    const int nb = (int)std::min<size_t>(batch, n - base);
+    bool have[PAIRS_BMAX];
+    for (int b = 0; b < nb; b++) {
+      const size_t i = base + b;
+      u32 qx[8], qy[8];
+      have[b] = parse_pubkey(key + (size_t)keylen * i, keylen, qx, qy) && (recs[i].flags & PREP_VALID) != 0;
+      out[i] = 0;
+      if (have[b]) keytable_build<T>(&tabs[(size_t)b * kc_stride(T)], scratch.data(), ge_from_words(qx, qy));
+    }
+    pairs_batch<T>(nb, g_table.data(), ws.data(), PAIRS_WS_WORDS,
+                   [&](int b, bool, const prep_rec **rec, const u32 **tab) {
+                     *rec = &recs[base + b];
+                     *tab = &tabs[(size_t)b * kc_stride(T)];
+                     return have[b];
+                   },
+                   [&](int b, gej R, bool suspect) {
+                     const size_t i = base + b;
+                     if (suspect) { g_suspects++; R = ecmult_lane_keyed<T>(recs[i], &tabs[(size_t)b * kc_stride(T)], g_table.data()); }
+                     u32 rw[8];
+                     be_to_words(rw, sig64 + 64 * i);
+                     out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
+                   });
+  }
+  if (mode == MODE_SCHNORR) schnorr_final_thread(0, 1, n, fin.data(), out, 32);
+}
 template <int T>
 static void keytable_entry_t(const u32 *qx, const u32 *qy, int idx, u8 *out96) {
   std::vector<u32> tab(kc_stride(T)), scratch(kc_scratch_words(T));
@@ -228,6 +264,11 @@ extern "C" int dm_txsig_hash(const u8 *pre, size_t len, int sighash_type, int ha
 }
 extern "C" {
 int dm_comb_spacing(int T) { return kc_spacing(T); }
+void dm_verify_pairs(int mode, int T, size_t n, int batch, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
+  if (T == 7) verify_pairs_t<7>(mode, n, batch, a32, sig64, key, keylen, out);
+  else if (T == 8) verify_pairs_t<8>(mode, n, batch, a32, sig64, key, keylen, out);
+  else verify_pairs_t<10>(mode, n, batch, a32, sig64, key, keylen, out);
+}
 void dm_verify_keyed(int mode, int T, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
   if (T == 7) verify_keyed_t<7>(mode, n, a32, sig64, key, keylen, out);
   else if (T == 8) verify_keyed_t<8>(mode, n, a32, sig64, key, keylen, out);

@@ -300,6 +300,33 @@ def test_keyed_path_tables_and_verdicts(dm, kat):
         assert not bad, (T, bad[:10])
 
 
+def test_pairs_first_ecmult_gives_the_golden_verdicts(dm, kat):
+    """verify_core.h "Pairs first": half of a verification's mixed additions replaced by affine + affine additions whose inverses
+    come from ONE inversion per batch of rows (Montgomery's trick; the inversion by division steps).  Every ECDSA golden (reference
+    KATs, all edge classes, special keys) and every BIP-340 golden, comb shapes 7 / 10, batches of 1 .. PAIRS_BMAX rows -- the rows
+    with degenerate sums (R = infinity, u1*G = +-u2*Q) must come back as suspects and be decided by the complete formulas."""
+    dm.dm_verify_pairs.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p]
+    dm.dm_suspects(1)
+    for T in (7, 10):
+        for batch in (1, 2, 5, 6):
+            for publen in (33, 65):
+                rows = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
+                if batch not in (1, 6):
+                    rows = rows[:40] + rows[-40:]
+                out = ctypes.create_string_buffer(len(rows))
+                dm.dm_verify_pairs(0, T, len(rows), batch, b"".join(H(v["hash"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+                                   b"".join(H(v["pub"]) for v in rows), publen, out)
+                bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
+                assert not bad, (T, batch, bad[:10])
+            rows = kat["schnorr"][:60]
+            out = ctypes.create_string_buffer(len(rows))
+            dm.dm_verify_pairs(1, T, len(rows), batch, b"".join(H(v["msg"]) for v in rows), b"".join(H(v["sig"]) for v in rows),
+                               b"".join(H(v["pk"]) for v in rows), 32, out)
+            bad = [v["name"] for v, g in zip(rows, out.raw) if bool(g) != v["expect"]]
+            assert not bad, (T, batch, bad[:10])
+    assert dm.dm_suspects(0) > 0   # the edge classes reached the complete formulas
+
+
 def test_task_split_of_the_latency_path_gives_the_golden_verdicts(dm, kat):
     """k_small_verify's arithmetic on the host: one verification cut into five independent partial sums (u1*G; the comb's two
     GLV halves, each split at a column -- or the two ladder halves for a key without a table) merged with complete Jacobian

@@ -5,24 +5,26 @@ statement is that hipcc's hazard recogniser, which assumes a dst-forwarding haza
 cannot put s_nop between the dependent v_mad_u64_u32, and that the instruction order is ours.
 
 Schedule (round 4; fe.h explains the arithmetic):
-  high chain   columns 8..16 in the HI accumulator -> h[0..8] (29 bits each), HI = H17
-  fold         h[1] += H17 << 8;  P8 = R0*H17 + 256*h[8] + h[0] (in HI);  h[1] += P8.hi << 3
-  low chain    columns 0..7 in the LO accumulator with R0*h[k+1] and 256*h[k] -> r[0..7], LO = carry of column 7
+  column 8     in the LO accumulator; HI = LO >> 29 carries on, LO = [h8 : 0] is kept as a 64-bit addend
+  high chain   columns 9..15 in HI -> h[1..7] (29 bits each); column 16 stays whole in HI: V = [Vlo : Vhi]
+  fold         h[1] += Vhi << 11;  P8 = 8*R0*Vhi + h8 + 256*Vlo (in LO);  h[1] += P8.hi << 3;  P8.lo moves to a temporary
+  low chain    columns 0..7 in LO with R0*h[k+1] (column 7: R0*Vlo) and 256*h[k] -> r[0..7], LO = carry of column 7
   end          LO += P8.lo;  r8 = LO & (2^24-1);  e2 = LO >> 24;  r0 += 977*e2;  r1 += 8*e2
 The two 64-bit accumulators are pinned to fixed VGPR pairs because an inline-asm operand cannot name the halves of a 64-bit
-register operand (the low halves feed v_and_b32 / v_alignbit_b32 / a multiply-add).  r[k] (k >= 1) is written into the
-register that held h[k], dead by then; e2 into h[0]'s.
-Operands: %0 r[0] | %1..%9 h[0..8] = (e2, r[1..8]) | %10 HI (pinned) | %11 LO (pinned) | %12..%20 a[0..8] |
-%21..%29 b[0..8] (fe_sqr: the doubled limbs d[0..8]) | %30 R0 | %31 256 | %32 977 | %33.. second product / addend limbs.
+register operand (the halves feed v_and_b32 / v_alignbit_b32 / a multiply-add).  r[k] (1 <= k <= 7) is written into the
+register that held h[k], dead by then.
+Operands: %0 r[0] | %1 temporary (P8.lo, then e2) | %2..%8 h[1..7] = r[1..7] | %9 r[8] | %10 HI (pinned) | %11 LO (pinned) |
+%12..%20 a[0..8] | %21..%29 b[0..8] (fe_sqr: the doubled limbs d[0..8]) | %30 R0 | %31 256 | %32 977 | %33 8*R0 |
+%34.. second product / addend limbs.
 usage: tools/gen_fe_asm.py > lightning_amd/csrc/fe_asm.inc"""
 HI, LO = 20, 22                      # v[20:21], v[22:23]
 R0r = "%0"
 H = lambda j: "%%%d" % (1 + j)       # h[j], j = 0..8; r[k] = H(k) for k >= 1
 A = lambda i: "%%%d" % (12 + i)
 B = lambda i: "%%%d" % (21 + i)
-SR0, S256, S977 = "%30", "%31", "%32"
-C2 = lambda i: "%%%d" % (33 + i)     # second product's left operand (LAMD_FE_MUL2_ASM) / the addend limbs (..._ADD_ASM)
-D2 = lambda i: "%%%d" % (42 + i)     # second product's right operand
+SR0, S256, S977, S8R0 = "%30", "%31", "%32", "%33"
+C2 = lambda i: "%%%d" % (34 + i)     # second product's left operand (LAMD_FE_MUL2_ASM) / the addend limbs (..._ADD_ASM)
+D2 = lambda i: "%%%d" % (43 + i)     # second product's right operand
 M29, M24 = "0x1fffffff", "0xffffff"
 hi, lo = "v[%d:%d]" % (HI, HI + 1), "v[%d:%d]" % (LO, LO + 1)
 hil, hih, lol, loh = "v%d" % HI, "v%d" % (HI + 1), "v%d" % LO, "v%d" % (LO + 1)
@@ -56,24 +58,28 @@ def column(acc, k, square, first):
 
 
 def body(square):
-    ins = []
-    for j in range(9):                               # high chain: columns 8..16
-        ins += column(hi, 8 + j, square, j == 0)
+    T0, R8 = H(0), H(8)
+    ins = column(lo, 8, square, True)                # column 8; its carry heads the high chain, its low 29 bits wait in LO
+    ins += ["v_lshrrev_b64 %s, 29, %s" % (hi, lo), "v_and_b32 %s, %s, %s" % (lol, M29, lol), "v_mov_b32 %s, 0" % loh]
+    for j in range(1, 8):                            # high chain: columns 9..15
+        ins += column(hi, 8 + j, square, False)
         ins += ["v_and_b32 %s, %s, %s" % (H(j), M29, hil), "v_lshrrev_b64 %s, 29, %s" % (hi, hi)]
-    ins.append("v_lshl_add_u32 %s, %s, 8, %s" % (H(1), hil, H(1)))          # 256*H17*2^(29*9) joins h9
-    ins += [mad(hi, hil, SR0, "0"), mad(hi, H(8), S256), mad(hi, H(0), "1")]  # P8
-    ins.append("v_lshl_add_u32 %s, %s, 3, %s" % (H(1), hih, H(1)))          # P8.hi * 2^32 * 2^232 = 8 * P8.hi * 2^261
+    ins += column(hi, 16, square, False)             # column 16 stays whole: V = Vlo + 2^32 * Vhi
+    ins.append("v_lshl_add_u32 %s, %s, 11, %s" % (H(1), hih, H(1)))         # 2^8 * (8 * Vhi) * 2^(29*9) joins h9
+    ins += [mad(lo, hih, S8R0), mad(lo, hil, S256)]                         # P8 = R0 * 8 * Vhi + 2^8 * Vlo + h8
+    ins.append("v_lshl_add_u32 %s, %s, 3, %s" % (H(1), loh, H(1)))          # P8.hi * 2^32 * 2^232 = 8 * P8.hi * 2^261
+    ins.append("v_mov_b32 %s, %s" % (T0, lol))
     for k in range(8):                               # low chain: columns 0..7
         ins += column(lo, k, square, k == 0)
-        ins.append(mad(lo, H(k + 1), SR0))
+        ins.append(mad(lo, H(k + 1) if k < 7 else hil, SR0))
         if k > 0:
             ins.append(mad(lo, H(k), S256))
         ins += ["v_and_b32 %s, %s, %s" % (R0r if k == 0 else H(k), M29, lol), "v_lshrrev_b64 %s, 29, %s" % (lo, lo)]
-    ins.append(mad(lo, hil, "1"))                    # column 8 = carry of column 7 + P8.lo
-    ins.append("v_and_b32 %s, %s, %s" % (H(8), M24, lol))
-    ins.append("v_alignbit_b32 %s, %s, %s, 24" % (H(0), loh, lol))          # e2 < 2^12
-    ins.append("v_mad_u32_u24 %s, %s, %s, %s" % (R0r, H(0), S977, R0r))
-    ins.append("v_lshl_add_u32 %s, %s, 3, %s" % (H(1), H(0), H(1)))
+    ins.append(mad(lo, T0, "1"))                     # column 8 = carry of column 7 + P8.lo
+    ins.append("v_and_b32 %s, %s, %s" % (R8, M24, lol))
+    ins.append("v_alignbit_b32 %s, %s, %s, 24" % (T0, loh, lol))            # e2 < 2^12
+    ins.append("v_mad_u32_u24 %s, %s, %s, %s" % (R0r, T0, S977, R0r))
+    ins.append("v_lshl_add_u32 %s, %s, 3, %s" % (H(1), T0, H(1)))
     return ins
 
 
@@ -94,6 +100,6 @@ print("#define LAMD_FE_ASM_HI \"{v[%d:%d]}\"" % (HI, HI + 1))
 print("#define LAMD_FE_ASM_LO \"{v[%d:%d]}\"" % (LO, LO + 1))
 emit("LAMD_FE_MUL_ASM", False)
 emit("LAMD_FE_SQR_ASM", True)
-emit("LAMD_FE_MULADD_ASM", False, addend=True)   # a*b + e      (%33.. = e[0..8])
+emit("LAMD_FE_MULADD_ASM", False, addend=True)   # a*b + e      (%34.. = e[0..8])
 emit("LAMD_FE_SQRADD_ASM", True, addend=True)    # a^2 + e
-emit("LAMD_FE_MUL2_ASM", False, prod2=True)      # a*b + c*d    (%33.. = c[0..8], %42.. = d[0..8])
+emit("LAMD_FE_MUL2_ASM", False, prod2=True)      # a*b + c*d    (%34.. = c[0..8], %43.. = d[0..8])
