@@ -593,10 +593,12 @@ def test_single_lane_mode_matches(orc):
 
 
 @pytest.mark.parametrize("env", [{"LAMD_FUSED_FRONT": "0"}, {"LAMD_MERGE_SIDE": "0"}, {"LAMD_ECMULT_CHAIN": "1"}, {"LAMD_ECMULT_CHAIN": "2", "LAMD_ECMULT_TAIL": "50000"}, {"LAMD_COPY_STREAM": "0"},
-                                 {"LAMD_FUSED_FRONT": "0", "LAMD_CACHE": "0"}, {"LAMD_CACHE": "0"}])
+                                 {"LAMD_FUSED_FRONT": "0", "LAMD_CACHE": "0"}, {"LAMD_CACHE": "0"}, {"LAMD_GROUP": "0"}, {"LAMD_PAIRS": "1"},
+                                 {"LAMD_PAIRS": "1", "LAMD_GROUP": "0", "LAMD_CACHE": "0"}])
 def test_scheduling_variants_give_the_same_verdicts(orc, env):
     """the round-2 front end (19 launches), the ladder on a stream of its own, chained ecmult launches, flush copies on the lane's prep
-    stream: every scheduling variant the engine still carries must produce the verdicts of the default one -- against the C oracle on a
+    stream, row lists in arrival order instead of grouped by key, the pairs-first ecmult kernel (k_ecmult_keyed_pairs: both comb shapes
+    occur below): every scheduling variant the engine still carries must produce the verdicts of the default one -- against the C oracle on a
     sample and by construction on every row; calls back to back over all lanes, the streaming queue with more flushes in flight than lanes"""
     import os
     from lightning_amd import Engine, workload
@@ -980,6 +982,46 @@ def test_keyed_fast_path_degenerate_rows_take_the_complete_formulas(eng_keyed, k
             # u1*G + u2*Q = infinity, or the last addition is a doubling: Z = 0 in the bare formulas
             inf = e.info()
             assert inf["last_hot_rows"] > 0 and inf["last_suspect_rows"] >= 4 * reps, inf
+
+
+@pytest.mark.parametrize("teeth", [7, 10])
+def test_pairs_first_kernel_goldens_and_degenerate_rows(kat, teeth):
+    """k_ecmult_keyed_pairs (LAMD_PAIRS=1: affine pair sums sharing one inversion per lane and batch of rows -- an experiment knob, kept
+    parity-green): every ECDSA golden (reference KATs, every edge class, special keys) and every BIP-340 golden, each row repeated so
+    that its key gets a comb table of the forced shape and a lane's batch holds several rows; the rows whose sums degenerate
+    (u1*G = +-u2*Q, R = infinity, Q = G, Q = lambda*G) must come back from the complete formulas"""
+    import os
+    from lightning_amd import Engine
+    env = {"LAMD_PAIRS": "1", "LAMD_KEYED": "1", "LAMD_KEYED_TEETH": str(teeth), "LAMD_CACHE": "0"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        e = Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    try:
+        suspects = 0
+        for publen in (33, 65):
+            vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 2 * publen]
+            reps = (40000 + len(vs) - 1) // len(vs)
+            got = e.verify_ecdsa(_rows([H(v["hash"]) for v in vs] * reps, 32), _rows([H(v["sig"]) for v in vs] * reps, 64), _rows([H(v["pub"]) for v in vs] * reps, publen))
+            bad = sorted({v["name"] for v, g in zip(vs * reps, got) if bool(g) != v["expect"]})
+            assert not bad, (publen, bad[:10])
+            inf = e.info()
+            assert inf["last_keyed"] == teeth and inf["last_hot_rows"] > 0.8 * len(got), inf
+            suspects += inf["last_suspect_rows"]
+        assert suspects > 0
+        vs = kat["schnorr"]
+        reps = (40000 + len(vs) - 1) // len(vs)
+        got = e.verify_schnorr(_rows([H(v["msg"]) for v in vs] * reps, 32), _rows([H(v["pk"]) for v in vs] * reps, 32), _rows([H(v["sig"]) for v in vs] * reps, 64))
+        bad = sorted({v["name"] for v, g in zip(vs * reps, got) if bool(g) != v["expect"]})
+        assert not bad, bad[:10]
+    finally:
+        e.close()
 
 
 def test_check_tx_sig_from_transaction_templates_vs_spec_model(eng, orc):

@@ -59,3 +59,4 @@ def test_million_edge_class_rows_gpu_equals_oracle_equals_construction(orc):
         assert bad.size == 0, ("BIP-340: %d rows differ; first %d class %d gpu %d oracle %d expected %d" % (bad.size, bad[0], c[bad[0]], got[bad[0]], cpu[bad[0]], e[bad[0]]))
         small = eng.verify_schnorr(np.ascontiguousarray(m[:3000]), np.ascontiguousarray(x[:3000]), np.ascontiguousarray(sg[:3000])).astype(np.uint8)
         assert np.array_equal(small, e[:3000])
+
