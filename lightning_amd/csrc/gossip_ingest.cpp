@@ -51,6 +51,34 @@ struct noinit_alloc : std::allocator<T> {
   template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
 };
 typedef std::vector<u8, noinit_alloc<u8>> bytes;
+// the gossip_store image: a byte buffer that grows by realloc() -- for a block of this size glibc moves the PAGES (mremap), where a std::vector
+// allocates anew, copies every byte and takes the page faults of the copy again (47 MB copied to make room for a batch of updates: 20 ms)
+struct image_buf {
+  typedef u8 value_type;
+  u8 *p = nullptr;
+  size_t n = 0, cap = 0;
+  image_buf() = default;
+  image_buf(const image_buf &) = delete;
+  image_buf &operator=(const image_buf &) = delete;
+  ~image_buf() { free(p); }
+  u8 *data() { return p; }
+  const u8 *data() const { return p; }
+  const u8 *begin() const { return p; }
+  size_t size() const { return n; }
+  size_t capacity() const { return cap; }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    u8 *q = (u8 *)realloc(p, want);
+    if (!q) throw std::bad_alloc();
+    p = q;
+    cap = want;
+  }
+  void resize(size_t want) {  // (new bytes uninitialised: every caller fills what it grows)
+    if (want > cap) reserve(want + (want >> 2) + 4096);
+    n = want;
+  }
+  void assign(size_t count, u8 v) { resize(count); memset(p, v, count); }
+};
 // a message by reference: bytes of the batch arena (alive until the batch has been applied) or of a waiting list's own copy
 struct mview {
   const u8 *p;
@@ -100,6 +128,199 @@ struct nodeid_hash {
   u64 seed;
   size_t operator()(const nodeid &n) const { return (size_t)content_hash(seed, n.k, 33); }
 };
+// K -> V for the maps every gossip message consults (channels, announcements waiting for their txout, failed txouts by short_channel_id;
+// nodes by node id): an open-addressing index (linear probing, 12 bytes per slot, load <= 1/2) over entries that live in fixed blocks -- an
+// entry never moves (the plan keeps chan pointers across the apply pass), an insertion allocates nothing, and the slot a key WILL probe is
+// known from its hash alone, so the replay can prefetch it for the messages ahead (prefetch()).  The interface is the part of
+// std::unordered_map this file uses; concurrent readers are fine, writers are not.  Traits: tag(key, seed) = the 64-bit word the index stores
+// (the key itself for a short_channel_id, a seeded hash for a node id), home(tag, seed) = where probing starts, exact = "equal tags mean equal keys".
+struct scid_key_traits {
+  static constexpr bool exact = true;
+  static u64 tag(u64 k, u64) { return k; }
+  static size_t home(u64 tag, u64 seed) { return (size_t)mix64(tag ^ seed); }
+};
+struct nodeid_key_traits {
+  static constexpr bool exact = false;
+  static u64 tag(const nodeid &k, u64 seed) { return content_hash(seed, k.k, 33); }
+  static size_t home(u64 tag, u64) { return (size_t)tag; }
+};
+template <class K, class V, class TR>
+struct stable_map {
+  struct entry { K first; V second; };
+  static constexpr u32 BLOCK = 4096, EMPTY = 0, TOMB = 0xFFFFFFFFu;
+  u64 seed;
+  std::vector<u64> ikey;
+  std::vector<u32> islot;          // 0 = never used, TOMB = erased, else entry index + 1
+  size_t mask = 0, live = 0, filled = 0;
+  std::vector<entry *> blocks;
+  std::vector<u8> alive;           // per entry index
+  std::vector<u32> free_list;
+  u32 top = 0;                     // entry indices handed out so far
+
+  explicit stable_map(u64 seed_) : seed(seed_) { rehash(64); }
+  stable_map(const stable_map &) = delete;
+  stable_map &operator=(const stable_map &) = delete;
+  ~stable_map() {
+    for (u32 i = 0; i < top; i++)
+      if (alive[i]) at(i)->~entry();
+    for (entry *b : blocks) ::operator delete((void *)b);
+  }
+  entry *at(u32 i) const { return blocks[i / BLOCK] + (i % BLOCK); }
+  void prefetch_t(u64 tag) const { const size_t h = TR::home(tag, seed) & mask; __builtin_prefetch(&ikey[h]); __builtin_prefetch(&islot[h]); }
+  void prefetch(const K &k) const { prefetch_t(TR::tag(k, seed)); }
+  struct iterator {
+    const stable_map *m;
+    u32 i;  // entry index; m->top = end
+    entry *operator->() const { return m->at(i); }
+    entry &operator*() const { return *m->at(i); }
+    bool operator==(const iterator &o) const { return i == o.i; }
+    bool operator!=(const iterator &o) const { return i != o.i; }
+    iterator &operator++() { do { i++; } while (i < m->top && !m->alive[i]); return *this; }
+  };
+  iterator end() const { return iterator{this, top}; }
+  iterator begin() const { iterator it{this, 0}; if (top && !alive[0]) ++it; return it; }
+  // index slot of k, or of the place it would be inserted at (first tombstone on the way, else the empty slot that ended the probe)
+  bool locate(const K &k, u64 tag, size_t *slot) const {
+    size_t tomb = (size_t)-1;
+    for (size_t h = TR::home(tag, seed) & mask;; h = (h + 1) & mask) {
+      const u32 s = islot[h];
+      if (s == EMPTY) { *slot = tomb != (size_t)-1 ? tomb : h; return false; }
+      if (s == TOMB) { if (tomb == (size_t)-1) tomb = h; continue; }
+      if (ikey[h] == tag && (TR::exact || at(s - 1)->first == k)) { *slot = h; return true; }
+    }
+  }
+  iterator find_t(const K &k, u64 tag) const {
+    size_t h;
+    return locate(k, tag, &h) ? iterator{this, islot[h] - 1} : end();
+  }
+  iterator find(const K &k) const { return find_t(k, TR::tag(k, seed)); }
+  // second stage of a look-ahead: the index slot is (by now) in cache, fetch the entry it names
+  void prefetch_entry_t(const K &k, u64 tag) const {
+    size_t h;
+    if (locate(k, tag, &h)) __builtin_prefetch(at(islot[h] - 1));
+  }
+  void prefetch_entry(const K &k) const { prefetch_entry_t(k, TR::tag(k, seed)); }
+  size_t count(const K &k) const { return find(k).i != top; }
+  size_t size() const { return live; }
+  bool empty() const { return live == 0; }
+  void rehash(size_t slots) {
+    size_t m = 64;
+    while (m < slots) m <<= 1;
+    std::vector<u64> k2(m, 0);
+    std::vector<u32> s2(m, EMPTY);
+    const size_t mk = m - 1;
+    for (size_t h = 0; h < islot.size(); h++) {
+      const u32 s = islot[h];
+      if (s == EMPTY || s == TOMB) continue;
+      size_t g = TR::home(ikey[h], seed) & mk;
+      while (s2[g] != EMPTY) g = (g + 1) & mk;
+      k2[g] = ikey[h];
+      s2[g] = s;
+    }
+    ikey.swap(k2);
+    islot.swap(s2);
+    mask = mk;
+    filled = live;
+  }
+  void reserve(size_t n) { if (2 * (n + 1) > mask + 1) rehash(2 * (n + 1)); }
+  template <class... A>
+  std::pair<iterator, bool> emplace(const K &k, A &&...a) { return emplace_t(k, TR::tag(k, seed), std::forward<A>(a)...); }
+  template <class... A>
+  std::pair<iterator, bool> emplace_t(const K &k, u64 tag, A &&...a) {
+    if (2 * (filled + 1) > mask + 1) rehash(live * 4 + 64);   // load <= 1/2 counting tombstones
+    size_t h;
+    if (locate(k, tag, &h)) return {iterator{this, islot[h] - 1}, false};
+    u32 i;
+    if (!free_list.empty()) { i = free_list.back(); free_list.pop_back(); }
+    else {
+      i = top++;
+      if (i / BLOCK >= blocks.size()) blocks.push_back((entry *)::operator new(sizeof(entry) * BLOCK));
+      alive.push_back(0);
+    }
+    ::new ((void *)at(i)) entry{k, V(std::forward<A>(a)...)};
+    alive[i] = 1;
+    if (islot[h] == EMPTY) filled++;
+    ikey[h] = tag;
+    islot[h] = i + 1;
+    live++;
+    return {iterator{this, i}, true};
+  }
+  V &operator[](const K &k) { return emplace(k).first->second; }
+  size_t erase(const K &k) { return erase_t(k, TR::tag(k, seed)); }
+  size_t erase_t(const K &k, u64 tag) {
+    size_t h;
+    if (!locate(k, tag, &h)) return 0;
+    const u32 i = islot[h] - 1;
+    islot[h] = TOMB;
+    at(i)->~entry();
+    alive[i] = 0;
+    free_list.push_back(i);
+    live--;
+    return 1;
+  }
+  void erase(const iterator &it) { const K k = it->first; erase(k); }
+};
+// NS independent stable_maps behind the same interface, a key's shard taken from the top bits of its probe start: single-threaded code does not
+// notice; a parallel pass gives every worker the keys of its own shards (worker w owns shard s when s % workers == w), so workers never write
+// the same map -- and since a shard sees its keys in arrival order, the maps end up exactly as the one-by-one replay leaves them.
+template <class K, class V, class TR, unsigned NS = 16>
+struct sharded_map {
+  typedef stable_map<K, V, TR> shard_t;
+  typedef typename shard_t::entry entry;
+  u64 seed;
+  std::vector<std::unique_ptr<shard_t>> s;
+  explicit sharded_map(u64 seed_) : seed(seed_) { for (unsigned i = 0; i < NS; i++) s.emplace_back(new shard_t(seed_)); }
+  static constexpr unsigned shards() { return NS; }
+  unsigned shard_t_of(u64 tag) const { return (unsigned)((u64)TR::home(tag, seed) >> 58) % NS; }
+  unsigned shard_of(const K &k) const { return shard_t_of(TR::tag(k, seed)); }
+  shard_t &shard(unsigned i) { return *s[i]; }
+  const shard_t &shard(unsigned i) const { return *s[i]; }
+  struct iterator {
+    const sharded_map *m;
+    u32 sh, i;  // sh == NS: end
+    entry *operator->() const { return m->s[sh]->at(i); }
+    entry &operator*() const { return *m->s[sh]->at(i); }
+    bool operator==(const iterator &o) const { return sh == o.sh && i == o.i; }
+    bool operator!=(const iterator &o) const { return !(*this == o); }
+    void settle() {  // onto the next live entry at or after (sh, i)
+      while (sh < NS) {
+        const shard_t &t = *m->s[sh];
+        while (i < t.top && !t.alive[i]) i++;
+        if (i < t.top) return;
+        sh++;
+        i = 0;
+      }
+      i = 0;
+    }
+    iterator &operator++() { i++; settle(); return *this; }
+  };
+  iterator end() const { return iterator{this, NS, 0}; }
+  iterator begin() const { iterator it{this, 0, 0}; it.settle(); return it; }
+  iterator find(const K &k) const {
+    const u64 tag = TR::tag(k, seed);
+    const unsigned sh = shard_t_of(tag);
+    const auto it = s[sh]->find_t(k, tag);
+    return it == s[sh]->end() ? end() : iterator{this, sh, it.i};
+  }
+  size_t count(const K &k) const { return find(k).sh != NS; }
+  size_t size() const { size_t n = 0; for (const auto &t : s) n += t->size(); return n; }
+  bool empty() const { for (const auto &t : s) if (!t->empty()) return false; return true; }
+  void reserve(size_t n) { for (auto &t : s) t->reserve(n / NS + n / (4 * NS) + 16); }
+  void prefetch(const K &k) const { const u64 tag = TR::tag(k, seed); s[shard_t_of(tag)]->prefetch_t(tag); }
+  void prefetch_entry(const K &k) const { const u64 tag = TR::tag(k, seed); s[shard_t_of(tag)]->prefetch_entry_t(k, tag); }
+  template <class... A>
+  std::pair<iterator, bool> emplace(const K &k, A &&...a) {
+    const u64 tag = TR::tag(k, seed);
+    const unsigned sh = shard_t_of(tag);
+    const auto r = s[sh]->emplace_t(k, tag, std::forward<A>(a)...);
+    return {iterator{this, sh, r.first.i}, r.second};
+  }
+  V &operator[](const K &k) { return emplace(k).first->second; }
+  size_t erase(const K &k) { const u64 tag = TR::tag(k, seed); return s[shard_t_of(tag)]->erase_t(k, tag); }
+  void erase(const iterator &it) { const K k = it->first; erase(k); }
+};
+template <class V> using scid_map = sharded_map<u64, V, scid_key_traits>;
+
 // a (message, signer) pair by reference: the bytes live in the batch / the waiting lists for as long as a map holds the key
 struct msgkey {
   const u8 *m;
@@ -289,12 +510,38 @@ static void parallel_for(thread_pool *pool, size_t n, size_t min_per_thread, F f
   pool->run(t, [&](unsigned k) { f(std::min(n, k * step), std::min(n, (k + 1) * step)); });
 }
 
+// first touch of fresh memory by ALL cores: a page fault costs 0.5-2 us (more under a hypervisor) and a flood grows the store image, the work
+// buffers and the record list by hundreds of megabytes -- taken one after the other by the thread that happens to write first, the faults
+// of a 2 M-message batch are several tenths of a second; page faults on different pages proceed in parallel.  The bytes are not yet part of
+// any object (the caller constructs over them afterwards).
+static void prefault(thread_pool *pool, void *p, size_t nbytes) {
+  if (nbytes < ((size_t)4 << 20)) return;
+  u8 *b = (u8 *)p;
+  parallel_for(pool, nbytes >> 12, 512, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) ((volatile u8 *)b)[i << 12] = 0;
+  });
+}
+// grow a vector's capacity to at least `want` elements, the new storage touched by all cores
+template <class VEC>
+static void reserve_prefaulted(thread_pool *pool, VEC &v, size_t want) {
+  if (v.capacity() >= want) return;
+  v.reserve(want + (want >> 3));
+  prefault(pool, (void *)(v.data() + v.size()), (v.capacity() - v.size()) * sizeof(typename VEC::value_type));
+}
+// the expected scriptpubkey of a channel_announcement's funding output: always OP_0 <32 bytes> -- inline, no heap block to miss on
+struct p2wsh_spk {
+  u8 b[34];
+  void resize(size_t) {}
+  size_t size() const { return 34; }
+  const u8 *data() const { return b; }
+  u8 &operator[](size_t i) { return b[i]; }
+};
 struct pending_cannounce {  // gossmap_manage.c:36-45
   bytes msg;
   bool has_src;
   nodeid src;
   nodeid node[2];
-  bytes spk;
+  p2wsh_spk spk;
 };
 struct pending_cupdate {  // :47-62
   u64 scid;
@@ -432,17 +679,17 @@ struct lamd_gossipd {
   // connectd's queue: the messages sit back to back in ONE arena (a push is an append, a batch push one memcpy)
   bytes qarena;
   std::vector<qent> queue;
-  std::unordered_map<u64, chan, scid_hash> chans{16, scid_hash{seed}};
-  std::unordered_map<nodeid, node, nodeid_hash> nodes{16, nodeid_hash{seed}};
-  std::unordered_map<u64, pending_cannounce, scid_hash> pending_ann{16, scid_hash{seed}};
+  scid_map<chan> chans{seed};
+  sharded_map<nodeid, node, nodeid_key_traits> nodes{seed};
+  scid_map<pending_cannounce> pending_ann{seed};
   std::map<u64, pending_cannounce> early_ann;  // ordered: new_block walks early_ann by ascending scid
   std::vector<pending_cupdate> pending_cupdates, early_cupdates;
   std::vector<pending_nannounce> pending_nannounces;
-  std::unordered_map<u64, bool, scid_hash> txout_failures{16, scid_hash{seed}};
+  scid_map<bool> txout_failures{seed};
   std::vector<record> store;
   // the gossip_store file as gossip_store.c would hold it: version byte, (v16: the uuid record), then gossip_hdr + message per
   // record -- flags / crc / timestamp rewritten in place by del / set_timestamp / set_flag exactly as the reference pwrite()s them
-  bytes image;
+  image_buf image;
   std::vector<chan_dying> dying_channels;
 
   // verdicts of the batch being applied: (message bytes, signer) -> verdict.  The keys refer to the bytes, they do not own them:
@@ -801,7 +1048,6 @@ struct lamd_gossipd {
       pending_cannounce pca;
       if (p.pre) {  // built by the parallel planning pass
         pca = std::move(*p.pre);
-        delete p.pre;
         p.pre = nullptr;
       } else {
         pca.msg.assign(m.begin(), m.end());
@@ -955,6 +1201,36 @@ struct lamd_gossipd {
   // the run, as every other kind of message does.)  One damaged message in a hundred would otherwise cut a flood into runs too short to take.
   bool run_side(const planned &p, const std::vector<int8_t> &v) const {
     return !on_event && p.type == GOSSIP_CUPD && (p.malformed || !p.pc) && !(p.slot >= 0 && v[p.slot] == -2);
+  }
+  // ---- a run of plain channel_announcements (a flood's first phase): well-formed, all four signatures good, node ids in order, this chain,
+  // deep enough, the waiting record already built by the planning pass.  What is left of apply_cann() for such a message is three map probes
+  // and one insertion into pending_ann -- by short_channel_id shard on all cores (a shard's announcements in arrival order: the first of two
+  // announcements of one channel wins, as in the replay), then one serial pass for the LAMD_GEV_GET_TXOUT events in arrival order.
+  bool cann_run_member(const planned &p, const std::vector<int8_t> &v) const {
+    return p.type == GOSSIP_CANN && !p.malformed && p.keyslot < 0 && p.slot >= 0 && v[p.slot] == 0 && p.pre != nullptr &&
+           scid_depth_announceable(p.scid, cfg.blockheight);
+  }
+  std::vector<u8> cann_took;
+  void apply_cann_run(std::vector<planned> &plan, size_t a, size_t b) {
+    cann_took.assign(b - a, 0);
+    const unsigned NSH = pending_ann.shards();
+    for (unsigned sh = 0; sh < NSH; sh++) pending_ann.shard(sh).reserve(pending_ann.shard(sh).size() + (b - a) / NSH + (b - a) / (4 * NSH) + 16);
+    const bool early_empty = early_ann.empty(), fail_empty = txout_failures.empty();
+    parallel_for(get_pool(), NSH, 1, [&](size_t lo, size_t hi) {
+      for (size_t i = a; i < b; i++) {
+        planned &p = plan[i];
+        const unsigned sh = pending_ann.shard_of(p.scid);
+        if (sh < lo || sh >= hi) continue;
+        const bool drop = (!fail_empty && txout_failures.shard(sh).count(p.scid)) ||                 // :679-681
+                          chans.shard(sh).count(p.scid) || (!early_empty && early_ann.count(p.scid));  // :684-687
+        if (!drop && pending_ann.shard(sh).emplace(p.scid, std::move(*p.pre)).second) cann_took[i - a] = 1;   // :744-750
+        p.pre = nullptr;
+      }
+    });
+    if (on_event)
+      for (size_t i = a; i < b; i++)
+        if (cann_took[i - a]) ev_scid(LAMD_GEV_GET_TXOUT, false, nullptr, plan[i].scid);
+    st.messages += b - a;
   }
   enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3, RO_SIDE = 4 };
   // (what pass A decides about one update.  One array PER SHARD, in the shard's arrival order: the thread that owns a channel writes only
@@ -1436,7 +1712,6 @@ extern "C" lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_conf
 static void free_stages(ingest_stage *s);
 extern "C" void lamd_gossipd_free(lamd_gossipd *g) {
   if (!g) return;
-  for (planned &p : g->w_plan) delete p.pre;
   delete g->pool;
   delete g->pool_bg;
   free_stages(g->w_stage);
@@ -1519,6 +1794,9 @@ struct ingest_stage {
   bool has_cann = false;
   int rc = LAMD_OK;
   double t_plan = 0, t_slots = 0, t_verify = 0;
+  // the waiting records the planning pass builds for its channel_announcements, one per message of the stage: planned::pre points in here (no
+  // allocation per record, nothing to free; the record's message bytes are the one heap block that travels on into pending_ann)
+  std::vector<pending_cannounce> pre_pool;
 };
 static void free_stages(ingest_stage *s) { delete[] s; }
 static double ingest_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -1534,6 +1812,7 @@ static void ingest_stage1(lamd_gossipd *g, const bytes &arena, const std::vector
   // Pass 1 (parallel over the messages; reads the maps, writes nothing shared): framing, r/s range, the filters that need no
   // curve arithmetic, the expected signer, the content hash that keys the verdict, the P2WSH program of an announcement.
   st.wb.pool = pool;
+  if (st.pre_pool.size() < n) st.pre_pool.resize(n);
   parallel_for(pool, n, 2048, [&](size_t l, size_t h) {
     for (size_t i = lo + l; i < lo + h; i++) {
       queued &q = batch[i];
@@ -1552,7 +1831,7 @@ static void ingest_stage1(lamd_gossipd *g, const bytes &arena, const std::vector
       p.signer = nullptr;
       p.pc = nullptr;
       p.h = 0;
-      if (p.pre) { delete p.pre; p.pre = nullptr; }   // (the plan vector is reused: an entry the replay never consumed)
+      p.pre = nullptr;
       if (f.type == GOSSIP_CANN) {
         if (!p.malformed)
           for (int s = 0; s < 4; s++) p.malformed |= !sig_in_range(&m[2 + 64 * s]);
@@ -1574,7 +1853,7 @@ static void ingest_stage1(lamd_gossipd *g, const bytes &arena, const std::vector
           script[69] = 0x52; script[70] = 0xae;
           lamd_gossipd::sha256_single(script, sizeof script, p.spk);
           p.spk_set = true;
-          pending_cannounce *pca = new pending_cannounce;
+          pending_cannounce *pca = &st.pre_pool[i - st.lo];
           pca->msg.assign(m.begin(), m.end());
           pca->has_src = q.has_src;
           pca->src = q.src;
@@ -1645,10 +1924,15 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   if (!n) return 0;
   // (work buffers live with the ingest and only grow: a drained queue of 400 k messages is ~100 MB of scratch, and first-touch page faults on
   // fresh memory cost more than the planning pass itself -- 2-20 us each under a hypervisor)
+  static const bool prof0 = getenv("LAMD_INGEST_PROFILE") != nullptr;
+  const double tp0 = prof0 ? ingest_now() : 0;
   std::vector<queued> &batch = g->w_batch;
   std::vector<planned> &plan = g->w_plan;
+  reserve_prefaulted(g->get_pool(), batch, n);
+  reserve_prefaulted(g->get_pool(), plan, n);
   if (batch.size() < n) batch.resize(n);
   if (plan.size() < n) plan.resize(n);
+  const double tp1 = prof0 ? ingest_now() : 0;
   static const bool prof = getenv("LAMD_INGEST_PROFILE") != nullptr;
   // The drained queue is ONE batch to the caller and a pipeline inside: sub-batches of `sub` messages, the planning stage (framing, filters,
   // slots, the device call) of sub-batch k+1 on a second thread UNDER the apply pass of sub-batch k.  The planning stage reads only what no
@@ -1674,11 +1958,13 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   setup(stage[0], 0);
   ingest_stage1(g, arena, ents, batch, plan, stage[0], g->get_pool());
   g->st.sub_batches++;
+  const double tp2 = prof0 ? ingest_now() : 0;
   // (every message of the batch may become a store record: grow the image and the record list once, not by doubling through the pass)
-  if (g->image.capacity() < g->image.size() + arena.size() + 12 * n) g->image.reserve(g->image.size() + arena.size() + 12 * n + (g->image.size() >> 2));
-  if (g->store.capacity() < g->store.size() + n) g->store.reserve(g->store.size() + n + (g->store.size() >> 2));
+  reserve_prefaulted(g->get_pool(), g->image, g->image.size() + arena.size() + 12 * n + (g->image.size() >> 2));
+  reserve_prefaulted(g->get_pool(), g->store, g->store.size() + n + (g->store.size() >> 2));
   g->in_process = true;
   long ret = (long)n;
+  if (prof0) fprintf(stderr, "[ingest] process n=%zu: work buffers %.1f ms, first planning stage %.1f ms, store / image growth %.1f ms\n", n, (tp1 - tp0) * 1e3, (tp2 - tp1) * 1e3, (ingest_now() - tp2) * 1e3);
   for (size_t k = 0; k < nsub; k++) {
     ingest_stage &cur = stage[k & 1], &nxt = stage[(k + 1) & 1];
     if (cur.rc != LAMD_OK) {  // the device call of this sub-batch failed: it and everything behind it go back to the queue, unapplied
@@ -1704,6 +1990,15 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     const bool runs = g->run_ok();
     size_t fault_at = SIZE_MAX;
     for (size_t i = cur.lo; i < cur.hi; i++) {
+      if (g->run_min != 0 && g->cann_run_member(plan[i], g->cur_v)) {  // a run of plain channel_announcements: all cores (apply_cann_run)
+        size_t j = i + 1;
+        while (j < cur.hi && g->cann_run_member(plan[j], g->cur_v)) j++;
+        if (j - i >= g->run_min) {
+          g->apply_cann_run(plan, i, j);
+          i = j - 1;
+          continue;
+        }
+      }
       if (runs && g->run_member(plan[i], batch[i], g->cur_v)) {  // a run of plain updates of known channels: all cores (apply_cupd_run)
         size_t j = i + 1, members = 1;
         for (; j < cur.hi; j++) {
@@ -1732,6 +2027,14 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
         if (c->set[dir]) __builtin_prefetch(g->image.data() + g->store[c->cupd_rec[dir]].off - 12);
         else if (!c->set[!dir]) { const u8 *h = g->image.data() + g->store[c->cann_rec].off - 12; __builtin_prefetch(h); __builtin_prefetch(h + 64); __builtin_prefetch(h + 448 - 64); }
       }
+      // a channel_announcement probes three maps by its short_channel_id (failed txouts, channels, waiting announcements): their index slots
+      // for the messages ahead
+      if (i + 12 < cur.hi && plan[i + 12].type == GOSSIP_CANN) {
+        const u64 sc = plan[i + 12].scid;
+        g->chans.prefetch(sc);
+        g->pending_ann.prefetch(sc);
+        if (!g->txout_failures.empty()) g->txout_failures.prefetch(sc);
+      }
       const queued &q = batch[i];
       planned &p = plan[i];
       if (p.type == GOSSIP_CANN) g->apply_cann(q, p, p.keyslot >= 0 ? (cur.keyok[2 * p.keyslot] && cur.keyok[2 * p.keyslot + 1]) : 1);
@@ -1757,6 +2060,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   }
   g->drop_verdicts();
   g->in_process = false;
+  if (prof0) fprintf(stderr, "[ingest] process n=%zu: %.1f ms in all\n", n, (ingest_now() - tp0) * 1e3);
   // the drained arena's memory serves the next queue (unless a callback or a requeue has already started one)
   if (g->queue.empty() && g->qarena.empty()) {
     arena.clear();
@@ -1778,7 +2082,7 @@ extern "C" int lamd_gossipd_txout_reply(lamd_gossipd *g, uint64_t scid, uint64_t
   if (script_len == 0) {
     bad = true;  // :789-809 (the rate-limited trace is not reproduced)
   } else if (script_len != pca.spk.size() || memcmp(script, pca.spk.data(), script_len) != 0) {
-    g->peer_warning(pca.has_src, &pca.src, "channel_announcement: txout " + fmt_scid(scid) + " expected " + hexs(pca.spk) + ", got " + hexs(script, script_len));  // :811-817
+    g->peer_warning(pca.has_src, &pca.src, "channel_announcement: txout " + fmt_scid(scid) + " expected " + hexs(pca.spk.data(), pca.spk.size()) + ", got " + hexs(script, script_len));  // :811-817
     bad = true;
   }
   if (bad) {
@@ -1813,51 +2117,89 @@ extern "C" int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const u
   if (!g || (n && (!scids || !sats || !scripts || !script_off))) return LAMD_ERR_ARG;
   if (g->in_process) return LAMD_ERR_STATE;
   g->chans.reserve(g->chans.size() + n);
-  g->store.reserve(g->store.size() + 2 * n);
-  // A batch of replies with no listener and nothing waiting in the queues (reprocess_queued_msgs() would return at once after every reply): the
-  // maps are updated one reply after the other, as ever; the two store records of every new channel -- channel_announcement + amount, 466 bytes
-  // of memcpy and crc32c per channel -- are written by all cores afterwards, at the offsets the serial pass assigned.
+  reserve_prefaulted(g->get_pool(), g->store, g->store.size() + 2 * n);
+  if (n >= 1024) reserve_prefaulted(g->get_pool(), g->image, g->image.size() + n * (size_t)(12 + 432 + 12 + 10));
+  // A batch of replies with no listener and nothing waiting in the queues (reprocess_queued_msgs() would return at once after every reply), by
+  // all cores in four passes that leave the maps, the record numbers and the store image exactly as reply-by-reply would:
+  //   1 per short_channel_id SHARD (a worker owns whole shards of pending_ann / chans / txout_failures and takes its replies in arrival order):
+  //     the waiting announcement leaves pending_ann, its script is compared, the channel enters chans;
+  //   2 serial, light: record numbers and store offsets of the new channels in arrival order;
+  //   3 per node-id SHARD: the two nodes of every new channel, in arrival order (a node's channel list comes out in the serial order);
+  //   4 the two store records of every new channel -- channel_announcement + amount, 466 bytes of memcpy and crc32c -- at their offsets.
   if (!g->on_event && n >= 1024 && g->pending_cupdates.empty() && g->early_cupdates.empty() && g->pending_nannounces.empty()) {
-    struct newchan { pending_cannounce pca; u64 sat, rec, off; };
-    std::vector<newchan> acc;
+    static const bool prof = getenv("LAMD_INGEST_PROFILE") != nullptr;
+    const double t0 = prof ? ingest_now() : 0;
+    struct newchan { pending_cannounce pca; chan *c; u64 scid, sat, rec, off; };
+    std::unique_ptr<newchan[]> slot(new newchan[n]);
+    std::vector<u8> took(n, 0);   // reply i created a channel (slot[i] is filled)
+    thread_pool *pool = g->get_pool();
+    const unsigned NSH = g->chans.shards();
+    for (unsigned sh = 0; sh < NSH; sh++) { g->pending_ann.shard(sh).reserve(g->pending_ann.shard(sh).size() + 16); }
+    parallel_for(pool, NSH, 1, [&](size_t lo, size_t hi) {
+      for (size_t i = 0; i < n; i++) {
+        const u64 scid = scids[i];
+        const unsigned sh = g->chans.shard_of(scid);   // the three maps share traits and seed: one shard number for all of them
+        if (sh < lo || sh >= hi) continue;
+        auto &pend = g->pending_ann.shard(sh);
+        auto it = pend.find(scid);
+        if (it == pend.end()) continue;  // :770-780
+        newchan &nc = slot[i];
+        nc.pca = std::move(it->second);
+        pend.erase(scid);
+        const u8 *script = scripts + script_off[i];
+        const size_t script_len = (size_t)(script_off[i + 1] - script_off[i]);
+        if (script_len == 0 || script_len != nc.pca.spk.size() || memcmp(script, nc.pca.spk.data(), script_len) != 0) {  // :789-817 (the warning is an event)
+          g->txout_failures.shard(sh)[scid] = true;  // :868-869
+          continue;
+        }
+        chan c;
+        c.node[0] = nc.pca.node[0];
+        c.node[1] = nc.pca.node[1];
+        c.set[0] = c.set[1] = false;
+        c.cupd_rec[0] = c.cupd_rec[1] = 0;
+        c.cann_rec = 0;
+        const auto r = g->chans.shard(sh).emplace(scid, c);
+        if (!r.second) continue;  // :825-846 "Redundant channel_announce"
+        nc.c = &r.first->second;
+        nc.scid = scid;
+        nc.sat = sats[i];
+        took[i] = 1;
+      }
+    });
+    const double t1 = prof ? ingest_now() : 0;
+    std::vector<u32> acc;
     acc.reserve(n);
     u64 nrec = g->store.size(), pos = g->image.size();
     for (size_t i = 0; i < n; i++) {
-      const u64 scid = scids[i];
-      const u8 *script = scripts + script_off[i];
-      const size_t script_len = (size_t)(script_off[i + 1] - script_off[i]);
-      auto it = g->pending_ann.find(scid);
-      if (it == g->pending_ann.end()) continue;  // :770-780
-      pending_cannounce pca = std::move(it->second);
-      g->pending_ann.erase(it);
-      if (script_len == 0 || script_len != pca.spk.size() || memcmp(script, pca.spk.data(), script_len) != 0) {  // :789-817 (the warning is an event)
-        g->txout_failures[scid] = true;  // :868-869
-        continue;
-      }
-      if (g->chans.count(scid)) continue;  // :825-846 "Redundant channel_announce"
-      chan c;
-      c.node[0] = pca.node[0];
-      c.node[1] = pca.node[1];
-      c.set[0] = c.set[1] = false;
-      c.cupd_rec[0] = c.cupd_rec[1] = 0;
-      c.cann_rec = nrec;
-      g->chans.emplace(scid, c);
-      for (int k = 0; k < 2; k++) {
-        if (k == 1 && pca.node[1] == pca.node[0]) continue;
-        node &nd = g->nodes[pca.node[k]];
-        nd.nchans++;
-        nd.scids.push_back(scid);
-      }
-      const size_t mlen = pca.msg.size();
-      acc.push_back(newchan{std::move(pca), sats[i], nrec, pos + 12});
+      if (!took[i]) continue;
+      newchan &nc = slot[i];
+      nc.rec = nrec;
+      nc.off = pos + 12;
+      nc.c->cann_rec = nrec;
       nrec += 2;
-      pos += 12 + mlen + 12 + 10;
+      pos += 12 + nc.pca.msg.size() + 12 + 10;
+      acc.push_back((u32)i);
     }
     g->store.resize(nrec);
     g->image.resize(pos);
-    parallel_for(g->get_pool(), acc.size(), 1024, [&](size_t lo, size_t hi) {
+    const double t2 = prof ? ingest_now() : 0;
+    parallel_for(pool, g->nodes.shards(), 1, [&](size_t lo, size_t hi) {
+      for (const u32 i : acc) {
+        const newchan &nc = slot[i];
+        for (int k = 0; k < 2; k++) {
+          if (k == 1 && nc.pca.node[1] == nc.pca.node[0]) continue;  // a channel with itself is one entry of that node's list
+          const unsigned sh = g->nodes.shard_of(nc.pca.node[k]);
+          if (sh < lo || sh >= hi) continue;
+          node &nd = g->nodes.shard(sh)[nc.pca.node[k]];  // value-initialised on first sight
+          nd.nchans++;
+          nd.scids.push_back(nc.scid);
+        }
+      }
+    });
+    const double t3 = prof ? ingest_now() : 0;
+    parallel_for(pool, acc.size(), 1024, [&](size_t lo, size_t hi) {
       for (size_t j = lo; j < hi; j++) {
-        const newchan &nc = acc[j];
+        const newchan &nc = slot[acc[j]];
         const size_t mlen = nc.pca.msg.size();
         u8 *h = g->image.data() + nc.off - 12;
         put_be16(h, GS_COMPLETED); put_be16(h + 2, (u32)mlen); put_be32(h + 4, crc32c(0, nc.pca.msg.data(), mlen)); put_be32(h + 8, 0);
@@ -1871,6 +2213,8 @@ extern "C" int lamd_gossipd_txout_reply_batch(lamd_gossipd *g, size_t n, const u
         g->store[nc.rec + 1] = record{4101, 0, false, nc.off + mlen + 12, 10};
       }
     });
+    if (prof) fprintf(stderr, "[ingest] txout replies n=%zu: maps by scid shard %.1f ms, numbering %.1f ms, nodes by shard %.1f ms, store records %.1f ms\n", n, (t1 - t0) * 1e3,
+                      (t2 - t1) * 1e3, (t3 - t2) * 1e3, (ingest_now() - t3) * 1e3);
     if (applied) *applied = n;
     return LAMD_OK;
   }

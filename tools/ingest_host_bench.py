@@ -96,8 +96,11 @@ for rep in range(5):
     ing.txout_reply_batch(scid, sats, spk_blob, spk_off)
     t3 = time.perf_counter()
     ing.push_batch(peer, cupd_blob, cupd_off)
+    t3b = time.perf_counter()
     ing.process()
     t4 = time.perf_counter()
+    if os.environ.get("LAMD_INGEST_PROFILE"):
+        print("[bench] updates: push_batch %.1f ms, process %.1f ms" % ((t3b - t3) * 1e3, (t4 - t3b) * 1e3), file=sys.stderr)
     st = ing.stats()
     ing.close()
     assert st["channels"] == n_cann and st["store_records"] == 2 * n_cann + n_cupd + 1 and st["verified_sigs"] == 4 * n_cann + n_cupd, st
