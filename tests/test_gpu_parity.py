@@ -1012,7 +1012,7 @@ def test_pairs_first_kernel_goldens_and_degenerate_rows(kat, teeth):
             bad = sorted({v["name"] for v, g in zip(vs * reps, got) if bool(g) != v["expect"]})
             assert not bad, (publen, bad[:10])
             inf = e.info()
-            assert inf["last_keyed"] == teeth and inf["last_hot_rows"] > 0.8 * len(got), inf
+            assert inf["last_keyed"] == teeth and inf["last_hot_rows"] > 0.3 * len(got), inf   # (many goldens are decided before the ecmult: bad scalars, keys that do not parse)
             suspects += inf["last_suspect_rows"]
         assert suspects > 0
         vs = kat["schnorr"]
