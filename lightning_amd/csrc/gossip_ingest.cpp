@@ -1210,8 +1210,14 @@ struct lamd_gossipd {
     return p.type == GOSSIP_CANN && !p.malformed && p.keyslot < 0 && p.slot >= 0 && v[p.slot] == 0 && p.pre != nullptr &&
            scid_depth_announceable(p.scid, cfg.blockheight);
   }
+  // (announcements whose replay cannot change anything a run reads or writes -- malformed, an unparsable bitcoin key, a bad signature: a warning
+  // to the peer and nothing else -- ride along: they are replayed in the serial pass, in arrival order among the run's events.  One damaged
+  // message in a hundred would otherwise cut a flood into runs too short to take.)
+  bool cann_run_side(const planned &p, const std::vector<int8_t> &v) const {
+    return p.type == GOSSIP_CANN && p.keyslot < 0 && (p.malformed || (p.slot >= 0 && (v[p.slot] == -1 || v[p.slot] > 0)));
+  }
   std::vector<u8> cann_took;
-  void apply_cann_run(std::vector<planned> &plan, size_t a, size_t b) {
+  void apply_cann_run(const std::vector<queued> &batch, std::vector<planned> &plan, size_t a, size_t b) {
     cann_took.assign(b - a, 0);
     const unsigned NSH = pending_ann.shards();
     for (unsigned sh = 0; sh < NSH; sh++) pending_ann.shard(sh).reserve(pending_ann.shard(sh).size() + (b - a) / NSH + (b - a) / (4 * NSH) + 16);
@@ -1219,6 +1225,7 @@ struct lamd_gossipd {
     parallel_for(get_pool(), NSH, 1, [&](size_t lo, size_t hi) {
       for (size_t i = a; i < b; i++) {
         planned &p = plan[i];
+        if (!cann_run_member(p, cur_v)) continue;  // rides along (cann_run_side): the serial pass replays it
         const unsigned sh = pending_ann.shard_of(p.scid);
         if (sh < lo || sh >= hi) continue;
         const bool drop = (!fail_empty && txout_failures.shard(sh).count(p.scid)) ||                 // :679-681
@@ -1227,9 +1234,10 @@ struct lamd_gossipd {
         p.pre = nullptr;
       }
     });
-    if (on_event)
-      for (size_t i = a; i < b; i++)
-        if (cann_took[i - a]) ev_scid(LAMD_GEV_GET_TXOUT, false, nullptr, plan[i].scid);
+    for (size_t i = a; i < b; i++) {
+      if (cann_took[i - a]) { st.run_announcements++; if (on_event) ev_scid(LAMD_GEV_GET_TXOUT, false, nullptr, plan[i].scid); }
+      else if (cann_run_side(plan[i], cur_v)) apply_cann(batch[i], plan[i], 1);
+    }
     st.messages += b - a;
   }
   enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3, RO_SIDE = 4 };
@@ -1991,10 +1999,14 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     size_t fault_at = SIZE_MAX;
     for (size_t i = cur.lo; i < cur.hi; i++) {
       if (g->run_min != 0 && g->cann_run_member(plan[i], g->cur_v)) {  // a run of plain channel_announcements: all cores (apply_cann_run)
-        size_t j = i + 1;
-        while (j < cur.hi && g->cann_run_member(plan[j], g->cur_v)) j++;
-        if (j - i >= g->run_min) {
-          g->apply_cann_run(plan, i, j);
+        size_t j = i + 1, members = 1;
+        for (; j < cur.hi; j++) {
+          if (g->cann_run_member(plan[j], g->cur_v)) members++;
+          else if (!g->cann_run_side(plan[j], g->cur_v)) break;
+        }
+        while (!g->cann_run_member(plan[j - 1], g->cur_v)) j--;   // a run ends with a member
+        if (members >= g->run_min) {
+          g->apply_cann_run(batch, plan, i, j);
           i = j - 1;
           continue;
         }

@@ -386,6 +386,88 @@ def test_update_runs_on_all_cores_equal_the_one_by_one_replay(orc, listener, mon
             assert kinds.get(kind, 0) > 10, (kind, kinds)
 
 
+def _announcement_flood(orc, seed, n_chans=240):
+    """ONE queue of channel_announcements: good ones, the same bytes relayed twice (the second meets a waiting announcement), damaged
+    signatures / truncated / bad bitcoin keys (warnings only: they ride along in a run), swapped node ids and another chain (the plan
+    expects a drop: they end a run), channels not deep enough (gs.Net: every 7th -- early_ann or "Bad gossip order": they end a run),
+    a node_announcement now and then; the txout replies; then a second queue that re-announces known channels among new ones"""
+    import random
+    net = gs.Net(orc, seed, n_nodes=14, n_chans=n_chans)
+    rnd = random.Random(seed * 11 + 3)
+    ops = []
+    first = n_chans * 3 // 4
+
+    def wave(chans):
+        for c in chans:
+            peer = rnd.choice(net.peers)
+            x = rnd.random()
+            if x < 0.06:
+                m = gs.damage(rnd, net.cann(c), "sig")
+            elif x < 0.09:
+                m = gs.damage(rnd, net.cann(c), "trunc")
+            elif x < 0.11:
+                m = gs.damage(rnd, net.cann(c), "badkey")
+            elif x < 0.125:
+                m = net.cann(c, swap_ids=True)
+            elif x < 0.14:
+                m = net.cann(c, chain=gs.OTHER_CHAIN)
+            else:
+                m = net.cann(c)
+            ops.append(("push", peer, m))
+            if x > 0.92:
+                ops.append(("push", rnd.choice(net.peers), m))
+            if c % 61 == 60:
+                ops.append(("push", peer, net.nann(rnd.randrange(14), gs.NOW - 300 + c)))
+        ops.append(("process",))
+
+    wave(range(first))
+    for c in range(first):
+        if c % 7:                                                   # (the others are not deep enough: nobody asked for their txout)
+            ops.append(("txout", net.chans[c]["scid"], net.chans[c]["sat"], net.spk(c) if c % 29 else b"\x00\x20" + bytes(32)))
+    order = list(range(first, n_chans)) + rnd.sample(range(first), 60)   # new channels among re-announcements of known (and of failed) ones
+    rnd.shuffle(order)
+    wave(order)
+    for c in range(first, n_chans):
+        if c % 7:
+            ops.append(("txout", net.chans[c]["scid"], net.chans[c]["sat"], net.spk(c)))
+    return net, ops
+
+
+@pytest.mark.parametrize("listener", [True, False])
+def test_announcement_runs_on_all_cores_equal_the_one_by_one_replay(orc, listener, monkeypatch):
+    """apply_cann_run (runs of plain channel_announcements entered into the sharded map of waiting announcements by all host cores, a
+    shard's announcements in arrival order; damaged ones ride along and get their warnings in the serial pass) and the sharded
+    txout replies against (a) the one-by-one replay of the same ingest and (b) the sequential model of gossmap_manage.c: the same events
+    in the same order, the same maps, the same gossip_store image byte for byte -- with a listener and without one"""
+    from lightning_amd.gossipd import GossipIngest
+    net, ops = _announcement_flood(orc, 23)
+    model = ModelReceiver(orc, net)
+    gs.drive(net, ops, model, 23)
+    out = {}
+    for name, env in (("one_by_one", {"LAMD_INGEST_RUN_MIN": "0", "LAMD_INGEST_SUB": "1000000"}),
+                      ("runs", {"LAMD_INGEST_RUN_MIN": "4", "LAMD_INGEST_SUB": "1000000", "LAMD_INGEST_THREADS": "5"}),
+                      ("runs_pipelined", {"LAMD_INGEST_RUN_MIN": "4", "LAMD_INGEST_SUB": "50", "LAMD_INGEST_THREADS": "5"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc), collect_events=listener) as ing:
+            gs.drive(net, ops, ing, 23)
+            out[name] = (list(ing.events) if listener else None, ing.store_image(), ing.stats())
+    assert out["one_by_one"][2]["run_announcements"] == 0
+    assert out["runs"][2]["run_announcements"] > 100 and out["runs_pipelined"][2]["run_announcements"] > 60, (out["runs"][2], out["runs_pipelined"][2])
+    for name in ("runs", "runs_pipelined"):
+        assert out[name][1] == out["one_by_one"][1], "%s: the gossip_store image differs from the one-by-one replay's" % name
+        for key in ("messages", "channels", "nodes", "pending", "store_records"):
+            assert out[name][2][key] == out["one_by_one"][2][key], (name, key, out[name][2], out["one_by_one"][2])
+    assert out["one_by_one"][2]["channels"] > 100 and out["one_by_one"][2]["pending"] > 0   # (second-wave announcements nobody answered keep waiting)
+    if listener:
+        _compare(out["one_by_one"][0], model.events)
+        _compare(out["runs"][0], model.events)
+        _compare(out["runs_pipelined"][0], model.events)
+        kinds = _kinds(model.events)
+        for kind in ("GET_TXOUT", "WARNING", "STORE_ADD", "TXOUT_FAILED"):
+            assert kinds.get(kind, 0) > 3, (kind, kinds)
+
+
 def test_txout_reply_batch_on_all_cores_equals_reply_by_reply(orc):
     """lamd_gossipd_txout_reply_batch without a listener updates the maps reply by reply and writes the new channels' store records
     (channel_announcement + amount) with all cores afterwards: the image, the maps and what later channel_updates do to them must equal

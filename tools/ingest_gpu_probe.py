@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The gossip ingest flood of bench.py by itself, with the ingest's own phase clock (LAMD_INGEST_PROFILE=1): 100 k channel_announcements,
-their txout replies, 400 k channel_updates through csrc/gossip_ingest.cpp around the device calls."""
+"""The gossip ingest flood of bench.py by itself, with the ingest's own phase clock (LAMD_INGEST_PROFILE=1): channel_announcements,
+their txout replies, channel_updates through csrc/gossip_ingest.cpp around the device calls.
+usage: ingest_gpu_probe.py [n_announcements=100000] [n_updates=400000]"""
 import hashlib
 import os
 import sys
@@ -14,7 +15,9 @@ from lightning_amd import Engine, workload
 from lightning_amd.gossipd import GossipIngest
 
 eng = Engine(0)
-g = workload.make_gossip(eng, 100_000, 400_000, n_nodes=15000, corrupt_frac=0.01, device="cuda:0")
+NA = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+NU = int(sys.argv[2]) if len(sys.argv) > 2 else 400_000
+g = workload.make_gossip(eng, NA, NU, n_nodes=15000, corrupt_frac=0.01, device="cuda:0")
 chain = bytes(g.msgs[260:292])
 peer = bytes(g.ids[g.n_cann])
 cann_blob, cann_off = g.msgs[:int(g.off[g.n_cann]) + 1], g.off[:g.n_cann + 1].copy()
@@ -38,9 +41,13 @@ for rep in range(3):
         t2 = time.perf_counter()
         ing.txout_reply_batch(scids, sats, spk_blob, spk_off)
         t3 = time.perf_counter()
-        ing.push_batch(peer, cupd_blob, cupd_off)
-        tq = time.perf_counter()
-        ing.process()
+        tq = t3
+        for o in range(0, g.n_cupd, 500_000):      # connectd's queue bound: the updates arrive as queues of 500 k
+            e_ = min(g.n_cupd, o + 500_000)
+            tq0 = time.perf_counter()
+            ing.push_batch(peer, cupd_blob[int(cupd_off[o]):int(cupd_off[e_]) + 1], (cupd_off[o:e_ + 1] - cupd_off[o]).copy())
+            tq += time.perf_counter() - tq0
+            ing.process()
         t4 = time.perf_counter()
         st = ing.stats()
     print("rep %d: announcements %.2f M/s (push %.1f ms, process %.1f ms), replies %.2f M/s, updates %.2f M/s (push %.1f ms, process %.1f ms); channels %d late %d"
