@@ -1225,9 +1225,9 @@ struct lamd_gossipd {
     parallel_for(get_pool(), NSH, 1, [&](size_t lo, size_t hi) {
       for (size_t i = a; i < b; i++) {
         planned &p = plan[i];
-        if (!cann_run_member(p, cur_v)) continue;  // rides along (cann_run_side): the serial pass replays it
         const unsigned sh = pending_ann.shard_of(p.scid);
-        if (sh < lo || sh >= hi) continue;
+        if (sh < lo || sh >= hi) continue;             // (first: only the shard's owner looks at, and clears, p.pre)
+        if (!cann_run_member(p, cur_v)) continue;      // rides along (cann_run_side): the serial pass replays it
         const bool drop = (!fail_empty && txout_failures.shard(sh).count(p.scid)) ||                 // :679-681
                           chans.shard(sh).count(p.scid) || (!early_empty && early_ann.count(p.scid));  // :684-687
         if (!drop && pending_ann.shard(sh).emplace(p.scid, std::move(*p.pre)).second) cann_took[i - a] = 1;   // :744-750
@@ -1258,7 +1258,7 @@ struct lamd_gossipd {
   thread_pool *get_pool_bg() { if (!pool_bg) pool_bg = new thread_pool(std::max(1u, host_threads() / 2) - 1); return pool_bg; }
   std::vector<queued> w_batch;
   std::vector<planned> w_plan;
-  ingest_stage *w_stage = nullptr;   // two planning stages (lamd_gossipd_process), allocated on first use
+  ingest_stage *w_stage = nullptr;   // three stages in flight (lamd_gossipd_process), allocated on first use
   void apply_cupd_run(const std::vector<queued> &batch, const std::vector<planned> &plan, const std::vector<int8_t> &v, size_t a, size_t b) {
     const size_t m = b - a;
     const unsigned T = std::max(1u, std::min(get_pool()->size(), (unsigned)(m / 1024 + 1)));
@@ -1911,14 +1911,19 @@ static void ingest_stage1(lamd_gossipd *g, const bytes &arena, const std::vector
     }
   }
   const double t2 = ingest_now();
-  // ---- verify: one call for the signatures, one for the keys of announcements that are dropped anyway
+  st.t_plan = t1 - t0; st.t_slots = t2 - t1;
+}
+// ---- the stage's device calls: one for the signatures, one for the keys of announcements that are dropped anyway.  Touches nothing of the
+// ingest but `st` and the back end (under be_mu): it runs on a thread of its own while the stage before it is applied and the one after it planned
+static void ingest_stage_verify(lamd_gossipd *g, ingest_stage &st, thread_pool *pool) {
+  const double t2 = ingest_now();
+  st.wb.pool = pool;
   st.rc = g->verify_into(st.sl, st.v, st.wb, st.cnt);
   if (st.rc == LAMD_OK) {
     st.keyok.assign(st.keyblob.size() / 33, 0);
     if (!st.keyok.empty()) st.rc = g->backend_keyparse(st.keyok.size(), st.keyblob.data(), st.keyok.data());
   }
-  const double t3 = ingest_now();
-  st.t_plan = t1 - t0; st.t_slots = t2 - t1; st.t_verify = t3 - t2;
+  st.t_verify = ingest_now() - t2;
 }
 
 extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
@@ -1954,7 +1959,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   if (const char *e = getenv("LAMD_INGEST_SUB")) sub = (size_t)atoll(e) < 1 ? 1 : (size_t)atoll(e);
   if (const char *e = getenv("LAMD_INGEST_RUN_MIN")) g->run_min = (size_t)atoll(e);
   const size_t nsub = (n + sub - 1) / sub;
-  if (!g->w_stage) g->w_stage = new ingest_stage[2];
+  if (!g->w_stage) g->w_stage = new ingest_stage[3];
   ingest_stage *stage = g->w_stage;
   auto setup = [&](ingest_stage &s, size_t k) {
     s.lo = k * sub; s.hi = std::min(n, (k + 1) * sub);
@@ -1963,9 +1968,20 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     s.cnt = lamd_gossipd::vcount();
     s.has_cann = false; s.rc = LAMD_OK;
   };
+  // Three stages in flight: while sub-batch k is APPLIED (this thread, all cores for its runs), the signatures of sub-batch k+1 are on the device
+  // (a thread that mostly waits) and sub-batch k+2 is PLANNED (a thread with half of the cores).  Before the loop: plan 0, then verify 0 next to plan 1.
   setup(stage[0], 0);
   ingest_stage1(g, arena, ents, batch, plan, stage[0], g->get_pool());
   g->st.sub_batches++;
+  {
+    std::thread tb([&] { ingest_stage_verify(g, stage[0], nullptr); });
+    if (nsub > 1) {
+      setup(stage[1], 1);
+      ingest_stage1(g, arena, ents, batch, plan, stage[1], g->get_pool());
+      g->st.sub_batches++;
+    }
+    tb.join();
+  }
   const double tp2 = prof0 ? ingest_now() : 0;
   // (every message of the batch may become a store record: grow the image and the record list once, not by doubling through the pass)
   reserve_prefaulted(g->get_pool(), g->image, g->image.size() + arena.size() + 12 * n + (g->image.size() >> 2));
@@ -1974,18 +1990,24 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   long ret = (long)n;
   if (prof0) fprintf(stderr, "[ingest] process n=%zu: work buffers %.1f ms, first planning stage %.1f ms, store / image growth %.1f ms\n", n, (tp1 - tp0) * 1e3, (tp2 - tp1) * 1e3, (ingest_now() - tp2) * 1e3);
   for (size_t k = 0; k < nsub; k++) {
-    ingest_stage &cur = stage[k & 1], &nxt = stage[(k + 1) & 1];
+    ingest_stage &cur = stage[k % 3], &nxt = stage[(k + 1) % 3], &nn = stage[(k + 2) % 3];
     if (cur.rc != LAMD_OK) {  // the device call of this sub-batch failed: it and everything behind it go back to the queue, unapplied
       g->drop_verdicts();
       requeue(g, arena, ents, cur.lo);
       ret = cur.rc;
       break;
     }
-    std::thread bg;
+    std::thread bg, bv;
     const bool overlap = k + 1 < nsub;
-    if (k + 1 < nsub) setup(nxt, k + 1);
+    if (overlap) bv = std::thread([&] { ingest_stage_verify(g, nxt, nullptr); });   // sub-batch k+1 was planned an iteration ago
     // (the planning thread takes half of the cores while it shares the machine with the apply pass)
-    if (overlap) { thread_pool *pb = g->get_pool_bg(); bg = std::thread([&, pb] { ingest_stage1(g, arena, ents, batch, plan, nxt, pb); }); g->st.sub_batches++; g->st.overlapped_stages++; }
+    if (k + 2 < nsub) {
+      setup(nn, k + 2);
+      thread_pool *pb = g->get_pool_bg();
+      bg = std::thread([&, pb] { ingest_stage1(g, arena, ents, batch, plan, nn, pb); });
+      g->st.sub_batches++;
+    }
+    if (overlap) g->st.overlapped_stages++;
     // ---- apply sub-batch k in arrival order.  Event callbacks fire from here: they must not re-enter lamd_gossipd_process / _txout_reply /
     // _new_block (those return LAMD_ERR_STATE while in_process is set -- answer LAMD_GEV_GET_TXOUT after process() returns; _push is fine).
     const double ta = prof ? ingest_now() : 0;
@@ -2058,6 +2080,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
     }
     const double tb = prof ? ingest_now() : 0;
     if (bg.joinable()) bg.join();
+    if (bv.joinable()) bv.join();
     if (fault_at != SIZE_MAX) {  // message fault_at and everything after it go back to the queue, unapplied
       ret = g->fault_rc;
       g->fault_rc = LAMD_OK;
@@ -2065,10 +2088,9 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
       requeue(g, arena, ents, fault_at);
       break;
     }
-    if (k + 1 < nsub && !overlap) { ingest_stage1(g, arena, ents, batch, plan, nxt, g->get_pool()); g->st.sub_batches++; }
     if (prof)
       fprintf(stderr, "[ingest] sub-batch %zu/%zu n=%zu plan(parallel) %.1f ms, slots %.1f ms, verify %.1f ms | apply %.1f ms%s\n", k + 1, nsub, cur.hi - cur.lo,
-              cur.t_plan * 1e3, cur.t_slots * 1e3, cur.t_verify * 1e3, (tb - ta) * 1e3, overlap ? " (next sub-batch planned under it)" : "");
+              cur.t_plan * 1e3, cur.t_slots * 1e3, cur.t_verify * 1e3, (tb - ta) * 1e3, overlap ? " (the next sub-batch verified, the one after it planned under it)" : "");
   }
   g->drop_verdicts();
   g->in_process = false;
