@@ -13,8 +13,8 @@ touch $SO
 export TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path=/tmp/lamd_tsan"
 rm -f /tmp/lamd_tsan.*
 export LD_PRELOAD="$(gcc -print-file-name=libtsan.so)"
-python -m pytest tests/test_gossip_ingest.py -x -q -m "not gpu" -k "runs or reply_batch or sequential_model_cpu"
-LAMD_INGEST_SUB=3000 python tools/ingest_host_bench.py 20000 4
+# (the Python test suite under ThreadSanitizer takes tens of minutes on a small VM: the flood below drives every parallel pass)
+LAMD_INGEST_SUB=1500 LAMD_INGEST_RUN_MIN=64 LAMD_INGEST_THREADS=4 timeout 1200 python tools/ingest_host_bench.py 6000 4
 unset LD_PRELOAD
 if ls /tmp/lamd_tsan.* >/dev/null 2>&1; then echo "ThreadSanitizer reports:"; grep -h "WARNING: ThreadSanitizer" /tmp/lamd_tsan.* | sort | uniq -c; grep -h -A 12 "WARNING: ThreadSanitizer: data race" /tmp/lamd_tsan.* | grep -E "gossip_ingest|#0|#1" | head -40; exit 1; fi
 echo "ThreadSanitizer: no reports"
