@@ -1274,6 +1274,10 @@ struct lamd_ctx {
   hipEvent_t ev_sigs_wait = nullptr;   // the event that copy is followed by (the lane's own ev_sigs, or the staging set's)
   hipStream_t copy_stream = nullptr;   // root only: the H2D copies of every flush, in flush order, behind nothing but each other (lamd_flush)
   bool use_copy_stream = true;         // LAMD_COPY_STREAM=0: a flush's copies go down its lane's prep stream (the round-2 form)
+  hipStream_t d2h_stream = nullptr;    // root only, LAMD_D2H_STREAM=1 (experiment): the verdict copies of every flush on a stream of their own instead of the flush's lane.
+                                       // Measured (profiles/r04_ab_variants.txt): nothing on the cold streaming loop, and one more stream per engine costs the SECOND
+                                       // engine of a process a quarter of its streaming rate (20 streams on 16 hardware queues) -- off
+  bool use_d2h_stream = false;
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   bool fused_front = true;        // LAMD_FUSED_FRONT=0: the front end of a keyed call as the 19 launches + 5 fills of round 2 (see k_call_init)
@@ -1329,11 +1333,13 @@ struct lamd_ctx {
     std::vector<span> tickets;  // rows [row0, row0 + count) of this queue return as verdicts [ticket0, ...) of the staging set
     devbuf d_a, d_b, d_c, d_ok;
     hipEvent_t ev_keys = nullptr, ev_sigs = nullptr, ev_all = nullptr;  // behind the three H2D copies of a flush on the copy stream
+    hipEvent_t ev_res = nullptr;     // behind the flush's last kernel on its lane: the verdict copy on the D2H stream waits for it
     bool small_flush = false;   // this flush ran as ONE k_small_verify launch over the staging rows themselves (h_ok + cap: the rows' shapes)
   };
   struct queue_set {
     queue q[Q_KINDS];
     hipEvent_t done = nullptr;
+    hipEvent_t tail = nullptr;   // behind everything the flush put on its lane's main stream: `done` on the D2H stream waits for it too (a small flush has no copy)
     size_t rows = 0;  // triples queued into this set so far = the next ticket
   } qs[QUEUE_SETS];
   int q_open = 0;                 // the set being filled, -1 when every set is in flight
@@ -1468,10 +1474,13 @@ static int create_streams(lamd_ctx *ctx) {
   if (!ctx->is_lane) {
     for (auto &qs : ctx->qs) {
       HIPCHK(ctx, hipEventCreateWithFlags(&qs.done, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&qs.tail, hipEventDisableTiming));
       for (auto &q : qs.q)
-        for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all, &q.ev_res}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (const char *w = getenv("LAMD_D2H_STREAM")) ctx->use_d2h_stream = atoi(w) != 0;
+    if (ctx->use_d2h_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
     for (auto &e : ctx->ev_ecm) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (const char *w = getenv("LAMD_ECMULT_CHAIN")) ctx->ecm_chain = atoi(w);
     if (const char *w = getenv("LAMD_ECMULT_TAIL")) ctx->ecm_tail = (u32)atol(w);
@@ -1651,6 +1660,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     L = nullptr;
   }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (devbuf *b : {&ctx->row_ent, &ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->plan,
                     &ctx->kt_fin, &ctx->hk7_row, &ctx->hk7_ent, &ctx->hk7_slot, &ctx->hk7_qwords, &ctx->hk7_keyok, &ctx->hk7_scratch,
@@ -1676,12 +1686,14 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
       for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
         if (*h) (void)hipHostFree(*h);
       for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
-      for (hipEvent_t e : {q.ev_keys, q.ev_sigs, q.ev_all})
+      for (hipEvent_t e : {q.ev_keys, q.ev_sigs, q.ev_all, q.ev_res})
         if (e) (void)hipEventDestroy(e);
     }
     if (qs.done) (void)hipEventDestroy(qs.done);
+    if (qs.tail) (void)hipEventDestroy(qs.tail);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   for (auto &e : ctx->ev_ecm)
     if (e) (void)hipEventDestroy(e);
   if (ctx->gtable && !ctx->is_lane) (void)hipFree(ctx->gtable);
@@ -1714,6 +1726,7 @@ extern "C" int lamd_synchronize(lamd_ctx *ctx) {
     if (rc != LAMD_OK) { ctx->err = L->err; return rc; }
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d2h_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->d2h_stream));   // (root only: the verdict copies of the flushes in flight)
   if (ctx->timing && ctx->ev_recorded) {
     for (int i = 0; i < 4; i++) {
       float ms = 0;
@@ -3423,9 +3436,23 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       if (L != ctx) ctx->err = L->err;
       return rc;
     }
-    HIPCHK(ctx, hipMemcpyAsync(q.h_ok, q.d_ok.p, q.n, hipMemcpyDeviceToHost, L->stream));
+    if (ctx->use_d2h_stream) {
+      // the verdicts leave on a stream of their own: on the lane's stream the copy (and its completion) stood between this flush's last kernel
+      // and the first kernel of the lane's next call
+      HIPCHK(ctx, hipEventRecord(q.ev_res, L->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->d2h_stream, q.ev_res, 0));
+      HIPCHK(ctx, hipMemcpyAsync(q.h_ok, q.d_ok.p, q.n, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(q.h_ok, q.d_ok.p, q.n, hipMemcpyDeviceToHost, L->stream));
+    }
   }
-  HIPCHK(ctx, hipEventRecord(qs.done, L->stream));
+  if (ctx->use_d2h_stream) {
+    HIPCHK(ctx, hipEventRecord(qs.tail, L->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->d2h_stream, qs.tail, 0));
+    HIPCHK(ctx, hipEventRecord(qs.done, ctx->d2h_stream));
+  } else {
+    HIPCHK(ctx, hipEventRecord(qs.done, L->stream));
+  }
   ctx->q_fifo[ctx->q_inflight++] = ctx->q_open;
   // the next set to fill: any set that is not in flight
   ctx->q_open = -1;
