@@ -647,6 +647,29 @@ def test_scheduling_variants_give_the_same_verdicts(orc, env):
         e.close()
 
 
+def test_engines_of_one_process_share_the_g_table(kat):
+    """the 11 GiB static table of G exists once per device and process (reference-counted by lamd_init / lamd_shutdown): a second engine does
+    not build another, closing the first leaves it to the second, and after the last one is gone the next engine builds it again"""
+    import time
+    from lightning_amd import Engine
+    vs = [v for v in kat["ecdsa"] if len(v["pub"]) == 66][:64]
+    rows = (_rows([H(v["hash"]) for v in vs], 32), _rows([H(v["sig"]) for v in vs], 64), _rows([H(v["pub"]) for v in vs], 33))
+    want = [v["expect"] for v in vs]
+    e1 = Engine(0)
+    t0 = time.perf_counter()
+    e2 = Engine(0)
+    t_second = time.perf_counter() - t0
+    assert [bool(g) for g in e1.verify_ecdsa(*rows)] == want
+    e1.close()
+    assert [bool(g) for g in e2.verify_ecdsa(*rows)] == want          # the table outlives the engine that built it
+    big = [np.concatenate([r] * 200) for r in rows]                     # the general path reads it too
+    assert [bool(g) for g in e2.verify_ecdsa(*big)] == want * 200
+    e2.close()
+    with Engine(0) as e3:                                               # built afresh
+        assert [bool(g) for g in e3.verify_ecdsa(*rows)] == want
+    assert t_second < 5.0
+
+
 def test_device_self_diagnostics(eng, kat):
     """the diagnostic entry points (every arithmetic stage evaluated on the device and, with the same inline functions, on
     the host) must report no difference -- they are how a code-generation problem is localised on a new toolchain"""
