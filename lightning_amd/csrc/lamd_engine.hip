@@ -1223,9 +1223,13 @@ enum { Q_ECDSA33 = 0, Q_ECDSA65 = 1, Q_SCHNORR = 2, Q_KINDS = 3 };
 constexpr int QUEUE_SETS = LAMD_QUEUE_SETS;  // staging sets of the streaming queue: one open + up to QUEUE_SETS - 1 flushes in flight
 
 // the static G table, one per device and process (lamd_init / lamd_shutdown)
-struct shared_gtable { u32 *p = nullptr; int refs = 0; };
-static std::mutex g_gtable_mu;
-static std::map<int, shared_gtable> g_gtables;
+struct shared_gtable { std::mutex mu; u32 *p = nullptr; int refs = 0; };
+static std::mutex g_gtable_mu;                       // guards the map only: tables of different devices are built side by side (lamd_multi_init)
+static std::map<int, shared_gtable> g_gtables;       // (std::map: a slot's address is stable)
+static shared_gtable &gtable_slot(int device) {
+  std::lock_guard<std::mutex> lk(g_gtable_mu);
+  return g_gtables[device];
+}
 
 struct lamd_ctx {
   int device = 0;
@@ -1615,8 +1619,8 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     // ONE static table of G per device and process, shared by every context on that device (read-only after its build) and freed with the last of
     // them: a second engine in a process (a sidecar's reload, bench.py's cache-on engine, a test suite's two dozen) costs neither another 11 GiB nor
     // another 0.36 s
-    std::lock_guard<std::mutex> lk(g_gtable_mu);
-    shared_gtable &sg = g_gtables[device];
+    shared_gtable &sg = gtable_slot(device);
+    std::lock_guard<std::mutex> lk(sg.mu);
     if (sg.refs == 0) {
       u32 *d_bases = nullptr;
       HIPCHK(ctx, hipMalloc(&d_bases, bases.size() * 4));
@@ -1723,8 +1727,8 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   for (auto &e : ctx->ev_ecm)
     if (e) (void)hipEventDestroy(e);
   if (ctx->gtable && !ctx->is_lane) {
-    std::lock_guard<std::mutex> lk(g_gtable_mu);
-    shared_gtable &sg = g_gtables[ctx->gtable_device];
+    shared_gtable &sg = gtable_slot(ctx->gtable_device);
+    std::lock_guard<std::mutex> lk(sg.mu);
     if (sg.refs > 0 && --sg.refs == 0) {
       (void)hipFree(sg.p);
       sg.p = nullptr;
