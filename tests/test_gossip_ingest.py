@@ -109,6 +109,29 @@ def test_batched_ingest_equals_sequential_model_cpu_backend(orc):
     assert tot["duplicates"] > 0 and tot["keyparse_messages"] > 0
 
 
+@pytest.mark.parametrize("env", [{"LAMD_INGEST_RUN_MIN": "2", "LAMD_INGEST_SUB": "1000000", "LAMD_INGEST_THREADS": "5"},
+                                 {"LAMD_INGEST_RUN_MIN": "2", "LAMD_INGEST_SUB": "7", "LAMD_INGEST_THREADS": "3"}])
+def test_random_scripts_with_every_run_taken_equal_the_sequential_model(orc, env, monkeypatch):
+    """the random scripts of the test above (every kind of message, damage and ordering; txout replies, new blocks, pruning in between)
+    with the shortest possible runs -- two plain channel_updates or two plain channel_announcements in a row already go through the
+    all-cores passes -- and with sub-batches of seven messages (three pipeline stages in flight over nearly every queue): the events must
+    still be the sequential model's, one for one"""
+    from lightning_amd.gossipd import GossipIngest
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    runs = 0
+    for seed in (11, 12, 13, 14, 15, 16):
+        net, ops = gs.make_script(orc, seed)
+        model = ModelReceiver(orc, net)
+        gs.drive(net, ops, model, seed)
+        with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc)) as ing:
+            gs.drive(net, ops, ing, seed)
+            _compare(ing.events, model.events)
+            st = ing.stats()
+        runs += st["run_updates"] + st["run_announcements"]
+    assert runs > 20, runs
+
+
 def test_channel_life_cycle_spent_dying_pruned_equals_sequential_model(orc):
     """remove_channel (gossmap_manage.c:296-375) reached through channel_spent -> 72 blocks -> new_block (:1419-1497) and through
     prune_network (:398-470): tombstones, deleted records, node_announcements deleted with their last channel / moved behind a
