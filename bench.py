@@ -647,7 +647,7 @@ def main():
             # lamd_wait): while the device works on one flush the host fills the next staging set and its H2D copies run under the
             # kernels of the flushes before it (up to eight in flight; the copies of all flushes go down one copy stream in flush order).  Staging memcpy + H2D + verification + D2H inside the clock.
             H2H_STEPS = 30
-            H2H_DEPTH = min(8, eng.info()["queue_sets"] - 1)   # flushes kept in flight (4 lanes: the copies of the next four run under the kernels of these)
+            H2H_DEPTH = min(8, eng.info()["queue_sets"] - 1)   # flushes kept in flight (the copies of the flushes behind the lanes' current ones run under their kernels)
             # (the clock stops when the last verdict vector is in host memory; the vectors are compared with the expected verdicts AFTER it -- the
             # check is the bench's, not the path's: a 1 M-element numpy compare per flush is 1-1.5 ms of host time)
             def host_mix(e, reps):

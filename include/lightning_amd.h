@@ -83,7 +83,7 @@ int lamd_verify_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, con
 /* ---- the same with every buffer already resident in HBM (device pointers), asynchronous: the work is ordered after
  * whatever is already queued on the context's stream (lamd_stream()) and the verdicts are complete after
  * lamd_synchronize(), or, without blocking the host, for a stream passed to lamd_stream_wait_results().  Successive
- * calls rotate over LAMD_LANES internal lanes (default 4; own streams and workspaces) so that one call's key
+ * calls rotate over LAMD_LANES internal lanes (default 6; own streams and workspaces) so that one call's key
  * de-duplication and table building run under the ecmult kernels of the calls before it; LAMD_LANES=1 turns that off
  * (strictly one stream).  d_ok is never read and is written once per call, with final verdicts (one device-to-device copy at the
  * end of the call): calls in flight at the same time may be handed the same verdict buffer.
@@ -289,7 +289,7 @@ typedef struct {
 	size_t last_hot_rows;     /* rows verified against per-key comb tables (the rest took the per-signature ladder) */
 	int last_keyed;           /* 0: ladder only; else the largest comb used (7 or 10 teeth) */
 	int last_mode;            /* 0: the last chunk was ECDSA, 1: BIP-340 */
-	int lanes;                /* number of lanes (LAMD_LANES, default 4; 1 = strictly one stream) */
+	int lanes;                /* number of lanes (LAMD_LANES, default 6; 1 = strictly one stream) */
 	size_t last_cache_hits;   /* rows whose key already had a table in the cache */
 	size_t last_cold_rows;    /* rows that took the ladder */
 	size_t last_new_tables;   /* comb tables built by that chunk */

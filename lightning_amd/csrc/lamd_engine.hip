@@ -1357,7 +1357,7 @@ struct lamd_ctx {
   int q_open = 0;                 // the set being filled, -1 when every set is in flight
   int q_fifo[QUEUE_SETS] = {0};   // flushed sets, oldest first
   int q_inflight = 0;
-  // Lanes: the device-pointer entry points rotate over LAMD_LANES (default 4) complete sub-contexts (own streams and
+  // Lanes: the device-pointer entry points rotate over LAMD_LANES (default 6) complete sub-contexts (own streams and
   // workspaces, the G table shared), so that the latency-bound front end of one call (key de-duplication, the count
   // read-back, table building) runs under the VALU-bound ecmult kernels of the calls before it.  A lane's `peer` is the
   // next lane; the root context (the handle the caller holds) keeps its own stream for staging, queues, generators.
@@ -1674,7 +1674,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     ctx->cache_resets = 0;
   }
   const char *lanes = getenv("LAMD_LANES");
-  const int nl = lanes ? atoi(lanes) : 4;
+  const int nl = lanes ? atoi(lanes) : 6;   // (6 since round 4: with the row-grouping stage a call's launch chain is longer; 4 / 5 / 6 / 7 / 8 lanes = 246 / 243 / 256 / 249 / 252 M verifies/s cold)
   if (nl > 1) {
     rc = make_lanes(ctx, nl > MAX_LANES ? MAX_LANES : nl);
     if (rc != LAMD_OK) return rc;

@@ -519,7 +519,7 @@ def test_lanes_back_to_back_calls_without_host_sync(eng, orc):
             assert np.array_equal(w.d_ok.cpu().numpy().astype(bool), w.expect), (rep, kind, w.n)
         assert np.array_equal(gv.cpu().numpy(), g.expect)
     inf = [eng.info(k) for k in range(eng.info()["lanes"])]
-    assert len(inf) == 4 and {i["last_mode"] for i in inf} <= {0, 1}
+    assert len(inf) == 6 and {i["last_mode"] for i in inf} <= {0, 1}   # (LAMD_LANES default)
     # a caller's stream can wait for the results on the device instead of blocking the host
     kind, w = ws[0]
     w.d_ok.zero_()
