@@ -156,6 +156,8 @@ typedef struct lamd_gossipd_stats {
 	uint64_t run_announcements; /* channel_announcements entered into the map of waiting announcements by all cores, as runs of plain announcements */
 } lamd_gossipd_stats;
 void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats *out);
+/* diagnostic: the ingest's open-addressing maps against std::unordered_map over `ops` random operations; 0 = every check passed */
+long lamd_gossipd_selftest_maps(uint64_t seed, long ops);
 
 #ifdef __cplusplus
 }

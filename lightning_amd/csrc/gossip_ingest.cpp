@@ -2306,3 +2306,94 @@ extern "C" void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats
   out->queued_nodes = g->pending_nannounces.size();
   out->store_records = g->store.size();
 }
+
+// ---- self-test of the ingest's map (stable_map / sharded_map) against std::unordered_map: `ops` random insertions, look-ups, erasures (by key and
+// by iterator), operator[] and reserves over a key space small enough that keys recur, erased entries are re-used and tombstones pile up; after
+// every few thousand operations the two maps are compared entry for entry in both directions (iteration included), and pointers handed out
+// earlier must still point at their entries.  Returns 0, or the 1-based number of the first check that failed.  (tests/test_gossip_ingest.py)
+extern "C" long lamd_gossipd_selftest_maps(uint64_t seed, long ops) {
+  struct val { u64 a; std::vector<u32> v; };
+  u64 st = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  long check = 0;
+  {
+    scid_map<val> m(seed ^ 0x5EED);
+    std::unordered_map<u64, val> ref;
+    std::unordered_map<u64, val *> where;   // entry addresses must never change while the entry lives
+    const u64 space = 5000;
+    for (long op = 0; op < ops; op++) {
+      const u64 k = (rnd() % space) * 0x100000001ull + 7;
+      const unsigned what = (unsigned)(rnd() % 16);
+      if (what < 7) {
+        val v{rnd(), std::vector<u32>((size_t)(rnd() % 5), (u32)op)};
+        const auto r = m.emplace(k, v);
+        const auto rr = ref.emplace(k, v);
+        ++check;
+        if (r.second != rr.second || r.first->first != k || r.first->second.a != rr.first->second.a) return check;
+        if (r.second) where[k] = &r.first->second;
+      } else if (what < 10) {
+        const size_t e1 = m.erase(k), e2 = ref.erase(k);
+        ++check;
+        if (e1 != e2) return check;
+        where.erase(k);
+      } else if (what < 11) {
+        auto it = m.find(k);
+        ++check;
+        if ((it != m.end()) != (ref.count(k) != 0)) return check;
+        if (it != m.end()) { m.erase(it); ref.erase(k); where.erase(k); }
+      } else if (what < 12) {
+        val &x = m[k];
+        val &y = ref[k];
+        ++check;
+        if (x.a != y.a || x.v != y.v) return check;
+        x.a = y.a = rnd();
+        where[k] = &x;
+      } else if (what < 13 && (rnd() % 64) == 0) {
+        m.reserve(m.size() + (size_t)(rnd() % 3000));
+      } else {
+        auto it = m.find(k);
+        auto rt = ref.find(k);
+        ++check;
+        if ((it == m.end()) != (rt == ref.end()) || m.count(k) != ref.count(k)) return check;
+        if (it != m.end() && (it->second.a != rt->second.a || it->second.v != rt->second.v || where[k] != &it->second)) return check;
+        m.prefetch(k);
+        m.prefetch_entry(k);
+      }
+      if (op % 4096 == 4095 || op + 1 == ops) {
+        ++check;
+        if (m.size() != ref.size() || m.empty() != ref.empty()) return check;
+        size_t seen = 0;
+        for (const auto &kv : m) {
+          auto rt = ref.find(kv.first);
+          if (rt == ref.end() || rt->second.a != kv.second.a || rt->second.v != kv.second.v) return check;
+          seen++;
+        }
+        if (seen != ref.size()) return check;
+        for (const auto &kv : ref) {
+          auto it = m.find(kv.first);
+          if (it == m.end() || it->second.a != kv.second.a || where[kv.first] != &it->second) return check;
+        }
+      }
+    }
+  }
+  {  // node ids: the index holds a hash, equal hashes must still tell keys apart -- a seed-independent check with many keys in few slots is not
+     // possible from outside, so: plain differential run over 33-byte keys
+    sharded_map<nodeid, u64, nodeid_key_traits> m(seed ^ 0xABCD);
+    std::map<std::string, u64> ref;
+    for (long op = 0; op < ops / 4; op++) {
+      nodeid id;
+      const u64 r = rnd() % 3000;
+      for (int i = 0; i < 33; i++) id.k[i] = (u8)((r >> ((i % 8) * 3)) + i * (r % 7));
+      const std::string key((const char *)id.k, 33);
+      if (rnd() % 3) { m[id] += op; ref[key] += (u64)op; }
+      else { ++check; if (m.erase(id) != ref.erase(key)) return check; }
+      ++check;
+      auto it = m.find(id);
+      auto rt = ref.find(key);
+      if ((it == m.end()) != (rt == ref.end()) || (it != m.end() && it->second != rt->second)) return check;
+    }
+    ++check;
+    if (m.size() != ref.size()) return check;
+  }
+  return 0;
+}

@@ -3,6 +3,7 @@ gossipd's receive path (oracle/gossipd_model.py, one sigcheck per message as gos
 warnings with the reference's exact texts, txout requests, store appends / deletions / timestamp rewrites, peer updates,
 traces -- in the same order, on traffic with duplicates, reordering, orphans, damaged and malformed messages.
 CPU: the host logic with the C oracle as verification back end.  GPU: the engine as back end."""
+import ctypes
 import os
 import sys
 
@@ -130,6 +131,18 @@ def test_random_scripts_with_every_run_taken_equal_the_sequential_model(orc, env
             st = ing.stats()
         runs += st["run_updates"] + st["run_announcements"]
     assert runs > 20, runs
+
+
+def test_ingest_maps_against_std_unordered_map():
+    """stable_map / sharded_map (gossip_ingest.cpp: open-addressing index over entries that never move, 16 shards) against
+    std::unordered_map over 400 000 random insertions, look-ups, erasures, operator[] and reserves on a key space where keys recur,
+    erased entries are re-used and tombstones pile up: same contents (iteration included) and stable entry addresses throughout"""
+    from lightning_amd import gossipd
+    L = gossipd._load()
+    L.lamd_gossipd_selftest_maps.restype = ctypes.c_long
+    L.lamd_gossipd_selftest_maps.argtypes = [ctypes.c_uint64, ctypes.c_long]
+    for seed in (1, 2, 0xC0FFEE):
+        assert L.lamd_gossipd_selftest_maps(seed, 400_000) == 0, seed
 
 
 def test_channel_life_cycle_spent_dying_pruned_equals_sequential_model(orc):
