@@ -504,6 +504,69 @@ def test_announcement_runs_on_all_cores_equal_the_one_by_one_replay(orc, listene
             assert kinds.get(kind, 0) > 3, (kind, kinds)
 
 
+@pytest.mark.parametrize("fail_calls", [{0}, {1}, {2, 3}, {1, 4, 5, 9}])
+def test_engine_fault_in_the_pipeline_requeues_the_unapplied_tail(orc, fail_calls, monkeypatch):
+    """a verification back end that FAILS some of its calls (an engine error: LAMD_ERR_HIP) under the three-stage pipeline of a drained
+    queue (sub-batches of 40 messages: one applied, one on the "device", one planned): process() must hand the error back, apply nothing
+    of the failed sub-batch or of those behind it, keep them queued in order -- and after the retries the events, the maps and the
+    gossip_store image must be those of the run whose back end never failed.  A fault is never turned into a warning to a peer."""
+    from lightning_amd import gossipd
+    from lightning_amd.gossipd import GossipIngest
+    monkeypatch.setenv("LAMD_INGEST_SUB", "40")
+    monkeypatch.setenv("LAMD_INGEST_RUN_MIN", "4")
+    monkeypatch.setenv("LAMD_INGEST_THREADS", "4")
+    net, ops = _update_flood(orc, 29, n_chans=30, n_updates=500)
+    with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc)) as ref:
+        gs.drive(net, ops, ref, 29)
+        want = (list(ref.events), ref.store_image(), ref.stats())
+    sig, key = oracle_backend(orc)
+    state = {"calls": 0, "failed": 0}
+
+    def c_sig(_user, n, msgs, off, ids, verdict):
+        k = state["calls"]
+        state["calls"] += 1
+        if k in fail_calls:
+            state["failed"] += 1
+            return -2                                                    # LAMD_ERR_HIP
+        offs = (ctypes.c_uint64 * (n + 1)).from_address(off)
+        out = sig(ctypes.string_at(msgs, offs[n]), list(offs), ctypes.string_at(ids, 33 * n) if ids else bytes(33 * n))
+        (ctypes.c_int8 * n).from_address(verdict)[:] = out
+        return 0
+
+    def c_key(_user, n, pub, ok):
+        (ctypes.c_ubyte * n).from_address(ok)[:] = key(ctypes.string_at(pub, 33 * n))
+        return 0
+
+    class Retrying:
+        def __init__(self, ing):
+            self.ing, self.errors = ing, 0
+
+        def __getattr__(self, name):
+            return getattr(self.ing, name)
+
+        def process(self):
+            for _ in range(40):
+                try:
+                    return self.ing.process()
+                except RuntimeError as e:
+                    assert "lamd_gossipd_process: -2" in str(e), e
+                    self.errors += 1
+            raise AssertionError("the queue never drained")
+
+    with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc)) as ing:
+        be = (gossipd.SIGCHECK_FN(c_sig), gossipd.KEYPARSE_FN(c_key))
+        ing._L.lamd_gossipd_set_backend(ing._g, be[0], be[1], None)
+        r = Retrying(ing)
+        gs.drive(net, ops, r, 29)
+        got = (list(ing.events), ing.store_image(), ing.stats())
+    assert state["failed"] == len(fail_calls) and r.errors >= 1, (state, r.errors)
+    _compare(got[0], want[0])
+    assert not any(e[0] == "WARNING" and "-2" in e[2] for e in got[0])
+    assert got[1] == want[1], "the gossip_store image differs from the run whose back end never failed"
+    for k_ in ("messages", "channels", "nodes", "pending", "store_records", "queued_updates"):
+        assert got[2][k_] == want[2][k_], (k_, got[2], want[2])
+
+
 def test_txout_reply_batch_on_all_cores_equals_reply_by_reply(orc):
     """lamd_gossipd_txout_reply_batch without a listener updates the maps reply by reply and writes the new channels' store records
     (channel_announcement + amount) with all cores afterwards: the image, the maps and what later channel_updates do to them must equal
