@@ -5,8 +5,8 @@
  *   bitcoin/signature.h:85-87    check_signed_hash()
  *   bitcoin/signature.h:120-124  check_tx_sig()            (see note below)
  *   bitcoin/signature.h:129-131  check_schnorr_sig()
- *   common/bolt11.c:1021-1057    secp256k1_ecdsa_recoverable_signature_parse_compact(), _convert(), secp256k1_ecdsa_recover(),
- *                                secp256k1_ecdsa_verify() (also lightningd/dual_open_control.c:2254)
+ *   common/bolt11.c:1021-1057    lamd_secp256k1_ecdsa_recoverable_signature_parse_compact(), _convert(), lamd_secp256k1_ecdsa_recover(),
+ *                                lamd_secp256k1_ecdsa_verify() (also lightningd/dual_open_control.c:2254) -- prefixed, see below
  *   onchaind/onchaind.c:388-438  grind_htlc_tx_fee()       (static there; its statics become arguments)
  *   bitcoin/signature.h:158-159  signature_from_der()      (bitcoin/signature.c:310-323)
  *   common/node_id.h:72-82       pubkey_from_node_id(), check_signed_hash_nodeid()
@@ -113,6 +113,22 @@ bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num,
 		  const u8 *witness,
 		  const struct pubkey *key,
 		  const struct bitcoin_signature *sig);
+/* channeld/channeld.c:2171-2232 (handle_peer_commit_sig) as ONE call: the commitment signature under remote_funding over txs[0] (:2171), the
+ * count of HTLC signatures (:2203), then htlc_sigs[i] under remote_htlckey over txs[1+i] with htlc_wscripts[i] (:2224) -- all 1 + N signatures go
+ * to the device as one batch (lamd_check_commitment_signed), the answer is the reference's: NULL when it would have gone on, else the text it
+ * hands peer_failed_warn() for the FIRST check that fails, character for character:
+ *   "Bad commit_sig signature <local_index> <sig> for tx <tx> wscript <hex> key <key> feerate <feerate><commit_warning_tail>"
+ *   "Expected <n> htlc sigs, not <m>"
+ *   "Bad commit_sig signature <sig> for htlc <tx> wscript <hex> key <key>"
+ * (fmt_bitcoin_signature: DER + sighash byte; fmt_bitcoin_tx: hex of the serialised transaction; fmt_pubkey: 33 bytes).
+ * txs: tal-style array of pointers, as channel_txs() returns it (:2144); htlc_sigs: tal-style array; htlc_wscripts[i]: what
+ * bitcoin_tx_output_get_witscript(tmpctx, txs[0], txs[i+1]->wtx->inputs[0].index) gives the reference (:2215); commit_warning_tail: the rest
+ * of the first warning after the feerate (". Outpoint %s, funding_sats: %s, funding_txid: %s, inflight splice count: %zu" -- values the
+ * check never reads), may be NULL.  The string is allocated like the sigcheck_* ones. */
+const char *check_commit_sigs(const tal_t *ctx, uint64_t local_index, const struct bitcoin_tx *const *txs, const u8 *funding_wscript,
+			      const struct pubkey *remote_funding, const struct bitcoin_signature *commit_sig,
+			      const u8 *const *htlc_wscripts, const struct pubkey *remote_htlckey,
+			      const struct bitcoin_signature *htlc_sigs, uint32_t feerate, const char *commit_warning_tail);
 /* the round-1 form, kept for callers that already hold the serialised BIP143 preimage */
 bool check_tx_sig_preimage(const u8 *bip143_preimage, size_t preimage_len, const u8 *witness_script,
 			   const struct pubkey *key, const struct bitcoin_signature *sig);
@@ -131,22 +147,32 @@ void sighash_from_merkle(const char *messagename, const char *fieldname, const s
 bool bolt12_check_signature(const struct tlv_field *fields, const char *messagename, const char *fieldname, const struct pubkey *key,
 			    const struct bip340sig *sig);
 
-/* Public-key recovery as common/bolt11.c:1021-1046 and lightningd/signmessage.c:193 use it, under libsecp256k1's own
- * names and return conventions (1 = ok, 0 = failure; the context argument is accepted and ignored).  The opaque
- * recoverable signature holds r||s||recid. */
+/* The four libsecp256k1 calls the reference makes directly on this path -- public-key recovery (common/bolt11.c:1021-1046,
+ * lightningd/signmessage.c:193) and the BOLT #11 `n`-field / dual-open verification (common/bolt11.c:1026-1027,1055,
+ * lightningd/dual_open_control.c:2254) -- with the library's prototypes and return conventions (1 = ok, 0 = failure; the context
+ * argument is accepted and ignored), under a lamd_ PREFIX.  They are NOT exported under libsecp256k1's own names: lightningd, libwally
+ * and bitcoin/signature.c all link the real library, whose opaque secp256k1_pubkey / secp256k1_ecdsa_signature have another memory
+ * layout than this mirror's (X||Y and r||s big-endian) -- a second global `secp256k1_ecdsa_verify` would be a duplicate definition
+ * or, interposed, would be handed the real library's objects and fail every check.  A translation unit that wants the reference's
+ * call sites to compile unchanged against THIS header's types defines LAMD_SHIM_LIBSECP_NAMES before including it (macros, no symbols).
+ * The opaque recoverable signature holds r||s||recid; convert drops the recovery id (returns 1 always, as upstream);
+ * lamd_secp256k1_ecdsa_verify() is check_signed_hash() without the struct wrappers -- 1 iff r, s in [1, n-1], s <= n/2 (upstream
+ * rejects high-S: bitcoin/signature.c:185-187) and the signature verifies; msghash32 is used as given (32 bytes, reduced mod n). */
 typedef struct { unsigned char data[65]; } secp256k1_ecdsa_recoverable_signature;
-int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *ctx, secp256k1_ecdsa_recoverable_signature *sig,
-							 const unsigned char *input64, int recid);
-int secp256k1_ecdsa_recover(const void *ctx, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
-			    const unsigned char *msghash32);
-/* The two libsecp256k1 calls the reference makes on the BOLT #11 `n`-field path (common/bolt11.c:1026-1027,1055) and in
- * lightningd/dual_open_control.c:2254, under the library's own names: convert drops the recovery id (returns 1 always, as upstream);
- * secp256k1_ecdsa_verify() is check_signed_hash() without the struct wrappers -- 1 iff r, s in [1, n-1], s <= n/2 (upstream rejects
- * high-S: bitcoin/signature.c:185-187) and the signature verifies; msghash32 is used as given (32 bytes, reduced mod n). */
-int secp256k1_ecdsa_recoverable_signature_convert(const void *ctx, secp256k1_ecdsa_signature *sig,
-						  const secp256k1_ecdsa_recoverable_signature *sigin);
-int secp256k1_ecdsa_verify(const void *ctx, const secp256k1_ecdsa_signature *sig, const unsigned char *msghash32,
-			   const secp256k1_pubkey *pubkey);
+int lamd_secp256k1_ecdsa_recoverable_signature_parse_compact(const void *ctx, secp256k1_ecdsa_recoverable_signature *sig,
+							      const unsigned char *input64, int recid);
+int lamd_secp256k1_ecdsa_recover(const void *ctx, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
+				 const unsigned char *msghash32);
+int lamd_secp256k1_ecdsa_recoverable_signature_convert(const void *ctx, secp256k1_ecdsa_signature *sig,
+						       const secp256k1_ecdsa_recoverable_signature *sigin);
+int lamd_secp256k1_ecdsa_verify(const void *ctx, const secp256k1_ecdsa_signature *sig, const unsigned char *msghash32,
+				const secp256k1_pubkey *pubkey);
+#ifdef LAMD_SHIM_LIBSECP_NAMES
+#define secp256k1_ecdsa_recoverable_signature_parse_compact lamd_secp256k1_ecdsa_recoverable_signature_parse_compact
+#define secp256k1_ecdsa_recover lamd_secp256k1_ecdsa_recover
+#define secp256k1_ecdsa_recoverable_signature_convert lamd_secp256k1_ecdsa_recoverable_signature_convert
+#define secp256k1_ecdsa_verify lamd_secp256k1_ecdsa_verify
+#endif
 void node_id_from_pubkey(struct node_id *id, const struct pubkey *key);   /* common/node_id.c:12-19 */
 
 /* onchaind/onchaind.c:388-438.  The reference's file-scope state becomes arguments (min/max_possible_feerate,

@@ -148,6 +148,37 @@ int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version,
 			       const uint8_t *sighash_type, const uint8_t *has_witness_script,
 			       const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok);
 
+/* ---- ONE commitment_signed as ONE call: the loop of channeld/channeld.c:2171-2232 (handle_peer_commit_sig).  The reference checks
+ *   check_tx_sig(txs[0], 0, NULL, funding_wscript, &remote_funding, &commit_sig)            (:2171)
+ * and then, for i = 0 .. tal_count(htlc_sigs) - 1,
+ *   check_tx_sig(txs[1+i], 0, NULL, wscript_i, &remote_htlckey, &htlc_sigs[i])              (:2224)
+ * one signature per call, failing the peer at the first bad one.  Here the 1 + N rows are one batch -- the largest natural batch of the
+ * product, <= 1 + 483 signatures, N of them under ONE key: the BIP143 hashes of all 1 + N inputs are computed on the device from the
+ * templates (nothing is hashed on the host), a commitment of <= 4096 rows is two launches with no copy command (k_txsig_tx_hash reading the
+ * templates from pinned memory, k_small_verify behind it), larger ones take the batch machinery.
+ *   *first_bad = -1: every signature verifies;  0: the commitment signature does not;  1 + i: htlc_sigs[i] is the first that does not
+ * -- the reference's order, so the caller prints exactly the warning the reference would ("Bad commit_sig signature ..." with or without
+ * "for htlc": include/cln_shim.h check_commit_sigs()).  ok_rows (optional, 1 + n_htlc bytes): every row's verdict.
+ * A transaction template is what check_tx_sig() / bitcoin_tx_hash_for_sig() (bitcoin/signature.c:120-151,194-221) read of one (transaction, input):
+ * the fields of lamd_check_tx_sig_tx_batch(), one struct per row; `script` is the witness script (funding_wscript; the HTLC output's wscript). */
+typedef struct lamd_tx_template {
+	uint32_t version, locktime;
+	const uint8_t *inputs40;   /* n_inputs x (txid 32, as hashed | vout u32 LE | nSequence u32 LE) */
+	uint32_t n_inputs;
+	uint32_t input_num;        /* the input the signature is for (0 for commitment and HTLC transactions) */
+	uint64_t amount_sat;       /* that input's amount */
+	const uint8_t *outputs;    /* the outputs in wire form, back to back (amount u64 LE | CompactSize | scriptPubKey) */
+	uint64_t outputs_len;
+	uint32_t n_outputs;
+	const uint8_t *script;     /* the witness script the signature commits to */
+	uint64_t script_len;
+} lamd_tx_template;
+int lamd_check_commitment_signed(lamd_ctx *ctx, const lamd_tx_template *commit_tx, const uint8_t remote_funding33[33],
+				 const uint8_t commit_sig64[64], uint8_t commit_sighash_type,
+				 size_t n_htlc, const lamd_tx_template *htlc_txs, const uint8_t remote_htlckey33[33],
+				 const uint8_t *htlc_sigs64, const uint8_t *htlc_sighash_types,
+				 int64_t *first_bad, uint8_t *ok_rows);
+
 /* ---- BOLT #12 signatures: n independent bolt12_check_signature(fields, messagename, fieldname, key, sig) calls
  * (common/bolt12.c:80-92): merkle_tlv() over the TLV stream minus its signature fields (types 240..1000) and
  * sighash_from_merkle() (common/bolt12_merkle.c:227-318: H("LnLeaf"), H("LnNonce"|first-tlv), H("LnBranch"), tag

@@ -8,6 +8,13 @@ c_u8p = ctypes.c_void_p
 c_sz = ctypes.c_size_t
 
 
+class LamdTxTemplate(ctypes.Structure):
+    """lamd_tx_template (include/lightning_amd.h): what check_tx_sig() reads of one (transaction, input)"""
+    _fields_ = [("version", ctypes.c_uint32), ("locktime", ctypes.c_uint32), ("inputs40", ctypes.c_void_p), ("n_inputs", ctypes.c_uint32),
+                ("input_num", ctypes.c_uint32), ("amount_sat", ctypes.c_uint64), ("outputs", ctypes.c_void_p), ("outputs_len", ctypes.c_uint64),
+                ("n_outputs", ctypes.c_uint32), ("script", ctypes.c_void_p), ("script_len", ctypes.c_uint64)]
+
+
 class LamdInfo(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("compute_units", ctypes.c_int), ("arch", ctypes.c_char * 64),
                 ("gtable_bytes", ctypes.c_size_t), ("last_kernel_ms", ctypes.c_double * 4), ("last_unique_keys", ctypes.c_size_t),
@@ -35,6 +42,8 @@ SYMBOLS = {
     "lamd_check_schnorr_sig": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p]),
     "lamd_check_tx_sig_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_sz, c_u8p]),
     "lamd_check_tx_sig_tx_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz] + [c_u8p] * 15 + [c_sz, c_sz, c_u8p]),
+    "lamd_check_commitment_signed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_u8p, c_u8p, ctypes.c_uint8, c_sz, ctypes.c_void_p, c_u8p, c_u8p, c_u8p,
+                                                    ctypes.POINTER(ctypes.c_int64), c_u8p]),
     "lamd_bolt12_check_signature_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, ctypes.c_char_p, ctypes.c_char_p, c_u8p, c_sz, c_u8p, c_u8p]),
     "lamd_bolt12_merkle_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, ctypes.c_char_p, ctypes.c_char_p, c_u8p, c_u8p, c_u8p]),
     "lamd_ecdsa_recover_batch": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p]),

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/lightning_amd.h"
 
@@ -236,6 +237,22 @@ static void put_compact_size(std::string &o, uint64_t v) {
   else if (v <= 0xffff) { o.push_back((char)0xfd); o.push_back((char)v); o.push_back((char)(v >> 8)); }
   else { o.push_back((char)0xfe); for (int i = 0; i < 4; i++) o.push_back((char)(v >> (8 * i))); }
 }
+// the two byte strings the device hashes of a transaction: inputs (txid | vout | nSequence, 40 bytes each) and outputs in wire form
+static bool flatten_tx(const struct bitcoin_tx *tx, std::string &in, std::string &out) {
+  for (size_t i = 0; i < tx->num_inputs; i++) {
+    in.append((const char *)tx->inputs[i].txid, 32);
+    for (int b = 0; b < 4; b++) in.push_back((char)(tx->inputs[i].index >> (8 * b)));
+    for (int b = 0; b < 4; b++) in.push_back((char)(tx->inputs[i].sequence >> (8 * b)));
+  }
+  for (size_t i = 0; i < tx->num_outputs; i++) {
+    for (int b = 0; b < 8; b++) out.push_back((char)(tx->outputs[i].amount_sat >> (8 * b)));
+    const size_t sl = shim_tal_bytelen(tx->outputs[i].script);
+    if (sl == SHIM_TAL_FOREIGN) { g_err = "check_tx_sig: output script is not a tal array"; return false; }
+    put_compact_size(out, sl);
+    out.append((const char *)tx->outputs[i].script, sl);
+  }
+  return true;
+}
 extern "C" bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, const u8 *redeemscript, const u8 *witness_script,
                              const struct pubkey *key, const struct bitcoin_signature *sig) {
   const bool use_segwit = witness_script != nullptr;                   // bitcoin/signature.c:198-199
@@ -249,18 +266,7 @@ extern "C" bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, cons
   if (!g_ctx && !lamd_shim_setup()) return false;
   // flatten the template: that is all the host does -- hashPrevouts/Sequence/Outputs, the preimage and SHA256d run on the device
   std::string in, out;
-  for (size_t i = 0; i < tx->num_inputs; i++) {
-    in.append((const char *)tx->inputs[i].txid, 32);
-    for (int b = 0; b < 4; b++) in.push_back((char)(tx->inputs[i].index >> (8 * b)));
-    for (int b = 0; b < 4; b++) in.push_back((char)(tx->inputs[i].sequence >> (8 * b)));
-  }
-  for (size_t i = 0; i < tx->num_outputs; i++) {
-    for (int b = 0; b < 8; b++) out.push_back((char)(tx->outputs[i].amount_sat >> (8 * b)));
-    const size_t sl = shim_tal_bytelen(tx->outputs[i].script);
-    if (sl == SHIM_TAL_FOREIGN) { g_err = "check_tx_sig: output script is not a tal array"; return false; }
-    put_compact_size(out, sl);
-    out.append((const char *)tx->outputs[i].script, sl);
-  }
+  if (!flatten_tx(tx, in, out)) return false;
   const uint32_t version = tx->version, locktime = tx->locktime, inum = (uint32_t)input_num, nout = (uint32_t)tx->num_outputs;
   const size_t script_len = shim_tal_bytelen(script);
   if (script_len == SHIM_TAL_FOREIGN) { g_err = "check_tx_sig: script is not a tal array"; return false; }
@@ -276,6 +282,95 @@ extern "C" bool check_tx_sig(const struct bitcoin_tx *tx, size_t input_num, cons
                                             sig->s.data, pub65, 65, 65, &ok);
   if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return false; }
   return ok != 0;
+}
+
+// ---- channeld/channeld.c:2171-2232 as ONE call (see cln_shim.h check_commit_sigs)
+static std::string hex(const u8 *p, size_t n);
+static std::string der_hex(const secp256k1_ecdsa_signature *sig);
+// fmt_bitcoin_signature (bitcoin/signature.c:336-343): the DER signature with the sighash byte appended, in hex
+static std::string fmt_bitcoin_signature_(const struct bitcoin_signature *sig) {
+  const u8 t = (u8)sig->sighash_type;
+  return der_hex(&sig->s) + hex(&t, 1);
+}
+// fmt_bitcoin_tx (bitcoin/tx.c:712-718): hex of linearize_tx() -- a transaction channel_txs() built has empty scriptSigs and no witness stack
+// (the signature just received sits in the PSBT, :2147-2151), so this is the plain serialisation
+static std::string fmt_bitcoin_tx_(const struct bitcoin_tx *tx) {
+  std::string o;
+  for (int b = 0; b < 4; b++) o.push_back((char)(tx->version >> (8 * b)));
+  put_compact_size(o, tx->num_inputs);
+  for (size_t i = 0; i < tx->num_inputs; i++) {
+    o.append((const char *)tx->inputs[i].txid, 32);
+    for (int b = 0; b < 4; b++) o.push_back((char)(tx->inputs[i].index >> (8 * b)));
+    o.push_back(0);
+    for (int b = 0; b < 4; b++) o.push_back((char)(tx->inputs[i].sequence >> (8 * b)));
+  }
+  put_compact_size(o, tx->num_outputs);
+  for (size_t i = 0; i < tx->num_outputs; i++) {
+    for (int b = 0; b < 8; b++) o.push_back((char)(tx->outputs[i].amount_sat >> (8 * b)));
+    const size_t sl = shim_tal_bytelen(tx->outputs[i].script);
+    put_compact_size(o, sl == SHIM_TAL_FOREIGN ? 0 : sl);
+    if (sl != SHIM_TAL_FOREIGN) o.append((const char *)tx->outputs[i].script, sl);
+  }
+  for (int b = 0; b < 4; b++) o.push_back((char)(tx->locktime >> (8 * b)));
+  return hex((const u8 *)o.data(), o.size());
+}
+static std::string fmt_pubkey_(const struct pubkey *key) {
+  u8 der[PUBKEY_CMPR_LEN];
+  pubkey_to_der(der, key);
+  return hex(der, sizeof der);
+}
+static const char *dup(const tal_t *ctx, const std::string &s);
+extern "C" const char *check_commit_sigs(const tal_t *ctx, uint64_t local_index, const struct bitcoin_tx *const *txs, const u8 *funding_wscript,
+                                         const struct pubkey *remote_funding, const struct bitcoin_signature *commit_sig, const u8 *const *htlc_wscripts,
+                                         const struct pubkey *remote_htlckey, const struct bitcoin_signature *htlc_sigs, uint32_t feerate,
+                                         const char *commit_warning_tail) {
+  const size_t txs_bytes = shim_tal_bytelen(txs), sigs_bytes = shim_tal_bytelen(htlc_sigs), fw_len = shim_tal_bytelen(funding_wscript);
+  if (txs_bytes == SHIM_TAL_FOREIGN || sigs_bytes == SHIM_TAL_FOREIGN || fw_len == SHIM_TAL_FOREIGN || txs_bytes < sizeof(void *))
+    return dup(ctx, "engine error: check_commit_sigs: txs / htlc_sigs / funding_wscript is not a tal array");
+  const size_t n_txs = txs_bytes / sizeof(void *), n_sigs = sigs_bytes / sizeof(struct bitcoin_signature);
+  if (!g_ctx && !lamd_shim_setup()) return dup(ctx, "engine error: " + g_err);
+  // every signature the reference's loop could reach goes into ONE device call: the commitment signature and, when the count is the expected
+  // one, the HTLC signatures (with another count the reference warns before it looks at any of them, :2203-2206)
+  const size_t n_htlc = n_sigs == n_txs - 1 ? n_sigs : 0;
+  std::vector<std::string> ins(1 + n_htlc), outs(1 + n_htlc);
+  std::vector<lamd_tx_template> tm(1 + n_htlc);
+  std::vector<u8> sigs64(64 * (n_htlc ? n_htlc : 1)), types(n_htlc ? n_htlc : 1);
+  for (size_t i = 0; i < 1 + n_htlc; i++) {
+    const struct bitcoin_tx *tx = txs[i];
+    if (tx->num_inputs < 1) abort();  // assert(input_num < tx->wtx->num_inputs), bitcoin/signature.c:213
+    if (!flatten_tx(tx, ins[i], outs[i])) return dup(ctx, "engine error: " + g_err);
+    const u8 *ws = i ? htlc_wscripts[i - 1] : funding_wscript;
+    const size_t wl = shim_tal_bytelen(ws);
+    if (wl == SHIM_TAL_FOREIGN) return dup(ctx, "engine error: check_commit_sigs: a witness script is not a tal array");
+    lamd_tx_template &t = tm[i];
+    t.version = tx->version; t.locktime = tx->locktime;
+    t.inputs40 = (const u8 *)ins[i].data(); t.n_inputs = (uint32_t)tx->num_inputs; t.input_num = 0; t.amount_sat = tx->inputs[0].amount_sat;
+    t.outputs = (const u8 *)outs[i].data(); t.outputs_len = outs[i].size(); t.n_outputs = (uint32_t)tx->num_outputs;
+    t.script = ws; t.script_len = wl;
+    if (i) {
+      memcpy(&sigs64[64 * (i - 1)], htlc_sigs[i - 1].s.data, 64);
+      types[i - 1] = (u8)htlc_sigs[i - 1].sighash_type;
+    }
+  }
+  u8 fund33[PUBKEY_CMPR_LEN], htlc33[PUBKEY_CMPR_LEN];
+  pubkey_to_der(fund33, remote_funding);
+  pubkey_to_der(htlc33, remote_htlckey);
+  int64_t first_bad = 0;
+  const int rc = lamd_check_commitment_signed(g_ctx, &tm[0], fund33, commit_sig->s.data, (u8)commit_sig->sighash_type, n_htlc, n_htlc ? &tm[1] : nullptr, htlc33,
+                                              sigs64.data(), types.data(), &first_bad, nullptr);
+  if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return dup(ctx, "engine error: " + g_err); }
+  if (first_bad == 0)  // :2171-2193
+    return dup(ctx, "Bad commit_sig signature " + std::to_string(local_index) + " " + fmt_bitcoin_signature_(commit_sig) + " for tx " + fmt_bitcoin_tx_(txs[0]) +
+                        " wscript " + hex(funding_wscript, fw_len) + " key " + fmt_pubkey_(remote_funding) + " feerate " + std::to_string(feerate) +
+                        (commit_warning_tail ? commit_warning_tail : ""));
+  if (n_sigs != n_txs - 1)  // :2203-2206
+    return dup(ctx, "Expected " + std::to_string(n_txs - 1) + " htlc sigs, not " + std::to_string(n_sigs));
+  if (first_bad > 0) {  // :2224-2231
+    const size_t i = (size_t)first_bad - 1;
+    return dup(ctx, "Bad commit_sig signature " + fmt_bitcoin_signature_(&htlc_sigs[i]) + " for htlc " + fmt_bitcoin_tx_(txs[1 + i]) + " wscript " +
+                        hex(htlc_wscripts[i], shim_tal_bytelen(htlc_wscripts[i])) + " key " + fmt_pubkey_(remote_htlckey));
+  }
+  return nullptr;
 }
 
 // ---- BOLT #12: the fields are re-serialised (towire of type, length, value: bolt12_merkle.c:33-40) and hashed on the device
@@ -330,7 +425,7 @@ extern "C" bool bolt12_check_signature(const struct tlv_field *fields, const cha
   return ok != 0;
 }
 
-extern "C" int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *, secp256k1_ecdsa_recoverable_signature *sig,
+extern "C" int lamd_secp256k1_ecdsa_recoverable_signature_parse_compact(const void *, secp256k1_ecdsa_recoverable_signature *sig,
                                                                     const unsigned char *input64, int recid) {
   if (recid < 0 || recid > 3 || !below_n(input64) || !below_n(input64 + 32)) {
     memset(sig->data, 0, sizeof(sig->data));
@@ -340,7 +435,7 @@ extern "C" int secp256k1_ecdsa_recoverable_signature_parse_compact(const void *,
   sig->data[64] = (unsigned char)recid;
   return 1;
 }
-extern "C" int secp256k1_ecdsa_recover(const void *, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
+extern "C" int lamd_secp256k1_ecdsa_recover(const void *, secp256k1_pubkey *pubkey, const secp256k1_ecdsa_recoverable_signature *sig,
                                        const unsigned char *msghash32) {
   memset(pubkey->data, 0, sizeof(pubkey->data));
   if (!g_ctx && !lamd_shim_setup()) return 0;
@@ -351,13 +446,13 @@ extern "C" int secp256k1_ecdsa_recover(const void *, secp256k1_pubkey *pubkey, c
   return parse_key(key33, 33, pubkey) ? 1 : 0;
 }
 // common/bolt11.c:1026-1027: drops the recovery id (upstream returns 1 unconditionally)
-extern "C" int secp256k1_ecdsa_recoverable_signature_convert(const void *, secp256k1_ecdsa_signature *sig,
+extern "C" int lamd_secp256k1_ecdsa_recoverable_signature_convert(const void *, secp256k1_ecdsa_signature *sig,
                                                               const secp256k1_ecdsa_recoverable_signature *sigin) {
   memcpy(sig->data, sigin->data, 64);
   return 1;
 }
 // common/bolt11.c:1055, lightningd/dual_open_control.c:2254, bitcoin/signature.c:188: the library call itself
-extern "C" int secp256k1_ecdsa_verify(const void *, const secp256k1_ecdsa_signature *sig, const unsigned char *msghash32,
+extern "C" int lamd_secp256k1_ecdsa_verify(const void *, const secp256k1_ecdsa_signature *sig, const unsigned char *msghash32,
                                       const secp256k1_pubkey *pubkey) {
   struct sha256_double h;
   memcpy(h.sha.u.u8, msghash32, 32);
@@ -420,48 +515,75 @@ static const char *dup(const tal_t *ctx, const std::string &s) { return tal_strd
 #else
 static const char *dup(const tal_t *ctx, const std::string &s) { return (const char *)shim_tal_dup(ctx, (const u8 *)s.c_str(), s.size() + 1); }
 #endif
-static std::string bad(const char *what, const secp256k1_ecdsa_signature *sig, const u8 *msg, size_t len, size_t off, const char *kind) {
-  struct sha256_double h;
-  sha256_double(&h, msg + (off < len ? off : len), off < len ? len - off : 0);
-  return std::string(what) + " " + der_hex(sig) + " hash " + hex(h.sha.u.u8, 32) + " on " + kind + " " + hex(msg, len);
-}
-// runs the raw message through the device path; the typed arguments (already parsed by the caller, as in the
-// reference) are what the error string prints
-static int device_verdict(const u8 *msg, size_t len, const struct node_id *id) {
+// gossipd/sigcheck.c:9-164 decides on its ARGUMENTS: the hash of the message tail, then check_signed_hash_nodeid(hash, sig_i, id_i) /
+// check_signed_hash(hash, sig_i, key_i) in order with an early return.  It never parses the message and never calls it malformed.  So does
+// this: SHA256d of the tail on the host, the rows (hash, PASSED signature, PASSED key) through ONE launch of the latency path, the first
+// row that fails names the string.  Keys travel in their 33-byte form (a struct pubkey is serialised as pubkey_to_der() does; the device
+// decompresses it -- for every struct pubkey a parser produced that is the same point), so a channel_announcement is one 4-row call.
+// -2: engine error (fails closed: a non-NULL string), -1: every row verifies, else the index of the first row that does not.
+static int first_bad_row(const struct sha256_double *hash, int n, const secp256k1_ecdsa_signature *const *sigs, const u8 (*keys33)[PUBKEY_CMPR_LEN]) {
   if (!g_ctx && !lamd_shim_setup()) return -2;
-  const uint64_t off[2] = {0, len};
-  int8_t v = -2;
-  const int rc = lamd_sigcheck_gossip_batch(g_ctx, 1, msg, off, id ? id->k : nullptr, &v);
+  u8 hs[4 * 32], sg[4 * 64], ok[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; i++) {
+    memcpy(hs + 32 * i, hash->sha.u.u8, 32);
+    memcpy(sg + 64 * i, sigs[i]->data, 64);
+  }
+  const int rc = lamd_verify_ecdsa_batch(g_ctx, (size_t)n, hs, sg, &keys33[0][0], PUBKEY_CMPR_LEN, PUBKEY_CMPR_LEN, ok);
   if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return -2; }
-  return v;
+  for (int i = 0; i < n; i++)
+    if (!ok[i]) return i;
+  return -1;
+}
+static std::string bad(const char *what, const secp256k1_ecdsa_signature *sig, const struct sha256_double *h, const u8 *msg, size_t len, const char *kind) {
+  return std::string(what) + " " + der_hex(sig) + " hash " + hex(h->sha.u.u8, 32) + " on " + kind + " " + hex(msg, len);
+}
+// the reference hashes tal_count(msg) - offset bytes and would run off the end of a message shorter than its offset (its callers have parsed the
+// message before, so that cannot happen there); here such a tail is empty
+static void tail_hash(struct sha256_double *h, const u8 *msg, size_t len, size_t offset) {
+  sha256_double(h, msg + (offset < len ? offset : len), offset < len ? len - offset : 0);
 }
 extern "C" const char *sigcheck_channel_update_len(const tal_t *ctx, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
                                                    const u8 *update, size_t len) {
-  const int v = device_verdict(update, len, node_id);
-  if (v == 0) return nullptr;
+  struct sha256_double hash;
+  tail_hash(&hash, update, len, 66);  // 2 byte msg type + 64 byte signature (sigcheck.c:29-33)
+  const secp256k1_ecdsa_signature *sigs[1] = {node_sig};
+  u8 keys[1][PUBKEY_CMPR_LEN];
+  memcpy(keys[0], node_id->k, PUBKEY_CMPR_LEN);
+  const int v = first_bad_row(&hash, 1, sigs, keys);
+  if (v == -1) return nullptr;
   if (v == -2) return dup(ctx, "engine error: " + g_err);
-  if (v == -1) return dup(ctx, std::string("malformed channel_update ") + hex(update, len));  // fromwire_* would have failed earlier
-  return dup(ctx, bad("Bad signature for", node_sig, update, len, 66, "channel_update"));
+  return dup(ctx, bad("Bad signature for", node_sig, &hash, update, len, "channel_update"));
 }
-extern "C" const char *sigcheck_channel_announcement_len(const tal_t *ctx, const struct node_id *, const struct node_id *, const struct pubkey *,
-                                                         const struct pubkey *, const secp256k1_ecdsa_signature *node1_sig,
-                                                         const secp256k1_ecdsa_signature *node2_sig, const secp256k1_ecdsa_signature *bitcoin1_sig,
-                                                         const secp256k1_ecdsa_signature *bitcoin2_sig, const u8 *announcement, size_t len) {
-  const int v = device_verdict(announcement, len, nullptr);
-  if (v == 0) return nullptr;
-  if (v == -2) return dup(ctx, "engine error: " + g_err);
-  if (v == -1) return dup(ctx, std::string("malformed channel_announcement ") + hex(announcement, len));  // fromwire_* would have failed earlier
-  static const char *names[4] = {"Bad node_signature_1", "Bad node_signature_2", "Bad bitcoin_signature_1", "Bad bitcoin_signature_2"};
+extern "C" const char *sigcheck_channel_announcement_len(const tal_t *ctx, const struct node_id *node1_id, const struct node_id *node2_id,
+                                                         const struct pubkey *bitcoin1_key, const struct pubkey *bitcoin2_key,
+                                                         const secp256k1_ecdsa_signature *node1_sig, const secp256k1_ecdsa_signature *node2_sig,
+                                                         const secp256k1_ecdsa_signature *bitcoin1_sig, const secp256k1_ecdsa_signature *bitcoin2_sig,
+                                                         const u8 *announcement, size_t len) {
+  struct sha256_double hash;
+  tail_hash(&hash, announcement, len, 258);  // 2 byte msg type + 256 byte signatures (sigcheck.c:71-76)
   const secp256k1_ecdsa_signature *sigs[4] = {node1_sig, node2_sig, bitcoin1_sig, bitcoin2_sig};
-  return dup(ctx, bad(names[v - 1], sigs[v - 1], announcement, len, 258, "channel_announcement"));
-}
-extern "C" const char *sigcheck_node_announcement_len(const tal_t *ctx, const struct node_id *, const secp256k1_ecdsa_signature *node_sig,
-                                                      const u8 *node_announcement, size_t len) {
-  const int v = device_verdict(node_announcement, len, nullptr);
-  if (v == 0) return nullptr;
+  u8 keys[4][PUBKEY_CMPR_LEN];
+  memcpy(keys[0], node1_id->k, PUBKEY_CMPR_LEN);     // :78  check_signed_hash_nodeid(&hash, node1_sig, node1_id)
+  memcpy(keys[1], node2_id->k, PUBKEY_CMPR_LEN);     // :87
+  pubkey_to_der(keys[2], bitcoin1_key);              // :96  check_signed_hash(&hash, bitcoin1_sig, bitcoin1_key)
+  pubkey_to_der(keys[3], bitcoin2_key);              // :105
+  const int v = first_bad_row(&hash, 4, sigs, keys);
+  if (v == -1) return nullptr;
   if (v == -2) return dup(ctx, "engine error: " + g_err);
-  if (v == -1) return dup(ctx, std::string("malformed node_announcement ") + hex(node_announcement, len));
-  return dup(ctx, bad("Bad signature for", node_sig, node_announcement, len, 66, "node_announcement"));
+  static const char *names[4] = {"Bad node_signature_1", "Bad node_signature_2", "Bad bitcoin_signature_1", "Bad bitcoin_signature_2"};
+  return dup(ctx, bad(names[v], sigs[v], &hash, announcement, len, "channel_announcement"));
+}
+extern "C" const char *sigcheck_node_announcement_len(const tal_t *ctx, const struct node_id *node_id, const secp256k1_ecdsa_signature *node_sig,
+                                                      const u8 *node_announcement, size_t len) {
+  struct sha256_double hash;
+  tail_hash(&hash, node_announcement, len, 66);  // sigcheck.c:136-141
+  const secp256k1_ecdsa_signature *sigs[1] = {node_sig};
+  u8 keys[1][PUBKEY_CMPR_LEN];
+  memcpy(keys[0], node_id->k, PUBKEY_CMPR_LEN);  // "If node_id is invalid, it fails here" (:142): the device's key parse decides
+  const int v = first_bad_row(&hash, 1, sigs, keys);
+  if (v == -1) return nullptr;
+  if (v == -2) return dup(ctx, "engine error: " + g_err);
+  return dup(ctx, bad("Bad signature for", node_sig, &hash, node_announcement, len, "node_announcement"));
 }
 // ---- the reference's own prototypes (gossipd/sigcheck.h:7-28): the message is a tal array, its length travels with the pointer
 // (tal_count(msg), gossipd/sigcheck.c:30-33,73-76,138-141).  A pointer whose length cannot be read fails closed.

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__res
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t row = rowbase[i];
-  malformed[i] = gossip_expand_one(msgs + off[i], off[i + 1] - off[i], node_ids + 33 * i, rowbase[i + 1] - row, hash32 + 32 * row, sig64 + 64 * row, pub33 + 33 * row);
+  malformed[i] = gossip_expand_one(msgs + off[i], off[i + 1] - off[i], node_ids ? node_ids + 33 * i : nullptr, rowbase[i + 1] - row, hash32 + 32 * row, sig64 + 64 * row, pub33 + 33 * row);
 }
 
 __global__ void __launch_bounds__(256) k_gossip_reduce(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
@@ -1051,6 +1051,7 @@ struct small_args {
   u32 *done;                     // device memory: blocks finished (grids of more than one block)
   u32 *flag;                     // ... and the completion word (set to `ticket` last)
   u32 ticket;
+  const u8 *gate;                // optional, device memory: row i verifies only if gate[i] != 0 (check_tx_sig's sighash-type gate, decided by the hashing kernel in front)
 };
 __device__ __forceinline__ void small_store(small_part *p, const gej &g) {
 #pragma unroll
@@ -1185,6 +1186,7 @@ __global__ void __launch_bounds__(512) k_small_verify(small_args A) {
       load_words_be(rw, A.sig64 + 64 * row);
       ok = A.mode == MODE_ECDSA ? ecdsa_final(R, rw) : schnorr_accept_one(R, rw);
     }
+    if (A.gate) ok &= A.gate[row] != 0;
     A.out[row] = ok ? 1 : 0;
   }
   __syncthreads();
@@ -1247,6 +1249,8 @@ struct lamd_ctx {
   devbuf list7, list10, listcold, listcold_ok;
   // latency path (k_small_verify): pinned, device-mapped staging for up to SMALL_MAX rows, the verdict bytes and the completion word
   u8 *h_small = nullptr;
+  u8 *h_tmpl = nullptr;       // pinned, device-mapped: the transaction templates of a lamd_check_commitment_signed call (read by k_txsig_tx_hash)
+  size_t h_tmpl_cap = 0;
   devbuf small_done;          // block counter of k_small_verify grids (device memory)
   std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, direct-mapped)
   u32 prio_mask = LAMD_PRIO_DEFAULT; // LAMD_PRIO: which kernel classes raise their wave priority (g_prio)
@@ -1737,6 +1741,7 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
   }
   if (ctx->h_plan) (void)hipHostFree(ctx->h_plan);
   if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+  if (ctx->h_tmpl) (void)hipHostFree(ctx->h_tmpl);
   if (ctx->stream_lo) { (void)hipStreamSynchronize(ctx->stream_lo); (void)hipStreamDestroy(ctx->stream_lo); }
   for (hipEvent_t e : {ctx->ev_lo_go, ctx->ev_lo_done})
     if (e) (void)hipEventDestroy(e);
@@ -2517,7 +2522,10 @@ static void small_forget(lamd_ctx *ctx, lamd_ctx *dst, const u8 *key, size_t key
     }
   }
 }
-static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok) {
+// d_a32 / d_gate (optional, device memory): the rows' hashes were produced on the device by a kernel queued in front on ctx->stream (`a` is not
+// read then) / the gate that kernel decided (check_tx_sig's sighash-type rule)
+static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *sig, const u8 *key, int keylen, size_t keystride, u8 *ok,
+                     const u8 *d_a32 = nullptr, const u8 *d_gate = nullptr) {
   int rc;
   if (!ctx->h_small) {
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_small, SMALL_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
@@ -2543,7 +2551,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
       return 1;
     }
   }
-  memcpy(h, a, n * 32);
+  if (!d_a32) memcpy(h, a, n * 32);
   memcpy(h + SMALL_OFF_SIG, sig, n * 64);
   if (keystride == (size_t)keylen) memcpy(h + SMALL_OFF_KEY, key, n * keylen);
   else
@@ -2554,7 +2562,8 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
   memset(h + SMALL_OFF_SHAPES, 0xEE, n);
   small_args A;
   memset(&A, 0, sizeof A);
-  A.a32 = h; A.sig64 = h + SMALL_OFF_SIG; A.key = h + SMALL_OFF_KEY;
+  A.a32 = d_a32 ? d_a32 : h; A.sig64 = h + SMALL_OFF_SIG; A.key = h + SMALL_OFF_KEY;
+  A.gate = d_gate;
   A.keylen = keylen; A.mode = mode; A.n = (u32)n;
   A.seed = ctx->hash_seed;
   if (ctx->cache_mode != 0 && ctx->cache_store.shared) {
@@ -2826,6 +2835,65 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
   return lamd_synchronize(ctx);
 }
 
+// ---- check_tx_sig from transaction templates: the templates of a call as ONE staging blob (fixed-width columns first, 16-byte aligned, then the
+// three byte strings; offsets relative to the call's first row) and the hashing kernel over it
+struct txsig_blob {
+  std::vector<u8> st;
+  size_t o_inoff, o_outoff, o_scoff, o_amt, o_ver, o_lock, o_inum, o_nout, o_type, o_wit, o_in, o_out, o_sc, total;
+};
+static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
+                       const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs, const uint64_t *out_off, const uint32_t *n_outputs,
+                       const uint8_t *scripts, const uint64_t *script_off, const uint8_t *sighash_type, const uint8_t *has_witness) {
+  const size_t nin = (size_t)(in_off[n] - in_off[0]), nout_b = (size_t)(out_off[n] - out_off[0]), nsc = (size_t)(script_off[n] - script_off[0]);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+  B.o_inoff = take((n + 1) * 8); B.o_outoff = take((n + 1) * 8); B.o_scoff = take((n + 1) * 8); B.o_amt = take(n * 8); B.o_ver = take(n * 4);
+  B.o_lock = take(n * 4); B.o_inum = take(n * 4); B.o_nout = take(n * 4); B.o_type = take(n); B.o_wit = take(n); B.o_in = take(nin * 40 + 16);
+  B.o_out = take(nout_b + 16); B.o_sc = take(nsc + 16); B.total = o;
+  B.st.assign(B.total, 0);
+  std::vector<u8> &st = B.st;
+  auto rel = [&](size_t at, const uint64_t *src) { for (size_t i = 0; i <= n; i++) ((u64 *)&st[at])[i] = src[i] - src[0]; };
+  rel(B.o_inoff, in_off); rel(B.o_outoff, out_off); rel(B.o_scoff, script_off);
+  memcpy(&st[B.o_amt], amount_sat, n * 8); memcpy(&st[B.o_ver], version, n * 4); memcpy(&st[B.o_lock], locktime, n * 4);
+  memcpy(&st[B.o_inum], input_num, n * 4); memcpy(&st[B.o_nout], n_outputs, n * 4); memcpy(&st[B.o_type], sighash_type, n); memcpy(&st[B.o_wit], has_witness, n);
+  memcpy(&st[B.o_in], inputs40 + 40 * in_off[0], nin * 40); memcpy(&st[B.o_out], outputs + out_off[0], nout_b); memcpy(&st[B.o_sc], scripts + script_off[0], nsc);
+}
+// BIP143 hash + gate of every row of the blob at `d` (device memory, or pinned device-mapped host memory) -> d_hash32, d_gate
+static int txsig_hash_launch(lamd_ctx *ctx, size_t n, const txsig_blob &B, const u8 *d, u8 *d_hash32, u8 *d_gate) {
+  hipLaunchKernelGGL(k_txsig_tx_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)(d + B.o_ver), (const u32 *)(d + B.o_lock), d + B.o_in,
+                     (const u64 *)(d + B.o_inoff), (const u32 *)(d + B.o_inum), (const u64 *)(d + B.o_amt), d + B.o_out, (const u64 *)(d + B.o_outoff),
+                     (const u32 *)(d + B.o_nout), d + B.o_sc, (const u64 *)(d + B.o_scoff), d + B.o_type, d + B.o_wit, d_hash32, d_gate);
+  HIPCHK(ctx, hipGetLastError());
+  return LAMD_OK;
+}
+// the general path: templates to the device, BIP143 hashes there, the batch machinery, the gate, verdicts back
+static int txsig_tx_general(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
+                            const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs, const uint64_t *out_off, const uint32_t *n_outputs,
+                            const uint8_t *scripts, const uint64_t *script_off, const uint8_t *sighash_type, const uint8_t *has_witness, const uint8_t *sig64,
+                            const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok) {
+  int rc;
+  txsig_blob B;
+  txsig_pack(B, n, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type, has_witness);
+  if ((rc = ensure(ctx, &ctx->g_msgs, B.total)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->in_c, n * pubstride)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, B.st.data(), B.total, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = txsig_hash_launch(ctx, n, B, (const u8 *)ctx->g_msgs.p, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
+  rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
+                  (u8 *)ctx->out.p);
+  ctx->force_learn = false;
+  if (rc != LAMD_OK) return rc;
+  hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
+  return lamd_synchronize(ctx);  // (B.st is pageable: the runtime staged it before hipMemcpyAsync returned)
+}
+
 extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40,
                                           const uint64_t *in_off, const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs,
                                           const uint64_t *out_off, const uint32_t *n_outputs, const uint8_t *scripts, const uint64_t *script_off,
@@ -2855,41 +2923,86 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
     if (rc != 1) return rc;
     ctx->force_learn = true;
   }
-  // one staging blob: fixed-width columns first (8-byte aligned), then the three byte strings
-  const size_t nin = (size_t)(in_off[n] - in_off[0]), nout_b = (size_t)(out_off[n] - out_off[0]), nsc = (size_t)(script_off[n] - script_off[0]);
-  size_t o = 0;
-  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
-  const size_t o_inoff = take((n + 1) * 8), o_outoff = take((n + 1) * 8), o_scoff = take((n + 1) * 8), o_amt = take(n * 8), o_ver = take(n * 4),
-               o_lock = take(n * 4), o_inum = take(n * 4), o_nout = take(n * 4), o_type = take(n), o_wit = take(n), o_in = take(nin * 40 + 16),
-               o_out = take(nout_b + 16), o_sc = take(nsc + 16), total = o;
-  std::vector<u8> st(total, 0);
-  auto rel = [&](size_t at, const uint64_t *src) { for (size_t i = 0; i <= n; i++) ((u64 *)&st[at])[i] = src[i] - src[0]; };
-  rel(o_inoff, in_off); rel(o_outoff, out_off); rel(o_scoff, script_off);
-  memcpy(&st[o_amt], amount_sat, n * 8); memcpy(&st[o_ver], version, n * 4); memcpy(&st[o_lock], locktime, n * 4);
-  memcpy(&st[o_inum], input_num, n * 4); memcpy(&st[o_nout], n_outputs, n * 4); memcpy(&st[o_type], sighash_type, n); memcpy(&st[o_wit], has_witness, n);
-  memcpy(&st[o_in], inputs40 + 40 * in_off[0], nin * 40); memcpy(&st[o_out], outputs + out_off[0], nout_b); memcpy(&st[o_sc], scripts + script_off[0], nsc);
-  if ((rc = ensure(ctx, &ctx->g_msgs, total)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->in_b, n * 64)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->in_c, n * pubstride)) != LAMD_OK) return rc;
-  if ((rc = ensure(ctx, &ctx->out, n)) != LAMD_OK) return rc;
-  const u8 *d = (const u8 *)ctx->g_msgs.p;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, st.data(), total, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->in_b.p, sig64, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->in_c.p, pub, n * pubstride, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_txsig_tx_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)(d + o_ver), (const u32 *)(d + o_lock), d + o_in,
-                     (const u64 *)(d + o_inoff), (const u32 *)(d + o_inum), (const u64 *)(d + o_amt), d + o_out, (const u64 *)(d + o_outoff),
-                     (const u32 *)(d + o_nout), d + o_sc, (const u64 *)(d + o_scoff), d + o_type, d + o_wit, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p);
-  HIPCHK(ctx, hipGetLastError());
-  rc = run_device(ctx, MODE_ECDSA, n, (const u8 *)ctx->in_a.p, (const u8 *)ctx->in_b.p, (const u8 *)ctx->in_c.p, (int)publen, pubstride,
-                  (u8 *)ctx->out.p);
-  ctx->force_learn = false;
-  if (rc != LAMD_OK) return rc;
-  hipLaunchKernelGGL(k_apply_gate, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u8 *)ctx->g_malformed.p, (u8 *)ctx->out.p);
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(ok, ctx->out.p, n, hipMemcpyDeviceToHost, ctx->stream));
-  return lamd_synchronize(ctx);
+  return txsig_tx_general(ctx, n, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
+                          has_witness, sig64, pub, publen, pubstride, ok);
+}
+
+// ---- one commitment_signed as ONE call (channeld/channeld.c:2171-2232): include/lightning_amd.h
+extern "C" int lamd_check_commitment_signed(lamd_ctx *ctx, const lamd_tx_template *commit_tx, const uint8_t remote_funding33[33], const uint8_t commit_sig64[64],
+                                            uint8_t commit_sighash_type, size_t n_htlc, const lamd_tx_template *htlc_txs, const uint8_t remote_htlckey33[33],
+                                            const uint8_t *htlc_sigs64, const uint8_t *htlc_sighash_types, int64_t *first_bad, uint8_t *ok_rows) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!commit_tx || !remote_funding33 || !commit_sig64 || !first_bad || (n_htlc && (!htlc_txs || !remote_htlckey33 || !htlc_sigs64 || !htlc_sighash_types))) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  *first_bad = 0;  // fails closed: an error return never leaves "all good" behind
+  const size_t n = 1 + n_htlc;
+  // the 1 + N (transaction, input 0 .. , signature) rows in the reference's order: row 0 the commitment transaction under the funding key,
+  // row 1 + i HTLC transaction i under the htlc key
+  std::vector<uint32_t> version(n), locktime(n), input_num(n), n_outputs(n);
+  std::vector<uint64_t> in_off(n + 1), out_off(n + 1), sc_off(n + 1), amount(n);
+  std::vector<u8> type(n), wit(n, 1), sig(64 * n), pub(33 * n);
+  size_t nin = 0, nout = 0, nsc = 0;
+  for (size_t i = 0; i < n; i++) {
+    const lamd_tx_template *t = i ? &htlc_txs[i - 1] : commit_tx;
+    if ((t->n_inputs && !t->inputs40) || (t->outputs_len && !t->outputs) || (t->script_len && !t->script)) {
+      ctx->err = "bad argument: transaction template with a null array";
+      return LAMD_ERR_ARG;
+    }
+    in_off[i] = nin; out_off[i] = nout; sc_off[i] = nsc;
+    nin += t->n_inputs; nout += t->outputs_len; nsc += t->script_len;
+  }
+  in_off[n] = nin; out_off[n] = nout; sc_off[n] = nsc;
+  std::vector<u8> inputs(40 * nin + 1), outputs(nout + 1), scripts(nsc + 1);
+  for (size_t i = 0; i < n; i++) {
+    const lamd_tx_template *t = i ? &htlc_txs[i - 1] : commit_tx;
+    version[i] = t->version; locktime[i] = t->locktime; input_num[i] = t->input_num; n_outputs[i] = t->n_outputs; amount[i] = t->amount_sat;
+    if (t->n_inputs) memcpy(&inputs[40 * in_off[i]], t->inputs40, 40 * (size_t)t->n_inputs);
+    if (t->outputs_len) memcpy(&outputs[out_off[i]], t->outputs, t->outputs_len);
+    if (t->script_len) memcpy(&scripts[sc_off[i]], t->script, t->script_len);
+    type[i] = i ? htlc_sighash_types[i - 1] : commit_sighash_type;
+    memcpy(&sig[64 * i], i ? htlc_sigs64 + 64 * (i - 1) : commit_sig64, 64);
+    memcpy(&pub[33 * i], i ? remote_htlckey33 : remote_funding33, 33);
+  }
+  std::vector<u8> okv(n, 0);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
+  bool done = false;
+  if (small_path(ctx, n) && ctx->keyed_mode <= 0) {
+    // the latency path with the BIP143 hashes made ON THE DEVICE (hashing 1 + 483 templates on one host core costs several times the
+    // verification): the templates go into a pinned, device-mapped block, k_txsig_tx_hash reads them from there and leaves hashes and gate
+    // in device memory, k_small_verify -- queued right behind it -- takes them from there.  Two launches, no copy command.
+    txsig_blob B;
+    txsig_pack(B, n, version.data(), locktime.data(), inputs.data(), in_off.data(), input_num.data(), amount.data(), outputs.data(), out_off.data(),
+               n_outputs.data(), scripts.data(), sc_off.data(), type.data(), wit.data());
+    if (ctx->h_tmpl_cap < B.total) {
+      if (ctx->h_tmpl) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_tmpl); ctx->h_tmpl = nullptr; ctx->h_tmpl_cap = 0; }
+      const size_t want = B.total + B.total / 2 + 4096;
+      HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_tmpl, want, hipHostMallocMapped | hipHostMallocCoherent));
+      ctx->h_tmpl_cap = want;
+    }
+    if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+    memcpy(ctx->h_tmpl, B.st.data(), B.total);
+    if ((rc = txsig_hash_launch(ctx, n, B, ctx->h_tmpl, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
+    rc = run_small(ctx, MODE_ECDSA, n, nullptr, sig.data(), pub.data(), 33, 33, okv.data(), (const u8 *)ctx->in_a.p, (const u8 *)ctx->g_malformed.p);
+    if (rc == LAMD_OK) done = true;
+    else if (rc != 1) return rc;
+    else ctx->force_learn = true;  // a key the latency path met before without a table is back (the channel's htlc key): build and publish it below
+  }
+  if (!done) {
+    rc = txsig_tx_general(ctx, n, version.data(), locktime.data(), inputs.data(), in_off.data(), input_num.data(), amount.data(), outputs.data(), out_off.data(),
+                          n_outputs.data(), scripts.data(), sc_off.data(), type.data(), wit.data(), sig.data(), pub.data(), 33, 33, okv.data());
+    if (rc != LAMD_OK) return rc;
+  }
+  int64_t bad = -1;
+  for (size_t i = 0; i < n && bad < 0; i++)
+    if (!okv[i]) bad = (int64_t)i;  // 0: the commitment signature (:2171), 1 + i: htlc_sigs[i] (:2224) -- the first in the reference's order
+  *first_bad = bad;
+  if (ok_rows) memcpy(ok_rows, okv.data(), n);
+  return LAMD_OK;
 }
 
 // ---- BOLT #12 signatures: n independent bolt12_check_signature(fields, messagename, fieldname, key, sig) calls (common/bolt12.c:80-92)
@@ -3130,10 +3243,8 @@ extern "C" int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const 
   lamd_ctx *L;
   int rc = pick_lane(ctx, &L);
   if (rc != LAMD_OK) return rc;
-  if (!d_node_ids33) {  // the expand kernel never dereferences it without a channel_update, but keep the pointer valid
-    if ((rc = ensure(L, &L->g_ids, 64)) != LAMD_OK) { ctx->err = L->err; return rc; }
-    d_node_ids33 = L->g_ids.p;
-  }
+  // d_node_ids33 == NULL travels to the kernel as it is: a channel_update in such a batch gets verdict -1 (gossip_expand_one), nothing is
+  // read through a placeholder (the host-buffer call refuses the batch with LAMD_ERR_ARG; here the message types are only known on the device)
   rc = gossip_device(L, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, rows, (int8_t *)d_verdict);
   if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
   return rc;

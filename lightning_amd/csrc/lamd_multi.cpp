@@ -40,16 +40,38 @@ struct rccl_api {
   int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
+// "each GPU has its own pinned staging ring and stream".  The caller's rows are pageable; a device's host thread copies them
+// piece by piece into the device's ring of pinned slots and queues one asynchronous H2D per piece on the device's copy stream -- the thread
+// is filling slot k+1 while the copy engine drains slot k, and the engine's kernels wait for the copy stream on the device (lamd_wait_stream),
+// never the host.  (Rounds 1-4: hipMemcpy() straight from pageable memory -- the runtime stages such a copy through its own small bounce
+// buffers and the thread sleeps until the last byte has landed; LAMD_MULTI_PINNED=0 restores that.)
 struct eng_dev {
   int device = 0;
   lamd_ctx *ctx = nullptr;
   hipStream_t gstream = nullptr;  // the collective's stream on this device
   ncclComm_t comm = nullptr;
+  enum { SLOTS = 4 };
+  hipStream_t cstream = nullptr;  // H2D copies out of the staging ring
+  uint8_t *pin[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pin_ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+  bool pin_busy[SLOTS] = {false, false, false, false};
+  size_t pin_bytes = 0;           // per slot; 0: staging off (pageable hipMemcpy)
+  unsigned pin_next = 0;
+  bool copies_pending = false;    // the copy stream holds work the next verification has to wait for
 };
 struct eng_state {
   rccl_api nccl;
+  std::mutex err_mu;  // the per-device worker threads report failures side by side (a dead node fails every shard at once)
   std::string err;
   bool comms = false;
+  void fail(const std::string &what) {
+    std::lock_guard<std::mutex> lk(err_mu);
+    if (err.empty()) err = what; else if (err.find(what) == std::string::npos && err.size() < 1024) err += "; " + what;
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lk(err_mu);
+    err.clear();
+  }
 };
 
 int eng_open(void *user, int device, void **handle) {
@@ -58,16 +80,30 @@ int eng_open(void *user, int device, void **handle) {
   d->device = device;
   const int rc = lamd_init(&d->ctx, device);  // before the communicator: the lanes take their hardware queues first (lightning_amd.h, lamd_init)
   if (rc != LAMD_OK) {
-    st->err = std::string("lamd_init(device ") + std::to_string(device) + "): " + (d->ctx ? lamd_last_error(d->ctx) : "no device");
+    st->fail(std::string("lamd_init(device ") + std::to_string(device) + "): " + (d->ctx ? lamd_last_error(d->ctx) : "no device"));
     if (d->ctx) lamd_shutdown(d->ctx);
     delete d;
     return rc;
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->gstream, hipStreamNonBlocking) != hipSuccess) {
-    st->err = "hipStreamCreate failed";
+    st->fail("hipStreamCreate failed");
     lamd_shutdown(d->ctx);
     delete d;
     return LAMD_ERR_HIP;
+  }
+  size_t slot = 8u << 20;  // LAMD_MULTI_PINNED = bytes per staging slot (0: off)
+  if (const char *e = getenv("LAMD_MULTI_PINNED")) slot = (size_t)atoll(e);
+  if (slot) {
+    if (slot < (64u << 10)) slot = 64u << 10;
+    bool ok = hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < eng_dev::SLOTS && ok; k++)
+      ok = hipHostMalloc((void **)&d->pin[k], slot, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&d->pin_ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      st->fail("pinned staging ring: allocation failed (device " + std::to_string(device) + ")");
+      *handle = d;  // eng_close() releases what exists
+      return LAMD_ERR_NOMEM;
+    }
+    d->pin_bytes = slot;
   }
   *handle = d;
   return LAMD_OK;
@@ -76,6 +112,12 @@ void eng_close(void *, void *handle) {
   eng_dev *d = (eng_dev *)handle;
   if (!d) return;
   (void)hipSetDevice(d->device);
+  if (d->cstream) (void)hipStreamSynchronize(d->cstream);
+  for (int k = 0; k < eng_dev::SLOTS; k++) {
+    if (d->pin_ev[k]) (void)hipEventDestroy(d->pin_ev[k]);
+    if (d->pin[k]) (void)hipHostFree(d->pin[k]);
+  }
+  if (d->cstream) (void)hipStreamDestroy(d->cstream);
   if (d->gstream) (void)hipStreamDestroy(d->gstream);
   if (d->ctx) lamd_shutdown(d->ctx);
   delete d;
@@ -90,9 +132,30 @@ void eng_free(void *, void *handle, void *p) {
   (void)hipFree(p);
 }
 int eng_h2d(void *user, void *handle, void *dst, const void *src, size_t bytes) {
+  eng_dev *d = (eng_dev *)handle;
+  if (d->pin_bytes) {
+    if (hipSetDevice(d->device) != hipSuccess) { ((eng_state *)user)->fail("hipSetDevice failed"); return LAMD_ERR_HIP; }
+    for (size_t o = 0; o < bytes;) {
+      const unsigned k = d->pin_next++ % eng_dev::SLOTS;
+      const size_t c = bytes - o < d->pin_bytes ? bytes - o : d->pin_bytes;
+      bool ok = !d->pin_busy[k] || hipEventSynchronize(d->pin_ev[k]) == hipSuccess;  // the slot's previous copy has left it
+      if (ok) {
+        memcpy(d->pin[k], (const uint8_t *)src + o, c);
+        ok = hipMemcpyAsync((uint8_t *)dst + o, d->pin[k], c, hipMemcpyHostToDevice, d->cstream) == hipSuccess && hipEventRecord(d->pin_ev[k], d->cstream) == hipSuccess;
+      }
+      if (!ok) {
+        ((eng_state *)user)->fail("staged H2D failed (device " + std::to_string(d->device) + ")");
+        return LAMD_ERR_HIP;
+      }
+      d->pin_busy[k] = true;
+      d->copies_pending = true;
+      o += c;
+    }
+    return LAMD_OK;
+  }
   // synchronous: the caller's memory is pageable, the runtime stages it; the engine's (asynchronous) kernels of the chunk before run meanwhile
   if (hipSetDevice(((eng_dev *)handle)->device) != hipSuccess || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-    ((eng_state *)user)->err = "hipMemcpy H2D failed";
+    ((eng_state *)user)->fail("hipMemcpy H2D failed (device " + std::to_string(((eng_dev *)handle)->device) + ")");
     return LAMD_ERR_HIP;
   }
   return LAMD_OK;
@@ -101,22 +164,35 @@ int eng_d2h(void *user, void *handle, void *dst, const void *src, size_t bytes) 
   eng_dev *d = (eng_dev *)handle;
   if (hipSetDevice(d->device) != hipSuccess || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d->gstream) != hipSuccess ||
       hipStreamSynchronize(d->gstream) != hipSuccess) {
-    ((eng_state *)user)->err = "hipMemcpy D2H failed";
+    ((eng_state *)user)->fail("hipMemcpy D2H failed (device " + std::to_string(d->device) + ")");
     return LAMD_ERR_HIP;
   }
   return LAMD_OK;
 }
 int eng_fail(void *user, void *handle, int rc) {
-  if (rc != LAMD_OK) ((eng_state *)user)->err = lamd_last_error(((eng_dev *)handle)->ctx);
+  if (rc != LAMD_OK) ((eng_state *)user)->fail("device " + std::to_string(((eng_dev *)handle)->device) + ": " + lamd_last_error(((eng_dev *)handle)->ctx));
   return rc;
 }
+// the verification about to be submitted reads what the copy stream is still carrying: a device-side edge, the host does not wait
+int eng_join_copies(void *user, void *handle) {
+  eng_dev *d = (eng_dev *)handle;
+  if (!d->copies_pending) return LAMD_OK;
+  d->copies_pending = false;
+  return eng_fail(user, handle, lamd_wait_stream(d->ctx, d->cstream));
+}
 int eng_ecdsa(void *user, void *handle, size_t n, const void *h, const void *s, const void *p, size_t publen, size_t stride, void *ok) {
+  const int rc = eng_join_copies(user, handle);
+  if (rc != LAMD_OK) return rc;
   return eng_fail(user, handle, lamd_verify_ecdsa_batch_device(((eng_dev *)handle)->ctx, n, h, s, p, publen, stride, ok));
 }
 int eng_schnorr(void *user, void *handle, size_t n, const void *m, const void *x, const void *s, void *ok) {
+  const int rc = eng_join_copies(user, handle);
+  if (rc != LAMD_OK) return rc;
   return eng_fail(user, handle, lamd_verify_schnorr_batch_device(((eng_dev *)handle)->ctx, n, m, x, s, ok));
 }
 int eng_gossip(void *user, void *handle, size_t n, const void *msgs, const void *off, const void *ids, const void *rowbase, size_t rows, void *verdict) {
+  const int rc = eng_join_copies(user, handle);
+  if (rc != LAMD_OK) return rc;
   return eng_fail(user, handle, lamd_sigcheck_gossip_batch_device(((eng_dev *)handle)->ctx, n, msgs, off, ids, rowbase, rows, verdict));
 }
 int eng_gather_open(void *user, void **handles, int n) {
@@ -124,19 +200,19 @@ int eng_gather_open(void *user, void **handles, int n) {
   rccl_api &N = st->nccl;
   N.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!N.lib) N.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!N.lib) { st->err = std::string("dlopen(librccl.so): ") + dlerror(); return LAMD_ERR_HIP; }
+  if (!N.lib) { st->fail(std::string("dlopen(librccl.so): ") + dlerror()); return LAMD_ERR_HIP; }
   *(void **)&N.CommInitAll = dlsym(N.lib, "ncclCommInitAll");
   *(void **)&N.CommDestroy = dlsym(N.lib, "ncclCommDestroy");
   *(void **)&N.GroupStart = dlsym(N.lib, "ncclGroupStart");
   *(void **)&N.GroupEnd = dlsym(N.lib, "ncclGroupEnd");
   *(void **)&N.AllGather = dlsym(N.lib, "ncclAllGather");
   *(void **)&N.GetErrorString = dlsym(N.lib, "ncclGetErrorString");
-  if (!N.CommInitAll || !N.CommDestroy || !N.GroupStart || !N.GroupEnd || !N.AllGather) { st->err = "librccl.so lacks an entry point"; return LAMD_ERR_HIP; }
+  if (!N.CommInitAll || !N.CommDestroy || !N.GroupStart || !N.GroupEnd || !N.AllGather) { st->fail("librccl.so lacks an entry point"); return LAMD_ERR_HIP; }
   std::vector<int> devs(n);
   std::vector<ncclComm_t> comms(n);
   for (int i = 0; i < n; i++) devs[i] = ((eng_dev *)handles[i])->device;
   const int rc = N.CommInitAll(comms.data(), n, devs.data());
-  if (rc != 0) { st->err = std::string("ncclCommInitAll: ") + (N.GetErrorString ? N.GetErrorString(rc) : "error"); return LAMD_ERR_HIP; }
+  if (rc != 0) { st->fail(std::string("ncclCommInitAll: ") + (N.GetErrorString ? N.GetErrorString(rc) : "error")); return LAMD_ERR_HIP; }
   for (int i = 0; i < n; i++) ((eng_dev *)handles[i])->comm = comms[i];
   st->comms = true;
   return LAMD_OK;
@@ -147,7 +223,7 @@ int eng_all_gather(void *user, void **handles, int n, void **send, void **recv, 
   rccl_api &N = st->nccl;
   for (int i = 0; i < n; i++) {
     eng_dev *d = (eng_dev *)handles[i];
-    if (hipSetDevice(d->device) != hipSuccess) { st->err = "hipSetDevice failed"; return LAMD_ERR_HIP; }
+    if (hipSetDevice(d->device) != hipSuccess) { st->fail("hipSetDevice failed"); return LAMD_ERR_HIP; }
     const int rc = lamd_stream_wait_results(d->ctx, d->gstream);  // a device-side edge: the host does not wait for the kernels
     if (rc != LAMD_OK) return eng_fail(user, d, rc);
   }
@@ -158,21 +234,27 @@ int eng_all_gather(void *user, void **handles, int n, void **send, void **recv, 
     rc = N.AllGather(send[i], recv[i], bytes, 1 /* ncclUint8 */, d->comm, d->gstream);
   }
   const int rc2 = N.GroupEnd();
-  if (rc != 0 || rc2 != 0) { st->err = std::string("ncclAllGather: ") + (N.GetErrorString ? N.GetErrorString(rc ? rc : rc2) : "error"); return LAMD_ERR_HIP; }
+  if (rc != 0 || rc2 != 0) { st->fail(std::string("ncclAllGather: ") + (N.GetErrorString ? N.GetErrorString(rc ? rc : rc2) : "error")); return LAMD_ERR_HIP; }
   for (int i = 1; i < n; i++) {  // device 0's stream is drained by the D2H that follows; the others here, so that their buffers may be reused
     eng_dev *d = (eng_dev *)handles[i];
-    if (hipSetDevice(d->device) != hipSuccess || hipStreamSynchronize(d->gstream) != hipSuccess) { st->err = "hipStreamSynchronize failed"; return LAMD_ERR_HIP; }
+    if (hipSetDevice(d->device) != hipSuccess || hipStreamSynchronize(d->gstream) != hipSuccess) { st->fail("hipStreamSynchronize failed"); return LAMD_ERR_HIP; }
   }
   return LAMD_OK;
 }
 void eng_gather_close(void *user, void **handles, int n) {
   eng_state *st = (eng_state *)user;
-  if (st->comms)
+  // whatever communicators exist (an init that failed half-way leaves some), then the library itself
+  if (st->nccl.CommDestroy)
     for (int i = 0; i < n; i++)
-      if (handles[i] && ((eng_dev *)handles[i])->comm) (void)st->nccl.CommDestroy(((eng_dev *)handles[i])->comm);
+      if (handles[i] && ((eng_dev *)handles[i])->comm) {
+        (void)st->nccl.CommDestroy(((eng_dev *)handles[i])->comm);
+        ((eng_dev *)handles[i])->comm = nullptr;
+      }
   st->comms = false;
+  if (st->nccl.lib) (void)dlclose(st->nccl.lib);
+  st->nccl = rccl_api();
 }
-const char *eng_error(void *user) { return ((eng_state *)user)->err.c_str(); }
+const char *eng_error(void *user) { return ((eng_state *)user)->err.c_str(); }  // read on the calling thread, after every worker has been waited for
 void *eng_ctx(void *, void *handle) { return ((eng_dev *)handle)->ctx; }
 
 // ---------------------------------------------------------------- workers
@@ -259,6 +341,7 @@ extern "C" int lamd_shard_bounds(size_t n_groups, const uint32_t *group_rows, in
 
 static int multi_fail(lamd_multi *m, int rc, const char *what) {
   m->err = std::string(what) + ": " + (m->be.error ? m->be.error(m->be.user) : "error");
+  if (m->be.user == &m->eng) m->eng.clear();  // the next call starts with an empty report
   return rc;
 }
 static int ensure_buf(lamd_multi *m, int i, int which, size_t bytes) {
@@ -416,6 +499,10 @@ extern "C" int lamd_multi_sigcheck_gossip_batch(lamd_multi *m, size_t n, const u
   for (size_t i = 0; i < n; i++) {
     const uint64_t len = off[i + 1] - off[i];
     sigs[i] = (len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 0) ? 4u : 1u;
+    if (!node_ids33 && len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 2) {  // as lamd_sigcheck_gossip_batch refuses it
+      m->err = "channel_update in batch but node_ids33 is NULL";
+      return LAMD_ERR_ARG;
+    }
   }
   std::vector<size_t> bm(m->n + 1);
   lamd_shard_bounds(n, sigs.data(), m->n, bm.data(), nullptr);

@@ -1892,8 +1892,9 @@ LAMD_HD bool txsig_tx_hash_one(size_t i, const u32 *version, const u32 *locktime
 // host-side latency path of lamd_sigcheck_gossip_batch (a handful of messages: the rows go through k_small_verify).
 LAMD_HD bool gossip_expand_one(const u8 *m, size_t len, const u8 *node_id33, size_t nrows, u8 *hash32, u8 *sig64, u8 *pub33) {
   const gossip_frame fr = gossip_parse_frame(m, len);
-  bool bad = fr.bad;
   const u32 type = fr.type;
+  // a channel_update without a signer cannot be decided: the message is reported malformed (-1), nothing is read through the null pointer
+  bool bad = fr.bad | (type == GOSSIP_CUPD && node_id33 == nullptr);
   const size_t signed_off = fr.signed_off, keyoff = fr.keyoff;
   u8 h[32];
   if (!bad) sha256d_bytes(m + signed_off, len - signed_off, h);

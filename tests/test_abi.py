@@ -90,12 +90,19 @@ def test_mirror_header_is_installed_and_exported():
             "sigcheck_channel_announcement", "sigcheck_node_announcement", "signature_from_der", "pubkey_from_der",
             "fromwire_secp256k1_ecdsa_signature", "sha256_double", "bolt12_check_signature", "merkle_tlv", "sighash_from_merkle",
             "shim_tal_dup", "shim_tal_bytelen", "sigcheck_channel_update_len", "sigcheck_channel_announcement_len", "sigcheck_node_announcement_len",
-            "secp256k1_ecdsa_verify", "secp256k1_ecdsa_recoverable_signature_convert", "secp256k1_ecdsa_recoverable_signature_parse_compact",
-            "secp256k1_ecdsa_recover"]
+            "lamd_secp256k1_ecdsa_verify", "lamd_secp256k1_ecdsa_recoverable_signature_convert",
+            "lamd_secp256k1_ecdsa_recoverable_signature_parse_compact", "lamd_secp256k1_ecdsa_recover"]
     for n in want:
         assert re.search(r"\b%s\s*\(" % n, src), n
         assert hasattr(lib, n), n
     assert not hasattr(lib, "tal_bytelen")
+    # lightningd, libwally and bitcoin/signature.c link the real libsecp256k1, whose opaque types have another layout: the mirror must not
+    # define (and so interpose) any of that library's symbols, nor ccan's -- its libsecp-shaped entry points carry the lamd_ prefix
+    import subprocess
+    dyn = subprocess.check_output(["nm", "-D", "--defined-only", _build.build_shim()], text=True).split("\n")
+    exported = [ln.split()[-1] for ln in dyn if ln.strip()]
+    clash = [n for n in exported if n.startswith(("secp256k1_", "tal_", "wally_"))]
+    assert clash == [], clash
 
 
 def test_mirror_prototypes_equal_the_reference_headers_token_for_token(tmp_path):

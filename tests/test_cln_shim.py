@@ -68,7 +68,7 @@ def shim():
     for n in ("sigcheck_channel_update", "sigcheck_channel_announcement", "sigcheck_node_announcement", "sigcheck_channel_update_len",
               "sigcheck_channel_announcement_len", "sigcheck_node_announcement_len", "lamd_shim_last_error"):
         getattr(L, n).restype = ctypes.c_char_p  # leaks the shim_tal_dup()ed string; fine in a test
-    for n in ("secp256k1_ecdsa_verify", "secp256k1_ecdsa_recoverable_signature_convert"):
+    for n in ("lamd_secp256k1_ecdsa_verify", "lamd_secp256k1_ecdsa_recoverable_signature_convert"):
         getattr(L, n).restype = ctypes.c_int
     L.check_tx_sig_preimage.restype = ctypes.c_bool
     L.shim_tal_dup.restype = ctypes.c_void_p
@@ -127,6 +127,155 @@ def test_check_tx_sig_sighash_gate_needs_no_device(shim):
         assert shim.check_tx_sig_preimage(b"\x00" * 10, 10, wit, ctypes.byref(key), ctypes.byref(sig)) is False
         w = shim.shim_tal_dup(None, wit, len(wit)) if wit is not None else None
         assert shim.check_tx_sig(ctypes.byref(tx), 0, sub, w, ctypes.byref(key), ctypes.byref(sig)) is False
+
+
+def _cann_args(shim, m):
+    """what gossmap_manage.c:620-687 hands sigcheck_channel_announcement(): the fromwire_channel_announcement() fields of `m`"""
+    flen = int.from_bytes(m[258:260], "big")
+    koff = 260 + flen + 40
+    sigs = [Sig() for _ in range(4)]
+    for i in range(4):
+        assert shim.fromwire_secp256k1_ecdsa_signature(m[2 + 64 * i:66 + 64 * i], ctypes.byref(sigs[i]))
+    ids = [NodeId.from_buffer_copy(m[koff + 33 * i:koff + 33 * i + 33]) for i in range(2)]
+    keys = [Pubkey() for _ in range(2)]
+    for i in range(2):
+        assert shim.pubkey_from_der(m[koff + 66 + 33 * i:koff + 99 + 33 * i], 33, ctypes.byref(keys[i]))
+    return sigs, ids, keys
+
+
+def _nann_args(shim, m):
+    flen = int.from_bytes(m[66:68], "big")
+    sg = Sig()
+    assert shim.fromwire_secp256k1_ecdsa_signature(m[2:66], ctypes.byref(sg))
+    return sg, NodeId.from_buffer_copy(m[68 + flen + 4:68 + flen + 4 + 33])
+
+
+def _cann_call(shim, sigs, ids, keys, m):
+    return shim.sigcheck_channel_announcement_len(None, ctypes.byref(ids[0]), ctypes.byref(ids[1]), ctypes.byref(keys[0]), ctypes.byref(keys[1]),
+                                                  ctypes.byref(sigs[0]), ctypes.byref(sigs[1]), ctypes.byref(sigs[2]), ctypes.byref(sigs[3]), m, len(m))
+
+
+def _der_hex(sig64):
+    """fmt_secp256k1_ecdsa_signature (bitcoin/signature.c:325-335): hex of the DER serialisation"""
+    def enc(v):
+        v = v.lstrip(b"\x00") or b"\x00"
+        if v[0] & 0x80:
+            v = b"\x00" + v
+        return b"\x02" + bytes([len(v)]) + v
+    body = enc(sig64[:32]) + enc(sig64[32:])
+    return (b"\x30" + bytes([len(body)]) + body).hex().encode()
+
+
+@pytest.mark.gpu
+def test_sigcheck_verifies_its_arguments_not_the_message_bytes(shim, kat, orc):
+    """gossipd/sigcheck.c:35,78,87,96,105,144: the three functions hash the message tail and then decide check_signed_hash[_nodeid]() on the
+    signature and key ARGUMENTS, in order, first failure wins; they never parse the message and never call it malformed.  Every verdict below is
+    the C oracle's on (SHA256d(tail), passed signature, passed key), row by row in the reference's order."""
+    assert shim.lamd_shim_setup(), shim.lamd_shim_last_error()
+    names = [b"Bad node_signature_1", b"Bad node_signature_2", b"Bad bitcoin_signature_1", b"Bad bitcoin_signature_2"]
+    good = [H(v["msg"]) for v in kat["gossip"] if v["kind"] == "channel_announcement" and v["expect"] == 0 and v["name"].startswith(("ref-store", "cann/ok"))]
+    assert len(good) >= 8
+
+    def oracle_cann(sigs, ids, keys, m):
+        h = hashlib.sha256(hashlib.sha256(m[258:]).digest()).digest()
+        k33 = [bytes(ids[0].k), bytes(ids[1].k)]
+        for k in keys:
+            out = (ctypes.c_ubyte * 33)()
+            shim.pubkey_to_der(out, ctypes.byref(k))
+            k33.append(bytes(out))
+        for i in range(4):
+            if not orc.ecdsa_verify(h, bytes(sigs[i].data), k33[i]):
+                return i, h
+        return -1, h
+
+    def check(sigs, ids, keys, m):
+        err = _cann_call(shim, sigs, ids, keys, m)
+        bad, h = oracle_cann(sigs, ids, keys, m)
+        if bad < 0:
+            assert err is None, err
+        else:
+            want = names[bad] + b" " + _der_hex(bytes(sigs[bad].data)) + b" hash " + h.hex().encode() + b" on channel_announcement " + m.hex().encode()
+            assert err == want, (err, want)
+        return bad
+
+    a, b = good[0], good[1]
+    sa, ia, ka = _cann_args(shim, a)
+    sb, ib, kb = _cann_args(shim, b)
+    assert check(sa, ia, ka, a) == -1
+    # (a) one signature ARGUMENT swapped for another message's: the string names the position and prints the PASSED signature
+    for pos in range(4):
+        swapped = list(sa)
+        swapped[pos] = sb[pos]
+        assert check(swapped, ia, ka, a) == pos
+    # two bad arguments: the first in the reference's order is reported (early return)
+    assert check([sa[0], sb[1], sa[2], sb[3]], ia, ka, a) == 1
+    # a key argument that is not the message's
+    assert check(sa, [ia[0], ib[1]], ka, a) == 1
+    assert check(sa, ia, [kb[0], ka[1]], a) == 2
+    # (b) the signatures EMBEDDED in the message are garbage (not even in range: fromwire would have refused them), the arguments are
+    # good: NULL -- the function hashes msg + 258 and looks at nothing before it
+    garbled = a[:2] + b"\xff" * 256 + a[258:]
+    assert check(sa, ia, ka, garbled) == -1
+    # embedded keys are part of the signed tail: changing one changes the hash, every argument then fails from the first on
+    koff = 260 + int.from_bytes(a[258:260], "big") + 40
+    assert check(sa, ia, ka, a[:koff + 5] + bytes([a[koff + 5] ^ 1]) + a[koff + 6:]) == 0
+    # never "malformed": a truncated / over-long message is hashed as it stands
+    for m2 in (a[:300], a + b"\x00", a[:258]):
+        err = _cann_call(shim, sa, ia, ka, m2)
+        assert err is not None and err.startswith(b"Bad node_signature_1 ") and b"malformed" not in err
+        assert oracle_cann(sa, ia, ka, m2)[0] == 0
+    # an invalid node_id argument "fails here" (sigcheck.c:142, common/node_id.c:72-80)
+    assert check(sa, [NodeId.from_buffer_copy(b"\x05" + bytes(ia[0].k)[1:]), ia[1]], ka, a) == 0
+
+    # ---- channel_update: the signer is the node_id ARGUMENT, the signature the ARGUMENT
+    ups = [v for v in kat["gossip"] if v["kind"] == "channel_update" and v["expect"] == 0 and "node_id" in v]
+    u0, u1 = ups[0], ups[1]
+    m0, m1 = H(u0["msg"]), H(u1["msg"])
+    s0, s1 = Sig(), Sig()
+    assert shim.fromwire_secp256k1_ecdsa_signature(m0[2:66], ctypes.byref(s0)) and shim.fromwire_secp256k1_ecdsa_signature(m1[2:66], ctypes.byref(s1))
+    n0, n1 = NodeId.from_buffer_copy(H(u0["node_id"])), NodeId.from_buffer_copy(H(u1["node_id"]))
+    h0 = hashlib.sha256(hashlib.sha256(m0[66:]).digest()).digest()
+    for sg, nid, mm in ((s0, n0, m0), (s1, n0, m0), (s0, n1, m0), (s0, n0, m0[:2] + b"\xee" * 64 + m0[66:])):
+        err = shim.sigcheck_channel_update_len(None, ctypes.byref(nid), ctypes.byref(sg), mm, len(mm))
+        if orc.ecdsa_verify(h0, bytes(sg.data), bytes(nid.k)):
+            assert err is None
+        else:
+            assert err == b"Bad signature for " + _der_hex(bytes(sg.data)) + b" hash " + h0.hex().encode() + b" on channel_update " + mm.hex().encode()
+    assert shim.sigcheck_channel_update_len(None, ctypes.byref(n0), ctypes.byref(s0), m0[:2] + b"\xee" * 64 + m0[66:], len(m0)) is None
+    assert shim.sigcheck_channel_update_len(None, ctypes.byref(n0), ctypes.byref(s1), m0, len(m0)) is not None
+    assert u0["node_id"] == u1["node_id"] or shim.sigcheck_channel_update_len(None, ctypes.byref(n1), ctypes.byref(s0), m0, len(m0)) is not None
+
+    # ---- node_announcement
+    nn = [H(v["msg"]) for v in kat["gossip"] if v["kind"] == "node_announcement" and v["expect"] == 0][:2]
+    (g0, i0), (g1, i1) = _nann_args(shim, nn[0]), _nann_args(shim, nn[1])
+    hn = hashlib.sha256(hashlib.sha256(nn[0][66:]).digest()).digest()
+    for sg, nid, mm in ((g0, i0, nn[0]), (g1, i0, nn[0]), (g0, i1, nn[0]), (g0, i0, nn[0][:2] + bytes(64) + nn[0][66:])):
+        err = shim.sigcheck_node_announcement_len(None, ctypes.byref(nid), ctypes.byref(sg), mm, len(mm))
+        if orc.ecdsa_verify(hn, bytes(sg.data), bytes(nid.k)):
+            assert err is None
+        else:
+            assert err == b"Bad signature for " + _der_hex(bytes(sg.data)) + b" hash " + hn.hex().encode() + b" on node_announcement " + mm.hex().encode()
+    assert shim.sigcheck_node_announcement_len(None, ctypes.byref(i0), ctypes.byref(g0), nn[0][:2] + bytes(64) + nn[0][66:], len(nn[0])) is None
+
+
+@pytest.mark.gpu
+def test_sigcheck_arguments_from_c(kat, tmp_path):
+    """the same two properties from C through the reference's prototype (tests/c/run_sigcheck_arguments.c): (a) a valid message with the
+    node_signature_2 ARGUMENT taken from another message -> "Bad node_signature_2 <DER of the passed signature>"; (b) a message whose embedded
+    signatures are garbage with good arguments -> NULL"""
+    import subprocess
+    from lightning_amd import _build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _build.build_shim()
+    exe = tmp_path / "rsa"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), "-o", str(exe),
+                           os.path.join(root, "tests", "c", "run_sigcheck_arguments.c"), "-L" + os.path.join(root, "lightning_amd"),
+                           "-llightning_amd_cln", "-llightning_amd", "-Wl,-rpath," + os.path.join(root, "lightning_amd")])
+    good = [v["msg"] for v in kat["gossip"] if v["kind"] == "channel_announcement" and v["expect"] == 0 and v["name"].startswith(("ref-store", "cann/ok"))]
+    r = subprocess.run([str(exe), good[0], good[1]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    b = H(good[1])
+    assert "Bad node_signature_2 " + _der_hex(b[66:130]).decode() + " hash " in r.stdout
 
 
 @pytest.mark.gpu
@@ -247,8 +396,12 @@ def test_reference_unit_test_expectations(shim, kat):
     assert shim.sigcheck_channel_update(None, ctypes.byref(NodeId.from_buffer_copy(H(cu["node_id"]))), ctypes.byref(sg), tm) == err
     ok = next(v for v in kat["gossip"] if v["name"] == "nann/ok/0")
     m = H(ok["msg"])
-    assert shim.sigcheck_node_announcement_len(None, None, ctypes.byref(sg), m, len(m)) is None
-    assert shim.sigcheck_node_announcement(None, None, ctypes.byref(sg), ctypes.c_void_p(shim.shim_tal_dup(None, m, len(m)))) is None
+    nsg, nid = _nann_args(shim, m)
+    assert shim.sigcheck_node_announcement_len(None, ctypes.byref(nid), ctypes.byref(nsg), m, len(m)) is None
+    assert shim.sigcheck_node_announcement(None, ctypes.byref(nid), ctypes.byref(nsg), ctypes.c_void_p(shim.shim_tal_dup(None, m, len(m)))) is None
+    # the signature of ANOTHER message (the channel_update's) as the argument: the reference verifies what it is handed
+    err = shim.sigcheck_node_announcement_len(None, ctypes.byref(nid), ctypes.byref(sg), m, len(m))
+    assert err.startswith(b"Bad signature for 30") and b" on node_announcement 0101" in err
 
 
 @pytest.mark.gpu
@@ -289,15 +442,15 @@ def test_libsecp_names_of_the_bolt11_n_field_path(shim, kat):
         if not v["expect"] or not (v["name"].startswith("KAT-B11R") or v["name"].startswith("KAT-SIGNMSG")):
             continue
         rs, sg, pk = RecSig(), Sig(), Pubkey()
-        assert shim.secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"]) == 1
-        assert shim.secp256k1_ecdsa_recoverable_signature_convert(None, ctypes.byref(sg), ctypes.byref(rs)) == 1
+        assert shim.lamd_secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"]) == 1
+        assert shim.lamd_secp256k1_ecdsa_recoverable_signature_convert(None, ctypes.byref(sg), ctypes.byref(rs)) == 1
         assert bytes(sg.data) == H(v["sig"])
         assert shim.pubkey_from_der(H(v["expect"]), 33, ctypes.byref(pk))
         h = H(v["hash"])
         # secp256k1_ecdsa_verify accepts low-S signatures only (bitcoin/signature.c:185-187); recovery has no such rule
         low_s = int.from_bytes(H(v["sig"])[32:], "big") <= HALF_N
-        assert shim.secp256k1_ecdsa_verify(None, ctypes.byref(sg), h, ctypes.byref(pk)) == (1 if low_s else 0), v["name"]
-        assert shim.secp256k1_ecdsa_verify(None, ctypes.byref(sg), bytes([h[0] ^ 1]) + h[1:], ctypes.byref(pk)) == 0, v["name"]
+        assert shim.lamd_secp256k1_ecdsa_verify(None, ctypes.byref(sg), h, ctypes.byref(pk)) == (1 if low_s else 0), v["name"]
+        assert shim.lamd_secp256k1_ecdsa_verify(None, ctypes.byref(sg), bytes([h[0] ^ 1]) + h[1:], ctypes.byref(pk)) == 0, v["name"]
         n_checked += low_s
         if "/" not in v["name"].split("/", 1)[1]:          # the vector itself, not its other-parity / modified-message twin
             distinct.setdefault(bytes(pk.data), (sg, h, pk))
@@ -305,7 +458,7 @@ def test_libsecp_names_of_the_bolt11_n_field_path(shim, kat):
     ds = list(distinct.values())
     assert len(ds) >= 4
     for a, b in zip(ds, ds[1:]):      # under another vector's signer nothing verifies (both recovery ids of ONE signature do: those twins are skipped)
-        assert shim.secp256k1_ecdsa_verify(None, ctypes.byref(a[0]), a[1], ctypes.byref(b[2])) == 0
+        assert shim.lamd_secp256k1_ecdsa_verify(None, ctypes.byref(a[0]), a[1], ctypes.byref(b[2])) == 0
 
 
 @pytest.mark.gpu
@@ -319,12 +472,12 @@ def test_bolt11_recovery_through_libsecp_names(shim, kat):
     for v in kat["recover"]:
         if not v["name"].startswith("KAT-B11R/") and v["recid"] > 3:
             rs = RecSig()
-            assert shim.secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"]) == 0
+            assert shim.lamd_secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"]) == 0
             continue
         rs, pk, nid = RecSig(), Pubkey(), NodeId()
-        parsed = shim.secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"])
+        parsed = shim.lamd_secp256k1_ecdsa_recoverable_signature_parse_compact(None, ctypes.byref(rs), H(v["sig"]), v["recid"])
         got = None
-        if parsed and shim.secp256k1_ecdsa_recover(None, ctypes.byref(pk), ctypes.byref(rs), H(v["hash"])):
+        if parsed and shim.lamd_secp256k1_ecdsa_recover(None, ctypes.byref(pk), ctypes.byref(rs), H(v["hash"])):
             shim.node_id_from_pubkey(ctypes.byref(nid), ctypes.byref(pk))
             got = bytes(nid.k).hex()
         assert got == v["expect"], v["name"]
