@@ -31,6 +31,14 @@ int lamd_x2_debug(lamd_ctx *ctx, char *report, size_t cap); /* diagnostic: a^3 i
  * validity, 7 distinct-key affine words, 8 key tables) to host memory.  Tests only. */
 int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out);
 
+/* Measurement aid for bench.py's roofline block: the chip's sustained issue rate of the 32x32->64 multiply-add (v_mad_u64_u32 with an
+ * SGPR carry-out, dependency-free, eight accumulators per lane) at `waves_per_simd` (1..8) waves per SIMD over `launches` launches of at least
+ * min_ms each -- the ecmult kernel runs 3 waves per SIMD in launches of 3-4 ms, and a sub-millisecond micro-benchmark sees a boost clock such
+ * launches do not.  *lane_ops_per_s = lanes x multiply-adds / HIP-event time; *memtime_per_realtime = (s_memtime delta) / (s_memrealtime
+ * delta, 100 MHz) of one wave.  Computes nothing a verdict depends on. */
+int lamd_debug_mul32_peak(lamd_ctx *ctx, int waves_per_simd, double min_ms, int launches, double *lane_ops_per_s, double *avg_launch_ms,
+			  double *memtime_per_realtime);
+
 /* The static G table in device memory (11 windows x 2^24 affine entries): read by the test-traffic signer kernels of
  * liblightning_amd_testgen.so.  NULL without a context. */
 const void *lamd_debug_gtable(lamd_ctx *ctx);

@@ -66,6 +66,7 @@ SYMBOLS = {
     "lamd_inv_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_x2_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),
     "lamd_debug_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, c_sz, c_sz, c_u8p]),
+    "lamd_debug_mul32_peak": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 3),
     "lamd_debug_gtable": (ctypes.c_void_p, [ctypes.c_void_p]),
     "lamd_fuzz_field": (ctypes.c_int, [ctypes.c_void_p, c_sz, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, c_sz]),
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),

@@ -4044,6 +4044,68 @@ extern "C" int lamd_fuzz_field(lamd_ctx *ctx, size_t lanes, int iters, uint64_t 
 }
 
 // ---- diagnostic peek into the engine's device work buffers (tests / debugging only)
+// ---- the roofline's denominator, measured in the process that reports it (include/lightning_amd_debug.h lamd_debug_mul32_peak): a dependency-free
+// stream of v_mad_u64_u32 -- eight independent 64-bit accumulators per lane, the carry-out in an SGPR pair as the multiplier's columns have it --
+// on every SIMD of the chip at a given occupancy, long enough (>= min_ms per launch) for the clock governor to settle where the ecmult kernel's
+// launches (3-4 ms) run.  s_memtime / s_memrealtime deltas of one wave give the counter ratio next to it.
+#define LAMD_MAD8 "v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n\tv_mad_u64_u32 %1, s[20:21], %8, %9, %1\n\tv_mad_u64_u32 %2, s[20:21], %8, %9, %2\n\t" \
+                  "v_mad_u64_u32 %3, s[20:21], %8, %9, %3\n\tv_mad_u64_u32 %4, s[20:21], %8, %9, %4\n\tv_mad_u64_u32 %5, s[20:21], %8, %9, %5\n\t" \
+                  "v_mad_u64_u32 %6, s[20:21], %8, %9, %6\n\tv_mad_u64_u32 %7, s[20:21], %8, %9, %7\n\t"
+__global__ void __launch_bounds__(256) k_mul32_peak(u32 *__restrict__ out, u32 iters, u64 *__restrict__ clocks) {
+  const u32 x = threadIdx.x * 2654435761u + 12345u + blockIdx.x, y = x ^ 0x9E3779B9u;
+  u64 a0 = x, a1 = y, a2 = x + 1, a3 = y + 1, a4 = x + 2, a5 = y + 2, a6 = x + 3, a7 = y + 3;
+  const u64 c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+  for (u32 it = 0; it < iters; it++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      asm volatile(LAMD_MAD8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "s20", "s21");
+  }
+  const u64 c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = r1 - r0; }
+}
+extern "C" int lamd_debug_mul32_peak(lamd_ctx *ctx, int waves_per_simd, double min_ms, int launches, double *lane_ops_per_s, double *avg_launch_ms,
+                                     double *memtime_per_realtime) {
+  if (!ctx || waves_per_simd < 1 || waves_per_simd > 8 || launches < 1 || !lane_ops_per_s) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const unsigned blocks = (unsigned)ctx->prop.multiProcessorCount * (unsigned)waves_per_simd;  // 256 threads = one wave per SIMD of a CU
+  u32 *d_out = nullptr;
+  u64 *d_clk = nullptr;
+  HIPCHK(ctx, hipMalloc((void **)&d_out, (size_t)blocks * 256 * 4));
+  if (hipMalloc((void **)&d_clk, 16) != hipSuccess) { (void)hipFree(d_out); ctx->err = "hipMalloc failed"; return LAMD_ERR_NOMEM; }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = LAMD_OK;
+  auto run = [&](u32 iters, float *ms) -> bool {
+    if (hipEventRecord(e0, ctx->stream) != hipSuccess) return false;
+    hipLaunchKernelGGL(k_mul32_peak, dim3(blocks), dim3(256), 0, ctx->stream, d_out, iters, d_clk);
+    return hipEventRecord(e1, ctx->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(ms, e0, e1) == hipSuccess;
+  };
+  float ms = 0;
+  u32 iters = 2000;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || !run(200, &ms) || !run(iters, &ms)) rc = LAMD_ERR_HIP;
+  if (rc == LAMD_OK) {
+    if (ms > 0 && min_ms > ms) iters = (u32)((double)iters * min_ms / ms * 1.05) + 1;
+    double sum = 0, ratio = 0;
+    for (int l = 0; l < launches && rc == LAMD_OK; l++) {
+      if (!run(iters, &ms)) { rc = LAMD_ERR_HIP; break; }
+      sum += ms;
+      u64 clk[2] = {0, 0};
+      if (hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost) == hipSuccess && clk[1]) ratio += (double)clk[0] / (double)clk[1];
+    }
+    if (rc == LAMD_OK) {
+      const double avg = sum / launches;
+      *lane_ops_per_s = (double)blocks * 256.0 * (double)iters * 128.0 / (avg * 1e-3);
+      if (avg_launch_ms) *avg_launch_ms = avg;
+      if (memtime_per_realtime) *memtime_per_realtime = ratio / launches;
+    }
+  }
+  if (rc != LAMD_OK) ctx->err = "lamd_debug_mul32_peak: HIP error";
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_out);
+  (void)hipFree(d_clk);
+  return rc;
+}
 extern "C" const void *lamd_debug_gtable(lamd_ctx *ctx) { return ctx ? (const void *)ctx->gtable : nullptr; }
 extern "C" int lamd_debug_read(lamd_ctx *ctx, int which, size_t offset, size_t nbytes, void *out) {
   if (!ctx || !out) return LAMD_ERR_ARG;

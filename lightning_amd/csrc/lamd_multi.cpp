@@ -495,17 +495,21 @@ extern "C" int lamd_multi_sigcheck_gossip_batch(lamd_multi *m, size_t n, const u
   std::lock_guard<std::mutex> lk(m->call_mu);
   // signatures per message (4 for a channel_announcement, 1 otherwise: lamd_sigcheck_gossip_batch_device): shards are cut on MESSAGE boundaries
   // and balanced by signatures; the verdict vector that is gathered has one byte per message
-  std::vector<uint32_t> sigs(n);
+  // ... balanced by COST: a channel_announcement is four signatures, two of them under bitcoin keys that never recur and take the per-signature
+  // ladder (about twice a comb row) -- weight 6 against 1 (lightning_amd/sharding.py GOSSIP_WEIGHT_*; balanced by message count the first shard
+  // of a replay that starts with its announcements would carry a quarter of the job)
+  std::vector<uint32_t> sigs(n), wts(n);
   for (size_t i = 0; i < n; i++) {
     const uint64_t len = off[i + 1] - off[i];
     sigs[i] = (len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 0) ? 4u : 1u;
+    wts[i] = sigs[i] == 4u ? 6u : 1u;
     if (!node_ids33 && len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 2) {  // as lamd_sigcheck_gossip_batch refuses it
       m->err = "channel_update in batch but node_ids33 is NULL";
       return LAMD_ERR_ARG;
     }
   }
   std::vector<size_t> bm(m->n + 1);
-  lamd_shard_bounds(n, sigs.data(), m->n, bm.data(), nullptr);
+  lamd_shard_bounds(n, wts.data(), m->n, bm.data(), nullptr);
   auto job = [&](int i) -> int {
     const size_t lo = bm[i], cnt = bm[i + 1] - bm[i];
     if (!cnt) return LAMD_OK;

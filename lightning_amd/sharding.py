@@ -13,22 +13,47 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(n_rows, world, group_sizes=None):
+def shard_bounds(n_rows, world, group_sizes=None, weights=None):
     """-> int64 array b of world+1 row offsets; rank g owns rows [b[g], b[g+1]).
-    group_sizes: optional sequence summing to n_rows; cuts fall only between groups."""
-    if group_sizes is None:
+    group_sizes: optional sequence summing to n_rows; cuts fall only between groups.
+    weights: optional cost per group (per row when there are no groups); the cuts then balance the WEIGHT of the shards instead of their
+    row count -- a gossip replay is cut on message boundaries but balanced by what a message costs (a channel_announcement is four
+    signatures, two of them under bitcoin keys that never recur: GOSSIP_WEIGHT_*), or the strong-scaling time is the first shard's."""
+    if group_sizes is None and weights is None:
         return np.array([(n_rows * g) // world for g in range(world + 1)], dtype=np.int64)
+    if group_sizes is None:
+        group_sizes = np.ones(n_rows, dtype=np.int64)
     ends = np.cumsum(np.asarray(group_sizes, dtype=np.int64))
     if len(ends) == 0 or ends[-1] != n_rows:
         raise ValueError("group sizes do not add up to n_rows")
+    if weights is None:
+        wends, total = ends, n_rows
+    else:
+        wends = np.cumsum(np.asarray(weights, dtype=np.int64))
+        if len(wends) != len(ends):
+            raise ValueError("one weight per group")
+        total = int(wends[-1])
     b = [0]
     for g in range(1, world):
-        target = (n_rows * g) // world
-        j = int(np.searchsorted(ends, target, side="left"))  # first group end >= target
+        target = (total * g) // world
+        j = int(np.searchsorted(wends, target, side="left"))  # first group whose cumulative weight reaches the target
         cut = int(ends[j]) if j < len(ends) else n_rows
         b.append(max(cut, b[-1]))
     b.append(n_rows)
     return np.array(b, dtype=np.int64)
+
+
+# cost of one gossip message in units of one signature under a recurring key (node ids recur, bitcoin keys never do and take the per-signature
+# ladder: 124 against 240 M verifies/s, bench.py key_reuse_sweep): channel_announcement = 2 node signatures + 2 x 2; the others one signature
+GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER = 6, 1
+
+
+def gossip_weights(msgs, off):
+    """per-message shard weights of a packed gossip batch (type 256 = channel_announcement)"""
+    off = np.asarray(off, dtype=np.int64)
+    m = np.asarray(msgs)
+    is_cann = (m[off[:-1]] == 1) & (m[off[:-1] + 1] == 0)
+    return np.where(is_cann, GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER).astype(np.int64)
 
 
 def all_gather_verdicts(ok_local, bounds, rank, world):
@@ -49,13 +74,13 @@ def all_gather_verdicts(ok_local, bounds, rank, world):
     return torch.cat([out[g * m:g * m + sizes[g]] for g in range(world)]).view(dt)
 
 
-def run_sharded(n_verdicts, rank, world, verify_range, group_sizes=None):
+def run_sharded(n_verdicts, rank, world, verify_range, group_sizes=None, weights=None):
     """The north-star split of ONE global job over `world` ranks: rank g verifies verdict positions [b[g], b[g+1]) -- cut on group
     boundaries (a channel_announcement's four signatures, a commitment's 484) -- through `verify_range(lo, hi)` (-> 1-D uint8 / int8
     tensor of hi-lo verdicts on the rank's device: the engine on GPUs, a CPU checker in the gloo test), then every rank receives the
     whole verdict vector (ragged all-gather).  Returns (full_verdicts, bounds).  bench.py --gpus N runs BASELINE configs[3] and [4]
     through this function; tests/test_sharding_gloo.py runs the same function under gloo."""
-    b = shard_bounds(n_verdicts, world, group_sizes)
+    b = shard_bounds(n_verdicts, world, group_sizes, weights)
     lo, hi = int(b[rank]), int(b[rank + 1])
     local = verify_range(lo, hi)
     if local.numel() != hi - lo:
