@@ -1288,7 +1288,16 @@ struct lamd_ctx {
   hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr, ev_keys = nullptr, ev_sigs = nullptr;
   bool sigs_pending = false;  // lamd_flush sent the signature copy down another stream: the first kernel of the main stream that reads signatures waits for ev_sigs_wait
   hipEvent_t ev_sigs_wait = nullptr;   // the event that copy is followed by (the lane's own ev_sigs, or the staging set's)
-  hipStream_t copy_stream = nullptr;   // root only: the H2D copies of every flush, in flush order, behind nothing but each other (lamd_flush)
+  // root only: the H2D copies of the flushes, behind nothing but each other (lamd_flush).  Round 5: SEVERAL such streams, successive flushes taking
+  // turns (LAMD_COPY_STREAMS, default 2).  On ONE stream the three copies of a flush and the copies of the next flush follow each other with gaps of
+  // 0.1-1 ms (rocprofv3 --memory-copy-trace of the cold streaming loop, profiles/r05_stream_timeline.txt): 3.0 ms of transfers took 3.5-3.9 ms, the
+  // stream was busy 85-90 % of the time and set the loop's pace -- 4.25 ms per flush against the 4.05 ms the kernels need --, every call's front end
+  // started the moment its keys landed and only one table-driven ecmult launch was ever in flight.  With two streams the next flush's copies run in
+  // the gaps of the current one's.
+  static constexpr int MAX_COPY_STREAMS = 4;
+  hipStream_t copy_streams[MAX_COPY_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  int n_copy_streams = 2;
+  unsigned copy_turn = 0;
   bool use_copy_stream = true;         // LAMD_COPY_STREAM=0: a flush's copies go down its lane's prep stream (the round-2 form)
   hipStream_t d2h_stream = nullptr;    // root only, LAMD_D2H_STREAM=1 (experiment): the verdict copies of every flush on a stream of their own instead of the flush's lane.
                                        // Measured (profiles/r04_ab_variants.txt): nothing on the cold streaming loop, and one more stream per engine costs the SECOND
@@ -1494,7 +1503,9 @@ static int create_streams(lamd_ctx *ctx) {
       for (auto &q : qs.q)
         for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all, &q.ev_res}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (const char *w = getenv("LAMD_COPY_STREAMS")) ctx->n_copy_streams = atoi(w) < 1 ? 1 : atoi(w) > lamd_ctx::MAX_COPY_STREAMS ? lamd_ctx::MAX_COPY_STREAMS : atoi(w);
+    // (the streams themselves are created by the first flush that needs them: an engine that is only ever handed device pointers -- bench.py's
+    // resident loop, a rank of the collective path -- keeps their hardware-queue slots free for its lanes)
     if (const char *w = getenv("LAMD_D2H_STREAM")) ctx->use_d2h_stream = atoi(w) != 0;
     if (ctx->use_d2h_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
     for (auto &e : ctx->ev_ecm) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1693,7 +1704,8 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     if (L) lamd_shutdown(L);
     L = nullptr;
   }
-  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  for (hipStream_t cs : ctx->copy_streams)
+    if (cs) (void)hipStreamSynchronize(cs);
   if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (devbuf *b : {&ctx->row_ent, &ctx->kd_table, &ctx->kd_rep, &ctx->kd_uid, &ctx->kd_uniq, &ctx->kd_count, &ctx->kd_newent, &ctx->plan,
@@ -1726,7 +1738,8 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     if (qs.done) (void)hipEventDestroy(qs.done);
     if (qs.tail) (void)hipEventDestroy(qs.tail);
   }
-  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  for (hipStream_t cs : ctx->copy_streams)
+    if (cs) (void)hipStreamDestroy(cs);
   if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
   for (auto &e : ctx->ev_ecm)
     if (e) (void)hipEventDestroy(e);
@@ -2495,7 +2508,9 @@ constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG +
 // Keys that the latency path had to take down the ladder are remembered by fingerprint (host side, direct-mapped): the SECOND small
 // call that brings such a key takes the table-building path once (every key the cache misses gets a comb and is published), and
 // from then on the key is a cache hit -- a peer's node id or a channel's keys recur with every single check_signed_hash() call.
-constexpr size_t MISS_SLOTS = 4096;
+// (direct-mapped: two keys that share a slot evict each other's fingerprint on every pass and neither is ever learnt -- with 4096 slots that
+// hit 9 % of 400 recurring channel keys, the slow tail of the one-commitment-per-flush latency; 65 536 slots: 0.6 %)
+constexpr size_t MISS_SLOTS = 65536;
 __host__ __device__ static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen) {
   u64 h = seed ^ 0x6D697373ull;
   for (int o = 0; o < keylen; o += 8) {
@@ -3550,15 +3565,18 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       // next flush still crossed the bus only after the lane had gone idle (1.2 ms for the keys of 1 M rows before its first kernel
       // could start) -- which is why more staging sets bought nothing.  The device buffers belong to the staging set, and a set is
       // not refilled before its flush has been collected, so nothing else orders these copies.
-      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, ctx->copy_stream));
-      HIPCHK(ctx, hipEventRecord(q.ev_keys, ctx->copy_stream));
+      hipStream_t &csr = ctx->copy_streams[ctx->copy_turn++ % (unsigned)ctx->n_copy_streams];   // successive flushes (and kinds of one flush) take turns
+      if (!csr) HIPCHK(ctx, hipStreamCreateWithFlags(&csr, hipStreamNonBlocking));
+      hipStream_t cs = csr;
+      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
+      HIPCHK(ctx, hipEventRecord(q.ev_keys, cs));
       HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_keys, 0));
-      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, ctx->copy_stream));
-      HIPCHK(ctx, hipEventRecord(q.ev_sigs, ctx->copy_stream));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
+      HIPCHK(ctx, hipEventRecord(q.ev_sigs, cs));
       L->sigs_pending = true;
       L->ev_sigs_wait = q.ev_sigs;
-      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, ctx->copy_stream));
-      HIPCHK(ctx, hipEventRecord(q.ev_all, ctx->copy_stream));
+      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
+      HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));  // the preparation reads all three
     } else if (split) {
       HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));  // after whatever the lane's main stream still holds
@@ -4084,7 +4102,8 @@ extern "C" int lamd_debug_mul32_peak(lamd_ctx *ctx, int waves_per_simd, double m
   u32 iters = 2000;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || !run(200, &ms) || !run(iters, &ms)) rc = LAMD_ERR_HIP;
   if (rc == LAMD_OK) {
-    if (ms > 0 && min_ms > ms) iters = (u32)((double)iters * min_ms / ms * 1.05) + 1;
+    if (min_ms <= 0) iters = 150;  // the sub-millisecond launch of the round-1 micro-benchmark, for comparison
+    else if (ms > 0) iters = (u32)((double)iters * min_ms / ms * 1.05) + 1;
     double sum = 0, ratio = 0;
     for (int l = 0; l < launches && rc == LAMD_OK; l++) {
       if (!run(iters, &ms)) { rc = LAMD_ERR_HIP; break; }

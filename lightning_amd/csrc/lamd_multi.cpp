@@ -58,7 +58,47 @@ struct eng_dev {
   size_t pin_bytes = 0;           // per slot; 0: staging off (pageable hipMemcpy)
   unsigned pin_next = 0;
   bool copies_pending = false;    // the copy stream holds work the next verification has to wait for
+  // one helper thread per device copies the upper half of every staged piece while the device's own thread copies the lower half: one core
+  // moves 12-15 GB/s out of pageable memory, a PCIe gen5 link takes 50+ (measured round 5: one thread 95.7 M ECDSA-65 rows/s, below the 105 M/s of
+  // the runtime's own pageable path it was meant to beat)
+  std::thread helper;
+  std::mutex hmu;
+  std::condition_variable hcv;
+  const uint8_t *hsrc = nullptr;
+  uint8_t *hdst = nullptr;
+  size_t hbytes = 0;
+  bool hbusy = false, hquit = false;
+  void helper_loop() {
+    std::unique_lock<std::mutex> lk(hmu);
+    for (;;) {
+      hcv.wait(lk, [&] { return hbusy || hquit; });
+      if (hquit) return;
+      const uint8_t *sp = hsrc;
+      uint8_t *dp = hdst;
+      const size_t nb = hbytes;
+      lk.unlock();
+      memcpy(dp, sp, nb);
+      lk.lock();
+      hbusy = false;
+      hcv.notify_all();
+    }
+  }
+  void helper_post(uint8_t *dst, const uint8_t *src, size_t bytes) {
+    std::lock_guard<std::mutex> lk(hmu);
+    hdst = dst; hsrc = src; hbytes = bytes; hbusy = true;
+    hcv.notify_all();
+  }
+  void helper_wait() {
+    std::unique_lock<std::mutex> lk(hmu);
+    hcv.wait(lk, [&] { return !hbusy; });
+  }
 };
+// caller memory that is already page-locked (hipHostMalloc / hipHostRegister) needs no staging: the copy engine reads it where it lies
+bool is_pinned_host(const void *p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
 struct eng_state {
   rccl_api nccl;
   std::mutex err_mu;  // the per-device worker threads report failures side by side (a dead node fails every shard at once)
@@ -104,6 +144,7 @@ int eng_open(void *user, int device, void **handle) {
       return LAMD_ERR_NOMEM;
     }
     d->pin_bytes = slot;
+    if (!getenv("LAMD_MULTI_HELPER") || atoi(getenv("LAMD_MULTI_HELPER")) != 0) d->helper = std::thread([d] { d->helper_loop(); });
   }
   *handle = d;
   return LAMD_OK;
@@ -112,6 +153,10 @@ void eng_close(void *, void *handle) {
   eng_dev *d = (eng_dev *)handle;
   if (!d) return;
   (void)hipSetDevice(d->device);
+  if (d->helper.joinable()) {
+    { std::lock_guard<std::mutex> lk(d->hmu); d->hquit = true; d->hcv.notify_all(); }
+    d->helper.join();
+  }
   if (d->cstream) (void)hipStreamSynchronize(d->cstream);
   for (int k = 0; k < eng_dev::SLOTS; k++) {
     if (d->pin_ev[k]) (void)hipEventDestroy(d->pin_ev[k]);
@@ -135,12 +180,23 @@ int eng_h2d(void *user, void *handle, void *dst, const void *src, size_t bytes) 
   eng_dev *d = (eng_dev *)handle;
   if (d->pin_bytes) {
     if (hipSetDevice(d->device) != hipSuccess) { ((eng_state *)user)->fail("hipSetDevice failed"); return LAMD_ERR_HIP; }
+    if (bytes >= (1u << 20) && is_pinned_host(src)) {  // page-locked caller memory: one asynchronous copy, no staging
+      if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->cstream) != hipSuccess) {
+        ((eng_state *)user)->fail("H2D from pinned caller memory failed (device " + std::to_string(d->device) + ")");
+        return LAMD_ERR_HIP;
+      }
+      d->copies_pending = true;
+      return LAMD_OK;
+    }
     for (size_t o = 0; o < bytes;) {
       const unsigned k = d->pin_next++ % eng_dev::SLOTS;
       const size_t c = bytes - o < d->pin_bytes ? bytes - o : d->pin_bytes;
       bool ok = !d->pin_busy[k] || hipEventSynchronize(d->pin_ev[k]) == hipSuccess;  // the slot's previous copy has left it
       if (ok) {
-        memcpy(d->pin[k], (const uint8_t *)src + o, c);
+        const size_t half = d->helper.joinable() && c >= (256u << 10) ? (c / 2) & ~(size_t)63 : c;
+        if (half < c) d->helper_post(d->pin[k] + half, (const uint8_t *)src + o + half, c - half);
+        memcpy(d->pin[k], (const uint8_t *)src + o, half);
+        if (half < c) d->helper_wait();
         ok = hipMemcpyAsync((uint8_t *)dst + o, d->pin[k], c, hipMemcpyHostToDevice, d->cstream) == hipSuccess && hipEventRecord(d->pin_ev[k], d->cstream) == hipSuccess;
       }
       if (!ok) {
@@ -495,14 +551,14 @@ extern "C" int lamd_multi_sigcheck_gossip_batch(lamd_multi *m, size_t n, const u
   std::lock_guard<std::mutex> lk(m->call_mu);
   // signatures per message (4 for a channel_announcement, 1 otherwise: lamd_sigcheck_gossip_batch_device): shards are cut on MESSAGE boundaries
   // and balanced by signatures; the verdict vector that is gathered has one byte per message
-  // ... balanced by COST: a channel_announcement is four signatures, two of them under bitcoin keys that never recur and take the per-signature
-  // ladder (about twice a comb row) -- weight 6 against 1 (lightning_amd/sharding.py GOSSIP_WEIGHT_*; balanced by message count the first shard
-  // of a replay that starts with its announcements would carry a quarter of the job)
+  // ... balanced by COST: a channel_announcement is four signatures and four key parses, two of the signatures under bitcoin keys that never recur
+  // (the per-signature ladder) -- twelve channel_updates' worth, measured (lightning_amd/sharding.py GOSSIP_WEIGHT_*; balanced by message count the
+  // first shard of a replay that starts with its announcements would carry a third of the job)
   std::vector<uint32_t> sigs(n), wts(n);
   for (size_t i = 0; i < n; i++) {
     const uint64_t len = off[i + 1] - off[i];
     sigs[i] = (len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 0) ? 4u : 1u;
-    wts[i] = sigs[i] == 4u ? 6u : 1u;
+    wts[i] = sigs[i] == 4u ? 12u : 1u;
     if (!node_ids33 && len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 2) {  // as lamd_sigcheck_gossip_batch refuses it
       m->err = "channel_update in batch but node_ids33 is NULL";
       return LAMD_ERR_ARG;

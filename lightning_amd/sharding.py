@@ -43,9 +43,12 @@ def shard_bounds(n_rows, world, group_sizes=None, weights=None):
     return np.array(b, dtype=np.int64)
 
 
-# cost of one gossip message in units of one signature under a recurring key (node ids recur, bitcoin keys never do and take the per-signature
-# ladder: 124 against 240 M verifies/s, bench.py key_reuse_sweep): channel_announcement = 2 node signatures + 2 x 2; the others one signature
-GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER = 6, 1
+# cost of one gossip message in units of one channel_update under a node id the key-table cache knows, measured on one MI355X (round 5,
+# tools/call_trace_probe.py: 1/8 shards of BASELINE configs[3], T = 0.64 ms + 28.8 ns per channel_announcement / 2.43 ns per channel_update):
+# an announcement is four signatures, four key parses and a 430-byte SHA256d, and two of its signatures are under bitcoin keys that never recur,
+# i.e. on the per-signature ladder -- twelve updates' worth.  With these weights a 1/8 shard of announcements also stays below one full round of
+# the ladder kernel (196 608 lanes): 2 x 83 k cold rows take 1.5 ms, 2 x 104 k (one row over a round for 6 % of the lanes) 2.5 ms.
+GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER = 12, 1
 
 
 def gossip_weights(msgs, off):

@@ -68,6 +68,12 @@ def shim():
     for n in ("sigcheck_channel_update", "sigcheck_channel_announcement", "sigcheck_node_announcement", "sigcheck_channel_update_len",
               "sigcheck_channel_announcement_len", "sigcheck_node_announcement_len", "lamd_shim_last_error"):
         getattr(L, n).restype = ctypes.c_char_p  # leaks the shim_tal_dup()ed string; fine in a test
+    # (argtypes matter here: the eleventh argument of sigcheck_channel_announcement_len is a size_t that travels on the stack)
+    vp = ctypes.c_void_p
+    L.sigcheck_channel_announcement_len.argtypes = [vp] * 10 + [ctypes.c_size_t]
+    L.sigcheck_channel_announcement.argtypes = [vp] * 10
+    L.sigcheck_channel_update_len.argtypes = L.sigcheck_node_announcement_len.argtypes = [vp] * 4 + [ctypes.c_size_t]
+    L.sigcheck_channel_update.argtypes = L.sigcheck_node_announcement.argtypes = [vp] * 4
     for n in ("lamd_secp256k1_ecdsa_verify", "lamd_secp256k1_ecdsa_recoverable_signature_convert"):
         getattr(L, n).restype = ctypes.c_int
     L.check_tx_sig_preimage.restype = ctypes.c_bool

@@ -206,3 +206,15 @@ def test_multi_gossip_over_8_stub_devices(multi, orc, kat):
     assert np.array_equal(got, want)
     assert sum(n for _, k, n in st.calls if k == "gossip") == len(msgs) and len({d for d, _, _ in st.calls}) == 8
     assert list(want[:len(vs)]) == [v["expect"] for v in vs]
+    # the shards are the ones lightning_amd.sharding cuts for the same batch (message boundaries, balanced by cost: GOSSIP_WEIGHT_*)
+    from lightning_amd import sharding
+    b = sharding.shard_bounds(len(msgs), 8, None, sharding.gossip_weights(blob, off))
+    per_dev = {}
+    for d, k, n in st.calls:
+        if k == "gossip":
+            per_dev[d] = per_dev.get(d, 0) + n
+    assert sorted(per_dev.values()) == sorted(int(b[i + 1] - b[i]) for i in range(8))
+    # a channel_update without node ids is refused up front (as lamd_sigcheck_gossip_batch does), nothing reaches a device
+    before = len(st.calls)
+    rc = lib.lamd_multi_sigcheck_gossip_batch(m, len(msgs), blob.ctypes.data, off.ctypes.data, None, got.ctypes.data)
+    assert rc == -3 and b"node_ids33 is NULL" in lib.lamd_multi_last_error(m) and len(st.calls) == before

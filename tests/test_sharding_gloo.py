@@ -32,6 +32,18 @@ def test_shard_bounds_even_and_grouped():
     assert all(int(x) % 484 == 0 for x in b)
     with pytest.raises(ValueError):
         sharding.shard_bounds(5, 2, [2, 2])
+    # cuts balanced by COST, not by count: a replay that starts with its channel_announcements (weight GOSSIP_WEIGHT_CANN each) must not hand
+    # the first rank a shard that is all announcements and as long as the others'
+    w = np.array([sharding.GOSSIP_WEIGHT_CANN] * 500 + [sharding.GOSSIP_WEIGHT_OTHER] * 2000)
+    b = sharding.shard_bounds(2500, 8, None, w)
+    cost = [int(w[b[i]:b[i + 1]].sum()) for i in range(8)]
+    assert b[0] == 0 and b[-1] == 2500 and max(cost) - min(cost) <= 2 * sharding.GOSSIP_WEIGHT_CANN, cost
+    assert int(b[1]) < 2500 // 8 // 2      # far fewer messages in an announcement shard
+    # ... weights and groups together (cuts on group boundaries, balanced by the groups' weights)
+    b = sharding.shard_bounds(12, 2, [4, 4, 1, 1, 1, 1], [12, 12, 1, 1, 1, 1])
+    assert list(b) == [0, 8, 12] or list(b) == [0, 4, 12]
+    msgs = np.frombuffer(bytes([1, 0]) + bytes(10) + bytes([1, 2]) + bytes(5) + bytes([1, 1]) + bytes(3), dtype=np.uint8)
+    assert list(sharding.gossip_weights(msgs, [0, 12, 19, 24])) == [sharding.GOSSIP_WEIGHT_CANN, 1, 1]
 
 
 def _free_port():

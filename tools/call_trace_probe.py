@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Workloads for a rocprofv3 --kernel-trace (--memory-copy-trace) timeline, phases separated by marker kernels (a torch fill whose element count
+is the marker: 1000 * 256 * k elements -> Grid/Workgroup sizes that nothing else launches):
+  gossip : marker 1 | cann shard (1/8 of configs[3] by cost) x R, a synchronise after each | marker 2 | cupd shard x R | marker 3 | whole job x 2 | marker 4
+  stream : marker 5 | resident cold loop, S steps | marker 6 | host->host in-place cold streaming loop, S steps, 8 flushes in flight | marker 7
+Prints the host-side wall time of every repetition."""
+import os
+import sys
+import time
+
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import torch
+from lightning_amd import Engine, sharding, workload
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "gossip"
+R = int(os.environ.get("PROBE_REPS", "5"))
+S = int(os.environ.get("PROBE_STEPS", "12"))
+dev = "cuda:0"
+
+
+def marker(k):
+    torch.cuda.synchronize()
+    torch.zeros(1000 * 256 * k, dtype=torch.float32, device=dev).fill_(1.0)
+    torch.cuda.synchronize()
+
+
+if mode == "gossip":
+    eng = Engine(0)
+    g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=dev)
+    gw = sharding.gossip_weights(g.msgs, g.off)
+    b = sharding.shard_bounds(g.n, 8, None, gw)
+
+    def shard(lo, hi):
+        rb = (g.d_rowbase[lo:hi + 1] - g.d_rowbase[lo]).contiguous()
+        rows = int(g.rowbase[hi] - g.rowbase[lo])
+        d_v = torch.zeros(hi - lo, dtype=torch.int8, device=dev)
+        torch.cuda.synchronize()
+
+        def one():
+            t = time.perf_counter()
+            eng.sigcheck_gossip_device(hi - lo, g.d_msgs, g.d_off[lo:hi + 1], g.d_ids[lo:hi], rb, rows, d_v)
+            eng.synchronize()
+            return (time.perf_counter() - t) * 1e3
+        return one, d_v
+    whole, _ = shard(0, g.n)
+    for _ in range(eng.info()["lanes"] + 1):
+        whole()
+    for name, k, mk in (("cann shard 0", 0, 1), ("cupd shard 7", 7, 2)):
+        one, d_v = shard(int(b[k]), int(b[k + 1]))
+        for _ in range(eng.info()["lanes"]):
+            one()
+        marker(mk)
+        ts = [one() for _ in range(R)]
+        bad = int((d_v.cpu().numpy() != g.expect[int(b[k]):int(b[k + 1])]).sum())
+        print("%s: %d messages, host wall ms %s, mismatches %d" % (name, int(b[k + 1] - b[k]), " ".join("%.3f" % t for t in ts), bad))
+    marker(3)
+    print("whole job: host wall ms", " ".join("%.3f" % whole() for _ in range(2)))
+    marker(4)
+else:
+    os.environ["LAMD_CACHE"] = "0"
+    eng = Engine(0)
+    n = 1_000_000
+    we = workload.make_ecdsa(eng, n, seed=workload.SEED_CFG2, nkeys=65536, publen=65, device=dev)
+    ws = workload.make_schnorr(eng, n, seed=workload.SEED_CFG3, nkeys=65536, device=dev)
+    eng.auto_order = False
+
+    def resident(steps):
+        torch.cuda.synchronize(); eng.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
+            eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
+        eng.synchronize()
+        return time.perf_counter() - t
+
+    def stream(steps, filled, depth=8):
+        pend, bad = [], 0
+        got = []
+        t = time.perf_counter()
+        for r in range(steps):
+            for wl in (we, ws):
+                _, a, b_, c = eng.queue_reserve(n, 65 if wl is we else 32)
+                if a.ctypes.data not in filled:
+                    filled.add(a.ctypes.data)
+                    a[:] = wl.cols[0]
+                    if wl is we:
+                        b_[:], c[:] = wl.cols[1], wl.cols[2]
+                    else:
+                        c[:], b_[:] = wl.cols[1], wl.cols[2]
+                eng.flush()
+                pend.append(wl)
+                if len(pend) == depth:
+                    got.append((eng.wait(cap=n), pend.pop(0)))
+        while pend:
+            got.append((eng.wait(cap=n), pend.pop(0)))
+        dt = time.perf_counter() - t
+        return dt, sum(int((v != wl.expect).sum()) for v, wl in got)
+    resident(6)
+    seen = set()
+    stream(9, seen)
+    marker(5)
+    dt = resident(S)
+    print("resident cold loop: %.1f M verifies/s (%.3f ms per step)" % (2 * n * S / dt / 1e6, dt / S * 1e3))
+    marker(6)
+    dt, bad = stream(S, seen)
+    print("host->host in-place cold loop: %.1f M verifies/s (%.3f ms per step), mismatches %d" % (2 * n * S / dt / 1e6, dt / S * 1e3, bad))
+    marker(7)
+eng.close()

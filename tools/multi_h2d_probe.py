@@ -24,7 +24,8 @@ def main():
     base = 65536
     h, s, p, c, e = orc.gen_ecdsa_edge_batch(0xABCD, base, 65, 8)
     reps = (n + base - 1) // base
-    H, S, P, E = (np.ascontiguousarray(np.tile(x, (reps, 1))[:n]) for x in (h, s, p)) + (np.tile(e, reps)[:n],)
+    H, S, P = (np.ascontiguousarray(np.tile(x, (reps, 1))[:n]) for x in (h, s, p))
+    E = np.tile(e, reps)[:n]
     m = ctypes.c_void_p()
     assert lib.lamd_multi_init(ctypes.byref(m), None, ndev) == 0, lib.lamd_multi_last_error(m)
     ok = np.zeros(n, np.uint8)
