@@ -74,6 +74,10 @@ def stream_shard(eng, st, bounds, k, grp, depth):
     shard, 2.6 ms of a 5 ms 1/8 shard.)  -> {kind: uint8 verdicts of the shard}"""
     import numpy as np
     jobs = []
+    per = st["per"]
+    total = sum(int(bounds[kind][k + 1]) - int(bounds[kind][k]) for kind in ("ecdsa", "schnorr"))
+    # a short shard is cut finer (>= ~10 flushes, never below 64 commitments each): the pipeline's fill and drain are one flush long
+    grp = max(64 * per, min(grp, (total // 10) // per * per))
     for kind in ("ecdsa", "schnorr"):
         a, z = int(bounds[kind][k]), int(bounds[kind][k + 1])
         span = max(1, z - a)
@@ -221,7 +225,7 @@ def strong_scaling_sweep(eng, device, tstream):
     res3, bad3 = {}, 0
     for W in (1, 2, 4, 8):
         b = sharding.shard_bounds(g.n, W, None, gw)
-        shard_ms = []
+        shard_ms, split_ms = [], []
         for k in range(W):
             lo, hi = int(b[k]), int(b[k + 1])
             rb = (g.d_rowbase[lo:hi + 1] - g.d_rowbase[lo]).contiguous()
@@ -237,8 +241,23 @@ def strong_scaling_sweep(eng, device, tstream):
                 one()
             shard_ms.append(best(one, 4) * 1e3)
             bad3 += int((d_v.cpu().numpy() != g.expect[lo:hi]).sum())
+            if W > 1:
+                # the same shard cut into two chunks (lamd_set_chunk_rows): the second chunk's front end runs under the first chunk's ecmult launch --
+                # what a rank whose shard is the only thing its GPU has to do can afford
+                eng.set_chunk_rows((rows // 2 + 63) // 64 * 64 + 64)
+                d_v.zero_()
+                for _ in range(2):
+                    one()
+                split_ms.append(best(one, 4) * 1e3)
+                bad3 += int((d_v.cpu().numpy() != g.expect[lo:hi]).sum())
+                eng.set_chunk_rows(0)
         res3[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms), "shard_messages": [int(b[k + 1] - b[k]) for k in range(W)],
                         "shard_signatures": [int(g.rowbase[int(b[k + 1])] - g.rowbase[int(b[k])]) for k in range(W)]}
+        if W > 1:
+            res3[str(W)]["shard_ms_two_chunks"] = split_ms
+            res3[str(W)]["slowest_ms_one_chunk"] = max(shard_ms)
+            res3[str(W)]["slowest_ms"] = min(max(shard_ms), max(split_ms))
+            res3[str(W)]["chunks"] = 2 if max(split_ms) < max(shard_ms) else 1
     for W in ("2", "4", "8"):
         res3[W]["predicted_speedup"] = res3["1"]["slowest_ms"] / res3[W]["slowest_ms"]
     out["cfg4_gossip_replay"] = dict(res3, verifies=g.rows, messages=g.n, mismatches=bad3, predicted_speedup_8=res3["8"]["predicted_speedup"],

@@ -347,6 +347,11 @@ int lamd_cache_clear(lamd_ctx *ctx);
  * neighbour (6.9 ms against 3.1 ms by itself).  1: a launch waits for the one submitted before it -- the kernel saturates the VALU issue
  * port by itself, so what runs under it is only the other lanes' front end (3.9 ms in the loop). */
 int lamd_set_ecmult_chain(lamd_ctx *ctx, int enable);
+/* Rows per launch sequence ("chunk") of the device-pointer and streaming calls that follow: a call of more rows is cut into chunks that alternate
+ * between the call's lane and its peer lane, so that chunk k+1's front end (key de-duplication, tables, row lists) runs under chunk k's ecmult
+ * launch.  Default 2^22 (rows == 0 restores it; clamped to [4096, 2^22]).  A caller whose call is the only thing the device has to do -- one rank's
+ * shard of a strong-scaling job -- gains by cutting it in two; a caller that keeps several calls in flight leaves it alone (the calls overlap). */
+int lamd_set_chunk_rows(lamd_ctx *ctx, size_t rows);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,7 @@ SYMBOLS = {
     "lamd_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LamdInfo)]),
     "lamd_set_timing": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_set_ecmult_chain": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_set_chunk_rows": (ctypes.c_int, [ctypes.c_void_p, c_sz]),
     "lamd_cache_clear": (ctypes.c_int, [ctypes.c_void_p]),
     "lamd_get_lane_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LamdInfo)]),
     "lamd_stream_wait_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

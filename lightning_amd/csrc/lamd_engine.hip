@@ -1288,15 +1288,16 @@ struct lamd_ctx {
   hipEvent_t ev_fork = nullptr, ev_prep = nullptr, ev_cold = nullptr, ev_keys = nullptr, ev_sigs = nullptr;
   bool sigs_pending = false;  // lamd_flush sent the signature copy down another stream: the first kernel of the main stream that reads signatures waits for ev_sigs_wait
   hipEvent_t ev_sigs_wait = nullptr;   // the event that copy is followed by (the lane's own ev_sigs, or the staging set's)
-  // root only: the H2D copies of the flushes, behind nothing but each other (lamd_flush).  Round 5: SEVERAL such streams, successive flushes taking
-  // turns (LAMD_COPY_STREAMS, default 2).  On ONE stream the three copies of a flush and the copies of the next flush follow each other with gaps of
+  // root only: the H2D copies of the flushes, behind nothing but each other (lamd_flush).  Round 5 experiment: SEVERAL such streams, successive flushes taking
+  // turns (LAMD_COPY_STREAMS, default 1: two and three measured SLOWER, 212 / 203 against 218 M/s -- profiles/r05_ab_variants.txt).  On ONE stream the three copies of a flush and the copies of the next flush follow each other with gaps of
   // 0.1-1 ms (rocprofv3 --memory-copy-trace of the cold streaming loop, profiles/r05_stream_timeline.txt): 3.0 ms of transfers took 3.5-3.9 ms, the
   // stream was busy 85-90 % of the time and set the loop's pace -- 4.25 ms per flush against the 4.05 ms the kernels need --, every call's front end
   // started the moment its keys landed and only one table-driven ecmult launch was ever in flight.  With two streams the next flush's copies run in
   // the gaps of the current one's.
   static constexpr int MAX_COPY_STREAMS = 4;
   hipStream_t copy_streams[MAX_COPY_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
-  int n_copy_streams = 2;
+  int n_copy_streams = 1;
+  int copy_events = 3;          // LAMD_COPY_EVENTS: events a flush records between / behind its three copies (3: keys | signatures | hashes, 2: keys | rest, 1: all)
   unsigned copy_turn = 0;
   bool use_copy_stream = true;         // LAMD_COPY_STREAM=0: a flush's copies go down its lane's prep stream (the round-2 form)
   hipStream_t d2h_stream = nullptr;    // root only, LAMD_D2H_STREAM=1 (experiment): the verdict copies of every flush on a stream of their own instead of the flush's lane.
@@ -1503,6 +1504,7 @@ static int create_streams(lamd_ctx *ctx) {
       for (auto &q : qs.q)
         for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all, &q.ev_res}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
+    if (const char *w = getenv("LAMD_COPY_EVENTS")) ctx->copy_events = atoi(w) < 1 ? 1 : atoi(w) > 3 ? 3 : atoi(w);
     if (const char *w = getenv("LAMD_COPY_STREAMS")) ctx->n_copy_streams = atoi(w) < 1 ? 1 : atoi(w) > lamd_ctx::MAX_COPY_STREAMS ? lamd_ctx::MAX_COPY_STREAMS : atoi(w);
     // (the streams themselves are created by the first flush that needs them: an engine that is only ever handed device pointers -- bench.py's
     // resident loop, a rank of the collective path -- keeps their hardware-queue slots free for its lanes)
@@ -1863,6 +1865,16 @@ extern "C" int lamd_set_timing(lamd_ctx *ctx, int enable) {
     L->keyed_ms_sum[0] = L->keyed_ms_sum[1] = 0;
     L->keyed_launches[0] = L->keyed_launches[1] = 0;
   }
+  return LAMD_OK;
+}
+
+// rows per launch sequence from the next call on (include/lightning_amd.h)
+extern "C" int lamd_set_chunk_rows(lamd_ctx *ctx, size_t rows) {
+  if (!ctx) return LAMD_ERR_ARG;
+  const size_t c = rows == 0 ? CHUNK_DEFAULT : rows < 4096 ? 4096 : rows > CHUNK_DEFAULT ? CHUNK_DEFAULT : rows;
+  ctx->chunk = c;
+  for (lamd_ctx *L : ctx->lane)
+    if (L) L->chunk = c;
   return LAMD_OK;
 }
 
@@ -3568,16 +3580,34 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       hipStream_t &csr = ctx->copy_streams[ctx->copy_turn++ % (unsigned)ctx->n_copy_streams];   // successive flushes (and kinds of one flush) take turns
       if (!csr) HIPCHK(ctx, hipStreamCreateWithFlags(&csr, hipStreamNonBlocking));
       hipStream_t cs = csr;
+      if (ctx->copy_events == 1) {
+        // ONE event per flush, behind its last copy: an event record is a marker packet on the stream's compute queue, and the copy behind it
+        // waits for that packet -- between the copies of a busy chip that hand-over took 0.1-1 ms each (the gaps of profiles/r05_stream_timeline.txt).
+        // Three copies back to back, then the marker; the lane's front end starts once all three have landed.
+        HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
+        HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_all, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));
+      } else {
       HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
       HIPCHK(ctx, hipEventRecord(q.ev_keys, cs));
       HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_keys, 0));
       HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
-      HIPCHK(ctx, hipEventRecord(q.ev_sigs, cs));
-      L->sigs_pending = true;
-      L->ev_sigs_wait = q.ev_sigs;
+      if (ctx->copy_events >= 3) {
+        HIPCHK(ctx, hipEventRecord(q.ev_sigs, cs));
+        L->sigs_pending = true;
+        L->ev_sigs_wait = q.ev_sigs;
+      }
       HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
       HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
+      if (ctx->copy_events < 3) {  // two events: keys, then everything
+        L->sigs_pending = true;
+        L->ev_sigs_wait = q.ev_all;
+      }
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));  // the preparation reads all three
+      }
     } else if (split) {
       HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));  // after whatever the lane's main stream still holds
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));

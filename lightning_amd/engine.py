@@ -395,6 +395,10 @@ class Engine:
                     cache_capacity=inf.cache_capacity, cache_resets=inf.cache_resets,
                     keyed_ecmult_ms_sum=list(inf.keyed_ecmult_ms_sum), keyed_ecmult_launches=list(inf.keyed_ecmult_launches), hw_queues_env=int(inf.hw_queues_env), queue_sets=int(inf.queue_sets))
 
+    def set_chunk_rows(self, rows):
+        """lamd_set_chunk_rows: rows per launch sequence of the calls that follow (0 = default 2^22)"""
+        self._chk(self._lib.lamd_set_chunk_rows(self._ctx, rows))
+
     def mul32_peak(self, waves_per_simd=3, min_ms=4.0, launches=5):
         """lamd_debug_mul32_peak: sustained v_mad_u64_u32 rate of the chip (lane-ops/s), average launch ms, s_memtime / s_memrealtime ratio"""
         r, ms, ck = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)

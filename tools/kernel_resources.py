@@ -11,7 +11,12 @@ LLVM = "/opt/rocm/lib/llvm/bin/"
 so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lightning_amd", "liblightning_amd.so")
 with tempfile.TemporaryDirectory() as d:
     fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
-    subprocess.check_call([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, so], stderr=subprocess.DEVNULL)
+    # llvm-objcopy with no output operand rewrites its INPUT in place (round 4: running this tool changed the shipped library's bytes while its
+    # build stamp still said "fresh"): work on a copy, send the rewritten object to the bit bucket
+    import shutil
+    tmp_so = os.path.join(d, "lib.so")
+    shutil.copyfile(so, tmp_so)
+    subprocess.check_call([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, tmp_so, os.path.join(d, "discard.so")], stderr=subprocess.DEVNULL)
     subprocess.check_call([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
     notes = subprocess.check_output([LLVM + "llvm-readelf", "--notes", co]).decode()
     if len(sys.argv) > 2:
