@@ -1,0 +1,69 @@
+/* lightning_amd -- the shared-service front: ONE process (lamd_served) owns the engine context of a GPU, many
+ * client processes use it through liblightning_amd_client.so.
+ *
+ * Why: Core Lightning runs one channeld per channel (channeld/channeld.c:7019-7129) next to gossipd, lightningd and the
+ * plugins, every one of them a single-threaded process that calls check_signed_hash() / check_tx_sig() inline
+ * (SURVEY.md 8(b) "callers").  An engine context costs 11 GiB of HBM (the static G table) plus its table pools and 0.36 s to
+ * create -- one per daemon process does not scale.  The server holds the one context; a client process holds a socket and a
+ * shared-memory block.  Requests that are waiting at the same moment are MERGED: the ECDSA rows of every client go to the device
+ * as one lamd_verify_ecdsa_batch call (eight channelds validating a commitment_signed each = one 3872-row launch), their
+ * verdicts are scattered back per client.  That is the batching the north star asks the C host for, across process boundaries.
+ *
+ * liblightning_amd_client.so exports the entry points of include/lightning_amd.h that the mirror (include/cln_shim.h) and the
+ * gossip ingest use, with the SAME prototypes and meaning:
+ *     lamd_init / lamd_shutdown / lamd_last_error / lamd_version
+ *     lamd_verify_ecdsa_batch, lamd_verify_schnorr_batch, lamd_check_signed_hash, lamd_check_signed_hash_nodeid, lamd_check_schnorr_sig
+ *     lamd_pubkey_parse_batch, lamd_sigcheck_gossip_batch, lamd_check_tx_sig_tx_batch, lamd_check_commitment_signed
+ *     lamd_bolt12_check_signature_batch, lamd_bolt12_merkle_batch, lamd_ecdsa_recover_batch, lamd_grind_htlc_tx_fee
+ * so liblightning_amd_cln_client.so -- the mirror linked against the client instead of the engine -- gives a daemon the reference's
+ * own prototypes over the service with no source change.  lamd_init(&ctx, device) connects (LAMD_SERVED_SOCKET, default
+ * /tmp/lamd_served.sock; `device` is ignored: the server chose it) and fails with LAMD_ERR_NO_DEVICE when no server answers:
+ * the mirror then fails closed, as it does without a GPU.  No verification happens in the client: it frames bytes.
+ *
+ * Wire format (one request in flight per connection; the callers are synchronous):
+ *   connect -> client sends a memfd (SCM_RIGHTS) + its size in an LAMD_SRV_OP_SHM request; both sides mmap it
+ *   request  = struct lamd_srv_req over the socket; the argument arrays ("sections") lie in the shared block back to back,
+ *              each aligned to 16 bytes, in the order the operation defines (lamd_served.cpp, op table)
+ *   reply    = struct lamd_srv_rep over the socket; output sections follow the input sections in the shared block
+ * Both structs are plain little-endian host structs: client and server are processes of one machine.
+ */
+#ifndef LIGHTNING_AMD_SERVED_H
+#define LIGHTNING_AMD_SERVED_H
+#include <stdint.h>
+
+#define LAMD_SRV_MAGIC 0x4C414D44u /* "LAMD" */
+#define LAMD_SRV_DEFAULT_SOCKET "/tmp/lamd_served.sock"
+#define LAMD_SRV_MAX_SECTIONS 20
+
+enum lamd_srv_op {
+	LAMD_SRV_OP_SHM = 1,          /* (re)attach the shared block: fd by SCM_RIGHTS, scalar[0] = its size */
+	LAMD_SRV_OP_ECDSA = 2,        /* lamd_verify_ecdsa_batch: n, scalar[0] = publen; in: hash32[n] sig64[n] pub[n*publen]; out: ok[n].  MERGED across clients */
+	LAMD_SRV_OP_SCHNORR = 3,      /* lamd_verify_schnorr_batch: in: msg32 xonly32 sig64; out: ok[n].  MERGED across clients */
+	LAMD_SRV_OP_PUBKEY_PARSE = 4, /* lamd_pubkey_parse_batch: scalar[0] = publen; in: pub; out: xy64[n] ok[n] */
+	LAMD_SRV_OP_GOSSIP = 5,       /* lamd_sigcheck_gossip_batch: scalar[0] = node ids present; in: msgs off[n+1] ids33[n]; out: verdict[n] */
+	LAMD_SRV_OP_TXSIG_TX = 6,     /* lamd_check_tx_sig_tx_batch: scalar[0] = publen; in: the fifteen arrays in prototype order; out: ok[n] */
+	LAMD_SRV_OP_COMMITMENT = 7,   /* lamd_check_commitment_signed: n = 1 + n_htlc rows as TXSIG_TX arrays + keys + sigs; out: first_bad (8) ok[n] */
+	LAMD_SRV_OP_BOLT12_CHECK = 8, /* lamd_bolt12_check_signature_batch: in: tlvs off[n+1] messagename fieldname key33[n] sig64[n]; out: ok[n] */
+	LAMD_SRV_OP_BOLT12_MERKLE = 9,/* lamd_bolt12_merkle_batch: scalar[0] = sighash wanted; in: tlvs off messagename fieldname; out: merkle32[n] sighash32[n] ok[n] */
+	LAMD_SRV_OP_RECOVER = 10,     /* lamd_ecdsa_recover_batch: in: hash32 sig64 recid[n]; out: pub33[n] ok[n] */
+	LAMD_SRV_OP_GRIND = 11,       /* lamd_grind_htlc_tx_fee: scalars = input_sat weight min max sighash_type has_witness; in: preimage outputs sig64 pub33; out: rate(4) fee(8) found(4) */
+	LAMD_SRV_OP_STATS = 12        /* out: struct lamd_srv_stats */
+};
+
+struct lamd_srv_req {
+	uint32_t magic, op;
+	uint64_t n;
+	uint64_t scalar[6];
+	uint32_t n_sections, pad;
+	uint64_t section_len[LAMD_SRV_MAX_SECTIONS];
+};
+struct lamd_srv_rep {
+	uint32_t magic;
+	int32_t rc;          /* the engine call's return value (LAMD_OK, 0/1 for the single-item veneers, < 0 errors) */
+	uint64_t out_offset; /* where the output sections start in the shared block */
+	char err[216];       /* lamd_last_error() of the server's context when rc < 0 */
+};
+struct lamd_srv_stats {
+	uint64_t requests, engine_calls, merged_requests, merged_rows, largest_merge_requests, clients_now, clients_total;
+};
+#endif

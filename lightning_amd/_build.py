@@ -101,12 +101,44 @@ def build_testgen(force=False):
     return TESTGEN
 
 
+# the shared-service front (include/lightning_amd_served.h): host code only -- the server binds the engine through dlopen, the client speaks
+# to the server; liblightning_amd_cln_client.so is the mirror linked against the CLIENT instead of the engine
+SERVED = os.path.join(PKG, "lamd_served")
+CLIENT = os.path.join(PKG, "liblightning_amd_client.so")
+SHIM_CLIENT = os.path.join(PKG, "liblightning_amd_cln_client.so")
+SERVED_SOURCES = _H("lamd_served.cpp", "served_common.h") + _I("lightning_amd_served.h", "lightning_amd.h")
+CLIENT_SOURCES = _H("lamd_client.cpp", "served_common.h") + _I("lightning_amd_served.h", "lightning_amd.h")
+
+
+def build_served(force=False):
+    """lamd_served + liblightning_amd_client.so + liblightning_amd_cln_client.so (g++, seconds; no device code)"""
+    cxx = os.environ.get("CXX", "g++")
+    flags = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-function"]
+    d = _digest(SERVED_SOURCES, ["served-v1"])
+    if force or not _fresh(SERVED, d):
+        subprocess.check_call([cxx] + flags + ["-o", SERVED + ".tmp", os.path.join(CSRC, "lamd_served.cpp"), "-ldl"])
+        os.replace(SERVED + ".tmp", SERVED)
+        _stamp(SERVED, d)
+    d = _digest(CLIENT_SOURCES, ["client-v1"])
+    if force or not _fresh(CLIENT, d):
+        subprocess.check_call([cxx] + flags + ["-shared", "-o", CLIENT + ".tmp", os.path.join(CSRC, "lamd_client.cpp")])
+        os.replace(CLIENT + ".tmp", CLIENT)
+        _stamp(CLIENT, d)
+    d = _digest(SHIM_SOURCES + CLIENT_SOURCES, ["shim-client-v1"])
+    if force or not _fresh(SHIM_CLIENT, d):
+        subprocess.check_call([cxx] + flags + ["-shared", "-o", SHIM_CLIENT + ".tmp"] + SHIM_CPP + ["-L" + PKG, "-llightning_amd_client", "-Wl,-rpath,$ORIGIN"])
+        os.replace(SHIM_CLIENT + ".tmp", SHIM_CLIENT)
+        _stamp(SHIM_CLIENT, d)
+    return SERVED, CLIENT, SHIM_CLIENT
+
+
 def build(force=False, verbose=False):
     tus = _engine_digests()
     link_digest = _digest([], [d for _, d, _ in tus])
     if not force and _fresh(LIB, link_digest):
         build_shim()
         build_testgen()
+        build_served()
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
     objs = []
@@ -129,4 +161,5 @@ def build(force=False, verbose=False):
     _stamp(LIB, link_digest)
     build_shim(force=True)
     build_testgen()
+    build_served()
     return LIB

@@ -1297,7 +1297,8 @@ struct lamd_ctx {
   static constexpr int MAX_COPY_STREAMS = 4;
   hipStream_t copy_streams[MAX_COPY_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   int n_copy_streams = 1;
-  int copy_events = 3;          // LAMD_COPY_EVENTS: events a flush records between / behind its three copies (3: keys | signatures | hashes, 2: keys | rest, 1: all)
+  bool copy_one = true;         // LAMD_COPY_ONE=0: a full staging set still goes down as three copies
+  int copy_events = 0;          // LAMD_COPY_EVENTS: events a flush records between / behind its three copies (3: keys | signatures | hashes, 2: keys | rest, 1: all; 0: by load)
   unsigned copy_turn = 0;
   bool use_copy_stream = true;         // LAMD_COPY_STREAM=0: a flush's copies go down its lane's prep stream (the round-2 form)
   hipStream_t d2h_stream = nullptr;    // root only, LAMD_D2H_STREAM=1 (experiment): the verdict copies of every flush on a stream of their own instead of the flush's lane.
@@ -1353,11 +1354,16 @@ struct lamd_ctx {
   // streaming queues (pinned host staging): QUEUE_SETS sets, one being filled while up to QUEUE_SETS - 1 flushed ones are
   // in flight (each on the lane picked at its flush), collected oldest first
   struct queue {
-    u8 *h_a = nullptr, *h_b = nullptr, *h_c = nullptr, *h_ok = nullptr;  // hash/msg, sig, key, verdicts
+    // ONE pinned block per (set, kind), laid out for `cap` rows: keys | signatures | hashes (the order a flush sends them); h_c / h_b / h_a point
+    // into it.  A flush that fills the set exactly (n == cap: a producer that reserves its batch in one go) crosses the bus as ONE copy.
+    u8 *h_blk = nullptr;
+    u8 *h_a = nullptr, *h_b = nullptr, *h_c = nullptr, *h_ok = nullptr;  // hash/msg, sig, key (inside h_blk); verdicts (own block)
     size_t cap = 0, n = 0;
+    static size_t key_bytes_padded(size_t cap, size_t keybytes) { return (cap * keybytes + 63) & ~(size_t)63; }
+    static size_t blk_bytes(size_t cap, size_t keybytes) { return key_bytes_padded(cap, keybytes) + cap * 96; }
     struct span { size_t row0; u32 ticket0; size_t count; };
     std::vector<span> tickets;  // rows [row0, row0 + count) of this queue return as verdicts [ticket0, ...) of the staging set
-    devbuf d_a, d_b, d_c, d_ok;
+    devbuf d_blk, d_ok;   // the device twin of h_blk (same layout), the verdicts
     hipEvent_t ev_keys = nullptr, ev_sigs = nullptr, ev_all = nullptr;  // behind the three H2D copies of a flush on the copy stream
     hipEvent_t ev_res = nullptr;     // behind the flush's last kernel on its lane: the verdict copy on the D2H stream waits for it
     bool small_flush = false;   // this flush ran as ONE k_small_verify launch over the staging rows themselves (h_ok + cap: the rows' shapes)
@@ -1504,7 +1510,8 @@ static int create_streams(lamd_ctx *ctx) {
       for (auto &q : qs.q)
         for (hipEvent_t *e : {&q.ev_keys, &q.ev_sigs, &q.ev_all, &q.ev_res}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
-    if (const char *w = getenv("LAMD_COPY_EVENTS")) ctx->copy_events = atoi(w) < 1 ? 1 : atoi(w) > 3 ? 3 : atoi(w);
+    if (const char *w = getenv("LAMD_COPY_ONE")) ctx->copy_one = atoi(w) != 0;
+    if (const char *w = getenv("LAMD_COPY_EVENTS")) ctx->copy_events = atoi(w) < 0 ? 0 : atoi(w) > 3 ? 3 : atoi(w);
     if (const char *w = getenv("LAMD_COPY_STREAMS")) ctx->n_copy_streams = atoi(w) < 1 ? 1 : atoi(w) > lamd_ctx::MAX_COPY_STREAMS ? lamd_ctx::MAX_COPY_STREAMS : atoi(w);
     // (the streams themselves are created by the first flush that needs them: an engine that is only ever handed device pointers -- bench.py's
     // resident loop, a rank of the collective path -- keeps their hardware-queue slots free for its lanes)
@@ -1731,9 +1738,10 @@ extern "C" void lamd_shutdown(lamd_ctx *ctx) {
     release(b);
   for (auto &qs : ctx->qs) {
     for (auto &q : qs.q) {
-      for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
+      q.h_a = q.h_b = q.h_c = nullptr;
+      for (u8 **h : {&q.h_blk, &q.h_ok})
         if (*h) (void)hipHostFree(*h);
-      for (devbuf *b : {&q.d_a, &q.d_b, &q.d_c, &q.d_ok}) release(b);
+      for (devbuf *b : {&q.d_blk, &q.d_ok}) release(b);
       for (hipEvent_t e : {q.ev_keys, q.ev_sigs, q.ev_all, q.ev_res})
         if (e) (void)hipEventDestroy(e);
     }
@@ -3380,26 +3388,26 @@ static int queue_reserve(lamd_ctx *ctx, lamd_ctx::queue &q, size_t keybytes, siz
   if (q.n < q.cap && want <= q.cap) return LAMD_OK;
   size_t ncap = q.cap ? q.cap * 2 : 1024;
   if (ncap < want) ncap = want;  // a large push sizes the set in one allocation (pinned allocations are slow)
-  u8 *na = nullptr, *nb = nullptr, *nc = nullptr, *nk = nullptr;
-  {  // all four or none: a failure (pinned memory is scarce exactly when this path is hit) must not leak the blocks already taken
-    hipError_t e = hipHostMalloc((void **)&na, ncap * 32, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&nb, ncap * 64, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&nc, ncap * keybytes, hipHostMallocDefault);
+  u8 *nblk = nullptr, *nk = nullptr;
+  {  // both or none: a failure (pinned memory is scarce exactly when this path is hit) must not leak the block already taken
+    hipError_t e = hipHostMalloc((void **)&nblk, lamd_ctx::queue::blk_bytes(ncap, keybytes), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&nk, 2 * ncap, hipHostMallocDefault);  // verdicts | row shapes of a small flush
     if (e != hipSuccess) {
-      for (u8 *h : {na, nb, nc, nk})
+      for (u8 *h : {nblk, nk})
         if (h) (void)hipHostFree(h);
       ctx->err = std::string("hipHostMalloc (staging set): ") + hipGetErrorString(e);
       return e == hipErrorOutOfMemory ? LAMD_ERR_NOMEM : LAMD_ERR_HIP;
     }
   }
+  u8 *nc = nblk, *nb = nblk + lamd_ctx::queue::key_bytes_padded(ncap, keybytes), *na = nb + ncap * 64;
   if (q.n) {
     memcpy(na, q.h_a, q.n * 32);
     memcpy(nb, q.h_b, q.n * 64);
     memcpy(nc, q.h_c, q.n * keybytes);
   }
-  for (u8 **h : {&q.h_a, &q.h_b, &q.h_c, &q.h_ok})
+  for (u8 **h : {&q.h_blk, &q.h_ok})
     if (*h) (void)hipHostFree(*h);
+  q.h_blk = nblk;
   q.h_a = na; q.h_b = nb; q.h_c = nc; q.h_ok = nk;
   q.cap = ncap;
   return LAMD_OK;
@@ -3559,10 +3567,9 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
         continue;
       }
     }
-    if ((rc = ensure(ctx, &q.d_a, q.n * 32)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &q.d_b, q.n * 64)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &q.d_c, q.n * kb + 16)) != LAMD_OK) return rc;
+    if ((rc = ensure(ctx, &q.d_blk, lamd_ctx::queue::blk_bytes(q.cap, kb) + 64)) != LAMD_OK) return rc;
     if ((rc = ensure(ctx, &q.d_ok, q.n)) != LAMD_OK) return rc;
+    u8 *const qd_c = (u8 *)q.d_blk.p, *const qd_b = qd_c + lamd_ctx::queue::key_bytes_padded(q.cap, kb), *const qd_a = qd_b + q.cap * 64;
     // The keys first: de-duplication and table building (main stream) only need them and start while the hashes and signatures
     // are still on the bus.  All three copies go down the lane's PREP stream back to back and the main stream waits for the
     // keys' event: a copy that itself waits for another stream's copy starts 0.5-1 ms late (rocprofv3 timeline of the pipelined
@@ -3580,29 +3587,39 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       hipStream_t &csr = ctx->copy_streams[ctx->copy_turn++ % (unsigned)ctx->n_copy_streams];   // successive flushes (and kinds of one flush) take turns
       if (!csr) HIPCHK(ctx, hipStreamCreateWithFlags(&csr, hipStreamNonBlocking));
       hipStream_t cs = csr;
-      if (ctx->copy_events == 1) {
+      // (LAMD_COPY_EVENTS unset: one event when other flushes are already in flight -- their kernels cover the 1.8 ms the front end now waits for the
+      // signatures and hashes --, three when this flush is alone and its latency is what the caller sees)
+      const int events = ctx->copy_events ? ctx->copy_events : (ctx->q_inflight >= 2 ? 1 : 3);
+      if (events == 1 && q.n == q.cap && ctx->copy_one) {
+        // the set is full to the row: keys | signatures | hashes are one contiguous block on both sides -- ONE copy command (every command on
+        // the copy stream is followed by a gap of 0.1-1 ms while the chip is busy: profiles/r05_stream_timeline.txt)
+        HIPCHK(ctx, hipMemcpyAsync(qd_c, q.h_blk, lamd_ctx::queue::blk_bytes(q.cap, kb), hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
+        HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_all, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));
+      } else if (events == 1) {
         // ONE event per flush, behind its last copy: an event record is a marker packet on the stream's compute queue, and the copy behind it
         // waits for that packet -- between the copies of a busy chip that hand-over took 0.1-1 ms each (the gaps of profiles/r05_stream_timeline.txt).
         // Three copies back to back, then the marker; the lane's front end starts once all three have landed.
-        HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
-        HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
-        HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipMemcpyAsync(qd_c, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipMemcpyAsync(qd_b, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipMemcpyAsync(qd_a, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
         HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
         HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_all, 0));
         HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));
       } else {
-      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
+      HIPCHK(ctx, hipMemcpyAsync(qd_c, q.h_c, q.n * kb, hipMemcpyHostToDevice, cs));
       HIPCHK(ctx, hipEventRecord(q.ev_keys, cs));
       HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_keys, 0));
-      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
-      if (ctx->copy_events >= 3) {
+      HIPCHK(ctx, hipMemcpyAsync(qd_b, q.h_b, q.n * 64, hipMemcpyHostToDevice, cs));
+      if (events >= 3) {
         HIPCHK(ctx, hipEventRecord(q.ev_sigs, cs));
         L->sigs_pending = true;
         L->ev_sigs_wait = q.ev_sigs;
       }
-      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
+      HIPCHK(ctx, hipMemcpyAsync(qd_a, q.h_a, q.n * 32, hipMemcpyHostToDevice, cs));
       HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
-      if (ctx->copy_events < 3) {  // two events: keys, then everything
+      if (events < 3) {  // two events: keys, then everything
         L->sigs_pending = true;
         L->ev_sigs_wait = q.ev_all;
       }
@@ -3611,23 +3628,23 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     } else if (split) {
       HIPCHK(ctx, hipEventRecord(L->ev_fork, L->stream));  // after whatever the lane's main stream still holds
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, L->ev_fork, 0));
-      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream2));
+      HIPCHK(ctx, hipMemcpyAsync(qd_c, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream2));
       HIPCHK(ctx, hipEventRecord(L->ev_keys, L->stream2));
       HIPCHK(ctx, hipStreamWaitEvent(L->stream, L->ev_keys, 0));
       // signatures before hashes: the row-list builders on the main stream read r and s (early reject) long before the
       // preparation needs the hashes
-      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream2));
+      HIPCHK(ctx, hipMemcpyAsync(qd_b, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream2));
       HIPCHK(ctx, hipEventRecord(L->ev_sigs, L->stream2));
       L->sigs_pending = true;
       L->ev_sigs_wait = L->ev_sigs;
-      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream2));
+      HIPCHK(ctx, hipMemcpyAsync(qd_a, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream2));
     } else {
-      HIPCHK(ctx, hipMemcpyAsync(q.d_c.p, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
-      HIPCHK(ctx, hipMemcpyAsync(q.d_a.p, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream));
-      HIPCHK(ctx, hipMemcpyAsync(q.d_b.p, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream));
+      HIPCHK(ctx, hipMemcpyAsync(qd_c, q.h_c, q.n * kb, hipMemcpyHostToDevice, L->stream));
+      HIPCHK(ctx, hipMemcpyAsync(qd_a, q.h_a, q.n * 32, hipMemcpyHostToDevice, L->stream));
+      HIPCHK(ctx, hipMemcpyAsync(qd_b, q.h_b, q.n * 64, hipMemcpyHostToDevice, L->stream));
     }
-    rc = run_device(L, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)q.d_a.p, (const u8 *)q.d_b.p,
-                    (const u8 *)q.d_c.p, (int)kb, kb, (u8 *)q.d_ok.p);
+    rc = run_device(L, kind == Q_SCHNORR ? MODE_SCHNORR : MODE_ECDSA, q.n, (const u8 *)qd_a, (const u8 *)qd_b,
+                    (const u8 *)qd_c, (int)kb, kb, (u8 *)q.d_ok.p);
     L->force_learn = false;
     if (rc != LAMD_OK) {
       if (L != ctx) ctx->err = L->err;

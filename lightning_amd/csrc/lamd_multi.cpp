@@ -552,13 +552,13 @@ extern "C" int lamd_multi_sigcheck_gossip_batch(lamd_multi *m, size_t n, const u
   // signatures per message (4 for a channel_announcement, 1 otherwise: lamd_sigcheck_gossip_batch_device): shards are cut on MESSAGE boundaries
   // and balanced by signatures; the verdict vector that is gathered has one byte per message
   // ... balanced by COST: a channel_announcement is four signatures and four key parses, two of the signatures under bitcoin keys that never recur
-  // (the per-signature ladder) -- twelve channel_updates' worth, measured (lightning_amd/sharding.py GOSSIP_WEIGHT_*; balanced by message count the
+  // (the per-signature ladder) -- ten channel_updates' worth, measured (lightning_amd/sharding.py GOSSIP_WEIGHT_*; balanced by message count the
   // first shard of a replay that starts with its announcements would carry a third of the job)
   std::vector<uint32_t> sigs(n), wts(n);
   for (size_t i = 0; i < n; i++) {
     const uint64_t len = off[i + 1] - off[i];
     sigs[i] = (len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 0) ? 4u : 1u;
-    wts[i] = sigs[i] == 4u ? 12u : 1u;
+    wts[i] = sigs[i] == 4u ? 10u : 1u;
     if (!node_ids33 && len >= 2 && msgs[off[i]] == 1 && msgs[off[i] + 1] == 2) {  // as lamd_sigcheck_gossip_batch refuses it
       m->err = "channel_update in batch but node_ids33 is NULL";
       return LAMD_ERR_ARG;

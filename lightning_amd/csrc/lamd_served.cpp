@@ -1,0 +1,454 @@
+// lamd_served -- ONE process owns the GPU's engine context; many client processes (liblightning_amd_client.so) share it.
+// Protocol and rationale: include/lightning_amd_served.h.  SURVEY.md section 7 "Process model": one channeld per channel
+// (channeld/channeld.c:7019-7129), gossipd, lightningd and plugins are separate single-threaded processes that verify inline.
+//
+//   lamd_served [--socket PATH] [--device N] [--engine LIB] [--max-merge ROWS] [--linger-us US]
+//
+// Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job, waits for its completion, sends the reply);
+// ONE engine thread, the only caller of the engine (a context is not thread-safe).  The engine thread takes EVERYTHING that is queued at
+// the moment it looks: the ECDSA jobs of equal key length become one lamd_verify_ecdsa_batch call, the BIP-340 jobs one
+// lamd_verify_schnorr_batch call (rows copied into one contiguous batch, verdicts scattered back); every other operation runs by itself.
+// With --linger-us the engine thread waits that long after the first job of a round for company (default 0: merge what is there).
+//
+// The engine is bound through dlopen (--engine, default liblightning_amd.so next to this executable): the server itself has no
+// verification code, and tests bind a stub library to run the queueing / merging / scattering on a machine without a GPU.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/un.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/lightning_amd.h"
+#include "served_common.h"
+
+using namespace lamd_srv;
+
+namespace {
+
+struct engine_api {
+  void *lib = nullptr;
+  decltype(&lamd_init) init = nullptr;
+  decltype(&lamd_shutdown) shutdown = nullptr;
+  decltype(&lamd_last_error) last_error = nullptr;
+  decltype(&lamd_verify_ecdsa_batch) verify_ecdsa = nullptr;
+  decltype(&lamd_verify_schnorr_batch) verify_schnorr = nullptr;
+  decltype(&lamd_pubkey_parse_batch) pubkey_parse = nullptr;
+  decltype(&lamd_sigcheck_gossip_batch) gossip = nullptr;
+  decltype(&lamd_check_tx_sig_tx_batch) txsig_tx = nullptr;
+  decltype(&lamd_check_commitment_signed) commitment = nullptr;
+  decltype(&lamd_bolt12_check_signature_batch) bolt12_check = nullptr;
+  decltype(&lamd_bolt12_merkle_batch) bolt12_merkle = nullptr;
+  decltype(&lamd_ecdsa_recover_batch) recover = nullptr;
+  decltype(&lamd_grind_htlc_tx_fee) grind = nullptr;
+};
+template <typename F>
+bool bind(void *lib, const char *name, F *fn) {
+  *(void **)fn = dlsym(lib, name);
+  if (!*fn) fprintf(stderr, "lamd_served: engine library lacks %s\n", name);
+  return *fn != nullptr;
+}
+
+struct conn {
+  int fd = -1;
+  uint8_t *shm = nullptr;
+  size_t shm_size = 0;
+};
+struct job {
+  lamd_srv_req req;
+  conn *c = nullptr;
+  size_t off[LAMD_SRV_MAX_SECTIONS];
+  size_t out_off = 0;
+  lamd_srv_rep rep;
+  bool done = false;
+};
+
+engine_api E;
+lamd_ctx *g_ctx = nullptr;
+std::mutex qmu;
+std::condition_variable qcv, donecv;
+std::deque<job *> Q;
+std::atomic<bool> g_quit{false};
+lamd_srv_stats g_stats;
+size_t g_max_merge = (size_t)1 << 20;
+unsigned g_linger_us = 0;
+
+const uint8_t *sec(const job *j, int i) { return j->c->shm + j->off[i]; }
+size_t seclen(const job *j, int i) { return (size_t)j->req.section_len[i]; }
+uint8_t *outp(const job *j, size_t o) { return j->c->shm + j->out_off + o; }
+
+void fail(job *j, int rc, const char *why) {
+  j->rep.rc = rc;
+  snprintf(j->rep.err, sizeof j->rep.err, "%s", why);
+}
+void engine_error(job *j, int rc) {
+  j->rep.rc = rc;
+  if (rc < 0) snprintf(j->rep.err, sizeof j->rep.err, "%s", E.last_error(g_ctx));
+}
+// input sections present with exactly these lengths, and `out_bytes` of output fit behind them
+bool shape(job *j, std::initializer_list<size_t> lens, size_t out_bytes) {
+  if (j->req.n_sections != lens.size()) { fail(j, LAMD_ERR_ARG, "wrong number of sections"); return false; }
+  int i = 0;
+  for (size_t l : lens) {
+    if (l != (size_t)-1 && seclen(j, i) != l) { fail(j, LAMD_ERR_ARG, "section length does not match n"); return false; }
+    i++;
+  }
+  if (j->out_off + align16(out_bytes) + 64 > j->c->shm_size) { fail(j, LAMD_ERR_ARG, "shared block too small for the reply"); return false; }
+  return true;
+}
+const size_t ANY = (size_t)-1;
+
+// n * w without overflow surprises (n is bounded before any use)
+bool sane_n(job *j) {
+  if (j->req.n > ((uint64_t)1 << 28)) { fail(j, LAMD_ERR_ARG, "n too large"); return false; }
+  return true;
+}
+
+void run_merged(std::vector<job *> &js, bool schnorr) {
+  // one engine call for the rows of all these requests (equal key length)
+  if (js.empty()) return;
+  const size_t kl = schnorr ? 32 : (size_t)js[0]->req.scalar[0];
+  size_t total = 0;
+  for (job *j : js) total += (size_t)j->req.n;
+  if (js.size() == 1) {
+    job *j = js[0];
+    const int rc = schnorr ? E.verify_schnorr(g_ctx, (size_t)j->req.n, sec(j, 0), sec(j, 1), sec(j, 2), outp(j, 0))
+                           : E.verify_ecdsa(g_ctx, (size_t)j->req.n, sec(j, 0), sec(j, 1), sec(j, 2), kl, kl, outp(j, 0));
+    engine_error(j, rc);
+    g_stats.engine_calls++;
+    return;
+  }
+  std::vector<uint8_t> a(32 * total), b(64 * total), c(kl * total), ok(total);
+  size_t o = 0;
+  for (job *j : js) {
+    const size_t n = (size_t)j->req.n;
+    memcpy(&a[32 * o], sec(j, 0), 32 * n);
+    if (schnorr) {
+      memcpy(&c[32 * o], sec(j, 1), 32 * n);
+      memcpy(&b[64 * o], sec(j, 2), 64 * n);
+    } else {
+      memcpy(&b[64 * o], sec(j, 1), 64 * n);
+      memcpy(&c[kl * o], sec(j, 2), kl * n);
+    }
+    o += n;
+  }
+  const int rc = schnorr ? E.verify_schnorr(g_ctx, total, a.data(), c.data(), b.data(), ok.data())
+                         : E.verify_ecdsa(g_ctx, total, a.data(), b.data(), c.data(), kl, kl, ok.data());
+  g_stats.engine_calls++;
+  g_stats.merged_requests += js.size();
+  g_stats.merged_rows += total;
+  if (js.size() > g_stats.largest_merge_requests) g_stats.largest_merge_requests = js.size();
+  o = 0;
+  for (job *j : js) {
+    const size_t n = (size_t)j->req.n;
+    if (rc == LAMD_OK) memcpy(outp(j, 0), &ok[o], n);
+    engine_error(j, rc);
+    o += n;
+  }
+}
+
+void run_one(job *j) {
+  const lamd_srv_req &r = j->req;
+  const size_t n = (size_t)r.n;
+  g_stats.engine_calls++;
+  switch (r.op) {
+    case LAMD_SRV_OP_PUBKEY_PARSE: {
+      const size_t kl = (size_t)r.scalar[0];
+      if ((kl != 33 && kl != 65) || !shape(j, {kl * n}, align16(64 * n) + n)) return;
+      engine_error(j, E.pubkey_parse(g_ctx, n, sec(j, 0), kl, kl, outp(j, 0), outp(j, align16(64 * n))));
+      return;
+    }
+    case LAMD_SRV_OP_GOSSIP: {
+      const bool ids = r.scalar[0] != 0;
+      if (!shape(j, {ANY, 8 * (n + 1), ids ? 33 * n : 0}, n)) return;
+      const uint64_t *off = (const uint64_t *)sec(j, 1);
+      for (size_t i = 0; i < n; i++)
+        if (off[i + 1] < off[i] || off[i + 1] > seclen(j, 0)) { fail(j, LAMD_ERR_ARG, "message offsets outside the blob"); return; }
+      engine_error(j, E.gossip(g_ctx, n, sec(j, 0), off, ids ? sec(j, 2) : nullptr, (int8_t *)outp(j, 0)));
+      return;
+    }
+    case LAMD_SRV_OP_TXSIG_TX:
+    case LAMD_SRV_OP_COMMITMENT: {
+      // sections 0..10: version locktime inputs40 in_off input_num amount outputs out_off n_outputs scripts script_off
+      const bool commit = r.op == LAMD_SRV_OP_COMMITMENT;
+      const size_t kl = commit ? 33 : (size_t)r.scalar[0];
+      if (n == 0 || (kl != 33 && kl != 65)) { fail(j, LAMD_ERR_ARG, "bad n / key length"); return; }
+      if (commit ? !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, 64 * n, 33, 33}, 16 + n)
+                 : !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, n, 64 * n, kl * n}, n))
+        return;
+      const uint64_t *in_off = (const uint64_t *)sec(j, 3), *out_off = (const uint64_t *)sec(j, 7), *sc_off = (const uint64_t *)sec(j, 10);
+      for (size_t i = 0; i < n; i++)
+        if (in_off[i + 1] < in_off[i] || 40 * in_off[i + 1] > seclen(j, 2) || out_off[i + 1] < out_off[i] || out_off[i + 1] > seclen(j, 6) ||
+            sc_off[i + 1] < sc_off[i] || sc_off[i + 1] > seclen(j, 9)) {
+          fail(j, LAMD_ERR_ARG, "template offsets outside their arrays");
+          return;
+        }
+      if (!commit) {
+        engine_error(j, E.txsig_tx(g_ctx, n, (const uint32_t *)sec(j, 0), (const uint32_t *)sec(j, 1), sec(j, 2), in_off, (const uint32_t *)sec(j, 4),
+                                   (const uint64_t *)sec(j, 5), sec(j, 6), out_off, (const uint32_t *)sec(j, 8), sec(j, 9), sc_off, sec(j, 11), sec(j, 12),
+                                   sec(j, 13), sec(j, 14), kl, kl, outp(j, 0)));
+        return;
+      }
+      std::vector<lamd_tx_template> t(n);
+      const uint32_t *ver = (const uint32_t *)sec(j, 0), *lock = (const uint32_t *)sec(j, 1), *inum = (const uint32_t *)sec(j, 4), *nout = (const uint32_t *)sec(j, 8);
+      const uint64_t *amt = (const uint64_t *)sec(j, 5);
+      for (size_t i = 0; i < n; i++) {
+        t[i].version = ver[i]; t[i].locktime = lock[i];
+        t[i].inputs40 = sec(j, 2) + 40 * in_off[i]; t[i].n_inputs = (uint32_t)(in_off[i + 1] - in_off[i]);
+        t[i].input_num = inum[i]; t[i].amount_sat = amt[i];
+        t[i].outputs = sec(j, 6) + out_off[i]; t[i].outputs_len = out_off[i + 1] - out_off[i]; t[i].n_outputs = nout[i];
+        t[i].script = sec(j, 9) + sc_off[i]; t[i].script_len = sc_off[i + 1] - sc_off[i];
+      }
+      int64_t first_bad = 0;
+      const uint8_t *types = sec(j, 11), *sigs = sec(j, 12);
+      const int rc = E.commitment(g_ctx, &t[0], sec(j, 13), sigs, types[0], n - 1, n > 1 ? &t[1] : nullptr, sec(j, 14), sigs + 64, types + 1, &first_bad, outp(j, 16));
+      memcpy(outp(j, 0), &first_bad, 8);
+      engine_error(j, rc);
+      return;
+    }
+    case LAMD_SRV_OP_BOLT12_CHECK:
+    case LAMD_SRV_OP_BOLT12_MERKLE: {
+      const bool check = r.op == LAMD_SRV_OP_BOLT12_CHECK;
+      if (check ? !shape(j, {ANY, 8 * (n + 1), ANY, ANY, 33 * n, 64 * n}, n) : !shape(j, {ANY, 8 * (n + 1), ANY, ANY}, 2 * align16(32 * n) + n)) return;
+      const uint64_t *off = (const uint64_t *)sec(j, 1);
+      for (size_t i = 0; i < n; i++)
+        if (off[i + 1] < off[i] || off[i + 1] > seclen(j, 0)) { fail(j, LAMD_ERR_ARG, "stream offsets outside the blob"); return; }
+      if (!seclen(j, 2) || !seclen(j, 3) || sec(j, 2)[seclen(j, 2) - 1] != 0 || sec(j, 3)[seclen(j, 3) - 1] != 0) { fail(j, LAMD_ERR_ARG, "names must be NUL-terminated"); return; }
+      if (check)
+        engine_error(j, E.bolt12_check(g_ctx, n, sec(j, 0), off, (const char *)sec(j, 2), (const char *)sec(j, 3), sec(j, 4), 33, sec(j, 5), outp(j, 0)));
+      else
+        engine_error(j, E.bolt12_merkle(g_ctx, n, sec(j, 0), off, (const char *)sec(j, 2), (const char *)sec(j, 3), outp(j, 0),
+                                        r.scalar[0] ? outp(j, align16(32 * n)) : nullptr, outp(j, 2 * align16(32 * n))));
+      return;
+    }
+    case LAMD_SRV_OP_RECOVER:
+      if (!shape(j, {32 * n, 64 * n, n}, align16(33 * n) + n)) return;
+      engine_error(j, E.recover(g_ctx, n, sec(j, 0), sec(j, 1), sec(j, 2), outp(j, 0), outp(j, align16(33 * n))));
+      return;
+    case LAMD_SRV_OP_GRIND: {
+      if (!shape(j, {ANY, ANY, 64, 33}, 32)) return;
+      uint32_t rate = 0;
+      uint64_t fee = 0;
+      const int rc = E.grind(g_ctx, sec(j, 0), seclen(j, 0), sec(j, 1), seclen(j, 1), r.scalar[0], r.scalar[1], (uint32_t)r.scalar[2], (uint32_t)r.scalar[3], sec(j, 2),
+                             (uint8_t)r.scalar[4], (int)r.scalar[5], sec(j, 3), &rate, &fee);
+      memcpy(outp(j, 0), &rate, 4);
+      memcpy(outp(j, 8), &fee, 8);
+      engine_error(j, rc);
+      return;
+    }
+    case LAMD_SRV_OP_STATS:
+      g_stats.engine_calls--;
+      if (!shape(j, std::initializer_list<size_t>{}, sizeof g_stats)) return;
+      memcpy(outp(j, 0), &g_stats, sizeof g_stats);
+      j->rep.rc = LAMD_OK;
+      return;
+    default:
+      fail(j, LAMD_ERR_ARG, "unknown operation");
+  }
+}
+
+void engine_loop() {
+  for (;;) {
+    std::vector<job *> round;
+    {
+      std::unique_lock<std::mutex> lk(qmu);
+      qcv.wait(lk, [] { return !Q.empty() || g_quit.load(); });
+      if (g_quit.load() && Q.empty()) return;
+      if (g_linger_us) {  // company for the first job of the round
+        lk.unlock();
+        std::this_thread::sleep_for(std::chrono::microseconds(g_linger_us));
+        lk.lock();
+      }
+      round.assign(Q.begin(), Q.end());
+      Q.clear();
+    }
+    // merge classes: ECDSA by key length, BIP-340; the rest in arrival order
+    std::vector<job *> e33, e65, sch;
+    size_t r33 = 0, r65 = 0, rs = 0;
+    for (job *j : round) {
+      const lamd_srv_req &r = j->req;
+      if (r.op == LAMD_SRV_OP_ECDSA || r.op == LAMD_SRV_OP_SCHNORR) {
+        const size_t n = (size_t)r.n, kl = r.op == LAMD_SRV_OP_SCHNORR ? 32 : (size_t)r.scalar[0];
+        if (!sane_n(j)) continue;
+        if (n == 0) { j->rep.rc = LAMD_OK; continue; }
+        if (r.op == LAMD_SRV_OP_ECDSA && kl != 33 && kl != 65) { fail(j, LAMD_ERR_ARG, "publen must be 33 or 65"); continue; }
+        if (r.op == LAMD_SRV_OP_ECDSA ? !shape(j, {32 * n, 64 * n, kl * n}, n) : !shape(j, {32 * n, 32 * n, 64 * n}, n)) continue;
+        std::vector<job *> &cls = r.op == LAMD_SRV_OP_SCHNORR ? sch : kl == 33 ? e33 : e65;
+        size_t &rows = r.op == LAMD_SRV_OP_SCHNORR ? rs : kl == 33 ? r33 : r65;
+        if (rows + n > g_max_merge && !cls.empty()) {  // a merged batch stays below --max-merge rows
+          run_merged(cls, r.op == LAMD_SRV_OP_SCHNORR);
+          cls.clear();
+          rows = 0;
+        }
+        cls.push_back(j);
+        rows += n;
+      }
+    }
+    run_merged(e33, false);
+    run_merged(e65, false);
+    run_merged(sch, true);
+    for (job *j : round)
+      if (j->req.op != LAMD_SRV_OP_ECDSA && j->req.op != LAMD_SRV_OP_SCHNORR && sane_n(j)) run_one(j);
+    {
+      std::lock_guard<std::mutex> lk(qmu);
+      for (job *j : round) j->done = true;
+      g_stats.requests += round.size();
+    }
+    donecv.notify_all();
+  }
+}
+
+void serve(int fd) {
+  conn c;
+  c.fd = fd;
+  {
+    std::lock_guard<std::mutex> lk(qmu);
+    g_stats.clients_now++;
+    g_stats.clients_total++;
+  }
+  for (;;) {
+    job j;
+    int newfd = -1;
+    if (!recv_with_fd(fd, &j.req, sizeof j.req, &newfd)) break;
+    memset(&j.rep, 0, sizeof j.rep);
+    j.rep.magic = LAMD_SRV_MAGIC;
+    j.c = &c;
+    if (j.req.magic != LAMD_SRV_MAGIC) { if (newfd >= 0) close(newfd); break; }
+    if (j.req.op == LAMD_SRV_OP_SHM) {
+      const size_t sz = (size_t)j.req.scalar[0];
+      struct stat sb;
+      if (newfd < 0 || sz < 4096 || fstat(newfd, &sb) != 0 || (size_t)sb.st_size < sz) {
+        if (newfd >= 0) close(newfd);
+        fail(&j, LAMD_ERR_ARG, "LAMD_SRV_OP_SHM without a usable descriptor");
+      } else {
+        void *p = mmap(nullptr, sz, PROT_READ | PROT_WRITE, MAP_SHARED, newfd, 0);
+        close(newfd);
+        if (p == MAP_FAILED) fail(&j, LAMD_ERR_NOMEM, "mmap of the client's block failed");
+        else {
+          if (c.shm) munmap(c.shm, c.shm_size);
+          c.shm = (uint8_t *)p;
+          c.shm_size = sz;
+          j.rep.rc = LAMD_OK;
+        }
+      }
+      if (!send_all(fd, &j.rep, sizeof j.rep)) break;
+      continue;
+    }
+    if (newfd >= 0) close(newfd);
+    j.out_off = layout(j.req, j.off);
+    if (!c.shm || j.out_off == (size_t)-1 || j.out_off > c.shm_size) {
+      fail(&j, LAMD_ERR_ARG, "request does not fit the shared block");
+    } else {
+      j.rep.out_offset = j.out_off;
+      std::unique_lock<std::mutex> lk(qmu);
+      Q.push_back(&j);
+      qcv.notify_one();
+      donecv.wait(lk, [&] { return j.done; });
+    }
+    if (!send_all(fd, &j.rep, sizeof j.rep)) break;
+  }
+  if (c.shm) munmap(c.shm, c.shm_size);
+  close(fd);
+  std::lock_guard<std::mutex> lk(qmu);
+  g_stats.clients_now--;
+}
+
+int g_listen = -1;
+void on_term(int) {
+  g_quit.store(true);
+  if (g_listen >= 0) shutdown(g_listen, SHUT_RDWR);
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  std::string sock = getenv("LAMD_SERVED_SOCKET") ? getenv("LAMD_SERVED_SOCKET") : LAMD_SRV_DEFAULT_SOCKET, engine;
+  int device = 0;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+    if (a == "--socket") sock = val();
+    else if (a == "--device") device = atoi(val());
+    else if (a == "--engine") engine = val();
+    else if (a == "--max-merge") g_max_merge = (size_t)atoll(val());
+    else if (a == "--linger-us") g_linger_us = (unsigned)atoi(val());
+    else {
+      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N] [--engine LIB] [--max-merge ROWS] [--linger-us US]\n");
+      return 2;
+    }
+  }
+  if (engine.empty()) {  // liblightning_amd.so next to this executable
+    char self[4096];
+    const ssize_t k = readlink("/proc/self/exe", self, sizeof self - 1);
+    std::string dir = k > 0 ? std::string(self, (size_t)k) : std::string(".");
+    dir = dir.substr(0, dir.find_last_of('/'));
+    engine = dir + "/liblightning_amd.so";
+  }
+  E.lib = dlopen(engine.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!E.lib) { fprintf(stderr, "lamd_served: dlopen(%s): %s\n", engine.c_str(), dlerror()); return 1; }
+  bool ok = bind(E.lib, "lamd_init", &E.init) & bind(E.lib, "lamd_shutdown", &E.shutdown) & bind(E.lib, "lamd_last_error", &E.last_error) &
+            bind(E.lib, "lamd_verify_ecdsa_batch", &E.verify_ecdsa) & bind(E.lib, "lamd_verify_schnorr_batch", &E.verify_schnorr) &
+            bind(E.lib, "lamd_pubkey_parse_batch", &E.pubkey_parse) & bind(E.lib, "lamd_sigcheck_gossip_batch", &E.gossip) &
+            bind(E.lib, "lamd_check_tx_sig_tx_batch", &E.txsig_tx) & bind(E.lib, "lamd_check_commitment_signed", &E.commitment) &
+            bind(E.lib, "lamd_bolt12_check_signature_batch", &E.bolt12_check) & bind(E.lib, "lamd_bolt12_merkle_batch", &E.bolt12_merkle) &
+            bind(E.lib, "lamd_ecdsa_recover_batch", &E.recover) & bind(E.lib, "lamd_grind_htlc_tx_fee", &E.grind);
+  if (!ok) return 1;
+  const int rc = E.init(&g_ctx, device);
+  if (rc != LAMD_OK) {
+    fprintf(stderr, "lamd_served: lamd_init(device %d) failed (%d): %s\n", device, rc, g_ctx ? E.last_error(g_ctx) : "no device");
+    if (g_ctx) E.shutdown(g_ctx);
+    return 1;  // no engine, no service: there is no CPU verification to fall back to
+  }
+  memset(&g_stats, 0, sizeof g_stats);
+  g_listen = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+  struct sockaddr_un sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sun_family = AF_UNIX;
+  if (sock.size() >= sizeof sa.sun_path) { fprintf(stderr, "lamd_served: socket path too long\n"); return 1; }
+  strcpy(sa.sun_path, sock.c_str());
+  unlink(sock.c_str());
+  if (g_listen < 0 || bind(g_listen, (struct sockaddr *)&sa, sizeof sa) != 0 || listen(g_listen, 128) != 0) {
+    perror("lamd_served: bind/listen");
+    E.shutdown(g_ctx);
+    return 1;
+  }
+  chmod(sock.c_str(), 0600);  // the daemons of one lightningd run under one user
+  signal(SIGTERM, on_term);
+  signal(SIGINT, on_term);
+  signal(SIGPIPE, SIG_IGN);
+  std::thread eng(engine_loop);
+  printf("lamd_served: ready on %s (device %d, engine %s)\n", sock.c_str(), device, engine.c_str());
+  fflush(stdout);
+  std::vector<std::thread> readers;
+  while (!g_quit.load()) {
+    const int fd = accept4(g_listen, nullptr, nullptr, SOCK_CLOEXEC);
+    if (fd < 0) {
+      if (errno == EINTR) continue;
+      break;
+    }
+    readers.emplace_back(serve, fd);
+  }
+  g_quit.store(true);
+  qcv.notify_all();
+  eng.join();
+  for (auto &t : readers) t.detach();  // blocked in recv on connections their clients still hold; the process is leaving
+  close(g_listen);
+  unlink(sock.c_str());
+  E.shutdown(g_ctx);
+  printf("lamd_served: %llu requests, %llu engine calls, %llu requests in merged calls (largest merge %llu)\n", (unsigned long long)g_stats.requests,
+         (unsigned long long)g_stats.engine_calls, (unsigned long long)g_stats.merged_requests, (unsigned long long)g_stats.largest_merge_requests);
+  fflush(stdout);
+  _exit(0);
+}

@@ -46,9 +46,10 @@ def shard_bounds(n_rows, world, group_sizes=None, weights=None):
 # cost of one gossip message in units of one channel_update under a node id the key-table cache knows, measured on one MI355X (round 5,
 # tools/call_trace_probe.py: 1/8 shards of BASELINE configs[3], T = 0.64 ms + 28.8 ns per channel_announcement / 2.43 ns per channel_update):
 # an announcement is four signatures, four key parses and a 430-byte SHA256d, and two of its signatures are under bitcoin keys that never recur,
-# i.e. on the per-signature ladder -- twelve updates' worth.  With these weights a 1/8 shard of announcements also stays below one full round of
-# the ladder kernel (196 608 lanes): 2 x 83 k cold rows take 1.5 ms, 2 x 104 k (one row over a round for 6 % of the lanes) 2.5 ms.
-GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER = 12, 1
+# i.e. on the per-signature ladder -- ten to twelve updates' worth.  With weight 10 the 1/8 shards of configs[3] come out level (2.85 ms for 87.5 k
+# announcements, 2.9 ms for 875 k updates; with 12: 2.8 against 3.2 ms) and a shard of announcements stays below one full round of the ladder
+# kernel (196 608 lanes): 2 x 87 k cold rows take 1.5 ms, 2 x 104 k (one row over a round for 6 % of the lanes) 2.5 ms.
+GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER = 10, 1
 
 
 def gossip_weights(msgs, off):

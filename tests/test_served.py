@@ -1,0 +1,325 @@
+"""The shared-service front (include/lightning_amd_served.h): lamd_served owns the engine, client processes use it through
+liblightning_amd_client.so -- same C prototypes as the engine library.
+CPU part: the server bound to a stub engine (tests/c/stub_engine.c: verdicts are a fixed function of the input bytes) -- framing of every
+operation, requests of several client PROCESSES merged into one engine call and scattered back, error propagation, fail-closed without a server.
+GPU part (-m gpu): the real engine behind the server, 8 client processes issuing BASELINE configs[4] commitments; verdicts equal the in-process
+engine's and the oracle's."""
+import ctypes
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PER = 484
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint64) for k in ("requests", "engine_calls", "merged_requests", "merged_rows", "largest_merge_requests", "clients_now", "clients_total")]
+
+
+class TxTemplate(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_uint32), ("locktime", ctypes.c_uint32), ("inputs40", ctypes.c_void_p), ("n_inputs", ctypes.c_uint32),
+                ("input_num", ctypes.c_uint32), ("amount_sat", ctypes.c_uint64), ("outputs", ctypes.c_void_p), ("outputs_len", ctypes.c_uint64),
+                ("n_outputs", ctypes.c_uint32), ("script", ctypes.c_void_p), ("script_len", ctypes.c_uint64)]
+
+
+def _client():
+    from lightning_amd import _build
+    L = ctypes.CDLL(_build.build_served()[1])
+    L.lamd_last_error.restype = ctypes.c_char_p
+    L.lamd_last_error.argtypes = [ctypes.c_void_p]
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    L.lamd_init.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    L.lamd_shutdown.argtypes = [vp]
+    L.lamd_verify_ecdsa_batch.argtypes = [vp, sz, vp, vp, vp, sz, sz, vp]
+    L.lamd_verify_schnorr_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.lamd_pubkey_parse_batch.argtypes = [vp, sz, vp, sz, sz, vp, vp]
+    L.lamd_sigcheck_gossip_batch.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.lamd_check_signed_hash.argtypes = [vp, vp, vp, vp, sz]
+    L.lamd_check_schnorr_sig.argtypes = [vp, vp, vp, vp]
+    L.lamd_ecdsa_recover_batch.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+    L.lamd_check_commitment_signed.argtypes = [vp, vp, vp, vp, ctypes.c_uint8, sz, vp, vp, vp, vp, ctypes.POINTER(ctypes.c_int64), vp]
+    L.lamd_grind_htlc_tx_fee.argtypes = [vp, vp, sz, vp, sz, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, vp, ctypes.c_uint8, ctypes.c_int, vp,
+                                         ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]
+    L.lamd_client_server_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    return L
+
+
+def _start(sock, engine=None, extra=()):
+    from lightning_amd import _build
+    exe = _build.build_served()[0]
+    cmd = [exe, "--socket", sock] + (["--engine", engine] if engine else []) + list(extra)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = p.stdout.readline()
+    if "ready" not in line:
+        p.kill()
+        raise RuntimeError("lamd_served did not start: %r %r" % (line, p.stderr.read()))
+    return p
+
+
+def _stop(p):
+    p.terminate()
+    try:
+        out = p.communicate(timeout=20)[0]
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out = ""
+    return out
+
+
+@pytest.fixture(scope="module")
+def stub(tmp_path_factory):
+    d = tmp_path_factory.mktemp("served")
+    so = str(d / "libstub_engine.so")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-o", so, os.path.join(ROOT, "tests", "c", "stub_engine.c")])
+    return so, str(d)
+
+
+def _connect(L, sock):
+    os.environ["LAMD_SERVED_SOCKET"] = sock
+    ctx = ctypes.c_void_p()
+    rc = L.lamd_init(ctypes.byref(ctx), 0)
+    return rc, ctx
+
+
+def _rows(rng, n, w):
+    return np.ascontiguousarray(rng.integers(0, 256, (n, w), dtype=np.uint8))
+
+
+def test_every_operation_round_trips_through_the_server(stub):
+    so, d = stub
+    sock = os.path.join(d, "a.sock")
+    p = _start(sock, so)
+    L = _client()
+    try:
+        rc, ctx = _connect(L, sock)
+        assert rc == 0, L.lamd_last_error(ctx)
+        rng = np.random.default_rng(1)
+        for n, kl in ((1, 33), (484, 33), (5000, 65), (70000, 65)):      # the last one outgrows the first shared block: the client re-attaches a bigger one
+            h, s, k = _rows(rng, n, 32), _rows(rng, n, 64), _rows(rng, n, kl)
+            ok = np.full(n, 9, np.uint8)
+            assert L.lamd_verify_ecdsa_batch(ctx, n, h.ctypes.data, s.ctypes.data, k.ctypes.data, kl, kl, ok.ctypes.data) == 0, L.lamd_last_error(ctx)
+            assert np.array_equal(ok, (h[:, 0] ^ s[:, 63] ^ k[:, kl - 1]) & 1)
+        # a strided key array is packed by the client
+        h, s, k = _rows(rng, 50, 32), _rows(rng, 50, 64), _rows(rng, 50, 80)
+        ok = np.zeros(50, np.uint8)
+        assert L.lamd_verify_ecdsa_batch(ctx, 50, h.ctypes.data, s.ctypes.data, k.ctypes.data, 33, 80, ok.ctypes.data) == 0
+        assert np.array_equal(ok, (h[:, 0] ^ s[:, 63] ^ k[:, 32]) & 1)
+        m, x, sg = _rows(rng, 300, 32), _rows(rng, 300, 32), _rows(rng, 300, 64)
+        ok = np.zeros(300, np.uint8)
+        assert L.lamd_verify_schnorr_batch(ctx, 300, m.ctypes.data, x.ctypes.data, sg.ctypes.data, ok.ctypes.data) == 0
+        assert np.array_equal(ok, (m[:, 1] ^ x[:, 2] ^ sg[:, 3]) & 1)
+        # single-item veneers: 1 / 0, the BIP-340 one drops the parity byte of the 33-byte key
+        assert L.lamd_check_signed_hash(ctx, h[0].ctypes.data, s[0].ctypes.data, k[0].ctypes.data, 33) == int((h[0, 0] ^ s[0, 63] ^ k[0, 32]) & 1)
+        k33 = _rows(rng, 1, 33)
+        assert L.lamd_check_schnorr_sig(ctx, m[0].ctypes.data, k33.ctypes.data, sg[0].ctypes.data) == int((m[0, 1] ^ k33[0, 3] ^ sg[0, 3]) & 1)
+        # key parse: two output sections
+        pk = _rows(rng, 40, 33)
+        pk[:, 0] = rng.integers(1, 6, 40)
+        xy, ok = np.zeros((40, 64), np.uint8), np.zeros(40, np.uint8)
+        assert L.lamd_pubkey_parse_batch(ctx, 40, pk.ctypes.data, 33, 33, xy.ctypes.data, ok.ctypes.data) == 0
+        assert np.array_equal(ok, np.isin(pk[:, 0], (2, 3, 4)).astype(np.uint8)) and np.array_equal(xy[:, :32], pk[:, 1:33])
+        assert L.lamd_pubkey_parse_batch(ctx, 40, pk.ctypes.data, 33, 33, None, ok.ctypes.data) == 0
+        # gossip: blob + offsets (made relative by the client) + node ids
+        lens = rng.integers(3, 500, 60)
+        blob = _rows(rng, int(lens.sum()) + 7, 1).reshape(-1)
+        off = (np.concatenate([[0], np.cumsum(lens)]) + 7).astype(np.uint64)
+        ids = _rows(rng, 60, 33)
+        v = np.zeros(60, np.int8)
+        assert L.lamd_sigcheck_gossip_batch(ctx, 60, blob.ctypes.data, off.ctypes.data, ids.ctypes.data, v.ctypes.data) == 0
+        assert np.array_equal(v, ((blob[off[:-1].astype(np.int64) + 2] & 3) + (ids[:, 0] & 1)).astype(np.int8))
+        # recovery
+        rid = rng.integers(0, 4, 30).astype(np.uint8)
+        pub, ok = np.zeros((30, 33), np.uint8), np.zeros(30, np.uint8)
+        hh, ss = _rows(rng, 30, 32), _rows(rng, 30, 64)
+        assert L.lamd_ecdsa_recover_batch(ctx, 30, hh.ctypes.data, ss.ctypes.data, rid.ctypes.data, pub.ctypes.data, ok.ctypes.data) == 0
+        assert np.array_equal(pub[:, 1:], hh ^ ss[:, :32]) and np.array_equal(pub[:, 0], 2 + (rid & 1)) and ok.all()
+        # one commitment_signed: templates flattened by the client, rebuilt by the server
+        n_htlc = 483
+        bufs, tm = [], (TxTemplate * (n_htlc + 1))()
+        expect = []
+        sigs, types = _rows(rng, n_htlc + 1, 64), rng.choice([1, 0x83], n_htlc + 1).astype(np.uint8)
+        fund, hkey = _rows(rng, 1, 33), _rows(rng, 1, 33)
+        for i in range(n_htlc + 1):
+            ins, outs, sc = _rows(rng, 1, 40), _rows(rng, 1, int(rng.integers(9, 60))), _rows(rng, 1, int(rng.integers(1, 140)))
+            bufs += [ins, outs, sc]
+            tm[i] = TxTemplate(int(rng.integers(1, 3)), int(rng.integers(0, 1 << 30)), ins.ctypes.data, 1, 0, int(rng.integers(1, 1 << 40)), outs.ctypes.data, outs.shape[1], 1,
+                               sc.ctypes.data, sc.shape[1])
+            key = fund if i == 0 else hkey
+            expect.append(int((tm[i].version ^ tm[i].amount_sat ^ int(types[i]) ^ int(sigs[i, 0]) ^ int(key[0, 1]) ^ int(ins[0, 0]) ^ int(outs[0, -1]) ^ int(sc[0, 0])) & 1))
+        fb = ctypes.c_int64(7)
+        okr = np.zeros(n_htlc + 1, np.uint8)
+        rc = L.lamd_check_commitment_signed(ctx, ctypes.addressof(tm), fund.ctypes.data, sigs[0].ctypes.data, int(types[0]), n_htlc, ctypes.addressof(tm) + ctypes.sizeof(TxTemplate),
+                                            hkey.ctypes.data, sigs[1:].ctypes.data, types[1:].ctypes.data, ctypes.byref(fb), okr.ctypes.data)
+        assert rc == 0, L.lamd_last_error(ctx)
+        assert list(okr) == expect and fb.value == (expect.index(0) if 0 in expect else -1)
+        # grind: scalars in the header, the answer in the reply's rc
+        pre, outs = _rows(rng, 1, 290), _rows(rng, 1, 43)
+        rate, fee = ctypes.c_uint32(0), ctypes.c_uint64(0)
+        assert L.lamd_grind_htlc_tx_fee(ctx, pre.ctypes.data, 290, outs.ctypes.data, 43, 700000, 663, 100, 250000, sigs[0].ctypes.data, 1, 1, fund.ctypes.data,
+                                        ctypes.byref(rate), ctypes.byref(fee)) == 1
+        assert rate.value == 100 + (290 + 43) % (250000 - 100 + 1) and fee.value == rate.value * 663 // 1000 + 700000 % 7
+        assert L.lamd_grind_htlc_tx_fee(ctx, pre.ctypes.data, 290, outs.ctypes.data, 43, 700000, 663, 100, 250000, sigs[0].ctypes.data, 1, 0, fund.ctypes.data,
+                                        ctypes.byref(rate), ctypes.byref(fee)) == 0
+        # an engine error travels back with its text; the connection stays usable
+        h = _rows(rng, 4, 32)
+        h[0, :2] = 0xEE
+        ok = np.zeros(4, np.uint8)
+        assert L.lamd_verify_ecdsa_batch(ctx, 4, h.ctypes.data, s.ctypes.data, k.ctypes.data, 33, 80, ok.ctypes.data) == -2
+        assert b"poisoned" in L.lamd_last_error(ctx)
+        st = Stats()
+        assert L.lamd_client_server_stats(ctx, ctypes.byref(st)) == 0 and st.clients_now == 1 and st.requests >= 15
+        L.lamd_shutdown(ctx)
+    finally:
+        _stop(p)
+
+
+CLIENT_SCRIPT = r"""
+import ctypes, os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import test_served as T
+L = T._client()
+rc, ctx = T._connect(L, sys.argv[2])
+assert rc == 0, L.lamd_last_error(ctx)
+rng = np.random.default_rng(int(sys.argv[3]))
+bad = 0
+for it in range(int(sys.argv[4])):
+    n = T.PER
+    h, s, k = T._rows(rng, n, 32), T._rows(rng, n, 64), T._rows(rng, n, 33)
+    ok = np.full(n, 9, np.uint8)
+    assert L.lamd_verify_ecdsa_batch(ctx, n, h.ctypes.data, s.ctypes.data, k.ctypes.data, 33, 33, ok.ctypes.data) == 0
+    bad += int((ok != ((h[:, 0] ^ s[:, 63] ^ k[:, 32]) & 1)).sum())
+    if it % 5 == 0:
+        m, x, sg = T._rows(rng, 64, 32), T._rows(rng, 64, 32), T._rows(rng, 64, 64)
+        ok = np.zeros(64, np.uint8)
+        assert L.lamd_verify_schnorr_batch(ctx, 64, m.ctypes.data, x.ctypes.data, sg.ctypes.data, ok.ctypes.data) == 0
+        bad += int((ok != ((m[:, 1] ^ x[:, 2] ^ sg[:, 3]) & 1)).sum())
+L.lamd_shutdown(ctx)
+print("bad", bad)
+"""
+
+
+def test_requests_of_eight_client_processes_are_merged_and_scattered_back(stub):
+    so, d = stub
+    sock = os.path.join(d, "b.sock")
+    p = _start(sock, so, ["--linger-us", "300"])
+    try:
+        procs = [subprocess.Popen([sys.executable, "-c", CLIENT_SCRIPT, ROOT, sock, str(100 + i), "40"], stdout=subprocess.PIPE, text=True) for i in range(8)]
+        outs = [q.communicate(timeout=120)[0] for q in procs]
+        assert all(q.returncode == 0 for q in procs) and all(o.strip().endswith("bad 0") for o in outs), outs
+        L = _client()
+        rc, ctx = _connect(L, sock)
+        assert rc == 0
+        st = Stats()
+        assert L.lamd_client_server_stats(ctx, ctypes.byref(st)) == 0
+        L.lamd_shutdown(ctx)
+        # 8 x (40 + 8) verification requests; with eight clients waiting at once most of them travelled in merged calls
+        assert st.clients_total == 9 and st.requests >= 8 * 48
+        assert st.merged_requests >= 100 and st.largest_merge_requests >= 3 and st.engine_calls < st.requests
+    finally:
+        out = _stop(p)
+    assert "requests" in out
+
+
+def test_without_a_server_everything_fails_closed(stub, tmp_path):
+    L = _client()
+    rc, ctx = _connect(L, str(tmp_path / "nobody.sock"))
+    assert rc == -1 and b"no lamd_served" in L.lamd_last_error(ctx)
+    L.lamd_shutdown(ctx)
+    # ... and so does the mirror built on the client library: check_signed_hash() is false, sigcheck_* returns an "engine error" string
+    from lightning_amd import _build
+    shim = ctypes.CDLL(_build.build_served()[2])
+    shim.lamd_shim_setup.restype = ctypes.c_bool
+    shim.check_signed_hash.restype = ctypes.c_bool
+    shim.lamd_shim_last_error.restype = ctypes.c_char_p
+    assert shim.lamd_shim_setup() is False and b"no lamd_served" in shim.lamd_shim_last_error()
+    buf = ctypes.create_string_buffer(64)
+    assert shim.check_signed_hash(buf, buf, buf) is False
+    # a server whose engine has no device does not come up at all (there is no CPU verification to serve)
+    so, d = stub
+    from lightning_amd import _build as b2
+    r = subprocess.run([b2.build_served()[0], "--socket", os.path.join(d, "c.sock"), "--engine", so, "--device", "99"], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 1 and "lamd_init" in r.stderr
+
+
+GPU_CLIENT_SCRIPT = r"""
+import ctypes, os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import test_served as T
+L = T._client()
+rc, ctx = T._connect(L, sys.argv[2])
+assert rc == 0, L.lamd_last_error(ctx)
+d = np.load(sys.argv[3])
+h, s, k, e = d["h"], d["s"], d["k"], d["e"]
+bad = 0
+for rep in range(int(sys.argv[4])):
+    for a in range(0, len(h), T.PER):
+        z = min(len(h), a + T.PER)
+        ok = np.full(z - a, 9, np.uint8)
+        assert L.lamd_verify_ecdsa_batch(ctx, z - a, h[a:z].ctypes.data, s[a:z].ctypes.data, k[a:z].ctypes.data, 33, 33, ok.ctypes.data) == 0, L.lamd_last_error(ctx)
+        bad += int((ok != e[a:z]).sum())
+L.lamd_shutdown(ctx)
+print("bad", bad)
+"""
+
+
+@pytest.mark.gpu
+def test_eight_client_processes_share_one_engine(orc, kat, tmp_path):
+    """the real engine behind lamd_served: 8 client processes, each validating its own channels' commitments (1 + 483 signatures per request, the htlc key
+    recurring) -- every verdict equals the oracle's, the server merged concurrent requests into shared launches, and the mirror over the client
+    library (liblightning_amd_cln_client.so) gives the reference's answers"""
+    sock = str(tmp_path / "gpu.sock")
+    p = _start(sock)
+    try:
+        files = []
+        for i in range(8):
+            n = PER * 6
+            h, s, k, c, e = orc.gen_ecdsa_edge_batch(0x5E12 + i, n, 33, 4)
+            # commitments: the 483 HTLC rows of a request under ONE key (rows re-signed is not possible here, so the expected verdict follows the oracle)
+            f = str(tmp_path / ("rows%d.npz" % i))
+            np.savez(f, h=h, s=s, k=k, e=e.astype(np.uint8))
+            files.append(f)
+        procs = [subprocess.Popen([sys.executable, "-c", GPU_CLIENT_SCRIPT, ROOT, sock, files[i], "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(8)]
+        outs = [q.communicate(timeout=300) for q in procs]
+        assert all(q.returncode == 0 for q in procs), [o[1][-400:] for o in outs]
+        assert all(o[0].strip().endswith("bad 0") for o in outs), [o[0] for o in outs]
+        L = _client()
+        rc, ctx = _connect(L, sock)
+        assert rc == 0
+        st = Stats()
+        assert L.lamd_client_server_stats(ctx, ctypes.byref(st)) == 0
+        assert st.requests >= 8 * 18 and st.merged_requests > 0 and st.engine_calls < st.requests
+        # goldens through the client: ECDSA, BIP-340, a reference-signed gossip message
+        H = bytes.fromhex
+        for v in [v for v in kat["ecdsa"] if len(v["pub"]) == 66][:40]:
+            assert L.lamd_check_signed_hash(ctx, H(v["hash"]), H(v["sig"]), H(v["pub"]), 33) == int(v["expect"]), v["name"]
+        for v in kat["schnorr"][:15]:
+            ok = np.zeros(1, np.uint8)
+            assert L.lamd_verify_schnorr_batch(ctx, 1, H(v["msg"]), H(v["pk"]), H(v["sig"]), ok.ctypes.data) == 0
+            assert bool(ok[0]) == v["expect"], v["name"]
+        L.lamd_shutdown(ctx)
+        # the mirror over the client library: the reference's unit-test expectation (gossipd/test/run-check_channel_announcement.c:84-85)
+        from lightning_amd import _build
+        from test_cln_shim import _cann_args, _cann_call
+        shim = ctypes.CDLL(_build.build_served()[2])
+        for nme in ("lamd_shim_setup", "pubkey_from_der", "fromwire_secp256k1_ecdsa_signature"):
+            getattr(shim, nme).restype = ctypes.c_bool
+        shim.sigcheck_channel_announcement_len.restype = ctypes.c_char_p
+        shim.sigcheck_channel_announcement_len.argtypes = [ctypes.c_void_p] * 10 + [ctypes.c_size_t]
+        shim.lamd_shim_last_error.restype = ctypes.c_char_p
+        assert shim.lamd_shim_setup(), shim.lamd_shim_last_error()
+        m = H(next(v for v in kat["gossip"] if v["name"] == "KAT-G/orig")["msg"])
+        sigs, ids, keys = _cann_args(shim, m)
+        err = _cann_call(shim, sigs, ids, keys, m)
+        assert err is not None and err.startswith(b"Bad node_signature_1 3044022011effc9ed10f")
+        good = H(next(v for v in kat["gossip"] if v["kind"] == "channel_announcement" and v["expect"] == 0)["msg"])
+        sigs, ids, keys = _cann_args(shim, good)
+        assert _cann_call(shim, sigs, ids, keys, good) is None
+    finally:
+        _stop(p)
