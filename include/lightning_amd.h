@@ -102,6 +102,9 @@ int lamd_stream_wait_results(lamd_ctx *ctx, void *stream);
  * holds up every other stream that shares the queue (bench.py's collective path: the all-gather of step k is issued after the
  * calls of step k+1). */
 int lamd_results_mark(lamd_ctx *ctx, int slot);
+/* ... "the call submitted last" only: ONE event, on the lane that ran it -- what the consumer of that call's verdict buffer needs (bench.py's
+ * per-call all-gathers); lamd_stream_wait_mark() then waits for that one event. */
+int lamd_results_mark_last(lamd_ctx *ctx, int slot);
 int lamd_stream_wait_mark(lamd_ctx *ctx, int slot, void *stream);
 /* verification submitted from now on waits, on the device, for what `stream` holds at this moment */
 int lamd_wait_stream(lamd_ctx *ctx, void *stream);

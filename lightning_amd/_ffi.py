@@ -80,6 +80,7 @@ SYMBOLS = {
     "lamd_wait_event": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_queue_reserve": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz] + [ctypes.POINTER(ctypes.c_void_p)] * 3),
     "lamd_results_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "lamd_results_mark_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     # several devices behind one process (lamd_multi.cpp)
     "lamd_multi_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.c_int]),

@@ -1252,7 +1252,7 @@ struct lamd_ctx {
   u8 *h_tmpl = nullptr;       // pinned, device-mapped: the transaction templates of a lamd_check_commitment_signed call (read by k_txsig_tx_hash)
   size_t h_tmpl_cap = 0;
   devbuf small_done;          // block counter of k_small_verify grids (device memory)
-  std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, direct-mapped)
+  std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, 4-way set-associative)
   u32 prio_mask = LAMD_PRIO_DEFAULT; // LAMD_PRIO: which kernel classes raise their wave priority (g_prio)
   unsigned spin_us = 2000;         // LAMD_SPIN_US: longest busy-wait of a latency-path call before it blocks in the runtime
   std::vector<u64> learn_fps;      // the fingerprints that recurred in the call that set force_learn: only these keys get tables (learn_filter)
@@ -1345,6 +1345,7 @@ struct lamd_ctx {
   static const int MARK_SLOTS = 4;
   hipEvent_t ev_mark[MARK_SLOTS][MAX_LANES + 1] = {};  // lamd_results_mark(): one event per lane stream (+ the context's own)
   bool mark_set[MARK_SLOTS] = {};
+  int mark_only[MARK_SLOTS] = {-1, -1, -1, -1};  // lamd_results_mark_last(): the one lane whose event the slot holds (-1: every lane's)
   static const int KEV = 64;
   hipEvent_t kev[KEV][2] = {};
   int kev_mode[KEV] = {};
@@ -1840,6 +1841,24 @@ extern "C" int lamd_results_mark(lamd_ctx *ctx, int slot) {
     HIPCHK(ctx, hipEventRecord(e, L->stream));
   }
   ctx->mark_set[slot] = true;
+  ctx->mark_only[slot] = -1;
+  return LAMD_OK;
+}
+// the same for the call submitted LAST only: one event, on the lane that ran it (a call's verdict copy is the last thing on its lane, chunks on
+// the peer lane joined before it).  A consumer of that call's verdicts needs no more; marking every lane costs seven event records per call
+// and makes the consumer wait for whatever the other lanes were doing.
+extern "C" int lamd_results_mark_last(lamd_ctx *ctx, int slot) {
+  if (!ctx || slot < 0 || slot >= lamd_ctx::MARK_SLOTS) return LAMD_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int idx = MAX_LANES;
+  lamd_ctx *L = ctx;
+  for (int i = 0; i < MAX_LANES; i++)
+    if (ctx->lane[i] && ctx->lane[i] == ctx->last_lane) { idx = i; L = ctx->lane[i]; }
+  hipEvent_t &e = ctx->ev_mark[slot][idx];
+  if (!e) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(ctx, hipEventRecord(e, L->stream));
+  ctx->mark_set[slot] = true;
+  ctx->mark_only[slot] = idx;
   return LAMD_OK;
 }
 extern "C" int lamd_stream_wait_mark(lamd_ctx *ctx, int slot, void *stream) {
@@ -1847,6 +1866,10 @@ extern "C" int lamd_stream_wait_mark(lamd_ctx *ctx, int slot, void *stream) {
   if (!ctx->mark_set[slot]) {
     ctx->err = "lamd_stream_wait_mark: slot was never marked";
     return LAMD_ERR_STATE;
+  }
+  if (ctx->mark_only[slot] >= 0) {
+    HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_mark[slot][ctx->mark_only[slot]], 0));
+    return LAMD_OK;
   }
   for (int i = 0; i <= MAX_LANES; i++)
     if (ctx->ev_mark[slot][i]) HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->ev_mark[slot][i], 0));
@@ -2528,9 +2551,29 @@ constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG +
 // Keys that the latency path had to take down the ladder are remembered by fingerprint (host side, direct-mapped): the SECOND small
 // call that brings such a key takes the table-building path once (every key the cache misses gets a comb and is published), and
 // from then on the key is a cache hit -- a peer's node id or a channel's keys recur with every single check_signed_hash() call.
-// (direct-mapped: two keys that share a slot evict each other's fingerprint on every pass and neither is ever learnt -- with 4096 slots that
-// hit 9 % of 400 recurring channel keys, the slow tail of the one-commitment-per-flush latency; 65 536 slots: 0.6 %)
-constexpr size_t MISS_SLOTS = 65536;
+// The table is 4-way set-associative.  Rounds 3-4 had it direct-mapped with 4096 slots: two keys that share a slot evict each other's
+// fingerprint on every pass and NEITHER is ever learnt -- 9 % of 400 recurring channel keys, the 0.8 ms tail of the one-commitment-per-flush
+// latency (p50 0.14 ms); 65 536 direct-mapped slots still left one or two such pairs per run (the same channels slow in every pass).
+constexpr size_t MISS_SLOTS = 65536, MISS_WAYS = 4;
+static inline u64 *miss_bucket(std::vector<u64> &t, u64 fp) { return &t[((fp >> 1) % (MISS_SLOTS / MISS_WAYS)) * MISS_WAYS]; }
+static inline bool miss_has(std::vector<u64> &t, u64 fp) {
+  const u64 *b = miss_bucket(t, fp);
+  return b[0] == fp || b[1] == fp || b[2] == fp || b[3] == fp;
+}
+static inline void miss_put(std::vector<u64> &t, u64 fp) {
+  u64 *b = miss_bucket(t, fp);
+  for (size_t w = 0; w < MISS_WAYS; w++)
+    if (b[w] == fp) return;
+  for (size_t w = 0; w < MISS_WAYS; w++)
+    if (b[w] == 0) { b[w] = fp; return; }
+  b[(fp >> 40) % MISS_WAYS] = fp;  // a full bucket: five waiting keys in one of 16 384 buckets
+}
+static inline bool miss_take(std::vector<u64> &t, u64 fp) {  // present -> removed, true
+  u64 *b = miss_bucket(t, fp);
+  for (size_t w = 0; w < MISS_WAYS; w++)
+    if (b[w] == fp) { b[w] = 0; return true; }
+  return false;
+}
 __host__ __device__ static inline u64 small_fingerprint(u64 seed, const u8 *key, int keylen) {
   u64 h = seed ^ 0x6D697373ull;
   for (int o = 0; o < keylen; o += 8) {
@@ -2550,11 +2593,7 @@ static void small_forget(lamd_ctx *ctx, lamd_ctx *dst, const u8 *key, size_t key
   for (size_t i = 0; i < n; i++) {
     if (i && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0) continue;
     const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
-    u64 &slot = ctx->small_missed[(fp >> 1) % MISS_SLOTS];
-    if (slot == fp) {
-      slot = 0;
-      dst->learn_fps.push_back(fp);
-    }
+    if (miss_take(ctx->small_missed, fp)) dst->learn_fps.push_back(fp);
   }
 }
 // d_a32 / d_gate (optional, device memory): the rows' hashes were produced on the device by a kernel queued in front on ctx->stream (`a` is not
@@ -2579,7 +2618,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
     for (size_t i = 0; i < n && !learn; i++) {
       if (i && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0) continue;  // a commitment's rows share their key
       const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
-      learn = ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp;  // seen before without a table: the caller takes the learning path
+      learn = miss_has(ctx->small_missed, fp);  // seen before without a table: the caller takes the learning path
     }
     if (learn) {
       small_forget(ctx, ctx, key, keystride, keylen, n);
@@ -2658,7 +2697,7 @@ static int run_small(lamd_ctx *ctx, int mode, size_t n, const u8 *a, const u8 *s
     for (size_t i = 0; i < n; i++)
       if (h[SMALL_OFF_SHAPES + i] == 255 && !(i && h[SMALL_OFF_SHAPES + i - 1] == 255 && memcmp(key + i * keystride, key + (i - 1) * keystride, keylen) == 0)) {
         const u64 fp = small_fingerprint(ctx->hash_seed, key + i * keystride, keylen);
-        ctx->small_missed[(fp >> 1) % MISS_SLOTS] = fp;
+        miss_put(ctx->small_missed, fp);
       }
   }
   {  // what lamd_get_info() reports about the last call
@@ -3534,7 +3573,7 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
       for (size_t i = 0; i < q.n && !learn; i++) {
         if (i && memcmp(q.h_c + i * kb, q.h_c + (i - 1) * kb, kb) == 0) continue;
         const u64 fp = small_fingerprint(ctx->hash_seed, q.h_c + i * kb, (int)kb);
-        learn = ctx->small_missed[(fp >> 1) % MISS_SLOTS] == fp;
+        learn = miss_has(ctx->small_missed, fp);
       }
       if (learn) {
         L->force_learn = true;
@@ -3696,7 +3735,7 @@ static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
       for (size_t i = 0; i < q.n; i++)
         if (shapes[i] == 255 && !(i && shapes[i - 1] == 255 && memcmp(q.h_c + i * kb, q.h_c + (i - 1) * kb, kb) == 0)) {
           const u64 fp = small_fingerprint(ctx->hash_seed, q.h_c + i * kb, (int)kb);
-          ctx->small_missed[(fp >> 1) % MISS_SLOTS] = fp;
+          miss_put(ctx->small_missed, fp);
         }
     }
     q.small_flush = false;

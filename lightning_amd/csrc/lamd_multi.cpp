@@ -131,11 +131,20 @@ int eng_open(void *user, int device, void **handle) {
     delete d;
     return LAMD_ERR_HIP;
   }
-  size_t slot = 8u << 20;  // LAMD_MULTI_PINNED = bytes per staging slot (0: off)
+  // LAMD_MULTI_PINNED = bytes per staging slot; default 0 = no ring: on one MI355X the runtime's own pageable path measured FASTER than the ring
+  // (105-113 against 96-103 M ECDSA-65 rows/s for a 1 M-row call, helper thread included: profiles/r05_ab_variants.txt) -- both are bound by
+  // one or two cores copying out of pageable memory.  What does pay is caller memory that is ALREADY page-locked: eng_h2d sends it as one
+  // asynchronous copy per array (no staging, the thread does not wait).
+  size_t slot = 0;
   if (const char *e = getenv("LAMD_MULTI_PINNED")) slot = (size_t)atoll(e);
+  if (hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) != hipSuccess) {
+    st->fail("hipStreamCreate failed");
+    *handle = d;
+    return LAMD_ERR_HIP;
+  }
   if (slot) {
     if (slot < (64u << 10)) slot = 64u << 10;
-    bool ok = hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = true;
     for (int k = 0; k < eng_dev::SLOTS && ok; k++)
       ok = hipHostMalloc((void **)&d->pin[k], slot, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&d->pin_ev[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -178,16 +187,16 @@ void eng_free(void *, void *handle, void *p) {
 }
 int eng_h2d(void *user, void *handle, void *dst, const void *src, size_t bytes) {
   eng_dev *d = (eng_dev *)handle;
-  if (d->pin_bytes) {
-    if (hipSetDevice(d->device) != hipSuccess) { ((eng_state *)user)->fail("hipSetDevice failed"); return LAMD_ERR_HIP; }
-    if (bytes >= (1u << 20) && is_pinned_host(src)) {  // page-locked caller memory: one asynchronous copy, no staging
-      if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->cstream) != hipSuccess) {
-        ((eng_state *)user)->fail("H2D from pinned caller memory failed (device " + std::to_string(d->device) + ")");
-        return LAMD_ERR_HIP;
-      }
-      d->copies_pending = true;
-      return LAMD_OK;
+  if (hipSetDevice(d->device) != hipSuccess) { ((eng_state *)user)->fail("hipSetDevice failed"); return LAMD_ERR_HIP; }
+  if (bytes >= (1u << 20) && is_pinned_host(src)) {  // page-locked caller memory: one asynchronous copy, no staging
+    if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->cstream) != hipSuccess) {
+      ((eng_state *)user)->fail("H2D from pinned caller memory failed (device " + std::to_string(d->device) + ")");
+      return LAMD_ERR_HIP;
     }
+    d->copies_pending = true;
+    return LAMD_OK;
+  }
+  if (d->pin_bytes) {
     for (size_t o = 0; o < bytes;) {
       const unsigned k = d->pin_next++ % eng_dev::SLOTS;
       const size_t c = bytes - o < d->pin_bytes ? bytes - o : d->pin_bytes;
@@ -210,7 +219,7 @@ int eng_h2d(void *user, void *handle, void *dst, const void *src, size_t bytes) 
     return LAMD_OK;
   }
   // synchronous: the caller's memory is pageable, the runtime stages it; the engine's (asynchronous) kernels of the chunk before run meanwhile
-  if (hipSetDevice(((eng_dev *)handle)->device) != hipSuccess || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
     ((eng_state *)user)->fail("hipMemcpy H2D failed (device " + std::to_string(((eng_dev *)handle)->device) + ")");
     return LAMD_ERR_HIP;
   }

@@ -374,6 +374,10 @@ class Engine:
         """remember "everything submitted so far" in slot 0..3 (no waiting); see stream_wait_mark"""
         self._chk(self._lib.lamd_results_mark(self._ctx, int(slot)))
 
+    def results_mark_last(self, slot):
+        """lamd_results_mark_last: one event, on the lane of the call submitted last"""
+        self._chk(self._lib.lamd_results_mark_last(self._ctx, slot))
+
     def stream_wait_mark(self, slot, stream_ptr):
         """make a caller's HIP stream wait (on the device) for the work remembered by results_mark(slot)"""
         self._chk(self._lib.lamd_stream_wait_mark(self._ctx, int(slot), ctypes.c_void_p(stream_ptr)))

@@ -26,6 +26,14 @@ def main():
     reps = (n + base - 1) // base
     H, S, P = (np.ascontiguousarray(np.tile(x, (reps, 1))[:n]) for x in (h, s, p))
     E = np.tile(e, reps)[:n]
+    if os.environ.get("PROBE_PINNED_CALLER", "0") == "1":   # the caller's rows in page-locked memory (torch's pinned allocator): no staging at all
+        keep = []
+        def pin(a):
+            t = torch.empty(a.shape, dtype=torch.uint8, pin_memory=True)
+            t.numpy()[:] = a
+            keep.append(t)
+            return t.numpy()
+        H, S, P = pin(H), pin(S), pin(P)
     m = ctypes.c_void_p()
     assert lib.lamd_multi_init(ctypes.byref(m), None, ndev) == 0, lib.lamd_multi_last_error(m)
     ok = np.zeros(n, np.uint8)
