@@ -139,7 +139,7 @@ long lamd_gossipd_prune(lamd_gossipd *g);
  * store starts with the uuid record).  Store events carry the record's offset in values[0] (the offset gossip_store_add()
  * returns: of the message, after its header).  Valid until the next call that changes the ingest. */
 size_t lamd_gossipd_store_image(const lamd_gossipd *g, const uint8_t **data);
-void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now);
+void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now);   /* called from an event callback: takes effect when lamd_gossipd_process() returns */
 
 typedef struct lamd_gossipd_stats {
 	uint64_t messages;          /* applied so far */

@@ -892,6 +892,11 @@ struct lamd_gossipd {
   }
   int fault_rc = LAMD_OK;     // set by verdict_of(): an engine error during the ordered replay (never a peer-visible warning)
   bool in_process = false;    // lamd_gossipd_process() is applying a batch: callbacks must not re-enter the state-changing entry points
+  bool deferred_now = false, deferred_be = false;   // set_time / set_backend called from a callback: applied when process() returns
+  uint64_t d_now = 0;
+  lamd_gossipd_sigcheck_fn d_be_sig = nullptr;
+  lamd_gossipd_keyparse_fn d_be_key = nullptr;
+  void *d_be_user = nullptr;
 
   struct slotlist {
     std::vector<mview> msg;
@@ -1190,6 +1195,7 @@ struct lamd_gossipd {
   // one-by-one path (run_ok()).  Everything that is not a plain update of a known channel also stays on that path.
   static constexpr u32 RUN_NONE = 0xFFFFFFFFu;
   size_t run_min = 2048;    // LAMD_INGEST_RUN_MIN: shortest run worth the four passes
+  size_t sub_rows = 131072; // LAMD_INGEST_SUB: messages per sub-batch of the three-stage pipeline
   bool run_ok() const { return run_min != 0 && !(on_event && cfg.emit_store_writes); }
   bool run_member(const planned &p, const queued &q, const std::vector<int8_t> &v) const {
     return p.type == GOSSIP_CUPD && !p.malformed && p.pc && p.slot >= 0 && p.signer == &p.pc->node[q.msg[111] & 1] && v[p.slot] != -2;
@@ -1714,6 +1720,8 @@ extern "C" lamd_gossipd *lamd_gossipd_new(lamd_ctx *ctx, const lamd_gossipd_conf
   g->on_event = on_event;
   g->user = user;
   memset(&g->st, 0, sizeof g->st);
+  if (const char *e = getenv("LAMD_INGEST_SUB")) g->sub_rows = (size_t)atoll(e) < 1 ? 1 : (size_t)atoll(e);
+  if (const char *e = getenv("LAMD_INGEST_RUN_MIN")) g->run_min = (size_t)atoll(e);
   g->store_init();
   return g;
 }
@@ -1725,13 +1733,25 @@ extern "C" void lamd_gossipd_free(lamd_gossipd *g) {
   free_stages(g->w_stage);
   delete g;
 }
+// Both setters are DEFERRED while lamd_gossipd_process() runs (an event callback may call them): the planning thread reads cfg.now through
+// timestamp_reasonable() and the verify thread the back end's pointers -- plan and apply of one batch must see one clock and one back end.  The new
+// values take effect when process() returns.
 extern "C" void lamd_gossipd_set_backend(lamd_gossipd *g, lamd_gossipd_sigcheck_fn sigcheck, lamd_gossipd_keyparse_fn keyparse, void *user) {
   if (!g) return;
+  if (g->in_process) {
+    g->deferred_be = true;
+    g->d_be_sig = sigcheck; g->d_be_key = keyparse; g->d_be_user = user;
+    return;
+  }
   g->be_sig = sigcheck;
   g->be_key = keyparse;
   g->be_user = user;
 }
-extern "C" void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now) { if (g) g->cfg.now = now; }
+extern "C" void lamd_gossipd_set_time(lamd_gossipd *g, uint64_t now) {
+  if (!g) return;
+  if (g->in_process) { g->deferred_now = true; g->d_now = now; return; }
+  g->cfg.now = now;
+}
 
 extern "C" int lamd_gossipd_push(lamd_gossipd *g, const uint8_t *source_peer33, const uint8_t *msg, size_t len) {
   if (!g || (!msg && len) || len > 0xFFFFFFFFu) return LAMD_ERR_ARG;
@@ -1955,9 +1975,7 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   // outcome, four signatures wasted on a re-announcement.)  Planning from the maps as they stood a sub-batch earlier is what the single-batch
   // form does for the WHOLE queue: the apply pass re-checks every filter that state can change, and a pair the plan did not foresee is verified
   // late (stats.late_verifies).
-  size_t sub = 131072;
-  if (const char *e = getenv("LAMD_INGEST_SUB")) sub = (size_t)atoll(e) < 1 ? 1 : (size_t)atoll(e);
-  if (const char *e = getenv("LAMD_INGEST_RUN_MIN")) g->run_min = (size_t)atoll(e);
+  const size_t sub = g->sub_rows;   // (LAMD_INGEST_SUB / _RUN_MIN are read once, in lamd_gossipd_new)
   const size_t nsub = (n + sub - 1) / sub;
   if (!g->w_stage) g->w_stage = new ingest_stage[3];
   ingest_stage *stage = g->w_stage;
@@ -2102,6 +2120,8 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
   }
   g->drop_verdicts();
   g->in_process = false;
+  if (g->deferred_now) { g->cfg.now = g->d_now; g->deferred_now = false; }
+  if (g->deferred_be) { g->be_sig = g->d_be_sig; g->be_key = g->d_be_key; g->be_user = g->d_be_user; g->deferred_be = false; }
   if (prof0) fprintf(stderr, "[ingest] process n=%zu: %.1f ms in all\n", n, (ingest_now() - tp0) * 1e3);
   // the drained arena's memory serves the next queue (unless a callback or a requeue has already started one)
   if (g->queue.empty() && g->qarena.empty()) {

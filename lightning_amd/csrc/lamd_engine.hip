@@ -1648,18 +1648,24 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
     std::lock_guard<std::mutex> lk(sg.mu);
     if (sg.refs == 0) {
       u32 *d_bases = nullptr;
-      HIPCHK(ctx, hipMalloc(&d_bases, bases.size() * 4));
-      HIPCHK(ctx, hipMemcpy(d_bases, bases.data(), bases.size() * 4, hipMemcpyHostToDevice));
-      HIPCHK(ctx, hipMalloc(&sg.p, GTABLE_BYTES));
-      hipLaunchKernelGGL(k_gtable_build, dim3(blocks_for(GTABLE_ENTRIES)), dim3(256), 0, ctx->stream, sg.p, d_bases);
-      hipError_t e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      (void)hipFree(d_bases);
+      const char *what = "hipMalloc (window bases)";
+      hipError_t e = hipMalloc(&d_bases, bases.size() * 4);
+      if (e == hipSuccess) { what = "hipMemcpy (window bases)"; e = hipMemcpy(d_bases, bases.data(), bases.size() * 4, hipMemcpyHostToDevice); }
+      // 11 GiB: a partitioned or busy device may not have them -- say so (include/lightning_amd.h, lamd_init; one table per process and device)
+      if (e == hipSuccess) { what = "hipMalloc (static G table, 11 GiB)"; e = hipMalloc(&sg.p, GTABLE_BYTES); }
+      if (e == hipSuccess) {
+        what = "k_gtable_build";
+        hipLaunchKernelGGL(k_gtable_build, dim3(blocks_for(GTABLE_ENTRIES)), dim3(256), 0, ctx->stream, sg.p, d_bases);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      }
+      if (d_bases) (void)hipFree(d_bases);   // on every path (round 4 leaked it when a later step failed)
       if (e != hipSuccess) {
-        (void)hipFree(sg.p);
+        if (sg.p) (void)hipFree(sg.p);
         sg.p = nullptr;
-        ctx->err = std::string("k_gtable_build: ") + hipGetErrorString(e);
-        return LAMD_ERR_HIP;
+        (void)hipGetLastError();
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? LAMD_ERR_NOMEM : LAMD_ERR_HIP;
       }
     }
     sg.refs++;
