@@ -386,8 +386,11 @@ def main():
     #     wait that lasts a whole step.
     # Coupling the two calls of a step instead (one gather per step, the next-but-one step waiting for it) held the ECDSA lane back until
     # the BIP-340 call of the same step had finished: a 3-4 ms bubble every other step in the rocprofv3 timeline, -12 % (profiles/r02m_*).
-    ok_e = [we.d_ok, torch.zeros_like(we.d_ok)] if multi else [we.d_ok]
-    ok_s = [ws.d_ok, torch.zeros_like(ws.d_ok)] if multi else [ws.d_ok]
+    # (round 5: FOUR buffers per kind instead of two -- LAMD_BENCH_GATHER_BUFS --: with two, step k + 2 waits for the gather of step k, a small copy kernel that
+    # takes 0.3-1 ms to get its waves onto the saturated chip; in the kernel trace of that loop the calls bunched up in pairs with 3-4 ms holes between them)
+    nbuf = max(2, min(8, int(os.environ.get("LAMD_BENCH_GATHER_BUFS", "4"))))
+    ok_e = [we.d_ok] + [torch.zeros_like(we.d_ok) for _ in range(nbuf - 1)] if multi else [we.d_ok]
+    ok_s = [ws.d_ok] + [torch.zeros_like(ws.d_ok) for _ in range(nbuf - 1)] if multi else [ws.d_ok]
 
     def new_event():
         ev = torch.cuda.Event()
@@ -808,7 +811,9 @@ def main():
             # and their verdicts end in host memory, through the streaming queue (lamd_queue_*_batch -> pinned staging set, lamd_flush,
             # lamd_wait): while the device works on one flush the host fills the next staging set and its H2D copies run under the
             # kernels of the flushes before it (up to eight in flight; the copies of all flushes go down one copy stream in flush order).  Staging memcpy + H2D + verification + D2H inside the clock.
-            H2H_STEPS = 30
+            # (100 steps since round 5: the clock runs from an empty pipeline to the last verdict in host memory, i.e. it holds one fill and one drain of
+            # ~10 ms; over 30 steps that alone was 3-4 % of the region, where the resident loop's 250 steps hold theirs to 0.4 %)
+            H2H_STEPS = 100
             H2H_DEPTH = min(8, eng.info()["queue_sets"] - 1)   # flushes kept in flight (the copies of the flushes behind the lanes' current ones run under their kernels)
             # (the clock stops when the last verdict vector is in host memory; the vectors are compared with the expected verdicts AFTER it -- the
             # check is the bench's, not the path's: a 1 M-element numpy compare per flush is 1-1.5 ms of host time)

@@ -96,7 +96,7 @@ void *lamd_stream(lamd_ctx *ctx); /* hipStream_t */
 int lamd_synchronize(lamd_ctx *ctx);
 /* `stream` (hipStream_t) waits, on the device, for every verification submitted so far */
 int lamd_stream_wait_results(lamd_ctx *ctx, void *stream);
-/* The same in two phases: lamd_results_mark() remembers "everything submitted so far" in slot 0..3 (events on the lanes' streams,
+/* The same in two phases: lamd_results_mark() remembers "everything submitted so far" in slot 0..15 (events on the lanes' streams,
  * nothing waits); lamd_stream_wait_mark() later makes `stream` wait for exactly that work.  A consumer that joins late -- after
  * the next batch has been submitted -- keeps its stream's wait short: a wait that sits in a hardware queue for a whole batch
  * holds up every other stream that shares the queue (bench.py's collective path: the all-gather of step k is issued after the

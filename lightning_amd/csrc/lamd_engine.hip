@@ -1342,10 +1342,10 @@ struct lamd_ctx {
   // the dominant kernel alone: an event pair right around every large table-driven ecmult launch while timing is on (the
   // start event sits AFTER the waits for the prep / cold streams, so the interval is the launch itself, as rocprofv3 sees it);
   // read and summed per mode (ECDSA / BIP-340) by lamd_synchronize(), reset by lamd_set_timing()
-  static const int MARK_SLOTS = 4;
+  static const int MARK_SLOTS = 16;
   hipEvent_t ev_mark[MARK_SLOTS][MAX_LANES + 1] = {};  // lamd_results_mark(): one event per lane stream (+ the context's own)
   bool mark_set[MARK_SLOTS] = {};
-  int mark_only[MARK_SLOTS] = {-1, -1, -1, -1};  // lamd_results_mark_last(): the one lane whose event the slot holds (-1: every lane's)
+  int mark_only[MARK_SLOTS] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // lamd_results_mark_last(): the one lane whose event the slot holds (-1: every lane's)
   static const int KEV = 64;
   hipEvent_t kev[KEV][2] = {};
   int kev_mode[KEV] = {};

@@ -96,7 +96,9 @@ class LateGather:
     """The collective step of the weak-scaling headline (bench.py --gpus N): every rank verifies its own batches, and the verdict
     bytes of every batch are all-gathered -- with every dependency per call and by device-side events, no host synchronisation:
 
-    * a verdict buffer (two per batch kind, alternating by step) is written again only after the gather that read it:
+    * a verdict buffer (`nbuf` per batch kind, taken in turn step by step: FOUR in bench.py since round 5 -- with two, step k + 2 could not start before
+      the gather of step k had run, and that gather is a small copy kernel that waits 0.3-1 ms for wave slots on the saturated chip: the calls bunched up in
+      pairs with holes of 3-4 ms without a table-driven launch between them, 0.91 of the plain loop) is written again only after the gather that read it:
       `before_call(kind, b)` makes the engine wait for that gather's event (lamd_wait_event);
     * a gather waits for "everything submitted up to its call": `after_call(kind, b)` marks it (lamd_results_mark), the consumer
       stream joins the mark when the gather is issued (lamd_stream_wait_mark);
@@ -112,20 +114,21 @@ class LateGather:
     torch.distributed / torch.cuda on GPUs."""
 
     def __init__(self, eng, kinds, bufs, outs, stream_ptr, all_gather, new_event):
-        if 2 * len(kinds) > 4:
-            raise ValueError("lamd_results_mark has four slots: at most two batch kinds")
+        self.nbuf = len(next(iter(bufs.values())))
+        if self.nbuf * len(kinds) > 16:
+            raise ValueError("lamd_results_mark has sixteen slots: buffers x batch kinds must not exceed them")
         self.eng, self.kinds, self.bufs, self.outs = eng, list(kinds), bufs, outs
         self.stream_ptr, self.all_gather, self.new_event = stream_ptr, all_gather, new_event
-        self.consumed = {k: [None, None] for k in self.kinds}
+        self.consumed = {k: [None] * self.nbuf for k in self.kinds}
         self.pending = None
         self.log = []          # (kind, buffer index) in the order the gathers were issued
 
     def reset(self):
-        self.consumed = {k: [None, None] for k in self.kinds}
+        self.consumed = {k: [None] * self.nbuf for k in self.kinds}
         self.pending = None
 
     def slot(self, kind, b):
-        return 2 * b + self.kinds.index(kind)
+        return len(self.kinds) * b + self.kinds.index(kind)
 
     def before_call(self, kind, b):
         ev = self.consumed[kind][b]

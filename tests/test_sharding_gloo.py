@@ -146,7 +146,7 @@ class _StandInEngine:
         self.trace, self.marked = [], set()
 
     def results_mark(self, slot):
-        assert 0 <= slot < 4
+        assert 0 <= slot < 16
         self.marked.add(slot)
         self.trace.append(("mark", slot))
 
@@ -158,14 +158,14 @@ class _StandInEngine:
         self.trace.append(("wait", ev))
 
 
-def _worker_late(rank, world, port, q):
+def _worker_late(rank, world, port, q, nbuf=2):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n, steps = 97, 5
+    n, steps = 97, 5 if nbuf == 2 else 11
     kinds = ("e", "s")
-    bufs = {k: [torch.zeros(n, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8)] for k in kinds}
+    bufs = {k: [torch.zeros(n, dtype=torch.uint8) for _ in range(nbuf)] for k in kinds}
     outs = {k: torch.zeros(world * n, dtype=torch.uint8) for k in kinds}
     pattern = lambda r, step, k: ((torch.arange(n) * (3 + kinds.index(k)) + 7 * r + 5 * step) % 3 == 0).to(torch.uint8)
     eng, shots, events = _StandInEngine(), [], []
@@ -183,7 +183,7 @@ def _worker_late(rank, world, port, q):
         shots.append(out.clone())
     g = sharding.LateGather(eng, kinds, bufs, outs, 1234, all_gather, new_event)
     for step in range(steps):                        # the loop of bench.py's step(), with a synchronous stand-in for the device calls
-        b = step % 2
+        b = step % nbuf
         for k in kinds:
             g.before_call(k, b)
             bufs[k][b].copy_(pattern(rank, step, k))
@@ -191,17 +191,17 @@ def _worker_late(rank, world, port, q):
         g.end_step(b)
         assert len(shots) == 2 * step                # the gathers of step k are issued by step k+1
     g.flush()
-    ok = len(shots) == 2 * steps and g.log == [(k, s % 2) for s in range(steps) for k in kinds]
+    ok = len(shots) == 2 * steps and g.log == [(k, s % nbuf) for s in range(steps) for k in kinds]
     for s in range(steps):                           # gather j carried step j's verdicts of BOTH ranks, whatever was written since
         for i, k in enumerate(kinds):
             want = torch.cat([pattern(r, s, k) for r in range(world)])
             ok = ok and bool(torch.equal(shots[2 * s + i], want))
-    # protocol: from step 2 on every call first waits for the event of the gather that read its buffer two steps earlier
+    # protocol: from step nbuf on every call first waits for the event of the gather that read its buffer nbuf steps earlier (bench.py: four buffers)
     waits = [t[1] for t in eng.trace if t[0] == "wait"]
-    ok = ok and waits == [100 + 2 * (s - 2) + i for s in range(2, steps) for i in range(2)]
+    ok = ok and waits == [100 + 2 * (s - nbuf) + i for s in range(nbuf, steps) for i in range(2)]
     # ... and every join follows the mark of the same slot
     joins = [t[1] for t in eng.trace if t[0] == "join"]
-    ok = ok and joins == [2 * (s % 2) + i for s in range(steps) for i in range(2)]
+    ok = ok and joins == [2 * (s % nbuf) + i for s in range(steps) for i in range(2)]
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -211,16 +211,17 @@ def test_two_rank_late_gather_protocol_and_payload():
     waits in the right order, every step's verdicts of both ranks gathered exactly once, the last step's by flush()"""
     world = 2
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    ps = [ctx.Process(target=_worker_late, args=(r, world, port, q)) for r in range(world)]
-    for p in ps:
-        p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
-    for p in ps:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), res
+    for nbuf in (2, 4):   # two verdict buffers per kind (rounds 2-4) and four (bench.py since round 5)
+        q = ctx.Queue()
+        port = _free_port()
+        ps = [ctx.Process(target=_worker_late, args=(r, world, port, q, nbuf)) for r in range(world)]
+        for p in ps:
+            p.start()
+        res = [q.get(timeout=120) for _ in range(world)]
+        for p in ps:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(r[0] for r in res) == [0, 1] and all(r[1] for r in res), (nbuf, res)
 
 
 def test_eight_rank_ragged_and_empty_shards():
