@@ -96,7 +96,7 @@ class LateGather:
     """The collective step of the weak-scaling headline (bench.py --gpus N): every rank verifies its own batches, and the verdict
     bytes of every batch are all-gathered -- with every dependency per call and by device-side events, no host synchronisation:
 
-    * a verdict buffer (`nbuf` per batch kind, taken in turn step by step: FOUR in bench.py since round 5 -- with two, step k + 2 could not start before
+    * a verdict buffer (`nbuf` per batch kind, taken in turn step by step: SIX in bench.py since round 5 -- with two, step k + 2 could not start before
       the gather of step k had run, and that gather is a small copy kernel that waits 0.3-1 ms for wave slots on the saturated chip: the calls bunched up in
       pairs with holes of 3-4 ms without a table-driven launch between them, 0.91 of the plain loop) is written again only after the gather that read it:
       `before_call(kind, b)` makes the engine wait for that gather's event (lamd_wait_event);
