@@ -594,7 +594,12 @@ def test_single_lane_mode_matches(orc):
 
 @pytest.mark.parametrize("env", [{"LAMD_FUSED_FRONT": "0"}, {"LAMD_MERGE_SIDE": "0"}, {"LAMD_ECMULT_CHAIN": "1"}, {"LAMD_ECMULT_CHAIN": "2", "LAMD_ECMULT_TAIL": "50000"}, {"LAMD_COPY_STREAM": "0"},
                                  {"LAMD_FUSED_FRONT": "0", "LAMD_CACHE": "0"}, {"LAMD_CACHE": "0"}, {"LAMD_GROUP": "0"}, {"LAMD_PAIRS": "1"},
-                                 {"LAMD_PAIRS": "1", "LAMD_GROUP": "0", "LAMD_CACHE": "0"}])
+                                 {"LAMD_PAIRS": "1", "LAMD_GROUP": "0", "LAMD_CACHE": "0"},
+                                 # round 5: the flush's copies -- three with three events (round 4), one event, two copy streams, a full set as one copy or not
+                                 {"LAMD_COPY_EVENTS": "3", "LAMD_COPY_ONE": "0"}, {"LAMD_COPY_EVENTS": "1", "LAMD_COPY_ONE": "0"}, {"LAMD_COPY_EVENTS": "2"},
+                                 {"LAMD_COPY_STREAMS": "2"}, {"LAMD_COPY_EVENTS": "1", "LAMD_COPY_ONE": "1", "LAMD_COPY_STREAMS": "3"},
+                                 # ... and calls cut into chunks that alternate between a lane and its peer (lamd_set_chunk_rows does the same at run time)
+                                 {"LAMD_CHUNK_ROWS": "20000"}])
 def test_scheduling_variants_give_the_same_verdicts(orc, env):
     """the round-2 front end (19 launches), the ladder on a stream of its own, chained ecmult launches, flush copies on the lane's prep
     stream, row lists in arrival order instead of grouped by key, the pairs-first ecmult kernel (k_ecmult_keyed_pairs: both comb shapes
@@ -626,6 +631,21 @@ def test_scheduling_variants_give_the_same_verdicts(orc, env):
             e.synchronize()
             for wl in (w, s, x):
                 assert np.array_equal(wl.d_ok.cpu().numpy().astype(bool), wl.expect), (env, rep, wl.kind)
+        # lamd_set_chunk_rows at run time: the same calls cut in two / in many, then whole again
+        for rows in (60000, 4096, 0):
+            e.set_chunk_rows(rows)
+            for wl in (w, x):
+                wl.d_ok.fill_(9)
+            torch.cuda.synchronize()
+            e.verify_ecdsa_device(w.dev[0], w.dev[1], w.dev[2], w.d_ok)
+            e.results_mark_last(5)                       # one event on the call's own lane: a consumer that waits for it sees this call's verdicts
+            e.stream_wait_mark(5, torch.cuda.current_stream().cuda_stream)
+            got_w = w.d_ok.clone()                       # (on torch's stream, behind the mark)
+            e.verify_ecdsa_device(x.dev[0], x.dev[1], x.dev[2], x.d_ok)
+            e.synchronize()
+            torch.cuda.synchronize()
+            assert np.array_equal(got_w.cpu().numpy().astype(bool), w.expect), (env, rows)
+            assert np.array_equal(x.d_ok.cpu().numpy().astype(bool), x.expect), (env, rows)
         sample = slice(0, 3000)
         assert np.array_equal(orc.ecdsa_verify_batch(*[np.ascontiguousarray(c[sample]) for c in w.cols], 33, 4).astype(bool), w.expect[sample])
         assert np.array_equal(orc.schnorr_verify_batch(*[np.ascontiguousarray(c[sample]) for c in s.cols], 4).astype(bool), s.expect[sample])
