@@ -542,9 +542,9 @@ def test_two_phase_join_and_event_ordering(eng):
     eng.synchronize()
     consumer = torch.cuda.Stream()
     with pytest.raises(LamdError):
-        eng.stream_wait_mark(3, consumer.cuda_stream)        # never marked
+        eng.stream_wait_mark(13, consumer.cuda_stream)       # never marked
     with pytest.raises(LamdError):
-        eng.results_mark(4)                                  # slots are 0..3
+        eng.results_mark(16)                                 # slots are 0..15
     copies, last_ev = [], [None, None]
     for rep in range(4):
         for slot, (w, call) in enumerate(((wa, eng.verify_ecdsa_device), (wb, eng.verify_schnorr_device))):
