@@ -6,8 +6,9 @@
  * (SURVEY.md 8(b) "callers").  An engine context costs 11 GiB of HBM (the static G table) plus its table pools and 0.36 s to
  * create -- one per daemon process does not scale.  The server holds the one context; a client process holds a socket and a
  * shared-memory block.  Requests that are waiting at the same moment are MERGED: the ECDSA rows of every client go to the device
- * as one lamd_verify_ecdsa_batch call (eight channelds validating a commitment_signed each = one 3872-row launch), their
- * verdicts are scattered back per client.  That is the batching the north star asks the C host for, across process boundaries.
+ * as one lamd_verify_ecdsa_batch call, the BIP-340 rows as one lamd_verify_schnorr_batch call, the commitment_signed validations and
+ * check_tx_sig batches (33-byte keys) as one lamd_check_tx_sig_tx_batch call (eight channelds validating a commitment_signed each =
+ * one hashing launch + one 3872-row verification launch); the verdicts are scattered back per client.  That is the batching the north star asks the C host for, across process boundaries.
  *
  * liblightning_amd_client.so exports the entry points of include/lightning_amd.h that the mirror (include/cln_shim.h) and the
  * gossip ingest use, with the SAME prototypes and meaning:
@@ -41,8 +42,8 @@ enum lamd_srv_op {
 	LAMD_SRV_OP_SCHNORR = 3,      /* lamd_verify_schnorr_batch: in: msg32 xonly32 sig64; out: ok[n].  MERGED across clients */
 	LAMD_SRV_OP_PUBKEY_PARSE = 4, /* lamd_pubkey_parse_batch: scalar[0] = publen; in: pub; out: xy64[n] ok[n] */
 	LAMD_SRV_OP_GOSSIP = 5,       /* lamd_sigcheck_gossip_batch: scalar[0] = node ids present; in: msgs off[n+1] ids33[n]; out: verdict[n] */
-	LAMD_SRV_OP_TXSIG_TX = 6,     /* lamd_check_tx_sig_tx_batch: scalar[0] = publen; in: the fifteen arrays in prototype order; out: ok[n] */
-	LAMD_SRV_OP_COMMITMENT = 7,   /* lamd_check_commitment_signed: n = 1 + n_htlc rows as TXSIG_TX arrays + keys + sigs; out: first_bad (8) ok[n] */
+	LAMD_SRV_OP_TXSIG_TX = 6,     /* lamd_check_tx_sig_tx_batch: scalar[0] = publen; in: the fifteen arrays in prototype order; out: ok[n].  MERGED (publen 33) */
+	LAMD_SRV_OP_COMMITMENT = 7,   /* lamd_check_commitment_signed: n = 1 + n_htlc rows as TXSIG_TX arrays + keys + sigs; out: first_bad (8) ok[n].  MERGED with 6 */
 	LAMD_SRV_OP_BOLT12_CHECK = 8, /* lamd_bolt12_check_signature_batch: in: tlvs off[n+1] messagename fieldname key33[n] sig64[n]; out: ok[n] */
 	LAMD_SRV_OP_BOLT12_MERKLE = 9,/* lamd_bolt12_merkle_batch: scalar[0] = sighash wanted; in: tlvs off messagename fieldname; out: merkle32[n] sighash32[n] ok[n] */
 	LAMD_SRV_OP_RECOVER = 10,     /* lamd_ecdsa_recover_batch: in: hash32 sig64 recid[n]; out: pub33[n] ok[n] */

@@ -2552,6 +2552,7 @@ extern "C" int lamd_verify_schnorr_batch_device(lamd_ctx *ctx, size_t n, const v
 // n <= SMALL_MAX rows from host memory: one launch of k_small_verify, inputs and verdicts through pinned device-mapped memory, the
 // host waits on the completion word the kernel's last instruction writes
 constexpr size_t SMALL_MAX = 4096;  // rows of a call that takes the one-launch path (a grid of 64-row blocks)
+constexpr size_t TXSIG_HOST_HASH_ROWS = 16;  // check_tx_sig batches up to here hash on the host (one launch); above, on the device (two launches)
 constexpr size_t SMALL_OFF_SIG = SMALL_MAX * 32, SMALL_OFF_KEY = SMALL_OFF_SIG + SMALL_MAX * 64, SMALL_OFF_OUT = SMALL_OFF_KEY + SMALL_MAX * 65 + 64,
                  SMALL_OFF_SHAPES = SMALL_OFF_OUT + SMALL_MAX, SMALL_OFF_FLAG = SMALL_OFF_SHAPES + SMALL_MAX, SMALL_BYTES = SMALL_OFF_FLAG + 64;
 // Keys that the latency path had to take down the ladder are remembered by fingerprint (host side, direct-mapped): the SECOND small
@@ -2974,6 +2975,32 @@ static int txsig_tx_general(lamd_ctx *ctx, size_t n, const uint32_t *version, co
   return lamd_synchronize(ctx);  // (B.st is pageable: the runtime staged it before hipMemcpyAsync returned)
 }
 
+// <= SMALL_MAX rows with the BIP143 hashes made ON THE DEVICE: the templates go into a pinned, device-mapped block, k_txsig_tx_hash reads them there and
+// leaves hashes and gate in device memory, k_small_verify -- queued right behind it -- takes them from there.  Two launches, no copy command.  (Hashing on
+// the host, which the small callers do for a handful of rows, is ~12 SHA-256 compressions per row: 1.7 ms for a 484-row commitment, 14 ms for eight of them.)
+// LAMD_OK: verdicts in ok[]; 1: a key the latency path met before without a table is back -- the caller takes the batch path (force_learn is set).
+static int txsig_small_device(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
+                              const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs, const uint64_t *out_off, const uint32_t *n_outputs,
+                              const uint8_t *scripts, const uint64_t *script_off, const uint8_t *sighash_type, const uint8_t *has_witness, const uint8_t *sig64,
+                              const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok) {
+  int rc;
+  txsig_blob B;
+  txsig_pack(B, n, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type, has_witness);
+  if (ctx->h_tmpl_cap < B.total) {
+    if (ctx->h_tmpl) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_tmpl); ctx->h_tmpl = nullptr; ctx->h_tmpl_cap = 0; }
+    const size_t want = B.total + B.total / 2 + 4096;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_tmpl, want, hipHostMallocMapped | hipHostMallocCoherent));
+    ctx->h_tmpl_cap = want;
+  }
+  if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  memcpy(ctx->h_tmpl, B.st.data(), B.total);
+  if ((rc = txsig_hash_launch(ctx, n, B, ctx->h_tmpl, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
+  rc = run_small(ctx, MODE_ECDSA, n, nullptr, sig64, pub, (int)publen, pubstride, ok, (const u8 *)ctx->in_a.p, (const u8 *)ctx->g_malformed.p);
+  if (rc == 1) ctx->force_learn = true;
+  return rc;
+}
+
 extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40,
                                           const uint64_t *in_off, const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs,
                                           const uint64_t *out_off, const uint32_t *n_outputs, const uint8_t *scripts, const uint64_t *script_off,
@@ -2989,7 +3016,8 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
-  if (small_path(ctx, n) && ctx->keyed_mode <= 0) {  // a few rows: BIP143 hash on the host, rows through the latency path (see lamd_check_tx_sig_batch)
+  if (small_path(ctx, n) && ctx->keyed_mode <= 0 && n <= TXSIG_HOST_HASH_ROWS) {
+    // a handful of rows: BIP143 hash on the host (the kernels' own inline function), rows through the latency path in ONE launch
     std::vector<u8> hs(32 * n), gate(n);
     for (size_t i = 0; i < n; i++)
       gate[i] = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
@@ -3002,6 +3030,10 @@ extern "C" int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_
     }
     if (rc != 1) return rc;
     ctx->force_learn = true;
+  } else if (small_path(ctx, n) && ctx->keyed_mode <= 0) {  // up to 4 096 rows (several commitments at once: lamd_served's merged call): hashes on the device
+    rc = txsig_small_device(ctx, n, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type, has_witness,
+                            sig64, pub, publen, pubstride, ok);
+    if (rc != 1) return rc;
   }
   return txsig_tx_general(ctx, n, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
                           has_witness, sig64, pub, publen, pubstride, ok);
@@ -3051,26 +3083,10 @@ extern "C" int lamd_check_commitment_signed(lamd_ctx *ctx, const lamd_tx_templat
   if ((rc = cache_maybe_reset(ctx)) != LAMD_OK) return rc;
   bool done = false;
   if (small_path(ctx, n) && ctx->keyed_mode <= 0) {
-    // the latency path with the BIP143 hashes made ON THE DEVICE (hashing 1 + 483 templates on one host core costs several times the
-    // verification): the templates go into a pinned, device-mapped block, k_txsig_tx_hash reads them from there and leaves hashes and gate
-    // in device memory, k_small_verify -- queued right behind it -- takes them from there.  Two launches, no copy command.
-    txsig_blob B;
-    txsig_pack(B, n, version.data(), locktime.data(), inputs.data(), in_off.data(), input_num.data(), amount.data(), outputs.data(), out_off.data(),
-               n_outputs.data(), scripts.data(), sc_off.data(), type.data(), wit.data());
-    if (ctx->h_tmpl_cap < B.total) {
-      if (ctx->h_tmpl) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_tmpl); ctx->h_tmpl = nullptr; ctx->h_tmpl_cap = 0; }
-      const size_t want = B.total + B.total / 2 + 4096;
-      HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_tmpl, want, hipHostMallocMapped | hipHostMallocCoherent));
-      ctx->h_tmpl_cap = want;
-    }
-    if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
-    if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
-    memcpy(ctx->h_tmpl, B.st.data(), B.total);
-    if ((rc = txsig_hash_launch(ctx, n, B, ctx->h_tmpl, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
-    rc = run_small(ctx, MODE_ECDSA, n, nullptr, sig.data(), pub.data(), 33, 33, okv.data(), (const u8 *)ctx->in_a.p, (const u8 *)ctx->g_malformed.p);
+    rc = txsig_small_device(ctx, n, version.data(), locktime.data(), inputs.data(), in_off.data(), input_num.data(), amount.data(), outputs.data(), out_off.data(),
+                            n_outputs.data(), scripts.data(), sc_off.data(), type.data(), wit.data(), sig.data(), pub.data(), 33, 33, okv.data());
     if (rc == LAMD_OK) done = true;
-    else if (rc != 1) return rc;
-    else ctx->force_learn = true;  // a key the latency path met before without a table is back (the channel's htlc key): build and publish it below
+    else if (rc != 1) return rc;   // 1: a key the latency path met before without a table is back (the channel's htlc key): built and published below
   }
   if (!done) {
     rc = txsig_tx_general(ctx, n, version.data(), locktime.data(), inputs.data(), in_off.data(), input_num.data(), amount.data(), outputs.data(), out_off.data(),

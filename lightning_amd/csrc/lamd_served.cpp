@@ -7,7 +7,8 @@
 // Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job, waits for its completion, sends the reply);
 // ONE engine thread, the only caller of the engine (a context is not thread-safe).  The engine thread takes EVERYTHING that is queued at
 // the moment it looks: the ECDSA jobs of equal key length become one lamd_verify_ecdsa_batch call, the BIP-340 jobs one
-// lamd_verify_schnorr_batch call (rows copied into one contiguous batch, verdicts scattered back); every other operation runs by itself.
+// lamd_verify_schnorr_batch call, the commitment_signed validations (and check_tx_sig batches) one lamd_check_tx_sig_tx_batch call (rows copied into
+// one contiguous batch, verdicts scattered back, a commitment's first_bad taken from its slice); every other operation runs by itself.
 // With --linger-us the engine thread waits that long after the first job of a round for company (default 0: merge what is there).
 //
 // The engine is bound through dlopen (--engine, default liblightning_amd.so next to this executable): the server itself has no
@@ -159,6 +160,90 @@ void run_merged(std::vector<job *> &js, bool schnorr) {
   }
 }
 
+// a TXSIG_TX / COMMITMENT request is well-formed: section lengths match n, every offset stays inside its array
+bool tx_valid(job *j) {
+  const lamd_srv_req &r = j->req;
+  const size_t n = (size_t)r.n;
+  const bool commit = r.op == LAMD_SRV_OP_COMMITMENT;
+  const size_t kl = commit ? 33 : (size_t)r.scalar[0];
+  if (n == 0 || (kl != 33 && kl != 65)) { fail(j, LAMD_ERR_ARG, "bad n / key length"); return false; }
+  if (commit ? !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, 64 * n, 33, 33}, 16 + n)
+             : !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, n, 64 * n, kl * n}, n))
+    return false;
+  const uint64_t *in_off = (const uint64_t *)sec(j, 3), *out_off = (const uint64_t *)sec(j, 7), *sc_off = (const uint64_t *)sec(j, 10);
+  for (size_t i = 0; i < n; i++)
+    if (in_off[i + 1] < in_off[i] || 40 * in_off[i + 1] > seclen(j, 2) || out_off[i + 1] < out_off[i] || out_off[i + 1] > seclen(j, 6) ||
+        sc_off[i + 1] < sc_off[i] || sc_off[i + 1] > seclen(j, 9)) {
+      fail(j, LAMD_ERR_ARG, "template offsets outside their arrays");
+      return false;
+    }
+  return true;
+}
+
+void run_one(job *j);
+// The commitment_signed validations (and check_tx_sig batches under 33-byte keys) of several clients as ONE lamd_check_tx_sig_tx_batch call: the rows'
+// templates are concatenated (offsets rebased), the BIP143 hashes of all of them are made on the device in one launch, the verdicts are cut back per
+// request and a commitment's first_bad is the first zero of its slice -- what lamd_check_commitment_signed computes for one (channeld.c:2171-2232 order).
+void run_tx_merged(std::vector<job *> &js) {
+  if (js.empty()) return;
+  if (js.size() == 1) { run_one(js[0]); return; }
+  size_t total = 0;
+  for (job *j : js) total += (size_t)j->req.n;
+  std::vector<uint32_t> ver(total), lock(total), inum(total), nout(total);
+  std::vector<uint64_t> amt(total), in_off(total + 1), out_off(total + 1), sc_off(total + 1);
+  std::vector<uint8_t> type(total), wit(total), sig(64 * total), pub(33 * total), ins, outs, scs, ok(total);
+  size_t o = 0;
+  for (job *j : js) {
+    const size_t n = (size_t)j->req.n;
+    const bool commit = j->req.op == LAMD_SRV_OP_COMMITMENT;
+    memcpy(&ver[o], sec(j, 0), 4 * n); memcpy(&lock[o], sec(j, 1), 4 * n); memcpy(&inum[o], sec(j, 4), 4 * n);
+    memcpy(&amt[o], sec(j, 5), 8 * n); memcpy(&nout[o], sec(j, 8), 4 * n);
+    const uint64_t *io = (const uint64_t *)sec(j, 3), *oo = (const uint64_t *)sec(j, 7), *so = (const uint64_t *)sec(j, 10);
+    const size_t ib = ins.size() / 40, ob = outs.size(), sb = scs.size();
+    for (size_t i = 0; i < n; i++) { in_off[o + i] = ib + io[i]; out_off[o + i] = ob + oo[i]; sc_off[o + i] = sb + so[i]; }
+    ins.insert(ins.end(), sec(j, 2), sec(j, 2) + 40 * io[n]);
+    outs.insert(outs.end(), sec(j, 6), sec(j, 6) + oo[n]);
+    scs.insert(scs.end(), sec(j, 9), sec(j, 9) + so[n]);
+    memcpy(&type[o], sec(j, 11), n);
+    if (commit) {
+      memset(&wit[o], 1, n);
+      memcpy(&sig[64 * o], sec(j, 12), 64 * n);
+      memcpy(&pub[33 * o], sec(j, 13), 33);
+      for (size_t i = 1; i < n; i++) memcpy(&pub[33 * (o + i)], sec(j, 14), 33);
+    } else {
+      memcpy(&wit[o], sec(j, 12), n);
+      memcpy(&sig[64 * o], sec(j, 13), 64 * n);
+      memcpy(&pub[33 * o], sec(j, 14), 33 * n);
+    }
+    o += n;
+  }
+  in_off[total] = ins.size() / 40; out_off[total] = outs.size(); sc_off[total] = scs.size();
+  ins.push_back(0); outs.push_back(0); scs.push_back(0);   // never empty arrays
+  const int rc = E.txsig_tx(g_ctx, total, ver.data(), lock.data(), ins.data(), in_off.data(), inum.data(), amt.data(), outs.data(), out_off.data(), nout.data(), scs.data(),
+                            sc_off.data(), type.data(), wit.data(), sig.data(), pub.data(), 33, 33, ok.data());
+  g_stats.engine_calls++;
+  g_stats.merged_requests += js.size();
+  g_stats.merged_rows += total;
+  if (js.size() > g_stats.largest_merge_requests) g_stats.largest_merge_requests = js.size();
+  o = 0;
+  for (job *j : js) {
+    const size_t n = (size_t)j->req.n;
+    if (rc == LAMD_OK) {
+      if (j->req.op == LAMD_SRV_OP_COMMITMENT) {
+        int64_t first_bad = -1;
+        for (size_t i = 0; i < n && first_bad < 0; i++)
+          if (!ok[o + i]) first_bad = (int64_t)i;
+        memcpy(outp(j, 0), &first_bad, 8);
+        memcpy(outp(j, 16), &ok[o], n);
+      } else {
+        memcpy(outp(j, 0), &ok[o], n);
+      }
+    }
+    engine_error(j, rc);
+    o += n;
+  }
+}
+
 void run_one(job *j) {
   const lamd_srv_req &r = j->req;
   const size_t n = (size_t)r.n;
@@ -184,17 +269,8 @@ void run_one(job *j) {
       // sections 0..10: version locktime inputs40 in_off input_num amount outputs out_off n_outputs scripts script_off
       const bool commit = r.op == LAMD_SRV_OP_COMMITMENT;
       const size_t kl = commit ? 33 : (size_t)r.scalar[0];
-      if (n == 0 || (kl != 33 && kl != 65)) { fail(j, LAMD_ERR_ARG, "bad n / key length"); return; }
-      if (commit ? !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, 64 * n, 33, 33}, 16 + n)
-                 : !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, n, 64 * n, kl * n}, n))
-        return;
+      if (!tx_valid(j)) return;
       const uint64_t *in_off = (const uint64_t *)sec(j, 3), *out_off = (const uint64_t *)sec(j, 7), *sc_off = (const uint64_t *)sec(j, 10);
-      for (size_t i = 0; i < n; i++)
-        if (in_off[i + 1] < in_off[i] || 40 * in_off[i + 1] > seclen(j, 2) || out_off[i + 1] < out_off[i] || out_off[i + 1] > seclen(j, 6) ||
-            sc_off[i + 1] < sc_off[i] || sc_off[i + 1] > seclen(j, 9)) {
-          fail(j, LAMD_ERR_ARG, "template offsets outside their arrays");
-          return;
-        }
       if (!commit) {
         engine_error(j, E.txsig_tx(g_ctx, n, (const uint32_t *)sec(j, 0), (const uint32_t *)sec(j, 1), sec(j, 2), in_off, (const uint32_t *)sec(j, 4),
                                    (const uint64_t *)sec(j, 5), sec(j, 6), out_off, (const uint32_t *)sec(j, 8), sec(j, 9), sc_off, sec(j, 11), sec(j, 12),
@@ -299,8 +375,23 @@ void engine_loop() {
     run_merged(e33, false);
     run_merged(e65, false);
     run_merged(sch, true);
-    for (job *j : round)
-      if (j->req.op != LAMD_SRV_OP_ECDSA && j->req.op != LAMD_SRV_OP_SCHNORR && sane_n(j)) run_one(j);
+    // commitment_signed validations and check_tx_sig batches under 33-byte keys: one device call for all that wait
+    std::vector<job *> txs;
+    size_t txrows = 0;
+    for (job *j : round) {
+      const lamd_srv_req &r = j->req;
+      const bool tx = r.op == LAMD_SRV_OP_COMMITMENT || (r.op == LAMD_SRV_OP_TXSIG_TX && r.scalar[0] == 33);
+      if (!tx || !sane_n(j) || !tx_valid(j)) continue;
+      if (txrows + (size_t)r.n > g_max_merge && !txs.empty()) { run_tx_merged(txs); txs.clear(); txrows = 0; }
+      txs.push_back(j);
+      txrows += (size_t)r.n;
+    }
+    run_tx_merged(txs);
+    for (job *j : round) {
+      const lamd_srv_req &r = j->req;
+      const bool tx = r.op == LAMD_SRV_OP_COMMITMENT || (r.op == LAMD_SRV_OP_TXSIG_TX && r.scalar[0] == 33);
+      if (r.op != LAMD_SRV_OP_ECDSA && r.op != LAMD_SRV_OP_SCHNORR && !tx && sane_n(j)) run_one(j);
+    }
     {
       std::lock_guard<std::mutex> lk(qmu);
       for (job *j : round) j->done = true;

@@ -90,6 +90,53 @@ def _rows(rng, n, w):
     return np.ascontiguousarray(rng.integers(0, 256, (n, w), dtype=np.uint8))
 
 
+def _commitment_from_dicts(L, ctx, commit_tx, fund33, commit_sig, commit_type, htlc_txs, hkey33, htlc_sigs, htlc_types):
+    """lamd_check_commitment_signed through the client library on templates given as the dicts of tests/test_gpu_commitment.py -> (rc, first_bad, ok rows)"""
+    def varint(v):
+        return bytes([v]) if v < 0xfd else (b"\xfd" + v.to_bytes(2, "little") if v <= 0xffff else b"\xfe" + v.to_bytes(4, "little"))
+    keep = []
+
+    def tmpl(t):
+        ins = b"".join(bytes(i[0]) + int(i[1]).to_bytes(4, "little") + int(i[2]).to_bytes(4, "little") for i in t["inputs"])
+        outs = b"".join(int(a).to_bytes(8, "little") + varint(len(spk)) + bytes(spk) for a, spk in t["outputs"])
+        bufs = [ctypes.create_string_buffer(x, len(x) + 1) for x in (ins, outs, bytes(t["script"]))]
+        keep.extend(bufs)
+        return TxTemplate(t["version"], t["locktime"], ctypes.addressof(bufs[0]), len(t["inputs"]), t.get("input_num", 0), t["amount"], ctypes.addressof(bufs[1]), len(outs),
+                          len(t["outputs"]), ctypes.addressof(bufs[2]), len(t["script"]))
+    n = len(htlc_txs)
+    arr = (TxTemplate * (n + 1))(*([tmpl(commit_tx)] + [tmpl(t) for t in htlc_txs]))
+    sigs = np.frombuffer(b"".join(htlc_sigs) + b"\x00", dtype=np.uint8).copy()
+    types = np.array(list(htlc_types) + [0], dtype=np.uint8)
+    fb = ctypes.c_int64(7)
+    okr = np.zeros(n + 1, np.uint8)
+    rc = L.lamd_check_commitment_signed(ctx, ctypes.addressof(arr), bytes(fund33), bytes(commit_sig), commit_type, n, ctypes.addressof(arr) + ctypes.sizeof(TxTemplate), bytes(hkey33),
+                                        sigs.ctypes.data, types.ctypes.data, ctypes.byref(fb), okr.ctypes.data)
+    return rc, fb.value, [bool(x) for x in okr]
+
+
+def _stub_commitment(rng, n_htlc):
+    """a random commitment (templates, keys, signatures) and the verdict rows tests/c/stub_engine.c gives them; -> (call(L, ctx) -> (rc, first_bad, ok_rows), expect)"""
+    bufs, tm, expect = [], (TxTemplate * (n_htlc + 1))(), []
+    sigs, types = _rows(rng, n_htlc + 1, 64), rng.choice([1, 0x83], n_htlc + 1).astype(np.uint8)
+    fund, hkey = _rows(rng, 1, 33), _rows(rng, 1, 33)
+    for i in range(n_htlc + 1):
+        ins, outs, sc = _rows(rng, 1, 40), _rows(rng, 1, int(rng.integers(9, 60))), _rows(rng, 1, int(rng.integers(1, 140)))
+        bufs += [ins, outs, sc]
+        tm[i] = TxTemplate(int(rng.integers(1, 3)), int(rng.integers(0, 1 << 30)), ins.ctypes.data, 1, 0, int(rng.integers(1, 1 << 40)), outs.ctypes.data, outs.shape[1], 1,
+                           sc.ctypes.data, sc.shape[1])
+        key = fund if i == 0 else hkey
+        expect.append(int((tm[i].version ^ tm[i].amount_sat ^ int(types[i]) ^ int(sigs[i, 0]) ^ int(key[0, 1]) ^ int(ins[0, 0]) ^ int(outs[0, -1]) ^ int(sc[0, 0])) & 1))
+
+    def call(L, ctx):
+        fb = ctypes.c_int64(7)
+        okr = np.zeros(n_htlc + 1, np.uint8)
+        rc = L.lamd_check_commitment_signed(ctx, ctypes.addressof(tm), fund.ctypes.data, sigs[0].ctypes.data, int(types[0]), n_htlc, ctypes.addressof(tm) + ctypes.sizeof(TxTemplate),
+                                            hkey.ctypes.data, sigs[1:].ctypes.data if n_htlc else None, types[1:].ctypes.data if n_htlc else None, ctypes.byref(fb), okr.ctypes.data)
+        return rc, fb.value, list(okr)
+    call.keep = (bufs, tm, sigs, types, fund, hkey)
+    return call, expect
+
+
 def test_every_operation_round_trips_through_the_server(stub):
     so, d = stub
     sock = os.path.join(d, "a.sock")
@@ -139,24 +186,12 @@ def test_every_operation_round_trips_through_the_server(stub):
         assert L.lamd_ecdsa_recover_batch(ctx, 30, hh.ctypes.data, ss.ctypes.data, rid.ctypes.data, pub.ctypes.data, ok.ctypes.data) == 0
         assert np.array_equal(pub[:, 1:], hh ^ ss[:, :32]) and np.array_equal(pub[:, 0], 2 + (rid & 1)) and ok.all()
         # one commitment_signed: templates flattened by the client, rebuilt by the server
-        n_htlc = 483
-        bufs, tm = [], (TxTemplate * (n_htlc + 1))()
-        expect = []
-        sigs, types = _rows(rng, n_htlc + 1, 64), rng.choice([1, 0x83], n_htlc + 1).astype(np.uint8)
-        fund, hkey = _rows(rng, 1, 33), _rows(rng, 1, 33)
-        for i in range(n_htlc + 1):
-            ins, outs, sc = _rows(rng, 1, 40), _rows(rng, 1, int(rng.integers(9, 60))), _rows(rng, 1, int(rng.integers(1, 140)))
-            bufs += [ins, outs, sc]
-            tm[i] = TxTemplate(int(rng.integers(1, 3)), int(rng.integers(0, 1 << 30)), ins.ctypes.data, 1, 0, int(rng.integers(1, 1 << 40)), outs.ctypes.data, outs.shape[1], 1,
-                               sc.ctypes.data, sc.shape[1])
-            key = fund if i == 0 else hkey
-            expect.append(int((tm[i].version ^ tm[i].amount_sat ^ int(types[i]) ^ int(sigs[i, 0]) ^ int(key[0, 1]) ^ int(ins[0, 0]) ^ int(outs[0, -1]) ^ int(sc[0, 0])) & 1))
-        fb = ctypes.c_int64(7)
-        okr = np.zeros(n_htlc + 1, np.uint8)
-        rc = L.lamd_check_commitment_signed(ctx, ctypes.addressof(tm), fund.ctypes.data, sigs[0].ctypes.data, int(types[0]), n_htlc, ctypes.addressof(tm) + ctypes.sizeof(TxTemplate),
-                                            hkey.ctypes.data, sigs[1:].ctypes.data, types[1:].ctypes.data, ctypes.byref(fb), okr.ctypes.data)
-        assert rc == 0, L.lamd_last_error(ctx)
-        assert list(okr) == expect and fb.value == (expect.index(0) if 0 in expect else -1)
+        for n_htlc in (483, 0, 7):
+            call, expect = _stub_commitment(rng, n_htlc)
+            rc, fb, okr = call(L, ctx)
+            assert rc == 0, L.lamd_last_error(ctx)
+            assert okr == expect and fb == (expect.index(0) if 0 in expect else -1)
+        sigs, fund = call.keep[2], call.keep[4]
         # grind: scalars in the header, the answer in the reply's rc
         pre, outs = _rows(rng, 1, 290), _rows(rng, 1, 43)
         rate, fee = ctypes.c_uint32(0), ctypes.c_uint64(0)
@@ -194,6 +229,11 @@ for it in range(int(sys.argv[4])):
     ok = np.full(n, 9, np.uint8)
     assert L.lamd_verify_ecdsa_batch(ctx, n, h.ctypes.data, s.ctypes.data, k.ctypes.data, 33, 33, ok.ctypes.data) == 0
     bad += int((ok != ((h[:, 0] ^ s[:, 63] ^ k[:, 32]) & 1)).sum())
+    if it % 2 == 0:   # a commitment_signed validation: merged with the other clients' into one check_tx_sig batch on the server
+        call, expect = T._stub_commitment(rng, int(rng.integers(0, 40)))
+        rc, fb, okr = call(L, ctx)
+        assert rc == 0, L.lamd_last_error(ctx)
+        bad += int(okr != expect) + int(fb != (expect.index(0) if 0 in expect else -1))
     if it % 5 == 0:
         m, x, sg = T._rows(rng, 64, 32), T._rows(rng, 64, 32), T._rows(rng, 64, 64)
         ok = np.zeros(64, np.uint8)
@@ -218,8 +258,8 @@ def test_requests_of_eight_client_processes_are_merged_and_scattered_back(stub):
         st = Stats()
         assert L.lamd_client_server_stats(ctx, ctypes.byref(st)) == 0
         L.lamd_shutdown(ctx)
-        # 8 x (40 + 8) verification requests; with eight clients waiting at once most of them travelled in merged calls
-        assert st.clients_total == 9 and st.requests >= 8 * 48
+        # 8 x (40 + 20 + 8) requests; with eight clients waiting at once most of them travelled in merged calls
+        assert st.clients_total == 9 and st.requests >= 8 * 68
         assert st.merged_requests >= 100 and st.largest_merge_requests >= 3 and st.engine_calls < st.requests
     finally:
         out = _stop(p)
@@ -258,7 +298,16 @@ assert rc == 0, L.lamd_last_error(ctx)
 d = np.load(sys.argv[3])
 h, s, k, e = d["h"], d["s"], d["k"], d["e"]
 bad = 0
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import json, test_gpu_commitment as C
+kat = json.load(open(os.path.join(sys.argv[1], "tests", "golden", "kat.json")))
+ctx_tx, fund, csig, htxs, hkey, hsigs, _, _ = C._bolt3(kat)
 for rep in range(int(sys.argv[4])):
+    # the BOLT #3 commitment the reference holds signed, all good and with HTLC (rep % 5) damaged: merged with the other clients' on the server
+    for sigs, want in ((hsigs, -1), (hsigs[:rep % 5] + [C._flip(hsigs[rep % 5])] + hsigs[rep % 5 + 1:], 1 + rep % 5)):
+        rc, fb, okr = T._commitment_from_dicts(L, ctx, ctx_tx, fund, csig, 1, htxs, hkey, sigs, [1] * 5)
+        assert rc == 0, L.lamd_last_error(ctx)
+        bad += int(fb != want) + int(okr != [i != want for i in range(6)])
     for a in range(0, len(h), T.PER):
         z = min(len(h), a + T.PER)
         ok = np.full(z - a, 9, np.uint8)
