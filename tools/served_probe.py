@@ -59,7 +59,7 @@ def main():
         np.savez(f, h=hs, s=ss, k=k33, e=st.expect[a:z].astype(np.uint8))
         files.append(f)
     # ---- in-process: one caller straight into the engine
-    d = np.load(files[0])
+    d = {k: v for k, v in np.load(files[0]).items()}   # (an NpzFile re-reads the archive on every access)
     lat = []
     for p in range(PASSES):
         for c in range(CH):
