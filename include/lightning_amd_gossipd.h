@@ -154,6 +154,7 @@ typedef struct lamd_gossipd_stats {
 	uint64_t sub_batches;       /* planning stages run (a drained queue is cut into sub-batches: the next one is planned while one is applied) */
 	uint64_t overlapped_stages; /* of those, planning stages that ran under an apply pass */
 	uint64_t run_announcements; /* channel_announcements entered into the map of waiting announcements by all cores, as runs of plain announcements */
+	uint64_t run_nodes;         /* node_announcements applied by all cores, as runs of plain announcements of known nodes (gossmap_manage.c:1162-1243) */
 } lamd_gossipd_stats;
 void lamd_gossipd_get_stats(const lamd_gossipd *g, lamd_gossipd_stats *out);
 /* diagnostic: the ingest's open-addressing maps against std::unordered_map over `ops` random operations; 0 = every check passed */

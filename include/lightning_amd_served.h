@@ -27,6 +27,10 @@
  *              each aligned to 16 bytes, in the order the operation defines (lamd_served.cpp, op table)
  *   reply    = struct lamd_srv_rep over the socket; output sections follow the input sections in the shared block
  * Both structs are plain little-endian host structs: client and server are processes of one machine.
+ *
+ * Trust: the socket is mode 0600 -- clients are the daemons of one lightningd, running as the server's user.  The server checks every length and offset
+ * of a request before it touches the block, but the block stays writable by its client while the request runs: a hostile client of the same user can
+ * at worst get wrong answers for ITSELF or crash the server it shares with its siblings; it cannot read another client's rows (one block per connection).
  */
 #ifndef LIGHTNING_AMD_SERVED_H
 #define LIGHTNING_AMD_SERVED_H

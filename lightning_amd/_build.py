@@ -119,9 +119,11 @@ def build_served(force=False):
         subprocess.check_call([cxx] + flags + ["-o", SERVED + ".tmp", os.path.join(CSRC, "lamd_served.cpp"), "-ldl"])
         os.replace(SERVED + ".tmp", SERVED)
         _stamp(SERVED, d)
-    d = _digest(CLIENT_SOURCES, ["client-v1"])
+    d = _digest(CLIENT_SOURCES, ["client-v2"])
     if force or not _fresh(CLIENT, d):
-        subprocess.check_call([cxx] + flags + ["-shared", "-o", CLIENT + ".tmp", os.path.join(CSRC, "lamd_client.cpp")])
+        # -Bsymbolic-functions: the library's own calls (lamd_check_signed_hash -> lamd_verify_ecdsa_batch) bind inside it even in a process that has the
+        # engine library's symbols of the same names in its global scope
+        subprocess.check_call([cxx] + flags + ["-shared", "-Wl,-Bsymbolic-functions", "-o", CLIENT + ".tmp", os.path.join(CSRC, "lamd_client.cpp")])
         os.replace(CLIENT + ".tmp", CLIENT)
         _stamp(CLIENT, d)
     d = _digest(SHIM_SOURCES + CLIENT_SOURCES, ["shim-client-v1"])

@@ -572,6 +572,7 @@ struct node {
   u32 nchans;
   bool announced;
   u64 nann_rec;
+  u32 run_last = 0xFFFFFFFFu;  // apply_nann_run(): the run index of the last node_announcement of the run accepted for this node (RUN_NONE outside a run)
   std::vector<u64> scids;  // its channels (gossmap_nth_chan): remove_channel() walks them
 };
 // one record of the store; `off` = offset of its MESSAGE in the gossip_store image (header at off - 12): what gossip_store_add()
@@ -1246,7 +1247,7 @@ struct lamd_gossipd {
     }
     st.messages += b - a;
   }
-  enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3, RO_SIDE = 4 };
+  enum : u8 { RO_DROP = 0, RO_ACCEPT = 1, RO_BADSIG = 2, RO_DONTFWD = 3, RO_SIDE = 4, RO_UNKNOWN = 5 };
   // (what pass A decides about one update.  One array PER SHARD, in the shard's arrival order: the thread that owns a channel writes only
   // its own array -- verdict bytes of neighbouring messages in one shared array ping-pong their cache lines between the cores, which made the
   // 16-thread run slower per update than the one-by-one replay)
@@ -1428,6 +1429,170 @@ struct lamd_gossipd {
       char bb[16];
       snprintf(bb, sizeof bb, "/%d now ", dir);
       ev_text(LAMD_GEV_TRACE, u.has_src, &u.src, "Received channel_update for channel " + fmt_scid(u.scid) + bb + ((u.cflags & 2) ? "DISABLED" : "ACTIVE"));
+    }
+  }
+
+  // ---- a run of plain node_announcements (gossmap_manage_node_announcement, gossmap_manage.c:1162-1243, + process_node_announcement :1122-1160) on all
+  // cores: well-formed, address list sound, a verification slot planned.  What the one-by-one replay does for such a message is a lookup of its node,
+  // a timestamp comparison with the node's standing announcement and -- if newer -- one store record added, the old one deleted.  As for the
+  // channel_update runs: the messages are sharded by NODE (a node's announcements stay in arrival order inside their shard: of two in one run the later
+  // supersedes the earlier only if its timestamp is newer, as in the replay), record numbers and file offsets are a prefix sum over arrival order, the
+  // record bytes are written in parallel, the events are emitted by one serial pass in the replay's order.  A message whose node the map does not hold
+  // (queued behind a pending channel_announcement, or an unknown-node query) and one whose signature fails take their one-by-one path in that pass.
+  bool nann_run_member(const planned &p, const std::vector<int8_t> &v) const {
+    return p.type == GOSSIP_NANN && !p.malformed && !p.addrs_bad && p.slot >= 0 && v[p.slot] != -2 && v[p.slot] != -1;
+  }
+  std::vector<node *> rb_node;
+  void apply_nann_run(const std::vector<queued> &batch, const std::vector<planned> &plan, const std::vector<int8_t> &v, size_t a, size_t b) {
+    const size_t m = b - a;
+    const unsigned T = std::max(1u, std::min(std::min(get_pool()->size(), (unsigned)(m / 512 + 1)), nodes.shards()));
+    rb.where.resize(m);
+    rb.shard.resize(m);
+    rb_node.assign(m, nullptr);
+    if (rb.bucket.size() < (size_t)T * T) rb.bucket.resize((size_t)T * T);
+    if (rb.res.size() < T) rb.res.resize(T);
+    rb.base.assign((size_t)T * T, 0);
+    rb.cnt_rec.assign(T, 0);
+    rb.cnt_bytes.assign(T, 0);
+    const size_t step = (m + T - 1) / T;
+    thread_pool *tp = get_pool();
+    auto on_threads = [&](const std::function<void(unsigned)> &f) { tp->run(T, f); };
+    auto id_of = [&](size_t i, nodeid *id, u32 *ts) {
+      const mview &msg = batch[a + i].msg;
+      const gossip_frame f = gossip_parse_frame(msg.data(), msg.size());
+      memcpy(id->k, &msg[f.keyoff], 33);
+      *ts = be32(&msg[f.keyoff - 4]);
+    };
+    // ---- shard by node id (the node map's own shards, folded onto T workers), keeping arrival order inside a shard
+    on_threads([&](unsigned r) {
+      const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
+      for (unsigned t = 0; t < T; t++) { auto &bk = rb.bucket[(size_t)r * T + t]; bk.clear(); bk.reserve((hi - lo) / T + 16); }
+      for (size_t i = lo; i < hi; i++) {
+        nodeid id;
+        u32 ts;
+        id_of(i, &id, &ts);
+        const unsigned t = nodes.shard_of(id) % T;
+        rb.shard[i] = (u8)t;
+        rb.bucket[(size_t)r * T + t].push_back((u32)i);
+      }
+    });
+    for (unsigned t = 0; t < T; t++) {
+      size_t k = 0;
+      for (unsigned r = 0; r < T; r++) { rb.base[(size_t)r * T + t] = k; k += rb.bucket[(size_t)r * T + t].size(); }
+      rb.res[t].resize(k);
+    }
+    on_threads([&](unsigned r) {
+      for (unsigned t = 0; t < T; t++) {
+        const auto &bk = rb.bucket[(size_t)r * T + t];
+        const size_t k0 = rb.base[(size_t)r * T + t];
+        for (size_t j = 0; j < bk.size(); j++) rb.where[bk[j]] = (u32)(k0 + j);
+      }
+    });
+    // ---- pass A: decisions, per shard in arrival order (:1216-1243, :1125-1126)
+    on_threads([&](unsigned t) {
+      std::vector<run_res> &res = rb.res[t];
+      size_t k = 0;
+      for (unsigned r = 0; r < T; r++)
+        for (const u32 i : rb.bucket[(size_t)r * T + t]) {
+          run_res &R = res[k++];
+          R = run_res{~0ull, 0, 0, RUN_NONE, RO_DROP, 0, 0, 0};
+          const planned &p = plan[a + i];
+          if (v[p.slot] != 0) { R.outcome = RO_BADSIG; continue; }        // :1216-1219
+          nodeid id;
+          u32 ts;
+          id_of(i, &id, &ts);
+          auto it = nodes.find(id);
+          if (it == nodes.end()) { R.outcome = RO_UNKNOWN; continue; }     // :1222-1238: the serial pass takes the one-by-one path
+          node &n = it->second;
+          rb_node[i] = &n;
+          const u32 pr = n.run_last;
+          if (pr != RUN_NONE || n.announced) {                             // :1125-1126
+            u32 cur;
+            if (pr != RUN_NONE) { nodeid pid; id_of(pr, &pid, &cur); }
+            else cur = store[n.nann_rec].timestamp;
+            if (cur >= ts) continue;   // RO_DROP
+          }
+          R.outcome = RO_ACCEPT;
+          if (pr != RUN_NONE) { R.prev_run = pr; res[rb.where[pr]].dead = 1; }
+          else if (n.announced) R.prev_rec = n.nann_rec;
+          n.run_last = i;
+        }
+    });
+    // ---- pass B: record numbers and file offsets = a prefix sum over arrival order
+    on_threads([&](unsigned r) {
+      const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
+      size_t nr = 0, nb = 0;
+      for (size_t i = lo; i < hi; i++)
+        if (rb.res[rb.shard[i]][rb.where[i]].outcome == RO_ACCEPT) { nr++; nb += 12 + batch[a + i].msg.size(); }
+      rb.cnt_rec[r] = nr;
+      rb.cnt_bytes[r] = nb;
+    });
+    u64 nrec = store.size(), pos = image.size();
+    std::vector<u64> rec0(T), pos0(T);
+    for (unsigned r = 0; r < T; r++) { rec0[r] = nrec; pos0[r] = pos; nrec += rb.cnt_rec[r]; pos += rb.cnt_bytes[r]; }
+    store.resize(nrec);
+    image.resize(pos);
+    // ---- pass C: the records
+    on_threads([&](unsigned r) {
+      const size_t lo = std::min(m, r * step), hi = std::min(m, (r + 1) * step);
+      u64 rn = rec0[r], ps = pos0[r];
+      for (size_t i = lo; i < hi; i++) {
+        run_res &R = rb.res[rb.shard[i]][rb.where[i]];
+        if (R.outcome != RO_ACCEPT) continue;
+        const mview &msg = batch[a + i].msg;
+        node &n = *rb_node[i];
+        nodeid id;
+        u32 ts;
+        id_of(i, &id, &ts);
+        R.rec = rn++;
+        R.off = ps + 12;
+        ps += 12 + msg.size();
+        u8 *h = image.data() + R.off - 12;
+        put_be16(h, GS_COMPLETED | (R.dead ? GS_DELETED : 0u));
+        put_be16(h + 2, (u32)msg.size());
+        put_be32(h + 4, crc32c(ts, msg.data(), msg.size()));
+        put_be32(h + 8, ts);
+        memcpy(h + 12, msg.data(), msg.size());
+        store[R.rec] = record{GOSSIP_NANN, ts, R.dead != 0, R.off, (u32)msg.size()};
+        if (R.prev_rec != ~0ull) {  // gossip_store_del of the announcement this one supersedes (a node's records belong to its shard's worker... but
+          record &old = store[R.prev_rec];  // two ranges may hold two announcements of one node: only the FIRST accepted one of the run has prev_rec set)
+          old.deleted = true;
+          u8 *ho = image.data() + old.off - 12;
+          put_be16(ho, (((u32)ho[0] << 8) | ho[1]) | GS_DELETED);
+        }
+        if (!R.dead) {  // the node's standing announcement
+          n.announced = true;
+          n.nann_rec = R.rec;
+          n.run_last = RUN_NONE;
+        }
+      }
+    });
+    st.messages += m;
+    st.run_nodes += m;
+    // ---- pass D: the events of the one-by-one replay, in its order; the messages that take the one-by-one path
+    for (size_t i = 0; i < m; i++) {
+      const run_res &R = rb.res[rb.shard[i]][rb.where[i]];
+      const queued &q = batch[a + i];
+      const mview &msg = q.msg;
+      if (R.outcome == RO_BADSIG) { warning(q.has_src, &q.src, sigcheck_text(GOSSIP_NANN, 1, msg)); continue; }
+      if (R.outcome == RO_UNKNOWN) { st.run_nodes--; apply_nann(q, plan[a + i]); continue; }
+      if (R.outcome != RO_ACCEPT || !on_event) continue;
+      nodeid id;
+      u32 ts;
+      id_of(i, &id, &ts);
+      lamd_gossipd_event ev;
+      memset(&ev, 0, sizeof ev);
+      ev.kind = LAMD_GEV_STORE_ADD; ev.index = R.rec; ev.type = GOSSIP_NANN; ev.timestamp = ts; ev.values[0] = R.off;
+      ev.data = msg.data(); ev.len = msg.size();
+      emit(ev);
+      const u64 old = R.prev_rec != ~0ull ? R.prev_rec : (R.prev_run != RUN_NONE ? rb.res[rb.shard[R.prev_run]][rb.where[R.prev_run]].rec : ~0ull);
+      if (old != ~0ull) {
+        memset(&ev, 0, sizeof ev);
+        ev.kind = LAMD_GEV_STORE_DEL; ev.index = old; ev.type = GOSSIP_NANN; ev.values[0] = store[old].off;
+        emit(ev);
+      }
+      good_gossip(q.has_src, &q.src);
+      ev_text(LAMD_GEV_TRACE, q.has_src, &q.src, "Received node_announcement for node " + hexs(id.k, 33));
     }
   }
 
@@ -2055,6 +2220,15 @@ extern "C" long lamd_gossipd_process(lamd_gossipd *g) {
         while (!g->cann_run_member(plan[j - 1], g->cur_v)) j--;   // a run ends with a member
         if (members >= g->run_min) {
           g->apply_cann_run(batch, plan, i, j);
+          i = j - 1;
+          continue;
+        }
+      }
+      if (runs && g->nann_run_member(plan[i], g->cur_v)) {  // a run of plain node_announcements: all cores (apply_nann_run)
+        size_t j = i + 1;
+        while (j < cur.hi && g->nann_run_member(plan[j], g->cur_v)) j++;
+        if (j - i >= g->run_min) {
+          g->apply_nann_run(batch, plan, g->cur_v, i, j);
           i = j - 1;
           continue;
         }

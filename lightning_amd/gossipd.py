@@ -21,7 +21,7 @@ class Config(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("messages", "batches", "verified_messages", "verified_sigs", "keyparse_messages", "duplicates",
                                                "late_verifies", "channels", "nodes", "pending", "early", "queued_updates", "queued_nodes",
-                                               "store_records", "run_updates", "sub_batches", "overlapped_stages", "run_announcements")]
+                                               "store_records", "run_updates", "sub_batches", "overlapped_stages", "run_announcements", "run_nodes")]
 
 
 EVENT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(Event))

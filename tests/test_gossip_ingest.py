@@ -422,6 +422,92 @@ def test_update_runs_on_all_cores_equal_the_one_by_one_replay(orc, listener, mon
             assert kinds.get(kind, 0) > 10, (kind, kinds)
 
 
+def _node_flood(orc, seed, n_nodes=60, n_chans=50, n_msgs=2200):
+    """announced channels (so that most nodes exist), then ONE queue of node_announcements: rising, equal and falling timestamps per node, the same bytes
+    relayed again, damaged signatures, announcements signed by another node's key, nodes that have no channel (unknown node: a query + a bad-gossip mark, or
+    queued while an announcement is pending), an address list that does not parse and a truncated message now and then (they end a run), a channel_update
+    in between"""
+    import random
+    net = gs.Net(orc, seed, n_nodes=n_nodes, n_chans=n_chans)
+    for ch in net.chans:
+        ch["scid"] = ((net.height - 100) << 40) | (ch["scid"] & 0xFFFFFFFFFF)
+    rnd = random.Random(seed * 13 + 5)
+    ops = []
+    known = n_chans - 6                        # the last channels stay unannounced for a while: their nodes may be unknown
+    for c in range(known):
+        ops.append(("push", net.peers[c % len(net.peers)], net.cann(c)))
+    ops.append(("process",))
+    for c in range(known):
+        ops.append(("txout", net.chans[c]["scid"], net.chans[c]["sat"], net.spk(c)))
+    last, sent = {}, []
+    for k in range(n_msgs):
+        n = rnd.randrange(n_nodes)
+        x = rnd.random()
+        base = last.get(n, gs.NOW - 9000)
+        ts = base + rnd.choice([1, 1, 1, 2, 9, 0, 0, -1, -40])
+        last[n] = max(base, ts)
+        peer = rnd.choice(net.peers)
+        if x < 0.06 and sent:
+            m = rnd.choice(sent)
+        elif x < 0.10:
+            m = gs.damage(rnd, net.nann(n, ts), "sig")
+        elif x < 0.12:
+            m = net.nann(n, ts, sk=net.node_sk[(n + 1) % n_nodes])      # signed by somebody else
+        elif x < 0.16:
+            m = net.nann(n, ts, addrs=bytes([1, 127, 0, 0, 1, 0x26, 0x07]))  # one ipv4 address
+        else:
+            m = net.nann(n, ts)
+        sent.append(m)
+        ops.append(("push", peer, m))
+        if k % 500 == 499:                                              # run breakers
+            ops.append(("push", peer, gs.damage(rnd, net.nann(n, ts + 70), "trunc")))
+            ops.append(("push", peer, net.nann(n, ts + 80, addrs=bytes([1, 127, 0]))))      # an address list that runs off its end
+            ops.append(("push", peer, net.cupd(rnd.randrange(known), 0, gs.NOW - 50 + k)))
+        if k == n_msgs // 2:                                            # a channel_announcement goes pending: unknown nodes' announcements now queue
+            ops.append(("process",))
+            ops.append(("push", peer, net.cann(known)))
+            ops.append(("process",))
+    ops.append(("process",))
+    ops.append(("txout", net.chans[known]["scid"], net.chans[known]["sat"], net.spk(known)))
+    ops.append(("process",))
+    return net, ops
+
+
+@pytest.mark.parametrize("listener", [True, False])
+def test_node_announcement_runs_on_all_cores_equal_the_one_by_one_replay(orc, listener, monkeypatch):
+    """apply_nann_run (runs of plain node_announcements applied by all host cores: decisions sharded by node, record numbers / offsets by a prefix sum over
+    arrival order, bytes written in parallel, the events by one serial pass) against (a) the one-by-one replay of the same ingest and (b) the sequential
+    model of gossmap_manage.c:1162-1243: the same events in the same order and the same gossip_store image, byte for byte"""
+    from lightning_amd.gossipd import GossipIngest
+    net, ops = _node_flood(orc, 31)
+    model = ModelReceiver(orc, net)
+    gs.drive(net, ops, model, 31)
+    out = {}
+    for name, env in (("one_by_one", {"LAMD_INGEST_RUN_MIN": "0", "LAMD_INGEST_SUB": "1000000"}),
+                      ("runs", {"LAMD_INGEST_RUN_MIN": "4", "LAMD_INGEST_SUB": "1000000", "LAMD_INGEST_THREADS": "5"}),
+                      ("runs_pipelined", {"LAMD_INGEST_RUN_MIN": "3", "LAMD_INGEST_SUB": "170", "LAMD_INGEST_THREADS": "7"})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        with GossipIngest(None, gs.CHAIN, net.our_id, net.height, gs.NOW, backend=oracle_backend(orc), collect_events=listener) as ing:
+            gs.drive(net, ops, ing, 31)
+            out[name] = (list(ing.events) if listener else None, ing.store_image(), ing.stats())
+    assert out["one_by_one"][2]["run_nodes"] == 0
+    assert out["runs"][2]["run_nodes"] > 1200 and out["runs"][2]["late_verifies"] == 0, out["runs"][2]
+    assert out["runs_pipelined"][2]["run_nodes"] > 1000 and out["runs_pipelined"][2]["overlapped_stages"] >= 3, out["runs_pipelined"][2]
+    for name in ("runs", "runs_pipelined"):
+        assert out[name][1] == out["one_by_one"][1], "%s: the gossip_store image differs from the one-by-one replay's" % name
+        for key in ("messages", "channels", "nodes", "store_records", "queued_nodes"):
+            assert out[name][2][key] == out["one_by_one"][2][key], (name, key)
+    if listener:
+        _compare(out["one_by_one"][0], model.events)
+        _compare(out["runs"][0], model.events)
+        _compare(out["runs_pipelined"][0], model.events)
+        kinds = _kinds(model.events)
+        for kind in ("STORE_ADD", "STORE_DEL", "WARNING", "GOOD_GOSSIP", "TRACE"):
+            assert kinds.get(kind, 0) > 10, (kind, kinds)
+        assert kinds.get("QUERY_NODE", 0) > 0, kinds
+
+
 def _announcement_flood(orc, seed, n_chans=240):
     """ONE queue of channel_announcements: good ones, the same bytes relayed twice (the second meets a waiting announcement), damaged
     signatures / truncated / bad bitcoin keys (warnings only: they ride along in a run), swapped node ids and another chain (the plan
