@@ -58,6 +58,40 @@ if mode == "gossip":
     marker(3)
     print("whole job: host wall ms", " ".join("%.3f" % whole() for _ in range(2)))
     marker(4)
+elif mode == "storm":
+    # one 1/8 shard of BASELINE configs[4] (1 250 commitments: 937 ECDSA + 313 BIP-340) through the streaming queue as bench.py's strong-scaling sweep
+    # runs it; marker 8 | the shard x R (host wall printed per repetition, with the host time spent inside queue_*_batch / flush / wait) | marker 9
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    eng = Engine(0)
+    st = workload.make_commit_storm(eng, 10_000, device=dev)
+    per = st["per"]
+    bb = {kind: sharding.shard_bounds(st[kind].n, 8, [per] * (st[kind].n // per)) for kind in ("ecdsa", "schnorr")}
+    tq = {"queue": 0.0, "flush": 0.0, "wait": 0.0}
+    real = (eng.queue_ecdsa_batch, eng.queue_schnorr_batch, eng.flush, eng.wait)
+
+    def timed(name, fn):
+        def w(*a, **k):
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            tq[name] += time.perf_counter() - t
+            return r
+        return w
+    eng.queue_ecdsa_batch, eng.queue_schnorr_batch = timed("queue", real[0]), timed("queue", real[1])
+    eng.flush, eng.wait = timed("flush", real[2]), timed("wait", real[3])
+    depth = min(8, eng.info()["queue_sets"] - 1)
+    for _ in range(3):
+        bench.stream_shard(eng, st, bb, 0, 256 * per, depth)
+    marker(8)
+    for r in range(R):
+        for k in tq:
+            tq[k] = 0.0
+        t = time.perf_counter()
+        got = bench.stream_shard(eng, st, bb, 0, 256 * per, depth)
+        dt = time.perf_counter() - t
+        bad = sum(int((got[kind].astype(bool) != st[kind].expect[int(bb[kind][0]):int(bb[kind][1])]).sum()) for kind in got)
+        print("storm shard 0 of 8: %.3f ms host wall (queue_*_batch %.3f, flush %.3f, wait %.3f ms), mismatches %d" % (dt * 1e3, tq["queue"] * 1e3, tq["flush"] * 1e3, tq["wait"] * 1e3, bad))
+    marker(9)
 else:
     os.environ["LAMD_CACHE"] = "0"
     eng = Engine(0)
