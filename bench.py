@@ -759,6 +759,34 @@ def main():
             lat["commitment_484_one_htlc_key"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
                                                   "cache_hits_last_call": int(eng.info()["last_cache_hits"])}
         if world == 1 and extras:
+            # the same batch as ONE call of lamd_check_commitment_signed (channeld.c:2171-2232: transaction templates in, first_bad out): BIP143 hashing of the
+            # 1 + 483 inputs on the device + the verification; the arguments are marshalled once, the clock holds the C call only
+            try:
+                rb = np.random.default_rng(0xC0117)
+                rbytes = lambda k: bytes(rb.integers(0, 256, k, dtype=np.uint8))
+                outs_c = [(int(rb.integers(330, 10**7)), b"\x00\x20" + rbytes(32)) for _ in range(485)]
+                ctx_tx = dict(version=2, locktime=0x20000000, inputs=[(rbytes(32), 0, 0x80000001)], outputs=outs_c, input_num=0, amount=sum(a for a, _ in outs_c) + 5000,
+                              script=b"\x52\x21" + rbytes(33) + b"\x21" + rbytes(33) + b"\x52\xae")
+                htx = [dict(version=2, locktime=0, inputs=[(rbytes(32), i, 0)], outputs=[(outs_c[i][0] - 100, b"\x00\x20" + rbytes(32))], input_num=0, amount=outs_c[i][0],
+                            script=rbytes(133)) for i in range(483)]
+                # (the signatures are the storm rows': they do not verify against these templates' hashes -- the call's cost does not depend on the verdicts;
+                # parity of this entry point is tests/test_gpu_commitment.py's business)
+                cc = eng.commitment_call(ctx_tx, bytes(pp[0]), bytes(ss[0]), 1, htx, bytes(pp[1]), [bytes(x) for x in ss[1:484]], [1] * 483)
+                t1 = time.perf_counter()
+                cc()
+                t_first = time.perf_counter() - t1
+                cc()
+                ts = []
+                for it in range(60):
+                    t1 = time.perf_counter()
+                    cc()
+                    ts.append(time.perf_counter() - t1)
+                ts = np.sort(np.array(ts[5:])) * 1e3
+                lat["commitment_signed_one_call_484"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
+                                                         "note": "lamd_check_commitment_signed: templates -> BIP143 hashes on the device -> 1 + 483 verifications -> first_bad"}
+            except Exception as e:
+                lat["commitment_signed_one_call_484"] = {"error": repr(e)}
+        if world == 1 and extras:
             # BASELINE configs[0]: the committed 1 024 triples (tests/golden/cfg1.bin), ONE call per
             # signature through the reference's own prototype check_signed_hash(hash, sig, key) (bitcoin/signature.c:174-192)
             # in the C++ mirror -- what an unmodified caller sees; ns per call as onchaind/test/run-grind_feerate.c reports

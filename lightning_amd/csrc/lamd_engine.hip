@@ -1249,7 +1249,7 @@ struct lamd_ctx {
   devbuf list7, list10, listcold, listcold_ok;
   // latency path (k_small_verify): pinned, device-mapped staging for up to SMALL_MAX rows, the verdict bytes and the completion word
   u8 *h_small = nullptr;
-  u8 *h_tmpl = nullptr;       // pinned, device-mapped: the transaction templates of a lamd_check_commitment_signed call (read by k_txsig_tx_hash)
+  u8 *h_tmpl = nullptr;       // pinned: the flattened transaction templates of a lamd_check_commitment_signed / mid-size check_tx_sig call, copied to HBM from here
   size_t h_tmpl_cap = 0;
   devbuf small_done;          // block counter of k_small_verify grids (device memory)
   std::vector<u64> small_missed;   // fingerprints of keys the latency path verified without a table (MISS_SLOTS, 4-way set-associative)
@@ -2975,8 +2975,8 @@ static int txsig_tx_general(lamd_ctx *ctx, size_t n, const uint32_t *version, co
   return lamd_synchronize(ctx);  // (B.st is pageable: the runtime staged it before hipMemcpyAsync returned)
 }
 
-// <= SMALL_MAX rows with the BIP143 hashes made ON THE DEVICE: the templates go into a pinned, device-mapped block, k_txsig_tx_hash reads them there and
-// leaves hashes and gate in device memory, k_small_verify -- queued right behind it -- takes them from there.  Two launches, no copy command.  (Hashing on
+// <= SMALL_MAX rows with the BIP143 hashes made ON THE DEVICE: the templates go into a pinned block, ONE asynchronous copy takes them to HBM, k_txsig_tx_hash
+// leaves hashes and gate in device memory, k_small_verify -- queued right behind it -- takes them from there.  One small copy, two launches.  (Hashing on
 // the host, which the small callers do for a handful of rows, is ~12 SHA-256 compressions per row: 1.7 ms for a 484-row commitment, 14 ms for eight of them.)
 // LAMD_OK: verdicts in ok[]; 1: a key the latency path met before without a table is back -- the caller takes the batch path (force_learn is set).
 static int txsig_small_device(lamd_ctx *ctx, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
@@ -2994,8 +2994,13 @@ static int txsig_small_device(lamd_ctx *ctx, size_t n, const uint32_t *version, 
   }
   if ((rc = ensure(ctx, &ctx->in_a, n * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
+  if ((rc = ensure(ctx, &ctx->g_msgs, B.total)) != LAMD_OK) return rc;
   memcpy(ctx->h_tmpl, B.st.data(), B.total);
-  if ((rc = txsig_hash_launch(ctx, n, B, ctx->h_tmpl, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
+  // one asynchronous copy of the block (pinned -> HBM, ~250 B per row), then the hashing kernel over HBM.  The first version of this path let the kernel
+  // read the templates where they lay, through the device mapping of the pinned block: 484 lanes walking ~250 bytes each byte by byte over PCIe took 6.5 ms
+  // (rocprofv3, tools/commit_trace_probe.py) -- reading host memory from a kernel is fine for one 161-byte row, not for a SHA-256 input stream.
+  HIPCHK(ctx, hipMemcpyAsync(ctx->g_msgs.p, ctx->h_tmpl, B.total, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = txsig_hash_launch(ctx, n, B, (const u8 *)ctx->g_msgs.p, (u8 *)ctx->in_a.p, (u8 *)ctx->g_malformed.p)) != LAMD_OK) return rc;
   rc = run_small(ctx, MODE_ECDSA, n, nullptr, sig64, pub, (int)publen, pubstride, ok, (const u8 *)ctx->in_a.p, (const u8 *)ctx->g_malformed.p);
   if (rc == 1) ctx->force_learn = true;
   return rc;

@@ -28,6 +28,7 @@ if "cfg4_gossip_replay" in o:
 if "latency" in d:
     print("latency", {k: (round(v["p50_ms"], 3), round(v["p99_ms"], 3)) for k, v in d["latency"].items() if isinstance(v, dict) and "p50_ms" in v},
           "commit first", round(d["latency"].get("commitment_484_one_htlc_key", {}).get("first_sight_ms", 0), 3),
+          "commitment_signed one call", d["latency"].get("commitment_signed_one_call_484"),
           "cfg1 ns/call", round(d["latency"].get("cfg1_one_by_one_check_signed_hash", {}).get("ns_per_call", 0)))
 ss = d.get("strong_scaling_1gpu")
 if ss:
