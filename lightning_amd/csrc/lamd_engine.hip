@@ -217,9 +217,15 @@ __global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__re
                                                        const u8 *__restrict__ outputs, const u64 *__restrict__ out_off,
                                                        const u32 *__restrict__ n_outputs, const u8 *__restrict__ scripts,
                                                        const u64 *__restrict__ script_off, const u8 *__restrict__ sighash_type,
-                                                       const u8 *__restrict__ has_witness, u8 *__restrict__ hash32, u8 *__restrict__ gate) {
+                                                       const u8 *__restrict__ has_witness, const u8 *__restrict__ host_done, const u8 *__restrict__ host_hash,
+                                                       u8 *__restrict__ hash32, u8 *__restrict__ gate) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (host_done[i]) {  // a row with a long input / output list: the host hashed it (txsig_pack) -- one lane would walk 20 KB of outputs for milliseconds
+    for (int b = 0; b < 32; b++) hash32[32 * i + b] = host_hash[32 * i + b];
+    gate[i] = host_done[i] == 1;
+    return;
+  }
   gate[i] = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
                               has_witness, hash32 + 32 * i);
 }
@@ -2920,8 +2926,12 @@ extern "C" int lamd_check_tx_sig_batch(lamd_ctx *ctx, size_t n, const uint8_t *p
 // three byte strings; offsets relative to the call's first row) and the hashing kernel over it
 struct txsig_blob {
   std::vector<u8> st;
-  size_t o_inoff, o_outoff, o_scoff, o_amt, o_ver, o_lock, o_inum, o_nout, o_type, o_wit, o_in, o_out, o_sc, total;
+  size_t o_inoff, o_outoff, o_scoff, o_amt, o_ver, o_lock, o_inum, o_nout, o_type, o_wit, o_in, o_out, o_sc, o_hdone, o_hhash, total;
 };
+// A row whose transaction has long lists (a commitment transaction with its 485 outputs: 20 KB under hashOutputs) is hashed on the HOST while the blob is
+// packed: SHA-256 is sequential, one lane needs ~6.5 ms for it (measured: the whole 484-row call took that long), a host core ~0.1 ms.  host_done: 0 = the
+// device hashes the row, 1 = hashed here and the gate passed, 2 = hashed here and the gate refused.
+constexpr size_t TXSIG_HOST_ROW_BYTES = 1024;
 static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
                        const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs, const uint64_t *out_off, const uint32_t *n_outputs,
                        const uint8_t *scripts, const uint64_t *script_off, const uint8_t *sighash_type, const uint8_t *has_witness) {
@@ -2930,7 +2940,7 @@ static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const u
   auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
   B.o_inoff = take((n + 1) * 8); B.o_outoff = take((n + 1) * 8); B.o_scoff = take((n + 1) * 8); B.o_amt = take(n * 8); B.o_ver = take(n * 4);
   B.o_lock = take(n * 4); B.o_inum = take(n * 4); B.o_nout = take(n * 4); B.o_type = take(n); B.o_wit = take(n); B.o_in = take(nin * 40 + 16);
-  B.o_out = take(nout_b + 16); B.o_sc = take(nsc + 16); B.total = o;
+  B.o_out = take(nout_b + 16); B.o_sc = take(nsc + 16); B.o_hdone = take(n); B.o_hhash = take(32 * n); B.total = o;
   B.st.assign(B.total, 0);
   std::vector<u8> &st = B.st;
   auto rel = [&](size_t at, const uint64_t *src) { for (size_t i = 0; i <= n; i++) ((u64 *)&st[at])[i] = src[i] - src[0]; };
@@ -2938,12 +2948,18 @@ static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const u
   memcpy(&st[B.o_amt], amount_sat, n * 8); memcpy(&st[B.o_ver], version, n * 4); memcpy(&st[B.o_lock], locktime, n * 4);
   memcpy(&st[B.o_inum], input_num, n * 4); memcpy(&st[B.o_nout], n_outputs, n * 4); memcpy(&st[B.o_type], sighash_type, n); memcpy(&st[B.o_wit], has_witness, n);
   memcpy(&st[B.o_in], inputs40 + 40 * in_off[0], nin * 40); memcpy(&st[B.o_out], outputs + out_off[0], nout_b); memcpy(&st[B.o_sc], scripts + script_off[0], nsc);
+  for (size_t i = 0; i < n; i++)
+    if ((size_t)(out_off[i + 1] - out_off[i]) + 40 * (size_t)(in_off[i + 1] - in_off[i]) > TXSIG_HOST_ROW_BYTES) {
+      const bool pass = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
+                                          has_witness, &st[B.o_hhash + 32 * i]);
+      st[B.o_hdone + i] = pass ? 1 : 2;
+    }
 }
 // BIP143 hash + gate of every row of the blob at `d` (device memory, or pinned device-mapped host memory) -> d_hash32, d_gate
 static int txsig_hash_launch(lamd_ctx *ctx, size_t n, const txsig_blob &B, const u8 *d, u8 *d_hash32, u8 *d_gate) {
   hipLaunchKernelGGL(k_txsig_tx_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)(d + B.o_ver), (const u32 *)(d + B.o_lock), d + B.o_in,
                      (const u64 *)(d + B.o_inoff), (const u32 *)(d + B.o_inum), (const u64 *)(d + B.o_amt), d + B.o_out, (const u64 *)(d + B.o_outoff),
-                     (const u32 *)(d + B.o_nout), d + B.o_sc, (const u64 *)(d + B.o_scoff), d + B.o_type, d + B.o_wit, d_hash32, d_gate);
+                     (const u32 *)(d + B.o_nout), d + B.o_sc, (const u64 *)(d + B.o_scoff), d + B.o_type, d + B.o_wit, d + B.o_hdone, d + B.o_hhash, d_hash32, d_gate);
   HIPCHK(ctx, hipGetLastError());
   return LAMD_OK;
 }
