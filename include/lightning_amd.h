@@ -157,8 +157,9 @@ int lamd_check_tx_sig_tx_batch(lamd_ctx *ctx, size_t n, const uint32_t *version,
  *   check_tx_sig(txs[1+i], 0, NULL, wscript_i, &remote_htlckey, &htlc_sigs[i])              (:2224)
  * one signature per call, failing the peer at the first bad one.  Here the 1 + N rows are one batch -- the largest natural batch of the
  * product, <= 1 + 483 signatures, N of them under ONE key: the BIP143 hashes of all 1 + N inputs are computed on the device from the
- * templates (nothing is hashed on the host), a commitment of <= 4096 rows is two launches with no copy command (k_txsig_tx_hash reading the
- * templates from pinned memory, k_small_verify behind it), larger ones take the batch machinery.
+ * templates (a row with a long output / input list -- the commitment transaction's one output per HTLC -- is hashed on the host while the
+ * rows are packed: SHA-256 is sequential and one lane would need milliseconds for it), a commitment of <= 4096 rows is one small copy and two
+ * launches (k_txsig_tx_hash, then k_small_verify taking hashes and sighash-type gate from device memory), larger ones take the batch machinery.
  *   *first_bad = -1: every signature verifies;  0: the commitment signature does not;  1 + i: htlc_sigs[i] is the first that does not
  * -- the reference's order, so the caller prints exactly the warning the reference would ("Bad commit_sig signature ..." with or without
  * "for htlc": include/cln_shim.h check_commit_sigs()).  ok_rows (optional, 1 + n_htlc bytes): every row's verdict.

@@ -211,23 +211,177 @@ __global__ void __launch_bounds__(256) k_txsig_hash(size_t n, const u8 *__restri
   if (i >= n) return;
   gate[i] = txsig_hash_one(pre + off[i], (size_t)(off[i + 1] - off[i]), sighash_type[i], has_witness[i] != 0, hash32 + 32 * i);
 }
-__global__ void __launch_bounds__(256) k_txsig_tx_hash(size_t n, const u32 *__restrict__ version, const u32 *__restrict__ locktime,
-                                                       const u8 *__restrict__ inputs40, const u64 *__restrict__ in_off,
-                                                       const u32 *__restrict__ input_num, const u64 *__restrict__ amount,
-                                                       const u8 *__restrict__ outputs, const u64 *__restrict__ out_off,
-                                                       const u32 *__restrict__ n_outputs, const u8 *__restrict__ scripts,
-                                                       const u64 *__restrict__ script_off, const u8 *__restrict__ sighash_type,
-                                                       const u8 *__restrict__ has_witness, const u8 *__restrict__ host_done, const u8 *__restrict__ host_hash,
-                                                       u8 *__restrict__ hash32, u8 *__restrict__ gate) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// ---- BIP143 on the device, one (transaction, input) per lane: what bip143_sighash() (verify_core.h: the host's form, byte-wise streaming) computes,
+// laid out for a wavefront.  The streaming form compiled to 72 k instructions (every shs_update site carries its own unrolled compression: 580 KB of code for
+// an instruction cache of 64 KB) with the block buffer in scratch because it is indexed by a run-time byte count: 226 us for the 483 HTLC rows of a
+// commitment_signed, a third of it compressions.  Here each of the four streams of a row (hashPrevouts, hashSequence, hashOutputs, the preimage) is laid
+// out as a padded message in a per-lane LDS buffer -- word j of lane t at w[j * TXH_LANES + t], so a wave's accesses fall into 64 different banks whatever
+// position each lane is at -- and hashed by ONE loop with ONE compression site (the second hash of the double SHA-256 is that loop's last turn).  Bytes
+// from global memory are fetched sixteen at a time so that their latencies overlap.  A row whose streams do not fit the buffer never gets here: txsig_pack
+// hashes it on the host (TXSIG_DEV_MAX_*).
+constexpr int TXH_LANES = 64;
+constexpr u32 TXH_WORDS = 240;                      // per lane: 960 bytes = 15 blocks (61 440 bytes of LDS per work-group)
+constexpr u32 TXH_MAX_STREAM = 4 * TXH_WORDS - 9;   // 0x80 and the 64-bit length must fit behind the message
+__device__ __forceinline__ void txh_put(u32 *w, u32 pos, u32 byte) {  // message byte `pos`; words are big-endian, LDS is little-endian
+  reinterpret_cast<u8 *>(w + (size_t)(pos >> 2) * TXH_LANES)[3 - (pos & 3)] = (u8)byte;
+}
+__device__ __forceinline__ u32 txh_copy(u32 *w, u32 pos, const u8 *__restrict__ p, u32 n) {
+#pragma unroll 1
+  for (u32 k = 0; k < n; k += 16) {
+    u32 b[16];
+#pragma unroll
+    for (u32 j = 0; j < 16; j++) b[j] = p[k + j < n ? k + j : n - 1];  // sixteen loads in flight; the index is clamped, not predicated
+#pragma unroll
+    for (u32 j = 0; j < 16; j++)
+      if (k + j < n) txh_put(w, pos + k + j, b[j]);
+  }
+  return pos + n;
+}
+__device__ __forceinline__ u32 txh_put_be32(u32 *w, u32 pos, u32 v) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) txh_put(w, pos + k, v >> (24 - 8 * k));
+  return pos + 4;
+}
+__device__ __forceinline__ u32 txh_put_le(u32 *w, u32 pos, u64 v, int bytes) {
+  for (int k = 0; k < bytes; k++) txh_put(w, pos + k, (u32)(v >> (8 * k)));
+  return pos + bytes;
+}
+// false: the template is inconsistent (bip143_sighash's cases) or a stream does not fit the buffer; h = SHA256d of the preimage as 8 big-endian words
+__device__ __forceinline__ bool bip143_sighash_lane(u32 *w, const tx_view &t, u32 in_idx, const u8 *__restrict__ script, u32 script_len, u64 amount,
+                                                    u32 sighash_type, u32 h[8]) {
+  if (in_idx >= t.n_in) return false;
+  if (t.outputs_len > TXH_MAX_STREAM || (u64)t.n_in * 36 > TXH_MAX_STREAM || (u64)script_len + 165 > TXH_MAX_STREAM) return false;
+  const bool acp = (sighash_type & 0x80u) != 0;
+  const u32 base = sighash_type & 0x1fu;
+  const bool single = base == 3, none = base == 2;
+  // the outputs must parse; SINGLE needs the boundaries of output [in_idx]
+  size_t at = 0, one_off = 0, one_len = 0;
+  for (u32 k = 0; k < t.n_out; k++) {
+    if (t.outputs_len - at < 8) return false;
+    u64 sl;
+    const size_t l = tx_compact_size(t.outputs + at + 8, t.outputs_len - at - 8, &sl);
+    if (!l || sl > t.outputs_len - at - 8 - l) return false;
+    const size_t len = 8 + l + (size_t)sl;
+    if (k == in_idx) { one_off = at; one_len = len; }
+    at += len;
+  }
+  if (at != t.outputs_len) return false;
+  u32 hp[8], hs[8], ho[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) hp[j] = hs[j] = ho[j] = h[j] = 0;
+#pragma unroll 1
+  for (int ph = 0; ph < 4; ph++) {
+    u32 len = 0;
+    bool run = true;
+    if (ph == 0) {  // hashPrevouts
+      run = !acp;
+      if (run)
+        for (u32 i = 0; i < t.n_in; i++) len = txh_copy(w, len, t.inputs + 40 * (size_t)i, 36);
+    } else if (ph == 1) {  // hashSequence
+      run = !acp && !single && !none;
+      if (run)
+        for (u32 i = 0; i < t.n_in; i++) len = txh_copy(w, len, t.inputs + 40 * (size_t)i + 36, 4);
+    } else if (ph == 2) {  // hashOutputs
+      if (single) {
+        run = in_idx < t.n_out;
+        if (run) len = txh_copy(w, 0, t.outputs + one_off, (u32)one_len);
+      } else if (none) {
+        run = false;
+      } else {
+        len = txh_copy(w, 0, t.outputs, (u32)t.outputs_len);
+      }
+    } else {  // nVersion | hashPrevouts | hashSequence | outpoint | varint script | amount | nSequence | hashOutputs | nLockTime | type
+      len = txh_put_le(w, len, t.version, 4);
+#pragma unroll
+      for (int j = 0; j < 8; j++) len = txh_put_be32(w, len, hp[j]);
+#pragma unroll
+      for (int j = 0; j < 8; j++) len = txh_put_be32(w, len, hs[j]);
+      len = txh_copy(w, len, t.inputs + 40 * (size_t)in_idx, 36);
+      if (script_len < 0xfd) len = txh_put_le(w, len, script_len, 1);
+      else if (script_len <= 0xffff) { len = txh_put_le(w, len, 0xfd, 1); len = txh_put_le(w, len, script_len, 2); }
+      else { len = txh_put_le(w, len, 0xfe, 1); len = txh_put_le(w, len, script_len, 4); }
+      len = txh_copy(w, len, script, script_len);
+      len = txh_put_le(w, len, amount, 8);
+      len = txh_copy(w, len, t.inputs + 40 * (size_t)in_idx + 36, 4);
+#pragma unroll
+      for (int j = 0; j < 8; j++) len = txh_put_be32(w, len, ho[j]);
+      len = txh_put_le(w, len, t.locktime, 4);
+      len = txh_put_le(w, len, sighash_type, 4);
+    }
+    if (!run) continue;
+    // padding: 0x80, zeros to the last two words of a block, the bit length
+    u32 pos = len;
+    txh_put(w, pos++, 0x80u);
+    while (pos & 3) txh_put(w, pos++, 0u);
+    u32 wi = pos >> 2;
+    for (; (wi & 15) != 14; wi++) w[(size_t)wi * TXH_LANES] = 0;
+    w[(size_t)wi * TXH_LANES] = 0;
+    w[(size_t)(wi + 1) * TXH_LANES] = len * 8;
+    const u32 nb = (wi + 2) >> 4;
+    u32 st[8] = LAMD_SHA256_IV;
+#pragma unroll 1
+    for (u32 b = 0; b <= nb; b++) {  // turn nb = the second hash, over the first one's digest
+      u32 x[16];
+      if (b < nb) {
+#pragma unroll
+        for (u32 j = 0; j < 16; j++) x[j] = w[(size_t)(16 * b + j) * TXH_LANES];
+      } else {
+        const u32 iv[8] = LAMD_SHA256_IV;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { x[j] = st[j]; st[j] = iv[j]; }
+        x[8] = 0x80000000u;
+#pragma unroll
+        for (int j = 9; j < 15; j++) x[j] = 0;
+        x[15] = 256;
+      }
+      sha256_compress(st, x);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (ph == 0) hp[j] = st[j];
+      else if (ph == 1) hs[j] = st[j];
+      else if (ph == 2) ho[j] = st[j];
+      else h[j] = st[j];
+    }
+  }
+  return true;
+}
+// hash32 must be 4-byte aligned (it is a device allocation of the context)
+__global__ void __launch_bounds__(TXH_LANES) k_txsig_tx_hash(size_t n, const u32 *__restrict__ version, const u32 *__restrict__ locktime,
+                                                             const u8 *__restrict__ inputs40, const u64 *__restrict__ in_off,
+                                                             const u32 *__restrict__ input_num, const u64 *__restrict__ amount,
+                                                             const u8 *__restrict__ outputs, const u64 *__restrict__ out_off,
+                                                             const u32 *__restrict__ n_outputs, const u8 *__restrict__ scripts,
+                                                             const u64 *__restrict__ script_off, const u8 *__restrict__ sighash_type,
+                                                             const u8 *__restrict__ has_witness, const u8 *__restrict__ host_done,
+                                                             const u8 *__restrict__ host_hash, u8 *__restrict__ hash32, u8 *__restrict__ gate) {
+  __shared__ u32 lds[TXH_WORDS * TXH_LANES];
+  const size_t i = (size_t)blockIdx.x * TXH_LANES + threadIdx.x;
   if (i >= n) return;
-  if (host_done[i]) {  // a row with a long input / output list: the host hashed it (txsig_pack) -- one lane would walk 20 KB of outputs for milliseconds
+  if (host_done[i]) {  // a row with a long input / output list or script: the host hashed it (txsig_pack) -- one lane would walk 20 KB of outputs for milliseconds
     for (int b = 0; b < 32; b++) hash32[32 * i + b] = host_hash[32 * i + b];
     gate[i] = host_done[i] == 1;
     return;
   }
-  gate[i] = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
-                              has_witness, hash32 + 32 * i);
+  const u8 t = sighash_type[i];
+  bool pass = t == 1 || (t == 0x83 && has_witness[i]);  // the gate of bitcoin/signature.c:206-211 (txsig_tx_hash_one)
+  u32 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pass) {
+    tx_view tv;
+    tv.version = version[i];
+    tv.locktime = locktime[i];
+    tv.inputs = inputs40 + 40 * in_off[i];
+    tv.n_in = (u32)(in_off[i + 1] - in_off[i]);
+    tv.outputs = outputs + out_off[i];
+    tv.outputs_len = (size_t)(out_off[i + 1] - out_off[i]);
+    tv.n_out = n_outputs[i];
+    const u64 sl = script_off[i + 1] - script_off[i];
+    pass = sl <= TXH_MAX_STREAM && bip143_sighash_lane(lds + threadIdx.x, tv, input_num[i], scripts + script_off[i], (u32)sl, amount[i], t, h);
+  }
+  u32 *out = reinterpret_cast<u32 *>(hash32) + 8 * i;
+#pragma unroll
+  for (int j = 0; j < 8; j++) out[j] = pass ? __builtin_bswap32(h[j]) : 0u;
+  gate[i] = pass;
 }
 // ---- BOLT #12: merkle root + tagged signature hash of one TLV stream per lane (bolt12.h); valid[i] = the stream obeys the TLV rules
 __global__ void __launch_bounds__(64) k_bolt12_hash(size_t n, const u8 *__restrict__ tlvs, const u64 *__restrict__ off, bolt12_mids mids,
@@ -2931,7 +3085,8 @@ struct txsig_blob {
 // A row whose transaction has long lists (a commitment transaction with its 485 outputs: 20 KB under hashOutputs) is hashed on the HOST while the blob is
 // packed: SHA-256 is sequential, one lane needs ~6.5 ms for it (measured: the whole 484-row call took that long), a host core ~0.1 ms.  host_done: 0 = the
 // device hashes the row, 1 = hashed here and the gate passed, 2 = hashed here and the gate refused.
-constexpr size_t TXSIG_HOST_ROW_BYTES = 1024;
+constexpr size_t TXSIG_DEV_MAX_OUT = 900, TXSIG_DEV_MAX_IN = 25, TXSIG_DEV_MAX_SCRIPT = 700;  // each stream of a device row stays below TXH_MAX_STREAM
+static_assert(TXSIG_DEV_MAX_OUT <= TXH_MAX_STREAM && 36 * TXSIG_DEV_MAX_IN <= TXH_MAX_STREAM && TXSIG_DEV_MAX_SCRIPT + 165 <= TXH_MAX_STREAM, "device rows must fit the lane buffer");
 static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
                        const uint32_t *input_num, const uint64_t *amount_sat, const uint8_t *outputs, const uint64_t *out_off, const uint32_t *n_outputs,
                        const uint8_t *scripts, const uint64_t *script_off, const uint8_t *sighash_type, const uint8_t *has_witness) {
@@ -2949,7 +3104,8 @@ static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const u
   memcpy(&st[B.o_inum], input_num, n * 4); memcpy(&st[B.o_nout], n_outputs, n * 4); memcpy(&st[B.o_type], sighash_type, n); memcpy(&st[B.o_wit], has_witness, n);
   memcpy(&st[B.o_in], inputs40 + 40 * in_off[0], nin * 40); memcpy(&st[B.o_out], outputs + out_off[0], nout_b); memcpy(&st[B.o_sc], scripts + script_off[0], nsc);
   for (size_t i = 0; i < n; i++)
-    if ((size_t)(out_off[i + 1] - out_off[i]) + 40 * (size_t)(in_off[i + 1] - in_off[i]) > TXSIG_HOST_ROW_BYTES) {
+    if ((size_t)(out_off[i + 1] - out_off[i]) > TXSIG_DEV_MAX_OUT || (size_t)(in_off[i + 1] - in_off[i]) > TXSIG_DEV_MAX_IN ||
+        (size_t)(script_off[i + 1] - script_off[i]) > TXSIG_DEV_MAX_SCRIPT) {
       const bool pass = txsig_tx_hash_one(i, version, locktime, inputs40, in_off, input_num, amount_sat, outputs, out_off, n_outputs, scripts, script_off, sighash_type,
                                           has_witness, &st[B.o_hhash + 32 * i]);
       st[B.o_hdone + i] = pass ? 1 : 2;
@@ -2957,7 +3113,7 @@ static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const u
 }
 // BIP143 hash + gate of every row of the blob at `d` (device memory, or pinned device-mapped host memory) -> d_hash32, d_gate
 static int txsig_hash_launch(lamd_ctx *ctx, size_t n, const txsig_blob &B, const u8 *d, u8 *d_hash32, u8 *d_gate) {
-  hipLaunchKernelGGL(k_txsig_tx_hash, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)(d + B.o_ver), (const u32 *)(d + B.o_lock), d + B.o_in,
+  hipLaunchKernelGGL(k_txsig_tx_hash, dim3((unsigned)((n + TXH_LANES - 1) / TXH_LANES)), dim3(TXH_LANES), 0, ctx->stream, n, (const u32 *)(d + B.o_ver), (const u32 *)(d + B.o_lock), d + B.o_in,
                      (const u64 *)(d + B.o_inoff), (const u32 *)(d + B.o_inum), (const u64 *)(d + B.o_amt), d + B.o_out, (const u64 *)(d + B.o_outoff),
                      (const u32 *)(d + B.o_nout), d + B.o_sc, (const u64 *)(d + B.o_scoff), d + B.o_type, d + B.o_wit, d + B.o_hdone, d + B.o_hhash, d_hash32, d_gate);
   HIPCHK(ctx, hipGetLastError());

@@ -1110,6 +1110,59 @@ def test_check_tx_sig_from_transaction_templates_vs_spec_model(eng, orc):
 
 
 @pytest.mark.gpu
+def test_check_tx_sig_templates_at_the_stream_boundaries(eng, orc):
+    """The device's BIP143 form lays each of a row's four SHA-256 streams out in a per-lane buffer of 960 bytes (k_txsig_tx_hash): every script
+    length 0 .. 140 (each padding case of the preimage), the CompactSize steps (252 / 253 / 254), input and output lists up to and across the
+    limits behind which txsig_pack hashes the row on the host (25 inputs, 900 bytes of outputs, a 700-byte script), no outputs at all,
+    SIGHASH_SINGLE|ANYONECANPAY on an input with and without its output.  Every row carries a VALID signature over pyref's sighash, so a
+    single wrong byte in any stream shows; every seventh row is damaged after signing."""
+    rnd = random.Random(5150)
+    rb = lambda k: bytes(rnd.randrange(256) for _ in range(k))
+    keys = [bytes(rnd.randrange(1, 256) for _ in range(32)) for _ in range(5)]
+    pubs33 = [pyref.ser33(pyref.pubkey_create(int.from_bytes(d, "big"))) for d in keys]
+    shapes = [(1, 1, sl) for sl in range(0, 141)]
+    shapes += [(1, 1, sl) for sl in (251, 252, 253, 254, 255, 256, 300, 511, 698, 699, 700, 701, 702, 786, 787, 900, 1500)]
+    shapes += [(ni, 1, 133) for ni in (2, 3, 7, 24, 25, 26, 27, 30, 60)]
+    shapes += [(1, no, 133) for no in (0, 2, 5, 19, 20, 21, 22, 23, 40)]        # 43 bytes each: 20 = 860, 21 = 903 bytes
+    shapes += [(rnd.randrange(1, 27), rnd.randrange(0, 23), rnd.randrange(0, 720)) for _ in range(120)]
+    txs, sigs, pubs, exp = [], [], [], []
+    for it, (n_in, n_out, sl) in enumerate(shapes * 2):
+        ty = 1 if it < len(shapes) else 0x83
+        inputs = [(rb(32), rnd.randrange(1 << 32), rnd.randrange(1 << 32)) for _ in range(n_in)]
+        outputs = [(rnd.randrange(1 << 40), rb(34)) for _ in range(n_out)]
+        t = dict(version=2, locktime=rnd.randrange(1 << 32), inputs=inputs, outputs=outputs, input_num=rnd.randrange(n_in), amount=rnd.randrange(1 << 44),
+                 script=rb(sl), sighash_type=ty, has_witness=True)
+        k = it % len(keys)
+        h = pyref.bip143_sighash(2, inputs, outputs, t["locktime"], t["input_num"], t["script"], t["amount"], ty)[0]
+        sig = orc.ecdsa_sign(h, keys[k], bytes(rnd.randrange(1, 256) for _ in range(32)))
+        if it % 7 == 3:
+            what = rnd.randrange(4)
+            if what == 0 and sl:
+                j = rnd.randrange(sl)
+                t["script"] = t["script"][:j] + bytes([t["script"][j] ^ 0x10]) + t["script"][j + 1:]
+            elif what == 1 and n_out:
+                j = rnd.randrange(n_out)
+                t["outputs"] = outputs[:j] + [(outputs[j][0] ^ 1, outputs[j][1])] + outputs[j + 1:]
+            elif what == 2:
+                j = rnd.randrange(n_in)
+                t["inputs"] = inputs[:j] + [(inputs[j][0], inputs[j][1] ^ 1, inputs[j][2])] + inputs[j + 1:]
+            else:
+                t["locktime"] ^= 1 << rnd.randrange(32)
+        h2 = pyref.bip143_sighash(2, t["inputs"], t["outputs"], t["locktime"], t["input_num"], t["script"], t["amount"], ty)[0]
+        txs.append(t); sigs.append(sig); pubs.append(pubs33[k])
+        exp.append(bool(orc.ecdsa_verify(h2, sig, pubs33[k])))
+    assert 17 < len(txs) <= 4096                       # the two-launch path (txsig_small_device)
+    got = eng.check_tx_sig_tx_batch(txs, _rows(sigs, 64), _rows(pubs, 33))
+    bad = [(i, shapes[i % len(shapes)], txs[i]["sighash_type"]) for i in range(len(txs)) if bool(got[i]) != exp[i]]
+    assert not bad, bad[:10]
+    assert sum(exp) > 0.8 * len(exp)
+    # the same rows through the batch machinery (more than 4096 rows in one call)
+    reps = 4096 // len(txs) + 1
+    got = eng.check_tx_sig_tx_batch(txs * reps, np.tile(_rows(sigs, 64), (reps, 1)), np.tile(_rows(pubs, 33), (reps, 1)))
+    assert [bool(g) for g in got] == exp * reps
+
+
+@pytest.mark.gpu
 def test_bolt12_reference_held_strings_on_device(eng, kat):
     """The lni1 / lnr1 literals of the reference tree (tests/test_misc.py:5254, tests/test_pay.py:7183, tests/test_xpay.py:788,
     doc/schemas -- signed by the reference's libsecp256k1; kat.json "bolt12"): lamd_bolt12_check_signature_batch must accept every
