@@ -3082,9 +3082,10 @@ struct txsig_blob {
   std::vector<u8> st;
   size_t o_inoff, o_outoff, o_scoff, o_amt, o_ver, o_lock, o_inum, o_nout, o_type, o_wit, o_in, o_out, o_sc, o_hdone, o_hhash, total;
 };
-// A row whose transaction has long lists (a commitment transaction with its 485 outputs: 20 KB under hashOutputs) is hashed on the HOST while the blob is
-// packed: SHA-256 is sequential, one lane needs ~6.5 ms for it (measured: the whole 484-row call took that long), a host core ~0.1 ms.  host_done: 0 = the
-// device hashes the row, 1 = hashed here and the gate passed, 2 = hashed here and the gate refused.
+// A row whose transaction has long lists (a commitment transaction with its 485 outputs: 20 KB under hashOutputs) or a very long script is hashed on the HOST
+// while the blob is packed: SHA-256 is sequential, one lane needed ~6.5 ms for the 20 KB (measured: the whole 484-row call took that long), a host core
+// ~0.1 ms; and the device's per-lane message buffer (k_txsig_tx_hash) holds 951 bytes per stream.  host_done: 0 = the device hashes the row, 1 = hashed here
+// and the gate passed, 2 = hashed here and the gate refused.
 constexpr size_t TXSIG_DEV_MAX_OUT = 900, TXSIG_DEV_MAX_IN = 25, TXSIG_DEV_MAX_SCRIPT = 700;  // each stream of a device row stays below TXH_MAX_STREAM
 static_assert(TXSIG_DEV_MAX_OUT <= TXH_MAX_STREAM && 36 * TXSIG_DEV_MAX_IN <= TXH_MAX_STREAM && TXSIG_DEV_MAX_SCRIPT + 165 <= TXH_MAX_STREAM, "device rows must fit the lane buffer");
 static void txsig_pack(txsig_blob &B, size_t n, const uint32_t *version, const uint32_t *locktime, const uint8_t *inputs40, const uint64_t *in_off,
