@@ -284,13 +284,19 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
   return r;
 
 // the asm statements' operand lists (tools/gen_fe_asm.py: operand map) and what follows them
+// (the latency schedule, fe_asm_ilp.inc, brings eight more pinned accumulators: LAMD_FE_ASM_EXTRA_DECL / _OUT)
+#if !defined(LAMD_FE_ASM_EXTRA_DECL)
+#define LAMD_FE_ASM_EXTRA_DECL
+#define LAMD_FE_ASM_EXTRA_OUT
+#endif
 #define LAMD_FE_ASM_DECL                                                                            \
   fe r;                                                                                             \
   u64 hi, lo;                                                                                       \
-  u32 e2;
+  u32 e2;                                                                                           \
+  LAMD_FE_ASM_EXTRA_DECL
 #define LAMD_FE_ASM_OUT                                                                             \
   "=&v"(r.n[0]), "=&v"(e2), "=&v"(r.n[1]), "=&v"(r.n[2]), "=&v"(r.n[3]), "=&v"(r.n[4]), "=&v"(r.n[5]), "=&v"(r.n[6]),       \
-      "=&v"(r.n[7]), "=&v"(r.n[8]), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo)
+      "=&v"(r.n[7]), "=&v"(r.n[8]), "=&" LAMD_FE_ASM_HI(hi), "=&" LAMD_FE_ASM_LO(lo) LAMD_FE_ASM_EXTRA_OUT
 #define LAMD_FE_ASM_K "s"(FE_R0), "s"(1u << FE_R1_SHIFT), "s"(977u), "s"(8u * FE_R0)
 #define LAMD_FE_ASM_DONE                                                                            \
   (void)e2;                                                                                         \

@@ -16,15 +16,28 @@ register that held h[k], dead by then.
 Operands: %0 r[0] | %1 temporary (P8.lo, then e2) | %2..%8 h[1..7] = r[1..7] | %9 r[8] | %10 HI (pinned) | %11 LO (pinned) |
 %12..%20 a[0..8] | %21..%29 b[0..8] (fe_sqr: the doubled limbs d[0..8]) | %30 R0 | %31 256 | %32 977 | %33 8*R0 |
 %34.. second product / addend limbs.
-usage: tools/gen_fe_asm.py > lightning_amd/csrc/fe_asm.inc"""
+
+--ilp: the LATENCY schedule (lightning_amd/csrc/fe_asm_ilp.inc, used by the translation unit of k_small_verify only).  The schedule above is ONE dependent
+chain of 139 instructions: right for a SIMD that holds three waves (its issue port is busy 94 % of the time), wrong for the latency path, where a wave is
+alone on its SIMD for most of its life and a dependent instruction issues every ~8.7 cycles instead of every ~4.3.  Here the pure products of the low
+columns 0..7 go into EIGHT accumulators of their own (L0..L7, pinned to v[24:39]), emitted between the instructions of the high chain (diagonally, so that
+neighbours are independent); the folds R0*h[k+1] / 256*h[k] join L_k as soon as the high chain has cut those limbs; what is left at the end is a carry
+pass of three instructions per column (v_lshl_add_u64 carry + L_k, mask, shift).  Same column sums, same cuts, the same result bit for bit; 146 instructions
+instead of 139, about 90 of them on the critical path.  Eight more pinned outputs shift the input operands by eight (%20.. a, %29.. b, ...).
+usage: tools/gen_fe_asm.py > lightning_amd/csrc/fe_asm.inc;  tools/gen_fe_asm.py --ilp > lightning_amd/csrc/fe_asm_ilp.inc"""
+import sys
+
+ILP = "--ilp" in sys.argv
+OFF = 8 if ILP else 0                # the latency schedule has eight more (pinned) outputs in front of the inputs
 HI, LO = 20, 22                      # v[20:21], v[22:23]
+LK = lambda k: 24 + 2 * k            # v[24:25] .. v[38:39]: L0..L7 (latency schedule)
 R0r = "%0"
 H = lambda j: "%%%d" % (1 + j)       # h[j], j = 0..8; r[k] = H(k) for k >= 1
-A = lambda i: "%%%d" % (12 + i)
-B = lambda i: "%%%d" % (21 + i)
-SR0, S256, S977, S8R0 = "%30", "%31", "%32", "%33"
-C2 = lambda i: "%%%d" % (34 + i)     # second product's left operand (LAMD_FE_MUL2_ASM) / the addend limbs (..._ADD_ASM)
-D2 = lambda i: "%%%d" % (43 + i)     # second product's right operand
+A = lambda i: "%%%d" % (12 + OFF + i)
+B = lambda i: "%%%d" % (21 + OFF + i)
+SR0, S256, S977, S8R0 = ("%%%d" % (30 + OFF), "%%%d" % (31 + OFF), "%%%d" % (32 + OFF), "%%%d" % (33 + OFF))
+C2 = lambda i: "%%%d" % (34 + OFF + i)     # second product's left operand (LAMD_FE_MUL2_ASM) / the addend limbs (..._ADD_ASM)
+D2 = lambda i: "%%%d" % (43 + OFF + i)     # second product's right operand
 M29, M24 = "0x1fffffff", "0xffffff"
 hi, lo = "v[%d:%d]" % (HI, HI + 1), "v[%d:%d]" % (LO, LO + 1)
 hil, hih, lol, loh = "v%d" % HI, "v%d" % (HI + 1), "v%d" % LO, "v%d" % (LO + 1)
@@ -83,9 +96,64 @@ def body(square):
     return ins
 
 
+def body_ilp(square):
+    T0, R8 = H(0), H(8)
+    L = lambda k: "v[%d:%d]" % (LK(k), LK(k) + 1)
+    # stream A: column 8 and the high chain, one dependent chain.  avail[j] = number of A instructions after which h[j] is final
+    a = column(lo, 8, square, True)
+    a += ["v_lshrrev_b64 %s, 29, %s" % (hi, lo), "v_and_b32 %s, %s, %s" % (lol, M29, lol), "v_mov_b32 %s, 0" % loh]
+    avail = {}
+    for j in range(1, 8):
+        a += column(hi, 8 + j, square, False)
+        a += ["v_and_b32 %s, %s, %s" % (H(j), M29, hil), "v_lshrrev_b64 %s, 29, %s" % (hi, hi)]
+        avail[j] = len(a)
+    a += column(hi, 16, square, False)
+    avail["vlo"] = len(a)
+    a.append("v_lshl_add_u32 %s, %s, 11, %s" % (H(1), hih, H(1)))
+    a += [mad(lo, hih, S8R0), mad(lo, hil, S256)]
+    a.append("v_lshl_add_u32 %s, %s, 3, %s" % (H(1), loh, H(1)))
+    a.append("v_mov_b32 %s, %s" % (T0, lol))
+    avail[1] = len(a)                                # h[1] is final only now
+    # stream B: the pure products of columns 0..7, each into its own accumulator, in diagonal order
+    cols = [column(L(k), k, square, True) for k in range(8)]
+    fill = []
+    while any(cols):
+        for c in cols:
+            if c:
+                fill.append((0, c.pop(0)))
+    # stream C: the folds, as soon as their limbs exist
+    for k in list(range(2, 8)) + [0, 1]:
+        src = H(k + 1) if k < 7 else hil
+        need = avail[k + 1] if k < 7 else avail["vlo"]
+        fill.append((need, mad(L(k), src, SR0)))
+        if k > 0:
+            fill.append((max(need, avail[k]), mad(L(k), H(k), S256)))
+    ins = []
+    for n, x in enumerate(a, 1):
+        ins.append(x)
+        for q, (need, y) in enumerate(fill):
+            if need <= n:
+                ins.append(y)
+                del fill[q]
+                break
+    # (what is left of the folds: a fold of column k only waits for other folds of column k)
+    rest = [y for _, y in fill]
+    ins += rest
+    # stream D: the carry pass
+    ins += ["v_and_b32 %s, %s, v%d" % (R0r, M29, LK(0)), "v_lshrrev_b64 %s, 29, %s" % (lo, L(0))]
+    for k in range(1, 8):
+        ins += ["v_lshl_add_u64 %s, %s, 0, %s" % (lo, lo, L(k)), "v_and_b32 %s, %s, %s" % (H(k), M29, lol), "v_lshrrev_b64 %s, 29, %s" % (lo, lo)]
+    ins.append(mad(lo, T0, "1"))
+    ins.append("v_and_b32 %s, %s, %s" % (R8, M24, lol))
+    ins.append("v_alignbit_b32 %s, %s, %s, 24" % (T0, loh, lol))
+    ins.append("v_mad_u32_u24 %s, %s, %s, %s" % (R0r, T0, S977, R0r))
+    ins.append("v_lshl_add_u32 %s, %s, 3, %s" % (H(1), T0, H(1)))
+    return ins
+
+
 def emit(name, square, prod2=False, addend=False):
     EXTRA["prod2"], EXTRA["addend"] = prod2, addend
-    ins = body(square)
+    ins = body_ilp(square) if ILP else body(square)
     nm = sum(1 for x in ins if x.startswith("v_mad_u64"))
     print("// %s: %d v_mad_u64_u32 + %d other instructions" % (name, nm, len(ins) - nm))
     print("#define %s \\" % name)
@@ -98,6 +166,10 @@ def emit(name, square, prod2=False, addend=False):
 print("// GENERATED by tools/gen_fe_asm.py -- do not edit.  See that file for the operand map.")
 print("#define LAMD_FE_ASM_HI \"{v[%d:%d]}\"" % (HI, HI + 1))
 print("#define LAMD_FE_ASM_LO \"{v[%d:%d]}\"" % (LO, LO + 1))
+if ILP:
+    print("// the latency schedule's own accumulators: eight more pinned outputs (fe.h appends them to LAMD_FE_ASM_DECL / LAMD_FE_ASM_OUT)")
+    print("#define LAMD_FE_ASM_EXTRA_DECL u64 " + ", ".join("l%d" % k for k in range(8)) + ";")
+    print("#define LAMD_FE_ASM_EXTRA_OUT , " + ", ".join('"=&{v[%d:%d]}"(l%d)' % (LK(k), LK(k) + 1, k) for k in range(8)))
 emit("LAMD_FE_MUL_ASM", False)
 emit("LAMD_FE_SQR_ASM", True)
 emit("LAMD_FE_MULADD_ASM", False, addend=True)   # a*b + e      (%34.. = e[0..8])
