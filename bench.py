@@ -74,11 +74,19 @@ def stream_shard(eng, st, bounds, k, grp, depth):
     shard, 2.6 ms of a 5 ms 1/8 shard.)  -> {kind: uint8 verdicts of the shard}"""
     import numpy as np
     jobs = []
+    per_unit = int(st["per"])
     # (cutting a short shard into finer flushes -- >= 10 per shard -- was tried: 5.5 against 4.6 ms for a 1/8 shard; a flush's fixed costs win)
     for kind in ("ecdsa", "schnorr"):
         a, z = int(bounds[kind][k]), int(bounds[kind][k + 1])
         span = max(1, z - a)
-        jobs += [((o - a) / span, kind, o, min(z, o + grp)) for o in range(a, z, grp)]
+        # LAMD_BENCH_RAMP=q: the first flushes of a kind are grp/q, 2 grp/q, ... rows, so that the pipeline has something in flight sooner (a shard is a handful of
+        # flushes: its fill and drain are a third of its time)
+        ramp = int(os.environ.get("LAMD_BENCH_RAMP", "0"))
+        o, step = a, (max(per_unit, grp // ramp // per_unit * per_unit) if ramp > 1 else grp)
+        while o < z:
+            e = min(z, o + step)
+            jobs.append(((o - a) / span, kind, o, e))
+            o, step = e, min(grp, step * 2)
     jobs.sort(key=lambda j: j[0])
     got = {kind: np.zeros(int(bounds[kind][k + 1]) - int(bounds[kind][k]), dtype=np.uint8) for kind in ("ecdsa", "schnorr")}
     pend = []
