@@ -28,8 +28,64 @@ static const u32 SHA256_K[64] = {
     0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u,
     0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__) && !defined(LAMD_NO_SHA_NI)
+}  // namespace lamd
+#include <cpuid.h>
+#include <immintrin.h>
+namespace lamd {
+#define LAMD_SHA_NI 1
+// Host side only: the x86 SHA extensions where the CPU has them (checked once with cpuid; every EPYC and every Xeon since Ice Lake does).  The host hashes
+// where the device would be the wrong tool -- the 20 KB output list of a commitment transaction while lamd_check_commitment_signed packs its rows (one lane
+// would need milliseconds, lamd_engine.hip txsig_pack), the handful of rows of a latency-path call -- and that hash sits in front of the launch: 117 us for
+// the commitment row with the portable rounds fed byte by byte, 19 us with these instructions and whole-block feeding on the same core.  Same function, same words in and out; the portable
+// rounds remain for other CPUs (-DLAMD_NO_SHA_NI forces them: tests/test_devmath_host.py runs both against the same vectors).
+static inline bool sha256_have_ni() {
+  static const int have = [] {
+    unsigned a, b, c, d;
+    if (!__get_cpuid_count(7, 0, &a, &b, &c, &d) || !((b >> 29) & 1u)) return 0;   // CPUID.7.0:EBX.SHA
+    if (!__get_cpuid(1, &a, &b, &c, &d)) return 0;
+    return (int)(((c >> 19) & 1u) && ((c >> 9) & 1u));                              // SSE4.1, SSSE3
+  }();
+  return have != 0;
+}
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_compress_ni(u32 st[8], const u32 w[16]) {
+  __m128i tmp = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)st), 0xB1);            // CDAB
+  __m128i s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)(st + 4)), 0x1B);       // EFGH
+  __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                                               // ABEF
+  s1 = _mm_blend_epi16(s1, tmp, 0xF0);                                                    // CDGH
+  const __m128i save0 = s0, save1 = s1;
+  __m128i m[4];
+  for (int i = 0; i < 4; i++) m[i] = _mm_loadu_si128((const __m128i *)(w + 4 * i));      // the words are big-endian values already
+  for (int i = 0; i < 16; i++) {
+    __m128i cur;
+    if (i < 4) {
+      cur = m[i];
+    } else {  // W[4i .. 4i+3] from the sixteen words before them
+      cur = _mm_sha256msg2_epu32(_mm_add_epi32(_mm_sha256msg1_epu32(m[0], m[1]), _mm_alignr_epi8(m[3], m[2], 4)), m[3]);
+      m[0] = m[1]; m[1] = m[2]; m[2] = m[3]; m[3] = cur;
+    }
+    __m128i t = _mm_add_epi32(cur, _mm_loadu_si128((const __m128i *)&SHA256_K[4 * i]));
+    s1 = _mm_sha256rnds2_epu32(s1, s0, t);
+    t = _mm_shuffle_epi32(t, 0x0E);
+    s0 = _mm_sha256rnds2_epu32(s0, s1, t);
+  }
+  s0 = _mm_add_epi32(s0, save0);
+  s1 = _mm_add_epi32(s1, save1);
+  tmp = _mm_shuffle_epi32(s0, 0x1B);                                                      // FEBA
+  s1 = _mm_shuffle_epi32(s1, 0xB1);                                                       // DCHG
+  _mm_storeu_si128((__m128i *)st, _mm_blend_epi16(tmp, s1, 0xF0));                        // DCBA
+  _mm_storeu_si128((__m128i *)(st + 4), _mm_alignr_epi8(s1, tmp, 8));                     // HGFE
+}
+#endif
+
 // one compression; w[16] = the block as big-endian words (clobbered)
 LAMD_HD void sha256_compress(u32 st[8], u32 w[16]) {
+#if defined(LAMD_SHA_NI)
+  if (sha256_have_ni()) {
+    sha256_compress_ni(st, w);
+    return;
+  }
+#endif
   u32 a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
 #pragma unroll
   for (int i = 0; i < 64; i++) {

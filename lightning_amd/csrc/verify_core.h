@@ -1407,7 +1407,26 @@ LAMD_HD void shs_init(sha_stream *s) {
   s->total = 0;
 }
 LAMD_HD void shs_update(sha_stream *s, const u8 *p, size_t n) {
-  for (size_t k = 0; k < n; k++) {
+  size_t k = 0;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // host: once the block buffer is empty, whole blocks go from the caller's bytes straight into the compression (a commitment transaction's 20 KB of outputs)
+  if (n >= 128) {
+    for (; s->fill != 0; k++) {
+      s->w[s->fill >> 2] |= (u32)p[k] << (24 - 8 * (s->fill & 3));
+      if (++s->fill == 64) {
+        sha256_compress(s->st, s->w);
+        for (int i = 0; i < 16; i++) s->w[i] = 0;
+        s->fill = 0;
+      }
+    }
+    for (; k + 64 <= n; k += 64) {
+      for (int i = 0; i < 16; i++) s->w[i] = load_be32(p + k + 4 * i);
+      sha256_compress(s->st, s->w);
+    }
+    for (int i = 0; i < 16; i++) s->w[i] = 0;
+  }
+#endif
+  for (; k < n; k++) {
     s->w[s->fill >> 2] |= (u32)p[k] << (24 - 8 * (s->fill & 3));
     if (++s->fill == 64) {
       sha256_compress(s->st, s->w);

@@ -673,6 +673,50 @@ def test_bip143_sighash_host_build_vs_pyref_and_reference_kat(dm, kat):
     assert dm.dm_bip143(version, lock, ib, 1, ob, len(ob), 2, 0, script, 1, amount, 1, o) == 0          # fewer outputs than claimed
 
 
+def test_host_sha256_with_and_without_the_sha_extensions():
+    """sha256.h on the host: the x86 SHA-extension compression (what txsig_pack hashes a commitment transaction's 20 KB of outputs with) and the
+    portable rounds (-DLAMD_NO_SHA_NI), and verify_core.h's whole-block path of the streaming form: both builds against hashlib on every length
+    0 .. 300 and on long inputs fed in pieces of 1 .. 5 000 bytes, and against the BIP143 model on transactions with up to 600 outputs"""
+    import hashlib
+    src = os.path.join(HERE, "c", "sha_host_paths.cpp")
+    libs = []
+    for tag, flags in (("ni", []), ("portable", ["-DLAMD_NO_SHA_NI"])):
+        so = os.path.join(HERE, "libsha_host_%s.so" % tag)
+        deps = [src] + [os.path.join(ROOT, "lightning_amd", "csrc", f) for f in ("sha256.h", "verify_core.h", "lamd_common.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"] + flags + ["-o", so, src])
+        L = ctypes.CDLL(so)
+        L.h_sha256d.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+        L.h_sha256d_stream.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p]
+        L.h_bip143.restype = ctypes.c_int
+        L.h_bip143.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint32,
+                               ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_char_p]
+        libs.append(L)
+    assert libs[1].h_sha_ni() == 0
+    has_ni = "sha_ni" in open("/proc/cpuinfo").read()
+    assert libs[0].h_sha_ni() == (1 if has_ni else 0)          # the fast path is what runs where the CPU has it
+    rnd = random.Random(256)
+    o = ctypes.create_string_buffer(32)
+    d2 = lambda b: hashlib.sha256(hashlib.sha256(b).digest()).digest()
+    for L in libs:
+        for n in list(range(0, 301)) + [447, 448, 449, 511, 512, 513, 4095, 4096, 20855, 65537]:
+            b = bytes(rnd.randrange(256) for _ in range(n))
+            L.h_sha256d(b, n, o)
+            assert o.raw == d2(b), n
+            for piece in (1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000):
+                if n and (n <= 600 or piece >= 63):
+                    L.h_sha256d_stream(b, n, piece, o)
+                    assert o.raw == d2(b), (n, piece)
+        for n_out in (0, 1, 2, 3, 4, 5, 30, 485, 600):
+            inputs = [(bytes(rnd.randrange(256) for _ in range(32)), rnd.randrange(1 << 32), rnd.randrange(1 << 32)) for _ in range(rnd.choice([1, 2, 9]))]
+            outputs = [(rnd.randrange(1 << 44), bytes(rnd.randrange(256) for _ in range(rnd.choice([22, 34])))) for _ in range(n_out)]
+            script = bytes(rnd.randrange(256) for _ in range(rnd.choice([71, 133, 500])))
+            ib, ob = _tx_flat(inputs, outputs)
+            for sht in (1, 0x83):
+                assert L.h_bip143(2, 7, ib, len(inputs), ob, len(ob), n_out, 0, script, len(script), 12345, sht, o) == 1
+                assert o.raw == pyref.bip143_sighash(2, inputs, outputs, 7, 0, script, 12345, sht)[0], (n_out, sht)
+
+
 def _tlv(t, v):
     return pyref.bigsize(t) + pyref.bigsize(len(v)) + v
 
