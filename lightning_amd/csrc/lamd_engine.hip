@@ -163,7 +163,12 @@ __global__ void __launch_bounds__(256, WAVES) k_ecmult(size_t n, const prep_rec 
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     qx[0] = a.x; qx[1] = a.y; qx[2] = a.z; qx[3] = a.w; qx[4] = b.x; qx[5] = b.y; qx[6] = b.z; qx[7] = b.w;
     qy[0] = c.x; qy[1] = c.y; qy[2] = c.z; qy[3] = c.w; qy[4] = d.x; qy[5] = d.y; qy[6] = d.z; qy[7] = d.w;
-    const gej R = ecmult_lane(rec, ge_from_words(qx, qy), slots + i * SLOT_WORDS, gtable);
+    // the ladder in its hot form (signed odd digits, bare additions: verify_core.h ecmult_lane_fast); a degenerate event -- adversarial scalars, or a
+    // result at infinity -- sends this lane through the complete ladder
+    bool suspect;
+    const ge q = ge_from_words(qx, qy);
+    gej R = ecmult_lane_fast(rec, q, slots + i * SLOT_WORDS, gtable, &suspect);
+    if (__builtin_expect(suspect, 0)) R = ecmult_lane(rec, q, slots + i * SLOT_WORDS, gtable);
     u32 rw[8];
     load_words_be(rw, sig64 + 64 * row);
     if (mode == MODE_ECDSA) {

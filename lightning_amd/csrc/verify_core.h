@@ -684,12 +684,9 @@ LAMD_HD void s160_negate_if(u32 r[5], const u32 a[5], bool neg) {
 #pragma unroll
   for (int i = 0; i < 5; i++) { c += (u64)(a[i] ^ m); r[i] = (u32)c; c >>= 32; }
 }
-template <int T>
-LAMD_HD comb_pair<T> comb_from_rec_odd(const prep_rec &rec) {
-  constexpr int D = kc_spacing(T), N = T * D;
-  static_assert(N >= 130, "comb must cover the adjusted halves");
+// the two halves after that adjustment, as signed 160-bit integers (two's complement): both odd, |k[h]| < 2^130
+LAMD_HD void glv_odd_halves(const prep_rec &rec, u32 k[2][5]) {
   // |k_i| from the biased form (mag + top * 2^128 - 0x88..8), as signed 160-bit integers
-  u32 k[2][5];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const u32 *mag = h ? rec.k2 : rec.k1;
@@ -720,6 +717,13 @@ LAMD_HD comb_pair<T> comb_from_rec_odd(const prep_rec &rec) {
   }
   s160_add(k[0], k[0], ax);
   s160_add(k[1], k[1], ay);
+}
+template <int T>
+LAMD_HD comb_pair<T> comb_from_rec_odd(const prep_rec &rec) {
+  constexpr int D = kc_spacing(T), N = T * D;
+  static_assert(N >= 130, "comb must cover the adjusted halves");
+  u32 k[2][5];
+  glv_odd_halves(rec, k);
   comb_pair<T> r;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
@@ -833,6 +837,133 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
     uw[7] >>= GTABLE_WINDOW_BITS;
     if (d != 0) {  // a zero digit (2^-22 per window) is a divergent skip, not a select
       const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
+      ge pt;
+      pt.x = slot_load_fe(e);
+      pt.y = slot_load_fe(e + TW);
+      acc = gej_add_ge_fast(acc, pt);
+    }
+  }
+  *suspect = fe_is_zero(acc.z);
+  return acc;
+}
+
+// ---- the per-signature ladder in its hot form (keys without a table: the cold rows of a batch, every row of an all-distinct batch).
+// ecmult_lane above adds with the complete formula under a zero-digit predicate, an infinity select and a degenerate-case test -- ~270 of
+// the ~1 700 instructions of each of its 66 + 11 additions.  Here both halves are made ODD in the scalar domain (glv_odd_halves: a lattice
+// vector, no repair additions) and written in signed odd digits: with w = (|k| >> 1) | 2^131, digit i = 2 * nibble_i(w) - 15 is one of
+// +-1, +-3, .., +-15 and sum digit_i 16^i = |k| (33 digits cover the 130 bits).  No digit is zero, the top digit is +1 or +3 and initialises
+// the accumulator, the table holds the eight odd multiples 1Q, 3Q, .., 15Q -- so every addition is the bare formula, and the G windows
+// skip a zero digit by branching, exactly as in ecmult_lane_keyed_fast.  Degenerate events leave Z = 0: *suspect, and the caller runs
+// ecmult_lane.  (An accumulator a*Q + b*lambda*Q meets +-d*Q or +-d*lambda*Q only if (a -+ d, b) resp. (a, b -+ d) is a vector of the GLV
+// lattice: never for honest scalars, constructible for chosen ones -- hence the test, not an argument.)
+// The table: 2Q is computed once, Q is carried to the isomorphic curve on which 2Q is affine, and seven mixed additions of 2Q give
+// 3Q .. 15Q; the entries are rescaled to the last one's Z from the H values, as build_multiples does.  Returns the Z that maps the
+// entries' curve back to secp256k1 (Zg * Z_2Q).
+LAMD_HD fe build_odd_multiples8(u32 *slot, u32 *hbuf, const ge &q) {
+  const gej d = gej_double(gej_from_ge(q));
+  const fe zd = fe_norm_weak(d.z);
+  const fe zd2 = fe_sqr(zd);
+  ge dd;
+  dd.x = d.x;
+  dd.y = d.y;
+  gej p;
+  p.x = fe_mul(q.x, zd2);
+  p.y = fe_mul(q.y, fe_mul(zd2, zd));
+  p.z = fe_set_int(1);
+  p.inf = false;
+  slot_store_fe(slot + 0, p.x);
+  slot_store_fe(slot + ENT_Y, p.y);
+#pragma unroll 1
+  for (int i = 1; i < 8; i++) {  // entry i = (2i+1)Q = entry(i-1) + 2Q: an odd and an even multiple never meet
+    bool degenerate;
+    fe h, rr;
+    p = gej_add_ge_core(p, dd, &degenerate, &h, &rr);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, p.x);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + ENT_Y, p.y);
+    slot_store_fe(hbuf + (i - 1) * TW, h);
+  }
+  const fe zg = fe_norm_weak(p.z);
+  const u32 betaw[8] = LAMD_BETA;
+  const fe beta = fe_from_words(betaw);
+  {
+    const fe x = slot_load_fe(slot + 7 * SLOT_ENTRY_WORDS);
+    slot_store_fe(slot + 7 * SLOT_ENTRY_WORDS + ENT_BX, fe_mul(x, beta));
+  }
+  fe rho = fe_set_int(1);
+#pragma unroll 1
+  for (int i = 6; i >= 0; i--) {  // rho = Zg / Z_entry(i) = H_(i+1) * .. * H_7 (Z_0 = 1 on the isomorphic curve)
+    rho = i == 6 ? slot_load_fe(hbuf + 6 * TW) : fe_mul(rho, slot_load_fe(hbuf + i * TW));
+    const fe r2 = fe_sqr(rho);
+    const fe r3 = fe_mul(r2, rho);
+    const fe x = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + 0), r2);
+    const fe y = fe_mul(slot_load_fe(slot + i * SLOT_ENTRY_WORDS + ENT_Y), r3);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + 0, x);
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + ENT_BX, fe_mul(x, beta));
+    slot_store_fe(slot + i * SLOT_ENTRY_WORDS + ENT_Y, y);
+  }
+  return fe_mul(zg, zd);
+}
+static_assert(SLOT_H_OFF + 7 * TW <= SLOT_WORDS, "the ladder's slot holds eight entries and seven H values");
+LAMD_HD gej ecmult_lane_fast(const prep_rec &rec, const ge &q, u32 *slot, const u32 *gtable, bool *suspect) {
+  const fe zg = build_odd_multiples8(slot, slot + SLOT_H_OFF, q);
+  u32 k[2][5];
+  glv_odd_halves(rec, k);
+  // w = (|k| >> 1) | 2^131 per half, kept as a shift register whose top nibble (bits 128..131) is the next digit
+  u32 w[2][5];
+  bool neg[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    neg[h] = (k[h][4] >> 31) != 0;
+    u32 m[6];
+    s160_negate_if(m, k[h], neg[h]);
+    m[5] = 0;
+    LAMD_ASSERT((m[0] & 1u) == 1u && m[4] < 4u);
+#pragma unroll
+    for (int i = 0; i < 5; i++) w[h][i] = (m[i] >> 1) | (m[i + 1] << 31);
+    w[h][4] |= 8u;
+  }
+  gej acc;
+#pragma unroll 1
+  for (int i = 32; i >= 0; i--) {
+    if (i != 32) {
+#pragma unroll 1
+      for (int j = 0; j < 4; j++) acc = gej_double(acc);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const u32 nib = w[h][4] & 15u;
+#pragma unroll
+      for (int t = 4; t > 0; t--) w[h][t] = (w[h][t] << 4) | (w[h][t - 1] >> 28);
+      w[h][0] <<= 4;
+      const bool dneg = nib < 8u;                    // digit = 2 * nib - 15
+      const u32 idx = dneg ? 7u - nib : nib - 8u;    // (|digit| - 1) / 2
+      const u32 *e = slot + idx * SLOT_ENTRY_WORDS;
+      ge pt;
+      pt.x = slot_load_fe(e + (h ? ENT_BX : ENT_X));
+      pt.y = slot_load_fe(e + ENT_Y);
+      pt = ge_neg_if_lazy(pt, dneg != neg[h]);
+      if (i == 32 && h == 0) {  // uniform across the wave: the first point is the accumulator
+        acc.x = pt.x;
+        acc.y = fe_norm_weak(pt.y);
+        acc.z = fe_set_int(1);
+        acc.inf = false;
+      } else {
+        acc = gej_add_ge_fast(acc, pt);
+      }
+    }
+  }
+  acc.z = fe_mul(acc.z, zg);  // back from the isomorphic curve
+  u32 uw[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) uw[i] = rec.u1[i];
+#pragma unroll 1
+  for (int wd = 0; wd < GTABLE_WINDOWS; wd++) {
+    const u32 d = uw[0] & ((1u << GTABLE_WINDOW_BITS) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) uw[i] = (uw[i] >> GTABLE_WINDOW_BITS) | (uw[i + 1] << (32 - GTABLE_WINDOW_BITS));
+    uw[7] >>= GTABLE_WINDOW_BITS;
+    if (d != 0) {
+      const u32 *e = gtable + (((size_t)wd << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
       ge pt;
       pt.x = slot_load_fe(e);
       pt.y = slot_load_fe(e + TW);

@@ -328,6 +328,58 @@ int dm_ecmult_keyed(int T, const u8 *key33, const u8 *u1, const u8 *u2, u8 *out6
   return ecmult_keyed_t<10>(qx, qy, u1, u2, out64);
 }
 #endif  // DM_NO_KEYED
+// R = u1*G + u2*Q through the per-signature ladder: the hot form (signed odd digits, bare additions, one Z == 0 test: ecmult_lane_fast) AND the complete
+// form (ecmult_lane); -1 if they describe different points, 0 for infinity, 1 with the affine point otherwise.  dm_ladder_suspects: how often the
+// hot form reported Z = 0 and the complete form decided.
+static size_t g_ladder_suspects;
+size_t dm_ladder_suspects(int reset) { const size_t v = g_ladder_suspects; if (reset) g_ladder_suspects = 0; return v; }
+int dm_ecmult_ladder(const u8 *key33, const u8 *u1, const u8 *u2, u8 *out64) {
+  dm_init();
+  u32 qx[8], qy[8];
+  if (!parse_pubkey(key33, 33, qx, qy)) return -2;
+  const ge q = ge_from_words(qx, qy);
+  prep_rec rec;
+  sc k; be_to_words(k.w, u2);
+  be_to_words(rec.u1, u1);
+  glv_half h1, h2;
+  glv_split(&h1, &h2, k);
+  for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
+  rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
+  std::vector<u32> slot(SLOT_WORDS), slot2(SLOT_WORDS);
+  bool suspect;
+  gej R = ecmult_lane_fast(rec, q, slot.data(), g_table.data(), &suspect);
+  const gej Rc = ecmult_lane(rec, q, slot2.data(), g_table.data());
+  if (suspect) {
+    g_ladder_suspects++;
+    R = Rc;
+  } else {
+    if (Rc.inf) return -1;
+    const fe z1 = fe_norm_weak(R.z), z2 = fe_norm_weak(Rc.z), z1s = fe_sqr(z1), z2s = fe_sqr(z2);
+    if (!fe_equal(fe_mul(R.x, z2s), fe_mul(Rc.x, z1s), 1)) return -1;
+    if (!fe_equal(fe_mul(R.y, fe_mul(z2s, z2)), fe_mul(Rc.y, fe_mul(z1s, z1)), 1)) return -1;
+  }
+  if (R.inf) return 0;
+  const fe zi = fe_inv(fe_norm_weak(R.z)), zi2 = fe_sqr(zi);
+  u32 w[8];
+  fe_to_words(w, fe_normalize(fe_mul(R.x, zi2))); words_to_be(out64, w);
+  fe_to_words(w, fe_normalize(fe_mul(R.y, fe_mul(zi2, zi)))); words_to_be(out64 + 32, w);
+  return 1;
+}
+// the ladder's table of odd multiples: entry e (0..7) as x | beta*x | y (canonical, 32 bytes each) and the Z that maps its curve back
+void dm_odd_table(const u8 *key33, u8 *out_entries /*8 * 96*/, u8 *zg32) {
+  dm_init();
+  u32 qx[8], qy[8];
+  parse_pubkey(key33, 33, qx, qy);
+  std::vector<u32> slot(SLOT_WORDS);
+  const fe zg = build_odd_multiples8(slot.data(), slot.data() + SLOT_H_OFF, ge_from_words(qx, qy));
+  u32 w[8];
+  fe_to_words(w, fe_normalize(zg)); words_to_be(zg32, w);
+  for (int e = 0; e < 8; e++)
+    for (int c = 0; c < 3; c++) {
+      fe_to_words(w, fe_normalize(slot_load_fe(slot.data() + e * SLOT_ENTRY_WORDS + c * TW)));
+      words_to_be(out_entries + 96 * e + 32 * c, w);
+    }
+}
 // public-key recovery exactly as the kernels stage it: prep (batch inversion over `threads` owners) -> key parse of R ->
 // ladder -> shared-inversion final stage
 void dm_recover_batch(size_t n, const u8 *hash32, const u8 *sig64, const u8 *recid, u8 *pub33, u8 *ok, size_t threads) {

@@ -384,6 +384,53 @@ def test_keyed_ecmult_special_scalars(dm):
         assert dm.dm_suspects(1) == 0
 
 
+def test_ladder_hot_form_special_scalars_and_its_table(dm):
+    """the per-signature ladder in its hot form (ecmult_lane_fast: both halves odd, signed odd 4-bit digits, the table 1Q, 3Q .. 15Q, bare
+    additions, one Z == 0 test) against the complete ladder and the model: the table's entries are (2e+1)Q on the curve its Z names; scalars that
+    stress the recoding (zero / even / tiny halves, halves that cancel, +-lambda^i, every small u2, partial sums that meet -u1*G) and random ones"""
+    LAM = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+    rng = random.Random(1515)
+    dm.dm_ladder_suspects.restype = ctypes.c_size_t
+    ent, zg = ctypes.create_string_buffer(8 * 96), ctypes.create_string_buffer(32)
+    for d in (1, 2, 3, 0x6C1F00D5A3E2B4C7918D7E6F5A4B3C2D1E0F99887766554433221100FFEEDDCC, rng.randrange(1, N), N - 1):
+        Q = pyref.pubkey_create(d)
+        dm.dm_odd_table(pyref.ser33(Q), ent, zg)
+        z = int.from_bytes(zg.raw, "big")
+        zi = pow(z, P - 2, P)
+        for e in range(8):
+            x, bx, y = (int.from_bytes(ent.raw[96 * e + 32 * c:96 * e + 32 * c + 32], "big") for c in range(3))
+            want = pyref.pmul(2 * e + 1, Q)
+            assert (x * zi * zi % P, y * pow(zi, 3, P) % P) == want, (hex(d), e)       # affine on y^2 = x^3 + 7 z^6 -> secp256k1
+            assert bx == x * BETA % P
+    d = 0x6C1F00D5A3E2B4C7918D7E6F5A4B3C2D1E0F99887766554433221100FFEEDDCC
+    Q = pyref.pubkey_create(d)
+    u2s = list(range(0, 40)) + [N - 1, N - 2, N - 3, LAM, N - LAM, LAM + 1, LAM - 1, 2 * LAM % N, (LAM + 2) % N, 3 * LAM % N, (15 * LAM) % N, (16 * LAM + 1) % N,
+                                LAM * LAM % N, (N - LAM * LAM) % N, 1 << 127, (1 << 128) - 1, 1 << 128, (1 << 128) + 1, ((1 << 127) * LAM + 2) % N, (N + 1) // 2,
+                                (1 << 129) - 1, ((1 << 128) - 1) * LAM % N, (0x88888888888888888888888888888888 * (LAM + 1)) % N]
+    u2s += [rng.randrange(N) for _ in range(40)]
+    o = ctypes.create_string_buffer(64)
+    dm.dm_ladder_suspects(1)
+    ninf = 0
+    for u2 in u2s:
+        for u1 in (0, 1, rng.randrange(N), (-u2 * d) % N, (-u2 * d + 1) % N):
+            got = dm.dm_ecmult_ladder(pyref.ser33(Q), u1.to_bytes(32, "big"), u2.to_bytes(32, "big"), o)      # -1: the two forms disagree
+            exp = pyref.padd(pyref.pmul(u1, pyref.G), pyref.pmul(u2, Q))
+            if exp is None:
+                assert got == 0, (hex(u1), hex(u2))
+                ninf += 1
+            else:
+                assert got == 1 and o.raw == exp[0].to_bytes(32, "big") + exp[1].to_bytes(32, "big"), (hex(u1), hex(u2))
+    assert dm.dm_ladder_suspects(1) >= ninf > 0          # every result at infinity went through the complete form
+    for _ in range(300):                                 # honest random scalars and keys never do
+        Qr = pyref.pubkey_create(rng.randrange(1, N))
+        u1, u2 = rng.randrange(N), rng.randrange(N)
+        assert dm.dm_ecmult_ladder(pyref.ser33(Qr), u1.to_bytes(32, "big"), u2.to_bytes(32, "big"), o) == 1
+        exp = pyref.padd(pyref.pmul(u1, pyref.G), pyref.pmul(u2, Qr))
+        assert o.raw == exp[0].to_bytes(32, "big") + exp[1].to_bytes(32, "big")
+    assert dm.dm_ladder_suspects(1) == 0
+
+
 def test_gtable_windows_that_straddle_words(kat):
     """the shipped G table uses 24-bit windows (11 windows, the last one runs past bit 255, two of three straddle a 32-bit word);
     the same digit extraction and table code built for the host with 11-bit windows must give the golden verdicts"""
