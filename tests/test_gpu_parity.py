@@ -1110,6 +1110,44 @@ def test_check_tx_sig_from_transaction_templates_vs_spec_model(eng, orc):
 
 
 @pytest.mark.gpu
+def test_ladder_whole_waves_of_degenerate_rows(eng, orc):
+    """The per-signature ladder's hot form (bare additions, one Z == 0 test) hands a lane to the complete ladder when the test fires.  The goldens hold
+    a handful of such rows; here whole waves of them, every row under its own never-seen key: z = -r*d (u1*G + u2*Q is the point at infinity:
+    reject), z = r*d with s = 2*r*d/k (u1*G == u2*Q, the last addition is a doubling: accept), and honest rows between them.  Verdicts by
+    construction, by the C oracle, and from the device -- through the batch path (ladder kernel) and, 64 rows at a time, the latency path"""
+    rnd = random.Random(4242)
+    N_ = pyref.N
+    hs, sigs, pubs, exp = [], [], [], []
+    for i in range(3 * 4096):
+        d = rnd.randrange(1, N_)
+        pub = orc.pubkey_create(d.to_bytes(32, "big"))
+        kind = i % 3
+        if kind == 0:      # R = infinity
+            r, s_ = rnd.randrange(1, N_), rnd.randrange(1, N_ // 2)
+            z, ok = (-r * d) % N_, False
+        elif kind == 1:    # u1*G == u2*Q
+            kk = rnd.randrange(1, N_)
+            r = int.from_bytes(orc.pubkey_create(kk.to_bytes(32, "big"))[1:33], "big") % N_
+            s_ = 2 * r * d * pow(kk, -1, N_) % N_
+            if s_ > N_ // 2:
+                s_ = N_ - s_
+            z, ok = r * d % N_, True
+        else:
+            z = rnd.randrange(1 << 256)
+            sg = orc.ecdsa_sign(z.to_bytes(32, "big"), d.to_bytes(32, "big"), rnd.randrange(1, N_).to_bytes(32, "big"))
+            r, s_, ok = int.from_bytes(sg[:32], "big"), int.from_bytes(sg[32:], "big"), True
+            z %= 1 << 256
+        hs.append((z % (1 << 256)).to_bytes(32, "big")); sigs.append(r.to_bytes(32, "big") + s_.to_bytes(32, "big")); pubs.append(pub); exp.append(ok)
+    h, sg, pk = _rows(hs, 32), _rows(sigs, 64), _rows(pubs, 65)
+    want = np.array(exp)
+    assert (np.asarray(orc.ecdsa_verify_batch(h, sg, pk, 65, 8)).astype(bool) == want).all()        # the construction is what the oracle sees
+    got = np.asarray(eng.verify_ecdsa(h, sg, pk)).astype(bool)
+    assert (got == want).all(), np.nonzero(got != want)[0][:10]
+    for o in range(0, 640, 64):                                                                      # the latency path's ladder (complete formulas)
+        assert (np.asarray(eng.verify_ecdsa(h[o:o + 64], sg[o:o + 64], pk[o:o + 64])).astype(bool) == want[o:o + 64]).all()
+
+
+@pytest.mark.gpu
 def test_check_tx_sig_templates_at_the_stream_boundaries(eng, orc):
     """The device's BIP143 form lays each of a row's four SHA-256 streams out in a per-lane buffer of 960 bytes (k_txsig_tx_hash): every script
     length 0 .. 140 (each padding case of the preimage), the CompactSize steps (252 / 253 / 254), input and output lists up to and across the
