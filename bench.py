@@ -12,13 +12,18 @@ inside the timed region, as the north star asks.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --gpus N              # without RANK in the environment: re-executes itself under torch.distributed.run
+    python bench.py --extras              # + latency, PCIe, the other configs, ingest flood, fee grind, recovery, key-reuse sweep
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (HIP-event
-timing of the dominant kernel, k_ecmult) and `cpu_baseline` (the CPU oracle on a bounded sample
-of the same rows, timed on this host's cores -- a reported baseline, and the bench-time parity
-check: its verdicts must equal the GPU's).
+stdout carries exactly ONE JSON line of at most LINE_LIMIT bytes (rank 0): the contract's keys,
+`roofline` (HIP-event timing of the dominant kernel), `cpu_baseline` (the CPU oracle on a bounded
+sample of the same rows, timed on this host's cores; its verdicts must equal the GPU's) and
+`parity`.  Everything else a run measures goes to `bench_details.json` (next to this file, and
+under gpurun_out/ when that directory exists) and, as one line, to stderr.  One number per run,
+as the reference's own micro-benchmark prints it (onchaind/test/run-grind_feerate.c:146-154).
 """
 import argparse
+import contextlib
+import importlib.util
 import json
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before the HIP runtime starts: the engine's lanes need their own hardware queues (DESIGN.md 3.3)
@@ -27,6 +32,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+LINE_LIMIT = 6000       # bytes of the one stdout line (round 5's line was 20 KB and the driver could not parse it)
 
 # algorithmic 32x32->64 multiplies per verification (implementation-independent yardstick)
 W_ECDSA65 = 1.32e5
@@ -67,28 +74,166 @@ BYTES_ECDSA65 = 32 + 64 + 65 + 1
 BYTES_SCHNORR = 32 + 32 + 64 + 1
 
 
-def stream_shard(eng, st, bounds, k, grp, depth):
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the ONE stdout line
+def _r(x, digits=6):
+    """floats to `digits` significant digits (a line of at most LINE_LIMIT bytes has no room for 17-digit floats)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    if hasattr(x, "item"):         # numpy scalars
+        return _r(x.item(), digits)
+    return x
+
+
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+CONFIG_KEYS = ("workload", "rows_per_gpu_per_step", "parallelism", "key_table_cache", "value_host_to_host", "host_to_host_over_value", "predicted_speedup_8")
+ROOFLINE_KEYS = ("kernel", "bound", "mode", "avg_launch_ms", "rows_in_launch", "executed_mul32_per_verify", "achieved", "peak", "unit", "frac",
+                 "peak_sustained", "peak_boost", "frac_step", "frac_isolated", "traffic", "traffic_unit", "traffic_over_algorithmic",
+                 "algorithmic_bytes_per_launch", "valu_instr_per_verify", "valu_issue_frac", "launches_timed", "sum_of_launches_le_step")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "note", "C1_1thread", "C1_all_cores", "C2", "C0", "ns_per_verify_1thread", "seconds")
+PARITY_KEYS = ("rows_checked", "mismatches", "oracle_rows_checked", "oracle_mismatches")
+REQUIRED = {"": LINE_KEYS + ("config", "roofline", "cpu_baseline", "parity"),
+            "config": ("workload", "rows_per_gpu_per_step", "parallelism"),
+            "roofline": ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "rows_in_launch"),
+            "parity": ("rows_checked", "mismatches")}
+
+
+def compact_line(d):
+    """the details dict of a run -> the dict printed as the ONE stdout line: the bench contract's keys, `config`, `roofline`, `cpu_baseline`
+    and `parity` cut to the keys above; notes and sub-reports stay in bench_details.json.  Raises when a required key is missing or the
+    line would not fit LINE_LIMIT (tests/test_bench_line.py runs this on canned numbers)."""
+    line = {k: d[k] for k in LINE_KEYS}
+    line["config"] = {k: d["config"][k] for k in CONFIG_KEYS if d["config"].get(k) is not None}
+    line["roofline"] = {k: d["roofline"].get(k) for k in ROOFLINE_KEYS if k in d["roofline"]}
+    cb = d.get("cpu_baseline")
+    if cb is not None:
+        cb = {k: cb[k] for k in CPU_KEYS if cb.get(k) is not None}
+        for k in ("note", "sample"):
+            if len(str(cb.get(k, ""))) > 160:
+                cb[k] = str(cb[k])[:157] + "..."
+    line["cpu_baseline"] = cb
+    line["parity"] = {k: d["parity"][k] for k in PARITY_KEYS if k in d["parity"]}
+    if d.get("steady_state"):
+        line["steady_state"] = {k: d["steady_state"][k] for k in ("value", "steps", "ms_per_step")}
+    if d.get("sharded_configs"):
+        line["sharded_configs"] = {name: {k: v[k] for k in ("verifies_per_s", "ms", "ranks", "mismatches", "scaling") if k in v}
+                                   for name, v in d["sharded_configs"].items()}
+    line["details"] = d.get("details_file", "bench_details.json")
+    line = _r(line)
+    for sect, keys in REQUIRED.items():
+        have = line if sect == "" else line[sect]
+        missing = [k for k in keys if k not in have]
+        if missing:
+            raise ValueError("bench line: %s lacks %s" % (sect or "top level", missing))
+    text = json.dumps(line, separators=(", ", ": "))
+    if len(text) >= LINE_LIMIT:
+        raise ValueError("bench line is %d bytes (limit %d): move the new keys to bench_details.json" % (len(text), LINE_LIMIT))
+    return line, text
+
+
+def write_outputs(details, json_fd, details_path=None):
+    """details -> bench_details.json (+ gpurun_out/ copy), one line on stderr, the compact line on the saved stdout"""
+    paths = [details_path or os.path.join(ROOT, "bench_details.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) and details_path is None:
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_details.json"))
+    details["details_file"] = os.path.relpath(paths[0], ROOT)
+    line, text = compact_line(details)
+    blob = json.dumps(_r(details, 9), indent=1)
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(blob + "\n")
+        except OSError as e:        # a read-only tree must not cost the line
+            sys.stderr.write("bench_details: %s\n" % e)
+    sys.stderr.write("BENCH_DETAILS " + json.dumps(_r(details, 6)) + "\n")
+    sys.stderr.flush()
+    os.write(json_fd, (text + "\n").encode())
+    return line
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# the machine under the bench: an MI355X through PyTorch-ROCm -- or, for the CPU tests of the multi-rank path, a stand-in module
+class GpuPlatform:
+    backend, is_stub = "nccl", False
+
+    def __init__(self, local_rank):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: lightning_amd has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        from lightning_amd import Engine, workload
+        self.torch, self.Engine, self.workload = torch, Engine, workload
+        self.device = "cuda:%d" % local_rank
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def stream_ptr(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def new_event(self):
+        ev = self.torch.cuda.Event()
+        ev.record()
+        return ev
+
+
+def load_platform(local_rank):
+    """LAMD_BENCH_STUB=<module.py>: tests/bench_stub.py -- host-memory "devices", gloo, verdicts a fixed function of the row bytes -- so that
+    the code the driver's `--gpus 8` run executes (argument handling, late gathers, sharded configs, the line) runs in the CPU suite"""
+    stub = os.environ.get("LAMD_BENCH_STUB")
+    if not stub:
+        return GpuPlatform(local_rank)
+    spec = importlib.util.spec_from_file_location("lamd_bench_stub", stub)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Platform(local_rank)
+
+
+class Clock:
+    """wall-clock seconds per phase of the run (bench_details.json `phase_seconds`)"""
+
+    def __init__(self):
+        self.t = {}
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            self.t[name] = self.t.get(name, 0.0) + time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+def stream_shard(eng, st, bounds, k, grp, depth, first_grp=0):
     """configs[4] for shard k: the commitments [bounds[kind][k], bounds[kind][k+1]) of BOTH kinds through the streaming queue as ONE pipeline -- flushes
     of `grp` rows, the two kinds taking turns in proportion to their length, up to `depth` flushes in flight -- from host memory to verdicts in host
     memory.  (Until round 5 the ECDSA rows were streamed and drained before the first BIP-340 flush went out: two pipeline fills and two drains per
-    shard, 2.6 ms of a 5 ms 1/8 shard.)  -> {kind: uint8 verdicts of the shard}"""
+    shard, 2.6 ms of a 5 ms 1/8 shard.)  first_grp > 0: the first flush of each kind is that many rows (the device starts sooner).
+    -> {kind: uint8 verdicts of the shard}"""
     import numpy as np
     jobs = []
     per_unit = int(st["per"])
-    # (cutting a short shard into finer flushes -- >= 10 per shard -- was tried: 5.5 against 4.6 ms for a 1/8 shard; a flush's fixed costs win)
     for kind in ("ecdsa", "schnorr"):
+        if kind not in st:
+            continue
         a, z = int(bounds[kind][k]), int(bounds[kind][k + 1])
         span = max(1, z - a)
-        # LAMD_BENCH_RAMP=q: the first flushes of a kind are grp/q, 2 grp/q, ... rows, so that the pipeline has something in flight sooner (a shard is a handful of
-        # flushes: its fill and drain are a third of its time)
-        ramp = int(os.environ.get("LAMD_BENCH_RAMP", "0"))
-        o, step = a, (max(per_unit, grp // ramp // per_unit * per_unit) if ramp > 1 else grp)
+        o, step = a, (max(per_unit, first_grp // per_unit * per_unit) if first_grp else grp)
         while o < z:
             e = min(z, o + step)
             jobs.append(((o - a) / span, kind, o, e))
-            o, step = e, min(grp, step * 2)
+            o, step = e, grp
     jobs.sort(key=lambda j: j[0])
-    got = {kind: np.zeros(int(bounds[kind][k + 1]) - int(bounds[kind][k]), dtype=np.uint8) for kind in ("ecdsa", "schnorr")}
+    got = {kind: np.zeros(int(bounds[kind][k + 1]) - int(bounds[kind][k]), dtype=np.uint8) for kind in ("ecdsa", "schnorr") if kind in st}
     pend = []
 
     def collect():
@@ -110,7 +255,12 @@ def stream_shard(eng, st, bounds, k, grp, depth):
     return got
 
 
-def sharded_configs(eng, rank, world, device, tstream):
+def storm_first_flush(per):
+    """rows of a shard's first flush per kind (LAMD_BENCH_FIRST_FLUSH commitments; default a quarter of the 256-commitment flush)"""
+    return int(os.environ.get("LAMD_BENCH_FIRST_FLUSH", "64")) * per
+
+
+def sharded_configs(plat, eng, rank, world, tstream, div=1):
     """BASELINE configs[3] and [4] the way the north star words them: ONE global job split over the ranks on message /
     commitment boundaries (lightning_amd.sharding.run_sharded: shard -> verify locally -> ragged RCCL all-gather of the verdict
     bytes), every rank ending with the whole verdict vector.  Strong scaling: the job is fixed, the time is max over ranks.
@@ -118,31 +268,32 @@ def sharded_configs(eng, rank, world, device, tstream):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from lightning_amd import sharding, workload
+    from lightning_amd import sharding
+    workload, device = plat.workload, plat.device
     out = {}
 
     def timed(fn, reps):
         ts, res = [], None
         for _ in range(reps):
             dist.barrier()
-            torch.cuda.synchronize(); eng.synchronize()
+            plat.synchronize(); eng.synchronize()
             t1 = time.perf_counter()
             res = fn()
-            torch.cuda.synchronize(); eng.synchronize()
+            plat.synchronize(); eng.synchronize()
             t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ts.append(float(t.item()))
         return ts, res
 
     # ---- configs[3]: gossip replay, 500 k channel_announcement + 2 M channel_update, sharded by message
-    g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
+    g = workload.make_gossip(eng, 500_000 // div, 2_000_000 // div, n_nodes=max(16, 15000 // div), device=device)
     gw = sharding.gossip_weights(g.msgs, g.off)      # cut on message boundaries, balanced by what a message costs (announcements: 4 signatures, 2 under cold keys)
     b = sharding.shard_bounds(g.n, world, None, gw)
     lo, hi = int(b[rank]), int(b[rank + 1])
     rb = (g.d_rowbase[lo:hi + 1] - g.d_rowbase[lo]).contiguous()
     rows = int(g.rowbase[hi] - g.rowbase[lo])
     d_v = torch.zeros(hi - lo, dtype=torch.int8, device=device)
-    torch.cuda.synchronize()
+    plat.synchronize()
 
     def gossip_range(a, z):
         assert (a, z) == (lo, hi)
@@ -153,61 +304,60 @@ def sharded_configs(eng, rank, world, device, tstream):
     bad = int((full.cpu().numpy() != g.expect).sum())
     out["cfg4_gossip_replay_sharded"] = {"messages": g.n, "verifies": g.rows, "ranks": world, "shard_messages": [int(b[k + 1] - b[k]) for k in range(world)],
                                          "verifies_per_s": g.rows / min(ts[-2:]), "messages_per_s": g.n / min(ts[-2:]), "ms": min(ts[-2:]) * 1e3,
-                                         "mismatches": bad, "scaling": "strong",
+                                         "mismatches": bad, "scaling": "strong", "verdicts_on_every_rank": int(full.numel()),
                                          "note": "raw wire messages resident in HBM; per rank: framing + SHA256d + verification of its shard, then the "
                                                  "ragged all-gather of int8 verdicts; every rank checks the WHOLE gathered vector against construction"}
     del g, d_v, rb, gw
     # ---- configs[4]: commit_tx storm, 10 k channels x 484, streaming batches from host memory, 484-row groups kept whole
-    st = workload.make_commit_storm(eng, 10_000, device=device)
+    st = workload.make_commit_storm(eng, max(world, 10_000 // div), device=device)
     per, grp = st["per"], 256 * st["per"]
 
     def storm():
         bb = {kind: sharding.shard_bounds(st[kind].n, world, [per] * (st[kind].n // per)) for kind in ("ecdsa", "schnorr")}
-        got = stream_shard(eng, st, bb, rank, grp, min(8, eng.info()["queue_sets"] - 1))
+        got = stream_shard(eng, st, bb, rank, grp, min(8, eng.info()["queue_sets"] - 1), storm_first_flush(per))
         return {kind: (sharding.all_gather_verdicts(torch.from_numpy(got[kind]).to(device), bb[kind], rank, world), bb[kind]) for kind in ("ecdsa", "schnorr")}
     ts, res = timed(storm, 3)
-    bad, shard_rows = 0, {}
+    bad, shard_rows, nfull = 0, {}, 0
     for kind in ("ecdsa", "schnorr"):
         full, bb = res[kind]
         bad += int((full.cpu().numpy().astype(bool) != st[kind].expect).sum())
+        nfull += int(full.numel())
         shard_rows[kind] = [int(bb[k + 1] - bb[k]) for k in range(world)]
         assert all(int(x) % per == 0 for x in bb)
     nv = st["ecdsa"].n + st["schnorr"].n
-    out["cfg5_commit_storm_streaming_sharded"] = {"channels": 10_000, "verifies": nv, "ranks": world, "shard_rows": shard_rows,
+    out["cfg5_commit_storm_streaming_sharded"] = {"channels": max(world, 10_000 // div), "verifies": nv, "ranks": world, "shard_rows": shard_rows,
                                                   "verifies_per_s": nv / min(ts[1:]), "ms": min(ts[1:]) * 1e3, "mismatches": bad, "scaling": "strong",
+                                                  "verdicts_on_every_rank": nfull,
                                                   "note": "inputs in host memory: per rank its commitments stream through the pinned staging queue "
-                                                          "(256 commitments per flush, 3 flushes in flight), then the ragged all-gather of the verdict bytes"}
+                                                          "(256 commitments per flush, up to 8 flushes in flight), then the ragged all-gather of the verdict bytes"}
+    # every rank must have ended with the whole vector and agree on the count of bad verdicts
+    tot = torch.tensor([out["cfg4_gossip_replay_sharded"]["mismatches"] + bad], dtype=torch.int64, device=device)
+    dist.all_reduce(tot)
+    out["mismatches_summed_over_ranks"] = int(tot.item())
     return out
 
 
-def strong_scaling_sweep(eng, device, tstream):
-    """VERDICT r04 "next" 3(a): what ONE rank of a strong-scaling run of BASELINE configs[3] / configs[4] would see, measured on one GPU.  For W in
-    1, 2, 4, 8 the global job is cut as `sharding.run_sharded` cuts it for W ranks and EVERY shard k of W is run by itself -- verification of the
-    shard, then the RCCL all-gather of its (padded) verdict bytes through a one-rank communicator (launch + kernel of the collective; the seven
-    other ranks' bytes would add ~0.3 MB over xGMI) -- and timed from submit to "gathered vector complete".  T(W) = the slowest shard of W;
-    predicted_speedup_W = T(1) / T(W).  A fresh process group (world 1, nccl) is created here, AFTER every other leg of the bench."""
+def strong_scaling_sweep(plat, eng, tstream, div=1):
+    """What ONE rank of a strong-scaling run of BASELINE configs[3] / configs[4] would see, measured on one GPU.  For W in 1, 2, 4, 8 the global
+    job is cut as `sharding.run_sharded` cuts it for W ranks and EVERY shard k of W is run by itself -- verification of the shard, then a
+    stand-in for the all-gather of its (padded) verdict bytes: a device copy of the same size on torch's stream, ordered after the verdicts by the
+    same device-side edge the collective uses (a --gpus 1 run creates no RCCL communicator; launched under torch.distributed.run with
+    LAMD_BENCH_GATHER=1 the copy is a real one-rank all-gather) -- and timed from submit to "gathered vector complete".  T(W) = the slowest shard
+    of W; predicted_speedup_W = T(1) / T(W)."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    from lightning_amd import sharding, workload
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
-    os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
-    own_group = not dist.is_initialized()
-    if own_group:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(device))
+    from lightning_amd import sharding
+    workload, device = plat.workload, plat.device
     out = {}
 
     def best(fn, reps):
         ts = []
         for _ in range(reps):
-            torch.cuda.synchronize(); eng.synchronize()
+            plat.synchronize(); eng.synchronize()
             t1 = time.perf_counter()
             fn()
-            torch.cuda.synchronize(); eng.synchronize()
+            plat.synchronize(); eng.synchronize()
             ts.append(time.perf_counter() - t1)
         return min(ts[1:]) if len(ts) > 1 else ts[0]
 
@@ -217,26 +367,28 @@ def strong_scaling_sweep(eng, device, tstream):
         pad = torch.zeros(m, dtype=torch.uint8, device=device)
         pad[:buf.numel()] = buf
         res = torch.empty(m, dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(res, pad)
+        if dist.is_initialized():
+            dist.all_gather_into_tensor(res, pad)
+        else:
+            res.copy_(pad)
         return res
-    # the collective alone (verdict bytes of a 1/8 shard), for the record
-    probe = torch.zeros(312_500, dtype=torch.uint8, device=device)
+    probe = torch.zeros(max(16, 312_500 // div), dtype=torch.uint8, device=device)
     gather(probe)
     t_gather = best(lambda: gather(probe), 6)
     lanes = eng.info()["lanes"]
     # ---- configs[3]: gossip replay, cut on message boundaries, balanced by cost
-    g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
+    g = workload.make_gossip(eng, 500_000 // div, 2_000_000 // div, n_nodes=max(16, 15000 // div), device=device)
     gw = sharding.gossip_weights(g.msgs, g.off)
     res3, bad3 = {}, 0
     for W in (1, 2, 4, 8):
         b = sharding.shard_bounds(g.n, W, None, gw)
-        shard_ms, split_ms = [], []
+        shard_ms = []
         for k in range(W):
             lo, hi = int(b[k]), int(b[k + 1])
             rb = (g.d_rowbase[lo:hi + 1] - g.d_rowbase[lo]).contiguous()
             rows = int(g.rowbase[hi] - g.rowbase[lo])
             d_v = torch.zeros(hi - lo, dtype=torch.int8, device=device)
-            torch.cuda.synchronize()
+            plat.synchronize()
 
             def one():
                 eng.sigcheck_gossip_device(hi - lo, g.d_msgs, g.d_off[lo:hi + 1], g.d_ids[lo:hi], rb, rows, d_v)
@@ -244,35 +396,20 @@ def strong_scaling_sweep(eng, device, tstream):
                 return gather(d_v)
             for _ in range(lanes if W == 1 and k == 0 else 1):   # every lane allocates its workspaces for the largest shape once
                 one()
-            shard_ms.append(best(one, 6) * 1e3)
+            shard_ms.append(best(one, 5 if W > 1 else 6) * 1e3)
             bad3 += int((d_v.cpu().numpy() != g.expect[lo:hi]).sum())
-            if W > 1 and os.environ.get("LAMD_BENCH_TWO_CHUNKS", "0") == "1":   # measured and lost (profiles/r05_ab_variants.txt); the knob re-runs it
-                # the same shard cut into two chunks (lamd_set_chunk_rows): the second chunk's front end runs under the first chunk's ecmult launch --
-                # what a rank whose shard is the only thing its GPU has to do can afford
-                eng.set_chunk_rows((rows // 2 + 63) // 64 * 64 + 64)
-                d_v.zero_()
-                for _ in range(2):
-                    one()
-                split_ms.append(best(one, 4) * 1e3)
-                bad3 += int((d_v.cpu().numpy() != g.expect[lo:hi]).sum())
-                eng.set_chunk_rows(0)
         res3[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms), "shard_messages": [int(b[k + 1] - b[k]) for k in range(W)],
                         "shard_signatures": [int(g.rowbase[int(b[k + 1])] - g.rowbase[int(b[k])]) for k in range(W)]}
-        if W > 1 and split_ms:
-            res3[str(W)]["shard_ms_two_chunks"] = split_ms
-            res3[str(W)]["slowest_ms_one_chunk"] = max(shard_ms)
-            res3[str(W)]["slowest_ms"] = min(max(shard_ms), max(split_ms))
-            res3[str(W)]["chunks"] = 2 if max(split_ms) < max(shard_ms) else 1
     for W in ("2", "4", "8"):
         res3[W]["predicted_speedup"] = res3["1"]["slowest_ms"] / res3[W]["slowest_ms"]
     out["cfg4_gossip_replay"] = dict(res3, verifies=g.rows, messages=g.n, mismatches=bad3, predicted_speedup_8=res3["8"]["predicted_speedup"],
                                      verifies_per_s_predicted_8=g.rows / (res3["8"]["slowest_ms"] * 1e-3))
     del g
     # ---- configs[4]: commit storm, streaming from host memory, commitments kept whole
-    st = workload.make_commit_storm(eng, 10_000, device=device)
+    st = workload.make_commit_storm(eng, max(8, 10_000 // div), device=device)
     per, grp = st["per"], 256 * st["per"]
     depth = min(8, eng.info()["queue_sets"] - 1)
-
+    first = storm_first_flush(per)
     res5, bad5 = {}, 0
     for W in (1, 2, 4, 8):
         bb = {kind: sharding.shard_bounds(st[kind].n, W, [per] * (st[kind].n // per)) for kind in ("ecdsa", "schnorr")}
@@ -281,7 +418,7 @@ def strong_scaling_sweep(eng, device, tstream):
             keep = {}
 
             def one():
-                keep.update(stream_shard(eng, st, bb, k, grp, depth))
+                keep.update(stream_shard(eng, st, bb, k, grp, depth, first))
                 for kind in ("ecdsa", "schnorr"):
                     gather(torch.from_numpy(keep[kind]).to(device))
             shard_ms.append(best(one, 3) * 1e3)
@@ -292,14 +429,157 @@ def strong_scaling_sweep(eng, device, tstream):
         res5[W]["predicted_speedup"] = res5["1"]["slowest_ms"] / res5[W]["slowest_ms"]
     nv = st["ecdsa"].n + st["schnorr"].n
     out["cfg5_commit_storm_streaming"] = dict(res5, verifies=nv, mismatches=bad5, predicted_speedup_8=res5["8"]["predicted_speedup"],
-                                              verifies_per_s_predicted_8=nv / (res5["8"]["slowest_ms"] * 1e-3))
+                                              verifies_per_s_predicted_8=nv / (res5["8"]["slowest_ms"] * 1e-3), first_flush_rows=first)
     out["gather_alone_ms"] = t_gather * 1e3
+    out["gather"] = "one-rank RCCL all-gather" if dist.is_initialized() else "device copy of the padded verdict bytes (no communicator in a --gpus 1 run)"
     out["note"] = ("one GPU plays every rank of W = 1, 2, 4, 8 in turn: shard k of W as sharding.run_sharded cuts it (message / commitment boundaries; gossip "
-                   "balanced by cost), verification + the RCCL all-gather of the shard's padded verdict bytes on a one-rank communicator; T(W) = slowest shard; "
-                   "predicted_speedup_W = T(1) / T(W).  Not an 8-GPU measurement: no xGMI transfer, no second process")
-    if own_group:
-        dist.destroy_process_group()
+                   "balanced by cost), verification + the gather stand-in; T(W) = slowest shard; predicted_speedup_W = T(1) / T(W).  Not an 8-GPU "
+                   "measurement: no xGMI transfer, no second process")
     return out
+
+
+def host_to_host(eng_cold, eng_warm, we, ws, n, steps):
+    """SURVEY 8(d)'s own wording of the metric on the headline MIX: both batches of a step start in (pageable) host memory and their verdicts end in
+    host memory, through the streaming queue (lamd_queue_*_batch -> pinned staging set, lamd_flush, lamd_wait): while the device works on one flush
+    the host fills the next staging set and its H2D copies run under the kernels of the flushes before it (up to eight in flight).  Staging memcpy +
+    H2D + verification + D2H inside the clock, which runs from an empty pipeline to the last verdict in host memory.  The verdict vectors are
+    compared with construction AFTER the clock (the check is the bench's, not the path's).  -> (dict of legs, mismatches)"""
+    depth = min(8, eng_cold.info()["queue_sets"] - 1)
+
+    def host_mix(e, reps):
+        pend, got = [], []
+        t1 = time.perf_counter()
+        for r in range(reps):
+            for wl in (we, ws):
+                if wl is we:
+                    e.queue_ecdsa_batch(wl.cols[0], wl.cols[1], wl.cols[2])
+                else:
+                    e.queue_schnorr_batch(wl.cols[0], wl.cols[1], wl.cols[2])
+                e.flush()
+                pend.append(wl)
+                if len(pend) == depth:
+                    got.append((e.wait(cap=n), pend.pop(0)))
+        while pend:
+            got.append((e.wait(cap=n), pend.pop(0)))
+        dt_ = time.perf_counter() - t1
+        return dt_, sum(int((v != wl.expect).sum()) for v, wl in got)
+
+    # the producer's form of the same loop: the rows already sit in the pinned staging sets (lamd_queue_reserve: a sidecar receives its
+    # callers' triples straight into them), so a step is reserve + flush + wait -- H2D, verification and D2H inside the clock, no
+    # host-side copy.  Each (staging set, kind) is filled the first time the loop meets it, i.e. during the priming pass.
+    def host_mix_in_place(e, reps, filled):
+        pend, got = [], []
+        t1 = time.perf_counter()
+        for r in range(reps):
+            for wl in (we, ws):
+                _, a, b_, c = e.queue_reserve(n, 65 if wl is we else 32)
+                if a.ctypes.data not in filled:
+                    filled.add(a.ctypes.data)
+                    a[:] = wl.cols[0]
+                    if wl is we:
+                        b_[:], c[:] = wl.cols[1], wl.cols[2]
+                    else:                        # BIP-340 columns are (msg, x-only key, signature)
+                        c[:], b_[:] = wl.cols[1], wl.cols[2]
+                e.flush()
+                pend.append(wl)
+                if len(pend) == depth:
+                    got.append((e.wait(cap=n), pend.pop(0)))
+        while pend:
+            got.append((e.wait(cap=n), pend.pop(0)))
+        dt_ = time.perf_counter() - t1
+        return dt_, sum(int((v != wl.expect).sum()) for v, wl in got)
+    hm, bad = {}, 0
+    legs = [("cold_tables_rebuilt_every_flush", eng_cold, False), ("in_place_cold", eng_cold, True)]
+    if eng_warm is not None and eng_warm is not eng_cold:
+        legs += [("key_table_cache_on", eng_warm, False), ("in_place_key_table_cache_on", eng_warm, True)]
+    for name, e, in_place in legs:
+        seen = set()
+        prime = 9 if not in_place else 9        # staging sets and per-lane workspaces are allocated on first use: nine sets x two kinds
+        if in_place:
+            host_mix_in_place(e, prime, seen)
+            dtm, badm = host_mix_in_place(e, steps, seen)
+        else:
+            host_mix(e, prime)
+            dtm, badm = host_mix(e, steps)
+        hm[name] = {"verifies_per_s": 2 * steps * n / dtm, "ms_per_2M_step": dtm / steps * 1e3, "steps": steps, "mismatches": badm}
+        bad += badm
+    hm.update(rows_per_flush=n, flushes_in_flight=depth,
+              note="1 M ECDSA-65 + 1 M BIP-340 per step from host memory to verdicts in host memory (289 MB in per step); in_place_* = rows written into "
+                   "the pinned staging set by the producer (lamd_queue_reserve), no host-side copy inside the clock; compare with `value` (inputs resident in HBM)")
+    return hm, bad
+
+
+def cpu_baseline(we, ws, got_e, got_s, sample, n):
+    """C0 = the reference's real CPU path (libsecp256k1 through dlopen, called as bitcoin/signature.c:188,425 call it) if this
+    machine has the library -- else "unavailable"; C1 = the restated C oracle, 1 thread and all cores; C2 = OpenSSL ECDSA_do_verify +
+    libsecp256k1's range / low-S rules, 1 thread.  Monotonic clock around each whole batch, verifies/s and ns per verification (the shape
+    of onchaind/test/run-grind_feerate.c:146-154).  Every leg's verdicts must equal the GPU's on the rows it was given.
+    -> (cpu_baseline dict, mismatches)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc  # test infrastructure: the checker / CPU baseline only
+    t_all = time.perf_counter()
+    m = min(sample, n)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a cgroup CPU quota caps what those threads can really use
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    ce_cols = [np.ascontiguousarray(x[:m]) for x in we.cols]
+    cs_cols = [np.ascontiguousarray(x[:m]) for x in ws.cols]
+
+    def leg(fn_e, fn_s, rows_e, rows_s):
+        """-> (dict, verdict mismatches against the GPU)"""
+        t1 = time.perf_counter()
+        ve = fn_e([c[:rows_e] for c in ce_cols]) if fn_e and rows_e else None
+        t2 = time.perf_counter()
+        vs = fn_s([c[:rows_s] for c in cs_cols]) if fn_s and rows_s else None
+        t3 = time.perf_counter()
+        bad = 0
+        d = {}
+        if ve is not None:
+            bad += int((ve.astype(bool) != got_e[:rows_e]).sum())
+            d.update(ecdsa_rows=rows_e, ecdsa_verifies_per_s=rows_e / (t2 - t1), ecdsa_ns_per_verify=(t2 - t1) / rows_e * 1e9)
+        if vs is not None:
+            bad += int((vs.astype(bool) != got_s[:rows_s]).sum())
+            d.update(schnorr_rows=rows_s, schnorr_verifies_per_s=rows_s / (t3 - t2), schnorr_ns_per_verify=(t3 - t2) / rows_s * 1e9)
+        rows = (rows_e if ve is not None else 0) + (rows_s if vs is not None else 0)
+        secs = (t2 - t1 if ve is not None else 0) + (t3 - t2 if vs is not None else 0)
+        d.update(value=rows / secs if secs else None, seconds=secs, gpu_vs_cpu_verdict_mismatches=bad)
+        return d, bad
+    orc.ecdsa_verify_batch(ce_cols[0][:64], ce_cols[1][:64], ce_cols[2][:64], 65, cores)  # table init outside the timed part
+    legs = {}
+    one = max(1, min(m, 10_000))
+    legs["C1_oracle_1_thread"], b1 = leg(lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, 1), lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], 1), one, one)
+    legs["C1_oracle_all_cores"], b2 = leg(lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, cores), lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], cores), m, m)
+    legs["C1_oracle_1_thread"]["threads"], legs["C1_oracle_all_cores"]["threads"] = 1, cores
+    ossl_rows = max(1, min(m, 5_000))
+    legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"], b3 = leg(lambda c: orc.ossl_ecdsa_verify_rules_batch(c[0], c[1], c[2], 65), None, ossl_rows, 0)
+    legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"]["threads"] = 1
+    secp = orc.libsecp_available()
+    if secp:
+        legs["C0_libsecp256k1_1_thread"], b0 = leg(lambda c: orc.libsecp_ecdsa_verify_batch(c[0], c[1], c[2], 65),
+                                                   lambda c: orc.libsecp_schnorr_verify_batch(c[0], c[1], c[2]), min(m, 100_000), min(m, 100_000))
+        legs["C0_libsecp256k1_1_thread"].update(threads=1, library=secp)
+    else:
+        legs["C0_libsecp256k1_1_thread"], b0 = "unavailable: no libsecp256k1.so can be dlopen()ed on this node (the reference's copy is an empty submodule)", 0
+    cm = b0 + b1 + b2 + b3
+    ac, c1 = legs["C1_oracle_all_cores"], legs["C1_oracle_1_thread"]
+    ref = legs["C0_libsecp256k1_1_thread"] if secp else None
+    cb = {"value": ref["value"] if ref else ac["value"], "unit": "verifies/s", "cores": 1 if ref else cores, "kind": "reference" if ref else "port",
+          "sample": ("libsecp256k1 via dlopen (%s), 1 thread, first %d ECDSA + %d Schnorr rows" % (os.path.basename(str(secp)), ref["ecdsa_rows"], ref.get("schnorr_rows", 0))) if ref else
+                    ("first %d ECDSA + %d Schnorr rows of the batch, %d threads, restated C oracle (not libsecp256k1: absent here)" % (m, m, cores)),
+          "note": None if ref else "restated oracle, 2-4x slower per verify than libsecp256k1 (SURVEY 6): GPU/CPU ratios are flattered by that",
+          "C1_1thread": c1["value"], "C1_all_cores": ac["value"], "C2": legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"]["value"],
+          "C0": ref["value"] if ref else "unavailable", "ns_per_verify_1thread": 1e9 / c1["value"] if c1["value"] else None,
+          "ecdsa_verifies_per_s": (ref or ac)["ecdsa_verifies_per_s"], "schnorr_verifies_per_s": (ref or ac).get("schnorr_verifies_per_s"),
+          "host_cores": cores, "libsecp256k1_found": secp, "legs": legs,
+          "legs_note": "BASELINE.md 3: C0 the reference's library (if present), C1 this repo's restated oracle, C2 OpenSSL's generic secp256k1 + "
+                       "libsecp256k1's acceptance rules; monotonic clock around each batch; every leg's verdicts compared with the GPU's",
+          "gpu_vs_cpu_verdict_mismatches": cm, "seconds": time.perf_counter() - t_all}
+    return cb, cm, 2 * m
 
 
 def main():
@@ -307,18 +587,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=250)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1_000_000, help="rows per kind per rank (1 M = BASELINE configs[1], [2])")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="rows per kind timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--rows", "--n", dest="n", type=int, default=1_000_000, help="rows per kind per rank (1 M = BASELINE configs[1], [2])")
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="rows per kind timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--skip-extra", action="store_true", help="skip the cfg4/cfg5 single-GPU data points")
+    ap.add_argument("--extras", action="store_true", help="also: warm key-table cache, latency, PCIe-inclusive calls, configs[3]/[4] on one GPU, gossip ingest flood, "
+                                                          "fee grind, key recovery, key-reuse sweep (tools/bench_extras.py; all of it lands in bench_details.json)")
+    ap.add_argument("--no-scaling", action="store_true", help="skip the one-GPU strong-scaling sweep (config.predicted_speedup_8) / the sharded configs of a multi-rank run")
+    ap.add_argument("--no-h2h", action="store_true", help="skip the host-to-host legs (config.value_host_to_host)")
+    ap.add_argument("--div", type=int, default=1, help="divide the sizes of configs[3]/[4] (quick runs, the CPU tests)")
+    ap.add_argument("--details", default=None, help="where bench_details.json goes (default: next to bench.py, and gpurun_out/)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="ONLY the loop `roofline.frac` is computed from (the cold loop with chained ecmult launches, warm-up + steps): every "
                          "k_ecmult_keyed<false, 3> launch of the process is one of that loop's, so the per-kernel average of `rocprofv3 "
                          "--kernel-trace --stats` over this command is directly comparable with roofline.avg_launch_ms")
-    ap.add_argument("--ab", action="store_true", help="A/B runs: the cold loop, the chained loop and the isolated calls only (no warm engine, latency, PCIe, "
-                                                       "other configs or CPU legs)")
+    ap.add_argument("--ab", action="store_true", help="A/B runs: the cold loop, the chained loop and the isolated calls only")
     ap.add_argument("--steady-steps", type=int, default=250,
                     help="when --steps gives a timed region under ~1 s: steps of an extra, longer cold loop reported as `steady_state` (0 = skip)")
+    ap.add_argument("--h2h-steps", type=int, default=60, help="steps of each host-to-host leg")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         # a plain `python bench.py --gpus N`: become the launcher -- one process per GPU over RCCL, rendezvous on 127.0.0.1
@@ -333,6 +618,8 @@ def main():
     # collective) goes to stderr instead
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    t_start = time.perf_counter()
+    clock = Clock()
 
     import numpy as np
     import torch
@@ -343,26 +630,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: lightning_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    plat = load_platform(local_rank)
+    device = plat.device
+    Engine, workload = plat.Engine, plat.workload
+    from lightning_amd import sharding
     # launched by torch.distributed.run (RANK set): the collective path runs even with one rank, so that a 1-GPU box can test it
     multi = world > 1 or ("RANK" in os.environ and os.environ.get("LAMD_BENCH_GATHER", "0") == "1")
-    from lightning_amd import Engine, sharding, workload
     # the engine first: its streams take their hardware queues before RCCL creates its own (the other order costs ~8 %:
     # measured with one rank forced through the collective path, 180 vs 196 M verifies/s)
-    # two engines: `eng_cold` rebuilds every key's comb table in every call (LAMD_CACHE=0: what a stateless library does, and
-    # what `value` is measured on); `eng` keeps tables in its key-table cache across calls, so from the second step on a repeated
-    # batch is all cache hits ("warm": reported beside the headline, never as it)
-    # With more than one rank ONLY the cold engine exists: one engine = one 11 GiB G table and one set of 16 hardware-queue-backed
-    # streams per rank.  Two engines plus RCCL's own streams is the many-queues regime in which the collective path lost up to 45 %
-    # on one rank (profiles/r02n_collective_path_and_queues.txt); the warm-cache leg is a single-GPU data point anyway.
-    # The cold engine is ALONE in the process while `value` is measured (a serving process holds one engine): the default engine is created
-    # after the cold legs -- two engines are 20 streams on 16 hardware queues, and the second one's share cost the cold loop 3-5 %.
-    os.environ["LAMD_CACHE"] = "0"
-    eng_cold = Engine(local_rank)
-    del os.environ["LAMD_CACHE"]
+    # `eng_cold` rebuilds every key's comb table in every call (LAMD_CACHE=0: what a stateless library does, and what `value` is measured on).
+    # It is ALONE in the process while `value` is measured (a serving process holds one engine): the default engine (key-table cache on) exists
+    # only under --extras and is created after the cold legs -- two engines are 20 streams on 16 hardware queues, and the second one's share cost
+    # the cold loop 3-5 %.  With more than one rank ONLY the cold engine exists: one engine = one 11 GiB G table per rank.
+    with clock("engine_init"):
+        os.environ["LAMD_CACHE"] = "0"
+        eng_cold = Engine(local_rank)
+        del os.environ["LAMD_CACHE"]
     eng = eng_cold
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -370,12 +653,17 @@ def main():
         # channel RCCL opens beyond that is a stream competing with the engine's lanes for hardware queues
         os.environ.setdefault("NCCL_MIN_NCHANNELS", "1")
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "2")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        with clock("process_group"):
+            if plat.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(device))
+            else:
+                dist.init_process_group(plat.backend)
     eng_cold.set_timing(True)
 
     n = args.n
-    we = workload.make_ecdsa(eng, n, seed=workload.SEED_CFG2 + rank, nkeys=65536, publen=65, device=device)
-    ws = workload.make_schnorr(eng, n, seed=workload.SEED_CFG3 + rank, nkeys=65536, device=device)
+    with clock("workload"):
+        we = workload.make_ecdsa(eng, n, seed=workload.SEED_CFG2 + rank, nkeys=65536, publen=65, device=device)
+        ws = workload.make_schnorr(eng, n, seed=workload.SEED_CFG3 + rank, nkeys=65536, device=device)
     # collective path: one all-gather per batch kind and step, issued one step late (after the calls of the next step: see step())
     ok_all_e = torch.zeros(world * n, dtype=torch.uint8, device=device) if multi else None
     ok_all_s = torch.zeros(world * n, dtype=torch.uint8, device=device) if multi else None
@@ -383,32 +671,21 @@ def main():
     kernel_ms = {"ecdsa": [], "schnorr": []}
     keyed = {}
 
-    tstream = torch.cuda.current_stream().cuda_stream
+    tstream = plat.stream_ptr()
 
-    # multi-rank: verdicts alternate between two buffers per kind so that the all-gather of a step's batch (on torch's stream, ordered
-    # after that call by device-side events) can still be reading buffer k%2 while step k+1 already writes the other one.  Every
-    # dependency is per call, by events, with no host synchronisation:
-    #   * a buffer is written again only after the gather that read it (lamd_wait_event on that gather's event, just before the call);
-    #   * a gather waits for "everything submitted up to its call" (lamd_results_mark right after the call, lamd_stream_wait_mark later);
-    #   * the gathers of step k are issued AFTER the calls of step k+1, when step k is (nearly) done: torch's stream then never carries a
-    #     wait that lasts a whole step.
-    # Coupling the two calls of a step instead (one gather per step, the next-but-one step waiting for it) held the ECDSA lane back until
-    # the BIP-340 call of the same step had finished: a 3-4 ms bubble every other step in the rocprofv3 timeline, -12 % (profiles/r02m_*).
-    # (round 5: SIX buffers per kind instead of two -- LAMD_BENCH_GATHER_BUFS; 2 / 4 / 6 buffers: 0.93 / 0.987 / 0.994 of the plain loop on one rank --: with two, step k + 2 waits for the gather of step k, a small copy kernel that
-    # takes 0.3-1 ms to get its waves onto the saturated chip; in the kernel trace of that loop the calls bunched up in pairs with 3-4 ms holes between them)
+    # multi-rank: verdicts rotate over `nbuf` buffers per kind so that the all-gather of a step's batch (on torch's stream, ordered
+    # after that call by device-side events) can still be reading buffer k while later steps write the others.  Every dependency is per call,
+    # by events, with no host synchronisation (sharding.LateGather).  Six buffers: with two, step k + 2 waited for the gather of
+    # step k, a small copy kernel that takes 0.3-1 ms to get its waves onto the saturated chip (2 / 4 / 6 buffers: 0.93 / 0.987 / 0.994 of the plain loop on one rank).
     nbuf = max(2, min(8, int(os.environ.get("LAMD_BENCH_GATHER_BUFS", "6"))))
     ok_e = [we.d_ok] + [torch.zeros_like(we.d_ok) for _ in range(nbuf - 1)] if multi else [we.d_ok]
     ok_s = [ws.d_ok] + [torch.zeros_like(ws.d_ok) for _ in range(nbuf - 1)] if multi else [ws.d_ok]
 
-    def new_event():
-        ev = torch.cuda.Event()
-        ev.record()
-        return ev
     lg = {}      # per engine: sharding.LateGather (the marks are the engine's)
     def late_gather(eng):
         if id(eng) not in lg:
             lg[id(eng)] = sharding.LateGather(eng, ("e", "s"), {"e": ok_e, "s": ok_s}, {"e": ok_all_e, "s": ok_all_s}, tstream,
-                                              dist.all_gather_into_tensor, new_event)
+                                              dist.all_gather_into_tensor, plat.new_event)
         return lg[id(eng)]
     stepno = [0]
     def step(eng, poison=False):
@@ -430,7 +707,7 @@ def main():
         eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ok_s[b])
         if multi:
             g.after_call("s", b)
-            g.end_step(b)      # issues the RCCL all-gathers of the PREVIOUS step
+            g.end_step(b)      # issues the all-gathers of the PREVIOUS step
 
     def record_kernel_times(eng):
         # HIP events recorded on the lanes' own streams around each kernel group of the LAST step inside the timed region
@@ -445,7 +722,7 @@ def main():
         if multi:
             late_gather(eng).flush()       # the last step's all-gathers belong to the timed region
             dist.barrier()
-        torch.cuda.synchronize()
+        plat.synchronize()
         eng.synchronize()
 
     launch_ms = {}
@@ -488,16 +765,18 @@ def main():
 
     # the headline first: cold, every table rebuilt in every call
     full = not args.roofline_only
-    extras = full and not args.ab
+    default_legs = full and not args.ab
     dt, mism_cold, steady = float("nan"), 0, None
     if full:
-        dt, mism_cold = timed(eng_cold)
+        with clock("headline_loop"):
+            dt, mism_cold = timed(eng_cold)
         record_kernel_times(eng_cold)
         if args.steady_steps > 0 and dt < 1.0 and not multi:
             # the driver's --steps 20 is a 0.17 s region: the same loop once more over a region of seconds, reported beside `value`
-            k_steps, args.steps = args.steps, args.steady_steps
-            dt_st, mism_st = timed(eng_cold)
-            args.steps = k_steps
+            with clock("steady_loop"):
+                k_steps, args.steps = args.steps, args.steady_steps
+                dt_st, mism_st = timed(eng_cold)
+                args.steps = k_steps
             steady = {"value": world * 2 * n * args.steady_steps / dt_st, "unit": "verifies/s", "steps": args.steady_steps, "seconds": dt_st,
                       "ms_per_step": dt_st / args.steady_steps * 1e3, "mismatches": mism_st,
                       "note": "the timed loop of `value` again over a region of seconds (box-to-box spread of the short region: +-3 %)"}
@@ -508,83 +787,76 @@ def main():
     # from the default mode above (2-3 % more throughput: the tail of one launch filled by the head of the next).
     chained = None
     if not multi:
-        lm_cold = launch_ms.get(id(eng_cold))
-        eng_cold.set_ecmult_chain(True)
-        dt_ch, mism_ch = timed(eng_cold)
-        chained = {"dt": dt_ch, "mismatches": mism_ch, "lm": launch_ms[id(eng_cold)], "rows": rows_per_kind(eng_cold)}
-        if not full:
-            record_kernel_times(eng_cold)
-            dt = dt_ch
-        eng_cold.set_ecmult_chain(False)
-        if lm_cold is not None:
-            launch_ms[id(eng_cold)] = lm_cold
-        mism_cold += mism_ch
-    eng_default, eng = eng, eng_cold      # the isolated launch durations below are the cold engine's too
+        with clock("chained_loop"):
+            lm_cold = launch_ms.get(id(eng_cold))
+            eng_cold.set_ecmult_chain(True)
+            dt_ch, mism_ch = timed(eng_cold)
+            chained = {"dt": dt_ch, "mismatches": mism_ch, "lm": launch_ms[id(eng_cold)], "rows": rows_per_kind(eng_cold)}
+            if not full:
+                record_kernel_times(eng_cold)
+                dt = dt_ch
+            eng_cold.set_ecmult_chain(False)
+            if lm_cold is not None:
+                launch_ms[id(eng_cold)] = lm_cold
+            mism_cold += mism_ch
     # the same kernels once more, one call at a time (nothing else on the GPU): the isolated durations
     isolated = {"ecdsa": [], "schnorr": []}
-    eng.set_timing(True)
+    eng_cold.set_timing(True)
     rows_in_launch = n
-    for _ in range(2 if full else 0):
-        eng.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
-        eng.synchronize()
-        isolated["ecdsa"].append(eng.info()["last_kernel_ms"])
-        # rows the table-driven launch really carries: rows whose signature scalars are certain to fail the preparation were rejected by the
-        # row-list builders (early reject), rows under rare / unparsable keys went to the ladder list
-        rows_in_launch = int(eng.info()["last_hot_rows"]) or n
-        eng.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
-        eng.synchronize()
-        isolated["schnorr"].append(eng.info()["last_kernel_ms"])
-    iso_launch = [sum(eng.info(l)["keyed_ecmult_ms_sum"][m] for l in range(eng.info()["lanes"])) /
-                  max(1, sum(eng.info(l)["keyed_ecmult_launches"][m] for l in range(eng.info()["lanes"]))) for m in (0, 1)] if full else [0.0, 0.0]
+    with clock("isolated_calls"):
+        for _ in range(2 if full else 0):
+            eng_cold.verify_ecdsa_device(we.dev[0], we.dev[1], we.dev[2], we.d_ok)
+            eng_cold.synchronize()
+            isolated["ecdsa"].append(eng_cold.info()["last_kernel_ms"])
+            rows_in_launch = int(eng_cold.info()["last_hot_rows"]) or n
+            eng_cold.verify_schnorr_device(ws.dev[0], ws.dev[1], ws.dev[2], ws.d_ok)
+            eng_cold.synchronize()
+            isolated["schnorr"].append(eng_cold.info()["last_kernel_ms"])
+    lanes_n = eng_cold.info()["lanes"]
+    iso_launch = [sum(eng_cold.info(l)["keyed_ecmult_ms_sum"][m] for l in range(lanes_n)) /
+                  max(1, sum(eng_cold.info(l)["keyed_ecmult_launches"][m] for l in range(lanes_n))) for m in (0, 1)] if full else [0.0, 0.0]
     if not full:
         rows_in_launch = (chained or {}).get("rows", {}).get(0, n)
         isolated = {k: [[float("nan")] * 4] for k in isolated}
-    # the roofline's denominator at the clock long launches sustain (VERDICT r04 "next" 2b): a dependency-free v_mad_u64_u32 stream on every SIMD in
-    # launches of >= 4 ms, at the ecmult kernel's occupancy (3 waves per SIMD) and at 8; the GPU is idle around it (everything above is synchronised)
+    # the roofline's denominator at the clock long launches sustain: a dependency-free v_mad_u64_u32 stream on every SIMD in launches of >= 4 ms,
+    # at the ecmult kernel's occupancy (3 waves per SIMD) and at 8; the GPU is idle around it (everything above is synchronised)
     peak_sust = None
-    try:
-        eng_cold.synchronize()
-        p3 = eng_cold.mul32_peak(3, 4.0, 5)
-        p8 = eng_cold.mul32_peak(8, 4.0, 5)
-        p8s = eng_cold.mul32_peak(8, 0.0, 5)
-        peak_sust = {"waves3": {"Tmul32_per_s": p3[0] / 1e12, "launch_ms": p3[1], "memtime_per_realtime": p3[2]},
-                     "waves8": {"Tmul32_per_s": p8[0] / 1e12, "launch_ms": p8[1], "memtime_per_realtime": p8[2]},
-                     "waves8_short_launch": {"Tmul32_per_s": p8s[0] / 1e12, "launch_ms": p8s[1], "memtime_per_realtime": p8s[2]}}
-    except Exception as e:   # an older library without the entry point (LAMD_LIB_PATH experiments)
-        peak_sust = {"error": repr(e)}
-    # now the default engine (key-table cache on) and its warm loop: after the warm-up steps every key of the repeated batch is a cache hit
-    if extras and not multi:
-        eng_default = Engine(local_rank)
-        eng_default.set_timing(True)
-        dt_warm, mism_warm = timed(eng_default)
-        warm_info = [eng_default.info(k) for k in range(eng_default.info()["lanes"])]
-    else:
-        dt_warm, mism_warm, warm_info = float("nan"), 0, []
-    eng = eng_default                     # latency, PCIe-inclusive and the other configs run on the default engine (cache on)
+    with clock("mul32_peak"):
+        try:
+            eng_cold.synchronize()
+            p3 = eng_cold.mul32_peak(3, 4.0, 4)
+            p8 = eng_cold.mul32_peak(8, 4.0, 4)
+            peak_sust = {"waves3": {"Tmul32_per_s": p3[0] / 1e12, "launch_ms": p3[1], "memtime_per_realtime": p3[2]},
+                         "waves8": {"Tmul32_per_s": p8[0] / 1e12, "launch_ms": p8[1], "memtime_per_realtime": p8[2]}}
+        except Exception as e:   # an older library without the entry point (LAMD_LIB_PATH experiments)
+            peak_sust = {"error": repr(e)}
     for k in isolated:
         if not kernel_ms[k]:          # LAMD_LANES=1: only the last call's events survive the timed region
             kernel_ms[k] = isolated[k]
             keyed.setdefault(k, keyed.get("schnorr", (0, 0)))
-    # ---- parity on every row of this rank (verdicts known by construction): the poisoned last step of both timed loops, and
+    # ---- parity on every row of this rank (verdicts known by construction): the poisoned last step of the timed loops, and
     # the isolated calls just made
     got_e = we.d_ok.cpu().numpy().astype(bool)
     got_s = ws.d_ok.cpu().numpy().astype(bool)
     mism_iso = int((got_e != we.expect).sum() + (got_s != ws.expect).sum()) if full else 0
-    mism = mism_iso + mism_cold + mism_warm
+    mism = mism_iso + mism_cold
     if multi:
-        # every rank must hold every other rank's verdicts after the all-gather
-        sl = slice(rank * n, (rank + 1) * n)
-        mism += int((ok_all_e[sl].cpu().numpy().astype(bool) != we.expect).sum() + (ok_all_s[sl].cpu().numpy().astype(bool) != ws.expect).sum())
+        # every rank must hold every other rank's verdicts after the all-gather: all ranks' expected verdicts are gathered too and compared WHOLE
+        exp_all = [torch.zeros(world * n, dtype=torch.uint8, device=device) for _ in range(2)]
+        dist.all_gather_into_tensor(exp_all[0], torch.from_numpy(we.expect.astype(np.uint8)).to(device))
+        dist.all_gather_into_tensor(exp_all[1], torch.from_numpy(ws.expect.astype(np.uint8)).to(device))
+        plat.synchronize()
+        mism += int((ok_all_e != exp_all[0]).sum().item() + (ok_all_s != exp_all[1]).sum().item())
         m = torch.tensor([mism], dtype=torch.int64, device=device)
         dist.all_reduce(m)
         mism = int(m.item())
 
     # ---- the two "8 GPUs" configs of BASELINE.json as ONE job split over the ranks (all ranks take part in the collectives)
     sharded = None
-    if multi and not args.skip_extra and extras:
-        sharded = sharded_configs(eng, rank, world, device, tstream)
-        for v in sharded.values():
-            mism += v["mismatches"] if rank == 0 else 0
+    if multi and default_legs and not args.no_scaling:
+        with clock("sharded_configs"):
+            sharded = sharded_configs(plat, eng_cold, rank, world, tstream, args.div)
+        mism += sharded["mismatches_summed_over_ranks"] if rank == 0 else 0
 
     out = None
     if rank == 0:
@@ -662,11 +934,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (256-bit modular integer)",
             "data": "synthetic",
             "config": {"workload": "configs[1]+configs[2]: %d ECDSA (65-byte keys, 65536 distinct) + %d BIP-340 Schnorr per GPU per step, "
-                                   "90%% valid / 10%% invalid, inputs resident in HBM" % (n, n),
+                                   "90%% valid / 10%% invalid, inputs resident in HBM%s" % (n, n, "" if full else "; --roofline-only: the chained loop"),
                        "rows_per_gpu_per_step": 2 * n, "parallelism": "shard-by-row x%d, RCCL all-gather of verdicts" % world,
-                       "key_table_cache": "off for `value` (tables rebuilt every call); on for `warm_cache`",
-                       "timed_loop": "default scheduling (large ecmult launches of successive calls may overlap)" if full else
-                                     "--roofline-only: the chained loop (this line's `value` is that loop's)"},
+                       "key_table_cache": "off (tables rebuilt every call)"},
             "steady_state": steady,
             "rates": {"ecdsa65_verifies_per_s_1gpu": n / (ke.sum() * 1e-3), "schnorr_verifies_per_s_1gpu": n / (ks.sum() * 1e-3),
                       "kernel_ms_ecdsa": {"prep": ke[0], "keys_and_tables": ke[1], "ecmult": ke[2], "parity_stage": ke[3]},
@@ -683,9 +953,7 @@ def main():
                 "achieved": achieved / 1e12, "peak": p_sust / 1e12, "unit": "Tmul32/s", "frac": achieved / p_sust,
                 "peak_sustained": p_sust / 1e12, "peak_boost": P_MUL32 / 1e12, "frac_vs_boost_peak": achieved / P_MUL32,
                 "peak_note": "peak = peak_sustained: dependency-free v_mad_u64_u32 on every SIMD in launches of >= 4 ms, measured in THIS process after the timed "
-                             "loops (lamd_debug_mul32_peak; the better of 3 and 8 waves per SIMD); peak_boost = 36.9: the round-1 micro-benchmark's sub-millisecond "
-                             "launches, which rounds 1-4 priced the fraction against; the shader clock of both kinds of launch is in profiles/r05_mul32_peak.txt "
-                             "(GRBM_GUI_ACTIVE / 8 / t)",
+                             "loops (lamd_debug_mul32_peak; the better of 3 and 8 waves per SIMD); peak_boost = 36.9: the round-1 micro-benchmark's sub-millisecond launches",
                 "peak_sustained_detail": peak_sust,
                 # the whole step against the peak: both table-driven launches' executed multiply-adds / ms_per_step (key tables, scalar preparation,
                 # de-duplication and every stall count as lost time)
@@ -706,543 +974,83 @@ def main():
                     "avg_launch_ms": lm_ov[0][0] / lm_ov[0][1], "avg_launch_ms_schnorr": (lm_ov[1][0] / lm_ov[1][1]) if lm_ov[1][1] else None,
                     "sum_of_launch_ms_per_step": (lm_ov[0][0] / lm_ov[0][1]) + ((lm_ov[1][0] / lm_ov[1][1]) if lm_ov[1][1] else 0.0),
                     "note": "the same brackets in the DEFAULT mode (the loop `value` is measured on): 1.1-1.5 such launches are in flight at any time, every "
-                            "bracket holds its neighbours' share too and their sum exceeds the step time -- not a kernel duration, kept for comparison with "
-                            "earlier rounds (r03 reported this as roofline.avg_launch_ms)"},
+                            "bracket holds its neighbours' share too and their sum exceeds the step time -- not a kernel duration"},
                 "pipeline": pipeline,
                 "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
+                "algorithmic_bytes_per_launch": algo_bytes,
                 "traffic_detail": None if traffic is None else {"fetch_size_factor": fetch_factor, "uncorrected_bytes": traffic_raw,
                                                                "achieved_TBs_at_avg_launch": traffic / t_ecmult / 1e12, "hbm_peak_frac": traffic / t_ecmult / 1e9 / HBM_PEAK_GBS},
                 "traffic_source": traffic_src,
                 # the multiplier instructions are 60 % of the kernel's VALU instructions and the VALU issue port is the limit
                 "valu_issue": valu_issue,
+                "valu_instr_per_verify": valu_issue["valu_instr_per_verify"] if valu_issue else None,
+                "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
                 # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time: NOT a
                 # utilisation figure (the combs execute 2.2x fewer multiplies than the yardstick's generic algorithm)
                 "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "yardstick_Tmul32_per_s_in_loop": W_ECDSA65 * n / t_ecmult / 1e12,
                                      "note": "rate at which SURVEY 8(d)'s generic-algorithm multiplies would have to run to finish in the same time; not a fraction of peak"},
                 "hbm": {"algorithmic_bytes_per_launch": algo_bytes, "achieved_GBs": algo_bytes / t_ecmult / 1e9,
                         "peak_GBs": HBM_PEAK_GBS, "frac": algo_bytes / t_ecmult / 1e9 / HBM_PEAK_GBS}}),
-            "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "mismatches_by_leg": {"cold_loop": mism_cold, "warm_loop": mism_warm, "isolated_calls": mism_iso},
-                       "against": "verdicts known by construction (all rows; the last timed step of "
-                       "both loops writes into poisoned verdict buffers)"},
-            # `value` above is COLD: every call builds the comb tables of its keys again (LAMD_CACHE=0), as a stateless library
-            # would.  With the key-table cache (the default for serving: gossip node ids and channel keys recur) the same loop is
-            "warm_cache": {"value": world * 2 * n * args.steps / dt_warm, "unit": "verifies/s", "ms_per_step": dt_warm / args.steps * 1e3,
-                           "note": "same timed loop on an engine with the key-table cache on: after the warm-up steps every key of this repeated "
-                                   "synthetic batch is a cache hit (no table is built) -- an upper bound for serving, not the headline",
-                           "cache_hits_last_call": [int(i["last_cache_hits"]) for i in warm_info], "new_tables_last_call": [int(i["last_new_tables"]) for i in warm_info],
-                           "comb_teeth_last_call": [int(i["last_keyed"]) for i in warm_info]},
+            "parity": {"rows_checked": world * 2 * n, "mismatches": mism, "mismatches_by_leg": {"cold_loops": mism_cold, "isolated_calls": mism_iso},
+                       "against": "verdicts known by construction (all rows; the last timed step of every loop writes into poisoned verdict buffers)"},
         }
-        if not extras or eng_default is eng_cold:
-            out["warm_cache"] = None
         if sharded is not None:
-            out["sharded_configs"] = sharded
-        # ---- batch latency (the metric's second half) and the PCIe-inclusive rate: host buffers in -> verdicts in
-        # host memory out, through lamd_verify_ecdsa_batch (pageable numpy memory; never `value`)
-        lat = {}
-        for bs in ((1, 484, 4096) if world == 1 and extras else ()):
-            hh, ss, pp = [np.ascontiguousarray(x[:bs]) for x in we.cols]
-            ts = []
-            for it in range(60 if bs > 1 else 120):
-                t1 = time.perf_counter()
-                eng.verify_ecdsa(hh, ss, pp)
-                ts.append(time.perf_counter() - t1)
-            ts = np.sort(np.array(ts[5:])) * 1e3
-            lat["ecdsa65_batch_%d" % bs] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)])}
-        if world == 1 and extras:
-            # one commitment_signed as channeld sees it (channeld.c:2171,2224): 1 signature under the funding key + 483 under ONE htlc key
-            # that recurs with every commitment of the channel -- first sight (the key gets its comb table) and afterwards (cache hit)
-            cs = workload.make_commit_storm(eng, 4, device=device)["ecdsa"]
-            hh, ss, pp = [np.ascontiguousarray(x[:484]) for x in cs.cols]
-            t1 = time.perf_counter()
-            first = eng.verify_ecdsa(hh, ss, pp)
-            t_first = time.perf_counter() - t1
-            ts = []
-            for it in range(60):
-                t1 = time.perf_counter()
-                got = eng.verify_ecdsa(hh, ss, pp)
-                ts.append(time.perf_counter() - t1)
-            ts = np.sort(np.array(ts[5:])) * 1e3
-            mism += int((got != cs.expect[:484]).sum() + (first != cs.expect[:484]).sum())
-            lat["commitment_484_one_htlc_key"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
-                                                  "cache_hits_last_call": int(eng.info()["last_cache_hits"])}
-        if world == 1 and extras:
-            # the same batch as ONE call of lamd_check_commitment_signed (channeld.c:2171-2232: transaction templates in, first_bad out): BIP143 hashing of the
-            # 1 + 483 inputs on the device + the verification; the arguments are marshalled once, the clock holds the C call only
-            try:
-                rb = np.random.default_rng(0xC0117)
-                rbytes = lambda k: bytes(rb.integers(0, 256, k, dtype=np.uint8))
-                outs_c = [(int(rb.integers(330, 10**7)), b"\x00\x20" + rbytes(32)) for _ in range(485)]
-                ctx_tx = dict(version=2, locktime=0x20000000, inputs=[(rbytes(32), 0, 0x80000001)], outputs=outs_c, input_num=0, amount=sum(a for a, _ in outs_c) + 5000,
-                              script=b"\x52\x21" + rbytes(33) + b"\x21" + rbytes(33) + b"\x52\xae")
-                htx = [dict(version=2, locktime=0, inputs=[(rbytes(32), i, 0)], outputs=[(outs_c[i][0] - 100, b"\x00\x20" + rbytes(32))], input_num=0, amount=outs_c[i][0],
-                            script=rbytes(133)) for i in range(483)]
-                # (the signatures are the storm rows': they do not verify against these templates' hashes -- the call's cost does not depend on the verdicts;
-                # parity of this entry point is tests/test_gpu_commitment.py's business)
-                cc = eng.commitment_call(ctx_tx, bytes(pp[0]), bytes(ss[0]), 1, htx, bytes(pp[1]), [bytes(x) for x in ss[1:484]], [1] * 483)
-                t1 = time.perf_counter()
-                cc()
-                t_first = time.perf_counter() - t1
-                cc()
-                ts = []
-                for it in range(60):
-                    t1 = time.perf_counter()
-                    cc()
-                    ts.append(time.perf_counter() - t1)
-                ts = np.sort(np.array(ts[5:])) * 1e3
-                lat["commitment_signed_one_call_484"] = {"first_sight_ms": t_first * 1e3, "p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99)]),
-                                                         "note": "lamd_check_commitment_signed: templates -> BIP143 hashes on the device -> 1 + 483 verifications -> first_bad"}
-            except Exception as e:
-                lat["commitment_signed_one_call_484"] = {"error": repr(e)}
-        if world == 1 and extras:
-            # BASELINE configs[0]: the committed 1 024 triples (tests/golden/cfg1.bin), ONE call per
-            # signature through the reference's own prototype check_signed_hash(hash, sig, key) (bitcoin/signature.c:174-192)
-            # in the C++ mirror -- what an unmodified caller sees; ns per call as onchaind/test/run-grind_feerate.c reports
-            try:
-                import ctypes
-                from lightning_amd import _build
-                shim = ctypes.CDLL(_build.build_shim())
-                shim.lamd_shim_use_context.argtypes = [ctypes.c_void_p]
-                shim.lamd_shim_use_context(eng._ctx)
-                shim.check_signed_hash.restype = ctypes.c_bool
-                shim.fromwire_secp256k1_ecdsa_signature.restype = ctypes.c_bool
-                shim.pubkey_from_der.restype = ctypes.c_bool
-                blob = open(os.path.join(ROOT, "tests", "golden", "cfg1.bin"), "rb").read()
-                rows = [(blob[o:o + 32], blob[o + 32:o + 96], blob[o + 96:o + 129], bool(blob[o + 129])) for o in range(0, len(blob), 130)]
-                parsed = []
-                for h, s, p, e in rows:
-                    hh, sg, pk = ctypes.create_string_buffer(h, 32), ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
-                    okp = bool(shim.fromwire_secp256k1_ecdsa_signature(s, sg)) and bool(shim.pubkey_from_der(p, 33, pk))
-                    parsed.append((hh, sg, pk, okp, e))
-                c1 = []
-                for rep in range(3):
-                    bad1 = 0
-                    t1 = time.perf_counter()
-                    for hh, sg, pk, okp, e in parsed:
-                        bad1 += (okp and bool(shim.check_signed_hash(hh, sg, pk))) != e
-                    c1.append(time.perf_counter() - t1)
-                lat["cfg1_one_by_one_check_signed_hash"] = {"rows": len(rows), "ns_per_call": min(c1) / len(rows) * 1e9, "ns_per_call_first_pass": c1[0] / len(rows) * 1e9,
-                                                            "ns_per_call_by_pass": [c / len(rows) * 1e9 for c in c1], "mismatches": int(bad1),
-                                                            "note": "1 024 calls of one signature each through the shim's check_signed_hash (host structs in, bool out), three "
-                                                                    "passes over the committed rows.  A call is ONE launch (k_small_verify).  First pass: a key's first sight is "
-                                                                    "verified by the ladder, its second sight builds and publishes its comb table, later sights are cache "
-                                                                    "hits; the later passes are all hits -- what a daemon sees for the keys of its peers and channels"}
-                mism += int(bad1)
-                shim.lamd_shim_use_context(None)
-            except (OSError, FileNotFoundError) as e:
-                lat["cfg1_one_by_one_check_signed_hash"] = {"error": repr(e)}
-        if lat:
-            out["latency"] = dict(lat, note="submit -> verdicts in host memory, one batch in flight, incl. H2D/D2H; 484 = one commitment_signed")
-        tp = []
-        for _ in range(3 if extras else 0):  # the first call of this size allocates the staging buffers (and, per hardware queue, kernel scratch)
-            t1 = time.perf_counter()
-            hv = eng.verify_ecdsa(we.cols[0], we.cols[1], we.cols[2])
-            tp.append(time.perf_counter() - t1)
-        if extras:
-            out["pcie_inclusive"] = {"ecdsa65_verifies_per_s": n / min(tp[1:]), "first_call_verifies_per_s": n / tp[0], "rows": n,
-                                     "note": "pageable host buffers in, verdicts out, one synchronous call (best of two after a warm-up call); not the headline value"}
-            mism += int((hv != we.expect).sum())
-        if world == 1 and extras:
-            # SURVEY 8(d)'s own definition of the metric on the headline MIX: both batches of a step start in (pageable) host memory
-            # and their verdicts end in host memory, through the streaming queue (lamd_queue_*_batch -> pinned staging set, lamd_flush,
-            # lamd_wait): while the device works on one flush the host fills the next staging set and its H2D copies run under the
-            # kernels of the flushes before it (up to eight in flight; the copies of all flushes go down one copy stream in flush order).  Staging memcpy + H2D + verification + D2H inside the clock.
-            # (100 steps since round 5: the clock runs from an empty pipeline to the last verdict in host memory, i.e. it holds one fill and one drain of
-            # ~10 ms; over 30 steps that alone was 3-4 % of the region, where the resident loop's 250 steps hold theirs to 0.4 %)
-            H2H_STEPS = 100
-            H2H_DEPTH = min(8, eng.info()["queue_sets"] - 1)   # flushes kept in flight (the copies of the flushes behind the lanes' current ones run under their kernels)
-            # (the clock stops when the last verdict vector is in host memory; the vectors are compared with the expected verdicts AFTER it -- the
-            # check is the bench's, not the path's: a 1 M-element numpy compare per flush is 1-1.5 ms of host time)
-            def host_mix(e, reps):
-                pend, got = [], []
-                t1 = time.perf_counter()
-                for r in range(reps):
-                    for wl in (we, ws):
-                        if wl is we:
-                            e.queue_ecdsa_batch(wl.cols[0], wl.cols[1], wl.cols[2])
-                        else:
-                            e.queue_schnorr_batch(wl.cols[0], wl.cols[1], wl.cols[2])
-                        e.flush()
-                        pend.append(wl)
-                        if len(pend) == H2H_DEPTH:
-                            got.append((e.wait(cap=n), pend.pop(0)))
-                while pend:
-                    got.append((e.wait(cap=n), pend.pop(0)))
-                dt_ = time.perf_counter() - t1
-                return dt_, sum(int((v != wl.expect).sum()) for v, wl in got)
-            hm = {}
-            for name, e in (("cold_tables_rebuilt_every_flush", eng_cold), ("key_table_cache_on", eng)):
-                host_mix(e, 9)                    # staging sets and per-lane workspaces are allocated on first use: nine sets x two kinds = 18 flushes
-                dtm, badm = host_mix(e, H2H_STEPS)   # incl. filling and draining the pipeline
-                hm[name] = {"verifies_per_s": 2 * H2H_STEPS * n / dtm, "ms_per_2M_step": dtm / H2H_STEPS * 1e3, "steps": H2H_STEPS, "mismatches": badm}
-                mism += badm
-            # the producer's form of the same loop: the rows already sit in the pinned staging sets (lamd_queue_reserve: a sidecar receives its
-            # callers' triples straight into them), so a step is reserve + flush + wait -- H2D, verification and D2H inside the clock, no
-            # host-side copy.  Each (staging set, kind) is filled the first time the loop meets it, i.e. during the priming pass.
-            def host_mix_in_place(e, reps, filled):
-                pend, got = [], []
-                t1 = time.perf_counter()
-                for r in range(reps):
-                    for wl in (we, ws):
-                        _, a, b_, c = e.queue_reserve(n, 65 if wl is we else 32)
-                        if a.ctypes.data not in filled:
-                            filled.add(a.ctypes.data)
-                            a[:] = wl.cols[0]
-                            if wl is we:
-                                b_[:], c[:] = wl.cols[1], wl.cols[2]
-                            else:                        # BIP-340 columns are (msg, x-only key, signature)
-                                c[:], b_[:] = wl.cols[1], wl.cols[2]
-                        e.flush()
-                        pend.append(wl)
-                        if len(pend) == H2H_DEPTH:
-                            got.append((e.wait(cap=n), pend.pop(0)))
-                while pend:
-                    got.append((e.wait(cap=n), pend.pop(0)))
-                dt_ = time.perf_counter() - t1
-                return dt_, sum(int((v != wl.expect).sum()) for v, wl in got)
-            for name, e in (("in_place_cold", eng_cold), ("in_place_key_table_cache_on", eng)):
-                seen = set()
-                host_mix_in_place(e, 9, seen)
-                dtm, badm = host_mix_in_place(e, H2H_STEPS, seen)
-                hm[name] = {"verifies_per_s": 2 * H2H_STEPS * n / dtm, "ms_per_2M_step": dtm / H2H_STEPS * 1e3, "steps": H2H_STEPS, "mismatches": badm,
-                            "note": "rows written into the pinned staging set by the producer (lamd_queue_reserve): no host-side copy inside the clock"}
-                mism += badm
+            out["sharded_configs"] = {k: v for k, v in sharded.items() if isinstance(v, dict)}
+        # ---- the metric as SURVEY 8(d) words it: host buffers in -> verdicts in host memory out (never `value`; config.value_host_to_host)
+        eng_warm = None
+        if world == 1 and args.extras and default_legs and not multi:
+            with clock("warm_engine_init"):
+                eng_warm = Engine(local_rank)
+                eng_warm.set_timing(True)
+        if world == 1 and default_legs and not multi and not args.no_h2h:
+            with clock("host_to_host"):
+                hm, badm = host_to_host(eng_cold, eng_warm, we, ws, n, args.h2h_steps)
+            mism += badm
             best_cold = max(hm["cold_tables_rebuilt_every_flush"]["verifies_per_s"], hm["in_place_cold"]["verifies_per_s"])
             out["value_host_to_host"] = {"value": best_cold, "unit": "verifies/s", "ratio_to_value": best_cold / value,
                                          "ratio_to_steady_state": (best_cold / steady["value"]) if steady else None,
                                          "what": "SURVEY 8(d)'s wording of the metric: the same 1 M ECDSA-65 + 1 M BIP-340 step with both batches starting in host "
                                                  "memory and the verdicts ending in host memory (streaming queue, tables rebuilt every flush; best of the copying "
-                                                 "and the in-place producer form).  `value` is the HBM-resident loop, as the bench contract defines it; this is "
-                                                 "the PCIe-inclusive counterpart (details under pcie_inclusive.mix_streaming)"}
-            # ... and where the driver's parser keeps it: `config` travels into BENCH_rNN.json's parsed summary, the top-level object above does not
+                                                 "and the in-place producer form).  `value` is the HBM-resident loop, as the bench contract defines it"}
             out["config"]["value_host_to_host"] = best_cold
             out["config"]["host_to_host_over_value"] = best_cold / value
-            out["config"]["workload"] += ("; `value` = this HBM-resident loop (the bench contract), config.value_host_to_host = the same step from host "
-                                          "buffers to verdicts in host memory (SURVEY 8(d)'s wording: H2D and D2H inside the clock)")
-            out["pcie_inclusive"]["mix_streaming"] = dict(hm, rows_per_flush=n, flushes_in_flight=H2H_DEPTH,
-                                                          note="1 M ECDSA-65 + 1 M BIP-340 per step from host memory to verdicts in host memory "
-                                                               "(289 MB in per step); compare with `value` (inputs resident in HBM)")
-        # ---- the two 8-GPU configs of BASELINE.json, run here on ONE GPU as extra data points (not part of `value`):
-        # configs[3] gossip replay (raw wire messages in HBM -> per-message verdicts, double-SHA256 on the device) and
-        # configs[4] commit_tx storm (484-signature groups sharing a key) as one super-batch
-        if not args.skip_extra and world == 1 and extras:
-            extra = {}
-            g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=device)
-            ts = []
-            for it in range(2 + eng.info()["lanes"]):       # every lane allocates its workspaces on its first call of this size
-                torch.cuda.synchronize(); eng.synchronize()
-                t1 = time.perf_counter()
-                eng.sigcheck_gossip_device(g.n, g.d_msgs, g.d_off, g.d_ids, g.d_rowbase, g.rows, g.d_verdict)
-                eng.synchronize()
-                ts.append(time.perf_counter() - t1)
-            gm = int((g.d_verdict.cpu().numpy() != g.expect).sum())
-            extra["cfg4_gossip_replay"] = {"messages": g.n, "verifies": g.rows, "verifies_per_s": g.rows / min(ts[-2:]), "messages_per_s": g.n / min(ts[-2:]),
-                                           "mismatches": gm, "keyed_comb_teeth": eng.info()["last_keyed"], "distinct_keys": eng.info()["last_unique_keys"]}
-            del g
-            st = workload.make_commit_storm(eng, 10_000, device=device)
-            ts = []
-            for it in range(2 + eng.info()["lanes"] // 2):
-                torch.cuda.synchronize(); eng.synchronize()
-                t1 = time.perf_counter()
-                eng.verify_ecdsa_device(st["ecdsa"].dev[0], st["ecdsa"].dev[1], st["ecdsa"].dev[2], st["ecdsa"].d_ok)
-                eng.verify_schnorr_device(st["schnorr"].dev[0], st["schnorr"].dev[1], st["schnorr"].dev[2], st["schnorr"].d_ok)
-                eng.synchronize()
-                ts.append(time.perf_counter() - t1)
-            sm = int((st["ecdsa"].d_ok.cpu().numpy().astype(bool) != st["ecdsa"].expect).sum() + (st["schnorr"].d_ok.cpu().numpy().astype(bool) != st["schnorr"].expect).sum())
-            nv = st["ecdsa"].n + st["schnorr"].n
-            extra["cfg5_commit_storm_superbatch"] = {"channels": 10_000, "verifies": nv, "verifies_per_s": nv / min(ts[-2:]), "mismatches": sm,
-                                                     "keyed_comb_teeth": eng.info()["last_keyed"]}
-            # the same storm as STREAMING batches from host memory: commitments (484 signatures each) are appended to the pinned
-            # staging queue, every 256 commitments are flushed as one batch, up to eight flushes stay in flight while the next staging
-            # set is being filled (lamd_queue_*_batch / lamd_flush / lamd_wait) -- H2D, verification and D2H all inside the clock
-            streaming = {}
-            c5_depth = min(8, eng.info()["queue_sets"] - 1)
-            for cpf in (256, 1024):
-                per, grp = st["per"], cpf * st["per"]
-                ts, sbad = [], 0
-                for it in range(3):
-                    jobs = []
-                    for kind in ("ecdsa", "schnorr"):
-                        wl = st[kind]
-                        for o in range(0, wl.n, grp):
-                            jobs.append((kind, wl, o, min(wl.n, o + grp)))
-                    jobs.sort(key=lambda j: j[2])                     # interleave the two kinds as the channels would arrive
-                    pend, sbad = [], 0
-                    t1 = time.perf_counter()
-                    for kind, wl, a, b in jobs:
-                        if kind == "ecdsa":
-                            eng.queue_ecdsa_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
-                        else:
-                            eng.queue_schnorr_batch(wl.cols[0][a:b], wl.cols[1][a:b], wl.cols[2][a:b])
-                        eng.flush()
-                        pend.append((wl, a, b))
-                        if len(pend) == c5_depth:
-                            wl0, a0, b0 = pend.pop(0)
-                            sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
-                    while pend:
-                        wl0, a0, b0 = pend.pop(0)
-                        sbad += int((eng.wait() != wl0.expect[a0:b0]).sum())
-                    ts.append(time.perf_counter() - t1)
-                streaming["%d_commitments_per_flush" % cpf] = {"verifies_per_s": nv / min(ts[1:]), "signatures_per_flush": grp, "mismatches": sbad}
-                mism += sbad
-            extra["cfg5_commit_storm_streaming"] = dict(streaming, channels=10_000, verifies=nv, flushes_in_flight=c5_depth,
-                                                        note="inputs in host memory: staging memcpy + H2D + verification + D2H inside the clock")
-            # configs[4] as BASELINE.json words it -- "streaming batches" of ONE commitment (484 signatures) each, in arrival order, the channels
-            # recurring: a flush of <= 4096 rows is one launch of the latency kernel over the pinned staging rows (no copies); per-batch latency
-            # = flush -> verdicts collected.  200 channels; two passes let every key reach its table (first sight: ladder, second: table built).
-            try:
-                wl = st["ecdsa"]
-                per, nch = st["per"], 200
-
-                def commit_pass(depth):
-                    pend, bad, lat = [], 0, []
-                    t1 = time.perf_counter()
-                    for b in range(nch):
-                        a = b * per
-                        eng.queue_ecdsa_batch(wl.cols[0][a:a + per], wl.cols[1][a:a + per], wl.cols[2][a:a + per])
-                        eng.flush()
-                        pend.append((a, time.perf_counter()))
-                        if len(pend) == depth:
-                            a0, t0 = pend.pop(0)
-                            bad += int((eng.wait() != wl.expect[a0:a0 + per]).sum())
-                            lat.append(time.perf_counter() - t0)
-                    while pend:
-                        a0, t0 = pend.pop(0)
-                        bad += int((eng.wait() != wl.expect[a0:a0 + per]).sum())
-                        lat.append(time.perf_counter() - t0)
-                    raw = np.array(lat) * 1e3
-                    return nch / (time.perf_counter() - t1), np.sort(raw), bad, raw
-                pc = {"channels": nch, "signatures_per_batch": per}
-                cbad = commit_pass(1)[2] + commit_pass(1)[2]
-                for depth in (1, 4, 8):
-                    best = None
-                    for _ in range(3):
-                        r = commit_pass(depth)
-                        cbad += r[2]
-                        if best is None or r[0] > best[0]:
-                            best = r
-                    p50 = float(best[1][len(best[1]) // 2])
-                    slow = [int(i) for i in np.nonzero(best[3] > 2 * p50)[0]]
-                    pc["in_flight_%d" % depth] = {"batches_per_s": best[0], "signatures_per_s": best[0] * per, "p50_ms": p50, "p90_ms": float(best[1][int(len(best[1]) * 0.9)]),
-                                                  "p99_ms": float(best[1][int(len(best[1]) * 0.99)]), "max_ms": float(best[1][-1]),
-                                                  # which batches (in submission order = channel index at depth 1) took more than twice the median, and how long
-                                                  "slower_than_2x_p50": {"count": len(slow), "index_ms": [[i, round(float(best[3][i]), 3)] for i in slow[:12]]}}
-                pc["mismatches"] = cbad
-                pc["note"] = "one commitment_signed per flush from host memory, verdicts back in host memory; the Python loop around the three calls per batch is inside the clock"
-                extra["cfg5_commit_storm_one_commitment_per_flush"] = pc
-                mism += cbad
-            except Exception as e:
-                extra["cfg5_commit_storm_one_commitment_per_flush"] = {"error": repr(e)}
-            del st
-            # ---- N2: configs[3] through the batched gossip INGEST (lightning_amd/csrc/gossip_ingest.cpp: gossipd's receive path -- filters,
-            # ordering, store -- around the device calls), in the shape of the reference's own flood benchmark (tools/bench-gossipd.sh:152-176:
-            # stream a gossip set through a peer into a FRESH store, stop the clock when the store holds every record): 500 k
-            # channel_announcements from a peer, lightningd's txout replies, then 2 M channel_updates for those channels.  Host code + GPU inside the clock.
-            try:
-                import hashlib
-                from lightning_amd.gossipd import GossipIngest
-                isc = max(1, int(os.environ.get("LAMD_BENCH_INGEST_DIV", "1")))     # (divide the flood for a quick run)
-                g = workload.make_gossip(eng, 500_000 // isc, 2_000_000 // isc, n_nodes=15000, corrupt_frac=0.01, device=device)
-                chain = bytes(g.msgs[260:292])
-                peer = bytes(g.ids[g.n_cann])          # some node relays everything
-                cann_blob, cann_off = g.msgs[:int(g.off[g.n_cann]) + 1], g.off[:g.n_cann + 1].copy()
-                cupd_blob = g.msgs[int(g.off[g.n_cann]):]
-                cupd_off = (g.off[g.n_cann:] - g.off[g.n_cann]).copy()
-                spk = []
-                for i in range(g.n_cann):
-                    m = g.msgs[int(g.off[i]):int(g.off[i + 1])]
-                    k1, k2 = sorted([bytes(m[366:399]), bytes(m[399:432])])
-                    spk.append(b"\x00\x20" + hashlib.sha256(b"\x52\x21" + k1 + b"\x21" + k2 + b"\x52\xae").digest())
-                spk_blob = np.frombuffer(b"".join(spk) + b"\x00", dtype=np.uint8)
-                spk_off = (np.arange(g.n_cann + 1, dtype=np.uint64) * 34)
-                scids = np.arange(g.n_cann, dtype=np.uint64)
-                sats = np.full(g.n_cann, 1_000_000, dtype=np.uint64)
-                res = {}
-                for rep in range(2):
-                    with GossipIngest(eng, chain, peer, 700_000, 1 << 32, prune_interval=0xFFFFFFFF, collect_events=False) as ing:   # a fresh store every time
-                        t1 = time.perf_counter()
-                        ing.push_batch(peer, cann_blob, cann_off)
-                        ing.process()
-                        t2 = time.perf_counter()
-                        ing.txout_reply_batch(scids, sats, spk_blob, spk_off)
-                        t3 = time.perf_counter()
-                        QMAX = 500_000          # connectd's queue bound (lamd_gossipd_push_batch refuses more): the updates arrive as four queues
-                        for o in range(0, g.n_cupd, QMAX):
-                            e_ = min(g.n_cupd, o + QMAX)
-                            ing.push_batch(peer, cupd_blob[int(cupd_off[o]):int(cupd_off[e_]) + 1], (cupd_off[o:e_ + 1] - cupd_off[o]).copy())
-                            ing.process()
-                        t4 = time.perf_counter()
-                        st_ = ing.stats()
-                        store_bytes = ing.store_size()
-                    res = {"channel_announcements": g.n_cann, "channel_updates": g.n_cupd, "peer_read_all_sec": t4 - t1, "store_bytes": store_bytes,
-                           "shape": "tools/bench-gossipd.sh:152-176 (peer_read_all_sec: a gossip set streamed into a fresh store, clock stopped when the store holds every record)",
-                           "updates_applied_by_all_cores": int(st_["run_updates"]), "planning_stages": int(st_["sub_batches"]), "planning_stages_under_an_apply_pass": int(st_["overlapped_stages"]),
-                           "announcements_per_s": g.n_cann / (t2 - t1), "txout_replies_per_s": g.n_cann / (t3 - t2), "updates_per_s": g.n_cupd / (t4 - t3),
-                           "messages_per_s_overall": g.n / (t4 - t1), "verified_sigs": int(st_["verified_sigs"]), "device_batches": int(st_["batches"]),
-                           "channels_accepted": int(st_["channels"]), "store_records": int(st_["store_records"]), "late_verifies": int(st_["late_verifies"])}
-                exp_ok_cann = int((g.expect[:g.n_cann] == 0).sum())
-                ibad = 0 if (res["channels_accepted"] == exp_ok_cann and res["late_verifies"] == 0) else 1
-                res["mismatches"] = ibad
-                res["note"] = ("host buffers in -> store events out; accepted channels = announcements with four good signatures by construction; the "
-                               "sequential reference does one libsecp256k1 call per signature here (gossmap_manage.c:687,924)")
-                extra["gossip_ingest_flood"] = res
-                mism += ibad
-                del g
-            except Exception as e:   # the ingest leg must not take the headline down
-                extra["gossip_ingest_flood"] = {"error": repr(e)}
-            # onchaind's fee grind with the reference's own transaction (onchaind/test/run-grind_feerate.c):
-            # every feerate 0..250 000 at weight 663 for one signature/key, hashing + verification on the device
-            try:
-                kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json")))
-                H = bytes.fromhex
-                gsig = H(next(v for v in kat["der"] if v["name"] == "KAT-O")["expect_sig"])
-                gpre = H(next(v for v in kat["bip143"] if v["name"] == "KAT-O/fee=0")["preimage"])
-                gspk = H("002082e03c5a9cb79c82cd5a0572dc175290bc044609aabe9cc852d6192743604179")
-                gout = (700000).to_bytes(8, "little") + bytes([len(gspk)]) + gspk
-                gkey = H("038ffd2621647812011960152bfb79c5a2787dfe6c4f37e2222547de054432eb7f")
-                ts, res = [], None
-                for _ in range(6):
-                    t1 = time.perf_counter()
-                    res = eng.grind_htlc_tx_fee(gpre, gout, 700000, 663, 0, 250000, gsig, 1, True, gkey)
-                    ts.append(time.perf_counter() - t1)
-                gbad = 0 if res == (250000, 165750) else 1
-                extra["fee_grind_250k_feerates"] = {"feerates": 250001, "distinct_fees": 165751, "found": list(res) if res else None,
-                                                    "ms_per_grind": min(ts[1:]) * 1e3, "candidate_fees_per_s": 165751 / min(ts[1:]), "mismatches": gbad,
-                                                    "note": "one call = the whole loop of onchaind.c:388-438 (host buffers in, answer out)"}
-                mism += gbad
-            except FileNotFoundError:
-                pass
-            # public-key recovery over the ECDSA batch of the main step: both recovery ids, the signer's
-            # compressed key must come back from exactly one of them on every untouched row
-            d_keys = [torch.zeros((n, 33), dtype=torch.uint8, device=device) for _ in range(2)]
-            d_oks = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(2)]
-            d_rids = [torch.full((n,), r, dtype=torch.uint8, device=device) for r in (0, 1)]
-            torch.cuda.synchronize()
-            ts = []
-            for _ in range(4):
-                t1 = time.perf_counter()
-                for r in (0, 1):
-                    eng.ecdsa_recover_device(we.dev[0], we.dev[1], d_rids[r], d_keys[r], d_oks[r])
-                eng.synchronize()
-                ts.append(time.perf_counter() - t1)
-            xs = we.dev[2][:, 1:33]                                     # x of the signer (65-byte keys: 04 | x | y)
-            par = (we.dev[2][:, 64] & 1) + 2
-            hit = [((d_keys[r][:, 1:] == xs).all(dim=1) & (d_keys[r][:, 0] == par) & (d_oks[r] == 1)) for r in (0, 1)]
-            goodrows = torch.from_numpy(we.expect).to(device)
-            rbad = int((~(hit[0] ^ hit[1]) & goodrows).sum())
-            extra["ecdsa_recover"] = {"recoveries": 2 * n, "recoveries_per_s": 2 * n / min(ts[1:]), "mismatches": rbad,
-                                      "check": "signer's key from exactly one recovery id on every valid row"}
-            mism += rbad
-            # ---- key-reuse sweep (cold engine: every call builds its tables again): 1 M ECDSA-65 rows under K distinct keys.  K = 65 536 is
-            # configs[1]; K = 1 and 256 put every row on a 10-tooth comb; "all distinct" puts every row on the per-signature GLV ladder
-            # (k_ecmult) -- the floor of the engine.  Eight calls back to back over the lanes, every verdict checked by construction.
-            sweep = {}
-            del d_keys, d_oks, d_rids
-            for label, nk, grp in (("K=1", 1, 0), ("K=256", 256, 0), ("K=65536", 65536, 0), ("K=1000000_all_distinct", 1 << 40, 1)):
-                wk = workload.make_ecdsa(eng_cold, n, seed=workload.SEED_CFG2 ^ (0x5EED0000 + nk % 65521), nkeys=nk, publen=65, device=device, group=grp)
-                for _ in range(eng_cold.info()["lanes"]):          # every lane allocates its workspaces for this shape once
-                    eng_cold.verify_ecdsa_device(wk.dev[0], wk.dev[1], wk.dev[2], wk.d_ok)
-                torch.cuda.synchronize(); eng_cold.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(8):
-                    eng_cold.verify_ecdsa_device(wk.dev[0], wk.dev[1], wk.dev[2], wk.d_ok)
-                eng_cold.synchronize()
-                dts = time.perf_counter() - t1
-                inf = eng_cold.info()
-                kbad = int((wk.d_ok.cpu().numpy().astype(bool) != wk.expect).sum())
-                sweep[label] = {"verifies_per_s": 8 * n / dts, "ms_per_call": dts / 8 * 1e3, "mismatches": kbad, "distinct_keys_seen": int(inf["last_unique_keys"]),
-                                "rows_on_comb_tables": int(inf["last_hot_rows"]), "rows_on_ladder": int(inf["last_cold_rows"]), "comb_teeth": int(inf["last_keyed"])}
-                mism += kbad
-                del wk
-            extra["key_reuse_sweep"] = dict(sweep, rows=n, calls=8, note="1 M ECDSA-65 rows per call, key-table cache off, 8 calls pipelined over the lanes; "
-                                            "K = number of distinct public keys the rows draw from")
-            out["other_configs_1gpu"] = extra
-            mism += gm + sm
-        if world == 1 and extras and not args.skip_extra and not multi:
-            # the strong-scaling floor, measured on this one GPU (after every other GPU leg: the RCCL communicator it creates takes hardware queues)
-            try:
-                ss = strong_scaling_sweep(eng, device, tstream)
-                out["strong_scaling_1gpu"] = ss
-                out["config"]["predicted_speedup_8"] = {"cfg4_gossip_replay": ss["cfg4_gossip_replay"]["predicted_speedup_8"],
-                                                        "cfg5_commit_storm_streaming": ss["cfg5_commit_storm_streaming"]["predicted_speedup_8"]}
-                mism += ss["cfg4_gossip_replay"]["mismatches"] + ss["cfg5_commit_storm_streaming"]["mismatches"]
-            except Exception as e:   # must not take the headline down
-                out["strong_scaling_1gpu"] = {"error": repr(e)}
-        if args.cpu_sample > 0 and world == 1 and extras:   # the CPU baseline is a rank-0, N=1 leg
-            # C0 = the reference's real CPU path (libsecp256k1 through dlopen, called as bitcoin/signature.c:188,425 call it) if this
-            # machine has the library -- else "unavailable"; C1 = the restated C oracle, 1 thread and all cores; C2 = OpenSSL ECDSA_do_verify +
-            # libsecp256k1's range / low-S rules, 1 thread.  Monotonic clock around each whole batch, verifies/s and ns per verification (the shape
-            # of onchaind/test/run-grind_feerate.c:146-154).  Every leg's verdicts must equal the GPU's on the rows it was given.
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import orc  # test infrastructure: the checker / CPU baseline only
-            m = min(args.cpu_sample, n)
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            try:  # a cgroup CPU quota caps what those threads can really use
-                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-                if q != "max":
-                    cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
-            except Exception:
-                pass
-            ce_cols = [np.ascontiguousarray(x[:m]) for x in we.cols]
-            cs_cols = [np.ascontiguousarray(x[:m]) for x in ws.cols]
-
-            def leg(fn_e, fn_s, rows_e, rows_s):
-                """-> (dict, verdict mismatches against the GPU)"""
-                t1 = time.perf_counter()
-                ve = fn_e([c[:rows_e] for c in ce_cols]) if fn_e and rows_e else None
-                t2 = time.perf_counter()
-                vs = fn_s([c[:rows_s] for c in cs_cols]) if fn_s and rows_s else None
-                t3 = time.perf_counter()
-                bad = 0
-                d = {}
-                if ve is not None:
-                    bad += int((ve.astype(bool) != got_e[:rows_e]).sum())
-                    d.update(ecdsa_rows=rows_e, ecdsa_verifies_per_s=rows_e / (t2 - t1), ecdsa_ns_per_verify=(t2 - t1) / rows_e * 1e9)
-                if vs is not None:
-                    bad += int((vs.astype(bool) != got_s[:rows_s]).sum())
-                    d.update(schnorr_rows=rows_s, schnorr_verifies_per_s=rows_s / (t3 - t2), schnorr_ns_per_verify=(t3 - t2) / rows_s * 1e9)
-                rows = (rows_e if ve is not None else 0) + (rows_s if vs is not None else 0)
-                secs = (t2 - t1 if ve is not None else 0) + (t3 - t2 if vs is not None else 0)
-                d.update(value=rows / secs if secs else None, seconds=secs, gpu_vs_cpu_verdict_mismatches=bad)
-                return d, bad
-            orc.ecdsa_verify_batch(ce_cols[0][:64], ce_cols[1][:64], ce_cols[2][:64], 65, cores)  # table init outside the timed part
-            legs = {}
-            one = max(1, min(m, 20_000))
-            legs["C1_oracle_1_thread"], b1 = leg(lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, 1), lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], 1), one, one)
-            legs["C1_oracle_all_cores"], b2 = leg(lambda c: orc.ecdsa_verify_batch(c[0], c[1], c[2], 65, cores), lambda c: orc.schnorr_verify_batch(c[0], c[1], c[2], cores), m, m)
-            legs["C1_oracle_1_thread"]["threads"], legs["C1_oracle_all_cores"]["threads"] = 1, cores
-            ossl_rows = max(1, min(m, 10_000))
-            legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"], b3 = leg(lambda c: orc.ossl_ecdsa_verify_rules_batch(c[0], c[1], c[2], 65), None, ossl_rows, 0)
-            legs["C2_openssl_ecdsa_do_verify_plus_rules_1_thread"]["threads"] = 1
-            secp = orc.libsecp_available()
-            if secp:
-                legs["C0_libsecp256k1_1_thread"], b0 = leg(lambda c: orc.libsecp_ecdsa_verify_batch(c[0], c[1], c[2], 65),
-                                                           lambda c: orc.libsecp_schnorr_verify_batch(c[0], c[1], c[2]), min(m, 100_000), min(m, 100_000))
-                legs["C0_libsecp256k1_1_thread"].update(threads=1, library=secp)
-            else:
-                legs["C0_libsecp256k1_1_thread"], b0 = "unavailable: no libsecp256k1.so can be dlopen()ed on this node (the reference's copy is an empty submodule)", 0
-            cm = b0 + b1 + b2 + b3
-            ac = legs["C1_oracle_all_cores"]
-            ref = legs["C0_libsecp256k1_1_thread"] if secp else None
-            out["cpu_baseline"] = {"value": ref["value"] if ref else ac["value"], "unit": "verifies/s", "cores": 1 if ref else cores, "kind": "reference" if ref else "port",
-                                   "sample": ("libsecp256k1 (%s) through dlopen, called as bitcoin/signature.c:188,425 do, 1 thread, first %d ECDSA + %d Schnorr rows" % (secp, ref["ecdsa_rows"], ref.get("schnorr_rows", 0))) if ref else
-                                             ("first %d ECDSA + first %d Schnorr rows of rank 0's batch, OpenMP over all %d host cores; restated C oracle "
-                                              "(oracle/secp256k1_oracle.c), NOT libsecp256k1 (absent from the reference tree and from this node)" % (m, m, cores)),
-                                   "ecdsa_verifies_per_s": (ref or ac)["ecdsa_verifies_per_s"], "schnorr_verifies_per_s": (ref or ac).get("schnorr_verifies_per_s"),
-                                   "note": None if ref else "a restated oracle (4x64-bit limbs, wNAF, no GLV, no endomorphism, generic C): 2-4x slower per verification than "
-                                                             "libsecp256k1 (SURVEY 6: ~25-50 us against this port's ~100 us) -- every GPU/CPU ratio built on it is flattered by that factor",
-                                   "host_cores": cores, "libsecp256k1_found": secp, "legs": legs,
-                                   "legs_note": "BASELINE.md 3: C0 the reference's library (if present), C1 this repo's restated oracle, C2 OpenSSL's generic secp256k1 + "
-                                                "libsecp256k1's acceptance rules; monotonic clock around each batch; every leg's verdicts compared with the GPU's",
-                                   "gpu_vs_cpu_verdict_mismatches": cm}
-            out["parity"]["oracle_rows_checked"] = 2 * m
+            out["pcie_inclusive"] = {"mix_streaming": hm}
+        # ---- the strong-scaling floor of configs[3] / configs[4], measured on this one GPU
+        if world == 1 and default_legs and not multi and not args.no_scaling:
+            with clock("strong_scaling_1gpu"):
+                try:
+                    ss = strong_scaling_sweep(plat, eng_cold, tstream, args.div)
+                    out["strong_scaling_1gpu"] = ss
+                    out["config"]["predicted_speedup_8"] = {"cfg4": ss["cfg4_gossip_replay"]["predicted_speedup_8"], "cfg5": ss["cfg5_commit_storm_streaming"]["predicted_speedup_8"]}
+                    mism += ss["cfg4_gossip_replay"]["mismatches"] + ss["cfg5_commit_storm_streaming"]["mismatches"]
+                except Exception as e:   # must not take the headline down
+                    out["strong_scaling_1gpu"] = {"error": repr(e)}
+        # ---- everything else a single GPU can tell (bench_details.json only)
+        if world == 1 and args.extras and default_legs and not multi:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_extras
+            with clock("extras"):
+                mism += bench_extras.run(plat=plat, eng=eng_warm, eng_cold=eng_cold, we=we, ws=ws, n=n, args=args, out=out, timed=timed, clock=clock,
+                                         local_rank=local_rank, root=ROOT)
+        out["parity"]["mismatches"] = mism
+        if args.cpu_sample > 0 and world == 1 and default_legs and not plat.is_stub:   # the CPU baseline is a rank-0, N=1 leg
+            with clock("cpu_baseline"):
+                cb, cm, rows = cpu_baseline(we, ws, got_e, got_s, args.cpu_sample, n)
+            out["cpu_baseline"] = cb
+            out["parity"]["oracle_rows_checked"] = rows
             out["parity"]["oracle_mismatches"] = cm
             mism += cm
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    eng.close()
-    if eng_cold is not eng:
-        eng_cold.close()
+            out["parity"]["mismatches"] = mism
+        else:
+            out["cpu_baseline"] = None
+        out["phase_seconds"] = dict(clock.t, total=time.perf_counter() - t_start)
+        write_outputs(out, json_fd, args.details)
+        if eng_warm is not None:
+            eng_warm.close()
+    eng_cold.close()
     if multi:
+        dist.barrier()
         dist.destroy_process_group()
     if not args.no_parity and rank == 0 and mism:
         raise SystemExit("PARITY FAILURE: %d mismatching verdicts" % mism)

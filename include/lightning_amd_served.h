@@ -28,16 +28,20 @@
  *   reply    = struct lamd_srv_rep over the socket; output sections follow the input sections in the shared block
  * Both structs are plain little-endian host structs: client and server are processes of one machine.
  *
- * Trust: the socket is mode 0600 -- clients are the daemons of one lightningd, running as the server's user.  The server checks every length and offset
- * of a request before it touches the block, but the block stays writable by its client while the request runs: a hostile client of the same user can
- * at worst get wrong answers for ITSELF or crash the server it shares with its siblings; it cannot read another client's rows (one block per connection).
+ * Trust: the socket path is LAMD_SERVED_SOCKET, else $XDG_RUNTIME_DIR/lamd_served.sock -- there is NO default under /tmp: whoever binds a
+ * world-writable path first would answer every check with "good".  The server binds under umask 0177 (mode 0600 from the start), refuses to replace a
+ * path it does not own, and drops connections whose SO_PEERCRED uid is not its own (LAMD_SERVED_UID names another); the client checks the same of
+ * the server and of the socket file's owner before it sends a row (lamd_init fails with LAMD_ERR_NO_DEVICE otherwise).  The server validates every
+ * length of a request and works on ITS OWN COPY of every offset array (the block stays writable by its client while the request runs): a hostile
+ * client of the same user can get wrong answers for itself, not crash the server or read another client's rows (one block per connection); an
+ * engine error inside a merged call is retried request by request, so that only the offending client sees it.
  */
 #ifndef LIGHTNING_AMD_SERVED_H
 #define LIGHTNING_AMD_SERVED_H
 #include <stdint.h>
 
 #define LAMD_SRV_MAGIC 0x4C414D44u /* "LAMD" */
-#define LAMD_SRV_DEFAULT_SOCKET "/tmp/lamd_served.sock"
+#define LAMD_SRV_SOCKET_NAME "lamd_served.sock" /* under $XDG_RUNTIME_DIR when LAMD_SERVED_SOCKET is unset */
 #define LAMD_SRV_MAX_SECTIONS 20
 
 enum lamd_srv_op {

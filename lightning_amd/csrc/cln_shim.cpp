@@ -183,6 +183,9 @@ static bool der_int(u8 out32[32], const u8 **p, const u8 *end) {
   return true;
 }
 static bool sighash_type_valid(int t) { return t == SIGHASH_ALL || t == (SIGHASH_SINGLE | SIGHASH_ANYONECANPAY); }
+// the engine's sighash gate sees one byte: an int the reference's gate rejects (bitcoin/signature.c:206-211; 0x101 would truncate to SIGHASH_ALL)
+// travels as 0, which no gate accepts -- the row is bad, in the reference's order
+static u8 sighash_byte(int t) { return sighash_type_valid(t) ? (u8)t : 0; }
 
 extern "C" bool signature_from_der(const u8 *der, size_t len, struct bitcoin_signature *sig) {
   if (len < 1) return false;
@@ -349,14 +352,14 @@ extern "C" const char *check_commit_sigs(const tal_t *ctx, uint64_t local_index,
     t.script = ws; t.script_len = wl;
     if (i) {
       memcpy(&sigs64[64 * (i - 1)], htlc_sigs[i - 1].s.data, 64);
-      types[i - 1] = (u8)htlc_sigs[i - 1].sighash_type;
+      types[i - 1] = sighash_byte(htlc_sigs[i - 1].sighash_type);
     }
   }
   u8 fund33[PUBKEY_CMPR_LEN], htlc33[PUBKEY_CMPR_LEN];
   pubkey_to_der(fund33, remote_funding);
   pubkey_to_der(htlc33, remote_htlckey);
   int64_t first_bad = 0;
-  const int rc = lamd_check_commitment_signed(g_ctx, &tm[0], fund33, commit_sig->s.data, (u8)commit_sig->sighash_type, n_htlc, n_htlc ? &tm[1] : nullptr, htlc33,
+  const int rc = lamd_check_commitment_signed(g_ctx, &tm[0], fund33, commit_sig->s.data, sighash_byte(commit_sig->sighash_type), n_htlc, n_htlc ? &tm[1] : nullptr, htlc33,
                                               sigs64.data(), types.data(), &first_bad, nullptr);
   if (rc != LAMD_OK) { g_err = lamd_last_error(g_ctx); return dup(ctx, "engine error: " + g_err); }
   if (first_bad == 0)  // :2171-2193

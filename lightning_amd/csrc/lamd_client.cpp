@@ -107,8 +107,9 @@ int lamd_init(lamd_ctx **out, int /*device: the server chose it*/) {
   if (!out) return LAMD_ERR_ARG;
   lamd_ctx *c = new lamd_ctx;
   *out = c;  // returned on failure too, so that lamd_last_error() can say why (as the engine does)
-  const char *path = getenv("LAMD_SERVED_SOCKET");
-  if (!path || !*path) path = LAMD_SRV_DEFAULT_SOCKET;
+  std::string sock_path;
+  if (!default_socket(&sock_path, &c->err)) return LAMD_ERR_NO_DEVICE;
+  const char *path = sock_path.c_str();
   struct sockaddr_un sa;
   memset(&sa, 0, sizeof sa);
   sa.sun_family = AF_UNIX;
@@ -118,6 +119,18 @@ int lamd_init(lamd_ctx **out, int /*device: the server chose it*/) {
   if (c->fd < 0 || connect(c->fd, (struct sockaddr *)&sa, sizeof sa) != 0) {
     c->err = std::string("no lamd_served at ") + path + " (" + strerror(errno) + "): there is no verification without the service";
     if (c->fd >= 0) close(c->fd);
+    c->fd = -1;
+    return LAMD_ERR_NO_DEVICE;
+  }
+  // the process that answers must be the service of THIS user (or of LAMD_SERVED_UID), and so must the owner of the socket file: anybody can
+  // bind a path in a directory they can write, and the client verifies nothing itself
+  uid_t peer = (uid_t)-1;
+  struct stat sb;
+  const uid_t want = expected_peer_uid();
+  if (!peer_uid_is(c->fd, want, &peer) || stat(path, &sb) != 0 || sb.st_uid != want) {
+    c->err = std::string("the server at ") + path + " does not run under uid " + std::to_string((unsigned long)want) + " (peer uid " +
+             (peer == (uid_t)-1 ? std::string("unknown") : std::to_string((unsigned long)peer)) + "): refusing to trust its verdicts";
+    close(c->fd);
     c->fd = -1;
     return LAMD_ERR_NO_DEVICE;
   }

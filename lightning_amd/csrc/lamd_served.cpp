@@ -74,6 +74,9 @@ struct job {
   size_t out_off = 0;
   lamd_srv_rep rep;
   bool done = false;
+  // the server's OWN copies of a request's offset arrays, taken once and validated: the shared block stays writable by its client while the
+  // request runs, and an offset re-read after the check could point anywhere
+  std::vector<uint64_t> o_in, o_out, o_sc;
 };
 
 engine_api E;
@@ -151,10 +154,17 @@ void run_merged(std::vector<job *> &js, bool schnorr) {
   g_stats.merged_requests += js.size();
   g_stats.merged_rows += total;
   if (js.size() > g_stats.largest_merge_requests) g_stats.largest_merge_requests = js.size();
+  if (rc < 0) {  // one request's rows made the merged call fail: every request again by itself, so that only the offender sees the error
+    for (job *j : js) {
+      std::vector<job *> one(1, j);
+      run_merged(one, schnorr);
+    }
+    return;
+  }
   o = 0;
   for (job *j : js) {
     const size_t n = (size_t)j->req.n;
-    if (rc == LAMD_OK) memcpy(outp(j, 0), &ok[o], n);
+    memcpy(outp(j, 0), &ok[o], n);
     engine_error(j, rc);
     o += n;
   }
@@ -170,9 +180,12 @@ bool tx_valid(job *j) {
   if (commit ? !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, 64 * n, 33, 33}, 16 + n)
              : !shape(j, {4 * n, 4 * n, ANY, 8 * (n + 1), 4 * n, 8 * n, ANY, 8 * (n + 1), 4 * n, ANY, 8 * (n + 1), n, n, 64 * n, kl * n}, n))
     return false;
-  const uint64_t *in_off = (const uint64_t *)sec(j, 3), *out_off = (const uint64_t *)sec(j, 7), *sc_off = (const uint64_t *)sec(j, 10);
+  j->o_in.assign((const uint64_t *)sec(j, 3), (const uint64_t *)sec(j, 3) + n + 1);
+  j->o_out.assign((const uint64_t *)sec(j, 7), (const uint64_t *)sec(j, 7) + n + 1);
+  j->o_sc.assign((const uint64_t *)sec(j, 10), (const uint64_t *)sec(j, 10) + n + 1);
+  const uint64_t *in_off = j->o_in.data(), *out_off = j->o_out.data(), *sc_off = j->o_sc.data();
   for (size_t i = 0; i < n; i++)
-    if (in_off[i + 1] < in_off[i] || 40 * in_off[i + 1] > seclen(j, 2) || out_off[i + 1] < out_off[i] || out_off[i + 1] > seclen(j, 6) ||
+    if (in_off[i + 1] < in_off[i] || in_off[i + 1] > seclen(j, 2) / 40 || out_off[i + 1] < out_off[i] || out_off[i + 1] > seclen(j, 6) ||
         sc_off[i + 1] < sc_off[i] || sc_off[i + 1] > seclen(j, 9)) {
       fail(j, LAMD_ERR_ARG, "template offsets outside their arrays");
       return false;
@@ -198,7 +211,7 @@ void run_tx_merged(std::vector<job *> &js) {
     const bool commit = j->req.op == LAMD_SRV_OP_COMMITMENT;
     memcpy(&ver[o], sec(j, 0), 4 * n); memcpy(&lock[o], sec(j, 1), 4 * n); memcpy(&inum[o], sec(j, 4), 4 * n);
     memcpy(&amt[o], sec(j, 5), 8 * n); memcpy(&nout[o], sec(j, 8), 4 * n);
-    const uint64_t *io = (const uint64_t *)sec(j, 3), *oo = (const uint64_t *)sec(j, 7), *so = (const uint64_t *)sec(j, 10);
+    const uint64_t *io = j->o_in.data(), *oo = j->o_out.data(), *so = j->o_sc.data();   // tx_valid()'s copies
     const size_t ib = ins.size() / 40, ob = outs.size(), sb = scs.size();
     for (size_t i = 0; i < n; i++) { in_off[o + i] = ib + io[i]; out_off[o + i] = ob + oo[i]; sc_off[o + i] = sb + so[i]; }
     ins.insert(ins.end(), sec(j, 2), sec(j, 2) + 40 * io[n]);
@@ -225,6 +238,10 @@ void run_tx_merged(std::vector<job *> &js) {
   g_stats.merged_requests += js.size();
   g_stats.merged_rows += total;
   if (js.size() > g_stats.largest_merge_requests) g_stats.largest_merge_requests = js.size();
+  if (rc < 0) {  // as in run_merged: only the offending client may see the error
+    for (job *j : js) run_one(j);
+    return;
+  }
   o = 0;
   for (job *j : js) {
     const size_t n = (size_t)j->req.n;
@@ -251,14 +268,16 @@ void run_one(job *j) {
   switch (r.op) {
     case LAMD_SRV_OP_PUBKEY_PARSE: {
       const size_t kl = (size_t)r.scalar[0];
-      if ((kl != 33 && kl != 65) || !shape(j, {kl * n}, align16(64 * n) + n)) return;
+      if (kl != 33 && kl != 65) { fail(j, LAMD_ERR_ARG, "publen must be 33 or 65"); return; }
+      if (!shape(j, {kl * n}, align16(64 * n) + n)) return;
       engine_error(j, E.pubkey_parse(g_ctx, n, sec(j, 0), kl, kl, outp(j, 0), outp(j, align16(64 * n))));
       return;
     }
     case LAMD_SRV_OP_GOSSIP: {
       const bool ids = r.scalar[0] != 0;
       if (!shape(j, {ANY, 8 * (n + 1), ids ? 33 * n : 0}, n)) return;
-      const uint64_t *off = (const uint64_t *)sec(j, 1);
+      j->o_in.assign((const uint64_t *)sec(j, 1), (const uint64_t *)sec(j, 1) + n + 1);
+      const uint64_t *off = j->o_in.data();
       for (size_t i = 0; i < n; i++)
         if (off[i + 1] < off[i] || off[i + 1] > seclen(j, 0)) { fail(j, LAMD_ERR_ARG, "message offsets outside the blob"); return; }
       engine_error(j, E.gossip(g_ctx, n, sec(j, 0), off, ids ? sec(j, 2) : nullptr, (int8_t *)outp(j, 0)));
@@ -270,7 +289,7 @@ void run_one(job *j) {
       const bool commit = r.op == LAMD_SRV_OP_COMMITMENT;
       const size_t kl = commit ? 33 : (size_t)r.scalar[0];
       if (!tx_valid(j)) return;
-      const uint64_t *in_off = (const uint64_t *)sec(j, 3), *out_off = (const uint64_t *)sec(j, 7), *sc_off = (const uint64_t *)sec(j, 10);
+      const uint64_t *in_off = j->o_in.data(), *out_off = j->o_out.data(), *sc_off = j->o_sc.data();
       if (!commit) {
         engine_error(j, E.txsig_tx(g_ctx, n, (const uint32_t *)sec(j, 0), (const uint32_t *)sec(j, 1), sec(j, 2), in_off, (const uint32_t *)sec(j, 4),
                                    (const uint64_t *)sec(j, 5), sec(j, 6), out_off, (const uint32_t *)sec(j, 8), sec(j, 9), sc_off, sec(j, 11), sec(j, 12),
@@ -298,7 +317,8 @@ void run_one(job *j) {
     case LAMD_SRV_OP_BOLT12_MERKLE: {
       const bool check = r.op == LAMD_SRV_OP_BOLT12_CHECK;
       if (check ? !shape(j, {ANY, 8 * (n + 1), ANY, ANY, 33 * n, 64 * n}, n) : !shape(j, {ANY, 8 * (n + 1), ANY, ANY}, 2 * align16(32 * n) + n)) return;
-      const uint64_t *off = (const uint64_t *)sec(j, 1);
+      j->o_in.assign((const uint64_t *)sec(j, 1), (const uint64_t *)sec(j, 1) + n + 1);
+      const uint64_t *off = j->o_in.data();
       for (size_t i = 0; i < n; i++)
         if (off[i + 1] < off[i] || off[i + 1] > seclen(j, 0)) { fail(j, LAMD_ERR_ARG, "stream offsets outside the blob"); return; }
       if (!seclen(j, 2) || !seclen(j, 3) || sec(j, 2)[seclen(j, 2) - 1] != 0 || sec(j, 3)[seclen(j, 3) - 1] != 0) { fail(j, LAMD_ERR_ARG, "names must be NUL-terminated"); return; }
@@ -415,6 +435,7 @@ void serve(int fd) {
     if (!recv_with_fd(fd, &j.req, sizeof j.req, &newfd)) break;
     memset(&j.rep, 0, sizeof j.rep);
     j.rep.magic = LAMD_SRV_MAGIC;
+    j.rep.rc = LAMD_ERR_STATE;  // a path that forgets to answer reads as a failure, never as "verified"
     j.c = &c;
     if (j.req.magic != LAMD_SRV_MAGIC) { if (newfd >= 0) close(newfd); break; }
     if (j.req.op == LAMD_SRV_OP_SHM) {
@@ -465,7 +486,8 @@ void on_term(int) {
 }  // namespace
 
 int main(int argc, char **argv) {
-  std::string sock = getenv("LAMD_SERVED_SOCKET") ? getenv("LAMD_SERVED_SOCKET") : LAMD_SRV_DEFAULT_SOCKET, engine;
+  std::string sock, engine, why;
+  default_socket(&sock, &why);
   int device = 0;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -480,6 +502,7 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
+  if (sock.empty()) { fprintf(stderr, "lamd_served: %s\n", why.c_str()); return 2; }
   if (engine.empty()) {  // liblightning_amd.so next to this executable
     char self[4096];
     const ssize_t k = readlink("/proc/self/exe", self, sizeof self - 1);
@@ -509,13 +532,22 @@ int main(int argc, char **argv) {
   sa.sun_family = AF_UNIX;
   if (sock.size() >= sizeof sa.sun_path) { fprintf(stderr, "lamd_served: socket path too long\n"); return 1; }
   strcpy(sa.sun_path, sock.c_str());
-  unlink(sock.c_str());
-  if (g_listen < 0 || bind(g_listen, (struct sockaddr *)&sa, sizeof sa) != 0 || listen(g_listen, 128) != 0) {
+  struct stat old;
+  if (lstat(sock.c_str(), &old) == 0) {  // a stale socket of OURS is replaced; anything else at the path is somebody else's business
+    if (!S_ISSOCK(old.st_mode) || old.st_uid != geteuid() || unlink(sock.c_str()) != 0) {
+      fprintf(stderr, "lamd_served: %s exists and is not a socket of uid %lu: not replacing it\n", sock.c_str(), (unsigned long)geteuid());
+      E.shutdown(g_ctx);
+      return 1;
+    }
+  }
+  const mode_t um = umask(0177);  // the socket is born 0600: no window in which another user can connect (the daemons of one lightningd run under one user)
+  const bool bound = g_listen >= 0 && bind(g_listen, (struct sockaddr *)&sa, sizeof sa) == 0 && listen(g_listen, 128) == 0;
+  umask(um);
+  if (!bound) {
     perror("lamd_served: bind/listen");
     E.shutdown(g_ctx);
     return 1;
   }
-  chmod(sock.c_str(), 0600);  // the daemons of one lightningd run under one user
   signal(SIGTERM, on_term);
   signal(SIGINT, on_term);
   signal(SIGPIPE, SIG_IGN);
@@ -528,6 +560,12 @@ int main(int argc, char **argv) {
     if (fd < 0) {
       if (errno == EINTR) continue;
       break;
+    }
+    uid_t peer = (uid_t)-1;
+    if (!peer_uid_is(fd, expected_peer_uid(), &peer)) {  // not one of this user's daemons
+      fprintf(stderr, "lamd_served: connection from uid %ld refused\n", peer == (uid_t)-1 ? -1L : (long)peer);
+      close(fd);
+      continue;
     }
     readers.emplace_back(serve, fd);
   }

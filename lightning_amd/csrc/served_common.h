@@ -4,16 +4,44 @@
 #include <errno.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
+
+#include <string>
 
 #include "../../include/lightning_amd_served.h"
 
 namespace lamd_srv {
 
 inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// Where the service listens when no --socket says otherwise: LAMD_SERVED_SOCKET, else $XDG_RUNTIME_DIR/lamd_served.sock (a directory only its
+// user can write).  Never a world-writable directory: whoever binds the path first answers every commitment_signed and gossip check with "good".
+inline bool default_socket(std::string *path, std::string *why) {
+  const char *e = getenv("LAMD_SERVED_SOCKET");
+  if (e && *e) { *path = e; return true; }
+  const char *x = getenv("XDG_RUNTIME_DIR");
+  if (x && *x == '/') { *path = std::string(x) + "/" LAMD_SRV_SOCKET_NAME; return true; }
+  *why = "no socket path: set LAMD_SERVED_SOCKET (or XDG_RUNTIME_DIR) -- there is no default in a world-writable directory";
+  return false;
+}
+// the process at the other end of a connected unix socket runs under `uid` (SO_PEERCRED: the kernel's word, taken at connect() / listen())
+inline bool peer_uid_is(int fd, uid_t uid, uid_t *seen) {
+  struct ucred cr;
+  socklen_t len = sizeof cr;
+  if (getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &len) != 0 || len != sizeof cr) return false;
+  if (seen) *seen = cr.uid;
+  return cr.uid == uid;
+}
+// the uid a client expects its server under (and a server its clients): the caller's own, unless LAMD_SERVED_UID names another (a service account)
+inline uid_t expected_peer_uid() {
+  const char *e = getenv("LAMD_SERVED_UID");
+  return e && *e ? (uid_t)strtoul(e, nullptr, 10) : geteuid();
+}
 
 // offsets of the request's input sections; returns the offset at which the output sections start (= total input bytes, aligned),
 // or (size_t)-1 when the header is not sane

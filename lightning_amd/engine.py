@@ -163,28 +163,8 @@ class Engine:
         """ONE commitment_signed (channeld/channeld.c:2171-2232) through lamd_check_commitment_signed.  commit_tx / htlc_txs[i]: dicts {version,
         locktime, inputs: [(txid32, vout, sequence)], outputs: [(amount, spk)], input_num, amount, script}.  Returns (first_bad, ok_rows):
         first_bad = -1 all good, 0 the commitment signature, 1 + i htlc_sigs[i] -- the first failure in the reference's order."""
-        def varint(v):
-            return bytes([v]) if v < 0xfd else (b"\xfd" + v.to_bytes(2, "little") if v <= 0xffff else b"\xfe" + v.to_bytes(4, "little"))
-        keep = []
-
-        def tmpl(t):
-            ins = b"".join(bytes(i[0]) + int(i[1]).to_bytes(4, "little") + int(i[2]).to_bytes(4, "little") for i in t["inputs"])
-            outs = b"".join(int(a).to_bytes(8, "little") + varint(len(spk)) + bytes(spk) for a, spk in t["outputs"])
-            bufs = [ctypes.create_string_buffer(x, len(x) + 1) for x in (ins, outs, bytes(t["script"]))]
-            keep.extend(bufs)
-            return _ffi.LamdTxTemplate(t["version"], t["locktime"], ctypes.addressof(bufs[0]), len(t["inputs"]), t.get("input_num", 0), t["amount"],
-                                       ctypes.addressof(bufs[1]), len(outs), len(t["outputs"]), ctypes.addressof(bufs[2]), len(t["script"]))
-        ct = tmpl(commit_tx)
-        n = len(htlc_txs)
-        arr = (_ffi.LamdTxTemplate * max(1, n))(*[tmpl(t) for t in htlc_txs])
-        sigs = np.ascontiguousarray(np.frombuffer(b"".join(bytes(x) for x in htlc_sigs64) + b"\x00", dtype=np.uint8))
-        types = np.array(list(htlc_sighash_types) + [0], dtype=np.uint8)
-        first_bad = ctypes.c_int64(0)
-        ok = np.zeros(1 + n, dtype=np.uint8)
-        fk, hk, cs = bytes(remote_funding33), bytes(remote_htlckey33), bytes(commit_sig64)
-        self._chk(self._lib.lamd_check_commitment_signed(self._ctx, ctypes.addressof(ct), fk, cs, commit_sighash_type, n, ctypes.addressof(arr), hk,
-                                                         sigs.ctypes.data, types.ctypes.data, ctypes.byref(first_bad), ok.ctypes.data))
-        return int(first_bad.value), ok.astype(bool)
+        return self.commitment_call(commit_tx, remote_funding33, commit_sig64, commit_sighash_type, htlc_txs, remote_htlckey33, htlc_sigs64,
+                                    htlc_sighash_types)()
 
     @staticmethod
     def _streams(streams):

@@ -56,7 +56,9 @@ def gossip_weights(msgs, off):
     """per-message shard weights of a packed gossip batch (type 256 = channel_announcement)"""
     off = np.asarray(off, dtype=np.int64)
     m = np.asarray(msgs)
-    is_cann = (m[off[:-1]] == 1) & (m[off[:-1] + 1] == 0)
+    has_type = (off[1:] - off[:-1]) >= 2          # a message shorter than its type field weighs 1 (as lamd_multi_sigcheck_gossip_batch has it)
+    at = np.where(has_type, off[:-1], 0)
+    is_cann = has_type & (m[at] == 1) & (m[np.minimum(at + 1, len(m) - 1)] == 0) if len(m) else np.zeros(len(off) - 1, dtype=bool)
     return np.where(is_cann, GOSSIP_WEIGHT_CANN, GOSSIP_WEIGHT_OTHER).astype(np.int64)
 
 

@@ -199,3 +199,10 @@ def test_mirror_check_commit_sigs_prints_the_reference_warnings(kat, orc):
     # the count check sits between the two (:2203-2206)
     assert call(bsig(csig), good, n_sigs=4) == b"Expected 5 htlc sigs, not 4"
     assert call(bsig(_flip(csig)), good, n_sigs=4).startswith(b"Bad commit_sig signature 42 ")
+    # a sighash type that only LOOKS like SIGHASH_ALL in its low byte is the reference gate's business (bitcoin/signature.c:206-211 compares the int):
+    # 0x101 on HTLC 2 makes that row the first bad one, 0x101 on the commitment signature the commitment's (the mirror used to truncate to u8)
+    err = call(bsig(csig), good[:2] + [bsig(hsigs[2], 0x101)] + good[3:])
+    assert err is not None and err.startswith(b"Bad commit_sig signature " + _der_hex(hsigs[2])) and b" for htlc " in err, err
+    err = call(bsig(csig, 0x101), good)
+    assert err is not None and err.startswith(b"Bad commit_sig signature 42 "), err
+    assert call(bsig(csig), good) is None

@@ -287,6 +287,66 @@ def test_without_a_server_everything_fails_closed(stub, tmp_path):
     assert r.returncode == 1 and "lamd_init" in r.stderr
 
 
+def test_the_client_trusts_only_a_server_of_its_own_user_and_there_is_no_default_under_tmp(stub, tmp_path):
+    """whoever binds a world-writable path first would answer every check with "good".  No default path outside LAMD_SERVED_SOCKET /
+    XDG_RUNTIME_DIR; the client checks SO_PEERCRED and the socket file's owner; the server binds 0600 from the start, does not replace a path it does
+    not own, and a raw PUBKEY_PARSE with a bad key length fails instead of answering rc 0 with stale bytes."""
+    so, d = stub
+    from lightning_amd import _build
+    served = _build.build_served()[0]
+    L = _client()
+    # no socket path at all: neither side invents one
+    env = {k: v for k, v in os.environ.items() if k not in ("LAMD_SERVED_SOCKET", "XDG_RUNTIME_DIR")}
+    r = subprocess.run([served, "--engine", so], capture_output=True, text=True, timeout=30, env=env)
+    assert r.returncode == 2 and "LAMD_SERVED_SOCKET" in r.stderr
+    code = ("import ctypes,sys; L=ctypes.CDLL(sys.argv[1]); L.lamd_last_error.restype=ctypes.c_char_p; c=ctypes.c_void_p(); "
+            "rc=L.lamd_init(ctypes.byref(c),0); print(rc, L.lamd_last_error(c).decode())")
+    r = subprocess.run([sys.executable, "-c", code, _build.build_served()[1]], capture_output=True, text=True, timeout=30, env=env)
+    assert r.stdout.startswith("-1 ") and "LAMD_SERVED_SOCKET" in r.stdout
+    # XDG_RUNTIME_DIR is the default's home
+    sock = str(tmp_path / "lamd_served.sock")
+    env2 = dict(env, XDG_RUNTIME_DIR=str(tmp_path))
+    p = subprocess.Popen([served, "--engine", so], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env2)
+    try:
+        assert "ready on " + sock in p.stdout.readline()
+        assert (os.stat(sock).st_mode & 0o777) == 0o600
+        r = subprocess.run([sys.executable, "-c", code, _build.build_served()[1]], capture_output=True, text=True, timeout=30, env=env2)
+        assert r.stdout.startswith("0 "), r.stdout + r.stderr
+        # a client that expects its server under another uid refuses this one before sending a row
+        r = subprocess.run([sys.executable, "-c", code, _build.build_served()[1]], capture_output=True, text=True, timeout=30,
+                           env=dict(env2, LAMD_SERVED_UID=str(os.geteuid() + 1)))
+        assert r.stdout.startswith("-1 ") and "refusing to trust" in r.stdout
+        # PUBKEY_PARSE with a key length the engine does not know: an error, not rc 0 over stale output bytes (raw request, as a foreign client would send it)
+        rc, ctx = _connect(L, sock)
+        assert rc == 0
+        ok = np.full(4, 1, np.uint8)
+        xy = np.zeros((4, 64), np.uint8)
+        keys = np.zeros((4, 40), np.uint8)
+        assert L.lamd_pubkey_parse_batch(ctx, 4, keys.ctypes.data, 40, 40, xy.ctypes.data, ok.ctypes.data) == -3          # the client refuses it itself ...
+        import socket as pysock, struct
+        raw = pysock.socket(pysock.AF_UNIX, pysock.SOCK_STREAM)
+        raw.connect(sock)
+        fd = os.memfd_create("blk")
+        os.ftruncate(fd, 1 << 16)
+        hdr = lambda op, n, scalar0, lens: struct.pack("<IIQ6Q I 4x 20Q".replace(" ", ""), 0x4C414D44, op, n, scalar0, 0, 0, 0, 0, 0, len(lens), *(list(lens) + [0] * (20 - len(lens))))
+        pysock.send_fds(raw, [hdr(1, 0, 1 << 16, [])], [fd])
+        rep = raw.recv(4096)
+        assert struct.unpack_from("<Ii", rep)[1] == 0
+        raw.sendall(hdr(4, 4, 40, [160]))               # ... and the server answers a raw one with LAMD_ERR_ARG
+        rep = raw.recv(4096)
+        assert struct.unpack_from("<Ii", rep) == (0x4C414D44, -3) and b"publen" in rep
+        raw.close()
+        os.close(fd)
+        L.lamd_shutdown(ctx)
+    finally:
+        _stop(p)
+    # a path that exists and is not a socket of this user is not replaced
+    victim = tmp_path / "notasocket"
+    victim.write_text("x")
+    r = subprocess.run([served, "--engine", so, "--socket", str(victim)], capture_output=True, text=True, timeout=30, env=env)
+    assert r.returncode == 1 and "not replacing" in r.stderr and victim.read_text() == "x"
+
+
 GPU_CLIENT_SCRIPT = r"""
 import ctypes, os, sys, numpy as np
 sys.path.insert(0, sys.argv[1])
