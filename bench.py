@@ -43,8 +43,14 @@ W_SCHNORR = 1.65e5
 # 180.  Mixed addition (group.h gej_add_ge_fast): S + (M+9) + M + (M+9) + S + M + M + (S+9) + 180 + M = 990; doubling: 3 S +
 # (S+9) + M + (M+9) + M = 567; acceptance test: 3 M + 1 S.
 M_MUL, M_SQR, M_ADD, M_DBL = 99, 63, 990, 567
-def _mads(dbl, add):
-    return dbl * M_DBL + add * M_ADD + 3 * M_MUL + M_SQR
+# Round 6: the G windows are a run of additions in XYZZ coordinates (group.h gexz_add_ge_fast: the Jacobian form's Z^2 is carried, not recomputed):
+# 990 - 63 = 927 per window, entering the run costs Z^2 and Z^3 once (S + M), and the acceptance test r*ZZ == X is one multiplication (its Z^2 is there).
+M_ADD_XZ = M_ADD - M_SQR
+def _mads(dbl, add, g_windows=0, xyzz=False):
+    """dbl doublings + add Jacobian mixed additions (+ g_windows G additions), the multiplication by the table's Zc and the acceptance test"""
+    if xyzz:
+        return dbl * M_DBL + add * M_ADD + M_MUL + (M_SQR + M_MUL) + g_windows * M_ADD_XZ + M_MUL
+    return dbl * M_DBL + (add + g_windows) * M_ADD + 3 * M_MUL + M_SQR
 # pairs first (verify_core.h "Pairs first", k_ecmult_keyed_pairs): the two comb entries of a column, and two G windows, are summed as affine
 # points first -- pass 1 one multiplication per pair (the prefix product), pass 2 M + M + M + (S+9) + (M+9) = 482 per pair -- and enter the
 # accumulator by ONE mixed addition; the inversion by division steps is ~1 840 32-bit multiplies (20 batches x 92), shared by the rows of a lane's batch
@@ -56,10 +62,10 @@ def _mads_pairs(cols, g_windows, rows_per_inversion):
 # ladder: 132 doublings (+1 for 2Q), 66 + 6 table additions, G windows; combs: both halves made odd by a lattice vector (no
 # repair additions), the first table point initialises the accumulator: 2D - 1 additions + D - 1 doublings + G windows.  G windows: one
 # mixed addition per window of the static table -- 11 with the 24-bit windows that ship from round 4 on (12 with 22 bits: rounds 1-3)
-def w_exec_table(g_windows, pairs=False, rows_per_inversion=4.8):
+def w_exec_table(g_windows, pairs=False, rows_per_inversion=4.8, xyzz=True):
     if pairs:
         return {0: _mads(132 + 1, 66 + g_windows + 6), 7: _mads_pairs(19, g_windows, rows_per_inversion), 10: _mads_pairs(13, g_windows, rows_per_inversion)}
-    return {0: _mads(132 + 1, 66 + g_windows + 6), 7: _mads(18, 37 + g_windows), 10: _mads(12, 25 + g_windows)}   # ladder, 7-tooth comb, 10-tooth comb
+    return {0: _mads(132 + 1, 66 + 6, g_windows), 7: _mads(18, 37, g_windows, xyzz), 10: _mads(12, 25, g_windows, xyzz)}   # ladder (Jacobian G run), 7-tooth comb, 10-tooth comb
 def g_windows_of(gtable_bytes):
     for bits in (16, 22, 24, 26):
         w = (256 + bits - 1) // bits
@@ -872,7 +878,7 @@ def main():
         g_windows = g_windows_of(int(eng_cold.info()["gtable_bytes"]))
         pairs_first = os.environ.get("LAMD_PAIRS", "0") == "1"          # experiment knob: k_ecmult_keyed_pairs for large calls (the default is k_ecmult_keyed<false, 3>)
         resident_lanes = int(eng_cold.info()["compute_units"]) * 3 * 4 * 64
-        w_exec_t = w_exec_table(g_windows, pairs_first, min(6.0, max(1.0, rows_in_launch / resident_lanes)))
+        w_exec_t = w_exec_table(g_windows, pairs_first, min(6.0, max(1.0, rows_in_launch / resident_lanes)), os.environ.get("LAMD_BENCH_G_RUN", "xyzz") == "xyzz")
         w_exec = w_exec_t.get(teeth, w_exec_t[0])
         kernel_name = "k_ecmult_keyed_pairs<3>" if pairs_first and teeth else ("k_ecmult_keyed<false, 3>" if teeth else "k_ecmult<3>")
         # the peak the fraction is priced against: the multiply-add's SUSTAINED issue rate (launches >= 4 ms, measured in this process a moment ago),

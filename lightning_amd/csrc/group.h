@@ -96,6 +96,38 @@ LAMD_HD gej gej_add_ge_fast(const gej &a, const ge &b) {
   return r;
 }
 
+// XYZZ coordinates (x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2) for a RUN of bare mixed additions with no doubling in between -- the eleven windows
+// of u1*G at the end of a verification.  The Jacobian addition above recomputes Z^2 and Z^3 from Z in every step; here they are carried:
+// ZZ3 = ZZ1*H^2, ZZZ3 = ZZZ1*H^3 (two multiplications where the Jacobian form has Z^2, Z*Z^2 and Z1*H: a squaring less per addition), and the
+// acceptance test r*Z^2 == X has its Z^2 for free.  Entering the run costs what the first Jacobian addition pays anyway (Z^2, Z^3).  A doubling
+// needs Z itself (Z3 = 2*Y*Z), which is why the comb columns stay Jacobian.  Degenerate events: H = 0 makes ZZ3 = 0, and a zero ZZ stays zero
+// through every later addition of the run -- the caller's one test moves from Z to ZZ.
+struct gexz {
+  fe x, y, zz, zzz;  // all magnitude 1
+};
+LAMD_HD gexz gexz_from_gej(const gej &a) {
+  gexz r;
+  r.x = a.x;
+  r.y = a.y;
+  r.zz = fe_sqr(a.z);
+  r.zzz = fe_mul(a.z, r.zz);
+  return r;
+}
+LAMD_HD gexz gexz_add_ge_fast(const gexz &a, const ge &b) {
+  gexz r;
+  const fe h = fe_mul_add(b.x, a.zz, fe_neg(a.x, 1));
+  const fe rr = fe_mul_add(b.y, a.zzz, fe_neg(a.y, 1));
+  const fe hh = fe_sqr(h);
+  const fe hhh = fe_mul(h, hh);
+  const fe v = fe_mul(a.x, hh);
+  r.x = fe_sqr_add(rr, fe_neg(fe_add(hhh, fe_mul_int(v, 2)), 3));
+  const fe t = fe_add(v, fe_neg(r.x, 1));  // (3)
+  r.y = fe_mul2(rr, t, a.y, fe_neg(hhh, 1));
+  r.zz = fe_mul(a.zz, hh);
+  r.zzz = fe_mul(a.zzz, hhh);
+  return r;
+}
+
 LAMD_HD gej gej_select(bool take_a, const gej &a, const gej &b) {
   gej r;
   r.x = fe_select(take_a, a.x, b.x);

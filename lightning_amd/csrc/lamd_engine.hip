@@ -2,6 +2,7 @@
 // One signature per wavefront lane in every kernel; the arithmetic lives in verify_core.h.
 // There is deliberately no CPU verification path in this library.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1049,15 +1050,16 @@ __global__ void __launch_bounds__(LAMD_KEYED_THREADS, WAVES) k_ecmult_keyed(u32 
     if (!CAREFUL && keyok_row) keyok_row[i] = 1;  // rows on these lists have a parsed key (the others were rejected by lookup / partition)
     bool ok = (rec.flags & PREP_VALID) != 0;
     if (ok) {
-      gej R;
+      // the careful form returns a Jacobian point that may be flagged infinite, the hot form an XYZZ point (group.h) whose ZZ == 0 says SUSPECT
+      std::conditional_t<CAREFUL, gej, gexz> R;
       bool suspect = false;
       if (ten) {
         const u32 *tab = pool10 + tabslot * kc_stride(10);
-        if (CAREFUL) R = ecmult_lane_keyed<10>(rec, tab, gtable);
+        if constexpr (CAREFUL) R = ecmult_lane_keyed<10>(rec, tab, gtable);
         else R = ecmult_lane_keyed_fast<10>(rec, tab, gtable, &suspect, glds);
       } else {
         const u32 *tab = pool7 + tabslot * kc_stride(7);
-        if (CAREFUL) R = ecmult_lane_keyed<7>(rec, tab, gtable);
+        if constexpr (CAREFUL) R = ecmult_lane_keyed<7>(rec, tab, gtable);
         else R = ecmult_lane_keyed_fast<7>(rec, tab, gtable, &suspect, glds);
       }
       if (suspect) {

@@ -98,6 +98,9 @@ constexpr int SLOT_WORDS = LAMD_TABLE_LIMBS ? 288 : 256;             // scratch 
 #ifndef LAMD_GTABLE_WINDOW_BITS
 #define LAMD_GTABLE_WINDOW_BITS 24
 #endif
+#ifndef LAMD_G_RUN_XYZZ
+#define LAMD_G_RUN_XYZZ 1
+#endif
 constexpr int GTABLE_WINDOW_BITS = LAMD_GTABLE_WINDOW_BITS;
 constexpr int GTABLE_WINDOWS = (256 + GTABLE_WINDOW_BITS - 1) / GTABLE_WINDOW_BITS;
 constexpr size_t GTABLE_ENTRIES = (size_t)GTABLE_WINDOWS << GTABLE_WINDOW_BITS;
@@ -758,7 +761,7 @@ LAMD_HD comb_pair<T> comb_from_rec_odd(const prep_rec &rec) {
 // Measured A/B in profiles/r03_ab_variants.txt; the shipped build has no such code.)
 constexpr int GLDS_BITS = 5, GLDS_WINDOWS = (256 + GLDS_BITS - 1) / GLDS_BITS, GLDS_WORDS = GLDS_WINDOWS * (1 << GLDS_BITS) * 16;
 template <int T>
-LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u32 *gtable, bool *suspect, const u32 *glds = nullptr) {
+LAMD_HD gexz ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u32 *gtable, bool *suspect, const u32 *glds = nullptr) {
   constexpr int D = kc_spacing(T), NE = kc_ne(T);
   const comb_pair<T> cp = comb_from_rec_odd<T>(rec);
   gej acc = gej_infinity();
@@ -826,8 +829,13 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
       }
     }
     *suspect = fe_is_zero(acc.z);
-    return acc;
+    return gexz_from_gej(acc);
   }
+#endif
+  // the G windows are a run of additions without a doubling: XYZZ coordinates (group.h), a squaring less per addition
+  // (-DLAMD_G_RUN_XYZZ=0: the Jacobian run of rounds 1-5, converted at the end -- the A/B in profiles/r06_ab_variants.txt)
+#if LAMD_G_RUN_XYZZ
+  gexz xz = gexz_from_gej(acc);
 #endif
 #pragma unroll 1
   for (int w = 0; w < GTABLE_WINDOWS; w++) {
@@ -836,15 +844,28 @@ LAMD_HD gej ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u3
     for (int i = 0; i < 7; i++) uw[i] = (uw[i] >> GTABLE_WINDOW_BITS) | (uw[i + 1] << (32 - GTABLE_WINDOW_BITS));
     uw[7] >>= GTABLE_WINDOW_BITS;
     if (d != 0) {  // a zero digit (2^-22 per window) is a divergent skip, not a select
+#if defined(LAMD_CLOCK_PROBE_G_HOT)
+      // clock experiment (profiles/r06_clock.txt; verdicts are WRONG in this build): every window reads from the first 64 MiB of the table --
+      // the same eleven additions and loads, served from the Infinity Cache instead of HBM
+      const u32 *e = gtable + (size_t)(d & 0xFFFFFu) * GT_ENTRY_WORDS;
+#else
       const u32 *e = gtable + (((size_t)w << GTABLE_WINDOW_BITS) + d) * GT_ENTRY_WORDS;
+#endif
       ge pt;
       pt.x = slot_load_fe(e);
       pt.y = slot_load_fe(e + TW);
+#if LAMD_G_RUN_XYZZ
+      xz = gexz_add_ge_fast(xz, pt);
+#else
       acc = gej_add_ge_fast(acc, pt);
+#endif
     }
   }
-  *suspect = fe_is_zero(acc.z);
-  return acc;
+#if !LAMD_G_RUN_XYZZ
+  const gexz xz = gexz_from_gej(acc);
+#endif
+  *suspect = fe_is_zero(xz.zz);
+  return xz;
 }
 
 // ---- the per-signature ladder in its hot form (keys without a table: the cold rows of a batch, every row of an all-distinct batch).
@@ -1403,11 +1424,17 @@ LAMD_HD bool schnorr_accept_one(const gej &R, const u32 rw[8]) {
 #define LAMD_P_MINUS_N {0x2FC9BAEEu, 0x402DA172u, 0x50B75FC4u, 0x45512319u, 1u, 0u, 0u, 0u}
 
 // ECDSA acceptance: R != inf and x(R) mod n == r, tested without inversion
+// r*Z^2 == X, or (r + n)*Z^2 == X when r + n < p (x(R) mod n == r, secp256k1_ecdsa_sig_verify), for a finite R given by X and Z^2
+LAMD_HD bool ecdsa_final_xzz(const fe &x, const fe &z2, const u32 rw[8]);
 LAMD_HD bool ecdsa_final(const gej &R, const u32 rw[8]) {
   if (R.inf) return false;
-  const fe z2 = fe_sqr(R.z);
+  return ecdsa_final_xzz(R.x, fe_sqr(R.z), rw);
+}
+// the hot form's result (XYZZ, never flagged infinite: a result at infinity has ZZ = 0 and went to the careful launch as SUSPECT)
+LAMD_HD bool ecdsa_final(const gexz &R, const u32 rw[8]) { return ecdsa_final_xzz(R.x, R.zz, rw); }
+LAMD_HD bool ecdsa_final_xzz(const fe &x, const fe &z2, const u32 rw[8]) {
   const fe rf = fe_from_words(rw);  // r < n < p
-  bool ok = fe_equal(fe_mul(rf, z2), R.x, 1);
+  bool ok = fe_equal(fe_mul(rf, z2), x, 1);
   const u32 pmn[8] = LAMD_P_MINUS_N;
   if (!words_ge(rw, pmn)) {  // r + n < p: x(R) may also be r + n
     const u32 nw[8] = LAMD_SC_N;
@@ -1419,7 +1446,7 @@ LAMD_HD bool ecdsa_final(const gej &R, const u32 rw[8]) {
       t[i] = (u32)c;
       c >>= 32;
     }
-    ok |= fe_equal(fe_mul(fe_from_words(t), z2), R.x, 1);
+    ok |= fe_equal(fe_mul(fe_from_words(t), z2), x, 1);
   }
   return ok;
 }
@@ -1442,6 +1469,19 @@ LAMD_HD u8 schnorr_stage1(const gej &R, const u32 rw[8], u32 *slot) {
   for (int i = 0; i < 9; i++) {
     slot[SLOT_FIN_Y + i] = R.y.n[i];
     slot[SLOT_FIN_Z + i] = z.n[i];
+  }
+  return SCHNORR_PENDING;
+}
+// the hot form's result (XYZZ): stage 2 computes Y' * Z'^-3 from what is parked, so Y' = Y * ZZZ and Z' = ZZ make that Y * ZZZ / ZZ^3 =
+// Y / ZZZ (ZZ^3 = ZZZ^2) -- one multiplication here, for the rows whose x matches only, and stage 2 stays what it is
+LAMD_HD u8 schnorr_stage1(const gexz &R, const u32 rw[8], u32 *slot) {
+  const fe rf = fe_from_words(rw);  // r < p checked in prep
+  if (!fe_equal(fe_mul(rf, R.zz), R.x, 1)) return 0;
+  const fe y = fe_mul(R.y, R.zzz);
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    slot[SLOT_FIN_Y + i] = y.n[i];
+    slot[SLOT_FIN_Z + i] = R.zz.n[i];
   }
   return SCHNORR_PENDING;
 }

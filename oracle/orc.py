@@ -105,10 +105,38 @@ def secpdl():
     return _secpdl
 
 
+def bundled_libsecp_candidates():
+    """shared objects under the interpreter's package directories that may BE a libsecp256k1: the wheels of coincurve, python-bitcoinlib's
+    friends, electrum, secp256k1, ... bundle one (coincurve/_libsecp256k1*.so, secp256k1/_libsecp256k1*.so, *.libs/libsecp256k1-*.so.*).
+    Only names are matched here; secpdl_open() decides by the symbols it finds."""
+    import glob
+    import site
+    import sysconfig
+    roots = []
+    for r in list(getattr(site, "getsitepackages", lambda: [])()) + [getattr(site, "getusersitepackages", lambda: "")(), sysconfig.get_paths().get("purelib", ""),
+                                                                    sysconfig.get_paths().get("platlib", "")]:
+        if r and os.path.isdir(r) and r not in roots:
+            roots.append(r)
+    out = []
+    for r in roots:
+        for pat in ("*secp256k1*.so*", "*/*secp256k1*.so*", "*.libs/*secp256k1*", "*/.libs/*secp256k1*", "*/*/*secp256k1*.so*"):
+            for f in sorted(glob.glob(os.path.join(r, pat))):
+                if os.path.isfile(f) and f not in out:
+                    out.append(f)
+    return out
+
+
 def libsecp_available(path=None):
-    """path of the libsecp256k1 shared object that could be loaded, or None"""
+    """path of the libsecp256k1 shared object that could be loaded, or None: `path`, $LAMD_LIBSECP256K1 and the usual sonames first (libsecp_dl.c),
+    then whatever a Python package of this interpreter bundles -- so that BASELINE.md's leg C0 appears the day a node has the library in ANY form"""
     L = secpdl()
-    return L.secpdl_path().decode() if L.secpdl_open(path.encode() if path else None) else None
+    if L.secpdl_open(path.encode() if path else None):
+        return L.secpdl_path().decode()
+    if path is None and not os.environ.get("LAMD_LIBSECP256K1"):
+        for cand in bundled_libsecp_candidates():
+            if L.secpdl_open(cand.encode()):
+                return L.secpdl_path().decode()
+    return None
 
 
 def libsecp_ecdsa_verify_batch(hashes, sigs, pubs, publen):

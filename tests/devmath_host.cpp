@@ -132,10 +132,15 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
       keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
       // as the kernels stage it: the bare-formula form first, the complete form only when it reports Z = 0
       bool suspect;
-      gej R = ecmult_lane_keyed_fast<T>(recs[i], tab.data(), g_table.data(), &suspect);
-      if (suspect) { g_suspects++; R = ecmult_lane_keyed<T>(recs[i], tab.data(), g_table.data()); }
+      const gexz R = ecmult_lane_keyed_fast<T>(recs[i], tab.data(), g_table.data(), &suspect);
       be_to_words(rw, sig64 + 64 * i);
-      out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
+      if (suspect) {
+        g_suspects++;
+        const gej Rc = ecmult_lane_keyed<T>(recs[i], tab.data(), g_table.data());
+        out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(Rc, rw) : schnorr_stage1(Rc, rw, &fin[i * 32]);
+      } else {
+        out[i] = mode == MODE_ECDSA ? (u8)ecdsa_final(R, rw) : schnorr_stage1(R, rw, &fin[i * 32]);
+      }
     }
   }
   if (mode == MODE_SCHNORR) schnorr_final_thread(0, 1, n, fin.data(), out, 32);
@@ -299,17 +304,19 @@ static int ecmult_keyed_t(const u32 *qx, const u32 *qy, const u8 *u1, const u8 *
   for (int i = 0; i < 4; i++) { rec.k1[i] = h1.mag[i]; rec.k2[i] = h2.mag[i]; }
   rec.flags = PREP_VALID | (h1.neg ? PREP_K1NEG : 0) | (h2.neg ? PREP_K2NEG : 0) | (h1.top ? PREP_K1TOP : 0) | (h2.top ? PREP_K2TOP : 0);
   bool suspect;
-  gej R = ecmult_lane_keyed_fast<T>(rec, tab.data(), g_table.data(), &suspect);
+  const gexz Rx = ecmult_lane_keyed_fast<T>(rec, tab.data(), g_table.data(), &suspect);
   const gej Rc = ecmult_lane_keyed<T>(rec, tab.data(), g_table.data());
+  const gej R = Rc;
   if (suspect) {
     g_suspects++;
-    R = Rc;
   } else {
-    // the two forms must describe the same point: X1*Z2^2 == X2*Z1^2, Y1*Z2^3 == Y2*Z1^3
+    // the two forms must describe the same point: X1*Z2^2 == X2*ZZ1, Y1*Z2^3 == Y2*ZZZ1 -- and the hot form's ZZ, ZZZ must be a square and a cube
+    // of ONE Z (ZZ^3 == ZZZ^2), or the BIP-340 parity stage would be fed a y of another curve
     if (Rc.inf) return -1;
-    const fe z1 = fe_norm_weak(R.z), z2 = fe_norm_weak(Rc.z), z1s = fe_sqr(z1), z2s = fe_sqr(z2);
-    if (!fe_equal(fe_mul(R.x, z2s), fe_mul(Rc.x, z1s), 1)) return -1;
-    if (!fe_equal(fe_mul(R.y, fe_mul(z2s, z2)), fe_mul(Rc.y, fe_mul(z1s, z1)), 1)) return -1;
+    const fe z2 = fe_norm_weak(Rc.z), z2s = fe_sqr(z2);
+    if (!fe_equal(fe_mul(Rx.x, z2s), fe_mul(Rc.x, Rx.zz), 1)) return -1;
+    if (!fe_equal(fe_mul(Rx.y, fe_mul(z2s, z2)), fe_mul(Rc.y, Rx.zzz), 1)) return -1;
+    if (!fe_equal(fe_mul(fe_sqr(Rx.zz), Rx.zz), fe_sqr(Rx.zzz), 1)) return -1;
   }
   if (R.inf) return 0;
   const fe zi = fe_inv(fe_norm_weak(R.z)), zi2 = fe_sqr(zi);
