@@ -103,7 +103,7 @@ LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_ste
 CONFIG_KEYS = ("workload", "rows_per_gpu_per_step", "parallelism", "key_table_cache", "value_host_to_host", "host_to_host_over_value", "predicted_speedup_8")
 ROOFLINE_KEYS = ("kernel", "bound", "mode", "avg_launch_ms", "rows_in_launch", "executed_mul32_per_verify", "achieved", "peak", "unit", "frac",
                  "peak_sustained", "peak_boost", "frac_step", "frac_isolated", "traffic", "traffic_unit", "traffic_over_algorithmic",
-                 "algorithmic_bytes_per_launch", "valu_instr_per_verify", "valu_issue_frac", "launches_timed", "sum_of_launches_le_step")
+                 "algorithmic_bytes_per_launch", "valu_instr_per_verify", "valu_issue_frac", "valu_issue_frac_step", "valu_share_key_tables", "launches_timed", "sum_of_launches_le_step")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "note", "C1_1thread", "C1_all_cores", "C2", "C0", "ns_per_verify_1thread", "seconds")
 PARITY_KEYS = ("rows_checked", "mismatches", "oracle_rows_checked", "oracle_mismatches")
 REQUIRED = {"": LINE_KEYS + ("config", "roofline", "cpu_baseline", "parity"),
@@ -928,6 +928,20 @@ def main():
             valu_issue = {"wave_instr_per_simd_cycle": pm["valu_issue_per_simd_cycle"], "saturated_at": 0.25,
                           "frac": pm["valu_issue_per_simd_cycle"] / 0.25, "valu_instr_per_verify": pm["valu_insts_per_verify"],
                           "source": pm["source"]}
+            if pm.get("step_valu_wave_instr_total") and n == 1_000_000:
+                # THE WHOLE STEP against the issue roofline (round 6): every kernel of a step competes for the same VALU issue slots, so the step is priced
+                # as one thing -- VALU wave-instructions of all its kernels (PMC, the same command) x 4 cycles / (SIMDs x clock x step time).  The clock is
+                # the multiply-add probe's (measured in this process; the kernels themselves run ~7 % below it), so the fraction is a lower bound.
+                simds = int(eng_cold.info()["compute_units"]) * 4
+                clk = p_sust / (int(eng_cold.info()["compute_units"]) * 64)
+                tot = float(pm["step_valu_wave_instr_total"])
+                sv = pm.get("step_valu_wave_instr", {})
+                tab = sum(v for k, v in sv.items() if k.startswith("k_kc_") or k.startswith("k_keys_bases"))
+                valu_issue["step"] = {"valu_wave_instr_per_step": tot, "issue_ms_at_probe_clock": tot * 4 / simds / clk * 1e3, "ms_per_step": dt / args.steps * 1e3,
+                                      "frac": tot * 4 / simds / clk / (dt / args.steps), "probe_clock_GHz": clk / 1e9,
+                                      "share_ecmult": sum(v for k, v in sv.items() if k.startswith("k_ecmult_keyed<false")) / tot,
+                                      "share_key_tables": tab / tot,
+                                      "note": "all kernels of a step: VALU wave-instructions x 4 cycles / (1024 SIMDs x clock x step time)"}
         except Exception:
             pass
         iso_ms = iso_launch[0] or float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2])
@@ -992,6 +1006,8 @@ def main():
                 "valu_issue": valu_issue,
                 "valu_instr_per_verify": valu_issue["valu_instr_per_verify"] if valu_issue else None,
                 "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
+                "valu_issue_frac_step": valu_issue["step"]["frac"] if valu_issue and "step" in valu_issue else None,
+                "valu_share_key_tables": valu_issue["step"]["share_key_tables"] if valu_issue and "step" in valu_issue else None,
                 # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time: NOT a
                 # utilisation figure (the combs execute 2.2x fewer multiplies than the yardstick's generic algorithm)
                 "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "yardstick_Tmul32_per_s_in_loop": W_ECDSA65 * n / t_ecmult / 1e12,

@@ -9,25 +9,43 @@
 #include <sys/mman.h>
 #include <sys/un.h>
 
+#include <map>
 #include <string>
+#include <vector>
 
 #include "../../include/lightning_amd.h"
 #include "served_common.h"
 
 using namespace lamd_srv;
 
+struct flush_slot {
+  uint8_t *p = nullptr;
+  size_t size = 0;
+  bool busy = false;
+  uint64_t seq = 0;
+  size_t n = 0;
+};
 struct lamd_ctx {
   int fd = -1;
-  uint8_t *shm = nullptr;
+  uint8_t *shm = nullptr;  // block 0: the synchronous calls
   size_t shm_size = 0;
   std::string err;
+  // streaming: the open set (queued locally), the blocks of the flushes in flight, the replies that arrived ahead of their turn
+  std::vector<uint8_t> qh, qs, qk;
+  std::vector<uint64_t> runs;  // keylen << 32 | rows, in ticket order
+  size_t qn = 0;
+  flush_slot slot[LAMD_SRV_FLUSH_SLOTS];
+  uint64_t next_seq = 1, oldest_seq = 1;
+  std::map<uint64_t, lamd_srv_rep> arrived;
 };
 
 namespace {
 
 struct section { const void *p; size_t len; };
 
-int attach(lamd_ctx *c, size_t size) {
+int recv_sync_reply(lamd_ctx *c, lamd_srv_rep *rep);
+// block 0 (slot 0) or the block of flush slot s - 1
+int attach(lamd_ctx *c, size_t size, int slot = 0) {
   const int mfd = memfd_create("lamd_client", MFD_CLOEXEC);
   if (mfd < 0 || ftruncate(mfd, (off_t)size) != 0) {
     if (mfd >= 0) close(mfd);
@@ -41,18 +59,30 @@ int attach(lamd_ctx *c, size_t size) {
   r.magic = LAMD_SRV_MAGIC;
   r.op = LAMD_SRV_OP_SHM;
   r.scalar[0] = size;
+  r.scalar[1] = (uint64_t)slot;
   lamd_srv_rep rep;
-  const bool ok = send_with_fd(c->fd, &r, sizeof r, mfd) && recv_all(c->fd, &rep, sizeof rep);
+  const bool ok = send_with_fd(c->fd, &r, sizeof r, mfd) && recv_sync_reply(c, &rep) == LAMD_OK;
   close(mfd);
-  if (!ok || rep.magic != LAMD_SRV_MAGIC || rep.rc != LAMD_OK) {
+  if (!ok || rep.rc != LAMD_OK) {
     munmap(p, size);
+    rep.err[sizeof rep.err - 1] = 0;
     c->err = ok ? std::string("server refused the shared block: ") + rep.err : "connection to lamd_served lost";
     return ok ? rep.rc : LAMD_ERR_STATE;
   }
-  if (c->shm) munmap(c->shm, c->shm_size);
-  c->shm = (uint8_t *)p;
-  c->shm_size = size;
+  uint8_t *&dst = slot ? c->slot[slot - 1].p : c->shm;
+  size_t &dsz = slot ? c->slot[slot - 1].size : c->shm_size;
+  if (dst) munmap(dst, dsz);
+  dst = (uint8_t *)p;
+  dsz = size;
   return LAMD_OK;
+}
+// the reply to a synchronous request: replies to flushes (seq != 0) that arrive first are kept for lamd_poll / lamd_wait
+int recv_sync_reply(lamd_ctx *c, lamd_srv_rep *rep) {
+  for (;;) {
+    if (!recv_all(c->fd, rep, sizeof *rep) || rep->magic != LAMD_SRV_MAGIC) return LAMD_ERR_STATE;
+    if (rep->seq == 0) return LAMD_OK;
+    c->arrived[rep->seq] = *rep;
+  }
 }
 
 // one round trip: the input sections go into the shared block, the reply's output sections are copied to `outs`
@@ -79,7 +109,7 @@ int call(lamd_ctx *c, uint32_t op, uint64_t n, const uint64_t scalar[6], const s
   for (int i = 0; i < n_in; i++)
     if (in[i].len) memcpy(c->shm + off[i], in[i].p, in[i].len);
   lamd_srv_rep rep;
-  if (!send_all(c->fd, &r, sizeof r) || !recv_all(c->fd, &rep, sizeof rep) || rep.magic != LAMD_SRV_MAGIC) {
+  if (!send_all(c->fd, &r, sizeof r) || recv_sync_reply(c, &rep) != LAMD_OK) {
     c->err = "connection to lamd_served lost";
     return LAMD_ERR_STATE;
   }
@@ -101,7 +131,7 @@ int call(lamd_ctx *c, uint32_t op, uint64_t n, const uint64_t scalar[6], const s
 
 extern "C" {
 
-const char *lamd_version(void) { return "lightning_amd client (lamd_served protocol 1)"; }
+const char *lamd_version(void) { return "lightning_amd client (lamd_served protocol 2)"; }
 
 int lamd_init(lamd_ctx **out, int /*device: the server chose it*/) {
   if (!out) return LAMD_ERR_ARG;
@@ -146,8 +176,135 @@ void lamd_shutdown(lamd_ctx *c) {
   if (!c) return;
   if (c->fd >= 0) close(c->fd);
   if (c->shm) munmap(c->shm, c->shm_size);
+  for (flush_slot &s : c->slot)
+    if (s.p) munmap(s.p, s.size);
   delete c;
 }
+
+// ---- streaming (include/lightning_amd.h "streaming"): the open set lives in this process until lamd_flush() hands it to the server
+static int queue_rows(lamd_ctx *c, size_t n, const uint8_t *a32, const uint8_t *sig64, const uint8_t *key, size_t keylen, size_t keystride) {
+  if (!c || c->fd < 0) return LAMD_ERR_ARG;
+  if (n == 0) return (int)c->qn;
+  if (!a32 || !sig64 || !key || (keylen != 32 && keylen != 33 && keylen != 65) || keystride < keylen) { c->err = "bad argument"; return LAMD_ERR_ARG; }
+  if (c->qn + n >= ((size_t)1 << 30)) { c->err = "fewer than 2^30 triples per flush"; return LAMD_ERR_ARG; }
+  const int first = (int)c->qn;
+  c->qh.insert(c->qh.end(), a32, a32 + 32 * n);
+  c->qs.insert(c->qs.end(), sig64, sig64 + 64 * n);
+  if (keystride == keylen) c->qk.insert(c->qk.end(), key, key + keylen * n);
+  else
+    for (size_t i = 0; i < n; i++) c->qk.insert(c->qk.end(), key + keystride * i, key + keystride * i + keylen);
+  if (!c->runs.empty() && (c->runs.back() >> 32) == keylen && (c->runs.back() & 0xFFFFFFFFu) + n <= 0xFFFFFFFFu) c->runs.back() += n;
+  else c->runs.push_back(((uint64_t)keylen << 32) | (uint64_t)n);
+  c->qn += n;
+  return first;
+}
+int lamd_queue_ecdsa_batch(lamd_ctx *c, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey, size_t publen, size_t pubstride) {
+  if (publen != 33 && publen != 65) { if (c) c->err = "publen must be 33 or 65"; return LAMD_ERR_ARG; }
+  return queue_rows(c, n, hash32, sig64, pubkey, publen, pubstride);
+}
+int lamd_queue_schnorr_batch(lamd_ctx *c, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64) {
+  return queue_rows(c, n, msg32, sig64, xonly32, 32, 32);
+}
+int lamd_queue_ecdsa(lamd_ctx *c, const uint8_t hash32[32], const uint8_t sig64[64], const uint8_t *pubkey, size_t publen) {
+  return lamd_queue_ecdsa_batch(c, 1, hash32, sig64, pubkey, publen, publen);
+}
+int lamd_queue_schnorr(lamd_ctx *c, const uint8_t msg32[32], const uint8_t xonly32[32], const uint8_t sig64[64]) {
+  return lamd_queue_schnorr_batch(c, 1, msg32, xonly32, sig64);
+}
+// the producer form: the rows are reserved in the open set and the caller writes them before lamd_flush() (pointers valid until the next queue / flush call)
+int lamd_queue_reserve(lamd_ctx *c, size_t n, size_t keylen, uint8_t **hash32, uint8_t **sig64, uint8_t **key) {
+  if (!c || !hash32 || !sig64 || !key || n == 0 || (keylen != 32 && keylen != 33 && keylen != 65)) { if (c) c->err = "bad argument"; return LAMD_ERR_ARG; }
+  if (c->qn + n >= ((size_t)1 << 30)) { c->err = "fewer than 2^30 triples per flush"; return LAMD_ERR_ARG; }
+  const int first = (int)c->qn;
+  const size_t oh = c->qh.size(), os = c->qs.size(), ok_ = c->qk.size();
+  c->qh.resize(oh + 32 * n);
+  c->qs.resize(os + 64 * n);
+  c->qk.resize(ok_ + keylen * n);
+  if (!c->runs.empty() && (c->runs.back() >> 32) == keylen && (c->runs.back() & 0xFFFFFFFFu) + n <= 0xFFFFFFFFu) c->runs.back() += n;
+  else c->runs.push_back(((uint64_t)keylen << 32) | (uint64_t)n);
+  c->qn += n;
+  *hash32 = &c->qh[oh];
+  *sig64 = &c->qs[os];
+  *key = &c->qk[ok_];
+  return first;
+}
+int lamd_flush(lamd_ctx *c) {
+  if (!c || c->fd < 0) return LAMD_ERR_ARG;
+  if (c->qn == 0) return LAMD_OK;
+  int s = -1;
+  for (int i = 0; i < LAMD_SRV_FLUSH_SLOTS; i++)
+    if (!c->slot[i].busy) { s = i; break; }
+  if (s < 0) { c->err = "too many flushes outstanding: collect one with lamd_poll / lamd_wait"; return LAMD_ERR_STATE; }
+  lamd_srv_req r;
+  memset(&r, 0, sizeof r);
+  r.magic = LAMD_SRV_MAGIC;
+  r.op = LAMD_SRV_OP_FLUSH;
+  r.n = c->qn;
+  r.scalar[0] = c->next_seq;
+  r.slot = (uint32_t)(s + 1);
+  r.n_sections = 4;
+  r.section_len[0] = 8 * c->runs.size();
+  r.section_len[1] = c->qh.size();
+  r.section_len[2] = c->qs.size();
+  r.section_len[3] = c->qk.size();
+  size_t off[LAMD_SRV_MAX_SECTIONS];
+  const size_t need = layout(r, off) + 64 + align16(c->qn);
+  if (need > c->slot[s].size) {
+    // (the slot is free: no flush is in flight in its block, so the server lets it be replaced)
+    size_t sz = c->slot[s].size ? c->slot[s].size : (size_t)1 << 20;
+    while (sz < need) sz *= 2;
+    const int rc = attach(c, sz, s + 1);
+    if (rc != LAMD_OK) return rc < 0 ? rc : LAMD_ERR_STATE;
+  }
+  uint8_t *b = c->slot[s].p;
+  memcpy(b + off[0], c->runs.data(), 8 * c->runs.size());
+  memcpy(b + off[1], c->qh.data(), c->qh.size());
+  memcpy(b + off[2], c->qs.data(), c->qs.size());
+  memcpy(b + off[3], c->qk.data(), c->qk.size());
+  if (!send_all(c->fd, &r, sizeof r)) { c->err = "connection to lamd_served lost"; return LAMD_ERR_STATE; }
+  c->slot[s].busy = true;
+  c->slot[s].seq = c->next_seq++;
+  c->slot[s].n = c->qn;
+  c->qh.clear(); c->qs.clear(); c->qk.clear(); c->runs.clear();
+  c->qn = 0;
+  return LAMD_OK;
+}
+// verdicts of the OLDEST outstanding flush: 1 = finished, 0 = still running (poll only), < 0 error
+static int collect(lamd_ctx *c, uint8_t *ok, size_t cap, size_t *n, bool block) {
+  if (!c || c->fd < 0 || !ok || !n) return LAMD_ERR_ARG;
+  flush_slot *f = nullptr;
+  for (flush_slot &s : c->slot)
+    if (s.busy && s.seq == c->oldest_seq) f = &s;
+  if (!f) { c->err = "no flush outstanding"; return LAMD_ERR_STATE; }
+  if (cap < f->n) { c->err = "verdict buffer smaller than the flush"; return LAMD_ERR_ARG; }
+  while (!c->arrived.count(f->seq)) {
+    lamd_srv_rep rep;
+    if (!block) {
+      const ssize_t k = recv(c->fd, &rep, sizeof rep, MSG_PEEK | MSG_DONTWAIT);
+      if (k < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) return 0;
+      if (k >= 0 && (size_t)k < sizeof rep && k != 0) return 0;  // a reply is on its way
+    }
+    if (!recv_all(c->fd, &rep, sizeof rep) || rep.magic != LAMD_SRV_MAGIC || rep.seq == 0) { c->err = "connection to lamd_served lost"; return LAMD_ERR_STATE; }
+    c->arrived[rep.seq] = rep;
+  }
+  const lamd_srv_rep rep = c->arrived[f->seq];
+  c->arrived.erase(f->seq);
+  f->busy = false;
+  c->oldest_seq++;
+  if (rep.rc < 0) {
+    char e[sizeof rep.err];
+    memcpy(e, rep.err, sizeof e);
+    e[sizeof e - 1] = 0;
+    c->err = e;
+    return rep.rc;
+  }
+  if (rep.out_offset + f->n > f->size) { c->err = "reply outside the flush block"; return LAMD_ERR_STATE; }
+  memcpy(ok, f->p + rep.out_offset, f->n);
+  *n = f->n;
+  return 1;
+}
+int lamd_poll(lamd_ctx *c, uint8_t *ok, size_t cap, size_t *n) { return collect(c, ok, cap, n, false); }
+int lamd_wait(lamd_ctx *c, uint8_t *ok, size_t cap, size_t *n) { return collect(c, ok, cap, n, true); }
 const char *lamd_last_error(const lamd_ctx *c) { return c ? c->err.c_str() : "no context"; }
 
 int lamd_verify_ecdsa_batch(lamd_ctx *c, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pub, size_t publen, size_t pubstride, uint8_t *ok) {

@@ -2,11 +2,14 @@
 // Protocol and rationale: include/lightning_amd_served.h.  SURVEY.md section 7 "Process model": one channeld per channel
 // (channeld/channeld.c:7019-7129), gossipd, lightningd and plugins are separate single-threaded processes that verify inline.
 //
-//   lamd_served [--socket PATH] [--device N] [--engine LIB] [--max-merge ROWS] [--linger-us US]
+//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--linger-us US]
 //
-// Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job, waits for its completion, sends the reply);
-// ONE engine thread, the only caller of the engine (a context is not thread-safe).  The engine thread takes EVERYTHING that is queued at
-// the moment it looks: the ECDSA jobs of equal key length become one lamd_verify_ecdsa_batch call, the BIP-340 jobs one
+// Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job; a synchronous job it waits for and answers, a
+// flush it hands over and goes on reading); ONE engine thread PER DEVICE, the only caller of that device's context (a context is not
+// thread-safe).  A job goes to the device its first key hashes to (key affinity: the rows of one channel / peer / signer keep meeting the same
+// key-table cache).  An engine thread takes EVERYTHING that is queued for its device at the moment it looks: the client flushes
+// (LAMD_SRV_OP_FLUSH) are queued into the engine's own staging set and flushed as ONE engine batch, up to eight of those in flight, their
+// verdicts scattered back and answered when the engine reports them (lamd_poll); the ECDSA jobs of equal key length become one lamd_verify_ecdsa_batch call, the BIP-340 jobs one
 // lamd_verify_schnorr_batch call, the commitment_signed validations (and check_tx_sig batches) one lamd_check_tx_sig_tx_batch call (rows copied into
 // one contiguous batch, verdicts scattered back, a commitment's first_bad taken from its slice); every other operation runs by itself.
 // With --linger-us the engine thread waits that long after the first job of a round for company (default 0: merge what is there).
@@ -54,6 +57,11 @@ struct engine_api {
   decltype(&lamd_bolt12_merkle_batch) bolt12_merkle = nullptr;
   decltype(&lamd_ecdsa_recover_batch) recover = nullptr;
   decltype(&lamd_grind_htlc_tx_fee) grind = nullptr;
+  decltype(&lamd_queue_ecdsa_batch) queue_ecdsa = nullptr;
+  decltype(&lamd_queue_schnorr_batch) queue_schnorr = nullptr;
+  decltype(&lamd_flush) flush = nullptr;
+  decltype(&lamd_poll) poll = nullptr;
+  decltype(&lamd_wait) wait = nullptr;
 };
 template <typename F>
 bool bind(void *lib, const char *name, F *fn) {
@@ -62,37 +70,73 @@ bool bind(void *lib, const char *name, F *fn) {
   return *fn != nullptr;
 }
 
+struct blk {
+  uint8_t *p = nullptr;
+  size_t size = 0;
+};
 struct conn {
   int fd = -1;
-  uint8_t *shm = nullptr;
-  size_t shm_size = 0;
+  blk shm[1 + LAMD_SRV_FLUSH_SLOTS];  // 0: synchronous calls; 1..: one flush each
+  std::mutex wmu;                     // replies to flushes are written by engine threads, replies to synchronous requests by the reader
+  std::atomic<int> async_pending{0};  // flushes handed to an engine thread and not answered yet: the blocks must stay mapped
+  std::atomic<int> slot_pending[1 + LAMD_SRV_FLUSH_SLOTS] = {};  // ... per block: a block with a flush in flight is not replaced
 };
 struct job {
   lamd_srv_req req;
   conn *c = nullptr;
+  int slot = 0;
   size_t off[LAMD_SRV_MAX_SECTIONS];
   size_t out_off = 0;
   lamd_srv_rep rep;
   bool done = false;
+  bool async = false;  // LAMD_SRV_OP_FLUSH: heap-allocated, answered and deleted by the engine thread
   // the server's OWN copies of a request's offset arrays, taken once and validated: the shared block stays writable by its client while the
   // request runs, and an offset re-read after the check could point anywhere
   std::vector<uint64_t> o_in, o_out, o_sc;
+  size_t queued_rows = 0;  // flush: rows that reached the engine's staging set
+};
+
+// one engine context = one GPU = one engine thread
+struct flight {  // one engine flush: the client flushes it carries, in ticket order
+  std::vector<job *> parts;
+  size_t rows = 0;
+};
+struct device {
+  int id = 0;
+  lamd_ctx *ctx = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<job *> Q;
+  std::deque<flight> inflight;
+  std::vector<uint8_t> okbuf;
+  std::thread th;
 };
 
 engine_api E;
-lamd_ctx *g_ctx = nullptr;
-std::mutex qmu;
-std::condition_variable qcv, donecv;
-std::deque<job *> Q;
+std::vector<device *> g_dev;
+thread_local device *D = nullptr;  // the device of the engine thread that runs the code below
+#define g_ctx (D->ctx)
+std::mutex donemu;
+std::condition_variable donecv;
 std::atomic<bool> g_quit{false};
+std::mutex statmu;
 lamd_srv_stats g_stats;
 size_t g_max_merge = (size_t)1 << 20;
 unsigned g_linger_us = 0;
+const size_t ENGINE_FLUSHES_IN_FLIGHT = 8;
 
-const uint8_t *sec(const job *j, int i) { return j->c->shm + j->off[i]; }
+const uint8_t *sec(const job *j, int i) { return j->c->shm[j->slot].p + j->off[i]; }
 size_t seclen(const job *j, int i) { return (size_t)j->req.section_len[i]; }
-uint8_t *outp(const job *j, size_t o) { return j->c->shm + j->out_off + o; }
+uint8_t *outp(const job *j, size_t o) { return j->c->shm[j->slot].p + j->out_off + o; }
 
+void stat_add(uint64_t *f, uint64_t d) {
+  std::lock_guard<std::mutex> lk(statmu);
+  *f += d;
+}
+void stat_max(uint64_t *f, uint64_t v) {
+  std::lock_guard<std::mutex> lk(statmu);
+  if (v > *f) *f = v;
+}
 void fail(job *j, int rc, const char *why) {
   j->rep.rc = rc;
   snprintf(j->rep.err, sizeof j->rep.err, "%s", why);
@@ -109,7 +153,7 @@ bool shape(job *j, std::initializer_list<size_t> lens, size_t out_bytes) {
     if (l != (size_t)-1 && seclen(j, i) != l) { fail(j, LAMD_ERR_ARG, "section length does not match n"); return false; }
     i++;
   }
-  if (j->out_off + align16(out_bytes) + 64 > j->c->shm_size) { fail(j, LAMD_ERR_ARG, "shared block too small for the reply"); return false; }
+  if (j->out_off + align16(out_bytes) + 64 > j->c->shm[j->slot].size) { fail(j, LAMD_ERR_ARG, "shared block too small for the reply"); return false; }
   return true;
 }
 const size_t ANY = (size_t)-1;
@@ -126,12 +170,13 @@ void run_merged(std::vector<job *> &js, bool schnorr) {
   const size_t kl = schnorr ? 32 : (size_t)js[0]->req.scalar[0];
   size_t total = 0;
   for (job *j : js) total += (size_t)j->req.n;
+  stat_add(&g_stats.rows_by_device[D->id], total);
   if (js.size() == 1) {
     job *j = js[0];
     const int rc = schnorr ? E.verify_schnorr(g_ctx, (size_t)j->req.n, sec(j, 0), sec(j, 1), sec(j, 2), outp(j, 0))
                            : E.verify_ecdsa(g_ctx, (size_t)j->req.n, sec(j, 0), sec(j, 1), sec(j, 2), kl, kl, outp(j, 0));
     engine_error(j, rc);
-    g_stats.engine_calls++;
+    stat_add(&g_stats.engine_calls, 1);
     return;
   }
   std::vector<uint8_t> a(32 * total), b(64 * total), c(kl * total), ok(total);
@@ -150,10 +195,10 @@ void run_merged(std::vector<job *> &js, bool schnorr) {
   }
   const int rc = schnorr ? E.verify_schnorr(g_ctx, total, a.data(), c.data(), b.data(), ok.data())
                          : E.verify_ecdsa(g_ctx, total, a.data(), b.data(), c.data(), kl, kl, ok.data());
-  g_stats.engine_calls++;
-  g_stats.merged_requests += js.size();
-  g_stats.merged_rows += total;
-  if (js.size() > g_stats.largest_merge_requests) g_stats.largest_merge_requests = js.size();
+  stat_add(&g_stats.engine_calls, 1);
+  stat_add(&g_stats.merged_requests, js.size());
+  stat_add(&g_stats.merged_rows, total);
+  stat_max(&g_stats.largest_merge_requests, js.size());
   if (rc < 0) {  // one request's rows made the merged call fail: every request again by itself, so that only the offender sees the error
     for (job *j : js) {
       std::vector<job *> one(1, j);
@@ -202,6 +247,7 @@ void run_tx_merged(std::vector<job *> &js) {
   if (js.size() == 1) { run_one(js[0]); return; }
   size_t total = 0;
   for (job *j : js) total += (size_t)j->req.n;
+  stat_add(&g_stats.rows_by_device[D->id], total);
   std::vector<uint32_t> ver(total), lock(total), inum(total), nout(total);
   std::vector<uint64_t> amt(total), in_off(total + 1), out_off(total + 1), sc_off(total + 1);
   std::vector<uint8_t> type(total), wit(total), sig(64 * total), pub(33 * total), ins, outs, scs, ok(total);
@@ -234,10 +280,10 @@ void run_tx_merged(std::vector<job *> &js) {
   ins.push_back(0); outs.push_back(0); scs.push_back(0);   // never empty arrays
   const int rc = E.txsig_tx(g_ctx, total, ver.data(), lock.data(), ins.data(), in_off.data(), inum.data(), amt.data(), outs.data(), out_off.data(), nout.data(), scs.data(),
                             sc_off.data(), type.data(), wit.data(), sig.data(), pub.data(), 33, 33, ok.data());
-  g_stats.engine_calls++;
-  g_stats.merged_requests += js.size();
-  g_stats.merged_rows += total;
-  if (js.size() > g_stats.largest_merge_requests) g_stats.largest_merge_requests = js.size();
+  stat_add(&g_stats.engine_calls, 1);
+  stat_add(&g_stats.merged_requests, js.size());
+  stat_add(&g_stats.merged_rows, total);
+  stat_max(&g_stats.largest_merge_requests, js.size());
   if (rc < 0) {  // as in run_merged: only the offending client may see the error
     for (job *j : js) run_one(j);
     return;
@@ -264,7 +310,7 @@ void run_tx_merged(std::vector<job *> &js) {
 void run_one(job *j) {
   const lamd_srv_req &r = j->req;
   const size_t n = (size_t)r.n;
-  g_stats.engine_calls++;
+  stat_add(&g_stats.engine_calls, 1);
   switch (r.op) {
     case LAMD_SRV_OP_PUBKEY_PARSE: {
       const size_t kl = (size_t)r.scalar[0];
@@ -344,136 +390,312 @@ void run_one(job *j) {
       engine_error(j, rc);
       return;
     }
-    case LAMD_SRV_OP_STATS:
-      g_stats.engine_calls--;
+    case LAMD_SRV_OP_STATS: {
+      stat_add(&g_stats.engine_calls, (uint64_t)-1);
       if (!shape(j, std::initializer_list<size_t>{}, sizeof g_stats)) return;
+      std::lock_guard<std::mutex> lk(statmu);
       memcpy(outp(j, 0), &g_stats, sizeof g_stats);
       j->rep.rc = LAMD_OK;
       return;
+    }
     default:
       fail(j, LAMD_ERR_ARG, "unknown operation");
   }
 }
 
-void engine_loop() {
+// ---- streaming: the flushes of the clients become engine flushes
+// a flush request is well-formed: runs of known key lengths that add up to n, sections of exactly the lengths the runs imply
+bool flush_valid(job *j) {
+  const lamd_srv_req &r = j->req;
+  const size_t n = (size_t)r.n;
+  if (!sane_n(j)) return false;
+  if (n == 0 || r.n_sections != 4 || seclen(j, 0) == 0 || seclen(j, 0) % 8 != 0 || seclen(j, 0) > 8 * n) { fail(j, LAMD_ERR_ARG, "flush: bad n / runs"); return false; }
+  j->o_in.assign((const uint64_t *)sec(j, 0), (const uint64_t *)sec(j, 0) + seclen(j, 0) / 8);  // the server's own copy of the run table
+  size_t rows = 0, keybytes = 0;
+  for (uint64_t run : j->o_in) {
+    const size_t kl = (size_t)(run >> 32), cnt = (size_t)(run & 0xFFFFFFFFu);
+    if ((kl != 32 && kl != 33 && kl != 65) || cnt == 0 || cnt > n) { fail(j, LAMD_ERR_ARG, "flush: run with a bad key length or count"); return false; }
+    rows += cnt;
+    keybytes += kl * cnt;
+  }
+  if (rows != n) { fail(j, LAMD_ERR_ARG, "flush: runs do not add up to n"); return false; }
+  return shape(j, {seclen(j, 0), 32 * n, 64 * n, keybytes}, n);
+}
+void answer_async(job *j) {
+  {
+    std::lock_guard<std::mutex> lk(j->c->wmu);
+    send_all(j->c->fd, &j->rep, sizeof j->rep);  // a client that went away does not read it: nothing to do about that here
+  }
+  j->c->slot_pending[j->slot].fetch_sub(1);
+  j->c->async_pending.fetch_sub(1);
+  delete j;
+}
+// the oldest engine flush of this device: verdicts back to the clients it carried.  block = wait for it.  -> false when it is still running
+bool collect_one(bool block) {
+  flight &f = D->inflight.front();
+  if (D->okbuf.size() < f.rows + 1) D->okbuf.resize(f.rows + 1);
+  size_t n = 0;
+  const int rc = block ? E.wait(g_ctx, D->okbuf.data(), D->okbuf.size(), &n) : E.poll(g_ctx, D->okbuf.data(), D->okbuf.size(), &n);
+  if (rc == 0) return false;
+  size_t o = 0;
+  for (job *j : f.parts) {
+    if (j->rep.rc == LAMD_ERR_STATE) {  // not failed while it was queued
+      if (rc == 1 && n == f.rows) {
+        memcpy(outp(j, 0), &D->okbuf[o], j->queued_rows);
+        j->rep.rc = LAMD_OK;
+      } else if (rc < 0) {
+        engine_error(j, rc);
+      } else {
+        fail(j, LAMD_ERR_STATE, "engine flush returned another number of verdicts than were queued");
+      }
+    }
+    o += j->queued_rows;
+    answer_async(j);
+  }
+  D->inflight.pop_front();
+  return true;
+}
+void submit_flushes(std::vector<job *> &fl) {
+  if (fl.empty()) return;
+  flight cur;
+  auto launch = [&]() {
+    if (cur.parts.empty()) return;
+    if (cur.rows) {
+      while (D->inflight.size() >= ENGINE_FLUSHES_IN_FLIGHT) collect_one(true);
+      const int rc = E.flush(g_ctx);
+      stat_add(&g_stats.engine_flushes, 1);
+      stat_max(&g_stats.largest_engine_flush_requests, cur.parts.size());
+      stat_add(&g_stats.rows_by_device[D->id], cur.rows);
+      if (rc < 0)
+        for (job *j : cur.parts)
+          if (j->rep.rc == LAMD_ERR_STATE) engine_error(j, rc);
+      if (rc < 0) {  // nothing went to the device: answer now
+        for (job *j : cur.parts) answer_async(j);
+        cur = flight();
+        return;
+      }
+      D->inflight.push_back(std::move(cur));
+    } else {
+      for (job *j : cur.parts) answer_async(j);  // every part failed before a row was queued
+    }
+    cur = flight();
+  };
+  for (job *j : fl) {
+    stat_add(&g_stats.flushes, 1);
+    if (!flush_valid(j)) { answer_async(j); continue; }
+    const size_t n = (size_t)j->req.n;
+    stat_add(&g_stats.flush_rows, n);
+    if (cur.rows && cur.rows + n > g_max_merge) launch();
+    size_t o = 0, ko = 0;
+    for (uint64_t run : j->o_in) {
+      const size_t kl = (size_t)(run >> 32), cnt = (size_t)(run & 0xFFFFFFFFu);
+      const int rc = kl == 32 ? E.queue_schnorr(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 3) + ko, sec(j, 2) + 64 * o)
+                              : E.queue_ecdsa(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 2) + 64 * o, sec(j, 3) + ko, kl, kl);
+      if (rc < 0) {  // the rows queued so far stay in the set (their verdicts are dropped); this client gets the error
+        engine_error(j, rc);
+        break;
+      }
+      j->queued_rows += cnt;
+      o += cnt;
+      ko += kl * cnt;
+    }
+    cur.rows += j->queued_rows;
+    cur.parts.push_back(j);
+  }
+  launch();
+}
+
+void run_round(std::vector<job *> &round) {
+  // merge classes: ECDSA by key length, BIP-340; the rest in arrival order
+  std::vector<job *> e33, e65, sch;
+  size_t r33 = 0, r65 = 0, rs = 0;
+  for (job *j : round) {
+    const lamd_srv_req &r = j->req;
+    if (r.op == LAMD_SRV_OP_ECDSA || r.op == LAMD_SRV_OP_SCHNORR) {
+      const size_t n = (size_t)r.n, kl = r.op == LAMD_SRV_OP_SCHNORR ? 32 : (size_t)r.scalar[0];
+      if (!sane_n(j)) continue;
+      if (n == 0) { j->rep.rc = LAMD_OK; continue; }
+      if (r.op == LAMD_SRV_OP_ECDSA && kl != 33 && kl != 65) { fail(j, LAMD_ERR_ARG, "publen must be 33 or 65"); continue; }
+      if (r.op == LAMD_SRV_OP_ECDSA ? !shape(j, {32 * n, 64 * n, kl * n}, n) : !shape(j, {32 * n, 32 * n, 64 * n}, n)) continue;
+      std::vector<job *> &cls = r.op == LAMD_SRV_OP_SCHNORR ? sch : kl == 33 ? e33 : e65;
+      size_t &rows = r.op == LAMD_SRV_OP_SCHNORR ? rs : kl == 33 ? r33 : r65;
+      if (rows + n > g_max_merge && !cls.empty()) {  // a merged batch stays below --max-merge rows
+        run_merged(cls, r.op == LAMD_SRV_OP_SCHNORR);
+        cls.clear();
+        rows = 0;
+      }
+      cls.push_back(j);
+      rows += n;
+    }
+  }
+  run_merged(e33, false);
+  run_merged(e65, false);
+  run_merged(sch, true);
+  // commitment_signed validations and check_tx_sig batches under 33-byte keys: one device call for all that wait
+  std::vector<job *> txs;
+  size_t txrows = 0;
+  for (job *j : round) {
+    const lamd_srv_req &r = j->req;
+    const bool tx = r.op == LAMD_SRV_OP_COMMITMENT || (r.op == LAMD_SRV_OP_TXSIG_TX && r.scalar[0] == 33);
+    if (!tx || !sane_n(j) || !tx_valid(j)) continue;
+    if (txrows + (size_t)r.n > g_max_merge && !txs.empty()) { run_tx_merged(txs); txs.clear(); txrows = 0; }
+    txs.push_back(j);
+    txrows += (size_t)r.n;
+  }
+  run_tx_merged(txs);
+  for (job *j : round) {
+    const lamd_srv_req &r = j->req;
+    const bool tx = r.op == LAMD_SRV_OP_COMMITMENT || (r.op == LAMD_SRV_OP_TXSIG_TX && r.scalar[0] == 33);
+    if (r.op != LAMD_SRV_OP_ECDSA && r.op != LAMD_SRV_OP_SCHNORR && !tx && sane_n(j)) run_one(j);
+  }
+  {
+    std::lock_guard<std::mutex> lk(donemu);
+    for (job *j : round) j->done = true;
+  }
+  stat_add(&g_stats.requests, round.size());
+  donecv.notify_all();
+}
+
+void engine_loop(device *dev) {
+  D = dev;
   for (;;) {
-    std::vector<job *> round;
+    std::vector<job *> round, sync, fl;
     {
-      std::unique_lock<std::mutex> lk(qmu);
-      qcv.wait(lk, [] { return !Q.empty() || g_quit.load(); });
-      if (g_quit.load() && Q.empty()) return;
-      if (g_linger_us) {  // company for the first job of the round
+      std::unique_lock<std::mutex> lk(D->mu);
+      if (D->inflight.empty()) D->cv.wait(lk, [] { return !D->Q.empty() || g_quit.load(); });
+      else D->cv.wait_for(lk, std::chrono::microseconds(40), [] { return !D->Q.empty() || g_quit.load(); });  // flushes in flight: look for their verdicts in between
+      if (g_quit.load() && D->Q.empty() && D->inflight.empty()) return;
+      if (g_linger_us && !D->Q.empty() && D->inflight.empty()) {  // company for the first job of the round
         lk.unlock();
         std::this_thread::sleep_for(std::chrono::microseconds(g_linger_us));
         lk.lock();
       }
-      round.assign(Q.begin(), Q.end());
-      Q.clear();
+      round.assign(D->Q.begin(), D->Q.end());
+      D->Q.clear();
     }
-    // merge classes: ECDSA by key length, BIP-340; the rest in arrival order
-    std::vector<job *> e33, e65, sch;
-    size_t r33 = 0, r65 = 0, rs = 0;
-    for (job *j : round) {
-      const lamd_srv_req &r = j->req;
-      if (r.op == LAMD_SRV_OP_ECDSA || r.op == LAMD_SRV_OP_SCHNORR) {
-        const size_t n = (size_t)r.n, kl = r.op == LAMD_SRV_OP_SCHNORR ? 32 : (size_t)r.scalar[0];
-        if (!sane_n(j)) continue;
-        if (n == 0) { j->rep.rc = LAMD_OK; continue; }
-        if (r.op == LAMD_SRV_OP_ECDSA && kl != 33 && kl != 65) { fail(j, LAMD_ERR_ARG, "publen must be 33 or 65"); continue; }
-        if (r.op == LAMD_SRV_OP_ECDSA ? !shape(j, {32 * n, 64 * n, kl * n}, n) : !shape(j, {32 * n, 32 * n, 64 * n}, n)) continue;
-        std::vector<job *> &cls = r.op == LAMD_SRV_OP_SCHNORR ? sch : kl == 33 ? e33 : e65;
-        size_t &rows = r.op == LAMD_SRV_OP_SCHNORR ? rs : kl == 33 ? r33 : r65;
-        if (rows + n > g_max_merge && !cls.empty()) {  // a merged batch stays below --max-merge rows
-          run_merged(cls, r.op == LAMD_SRV_OP_SCHNORR);
-          cls.clear();
-          rows = 0;
-        }
-        cls.push_back(j);
-        rows += n;
-      }
+    for (job *j : round) (j->async ? fl : sync).push_back(j);
+    submit_flushes(fl);
+    if (!sync.empty()) {
+      while (!D->inflight.empty()) collect_one(true);  // the context runs the synchronous calls with nothing of the streaming queue outstanding
+      run_round(sync);
     }
-    run_merged(e33, false);
-    run_merged(e65, false);
-    run_merged(sch, true);
-    // commitment_signed validations and check_tx_sig batches under 33-byte keys: one device call for all that wait
-    std::vector<job *> txs;
-    size_t txrows = 0;
-    for (job *j : round) {
-      const lamd_srv_req &r = j->req;
-      const bool tx = r.op == LAMD_SRV_OP_COMMITMENT || (r.op == LAMD_SRV_OP_TXSIG_TX && r.scalar[0] == 33);
-      if (!tx || !sane_n(j) || !tx_valid(j)) continue;
-      if (txrows + (size_t)r.n > g_max_merge && !txs.empty()) { run_tx_merged(txs); txs.clear(); txrows = 0; }
-      txs.push_back(j);
-      txrows += (size_t)r.n;
-    }
-    run_tx_merged(txs);
-    for (job *j : round) {
-      const lamd_srv_req &r = j->req;
-      const bool tx = r.op == LAMD_SRV_OP_COMMITMENT || (r.op == LAMD_SRV_OP_TXSIG_TX && r.scalar[0] == 33);
-      if (r.op != LAMD_SRV_OP_ECDSA && r.op != LAMD_SRV_OP_SCHNORR && !tx && sane_n(j)) run_one(j);
-    }
-    {
-      std::lock_guard<std::mutex> lk(qmu);
-      for (job *j : round) j->done = true;
-      g_stats.requests += round.size();
-    }
-    donecv.notify_all();
+    while (!D->inflight.empty() && collect_one(false)) {}
   }
 }
 
-void serve(int fd) {
-  conn c;
-  c.fd = fd;
+// key affinity: the device a request's FIRST KEY hashes to (FNV-1a over its first 32 bytes); requests without a key go to device 0
+device *pick_device(const job *j) {
+  if (g_dev.size() == 1) return g_dev[0];
+  const lamd_srv_req &r = j->req;
+  int s = -1;
+  switch (r.op) {
+    case LAMD_SRV_OP_ECDSA: s = 2; break;
+    case LAMD_SRV_OP_SCHNORR: s = 1; break;
+    case LAMD_SRV_OP_PUBKEY_PARSE: s = 0; break;
+    case LAMD_SRV_OP_GOSSIP: s = r.scalar[0] ? 2 : 0; break;
+    case LAMD_SRV_OP_TXSIG_TX: s = 14; break;
+    case LAMD_SRV_OP_COMMITMENT: s = 13; break;
+    case LAMD_SRV_OP_BOLT12_CHECK: s = 4; break;
+    case LAMD_SRV_OP_FLUSH: s = 3; break;
+    default: break;
+  }
+  if (s < 0 || (uint32_t)s >= r.n_sections || seclen(j, s) < 32 || j->off[s] + 32 > j->c->shm[j->slot].size) return g_dev[0];
+  uint64_t h = 1469598103934665603ull;
+  const uint8_t *k = sec(j, s);
+  for (int i = 0; i < 32; i++) h = (h ^ k[i]) * 1099511628211ull;
+  return g_dev[(size_t)((h >> 17) % g_dev.size())];
+}
+
+void serve(conn *cp) {
+  conn &c = *cp;
+  const int fd = c.fd;
   {
-    std::lock_guard<std::mutex> lk(qmu);
+    std::lock_guard<std::mutex> lk(statmu);
     g_stats.clients_now++;
     g_stats.clients_total++;
   }
   for (;;) {
-    job j;
+    job *jp = new job;
+    job &j = *jp;
     int newfd = -1;
-    if (!recv_with_fd(fd, &j.req, sizeof j.req, &newfd)) break;
+    if (!recv_with_fd(fd, &j.req, sizeof j.req, &newfd)) { delete jp; break; }
     memset(&j.rep, 0, sizeof j.rep);
     j.rep.magic = LAMD_SRV_MAGIC;
     j.rep.rc = LAMD_ERR_STATE;  // a path that forgets to answer reads as a failure, never as "verified"
     j.c = &c;
-    if (j.req.magic != LAMD_SRV_MAGIC) { if (newfd >= 0) close(newfd); break; }
+    if (j.req.magic != LAMD_SRV_MAGIC) { if (newfd >= 0) close(newfd); delete jp; break; }
+    auto reply = [&]() {
+      std::lock_guard<std::mutex> lk(c.wmu);
+      return send_all(fd, &j.rep, sizeof j.rep);
+    };
     if (j.req.op == LAMD_SRV_OP_SHM) {
-      const size_t sz = (size_t)j.req.scalar[0];
+      const size_t sz = (size_t)j.req.scalar[0], slot = (size_t)j.req.scalar[1];
       struct stat sb;
-      if (newfd < 0 || sz < 4096 || fstat(newfd, &sb) != 0 || (size_t)sb.st_size < sz) {
+      if (newfd < 0 || sz < 4096 || slot > LAMD_SRV_FLUSH_SLOTS || fstat(newfd, &sb) != 0 || (size_t)sb.st_size < sz) {
         if (newfd >= 0) close(newfd);
-        fail(&j, LAMD_ERR_ARG, "LAMD_SRV_OP_SHM without a usable descriptor");
+        fail(&j, LAMD_ERR_ARG, "LAMD_SRV_OP_SHM without a usable descriptor / slot");
+      } else if (slot && c.slot_pending[slot].load()) {  // a flush block is replaced only while no flush is in flight in it (the client library makes sure)
+        close(newfd);
+        fail(&j, LAMD_ERR_STATE, "LAMD_SRV_OP_SHM on a flush slot whose flush is outstanding");
       } else {
         void *p = mmap(nullptr, sz, PROT_READ | PROT_WRITE, MAP_SHARED, newfd, 0);
         close(newfd);
         if (p == MAP_FAILED) fail(&j, LAMD_ERR_NOMEM, "mmap of the client's block failed");
         else {
-          if (c.shm) munmap(c.shm, c.shm_size);
-          c.shm = (uint8_t *)p;
-          c.shm_size = sz;
+          if (c.shm[slot].p) munmap(c.shm[slot].p, c.shm[slot].size);
+          c.shm[slot].p = (uint8_t *)p;
+          c.shm[slot].size = sz;
           j.rep.rc = LAMD_OK;
         }
       }
-      if (!send_all(fd, &j.rep, sizeof j.rep)) break;
+      const bool ok = reply();
+      delete jp;
+      if (!ok) break;
       continue;
     }
     if (newfd >= 0) close(newfd);
+    j.async = j.req.op == LAMD_SRV_OP_FLUSH;
+    j.slot = (int)j.req.slot;
+    j.rep.seq = j.async ? j.req.scalar[0] : 0;
     j.out_off = layout(j.req, j.off);
-    if (!c.shm || j.out_off == (size_t)-1 || j.out_off > c.shm_size) {
-      fail(&j, LAMD_ERR_ARG, "request does not fit the shared block");
-    } else {
-      j.rep.out_offset = j.out_off;
-      std::unique_lock<std::mutex> lk(qmu);
-      Q.push_back(&j);
-      qcv.notify_one();
+    const bool slot_ok = j.req.slot <= LAMD_SRV_FLUSH_SLOTS && (j.async ? j.req.slot >= 1 && j.req.scalar[0] != 0 : j.req.slot == 0);
+    if (!slot_ok || !c.shm[j.slot].p || j.out_off == (size_t)-1 || j.out_off > c.shm[j.slot].size) {
+      if (!slot_ok) j.slot = 0;
+      fail(&j, LAMD_ERR_ARG, "request does not fit its shared block");
+      const bool ok = reply();
+      delete jp;
+      if (!ok) break;
+      continue;
+    }
+    j.rep.out_offset = j.out_off;
+    device *dev = pick_device(&j);
+    if (j.async) {  // handed over: the engine thread answers and deletes it
+      c.async_pending.fetch_add(1);
+      c.slot_pending[j.slot].fetch_add(1);
+      std::lock_guard<std::mutex> lk(dev->mu);
+      dev->Q.push_back(jp);
+      dev->cv.notify_one();
+      continue;
+    }
+    {
+      std::lock_guard<std::mutex> lk(dev->mu);
+      dev->Q.push_back(jp);
+      dev->cv.notify_one();
+    }
+    {
+      std::unique_lock<std::mutex> lk(donemu);
       donecv.wait(lk, [&] { return j.done; });
     }
-    if (!send_all(fd, &j.rep, sizeof j.rep)) break;
+    const bool ok = reply();
+    delete jp;
+    if (!ok) break;
   }
-  if (c.shm) munmap(c.shm, c.shm_size);
+  while (c.async_pending.load() > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));  // engine threads still write into the blocks
+  for (blk &b : c.shm)
+    if (b.p) munmap(b.p, b.size);
   close(fd);
-  std::lock_guard<std::mutex> lk(qmu);
+  delete cp;
+  std::lock_guard<std::mutex> lk(statmu);
   g_stats.clients_now--;
 }
 
@@ -488,20 +710,31 @@ void on_term(int) {
 int main(int argc, char **argv) {
   std::string sock, engine, why;
   default_socket(&sock, &why);
-  int device = 0;
+  std::vector<int> devices;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
     auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
     if (a == "--socket") sock = val();
-    else if (a == "--device") device = atoi(val());
+    else if (a == "--device") devices.assign(1, atoi(val()));
+    else if (a == "--devices") {
+      devices.clear();
+      for (const char *s = val(); *s;) {
+        char *e = nullptr;
+        devices.push_back((int)strtol(s, &e, 10));
+        if (e == s) { devices.clear(); break; }
+        s = *e == ',' ? e + 1 : e;
+      }
+    }
     else if (a == "--engine") engine = val();
     else if (a == "--max-merge") g_max_merge = (size_t)atoll(val());
     else if (a == "--linger-us") g_linger_us = (unsigned)atoi(val());
     else {
-      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N] [--engine LIB] [--max-merge ROWS] [--linger-us US]\n");
+      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--linger-us US]\n");
       return 2;
     }
   }
+  if (devices.empty()) devices.assign(1, 0);
+  if (devices.size() > LAMD_SRV_MAX_DEVICES) { fprintf(stderr, "lamd_served: at most %d devices\n", LAMD_SRV_MAX_DEVICES); return 2; }
   if (sock.empty()) { fprintf(stderr, "lamd_served: %s\n", why.c_str()); return 2; }
   if (engine.empty()) {  // liblightning_amd.so next to this executable
     char self[4096];
@@ -517,15 +750,25 @@ int main(int argc, char **argv) {
             bind(E.lib, "lamd_pubkey_parse_batch", &E.pubkey_parse) & bind(E.lib, "lamd_sigcheck_gossip_batch", &E.gossip) &
             bind(E.lib, "lamd_check_tx_sig_tx_batch", &E.txsig_tx) & bind(E.lib, "lamd_check_commitment_signed", &E.commitment) &
             bind(E.lib, "lamd_bolt12_check_signature_batch", &E.bolt12_check) & bind(E.lib, "lamd_bolt12_merkle_batch", &E.bolt12_merkle) &
-            bind(E.lib, "lamd_ecdsa_recover_batch", &E.recover) & bind(E.lib, "lamd_grind_htlc_tx_fee", &E.grind);
+            bind(E.lib, "lamd_ecdsa_recover_batch", &E.recover) & bind(E.lib, "lamd_grind_htlc_tx_fee", &E.grind) &
+            bind(E.lib, "lamd_queue_ecdsa_batch", &E.queue_ecdsa) & bind(E.lib, "lamd_queue_schnorr_batch", &E.queue_schnorr) &
+            bind(E.lib, "lamd_flush", &E.flush) & bind(E.lib, "lamd_poll", &E.poll) & bind(E.lib, "lamd_wait", &E.wait);
   if (!ok) return 1;
-  const int rc = E.init(&g_ctx, device);
-  if (rc != LAMD_OK) {
-    fprintf(stderr, "lamd_served: lamd_init(device %d) failed (%d): %s\n", device, rc, g_ctx ? E.last_error(g_ctx) : "no device");
-    if (g_ctx) E.shutdown(g_ctx);
-    return 1;  // no engine, no service: there is no CPU verification to fall back to
-  }
   memset(&g_stats, 0, sizeof g_stats);
+  for (size_t k = 0; k < devices.size(); k++) {
+    device *dev = new device;
+    dev->id = (int)k;
+    const int rc = E.init(&dev->ctx, devices[k]);
+    if (rc != LAMD_OK) {
+      fprintf(stderr, "lamd_served: lamd_init(device %d) failed (%d): %s\n", devices[k], rc, dev->ctx ? E.last_error(dev->ctx) : "no device");
+      if (dev->ctx) E.shutdown(dev->ctx);
+      for (device *d : g_dev) E.shutdown(d->ctx);
+      return 1;  // no engine, no service: there is no CPU verification to fall back to
+    }
+    g_dev.push_back(dev);
+  }
+  g_stats.devices = g_dev.size();
+  auto shutdown_all = [] { for (device *d : g_dev) E.shutdown(d->ctx); };
   g_listen = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
   struct sockaddr_un sa;
   memset(&sa, 0, sizeof sa);
@@ -536,7 +779,7 @@ int main(int argc, char **argv) {
   if (lstat(sock.c_str(), &old) == 0) {  // a stale socket of OURS is replaced; anything else at the path is somebody else's business
     if (!S_ISSOCK(old.st_mode) || old.st_uid != geteuid() || unlink(sock.c_str()) != 0) {
       fprintf(stderr, "lamd_served: %s exists and is not a socket of uid %lu: not replacing it\n", sock.c_str(), (unsigned long)geteuid());
-      E.shutdown(g_ctx);
+      shutdown_all();
       return 1;
     }
   }
@@ -545,14 +788,16 @@ int main(int argc, char **argv) {
   umask(um);
   if (!bound) {
     perror("lamd_served: bind/listen");
-    E.shutdown(g_ctx);
+    shutdown_all();
     return 1;
   }
   signal(SIGTERM, on_term);
   signal(SIGINT, on_term);
   signal(SIGPIPE, SIG_IGN);
-  std::thread eng(engine_loop);
-  printf("lamd_served: ready on %s (device %d, engine %s)\n", sock.c_str(), device, engine.c_str());
+  for (device *d : g_dev) d->th = std::thread(engine_loop, d);
+  std::string devs;
+  for (size_t k = 0; k < devices.size(); k++) devs += (k ? "," : "") + std::to_string(devices[k]);
+  printf("lamd_served: ready on %s (device %s, engine %s)\n", sock.c_str(), devs.c_str(), engine.c_str());
   fflush(stdout);
   std::vector<std::thread> readers;
   while (!g_quit.load()) {
@@ -567,17 +812,22 @@ int main(int argc, char **argv) {
       close(fd);
       continue;
     }
-    readers.emplace_back(serve, fd);
+    conn *c = new conn;
+    c->fd = fd;
+    readers.emplace_back(serve, c);
   }
   g_quit.store(true);
-  qcv.notify_all();
-  eng.join();
+  for (device *d : g_dev) {
+    d->cv.notify_all();
+    d->th.join();
+  }
   for (auto &t : readers) t.detach();  // blocked in recv on connections their clients still hold; the process is leaving
   close(g_listen);
   unlink(sock.c_str());
-  E.shutdown(g_ctx);
-  printf("lamd_served: %llu requests, %llu engine calls, %llu requests in merged calls (largest merge %llu)\n", (unsigned long long)g_stats.requests,
-         (unsigned long long)g_stats.engine_calls, (unsigned long long)g_stats.merged_requests, (unsigned long long)g_stats.largest_merge_requests);
+  shutdown_all();
+  printf("lamd_served: %llu requests, %llu engine calls, %llu requests in merged calls (largest merge %llu); %llu flushes in %llu engine flushes\n",
+         (unsigned long long)g_stats.requests, (unsigned long long)g_stats.engine_calls, (unsigned long long)g_stats.merged_requests,
+         (unsigned long long)g_stats.largest_merge_requests, (unsigned long long)g_stats.flushes, (unsigned long long)g_stats.engine_flushes);
   fflush(stdout);
   _exit(0);
 }

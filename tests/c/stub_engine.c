@@ -6,7 +6,9 @@
 
 #include "lightning_amd.h"
 
-struct lamd_ctx { int device; unsigned long calls, rows, largest; char err[64]; };
+#define STUB_SETS 16
+struct stub_set { uint8_t *ok; size_t n, cap; int polled; };
+struct lamd_ctx { int device; unsigned long calls, rows, largest; char err[64]; struct stub_set open, closed[STUB_SETS]; int head, count; };
 
 int lamd_init(lamd_ctx **ctx, int device) {
 	*ctx = calloc(1, sizeof **ctx);
@@ -117,4 +119,56 @@ int lamd_grind_htlc_tx_fee(lamd_ctx *ctx, const uint8_t *preimage, size_t preima
 	*feerate = min_feerate + (uint32_t)((preimage_len + outputs_len) % (max_feerate - min_feerate + 1));
 	*fee = (uint64_t)*feerate * weight / 1000 + input_sat % 7;
 	return 1;
+}
+
+/* ---- the streaming queue (include/lightning_amd.h "streaming"): the open set collects verdict bytes in ticket order, lamd_flush closes it,
+ * lamd_poll / lamd_wait hand the OLDEST closed set back.  Verdicts are the functions of the synchronous calls above; lamd_poll reports the
+ * oldest flush "still running" once (the server must come back for it), as a busy engine would. */
+#define g_open (ctx->open)
+#define g_closed (ctx->closed)
+#define g_head (ctx->head)
+#define g_count (ctx->count)
+static void push_ok(lamd_ctx *ctx, uint8_t v) {
+	if (g_open.n == g_open.cap) { g_open.cap = g_open.cap ? 2 * g_open.cap : 1024; g_open.ok = realloc(g_open.ok, g_open.cap); }
+	g_open.ok[g_open.n++] = v;
+}
+int lamd_queue_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *h, const uint8_t *s, const uint8_t *p, size_t publen, size_t stride) {
+	const int first = (int)g_open.n;
+	if (n && h[0] == 0xEE && h[1] == 0xEE) { strcpy(ctx->err, "stub: poisoned batch"); return LAMD_ERR_HIP; }
+	for (size_t i = 0; i < n; i++) push_ok(ctx, (h[32 * i] ^ s[64 * i + 63] ^ p[stride * i + publen - 1]) & 1);
+	ctx->rows += n;
+	return first;
+}
+int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *m, const uint8_t *x, const uint8_t *s) {
+	const int first = (int)g_open.n;
+	for (size_t i = 0; i < n; i++) push_ok(ctx, (m[32 * i + 1] ^ x[32 * i + 2] ^ s[64 * i + 3]) & 1);
+	ctx->rows += n;
+	return first;
+}
+int lamd_flush(lamd_ctx *ctx) {
+	if (!g_open.n) return LAMD_OK;
+	if (g_count == STUB_SETS) { strcpy(ctx->err, "stub: too many flushes outstanding"); return LAMD_ERR_STATE; }
+	g_closed[(g_head + g_count++) % STUB_SETS] = g_open;
+	memset(&g_open, 0, sizeof g_open);
+	note(ctx, 0);
+	return LAMD_OK;
+}
+static int take(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+	if (g_closed[g_head].n > cap) return LAMD_ERR_ARG;
+	memcpy(ok, g_closed[g_head].ok, g_closed[g_head].n);
+	*n = g_closed[g_head].n;
+	free(g_closed[g_head].ok);
+	memset(&g_closed[g_head], 0, sizeof g_closed[0]);
+	g_head = (g_head + 1) % STUB_SETS;
+	g_count--;
+	return 1;
+}
+int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+	if (!g_count) return LAMD_ERR_STATE;
+	if (!g_closed[g_head].polled++) return 0;
+	return take(ctx, ok, cap, n);
+}
+int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
+	if (!g_count) return LAMD_ERR_STATE;
+	return take(ctx, ok, cap, n);
 }

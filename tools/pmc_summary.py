@@ -67,6 +67,26 @@ for k in sorted(vals):
         lines.append("  %-22s %.6g" % (c, d[c]))
     summary[k] = d
     lines.append("")
+# ---- the whole step's VALU work, kernel by kernel (round 6: the pipeline is priced as one thing -- every kernel of a step competes for the same
+# issue slots): SQ_INSTS_VALU summed over EVERY dispatch of a kernel in the process / the steps the process ran (2 table-driven launches per step)
+step_valu, n_big = collections.defaultdict(float), 0
+for r in load("sq", "counter_collection"):
+    k = short(r["Kernel_Name"])
+    if r["Counter_Name"] != "SQ_INSTS_VALU" or not k.startswith("k_") or k.startswith("k_gen") or k.startswith("k_gtable") or k.startswith("k_mul32"):
+        continue
+    step_valu[k] += float(r["Counter_Value"])
+    if k.startswith("k_ecmult_keyed<false") and int(r["Grid_Size"]) >= 500000:
+        n_big += 1
+steps_run = max(1, n_big // 2)
+step_valu = {k: v / steps_run for k, v in step_valu.items()}
+tot = sum(step_valu.values())
+lines += ["[VALU wave-instructions per STEP (1 M ECDSA-65 + 1 M BIP-340), every dispatch of the process / %d steps]" % steps_run]
+for k, v in sorted(step_valu.items(), key=lambda kv: -kv[1]):
+    if v > 0:
+        lines.append("  %-32s %.4g  (%.1f %%)" % (k, v, 100 * v / tot))
+lines += ["  %-32s %.4g" % ("total", tot),
+          "  issue time of the total at one wave-instruction per SIMD and 4 cycles (1024 SIMDs): %.3f ms at 2.0 GHz" % (tot * 4 / 1024 / 2.0e9 * 1e3), ""]
+
 cand = [k for k in summary if k.startswith("k_ecmult_keyed") and "[ecdsa]" in k and summary[k].get("SQ_INSTS_VALU", 0) > 0] or \
        [k for k in summary if k.startswith("k_ecmult") and "[ecdsa]" in k]
 hot = max(cand, key=lambda k: summary[k].get("SQ_INSTS_VALU", 0))   # the table-driven kernel that does the work (not the empty careful / 10-tooth launches)
@@ -121,6 +141,7 @@ json.dump({"k_ecmult_ecdsa_1M": {"kernel": kname, "hbm_bytes_per_launch": hbm, "
                                   "valu_insts_per_verify": e["SQ_INSTS_VALU"] / nwaves,
                                   "valu_issue_per_simd_cycle": e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8),
                                   "fetch_size_factor": factor, "fetch_size_calibration": calib,
+                                  "step_valu_wave_instr": step_valu, "step_valu_wave_instr_total": tot, "steps_in_pmc_run": steps_run,
                                   "source": outp + "_pmc_summary.txt (rocprofv3 --pmc of `bench.py --roofline-only`, separate passes; FETCH_SIZE x %.3f, %s)" % (factor, fsrc)}},
           open(outp + "_pmc_latest.json", "w"), indent=1)
 # (run on the GPU box the output prefix lies under gpurun_out/: copy <prefix>_pmc_latest.json to profiles/pmc_latest.json, which bench.py reads)
