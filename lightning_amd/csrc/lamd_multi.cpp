@@ -40,58 +40,20 @@ struct rccl_api {
   int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
-// "each GPU has its own pinned staging ring and stream".  The caller's rows are pageable; a device's host thread copies them
-// piece by piece into the device's ring of pinned slots and queues one asynchronous H2D per piece on the device's copy stream -- the thread
-// is filling slot k+1 while the copy engine drains slot k, and the engine's kernels wait for the copy stream on the device (lamd_wait_stream),
-// never the host.  (Rounds 1-4: hipMemcpy() straight from pageable memory -- the runtime stages such a copy through its own small bounce
-// buffers and the thread sleeps until the last byte has landed; LAMD_MULTI_PINNED=0 restores that.)
+// SURVEY 8(e) words it "each GPU has its own pinned staging ring and stream".  What a device has here: its own copy stream, and TWO ways in.
+// Caller memory that is page-locked goes down that stream as one asynchronous copy per array (no staging, the host thread does not wait, the
+// engine's kernels wait for the copy stream on the device: lamd_wait_stream).  Pageable caller memory goes through the runtime's own staged
+// hipMemcpy().  A per-device ring of pinned slots filled by the device's host thread (plus a helper thread) was built in round 5 and measured
+// SLOWER than the runtime's path on one MI355X -- 96-103 against 105-113 M ECDSA-65 rows/s for a 1 M-row call, profiles/r05_ab_variants.txt: both
+// copy out of pageable memory with one or two cores (12-15 GB/s each), the runtime's staging copy is the better tuned of the two and overlaps its
+// own DMA -- and was deleted in round 6 rather than kept behind a switch.
 struct eng_dev {
   int device = 0;
   lamd_ctx *ctx = nullptr;
   hipStream_t gstream = nullptr;  // the collective's stream on this device
   ncclComm_t comm = nullptr;
-  enum { SLOTS = 4 };
-  hipStream_t cstream = nullptr;  // H2D copies out of the staging ring
-  uint8_t *pin[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t pin_ev[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
-  bool pin_busy[SLOTS] = {false, false, false, false};
-  size_t pin_bytes = 0;           // per slot; 0: staging off (pageable hipMemcpy)
-  unsigned pin_next = 0;
+  hipStream_t cstream = nullptr;  // H2D copies of page-locked caller memory
   bool copies_pending = false;    // the copy stream holds work the next verification has to wait for
-  // one helper thread per device copies the upper half of every staged piece while the device's own thread copies the lower half: one core
-  // moves 12-15 GB/s out of pageable memory, a PCIe gen5 link takes 50+ (measured round 5: one thread 95.7 M ECDSA-65 rows/s, below the 105 M/s of
-  // the runtime's own pageable path it was meant to beat)
-  std::thread helper;
-  std::mutex hmu;
-  std::condition_variable hcv;
-  const uint8_t *hsrc = nullptr;
-  uint8_t *hdst = nullptr;
-  size_t hbytes = 0;
-  bool hbusy = false, hquit = false;
-  void helper_loop() {
-    std::unique_lock<std::mutex> lk(hmu);
-    for (;;) {
-      hcv.wait(lk, [&] { return hbusy || hquit; });
-      if (hquit) return;
-      const uint8_t *sp = hsrc;
-      uint8_t *dp = hdst;
-      const size_t nb = hbytes;
-      lk.unlock();
-      memcpy(dp, sp, nb);
-      lk.lock();
-      hbusy = false;
-      hcv.notify_all();
-    }
-  }
-  void helper_post(uint8_t *dst, const uint8_t *src, size_t bytes) {
-    std::lock_guard<std::mutex> lk(hmu);
-    hdst = dst; hsrc = src; hbytes = bytes; hbusy = true;
-    hcv.notify_all();
-  }
-  void helper_wait() {
-    std::unique_lock<std::mutex> lk(hmu);
-    hcv.wait(lk, [&] { return !hbusy; });
-  }
 };
 // caller memory that is already page-locked (hipHostMalloc / hipHostRegister) needs no staging: the copy engine reads it where it lies
 bool is_pinned_host(const void *p) {
@@ -131,29 +93,10 @@ int eng_open(void *user, int device, void **handle) {
     delete d;
     return LAMD_ERR_HIP;
   }
-  // LAMD_MULTI_PINNED = bytes per staging slot; default 0 = no ring: on one MI355X the runtime's own pageable path measured FASTER than the ring
-  // (105-113 against 96-103 M ECDSA-65 rows/s for a 1 M-row call, helper thread included: profiles/r05_ab_variants.txt) -- both are bound by
-  // one or two cores copying out of pageable memory.  What does pay is caller memory that is ALREADY page-locked: eng_h2d sends it as one
-  // asynchronous copy per array (no staging, the thread does not wait).
-  size_t slot = 0;
-  if (const char *e = getenv("LAMD_MULTI_PINNED")) slot = (size_t)atoll(e);
   if (hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking) != hipSuccess) {
     st->fail("hipStreamCreate failed");
     *handle = d;
     return LAMD_ERR_HIP;
-  }
-  if (slot) {
-    if (slot < (64u << 10)) slot = 64u << 10;
-    bool ok = true;
-    for (int k = 0; k < eng_dev::SLOTS && ok; k++)
-      ok = hipHostMalloc((void **)&d->pin[k], slot, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&d->pin_ev[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-      st->fail("pinned staging ring: allocation failed (device " + std::to_string(device) + ")");
-      *handle = d;  // eng_close() releases what exists
-      return LAMD_ERR_NOMEM;
-    }
-    d->pin_bytes = slot;
-    if (!getenv("LAMD_MULTI_HELPER") || atoi(getenv("LAMD_MULTI_HELPER")) != 0) d->helper = std::thread([d] { d->helper_loop(); });
   }
   *handle = d;
   return LAMD_OK;
@@ -162,15 +105,7 @@ void eng_close(void *, void *handle) {
   eng_dev *d = (eng_dev *)handle;
   if (!d) return;
   (void)hipSetDevice(d->device);
-  if (d->helper.joinable()) {
-    { std::lock_guard<std::mutex> lk(d->hmu); d->hquit = true; d->hcv.notify_all(); }
-    d->helper.join();
-  }
   if (d->cstream) (void)hipStreamSynchronize(d->cstream);
-  for (int k = 0; k < eng_dev::SLOTS; k++) {
-    if (d->pin_ev[k]) (void)hipEventDestroy(d->pin_ev[k]);
-    if (d->pin[k]) (void)hipHostFree(d->pin[k]);
-  }
   if (d->cstream) (void)hipStreamDestroy(d->cstream);
   if (d->gstream) (void)hipStreamDestroy(d->gstream);
   if (d->ctx) lamd_shutdown(d->ctx);
@@ -194,28 +129,6 @@ int eng_h2d(void *user, void *handle, void *dst, const void *src, size_t bytes) 
       return LAMD_ERR_HIP;
     }
     d->copies_pending = true;
-    return LAMD_OK;
-  }
-  if (d->pin_bytes) {
-    for (size_t o = 0; o < bytes;) {
-      const unsigned k = d->pin_next++ % eng_dev::SLOTS;
-      const size_t c = bytes - o < d->pin_bytes ? bytes - o : d->pin_bytes;
-      bool ok = !d->pin_busy[k] || hipEventSynchronize(d->pin_ev[k]) == hipSuccess;  // the slot's previous copy has left it
-      if (ok) {
-        const size_t half = d->helper.joinable() && c >= (256u << 10) ? (c / 2) & ~(size_t)63 : c;
-        if (half < c) d->helper_post(d->pin[k] + half, (const uint8_t *)src + o + half, c - half);
-        memcpy(d->pin[k], (const uint8_t *)src + o, half);
-        if (half < c) d->helper_wait();
-        ok = hipMemcpyAsync((uint8_t *)dst + o, d->pin[k], c, hipMemcpyHostToDevice, d->cstream) == hipSuccess && hipEventRecord(d->pin_ev[k], d->cstream) == hipSuccess;
-      }
-      if (!ok) {
-        ((eng_state *)user)->fail("staged H2D failed (device " + std::to_string(d->device) + ")");
-        return LAMD_ERR_HIP;
-      }
-      d->pin_busy[k] = true;
-      d->copies_pending = true;
-      o += c;
-    }
     return LAMD_OK;
   }
   // synchronous: the caller's memory is pageable, the runtime stages it; the engine's (asynchronous) kernels of the chunk before run meanwhile

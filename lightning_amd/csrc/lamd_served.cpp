@@ -2,7 +2,7 @@
 // Protocol and rationale: include/lightning_amd_served.h.  SURVEY.md section 7 "Process model": one channeld per channel
 // (channeld/channeld.c:7019-7129), gossipd, lightningd and plugins are separate single-threaded processes that verify inline.
 //
-//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--linger-us US]
+//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US]
 //
 // Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job; a synchronous job it waits for and answers, a
 // flush it hands over and goes on reading); ONE engine thread PER DEVICE, the only caller of that device's context (a context is not
@@ -122,6 +122,11 @@ std::atomic<bool> g_quit{false};
 std::mutex statmu;
 lamd_srv_stats g_stats;
 size_t g_max_merge = (size_t)1 << 20;
+// rows of one ENGINE flush that client flushes are merged into.  Merging is for SMALL flushes (one commitment_signed = 484 rows: a hundred of them
+// share one engine flush); beyond a few 10^4 rows a larger batch buys no GPU efficiency and costs pipelining -- and a staging set that has to grow to
+// a size it never had is a pinned allocation of tens of milliseconds in the middle of a stream.  Measured (profiles/r06_served_stream.txt: eight
+// clients streaming 31 k-row flushes): unbounded 0.25 of one in-process producer's rate, 262 144 rows 0.41, 131 072 0.69, 65 536 0.77.
+size_t g_max_flush_rows = (size_t)1 << 16;
 unsigned g_linger_us = 0;
 const size_t ENGINE_FLUSHES_IN_FLIGHT = 8;
 
@@ -485,7 +490,7 @@ void submit_flushes(std::vector<job *> &fl) {
     if (!flush_valid(j)) { answer_async(j); continue; }
     const size_t n = (size_t)j->req.n;
     stat_add(&g_stats.flush_rows, n);
-    if (cur.rows && cur.rows + n > g_max_merge) launch();
+    if (cur.rows && cur.rows + n > g_max_flush_rows) launch();
     size_t o = 0, ko = 0;
     for (uint64_t run : j->o_in) {
       const size_t kl = (size_t)(run >> 32), cnt = (size_t)(run & 0xFFFFFFFFu);
@@ -727,9 +732,10 @@ int main(int argc, char **argv) {
     }
     else if (a == "--engine") engine = val();
     else if (a == "--max-merge") g_max_merge = (size_t)atoll(val());
+    else if (a == "--max-flush-rows") g_max_flush_rows = (size_t)atoll(val());
     else if (a == "--linger-us") g_linger_us = (unsigned)atoi(val());
     else {
-      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--linger-us US]\n");
+      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US]\n");
       return 2;
     }
   }

@@ -120,6 +120,20 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_gossip_weights_of_short_and_empty_messages():
+    """a batch whose last message is shorter than its type field (or empty) has weight 1, as lamd_multi_sigcheck_gossip_batch has it --
+    it used to raise IndexError"""
+    cann, cupd = bytes([1, 0]) + bytes(10), bytes([1, 2]) + bytes(4)
+    msgs = [cann, cupd, b"\x01", b"", cann, b""]
+    blob = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(m) for m in msgs])]).astype(np.uint64)
+    w = sharding.gossip_weights(blob, off)
+    assert w.tolist() == [sharding.GOSSIP_WEIGHT_CANN, 1, 1, 1, sharding.GOSSIP_WEIGHT_CANN, 1]
+    assert sharding.gossip_weights(np.zeros(0, np.uint8), np.zeros(3, np.uint64)).tolist() == [1, 1]
+    b = sharding.shard_bounds(len(msgs), 2, None, w)
+    assert b[0] == 0 and b[-1] == len(msgs)
+
+
 def test_two_rank_shard_and_all_gather():
     world = 2
     ctx = mp.get_context("spawn")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""lamd_multi_verify_ecdsa_batch from PAGEABLE caller memory on the devices of this box: rows/s with the per-device pinned staging ring
-(default) -- run with LAMD_MULTI_PINNED=0 for the synchronous pageable hipMemcpy of rounds 1-4.  Also checks the NULL-node_ids refusal."""
+"""lamd_multi_verify_ecdsa_batch from PAGEABLE caller memory on the devices of this box: rows/s through the runtime's staged hipMemcpy (the
+per-device pinned ring this probe compared it with in round 5 lost and was deleted in round 6: lamd_multi.cpp).  Also checks the NULL-node_ids refusal."""
 import ctypes
 import os
 import sys
@@ -52,7 +52,7 @@ def main():
     v = np.zeros(1, np.int8)
     rc = lib.lamd_multi_sigcheck_gossip_batch(m, 1, blob.ctypes.data, off.ctypes.data, None, v.ctypes.data)
     print("pinned=%s devices=%d rows=%d: best %.1f M ECDSA-65/s from pageable memory (%.2f ms; calls: %s) | NULL node_ids rc=%d (%s)" % (
-        os.environ.get("LAMD_MULTI_PINNED", "default"), ndev, n, n / min(ts[1:]) / 1e6, min(ts[1:]) * 1e3, " ".join("%.1f" % (x * 1e3) for x in ts), rc,
+        "runtime-staged", ndev, n, n / min(ts[1:]) / 1e6, min(ts[1:]) * 1e3, " ".join("%.1f" % (x * 1e3) for x in ts), rc,
         lib.lamd_multi_last_error(m).decode()))
     lib.lamd_multi_shutdown(m)
 
