@@ -427,7 +427,7 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
                 keep.update(stream_shard(eng, st, bb, k, grp, depth, first))
                 for kind in ("ecdsa", "schnorr"):
                     gather(torch.from_numpy(keep[kind]).to(device))
-            shard_ms.append(best(one, 3) * 1e3)
+            shard_ms.append(best(one, 3 if W < 4 else 5) * 1e3)      # short shards: more repetitions (a 5 ms shard that meets one hiccup reads 10 ms)
             for kind, got in keep.items():
                 bad5 += int((got.astype(bool) != st[kind].expect[int(bb[kind][k]):int(bb[kind][k + 1])]).sum())
         res5[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms), "shard_commitments": [int((bb["ecdsa"][k + 1] - bb["ecdsa"][k] + bb["schnorr"][k + 1] - bb["schnorr"][k]) // per) for k in range(W)]}
