@@ -101,6 +101,9 @@ constexpr int SLOT_WORDS = LAMD_TABLE_LIMBS ? 288 : 256;             // scratch 
 #ifndef LAMD_G_RUN_XYZZ
 #define LAMD_G_RUN_XYZZ 1
 #endif
+#ifndef LAMD_UNROLL_HALF
+#define LAMD_UNROLL_HALF 0
+#endif
 constexpr int GTABLE_WINDOW_BITS = LAMD_GTABLE_WINDOW_BITS;
 constexpr int GTABLE_WINDOWS = (256 + GTABLE_WINDOW_BITS - 1) / GTABLE_WINDOW_BITS;
 constexpr size_t GTABLE_ENTRIES = (size_t)GTABLE_WINDOWS << GTABLE_WINDOW_BITS;
@@ -768,7 +771,13 @@ LAMD_HD gexz ecmult_lane_keyed_fast(const prep_rec &rec, const u32 *tab, const u
 #pragma unroll 1
   for (int j = D - 1; j >= 0; j--) {
     if (j != D - 1) acc = gej_double(acc);
+    // (-DLAMD_UNROLL_HALF=1, an experiment: both additions of a column as straight-line code -- the accumulator's 27 registers are copied at
+    // the column loop's back edge only, not after every addition; 12 KB more code.  profiles/r06_ab_variants.txt)
+#if LAMD_UNROLL_HALF
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int half = 0; half < 2; half++) {
       u32 m = 0;
 #pragma unroll
