@@ -481,6 +481,31 @@ __device__ __forceinline__ u32 wave_alloc(u32 *counter, bool pred, u32 weight, u
   return base + prefix;
 }
 
+// Block-aggregated allocation from up to four global counters at once (round 6), for 256-thread blocks in which EVERY thread calls it: the counters
+// of a call's plan are single words that every wave of the call bumps -- 13 600 waves x 2-4 contended atomics were the 0.3 ms the list builders took
+// for 875 k rows (profiles/r06_shard_timeline_cold.txt).  A block's four waves leave their counts in LDS, four threads do one atomic each for the
+// block, every lane adds its prefix inside its wave.  pos[c] = the index lane got from counter c (meaningful where pr[c] holds).
+__device__ __forceinline__ void block_alloc4(u32 *const counters[4], const bool pr[4], u32 pos[4]) {
+  __shared__ u32 s_cnt[4][4], s_base[4][4];
+  const u32 lane = threadIdx.x & 63u, wave = (threadIdx.x >> 6) & 3u;
+  u32 pre[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const u64 m = __ballot(pr[c]);
+    pre[c] = (u32)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_cnt[wave][c] = (u32)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const u32 c = threadIdx.x, c0 = s_cnt[0][c], c1 = s_cnt[1][c], c2 = s_cnt[2][c], c3 = s_cnt[3][c], tot = c0 + c1 + c2 + c3;
+    const u32 b = tot ? atomicAdd(counters[c], tot) : 0u;
+    s_base[0][c] = b; s_base[1][c] = b + c0; s_base[2][c] = b + c0 + c1; s_base[3][c] = b + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; c++) pos[c] = s_base[wave][c] + pre[c];
+}
+
 // Key-table cache.  One entry per distinct public key that has a comb table: the serialised key bytes
 // (what the callers hand over: 33 / 65 SEC1 or 32 x-only -- no parsing needed to look a key up), the comb shape, the table
 // slot in the pool of that shape, and who published it when (an entry is usable by a call only if the host has SEEN the
@@ -554,9 +579,11 @@ __global__ void __launch_bounds__(256) k_cache_lookup(size_t n, const u8 *__rest
     if (keyok_row) keyok_row[i] = 1;
     T = 254;
   }
-  const u32 p7 = wave_alloc(&plan[P_L7], T == 7u), p10 = wave_alloc(&plan[P_L10], T == 10u);
-  (void)wave_alloc(&plan[P_HITS], found != ENT_NONE);
-  (void)wave_alloc(&plan[P_EARLY], dead);
+  u32 *const ctr[4] = {&plan[P_L7], &plan[P_L10], &plan[P_HITS], &plan[P_EARLY]};
+  const bool pr[4] = {T == 7u, T == 10u, found != ENT_NONE, dead};
+  u32 pos[4];
+  block_alloc4(ctr, pr, pos);
+  const u32 p7 = pos[0], p10 = pos[1];
   if (T == 7u) list7[p7] = (u32)i;
   else if (T == 10u) list10[p10] = (u32)i;
   else if (T == 0u) {  // a key that does not parse
@@ -767,9 +794,11 @@ __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ r
     if (keyok_row) keyok_row[i] = 1;
     T = 254;
   }
-  const u32 p7 = wave_alloc(&plan[P_L7], miss && T == 7u), p10 = wave_alloc(&plan[P_L10], miss && T == 10u);
-  const u32 pc = wave_alloc(&plan[P_COLD], miss && T == 255u);
-  (void)wave_alloc(&plan[P_EARLY], dead);
+  u32 *const ctr[4] = {&plan[P_L7], &plan[P_L10], &plan[P_COLD], &plan[P_EARLY]};
+  const bool pr[4] = {miss && T == 7u, miss && T == 10u, miss && T == 255u, dead};
+  u32 pos[4];
+  block_alloc4(ctr, pr, pos);
+  const u32 p7 = pos[0], p10 = pos[1], pc = pos[2];
   if (!miss || dead) return;
   if (T == 7u) list7[p7] = (u32)i;
   else if (T == 10u) list10[p10] = (u32)i;
