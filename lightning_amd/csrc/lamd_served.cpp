@@ -428,8 +428,12 @@ bool flush_valid(job *j) {
 }
 void answer_async(job *j) {
   {
+    // An engine thread must never sleep in a send: it serves everybody.  A connection has at most LAMD_SRV_FLUSH_SLOTS flushes outstanding (serve()
+    // refuses a second flush in a block that still carries one), so their 232-byte replies always fit the socket buffer; a client that
+    // manages to fill it anyway has stopped reading and loses its connection.
     std::lock_guard<std::mutex> lk(j->c->wmu);
-    send_all(j->c->fd, &j->rep, sizeof j->rep);  // a client that went away does not read it: nothing to do about that here
+    const ssize_t k = send(j->c->fd, &j->rep, sizeof j->rep, MSG_NOSIGNAL | MSG_DONTWAIT);
+    if (k != (ssize_t)sizeof j->rep) shutdown(j->c->fd, SHUT_RDWR);
   }
   j->c->slot_pending[j->slot].fetch_sub(1);
   j->c->async_pending.fetch_sub(1);
@@ -663,10 +667,11 @@ void serve(conn *cp) {
     j.slot = (int)j.req.slot;
     j.rep.seq = j.async ? j.req.scalar[0] : 0;
     j.out_off = layout(j.req, j.off);
-    const bool slot_ok = j.req.slot <= LAMD_SRV_FLUSH_SLOTS && (j.async ? j.req.slot >= 1 && j.req.scalar[0] != 0 : j.req.slot == 0);
-    if (!slot_ok || !c.shm[j.slot].p || j.out_off == (size_t)-1 || j.out_off > c.shm[j.slot].size) {
+    bool slot_ok = j.req.slot <= LAMD_SRV_FLUSH_SLOTS && (j.async ? j.req.slot >= 1 && j.req.scalar[0] != 0 : j.req.slot == 0);
+    const bool slot_busy = slot_ok && j.async && c.slot_pending[j.slot].load() > 0;  // one flush per block at a time: its verdicts go there
+    if (!slot_ok || slot_busy || !c.shm[j.slot].p || j.out_off == (size_t)-1 || j.out_off > c.shm[j.slot].size) {
       if (!slot_ok) j.slot = 0;
-      fail(&j, LAMD_ERR_ARG, "request does not fit its shared block");
+      fail(&j, slot_busy ? LAMD_ERR_STATE : LAMD_ERR_ARG, slot_busy ? "this block still carries a flush" : "request does not fit its shared block");
       const bool ok = reply();
       delete jp;
       if (!ok) break;
