@@ -94,6 +94,66 @@ def run_sharded(n_verdicts, rank, world, verify_range, group_sizes=None, weights
     return all_gather_verdicts(local, b, rank, world), b
 
 
+def segment_bounds(seg_edges, world, weights=None):
+    """A job whose MIX changes along its length -- a gossip replay is 500 k channel_announcements (four signatures each, two of them under keys that
+    never recur: the per-signature ladder) followed by 2 M channel_updates (one signature under a node key with a table) -- is cut segment by
+    segment: `seg_edges` = [0, e1, .., n] (non-decreasing) names the segments, EVERY segment is cut into `world` contiguous ranges (balanced by
+    `weights` inside the segment, cuts on unit boundaries), and rank r takes range r of every segment.  Every rank then holds the same mix -- with one
+    cut over the whole job five ranks of eight get nothing but announcements, and the job's time is the slowest kind's (profiles/r06_shard_timeline_cold.txt).
+    -> int64 array [segments, world + 1] of absolute offsets."""
+    seg_edges = [int(e) for e in seg_edges]
+    if len(seg_edges) < 2 or seg_edges[0] != 0 or any(b < a for a, b in zip(seg_edges, seg_edges[1:])):
+        raise ValueError("segment edges must start at 0 and not decrease")
+    out = np.zeros((len(seg_edges) - 1, world + 1), dtype=np.int64)
+    for s, (a, z) in enumerate(zip(seg_edges, seg_edges[1:])):
+        w = None if weights is None else np.asarray(weights)[a:z]
+        out[s] = a + shard_bounds(z - a, world, None, w if (w is not None and z > a) else None) if z > a else a
+    return out
+
+
+def run_sharded_segments(n_verdicts, seg_edges, rank, world, verify_range, weights=None, before_gather=None, empty=None):
+    """run_sharded() for a job of several segments (segment_bounds): rank r verifies range r of every segment -- `verify_range(lo, hi)` once per
+    non-empty range; on GPUs the calls are asynchronous and overlap on the engine's lanes -- then ONE ragged all-gather carries every rank's verdicts
+    of all its ranges, and every rank ends with the whole vector in job order.  `before_gather()` (optional) is called between the last
+    verify_range and the collective (the engine's device-side edge to the consumer stream); `empty` = a zero-length tensor of the verdicts' dtype on
+    the rank's device, for a rank that gets no position at all (default: uint8 on the CPU).  Returns (full_verdicts, bounds[segments, world + 1])."""
+    sb = segment_bounds(seg_edges, world, weights)
+    if int(sb[-1, -1]) != n_verdicts:
+        raise ValueError("segments do not cover the job")
+    parts = []
+    for s in range(sb.shape[0]):
+        lo, hi = int(sb[s, rank]), int(sb[s, rank + 1])
+        if hi > lo:
+            v = verify_range(lo, hi)
+            if v.numel() != hi - lo:
+                raise ValueError("verify_range returned %d verdicts for %d positions" % (v.numel(), hi - lo))
+            parts.append(v)
+    if before_gather is not None:
+        before_gather()
+    sizes = [int(sum(sb[s, g + 1] - sb[s, g] for s in range(sb.shape[0]))) for g in range(world)]
+    if not parts:      # a rank without a single position still takes part in the collective
+        parts = [empty if empty is not None else torch.empty(0, dtype=torch.uint8)]
+    local = torch.cat(parts) if len(parts) > 1 else parts[0]
+    dt = local.dtype
+    if world == 1:
+        gathered = [local.view(torch.uint8) if dt != torch.uint8 else local]
+    else:
+        m = max(sizes)
+        pad = torch.zeros(m, dtype=torch.uint8, device=local.device)
+        pad[:sizes[rank]] = local.view(torch.uint8) if dt != torch.uint8 else local
+        flat = torch.empty(world * m, dtype=torch.uint8, device=local.device)
+        dist.all_gather_into_tensor(flat, pad)
+        gathered = [flat[g * m:g * m + sizes[g]] for g in range(world)]
+    full = torch.empty(n_verdicts, dtype=torch.uint8, device=local.device)
+    for g in range(world):
+        o = 0
+        for s in range(sb.shape[0]):
+            a, z = int(sb[s, g]), int(sb[s, g + 1])
+            full[a:z] = gathered[g][o:o + z - a]
+            o += z - a
+    return full.view(dt), sb
+
+
 class LateGather:
     """The collective step of the weak-scaling headline (bench.py --gpus N): every rank verifies its own batches, and the verdict
     bytes of every batch are all-gathered -- with every dependency per call and by device-side events, no host synchronisation:

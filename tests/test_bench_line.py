@@ -132,6 +132,8 @@ def test_bench_with_one_rank_over_the_stub(tmp_path):
         assert k in det, k
     assert "no communicator" in det["strong_scaling_1gpu"]["gather"]
     assert det["strong_scaling_1gpu"]["cfg5_commit_storm_streaming"]["mismatches"] == 0 and det["strong_scaling_1gpu"]["cfg4_gossip_replay"]["mismatches"] == 0
+    c4 = det["strong_scaling_1gpu"]["cfg4_gossip_replay"]
+    assert len(c4["8"]["shard_ms"]) == 8 and len(c4["8"]["shard_messages"]) == 2 and "one_cut" in c4 and len(c4["one_cut"]["8"]["shard_ms"]) == 8
     assert "BENCH_DETAILS {" in err
     assert "gloo" not in err.lower() or "connected" not in err.lower()        # a one-rank run creates no process group
 
@@ -148,6 +150,8 @@ def test_bench_multi_rank_path_under_gloo(world, tmp_path):
     for v in sc.values():
         assert v["ranks"] == world and v["mismatches"] == 0 and v["scaling"] == "strong" and v["verifies_per_s"] > 0
     d4, d5 = det["sharded_configs"]["cfg4_gossip_replay_sharded"], det["sharded_configs"]["cfg5_commit_storm_streaming_sharded"]
-    assert d4["verdicts_on_every_rank"] == d4["messages"] == sum(d4["shard_messages"]) and len(d4["shard_messages"]) == world
+    # configs[3] is cut per message kind: every rank holds range r of the announcements and range r of the updates; the one-cut form is measured beside it
+    assert d4["verdicts_on_every_rank"] == d4["messages"] == sum(sum(k) for k in d4["shard_messages"])
+    assert len(d4["shard_messages"]) == 2 and all(len(k) == world for k in d4["shard_messages"]) and d4["one_cut_ms"] > 0
     assert d5["verdicts_on_every_rank"] == d5["verifies"] == sum(d5["shard_rows"]["ecdsa"]) + sum(d5["shard_rows"]["schnorr"])
     assert all(r % 484 == 0 for rows in d5["shard_rows"].values() for r in rows)          # a commitment's 484 signatures stay on one rank

@@ -258,3 +258,69 @@ def test_eight_rank_ragged_and_empty_shards():
     ranges = sorted((r[3], r[4]) for r in res)
     assert ranges[0][0] == 0 and ranges[-1][1] == 101 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
     assert len({hi - lo for lo, hi in ranges}) > 1          # ragged
+
+
+def test_segment_bounds_cut_every_segment_for_every_rank():
+    sb = sharding.segment_bounds([0, 10, 30], 4)
+    assert sb.tolist() == [[0, 2, 5, 7, 10], [10, 15, 20, 25, 30]]
+    # weights balance INSIDE a segment; an empty segment and a segment shorter than the world are fine
+    w = np.ones(30, dtype=np.int64)
+    w[:5] = 10
+    sb = sharding.segment_bounds([0, 10, 10, 12, 30], 4, w)
+    assert sb.shape == (4, 5) and sb[1].tolist() == [10] * 5 and sb[2, 0] == 10 and sb[2, -1] == 12 and sb[3, 0] == 12 and sb[3, -1] == 30
+    assert sb[0, 1] < 3                      # the heavy head of segment 0 is cut early
+    assert all(sb[s, g] <= sb[s, g + 1] for s in range(4) for g in range(4))
+    with pytest.raises(ValueError):
+        sharding.segment_bounds([1, 5], 2)
+    with pytest.raises(ValueError):
+        sharding.segment_bounds([0, 5, 3], 2)
+    # one rank: the job comes back in job order, several dtypes
+    for dt in (torch.uint8, torch.int8):
+        full, b = sharding.run_sharded_segments(30, [0, 10, 30], 0, 1, lambda lo, hi: (torch.arange(lo, hi) % 5).to(dt))
+        assert full.dtype == dt and full.tolist() == [i % 5 for i in range(30)]
+    with pytest.raises(ValueError):
+        sharding.run_sharded_segments(31, [0, 10, 30], 0, 1, lambda lo, hi: torch.zeros(hi - lo, dtype=torch.uint8))
+
+
+def _worker_segments(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok, calls = True, []
+    # a "gossip replay": 37 announcements (int8 verdict 0..4) then 203 updates (0..1); weights 10 / 1; a job that leaves ranks without a position
+    expect = np.concatenate([(np.arange(37) * 7) % 5, (np.arange(203) * 3) % 2]).astype(np.int8)
+    w = np.concatenate([np.full(37, 10), np.ones(203)]).astype(np.int64)
+
+    def verify(lo, hi):
+        calls.append((lo, hi))
+        return torch.from_numpy(expect[lo:hi].copy())
+    marks = []
+    full, sb = sharding.run_sharded_segments(240, [0, 37, 240], rank, world, verify, w, before_gather=lambda: marks.append(len(calls)),
+                                             empty=torch.empty(0, dtype=torch.int8))
+    ok &= full.dtype == torch.int8 and np.array_equal(full.numpy(), expect)
+    ok &= len(calls) <= 2 and marks == [len(calls)] and all(hi > lo for lo, hi in calls)
+    ok &= all((lo < 37) == (hi <= 37) for lo, hi in calls)          # a range never straddles the two kinds
+    tiny = np.array([1, 0, 1], dtype=np.uint8)
+    full2, _ = sharding.run_sharded_segments(3, [0, 1, 3], rank, world, lambda lo, hi: torch.from_numpy(tiny[lo:hi].copy()))
+    ok &= np.array_equal(full2.numpy(), tiny)
+    q.put((rank, bool(ok), calls))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_segmented_job_over_ranks_every_rank_gets_the_whole_vector(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_segments, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world)) and all(r[1] for r in res), res
+    # every rank holds a piece of BOTH kinds (that is the point of cutting segment by segment)
+    assert all(len(r[2]) == 2 for r in res), res
+    covered = sorted(rng for r in res for rng in r[2])
+    assert covered[0][0] == 0 and covered[-1][1] == 240 and sum(hi - lo for lo, hi in covered) == 240
