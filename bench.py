@@ -261,6 +261,19 @@ def stream_shard(eng, st, bounds, k, grp, depth, first_grp=0):
     return got
 
 
+def gossip_spans(g, ranges, device):
+    """the arguments of ONE lamd_sigcheck_gossip_spans_device call over several ranges of a resident gossip workload (made outside the clock, like the
+    rebased row offsets of a range call): (n, d_start, d_len, d_ids, d_rowbase, rows, d_verdict)"""
+    import torch
+    starts = torch.cat([g.d_off[lo:hi] for lo, hi in ranges]).contiguous()
+    lens = torch.cat([g.d_off[lo + 1:hi + 1] - g.d_off[lo:hi] for lo, hi in ranges]).contiguous()
+    ids = torch.cat([g.d_ids[lo:hi] for lo, hi in ranges]).contiguous()
+    rpm = torch.cat([g.d_rowbase[lo + 1:hi + 1] - g.d_rowbase[lo:hi] for lo, hi in ranges])
+    rowbase = torch.cat([torch.zeros(1, dtype=rpm.dtype, device=rpm.device), torch.cumsum(rpm, 0)]).contiguous()
+    n = int(starts.numel())
+    return n, starts, lens, ids, rowbase, int(rowbase[-1].item()), torch.zeros(n, dtype=torch.int8, device=device)
+
+
 def storm_first_flush(per):
     """rows of a shard's first flush per kind (LAMD_BENCH_FIRST_FLUSH commitments; default a quarter of the 256-commitment flush)"""
     return int(os.environ.get("LAMD_BENCH_FIRST_FLUSH", "64")) * per
@@ -318,6 +331,9 @@ def sharded_configs(plat, eng, rank, world, tstream, div=1):
     wait = lambda: eng.stream_wait_results(tstream)     # the collective (torch's stream) starts when the verdicts exist: device-side edge
     empty = torch.empty(0, dtype=torch.int8, device=device)
     reps = 2 + eng.info()["lanes"]
+    # (two asynchronous range calls per rank, not ONE spans call over both ranges -- lamd_sigcheck_gossip_spans_device, sharding's `verify_ranges`: measured on
+    # one GPU playing every rank, the two calls overlap one's front end with the other's ecmult and are as fast at W = 8 and 8 % faster at W = 4:
+    # profiles/r06_strong_scaling.txt)
     ts, (full, _) = timed(lambda: sharding.run_sharded_segments(g.n, seg, rank, world, gossip_range, gw, wait, empty), reps)
     bad = int((full.cpu().numpy() != g.expect).sum())
 
@@ -327,7 +343,7 @@ def sharded_configs(plat, eng, rank, world, tstream, div=1):
         return v
     ts1, (full1, _) = timed(lambda: sharding.run_sharded(g.n, rank, world, one_cut, None, gw), reps)
     bad += int((full1.cpu().numpy() != g.expect).sum())
-    out["cfg4_gossip_replay_sharded"] = {"messages": g.n, "verifies": g.rows, "ranks": world, "split": "per message kind (announcements | updates), range r of each per rank",
+    out["cfg4_gossip_replay_sharded"] = {"messages": g.n, "verifies": g.rows, "ranks": world, "split": "per message kind (announcements | updates), range r of each per rank: two asynchronous calls",
                                          "shard_messages": [[int(sb[s, k + 1] - sb[s, k]) for k in range(world)] for s in range(sb.shape[0])],
                                          "verifies_per_s": g.rows / min(ts[-2:]), "messages_per_s": g.n / min(ts[-2:]), "ms": min(ts[-2:]) * 1e3,
                                          "one_cut_ms": min(ts1[-2:]) * 1e3, "one_cut_verifies_per_s": g.rows / min(ts1[-2:]),
@@ -428,10 +444,25 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
     for W in (1, 2, 4, 8):
         sb = sharding.segment_bounds(seg, W, gw)
         b1 = sharding.shard_bounds(g.n, W, None, gw)
-        shard_ms, one_cut_ms = [], []
+        shard_ms, one_cut_ms, spans_ms = [], [], []
         for k in range(W):
             for form, ranges, dst in (("kinds", [(int(sb[s, k]), int(sb[s, k + 1])) for s in range(sb.shape[0])], shard_ms),
+                                      ("kinds_one_spans_call", [(int(sb[s, k]), int(sb[s, k + 1])) for s in range(sb.shape[0])], spans_ms),
                                       ("one_cut", [(int(b1[k]), int(b1[k + 1]))], one_cut_ms)):
+                if form == "kinds_one_spans_call":      # ONE spans call over the shard's ranges (lamd_sigcheck_gossip_spans_device)
+                    live = [(lo, hi) for lo, hi in ranges if hi > lo]
+                    sp = gossip_spans(g, live, device)
+                    plat.synchronize()
+
+                    def one(sp=sp):
+                        eng.sigcheck_gossip_spans_device(sp[0], g.d_msgs, sp[1], sp[2], sp[3], sp[4], sp[5], sp[6])
+                        eng.stream_wait_results(tstream)
+                        return gather(sp[6])
+                    for _ in range(lanes if W == 1 and k == 0 else 1):
+                        one()
+                    dst.append(best(one, 5 if W > 1 else 6) * 1e3)
+                    bad3 += int((sp[6].cpu().numpy() != np.concatenate([g.expect[lo:hi] for lo, hi in live])).sum())
+                    continue
                 one, prep = shard_fn(ranges)
                 for _ in range(lanes if W == 1 and k == 0 else 1):   # every lane allocates its workspaces for the largest shape once
                     one()
@@ -440,6 +471,7 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
                     bad3 += int((d_v.cpu().numpy() != g.expect[lo:hi]).sum())
         res3[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms),
                         "shard_messages": [[int(sb[s, k + 1] - sb[s, k]) for k in range(W)] for s in range(sb.shape[0])]}
+        res3[str(W)]["one_spans_call_shard_ms"] = spans_ms
         res3_one[str(W)] = {"shard_ms": one_cut_ms, "slowest_ms": max(one_cut_ms), "shard_messages": [int(b1[k + 1] - b1[k]) for k in range(W)]}
     t1 = min(res3["1"]["slowest_ms"], res3_one["1"]["slowest_ms"])      # T(1): the better way to run the whole job on one GPU
     for W in ("2", "4", "8"):
@@ -447,7 +479,7 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
         res3_one[W]["predicted_speedup"] = t1 / res3_one[W]["slowest_ms"]
     out["cfg4_gossip_replay"] = dict(res3, verifies=g.rows, messages=g.n, mismatches=bad3, predicted_speedup_8=res3["8"]["predicted_speedup"],
                                      verifies_per_s_predicted_8=g.rows / (res3["8"]["slowest_ms"] * 1e-3), t1_ms=t1,
-                                     split="per message kind: shard k = range k of the announcements + range k of the updates",
+                                     split="per message kind: shard k = range k of the announcements + range k of the updates, two asynchronous range calls (one_spans_call_shard_ms: as ONE spans call)",
                                      one_cut=dict(res3_one, predicted_speedup_8=res3_one["8"]["predicted_speedup"],
                                                   note="one cut over the whole job, balanced by cost (rounds 1-5): the slowest shard is a kind's worst case"))
     del g

@@ -250,6 +250,11 @@ int lamd_sigcheck_gossip_batch(lamd_ctx *ctx, size_t n, const uint8_t *msgs, con
 int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_off,
 				      const void *d_node_ids33, const void *d_rowbase, size_t rows,
 				      void *d_verdict);
+/* The spans form of the device-resident variant: message i = d_msgs[d_start[i], d_start[i] + d_len[i]) (uint64[n] each) -- any selection of a
+ * resident message blob, in any order, as ONE call: what a rank of a replay cut per message kind verifies (its range of the channel_announcements
+ * and its range of the channel_updates; lightning_amd/sharding.py segment_bounds).  d_node_ids33, d_rowbase, rows, d_verdict index the SELECTION. */
+int lamd_sigcheck_gossip_spans_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_start, const void *d_len,
+				      const void *d_node_ids33, const void *d_rowbase, size_t rows, void *d_verdict);
 
 /* ---- streaming front end for callers that produce triples one at a time (channeld's
  * commitment_signed loop, channeld/channeld.c:2171,2215-2232; gossip ingest).  Triples are

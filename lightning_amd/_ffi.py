@@ -61,6 +61,7 @@ SYMBOLS = {
     "lamd_poll": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
     "lamd_wait": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_sz, ctypes.POINTER(c_sz)]),
     "lamd_sigcheck_gossip_batch_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_u8p]),
+    "lamd_sigcheck_gossip_spans_device": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_u8p, c_u8p, c_sz, c_u8p]),
     "lamd_selftest": (ctypes.c_int, [ctypes.c_void_p, c_u8p, c_u8p, c_u8p, ctypes.c_char_p, c_sz]),
     "lamd_chain_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, c_sz]),
     "lamd_inv_debug": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_sz]),

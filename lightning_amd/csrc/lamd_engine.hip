@@ -426,14 +426,16 @@ __global__ void __launch_bounds__(256) k_grind(u32 ncand, u32 min_rate, u64 weig
 }
 
 // rowbase[i] = index of message i's first signature row; malformed[i] set here for framing errors
-__global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
+// message i = msgs[off[i], off[i + 1]) -- or, with `len` (the spans form: lamd_sigcheck_gossip_spans_device), msgs[off[i], off[i] + len[i]): the messages of a
+// call need not lie back to back, nor in order
+__global__ void __launch_bounds__(256) k_gossip_expand(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off, const u64 *__restrict__ len,
                                                        const u8 *__restrict__ node_ids, const u64 *__restrict__ rowbase,
                                                        u8 *__restrict__ hash32, u8 *__restrict__ sig64, u8 *__restrict__ pub33,
                                                        u8 *__restrict__ malformed) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t row = rowbase[i];
-  malformed[i] = gossip_expand_one(msgs + off[i], off[i + 1] - off[i], node_ids ? node_ids + 33 * i : nullptr, rowbase[i + 1] - row, hash32 + 32 * row, sig64 + 64 * row, pub33 + 33 * row);
+  malformed[i] = gossip_expand_one(msgs + off[i], len ? len[i] : off[i + 1] - off[i], node_ids ? node_ids + 33 * i : nullptr, rowbase[i + 1] - row, hash32 + 32 * row, sig64 + 64 * row, pub33 + 33 * row);
 }
 
 __global__ void __launch_bounds__(256) k_gossip_reduce(size_t n, const u8 *__restrict__ msgs, const u64 *__restrict__ off,
@@ -3521,7 +3523,7 @@ extern "C" int lamd_grind_htlc_tx_fee(lamd_ctx *ctx, const uint8_t *preimage, si
 // device core: everything resident.  The signature rows of all messages form one ECDSA batch with 33-byte keys (cut into
 // chunks like any other batch: a message's rows may straddle a chunk); the reduce runs once over all messages.
 static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d_off, const u8 *d_ids, const u64 *d_rowbase, size_t rows,
-                         int8_t *d_verdict) {
+                         int8_t *d_verdict, const u64 *d_len = nullptr) {
   int rc;
   if ((rc = ensure(ctx, &ctx->g_hash, rows * 32)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_sig, rows * 64)) != LAMD_OK) return rc;
@@ -3529,7 +3531,7 @@ static int gossip_device(lamd_ctx *ctx, size_t n, const u8 *d_msgs, const u64 *d
   if ((rc = ensure(ctx, &ctx->g_malformed, n)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->g_ok, rows)) != LAMD_OK) return rc;
   if ((rc = ensure(ctx, &ctx->keyok_row, rows)) != LAMD_OK) return rc;
-  hipLaunchKernelGGL(k_gossip_expand, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_msgs, d_off, d_ids, d_rowbase, (u8 *)ctx->g_hash.p,
+  hipLaunchKernelGGL(k_gossip_expand, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, d_msgs, d_off, d_len, d_ids, d_rowbase, (u8 *)ctx->g_hash.p,
                      (u8 *)ctx->g_sig.p, (u8 *)ctx->g_pub.p, (u8 *)ctx->g_malformed.p);
   HIPCHK(ctx, hipGetLastError());
   rc = run_device(ctx, MODE_ECDSA, rows, (const u8 *)ctx->g_hash.p, (const u8 *)ctx->g_sig.p, (const u8 *)ctx->g_pub.p, 33, 33, (u8 *)ctx->g_ok.p,
@@ -3556,6 +3558,26 @@ extern "C" int lamd_sigcheck_gossip_batch_device(lamd_ctx *ctx, size_t n, const 
   // d_node_ids33 == NULL travels to the kernel as it is: a channel_update in such a batch gets verdict -1 (gossip_expand_one), nothing is
   // read through a placeholder (the host-buffer call refuses the batch with LAMD_ERR_ARG; here the message types are only known on the device)
   rc = gossip_device(L, n, (const u8 *)d_msgs, (const u64 *)d_off, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, rows, (int8_t *)d_verdict);
+  if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
+  return rc;
+}
+
+// The spans form: message i = d_msgs[d_start[i], d_start[i] + d_len[i]).  One call over any selection of a resident message blob -- a rank of a job cut
+// per message kind (sharding.segment_bounds) verifies its range of the announcements and its range of the updates as ONE call with one front end.
+extern "C" int lamd_sigcheck_gossip_spans_device(lamd_ctx *ctx, size_t n, const void *d_msgs, const void *d_start, const void *d_len,
+                                                 const void *d_node_ids33, const void *d_rowbase, size_t rows, void *d_verdict) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (n == 0) return LAMD_OK;
+  if (!d_msgs || !d_start || !d_len || !d_rowbase || !d_verdict || rows == 0) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  lamd_ctx *L;
+  int rc = pick_lane(ctx, &L);
+  if (rc != LAMD_OK) return rc;
+  rc = gossip_device(L, n, (const u8 *)d_msgs, (const u64 *)d_start, (const u8 *)d_node_ids33, (const u64 *)d_rowbase, rows, (int8_t *)d_verdict,
+                     (const u64 *)d_len);
   if (rc != LAMD_OK && L != ctx) ctx->err = L->err;
   return rc;
 }

@@ -337,6 +337,13 @@ class Engine:
                                                               d_ids.data_ptr() if d_ids is not None else None, d_rowbase.data_ptr(), rows,
                                                               d_verdict.data_ptr()))
 
+    def sigcheck_gossip_spans_device(self, n, d_msgs, d_start, d_len, d_ids, d_rowbase, rows, d_verdict):
+        """lamd_sigcheck_gossip_spans_device: message i = d_msgs[d_start[i] : d_start[i] + d_len[i]]; ids / rowbase / verdicts index the selection"""
+        self._after_torch()
+        self._chk(self._lib.lamd_sigcheck_gossip_spans_device(self._ctx, n, d_msgs.data_ptr(), d_start.data_ptr(), d_len.data_ptr(),
+                                                              d_ids.data_ptr() if d_ids is not None else None, d_rowbase.data_ptr(), rows,
+                                                              d_verdict.data_ptr()))
+
     def selftest(self, hash32, sig64, pub33):
         buf = ctypes.create_string_buffer(4096)
         rc = self._chk(self._lib.lamd_selftest(self._ctx, bytes(hash32), bytes(sig64), bytes(pub33), buf, 4096))

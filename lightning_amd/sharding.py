@@ -111,19 +111,27 @@ def segment_bounds(seg_edges, world, weights=None):
     return out
 
 
-def run_sharded_segments(n_verdicts, seg_edges, rank, world, verify_range, weights=None, before_gather=None, empty=None):
+def run_sharded_segments(n_verdicts, seg_edges, rank, world, verify_range, weights=None, before_gather=None, empty=None, verify_ranges=None):
     """run_sharded() for a job of several segments (segment_bounds): rank r verifies range r of every segment -- `verify_range(lo, hi)` once per
     non-empty range; on GPUs the calls are asynchronous and overlap on the engine's lanes -- then ONE ragged all-gather carries every rank's verdicts
     of all its ranges, and every rank ends with the whole vector in job order.  `before_gather()` (optional) is called between the last
     verify_range and the collective (the engine's device-side edge to the consumer stream); `empty` = a zero-length tensor of the verdicts' dtype on
-    the rank's device, for a rank that gets no position at all (default: uint8 on the CPU).  Returns (full_verdicts, bounds[segments, world + 1])."""
+    the rank's device, for a rank that gets no position at all (default: uint8 on the CPU).  `verify_ranges(list of (lo, hi))`, when given, replaces
+    the per-range calls: ONE call for all of the rank's non-empty ranges that returns their verdicts concatenated in that order (the engine's
+    spans form, lamd_sigcheck_gossip_spans_device: one front end per rank instead of one per range).
+    Returns (full_verdicts, bounds[segments, world + 1])."""
     sb = segment_bounds(seg_edges, world, weights)
     if int(sb[-1, -1]) != n_verdicts:
         raise ValueError("segments do not cover the job")
     parts = []
-    for s in range(sb.shape[0]):
-        lo, hi = int(sb[s, rank]), int(sb[s, rank + 1])
-        if hi > lo:
+    mine = [(int(sb[s, rank]), int(sb[s, rank + 1])) for s in range(sb.shape[0]) if sb[s, rank + 1] > sb[s, rank]]
+    if verify_ranges is not None and mine:
+        v = verify_ranges(mine)
+        if v.numel() != sum(hi - lo for lo, hi in mine):
+            raise ValueError("verify_ranges returned %d verdicts for %d positions" % (v.numel(), sum(hi - lo for lo, hi in mine)))
+        parts.append(v)
+    else:
+        for lo, hi in mine:
             v = verify_range(lo, hi)
             if v.numel() != hi - lo:
                 raise ValueError("verify_range returned %d verdicts for %d positions" % (v.numel(), hi - lo))

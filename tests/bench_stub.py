@@ -122,6 +122,15 @@ class StubEngine:
         d_verdict.copy_(torch.from_numpy(gossip_verdicts(d_msgs.numpy(), d_off.numpy())))
         self._note(0, rows)
 
+    def sigcheck_gossip_spans_device(self, n, d_msgs, d_start, d_len, d_ids, d_rowbase, rows, d_verdict):
+        assert d_start.numel() == n and d_len.numel() == n and d_rowbase.numel() == n + 1 and int(d_rowbase[-1]) == rows and d_ids.shape[0] == n
+        m, st = d_msgs.numpy(), d_start.numpy().astype(np.int64)
+        assert (d_len.numpy() >= 3).all()
+        is_cann = (m[st] == 1) & (m[st + 1] == 0)
+        x = m[st + 2].astype(np.int64)
+        d_verdict.copy_(torch.from_numpy(np.where(is_cann, np.where(x % 7 == 0, 1 + x % 4, 0), (x % 11 == 0).astype(np.int64)).astype(np.int8)))
+        self._note(0, rows)
+
     # ---- the streaming queue
     def queue_ecdsa_batch(self, h, s, p):
         self._queued.append(verdict_rows(_t(h), _t(s), _t(p)).numpy().astype(bool))

@@ -249,6 +249,51 @@ def test_cfg4_gossip_replay_small_vs_oracle_and_construction(eng, orc):
     assert len(msgs[0]) == 432 and len(msgs[-1]) == 138 and msgs[0][:2] == b"\x01\x00" and msgs[-1][:2] == b"\x01\x02"
 
 
+def test_gossip_spans_any_selection_in_any_order_equals_the_range_call(eng):
+    """lamd_sigcheck_gossip_spans_device (round 6): message i = msgs[start[i] : start[i] + len[i]] -- a PERMUTED selection of both message kinds,
+    with gaps, as one call; every verdict equals the range call's (= construction) for the message it was taken from.  Also the two ranges a rank
+    of a job cut per message kind holds (sharding.segment_bounds), as bench.py issues them."""
+    import torch
+    from lightning_amd import sharding, workload
+    w = workload.make_gossip(eng, 700, 2100, n_nodes=40, corrupt_frac=0.08)
+    rng = np.random.default_rng(0x5A)
+    sel = rng.permutation(w.n)[:1900]                                   # any order, announcements and updates mixed, two thirds of the job
+    d_sel = torch.from_numpy(sel).to("cuda:0")
+    start = w.d_off[:-1][d_sel].contiguous()
+    ln = (w.d_off[1:] - w.d_off[:-1])[d_sel].contiguous()
+    ids = w.d_ids[d_sel].contiguous()
+    rpm = (w.d_rowbase[1:] - w.d_rowbase[:-1])[d_sel]
+    rowbase = torch.cat([torch.zeros(1, dtype=rpm.dtype, device=rpm.device), torch.cumsum(rpm, 0)]).contiguous()
+    d_v = torch.full((len(sel),), 9, dtype=torch.int8, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.sigcheck_gossip_spans_device(len(sel), w.d_msgs, start, ln, ids, rowbase, int(rowbase[-1].item()), d_v)
+    eng.synchronize()
+    got = d_v.cpu().numpy()
+    assert np.array_equal(got, w.expect[sel]), np.nonzero(got != w.expect[sel])[0][:10]
+    assert set(np.unique(got)) >= {0, 1, 2, 3, 4}
+    # a length that stops short of the message is that message's problem only (malformed -> -1), its neighbours keep their verdicts
+    ln2 = ln.clone()
+    ln2[5] = 40
+    d_v.fill_(9)
+    eng.sigcheck_gossip_spans_device(len(sel), w.d_msgs, start, ln2, ids, rowbase, int(rowbase[-1].item()), d_v)
+    eng.synchronize()
+    got2 = d_v.cpu().numpy()
+    assert got2[5] == -1 and np.array_equal(np.delete(got2, 5), np.delete(w.expect[sel], 5))
+    # the two ranges of rank 1 of 4 of the job cut per kind, as ONE call
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    gw = sharding.gossip_weights(w.msgs, w.off)
+    sb = sharding.segment_bounds([0, w.n_cann, w.n], 4, gw)
+    mine = [(int(sb[s, 1]), int(sb[s, 2])) for s in range(2)]
+    sp = bench.gossip_spans(w, mine, "cuda:0")
+    torch.cuda.synchronize()
+    eng.sigcheck_gossip_spans_device(sp[0], w.d_msgs, sp[1], sp[2], sp[3], sp[4], sp[5], sp[6])
+    eng.synchronize()
+    assert np.array_equal(sp[6].cpu().numpy(), np.concatenate([w.expect[lo:hi] for lo, hi in mine]))
+    assert mine[0][1] <= w.n_cann <= mine[1][0]
+
+
 def test_cfg4_full_size_properties(eng, orc):
     """500 k channel_announcements + 2 M channel_updates = 4 M verifies on one GPU: every untouched message verifies,
     every corrupted one reports exactly the corrupted signature; an oracle sample agrees"""

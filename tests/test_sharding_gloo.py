@@ -300,6 +300,14 @@ def _worker_segments(rank, world, port, q):
     ok &= full.dtype == torch.int8 and np.array_equal(full.numpy(), expect)
     ok &= len(calls) <= 2 and marks == [len(calls)] and all(hi > lo for lo, hi in calls)
     ok &= all((lo < 37) == (hi <= 37) for lo, hi in calls)          # a range never straddles the two kinds
+    # ... and as ONE call over all of the rank's ranges (the engine's spans form)
+    seen = []
+
+    def verify_all(ranges):
+        seen.append(list(ranges))
+        return torch.from_numpy(np.concatenate([expect[lo:hi] for lo, hi in ranges]))
+    full1, _ = sharding.run_sharded_segments(240, [0, 37, 240], rank, world, verify, w, empty=torch.empty(0, dtype=torch.int8), verify_ranges=verify_all)
+    ok &= np.array_equal(full1.numpy(), expect) and len(seen) == 1 and seen[0] == calls[:2] and len(calls) == 2
     tiny = np.array([1, 0, 1], dtype=np.uint8)
     full2, _ = sharding.run_sharded_segments(3, [0, 1, 3], rank, world, lambda lo, hi: torch.from_numpy(tiny[lo:hi].copy()))
     ok &= np.array_equal(full2.numpy(), tiny)
