@@ -472,6 +472,36 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
         res3[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms),
                         "shard_messages": [[int(sb[s, k + 1] - sb[s, k]) for k in range(W)] for s in range(sb.shape[0])]}
         res3[str(W)]["one_spans_call_shard_ms"] = spans_ms
+        if os.environ.get("LAMD_BENCH_BY_KEY", "0") == "1" and not plat.is_stub:
+            # experiment (profiles/r06_strong_scaling.txt): shard k = every message whose SIGNER KEY hashes to k -- the node id of a channel_update, node_id_1 of a
+            # channel_announcement (synthetic layout: feature length 0, the key at byte 300) -- as ONE spans call: a rank builds the tables of ITS node keys only
+            if W == 1:
+                key33 = np.where(np.arange(g.n)[:, None] < g.n_cann, 0, g.ids).astype(np.uint8)
+                o = g.off[:g.n_cann].astype(np.int64)
+                key33[:g.n_cann] = g.msgs[(o[:, None] + 300 + np.arange(33)[None, :])]
+                h = np.zeros(g.n, dtype=np.uint64) + np.uint64(1469598103934665603)
+                for b in range(33):
+                    h = (h ^ key33[:, b].astype(np.uint64)) * np.uint64(1099511628211)
+                key_hash = (h >> np.uint64(17))
+            by_key_ms = []
+            for k in range(W):
+                sel = np.nonzero(key_hash % np.uint64(W) == np.uint64(k))[0]
+                d_sel = torch.from_numpy(sel).to(device)
+                rpm = (g.d_rowbase[1:] - g.d_rowbase[:-1])[d_sel]
+                rowbase = torch.cat([torch.zeros(1, dtype=rpm.dtype, device=device), torch.cumsum(rpm, 0)]).contiguous()
+                sp = (len(sel), g.d_off[:-1][d_sel].contiguous(), (g.d_off[1:] - g.d_off[:-1])[d_sel].contiguous(), g.d_ids[d_sel].contiguous(), rowbase,
+                      int(rowbase[-1].item()), torch.zeros(len(sel), dtype=torch.int8, device=device))
+                plat.synchronize()
+
+                def one(sp=sp):
+                    eng.sigcheck_gossip_spans_device(sp[0], g.d_msgs, sp[1], sp[2], sp[3], sp[4], sp[5], sp[6])
+                    eng.stream_wait_results(tstream)
+                    return gather(sp[6])
+                for _ in range(lanes if W == 1 and k == 0 else 1):
+                    one()
+                by_key_ms.append(best(one, 5 if W > 1 else 6) * 1e3)
+                bad3 += int((sp[6].cpu().numpy() != g.expect[sel]).sum())
+            res3[str(W)]["by_signer_key_shard_ms"] = by_key_ms
         res3_one[str(W)] = {"shard_ms": one_cut_ms, "slowest_ms": max(one_cut_ms), "shard_messages": [int(b1[k + 1] - b1[k]) for k in range(W)]}
     t1 = min(res3["1"]["slowest_ms"], res3_one["1"]["slowest_ms"])      # T(1): the better way to run the whole job on one GPU
     for W in ("2", "4", "8"):

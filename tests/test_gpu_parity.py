@@ -279,6 +279,11 @@ def test_gossip_spans_any_selection_in_any_order_equals_the_range_call(eng):
     eng.synchronize()
     got2 = d_v.cpu().numpy()
     assert got2[5] == -1 and np.array_equal(np.delete(got2, 5), np.delete(w.expect[sel], 5))
+    # an empty selection is no work; missing arrays are the caller's error (raw ABI)
+    L, c = eng._lib, eng._ctx
+    assert L.lamd_sigcheck_gossip_spans_device(c, 0, None, None, None, None, None, 0, None) == 0
+    assert L.lamd_sigcheck_gossip_spans_device(c, 3, w.d_msgs.data_ptr(), start.data_ptr(), None, ids.data_ptr(), rowbase.data_ptr(), 3, d_v.data_ptr()) == -3
+    assert L.lamd_sigcheck_gossip_spans_device(c, 3, w.d_msgs.data_ptr(), start.data_ptr(), ln.data_ptr(), ids.data_ptr(), rowbase.data_ptr(), 0, d_v.data_ptr()) == -3
     # the two ranges of rank 1 of 4 of the job cut per kind, as ONE call
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
