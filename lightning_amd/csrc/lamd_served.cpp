@@ -427,6 +427,9 @@ bool flush_valid(job *j) {
   return shape(j, {seclen(j, 0), 32 * n, 64 * n, keybytes}, n);
 }
 void answer_async(job *j) {
+  // the block is free for its client's next flush from the moment the reply can be read: count it free BEFORE the reply goes out (a client that has
+  // read the reply may send the next flush on this block at once, and serve() refuses a block that still counts as carrying one)
+  j->c->slot_pending[j->slot].fetch_sub(1);
   {
     // An engine thread must never sleep in a send: it serves everybody.  A connection has at most LAMD_SRV_FLUSH_SLOTS flushes outstanding (serve()
     // refuses a second flush in a block that still carries one), so their 232-byte replies always fit the socket buffer; a client that
@@ -435,7 +438,6 @@ void answer_async(job *j) {
     const ssize_t k = send(j->c->fd, &j->rep, sizeof j->rep, MSG_NOSIGNAL | MSG_DONTWAIT);
     if (k != (ssize_t)sizeof j->rep) shutdown(j->c->fd, SHUT_RDWR);
   }
-  j->c->slot_pending[j->slot].fetch_sub(1);
   j->c->async_pending.fetch_sub(1);
   delete j;
 }
