@@ -957,6 +957,57 @@ __global__ void __launch_bounds__(256) k_kc_finish_both(const u32 *__restrict__ 
   else kc_finish_body<10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, P);
 }
 
+// The tree builder in the finish kernel's place (round 6, LAMD_KC_TREE=1; verify_core.h kc_tree_affine): one lane owns KPL keys of a shape -- four 7-tooth keys
+// or one 10-tooth key -- builds their entries as a doubling tree of affine additions with every level's inversions shared, and publishes their cache
+// entries.  One wave per workgroup: the grid is a few hundred waves, and single-wave groups fill the SIMDs evenly.
+template <int T, int KPL>
+__device__ __forceinline__ void kc_tree_body(size_t t, const u32 *__restrict__ plan, int which, const kc_shape_args &A, const publish_args &P) {
+  const u32 nkeys = plan[which] < A.cap ? plan[which] : A.cap;
+  const size_t u0 = t * KPL;
+  if (u0 >= nkeys) return;
+  kc_tree_keys K;
+  ge qs[KPL];
+  K.n = 0;
+#pragma unroll 1
+  for (int k = 0; k < KPL; k++) {
+    const size_t u = u0 + k;
+    if (u >= nkeys) break;
+    const bool ok = A.keyok[u] != 0;
+    if (ok) {
+      u32 qx[8], qy[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { qx[i] = A.qwords[u * 16 + i]; qy[i] = A.qwords[u * 16 + 8 + i]; }
+      qs[K.n] = ge_from_words(qx, qy);
+      K.tab[K.n] = A.pool + (size_t)A.hk_slot[u] * kc_stride(T);
+      K.scr[K.n] = A.scratch + u * kc_scratch_words(T);
+      K.n++;
+    }
+    // the key's cache entry (as kc_finish_body): a key that does not parse is entered as such
+    cache_ent e;
+    key_words(e.kw, P.keys + P.stride * (size_t)A.hk_row[u], P.keylen);
+    e.meta = (ok ? (u32)T : 0u) | (P.lane << 8);
+    e.seq = P.seq;
+    e.tabslot = A.hk_slot[u];
+    const u32 id = A.hk_ent[u];
+    P.ents[id] = e;
+    if (P.do_index) {
+      __threadfence();
+      u32 slot = (u32)key_words_hash(e.kw, P.seed) & P.mask;
+      for (;;) {
+        if (atomicCAS(&P.index[slot], 0u, id + 1u) == 0u) break;
+        slot = (slot + 1u) & P.mask;
+      }
+    }
+  }
+  if (K.n) kc_tree_affine<T>(K, qs);
+}
+constexpr int KC_TREE_KPL7 = 4, KC_TREE_KPL10 = 1;
+__global__ void __launch_bounds__(64) k_kc_tree_both(const u32 *__restrict__ plan, unsigned blocks7, kc_shape_args A7, kc_shape_args A10, publish_args P) {
+  LAMD_PRIO(8);
+  if (blockIdx.x < blocks7) kc_tree_body<7, KC_TREE_KPL7>((size_t)blockIdx.x * blockDim.x + threadIdx.x, plan, P_HK7, A7, P);
+  else kc_tree_body<10, KC_TREE_KPL10>((size_t)(blockIdx.x - blocks7) * blockDim.x + threadIdx.x, plan, P_HK10, A10, P);
+}
+
 // ---- rows of one key next to each other (round 4).  The row lists come out of the list builders in arrival order, so the 64 lanes of an ecmult
 // wave read 64 different keys' tables: every comb entry a cache miss, 4 KB of random HBM traffic per verification (25x the algorithmic bytes).
 // Three small kernels regroup the lists by key (cache entry) -- a counting sort whose histogram lives in a per-lane array over the entry ids:
@@ -1506,6 +1557,7 @@ struct lamd_ctx {
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
   bool fused_front = true;        // LAMD_FUSED_FRONT=0: the front end of a keyed call as the 19 launches + 5 fills of round 2 (see k_call_init)
+  bool kc_tree = false;           // LAMD_KC_TREE=1: key tables by the affine tree builder (k_kc_tree_both) instead of the Gray-code chains (k_kc_finish_both); read on the root context
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
   bool last_small_fused = false;  // the previous small batch of this lane ran k_ecmult_small (its plan holds P_DENSE)
   size_t last_small_n = 0;
@@ -1801,6 +1853,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_SPIN_US")) ctx->spin_us = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_PRIO")) ctx->prio_mask = (u32)atoi(w);
   if (const char *w = getenv("LAMD_FUSED_FRONT")) ctx->fused_front = atoi(w) != 0;
+  if (const char *w = getenv("LAMD_KC_TREE")) ctx->kc_tree = atoi(w) != 0;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
   {
@@ -2490,7 +2543,13 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
       const unsigned fb7 = on7 ? blocks_for(hk7_cap * kc_nsub(7)) : 0u, fb10 = on10 ? blocks_for(hk10_cap * kc_nsub(10)) : 0u;
       const publish_args P = {d_key, keylen, keystride, (u32)ctx->lane_id, seq ? seq : 1u, root->hash_seed, (cache_ent *)kc->ents.p, (u32 *)kc->index.p,
                               kc->index_mask, (int)use_cache};
-      hipLaunchKernelGGL(k_kc_finish_both, dim3(fb7 + fb10), dim3(256), 0, ctx->stream, (const u32 *)plan, fb7, A7, A10, P);
+      if (root->kc_tree) {
+        const unsigned tb7 = on7 ? (unsigned)((hk7_cap + 64 * KC_TREE_KPL7 - 1) / (64 * KC_TREE_KPL7)) : 0u;
+        const unsigned tb10 = on10 ? (unsigned)((hk10_cap + 64 * KC_TREE_KPL10 - 1) / (64 * KC_TREE_KPL10)) : 0u;
+        hipLaunchKernelGGL(k_kc_tree_both, dim3(tb7 + tb10), dim3(64), 0, ctx->stream, (const u32 *)plan, tb7, A7, A10, P);
+      } else {
+        hipLaunchKernelGGL(k_kc_finish_both, dim3(fb7 + fb10), dim3(256), 0, ctx->stream, (const u32 *)plan, fb7, A7, A10, P);
+      }
     }
     if (use_cache) {
       HIPCHK(ctx, hipEventRecord(root->ev_pub[ctx->lane_id], ctx->stream));

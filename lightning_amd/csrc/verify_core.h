@@ -633,6 +633,110 @@ LAMD_HD void keytable_build(u32 *tab, u32 *scratch, const ge &q) {
   for (int s = 0; s < kc_nsub(T); s++) kc_chain_bwd<T>(tab, scratch, s);
 }
 
+// ---- The tree builder (round 6): the 2^(T-1) entries of a key as a doubling TREE of AFFINE additions with the inversions shared.
+// Stage 1 (kc_bases) leaves P0 (Jacobian) and C_c = 2*B_c (affine) on the key's isomorphic curve E_b: y^2 = x^3 + 7*Zb^6 -- a curve whose
+// coefficient no addition formula reads.  Entry m = P0 + sum over the set bits c of m of C_c, so with S_0 = {P0} level c makes
+// S_(c+1) = S_c + (S_c + C_c): 2^c independent additions of ONE affine point, T - 1 levels, 2^(T-1) - 1 additions -- as many as the
+// Gray-code chains make, but
+//   * affine: 1 inversion + 2M + 1S per addition, the inversions of a whole level -- of every key the lane owns -- by Montgomery's trick
+//     (3M per addition + ONE division-step inversion per level), so 6M + 1S per entry with its beta*x against 8M + 3S for the mixed addition;
+//   * the entries come out affine on E_b with ONE Z (Zc = Zb): no Z products, no backward rescale (kc_prefix / kc_chain_bwd: 5M + 1S per entry).
+// A lane owns `nk` keys (7 teeth: four, so that a level's inversion of ~1.3e4 instructions is shared by 4 * 2^c additions; 10 teeth: one -- its
+// levels hold up to 256).  The prefix products of a level are parked in the keys' per-chain scratch areas (free after stage 1).
+// No addition can be degenerate (see above: distinct odd/even multiples of a point of prime order), so no denominator is zero.
+constexpr int KC_TREE_MAXK = 4;
+struct kc_tree_keys {
+  u32 *tab[KC_TREE_MAXK];
+  u32 *scr[KC_TREE_MAXK];
+  int n;
+};
+template <int T>
+LAMD_HD void kc_tree_affine(const kc_tree_keys &K, const ge *qs) {
+  constexpr int NE = kc_ne(T);
+  static_assert(kc_nsub(T) * KC_SUB_WORDS >= (NE / 2) * 9, "prefix products of the last level fit the per-chain scratch");
+  const u32 betaw[8] = LAMD_BETA;
+  const fe beta = fe_from_words(betaw);
+  // P0 of every key -> affine on its curve: one inversion for the lane
+  fe acc = fe_set_int(1);
+#pragma unroll 1
+  for (int k = 0; k < K.n; k++) {
+    store_raw(K.scr[k] + kc_sub_off(T), acc);
+    acc = fe_mul(acc, slot_load_raw(K.scr[k] + KC_P0 + 18));
+  }
+  fe inv = fe_inv_var(acc);
+#pragma unroll 1
+  for (int k = K.n - 1; k >= 0; k--) {
+    const fe zi = fe_mul(inv, slot_load_raw(K.scr[k] + kc_sub_off(T)));
+    inv = fe_mul(inv, slot_load_raw(K.scr[k] + KC_P0 + 18));
+    const fe zi2 = fe_sqr(zi);
+    const fe x = fe_mul(slot_load_raw(K.scr[k] + KC_P0 + 0), zi2);
+    const fe y = fe_mul(slot_load_raw(K.scr[k] + KC_P0 + 9), fe_mul(zi2, zi));
+    slot_store_fe(K.tab[k] + ENT_X, x);
+    slot_store_fe(K.tab[k] + ENT_BX, fe_mul(x, beta));
+    slot_store_fe(K.tab[k] + ENT_Y, y);
+  }
+#pragma unroll 1
+  for (int c = 0; c < T - 1; c++) {
+    const int cnt = 1 << c;
+    acc = fe_set_int(1);
+#pragma unroll 1
+    for (int k = 0; k < K.n; k++) {  // pass 1: the denominators x_C - x_P multiplied up, every prefix product parked
+      const fe cx = slot_load_raw(K.scr[k] + KC_C + c * 18 + 0);
+      u32 *wk = K.scr[k] + kc_sub_off(T);
+#pragma unroll 1
+      for (int m = 0; m < cnt; m++) {
+        const fe d = fe_add(cx, fe_neg(slot_load_fe(K.tab[k] + m * SLOT_ENTRY_WORDS + ENT_X), 1));
+        store_raw(wk + m * 9, acc);
+        acc = fe_mul(acc, d);
+      }
+    }
+    inv = fe_inv_var(acc);
+#pragma unroll 1
+    for (int k = K.n - 1; k >= 0; k--) {  // pass 2, backwards: 1 / d peeled off the running inverse, the new entry, its beta*x
+      const fe cx = slot_load_raw(K.scr[k] + KC_C + c * 18 + 0), cy = slot_load_raw(K.scr[k] + KC_C + c * 18 + 9);
+      const u32 *wk = K.scr[k] + kc_sub_off(T);
+#pragma unroll 1
+      for (int m = cnt - 1; m >= 0; m--) {
+        const u32 *e = K.tab[k] + m * SLOT_ENTRY_WORDS;
+        const fe xp = slot_load_fe(e + ENT_X), yp = slot_load_fe(e + ENT_Y);
+        const fe d = fe_add(cx, fe_neg(xp, 1));
+        const fe dinv = fe_mul(inv, slot_load_raw(wk + m * 9));
+        inv = fe_mul(inv, d);
+        const fe lam = fe_mul(fe_add(cy, fe_neg(yp, 1)), dinv);                 // (y_C - y_P) / (x_C - x_P)
+        const fe x3 = fe_sqr_add(lam, fe_neg(fe_add(xp, cx), 2));               // lambda^2 - x_P - x_C
+        const fe y3 = fe_mul_add(lam, fe_add(xp, fe_neg(x3, 1)), fe_neg(yp, 1)); // lambda * (x_P - x_3) - y_P
+        u32 *o = K.tab[k] + (m | cnt) * SLOT_ENTRY_WORDS;
+        slot_store_fe(o + ENT_X, x3);
+        slot_store_fe(o + ENT_BX, fe_mul(x3, beta));
+        slot_store_fe(o + ENT_Y, y3);
+      }
+    }
+  }
+#pragma unroll 1
+  for (int k = 0; k < K.n; k++) {  // Zc = Zb, and the entry of Q itself on E_b
+    const fe zb = slot_load_raw(K.scr[k] + KC_ZB);
+    slot_store_fe(K.tab[k] + kc_words(T), zb);
+    const fe z2 = fe_sqr(zb);
+    const fe x = fe_mul(qs[k].x, z2);
+    u32 *e = K.tab[k] + NE * SLOT_ENTRY_WORDS;
+    slot_store_fe(e + ENT_X, x);
+    slot_store_fe(e + ENT_BX, fe_mul(x, beta));
+    slot_store_fe(e + ENT_Y, fe_mul(qs[k].y, fe_mul(z2, zb)));
+  }
+}
+// sequential composition of the tree builder for nk keys (CPU test harness)
+template <int T>
+LAMD_HD void keytable_build_tree(u32 *const tabs[], u32 *const scratches[], const ge qs[], int nk) {
+  kc_tree_keys K;
+  K.n = nk;
+  for (int k = 0; k < nk; k++) {
+    K.tab[k] = tabs[k];
+    K.scr[k] = scratches[k];
+    kc_bases<T>(scratches[k], qs[k]);
+  }
+  kc_tree_affine<T>(K, qs);
+}
+
 // Comb recoding of one GLV half from its prep_rec form (|k| = mag + top*2^128 - 0x88..8): tooth i holds bits
 // iD..iD+D-1 of w = (|k| >> 1) | 2^(N-1)
 template <int T>

@@ -116,6 +116,32 @@ static size_t g_suspects;  // how often the bare-formula ecmult reported Z = 0 a
 size_t dm_suspects(int reset) { const size_t v = g_suspects; if (reset) g_suspects = 0; return v; }
 // keyed path: one window table per row's key (no sharing here -- this is an arithmetic test), then the table-driven ecmult
 }  // extern "C"
+// which builder makes the key tables of this harness: 0 = the Gray-code chains (keytable_build), nk = 1..4: the affine tree (keytable_build_tree) with nk
+// keys per lane -- the key under test LAST, the lane's other keys 2Q, 4Q, .. (so that the shared inversions really mix keys)
+static int g_tree_builder = 0;
+extern "C" void dm_set_table_builder(int nk) { g_tree_builder = nk < 0 ? 0 : nk > KC_TREE_MAXK ? KC_TREE_MAXK : nk; }
+template <int T>
+static void build_table(u32 *tab, u32 *scratch, const ge &q) {
+  if (!g_tree_builder) { keytable_build<T>(tab, scratch, q); return; }
+  const int nk = g_tree_builder;
+  std::vector<std::vector<u32>> tabs(nk, std::vector<u32>(kc_stride(T))), scrs(nk, std::vector<u32>(kc_scratch_words(T)));
+  std::vector<ge> qs(nk);
+  u32 *tp[KC_TREE_MAXK], *sp[KC_TREE_MAXK];
+  gej p = gej_from_ge(q);
+  for (int k = nk - 1; k >= 0; k--) {
+    if (k == nk - 1) qs[k] = q;
+    else {
+      p = gej_double(p);
+      const fe zi = fe_inv(fe_norm_weak(p.z)), zi2 = fe_sqr(zi);
+      qs[k].x = fe_normalize(fe_mul(p.x, zi2));
+      qs[k].y = fe_normalize(fe_mul(p.y, fe_mul(zi2, zi)));
+    }
+    tp[k] = tabs[k].data();
+    sp[k] = scrs[k].data();
+  }
+  keytable_build_tree<T>(tp, sp, qs.data(), nk);
+  memcpy(tab, tabs[nk - 1].data(), sizeof(u32) * kc_stride(T));
+}
 template <int T>
 static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, const u8 *key, int keylen, u8 *out) {
   dm_init();
@@ -129,7 +155,7 @@ static void verify_keyed_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
     ok &= (recs[i].flags & PREP_VALID) != 0;
     out[i] = 0;
     if (ok) {
-      keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+      build_table<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
       // as the kernels stage it: the bare-formula form first, the complete form only when it reports Z = 0
       bool suspect;
       const gexz R = ecmult_lane_keyed_fast<T>(recs[i], tab.data(), g_table.data(), &suspect);
@@ -163,7 +189,7 @@ static void verify_pairs_t(int mode, size_t n, int batch, const u8 *a32, const u
       u32 qx[8], qy[8];
       have[b] = parse_pubkey(key + (size_t)keylen * i, keylen, qx, qy) && (recs[i].flags & PREP_VALID) != 0;
       out[i] = 0;
-      if (have[b]) keytable_build<T>(&tabs[(size_t)b * kc_stride(T)], scratch.data(), ge_from_words(qx, qy));
+      if (have[b]) build_table<T>(&tabs[(size_t)b * kc_stride(T)], scratch.data(), ge_from_words(qx, qy));
     }
     pairs_batch<T>(nb, g_table.data(), ws.data(), PAIRS_WS_WORDS,
                    [&](int b, bool, const prep_rec **rec, const u32 **tab) {
@@ -184,7 +210,7 @@ static void verify_pairs_t(int mode, size_t n, int batch, const u8 *a32, const u
 template <int T>
 static void keytable_entry_t(const u32 *qx, const u32 *qy, int idx, u8 *out96) {
   std::vector<u32> tab(kc_stride(T)), scratch(kc_scratch_words(T));
-  keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  build_table<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
   // entries are affine on the key's isomorphic curve: x = x_true * Zc^2, y = y_true * Zc^3
   const fe zc = slot_load_fe(&tab[kc_words(T)]);
   const fe zi = fe_inv(zc), zi2 = fe_sqr(zi), zi3 = fe_mul(zi2, zi);
@@ -213,7 +239,7 @@ static void verify_split_t(int mode, size_t n, const u8 *a32, const u8 *sig64, c
     fe zscale;
     parts[ST_G] = small_task_g(recs[i], g_table.data());
     if (T) {
-      keytable_build<(T ? T : 7)>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+      build_table<(T ? T : 7)>(tab.data(), scratch.data(), ge_from_words(qx, qy));
       bool rt_same = true;
       for (int t = ST_H1LO; t <= ST_H2HI; t++) {
         parts[t] = small_task_comb<(T ? T : 7)>(recs[i], tab.data(), t);
@@ -295,7 +321,7 @@ template <int T>
 static int ecmult_keyed_t(const u32 *qx, const u32 *qy, const u8 *u1, const u8 *u2, u8 *out64) {
   dm_init();
   std::vector<u32> tab(kc_stride(T)), scratch(kc_scratch_words(T));
-  keytable_build<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
+  build_table<T>(tab.data(), scratch.data(), ge_from_words(qx, qy));
   prep_rec rec;
   sc k; be_to_words(k.w, u2);
   be_to_words(rec.u1, u1);

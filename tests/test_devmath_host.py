@@ -300,6 +300,19 @@ def test_keyed_path_tables_and_verdicts(dm, kat):
         assert not bad, (T, bad[:10])
 
 
+@pytest.mark.parametrize("nk", [1, 2, 4])
+def test_tree_builder_gives_the_same_tables_and_verdicts(dm, kat, nk):
+    """round 6, kc_tree_affine: the key tables as a doubling tree of affine additions with the inversions shared by the lane's nk keys -- every entry the
+    same POINT as the Gray-code chains make (checked against pyref like them), Zc = Zb, and the table-driven ecmult over such tables gives the golden
+    verdicts (ECDSA 33/65-byte keys, BIP-340).  The key under test shares its inversions with nk - 1 other keys (2Q, 4Q, ..)."""
+    dm.dm_set_table_builder(nk)
+    try:
+        test_keyed_path_tables_and_verdicts(dm, kat)
+        test_keyed_ecmult_special_scalars(dm)
+    finally:
+        dm.dm_set_table_builder(0)
+
+
 def test_pairs_first_ecmult_gives_the_golden_verdicts(dm, kat):
     """verify_core.h "Pairs first": half of a verification's mixed additions replaced by affine + affine additions whose inverses
     come from ONE inversion per batch of rows (Montgomery's trick; the inversion by division steps).  Every ECDSA golden (reference
