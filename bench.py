@@ -1041,6 +1041,10 @@ def main():
                 tab = sum(v for k, v in sv.items() if k.startswith("k_kc_") or k.startswith("k_keys_bases"))
                 valu_issue["step"] = {"valu_wave_instr_per_step": tot, "issue_ms_at_probe_clock": tot * 4 / simds / clk * 1e3, "ms_per_step": dt / args.steps * 1e3,
                                       "frac": tot * 4 / simds / clk / (dt / args.steps), "probe_clock_GHz": clk / 1e9,
+                                      # ... and at the clock the dominant kernel itself runs at (GRBM_GUI_ACTIVE / 8 / t in the counter pass: power holds it ~7 %
+                                      # below the dependency-free probe): how full the issue port is while the step runs
+                                      "kernel_clock_GHz": pm.get("shader_clock_GHz"),
+                                      "frac_at_kernel_clock": (tot * 4 / simds / (pm["shader_clock_GHz"] * 1e9) / (dt / args.steps)) if pm.get("shader_clock_GHz") else None,
                                       "share_ecmult": sum(v for k, v in sv.items() if k.startswith("k_ecmult_keyed<false")) / tot,
                                       "share_key_tables": tab / tot,
                                       "note": "all kernels of a step: VALU wave-instructions x 4 cycles / (1024 SIMDs x clock x step time)"}

@@ -140,6 +140,7 @@ os.makedirs(os.path.dirname(outp) or ".", exist_ok=True)
 json.dump({"k_ecmult_ecdsa_1M": {"kernel": kname, "hbm_bytes_per_launch": hbm, "fetch_kib": e.get("FETCH_SIZE"), "write_kib": e.get("WRITE_SIZE"),
                                   "valu_insts_per_verify": e["SQ_INSTS_VALU"] / nwaves,
                                   "valu_issue_per_simd_cycle": e["SQ_INSTS_VALU"] / 1024 / (e["GRBM_GUI_ACTIVE"] / 8),
+                                  "shader_clock_GHz": e["GRBM_GUI_ACTIVE"] / 8 / t_sq / 1e9,
                                   "fetch_size_factor": factor, "fetch_size_calibration": calib,
                                   "step_valu_wave_instr": step_valu, "step_valu_wave_instr_total": tot, "steps_in_pmc_run": steps_run,
                                   "source": outp + "_pmc_summary.txt (rocprofv3 --pmc of `bench.py --roofline-only`, separate passes; FETCH_SIZE x %.3f, %s)" % (factor, fsrc)}},
