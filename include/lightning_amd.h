@@ -291,7 +291,9 @@ int lamd_wait(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);
  * (lamd_shard_bounds: a channel_announcement's four signatures / a commitment's 1 + 483 rows stay on one device, so a per-key table is built
  * once), copies and verifies every range on its device (the ranges' host-to-device copies run side by side, piece k+1 of a range under the
  * kernels of piece k), all-gathers the verdict bytes ON THE DEVICES (ncclAllGather over xGMI, shards padded to the largest: every device
- * ends with the whole vector) and copies the vector to the host once, from the first device.  Verdicts are exactly those of the
+ * ends with the whole vector) and copies the vector to the host once, from the first device.  A gossip batch made of a few runs of one kind
+ * (a replay: its channel_announcements, then its channel_updates) is cut RUN BY RUN -- device i takes range i of every run, in one engine call --
+ * so that every device holds the same mix; the verdicts still come back in the caller's order.  Verdicts are exactly those of the
  * single-device calls (lamd_verify_ecdsa_batch, lamd_verify_schnorr_batch, lamd_sigcheck_gossip_batch); with n_devices == 1 the same path
  * runs on one GPU, collective included.  One call at a time per lamd_multi (internally locked); < 0 = LAMD_ERR_*, lamd_multi_last_error(). */
 typedef struct lamd_multi lamd_multi;

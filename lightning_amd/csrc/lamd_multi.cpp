@@ -486,29 +486,72 @@ extern "C" int lamd_multi_sigcheck_gossip_batch(lamd_multi *m, size_t n, const u
       return LAMD_ERR_ARG;
     }
   }
-  std::vector<size_t> bm(m->n + 1);
-  lamd_shard_bounds(n, wts.data(), m->n, bm.data(), nullptr);
+  // A batch whose MIX changes along its length -- a gossip replay is its channel_announcements (ten updates' worth each) followed by its
+  // channel_updates -- is cut kind by kind: every run of one kind (announcement / everything else) is cut into m->n ranges and device i takes
+  // range i of every run, so that every device holds the same mix (with one cut over the whole replay five devices of eight get nothing but
+  // announcements and the call lasts as long as the slowest kind: lightning_amd/sharding.py segment_bounds, profiles/r06_shard_timeline_cold.txt).
+  // A stream that interleaves its kinds (more than MAX_RUNS runs) is uniform already and is cut once.
+  constexpr size_t MAX_RUNS = 4;
+  std::vector<size_t> edge{0};
+  for (size_t i = 1; i < n && edge.size() <= MAX_RUNS; i++)
+    if ((sigs[i] == 4u) != (sigs[i - 1] == 4u)) edge.push_back(i);
+  if (edge.size() > MAX_RUNS) edge.assign(1, 0);
+  edge.push_back(n);
+  const size_t n_seg = edge.size() - 1;
+  std::vector<std::vector<size_t>> sb(n_seg, std::vector<size_t>(m->n + 1));  // sb[s][i] .. sb[s][i + 1]: device i's messages of run s
+  for (size_t s = 0; s < n_seg; s++) {
+    lamd_shard_bounds(edge[s + 1] - edge[s], wts.data() + edge[s], m->n, sb[s].data(), nullptr);
+    for (int i = 0; i <= m->n; i++) sb[s][i] += edge[s];
+  }
+  std::vector<size_t> tot(m->n + 1, 0);  // the gathered vector is in DEVICE order (each device's ranges back to back); put in job order below
+  for (int i = 0; i < m->n; i++) {
+    tot[i + 1] = tot[i];
+    for (size_t s = 0; s < n_seg; s++) tot[i + 1] += sb[s][i + 1] - sb[s][i];
+  }
   auto job = [&](int i) -> int {
-    const size_t lo = bm[i], cnt = bm[i + 1] - bm[i];
+    const size_t cnt = tot[i + 1] - tot[i];
     if (!cnt) return LAMD_OK;
-    const uint64_t base = off[lo], bytes = off[lo + cnt] - base;
+    // the device's ranges are laid back to back in its buffers -- bytes, offsets, node ids -- and verified by ONE engine call
+    uint64_t bytes = 0, rows = 0;
+    for (size_t s = 0; s < n_seg; s++) bytes += off[sb[s][i + 1]] - off[sb[s][i]];
     std::vector<uint64_t> rel(cnt + 1), rowbase(cnt + 1);
-    uint64_t rows = 0;
-    for (size_t k = 0; k <= cnt; k++) {
-      rel[k] = off[lo + k] - base;
-      rowbase[k] = rows;
-      if (k < cnt) rows += sigs[lo + k];
-    }
     int rc;
     if ((rc = ensure_buf(m, i, B_A, bytes + 64)) != LAMD_OK || (rc = ensure_buf(m, i, B_OFF, (cnt + 1) * 8)) != LAMD_OK ||
         (rc = ensure_buf(m, i, B_ROWBASE, (cnt + 1) * 8)) != LAMD_OK || (rc = ensure_buf(m, i, B_IDS, cnt * 33)) != LAMD_OK)
       return rc;
-    if ((rc = m->be.h2d(m->be.user, m->handle[i], m->buf[i].p[B_A], msgs + base, bytes)) != LAMD_OK) return rc;
+    size_t k = 0;
+    uint64_t at = 0;
+    for (size_t s = 0; s < n_seg; s++) {
+      const size_t lo = sb[s][i], c = sb[s][i + 1] - lo;
+      if (!c) continue;
+      const uint64_t base = off[lo], len = off[lo + c] - base;
+      for (size_t j = 0; j < c; j++, k++) {
+        rel[k] = at + (off[lo + j] - base);
+        rowbase[k] = rows;
+        rows += sigs[lo + j];
+      }
+      if ((rc = m->be.h2d(m->be.user, m->handle[i], (uint8_t *)m->buf[i].p[B_A] + at, msgs + base, len)) != LAMD_OK) return rc;
+      if (node_ids33 && (rc = m->be.h2d(m->be.user, m->handle[i], (uint8_t *)m->buf[i].p[B_IDS] + (k - c) * 33, node_ids33 + lo * 33, c * 33)) != LAMD_OK) return rc;
+      at += len;
+    }
+    rel[cnt] = at;
+    rowbase[cnt] = rows;
     if ((rc = m->be.h2d(m->be.user, m->handle[i], m->buf[i].p[B_OFF], rel.data(), (cnt + 1) * 8)) != LAMD_OK) return rc;
     if ((rc = m->be.h2d(m->be.user, m->handle[i], m->buf[i].p[B_ROWBASE], rowbase.data(), (cnt + 1) * 8)) != LAMD_OK) return rc;
-    if (node_ids33 && (rc = m->be.h2d(m->be.user, m->handle[i], m->buf[i].p[B_IDS], node_ids33 + lo * 33, cnt * 33)) != LAMD_OK) return rc;
     return m->be.sigcheck_gossip(m->be.user, m->handle[i], cnt, m->buf[i].p[B_A], m->buf[i].p[B_OFF], node_ids33 ? m->buf[i].p[B_IDS] : nullptr,
                                  m->buf[i].p[B_ROWBASE], (size_t)rows, m->buf[i].p[B_SEND]);
   };
-  return run_sharded(m, bm, job, (uint8_t *)verdict);
+  if (n_seg == 1) return run_sharded(m, tot, job, (uint8_t *)verdict);
+  std::vector<uint8_t> by_dev(n);
+  const int rc = run_sharded(m, tot, job, by_dev.data());
+  if (rc != LAMD_OK) return rc;
+  for (int i = 0; i < m->n; i++) {
+    size_t at = tot[i];
+    for (size_t s = 0; s < n_seg; s++) {
+      const size_t c = sb[s][i + 1] - sb[s][i];
+      if (c) memcpy(verdict + sb[s][i], by_dev.data() + at, c);
+      at += c;
+    }
+  }
+  return LAMD_OK;
 }

@@ -218,3 +218,38 @@ def test_multi_gossip_over_8_stub_devices(multi, orc, kat):
     before = len(st.calls)
     rc = lib.lamd_multi_sigcheck_gossip_batch(m, len(msgs), blob.ctypes.data, off.ctypes.data, None, got.ctypes.data)
     assert rc == -3 and b"node_ids33 is NULL" in lib.lamd_multi_last_error(m) and len(st.calls) == before
+
+
+def test_multi_gossip_replay_is_cut_kind_by_kind(multi, orc, kat):
+    """a replay -- every channel_announcement first, then everything else -- is cut run by run: device i takes range i of the announcements AND range
+    i of the rest in ONE engine call (its ranges back to back in its buffers), the verdicts come back in job order, and the cuts are the ones
+    lightning_amd.sharding.segment_bounds makes for the same batch"""
+    from lightning_amd import sharding
+    lib, make = multi
+    m, st = make(8)
+    vs = sorted(kat["gossip"] * 5, key=lambda v: 0 if v["msg"][:4] == "0100" else 1)    # stable: announcements | the rest
+    msgs = [H(v["msg"]) for v in vs]
+    n_cann = sum(1 for x in msgs if x[:2] == b"\x01\x00")
+    assert 0 < n_cann < len(msgs)
+    ids = [H(v["node_id"]) if "node_id" in v else bytes(33) for v in vs]
+    blob = np.frombuffer(b"".join(msgs) + b"\x00", dtype=np.uint8).copy()
+    off = np.concatenate([[0], np.cumsum([len(x) for x in msgs])]).astype(np.uint64)
+    idarr = np.frombuffer(b"".join(ids), dtype=np.uint8).reshape(len(ids), 33).copy()
+    want = orc.sigcheck_gossip_batch(blob, off, idarr, 4)
+    assert list(want) == [v["expect"] for v in vs] and len(set(want.tolist())) > 1
+    got = np.full(len(msgs), 99, np.int8)
+    rc = lib.lamd_multi_sigcheck_gossip_batch(m, len(msgs), blob.ctypes.data, off.ctypes.data, idarr.ctypes.data, got.ctypes.data)
+    assert rc == 0, lib.lamd_multi_last_error(m)
+    assert np.array_equal(got, want)
+    sb = sharding.segment_bounds([0, n_cann, len(msgs)], 8, sharding.gossip_weights(blob, off))
+    calls = [(d, n) for d, k, n in st.calls if k == "gossip"]
+    assert len(calls) == len({d for d, _ in calls}), "one engine call per device"
+    assert sorted(n for _, n in calls) == sorted(int(sb[0, i + 1] - sb[0, i] + sb[1, i + 1] - sb[1, i]) for i in range(8) if sb[0, i + 1] - sb[0, i] + sb[1, i + 1] - sb[1, i])
+    # a batch of ONE kind, and one with more runs than the host cuts by (interleaved: uniform already), still verify -- one cut
+    for sub in (slice(0, n_cann), slice(n_cann, len(msgs))):
+        o2 = (off[sub.start:sub.stop + 1] - off[sub.start]).astype(np.uint64)
+        b2 = np.concatenate([blob[int(off[sub.start]):int(off[sub.stop])], np.zeros(1, np.uint8)])
+        g2 = np.full(sub.stop - sub.start, 99, np.int8)
+        i2 = idarr[sub].copy()
+        assert lib.lamd_multi_sigcheck_gossip_batch(m, len(g2), b2.ctypes.data, o2.ctypes.data, i2.ctypes.data, g2.ctypes.data) == 0
+        assert np.array_equal(g2, want[sub])
