@@ -280,6 +280,17 @@ int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, cons
  * a caller-owned buffer.  The caller writes the rows before lamd_flush(); the pointers are valid until the next lamd_queue_* / lamd_flush call
  * on this context (a later push may move the set).  Returns the first ticket like the batch forms. */
 int lamd_queue_reserve(lamd_ctx *ctx, size_t n, size_t keylen, uint8_t **hash32, uint8_t **sig64, uint8_t **key);
+/* In-place form for a host that ALREADY holds the rows in pinned memory (lamd_served: its clients' shared blocks): the n triples (keys packed, publen
+ * / 32 bytes each) get tickets like the batch forms, but their bytes are not copied -- they cross the bus from the caller's buffers when the set is
+ * flushed.  The buffers must stay unchanged until the flush that carries the rows has been collected (lamd_poll / lamd_wait).  Batches of <= 4 096
+ * rows are copied as by lamd_queue_*_batch (the latency kernel reads the staging rows themselves).  lamd_host_register() pins a range for every
+ * device (hipHostRegister, portable) so that those transfers are DMA; unregistered memory still works, through the runtime's staging buffers.
+ * Both may be called from any thread while another drives the context.  (Replaces nothing in the reference: the producer side of SURVEY.md 8(f)'s
+ * sidecar, channeld/channeld.c:7063-7121 being one process per channel.) */
+int lamd_queue_ecdsa_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey, size_t publen);
+int lamd_queue_schnorr_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64);
+int lamd_host_register(lamd_ctx *ctx, void *p, size_t bytes);
+int lamd_host_unregister(lamd_ctx *ctx, void *p);
 int lamd_flush(lamd_ctx *ctx);
 /* 1 = finished (ok[0..*n) filled, tickets in submission order), 0 = still running, < 0 error */
 int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);

@@ -96,5 +96,6 @@ struct lamd_srv_stats {
 	uint64_t requests, engine_calls, merged_requests, merged_rows, largest_merge_requests, clients_now, clients_total;
 	uint64_t flushes, flush_rows, engine_flushes, largest_engine_flush_requests; /* client flushes, their rows, engine flushes they were merged into */
 	uint64_t devices, rows_by_device[LAMD_SRV_MAX_DEVICES];                      /* rows verified per device (key affinity) */
+	uint64_t flush_rows_in_place, pinned_blocks_now; /* flush rows that crossed the bus from the clients' own (pinned) blocks; blocks pinned right now */
 };
 #endif

@@ -80,6 +80,10 @@ SYMBOLS = {
     "lamd_wait_stream": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_wait_event": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_queue_reserve": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_sz] + [ctypes.POINTER(ctypes.c_void_p)] * 3),
+    "lamd_queue_ecdsa_batch_inplace": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p, c_sz]),
+    "lamd_queue_schnorr_batch_inplace": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p]),
+    "lamd_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz]),
+    "lamd_host_unregister": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "lamd_results_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_results_mark_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

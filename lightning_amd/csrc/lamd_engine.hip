@@ -1614,6 +1614,10 @@ struct lamd_ctx {
     static size_t blk_bytes(size_t cap, size_t keybytes) { return key_bytes_padded(cap, keybytes) + cap * 96; }
     struct span { size_t row0; u32 ticket0; size_t count; };
     std::vector<span> tickets;  // rows [row0, row0 + count) of this queue return as verdicts [ticket0, ...) of the staging set
+    // rows that were queued IN PLACE (lamd_queue_*_batch_inplace): they have a row range in the set and in its device twin like any other, but
+    // their bytes stay in the caller's (registered) memory and cross the bus from there -- no host copy at all.  Ordered by row0, disjoint.
+    struct foreign_span { size_t row0, count; const u8 *a, *b, *c; };
+    std::vector<foreign_span> foreign;
     devbuf d_blk, d_ok;   // the device twin of h_blk (same layout), the verdicts
     hipEvent_t ev_keys = nullptr, ev_sigs = nullptr, ev_all = nullptr;  // behind the three H2D copies of a flush on the copy stream
     hipEvent_t ev_res = nullptr;     // behind the flush's last kernel on its lane: the verdict copy on the D2H stream waits for it
@@ -3862,6 +3866,54 @@ extern "C" int lamd_queue_ecdsa_batch(lamd_ctx *ctx, size_t n, const uint8_t *ha
 extern "C" int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64) {
   return queue_push(ctx, Q_SCHNORR, n, msg32, sig64, xonly32, 32);
 }
+// The rows stay where they are: n triples in the caller's memory (keys packed, publen bytes each) get a row range in the open staging set and cross
+// the bus FROM THE CALLER'S BUFFERS when the set is flushed -- the form for a host that already holds its callers' rows in pinned memory (lamd_served:
+// the clients' shared blocks, registered with lamd_host_register()).  The buffers must not change until the flush that carries the rows has been
+// collected (lamd_poll / lamd_wait).  Batches the latency kernel would take (<= 4 096 rows) are copied like lamd_queue_*_batch(): that kernel reads the
+// staging rows themselves.
+static int queue_push_inplace(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *sig, const u8 *key) {
+  if (!ctx) return LAMD_ERR_ARG;
+  if (!a || !sig || !key) {
+    ctx->err = "bad argument";
+    return LAMD_ERR_ARG;
+  }
+  if (n <= SMALL_MAX || !ctx->use_copy_stream) return queue_push(ctx, kind, n, a, sig, key, Q_KEYBYTES[kind]);
+  u8 *da, *db, *dc;
+  const int first = queue_take(ctx, kind, n, &da, &db, &dc);
+  if (first < 0) return first;
+  lamd_ctx::queue &q = ctx->qs[ctx->q_open].q[kind];
+  q.foreign.push_back({q.n - n, n, a, sig, key});
+  return first;
+}
+extern "C" int lamd_queue_ecdsa_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey, size_t publen) {
+  if (ctx && publen != 33 && publen != 65) {
+    ctx->err = "bad key length";
+    return LAMD_ERR_ARG;
+  }
+  return queue_push_inplace(ctx, publen == 33 ? Q_ECDSA33 : Q_ECDSA65, n, hash32, sig64, pubkey);
+}
+extern "C" int lamd_queue_schnorr_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64) {
+  return queue_push_inplace(ctx, Q_SCHNORR, n, msg32, sig64, xonly32);
+}
+// Pins a range of the caller's memory for every device (hipHostRegisterPortable), so that rows queued in place leave it by DMA.  Callable from any
+// thread, also while another thread drives the context: nothing of the context is touched but its device number.  < 0: LAMD_ERR_HIP (the range stays
+// usable -- unpinned memory crosses the bus through the runtime's own staging buffers, slowly and synchronously).
+extern "C" int lamd_host_register(lamd_ctx *ctx, void *p, size_t bytes) {
+  if (!ctx || !p || !bytes) return LAMD_ERR_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return LAMD_ERR_HIP;
+  }
+  return LAMD_OK;
+}
+extern "C" int lamd_host_unregister(lamd_ctx *ctx, void *p) {
+  if (!ctx || !p) return LAMD_ERR_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return LAMD_ERR_HIP;
+  }
+  return LAMD_OK;
+}
 // Launches everything queued so far as one batch per kind (asynchronous, on the next lane) and opens the next staging set:
 // queueing continues while up to QUEUE_SETS - 1 flushes are in flight.
 extern "C" int lamd_flush(lamd_ctx *ctx) {
@@ -3934,7 +3986,29 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     // dependency in order on compute queues: 119-137 M verifies/s against 168-185 M/s for these copies, profiles/r03_ab_variants.txt:
     // device-initiated reads of host memory reach a fraction of the SDMA engines' 57 GB/s.  Dropped.)
     const bool split = q.n <= L->chunk;
-    if (split && ctx->use_copy_stream) {
+    if (!q.foreign.empty()) {
+      // rows queued in place: every run of rows -- the caller's buffers for the in-place ones, the staging set for what lies between them -- goes down
+      // the copy stream into its rows of the device twin, three copies per run, ONE event behind the last (as the single-event form below)
+      hipStream_t &csr = ctx->copy_streams[ctx->copy_turn++ % (unsigned)ctx->n_copy_streams];
+      if (!csr) HIPCHK(ctx, hipStreamCreateWithFlags(&csr, hipStreamNonBlocking));
+      hipStream_t cs = csr;
+      auto run = [&](size_t row0, size_t cnt, const u8 *a, const u8 *b, const u8 *c) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(qd_c + row0 * kb, c, cnt * kb, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipMemcpyAsync(qd_b + row0 * 64, b, cnt * 64, hipMemcpyHostToDevice, cs);
+        if (e == hipSuccess) e = hipMemcpyAsync(qd_a + row0 * 32, a, cnt * 32, hipMemcpyHostToDevice, cs);
+        return e;
+      };
+      size_t at = 0;
+      for (const auto &f : q.foreign) {
+        if (f.row0 > at) HIPCHK(ctx, run(at, f.row0 - at, q.h_a + 32 * at, q.h_b + 64 * at, q.h_c + kb * at));
+        HIPCHK(ctx, run(f.row0, f.count, f.a, f.b, f.c));
+        at = f.row0 + f.count;
+      }
+      if (at < q.n) HIPCHK(ctx, run(at, q.n - at, q.h_a + 32 * at, q.h_b + 64 * at, q.h_c + kb * at));
+      HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
+      HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_all, 0));
+      HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));
+    } else if (split && ctx->use_copy_stream) {
       // Round 3: the copies of EVERY flush go down one stream of their own, in flush order, behind nothing but each other.  On the
       // lane's prep stream they stood behind the lane's previous call, so with more flushes in flight than lanes the rows of the
       // next flush still crossed the bus only after the lane had gone idle (1.2 ms for the keys of 1 M rows before its first kernel
@@ -4057,6 +4131,7 @@ static int collect(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
     }
     q.small_flush = false;
     q.tickets.clear();
+    q.foreign.clear();
     q.n = 0;
   }
   qs.rows = 0;

@@ -2,7 +2,7 @@
 // Protocol and rationale: include/lightning_amd_served.h.  SURVEY.md section 7 "Process model": one channeld per channel
 // (channeld/channeld.c:7019-7129), gossipd, lightningd and plugins are separate single-threaded processes that verify inline.
 //
-//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US]
+//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US] [--copy-flushes]
 //
 // Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job; a synchronous job it waits for and answers, a
 // flush it hands over and goes on reading); ONE engine thread PER DEVICE, the only caller of that device's context (a context is not
@@ -59,6 +59,10 @@ struct engine_api {
   decltype(&lamd_grind_htlc_tx_fee) grind = nullptr;
   decltype(&lamd_queue_ecdsa_batch) queue_ecdsa = nullptr;
   decltype(&lamd_queue_schnorr_batch) queue_schnorr = nullptr;
+  decltype(&lamd_queue_ecdsa_batch_inplace) queue_ecdsa_inplace = nullptr;    // optional (an older engine library: every flush row is copied)
+  decltype(&lamd_queue_schnorr_batch_inplace) queue_schnorr_inplace = nullptr;
+  decltype(&lamd_host_register) host_register = nullptr;
+  decltype(&lamd_host_unregister) host_unregister = nullptr;
   decltype(&lamd_flush) flush = nullptr;
   decltype(&lamd_poll) poll = nullptr;
   decltype(&lamd_wait) wait = nullptr;
@@ -73,6 +77,7 @@ bool bind(void *lib, const char *name, F *fn) {
 struct blk {
   uint8_t *p = nullptr;
   size_t size = 0;
+  bool pinned = false;  // a flush block the runtime has pinned (lamd_host_register): its rows are queued IN PLACE and leave it by DMA
 };
 struct conn {
   int fd = -1;
@@ -128,6 +133,10 @@ size_t g_max_merge = (size_t)1 << 20;
 // clients streaming 31 k-row flushes): unbounded 0.25 of one in-process producer's rate, 262 144 rows 0.41, 131 072 0.69, 65 536 0.77.
 size_t g_max_flush_rows = (size_t)1 << 16;
 unsigned g_linger_us = 0;
+// Flush rows stay in the client's block and cross the bus from there (the block is pinned when it is attached) instead of being copied into the
+// engine's staging set first: the copy -- 161 bytes per row, by the one engine thread of the device and its copy helpers -- was a third of the
+// service's time per streamed row (profiles/r06_served_stream.txt).  --copy-flushes switches it off (the A/B, and for a runtime that cannot pin).
+bool g_inplace = true;
 const size_t ENGINE_FLUSHES_IN_FLIGHT = 8;
 
 const uint8_t *sec(const job *j, int i) { return j->c->shm[j->slot].p + j->off[i]; }
@@ -500,8 +509,14 @@ void submit_flushes(std::vector<job *> &fl) {
     size_t o = 0, ko = 0;
     for (uint64_t run : j->o_in) {
       const size_t kl = (size_t)(run >> 32), cnt = (size_t)(run & 0xFFFFFFFFu);
-      const int rc = kl == 32 ? E.queue_schnorr(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 3) + ko, sec(j, 2) + 64 * o)
-                              : E.queue_ecdsa(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 2) + 64 * o, sec(j, 3) + ko, kl, kl);
+      // (in place: the block is the client's to write, but it carries one flush at a time and is neither replaced nor unmapped before that flush is
+      // answered -- slot_pending, async_pending -- which is after the engine has handed the verdicts back)
+      const bool inplace = j->c->shm[j->slot].pinned;
+      const int rc = inplace ? (kl == 32 ? E.queue_schnorr_inplace(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 3) + ko, sec(j, 2) + 64 * o)
+                                         : E.queue_ecdsa_inplace(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 2) + 64 * o, sec(j, 3) + ko, kl))
+                     : kl == 32 ? E.queue_schnorr(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 3) + ko, sec(j, 2) + 64 * o)
+                                : E.queue_ecdsa(g_ctx, cnt, sec(j, 1) + 32 * o, sec(j, 2) + 64 * o, sec(j, 3) + ko, kl, kl);
+      if (rc >= 0 && inplace) stat_add(&g_stats.flush_rows_in_place, cnt);
       if (rc < 0) {  // the rows queued so far stay in the set (their verdicts are dropped); this client gets the error
         engine_error(j, rc);
         break;
@@ -617,6 +632,17 @@ device *pick_device(const job *j) {
   return g_dev[(size_t)((h >> 17) % g_dev.size())];
 }
 
+void drop_block(blk &b) {
+  if (!b.p) return;
+  if (b.pinned) {
+    if (E.host_unregister) E.host_unregister(g_dev[0]->ctx, b.p);
+    std::lock_guard<std::mutex> lk(statmu);
+    g_stats.pinned_blocks_now--;
+  }
+  munmap(b.p, b.size);
+  b = blk();
+}
+
 void serve(conn *cp) {
   conn &c = *cp;
   const int fd = c.fd;
@@ -653,9 +679,14 @@ void serve(conn *cp) {
         close(newfd);
         if (p == MAP_FAILED) fail(&j, LAMD_ERR_NOMEM, "mmap of the client's block failed");
         else {
-          if (c.shm[slot].p) munmap(c.shm[slot].p, c.shm[slot].size);
+          drop_block(c.shm[slot]);
           c.shm[slot].p = (uint8_t *)p;
           c.shm[slot].size = sz;
+          // a flush block is pinned once, here, for every device; a runtime that refuses the mapping leaves the block to the copying form
+          if (slot && g_inplace && E.host_register && E.queue_ecdsa_inplace && E.queue_schnorr_inplace && E.host_register(g_dev[0]->ctx, p, sz) == LAMD_OK) {
+            c.shm[slot].pinned = true;
+            stat_add(&g_stats.pinned_blocks_now, 1);
+          }
           j.rep.rc = LAMD_OK;
         }
       }
@@ -703,8 +734,7 @@ void serve(conn *cp) {
     if (!ok) break;
   }
   while (c.async_pending.load() > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));  // engine threads still write into the blocks
-  for (blk &b : c.shm)
-    if (b.p) munmap(b.p, b.size);
+  for (blk &b : c.shm) drop_block(b);
   close(fd);
   delete cp;
   std::lock_guard<std::mutex> lk(statmu);
@@ -741,8 +771,9 @@ int main(int argc, char **argv) {
     else if (a == "--max-merge") g_max_merge = (size_t)atoll(val());
     else if (a == "--max-flush-rows") g_max_flush_rows = (size_t)atoll(val());
     else if (a == "--linger-us") g_linger_us = (unsigned)atoi(val());
+    else if (a == "--copy-flushes") g_inplace = false;
     else {
-      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US]\n");
+      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US] [--copy-flushes]\n");
       return 2;
     }
   }
@@ -767,6 +798,11 @@ int main(int argc, char **argv) {
             bind(E.lib, "lamd_queue_ecdsa_batch", &E.queue_ecdsa) & bind(E.lib, "lamd_queue_schnorr_batch", &E.queue_schnorr) &
             bind(E.lib, "lamd_flush", &E.flush) & bind(E.lib, "lamd_poll", &E.poll) & bind(E.lib, "lamd_wait", &E.wait);
   if (!ok) return 1;
+  // optional: rows queued in place (silently absent in an older engine library: every flush row is copied)
+  *(void **)&E.queue_ecdsa_inplace = dlsym(E.lib, "lamd_queue_ecdsa_batch_inplace");
+  *(void **)&E.queue_schnorr_inplace = dlsym(E.lib, "lamd_queue_schnorr_batch_inplace");
+  *(void **)&E.host_register = dlsym(E.lib, "lamd_host_register");
+  *(void **)&E.host_unregister = dlsym(E.lib, "lamd_host_unregister");
   memset(&g_stats, 0, sizeof g_stats);
   for (size_t k = 0; k < devices.size(); k++) {
     device *dev = new device;

@@ -289,6 +289,29 @@ class Engine:
         views = [np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(n), w)) for p, w in zip(ptr, (32, 64, int(keylen)))]
         return (first, *views)
 
+    def queue_ecdsa_batch_inplace(self, hash32, sig64, pub):
+        """the rows are NOT copied: C-contiguous numpy uint8 [n,32], [n,64], [n,33|65] that the caller keeps alive and unchanged until the flush
+        carrying them has been collected (wait / poll); pin them with host_register() for DMA.  First ticket."""
+        for a, w in ((hash32, 32), (sig64, 64)):
+            if a.dtype != np.uint8 or not a.flags.c_contiguous or a.ndim != 2 or a.shape[1] != w:
+                raise ValueError("in-place rows must be C-contiguous uint8 [n,%d]" % w)
+        if pub.dtype != np.uint8 or not pub.flags.c_contiguous or pub.ndim != 2 or pub.shape[0] != hash32.shape[0] or sig64.shape[0] != hash32.shape[0]:
+            raise ValueError("in-place keys must be C-contiguous uint8 [n,33|65]")
+        return self._chk(self._lib.lamd_queue_ecdsa_batch_inplace(self._ctx, hash32.shape[0], hash32.ctypes.data, sig64.ctypes.data, pub.ctypes.data, pub.shape[1]))
+
+    def queue_schnorr_batch_inplace(self, msg32, xonly32, sig64):
+        for a, w in ((msg32, 32), (xonly32, 32), (sig64, 64)):
+            if a.dtype != np.uint8 or not a.flags.c_contiguous or a.ndim != 2 or a.shape[1] != w or a.shape[0] != msg32.shape[0]:
+                raise ValueError("in-place rows must be C-contiguous uint8 [n,%d]" % w)
+        return self._chk(self._lib.lamd_queue_schnorr_batch_inplace(self._ctx, msg32.shape[0], msg32.ctypes.data, xonly32.ctypes.data, sig64.ctypes.data))
+
+    def host_register(self, arr):
+        """pins a numpy array's memory for every device (rows queued in place leave it by DMA); False when the runtime refuses the range"""
+        return self._lib.lamd_host_register(self._ctx, arr.ctypes.data, arr.nbytes) == 0
+
+    def host_unregister(self, arr):
+        return self._lib.lamd_host_unregister(self._ctx, arr.ctypes.data) == 0
+
     def flush(self):
         self._chk(self._lib.lamd_flush(self._ctx))
 

@@ -6,9 +6,15 @@
 
 #include "lightning_amd.h"
 
+#include <pthread.h>
+
 #define STUB_SETS 16
-struct stub_set { uint8_t *ok; size_t n, cap; int polled; };
-struct lamd_ctx { int device; unsigned long calls, rows, largest; char err[64]; struct stub_set open, closed[STUB_SETS]; int head, count; };
+#define STUB_DEFERRED 64
+/* rows queued in place: their verdicts are computed when the flush is COLLECTED, from the caller's buffers -- a host that lets go of (or rewrites) a
+ * buffer before it has collected the flush gets the wrong verdicts here */
+struct stub_deferred { size_t pos, n, publen; const uint8_t *a, *b, *c; };
+struct stub_set { uint8_t *ok; size_t n, cap; int polled; struct stub_deferred late[STUB_DEFERRED]; int n_late; };
+struct lamd_ctx { int device; unsigned long calls, rows, largest, inplace_rows; char err[64]; struct stub_set open, closed[STUB_SETS]; int head, count; };
 
 int lamd_init(lamd_ctx **ctx, int device) {
 	*ctx = calloc(1, sizeof **ctx);
@@ -145,6 +151,55 @@ int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *m, const ui
 	ctx->rows += n;
 	return first;
 }
+/* the registered ranges are the process's, as hipHostRegister(portable)'s are; rows queued in place must lie inside one (the stub is stricter than the
+ * engine, which accepts unpinned memory and is slow on it: the server under test must register what it queues in place).  STUB_REFUSE_REGISTER=1: the
+ * runtime refuses every range, as it may for a mapping it cannot pin -- the server must fall back to the copying form. */
+static pthread_mutex_t reg_mu = PTHREAD_MUTEX_INITIALIZER;
+static struct { const uint8_t *p; size_t bytes; } reg[256];
+static int n_reg;
+int lamd_host_register(lamd_ctx *ctx, void *p, size_t bytes) {
+	const char *refuse = getenv("STUB_REFUSE_REGISTER");
+	if (!ctx || !p || !bytes) return LAMD_ERR_ARG;
+	if (refuse && refuse[0] == '1') return LAMD_ERR_HIP;
+	pthread_mutex_lock(&reg_mu);
+	int rc = LAMD_ERR_HIP;
+	if (n_reg < 256) { reg[n_reg].p = p; reg[n_reg++].bytes = bytes; rc = LAMD_OK; }
+	pthread_mutex_unlock(&reg_mu);
+	return rc;
+}
+int lamd_host_unregister(lamd_ctx *ctx, void *p) {
+	int rc = LAMD_ERR_HIP;
+	if (!ctx || !p) return LAMD_ERR_ARG;
+	pthread_mutex_lock(&reg_mu);
+	for (int i = 0; i < n_reg; i++)
+		if (reg[i].p == p) { reg[i] = reg[--n_reg]; rc = LAMD_OK; break; }
+	pthread_mutex_unlock(&reg_mu);
+	return rc;
+}
+static int registered(const uint8_t *p, size_t bytes) {
+	int ok = 0;
+	pthread_mutex_lock(&reg_mu);
+	for (int i = 0; i < n_reg && !ok; i++) ok = p >= reg[i].p && p + bytes <= reg[i].p + reg[i].bytes;
+	pthread_mutex_unlock(&reg_mu);
+	return ok;
+}
+static int push_late(lamd_ctx *ctx, size_t n, const uint8_t *a, const uint8_t *b, const uint8_t *c, size_t alen, size_t blen, size_t clen, size_t publen) {
+	const int first = (int)g_open.n;
+	if (!registered(a, alen * n) || !registered(b, blen * n) || !registered(c, clen * n)) { strcpy(ctx->err, "stub: in-place rows outside registered memory"); return LAMD_ERR_ARG; }
+	if (g_open.n_late == STUB_DEFERRED) { strcpy(ctx->err, "stub: too many in-place batches in one set"); return LAMD_ERR_STATE; }
+	g_open.late[g_open.n_late++] = (struct stub_deferred){g_open.n, n, publen, a, b, c};
+	for (size_t i = 0; i < n; i++) push_ok(ctx, 0xAA);
+	ctx->rows += n;
+	ctx->inplace_rows += n;
+	return first;
+}
+int lamd_queue_ecdsa_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *h, const uint8_t *s, const uint8_t *p, size_t publen) {
+	if (n && h[0] == 0xEE && h[1] == 0xEE) { strcpy(ctx->err, "stub: poisoned batch"); return LAMD_ERR_HIP; }
+	return push_late(ctx, n, h, s, p, 32, 64, publen, publen);
+}
+int lamd_queue_schnorr_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *m, const uint8_t *x, const uint8_t *s) {
+	return push_late(ctx, n, m, x, s, 32, 32, 64, 0);
+}
 int lamd_flush(lamd_ctx *ctx) {
 	if (!g_open.n) return LAMD_OK;
 	if (g_count == STUB_SETS) { strcpy(ctx->err, "stub: too many flushes outstanding"); return LAMD_ERR_STATE; }
@@ -155,6 +210,12 @@ int lamd_flush(lamd_ctx *ctx) {
 }
 static int take(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n) {
 	if (g_closed[g_head].n > cap) return LAMD_ERR_ARG;
+	for (int k = 0; k < g_closed[g_head].n_late; k++) {
+		const struct stub_deferred *d = &g_closed[g_head].late[k];
+		for (size_t i = 0; i < d->n; i++)
+			g_closed[g_head].ok[d->pos + i] = d->publen ? (d->a[32 * i] ^ d->b[64 * i + 63] ^ d->c[d->publen * i + d->publen - 1]) & 1
+							       : (d->a[32 * i + 1] ^ d->b[32 * i + 2] ^ d->c[64 * i + 3]) & 1;
+	}
 	memcpy(ok, g_closed[g_head].ok, g_closed[g_head].n);
 	*n = g_closed[g_head].n;
 	free(g_closed[g_head].ok);

@@ -130,9 +130,8 @@ def test_random_ecdsa_vs_oracle_ragged_sizes(eng, orc, n):
         assert n < 50 or (exp.sum() > n // 2 and (~exp).sum() > 0)
 
 
-@pytest.mark.parametrize("n", [1, 64, 65, 700, 3000])
-def test_random_schnorr_vs_oracle(eng, orc, n):
-    rnd = random.Random(2000 + n)
+def _random_schnorr(orc, rnd, n):
+    """n BIP-340 rows, about three in eight damaged -> (msg [n,32], x-only key [n,32], sig [n,64], the oracle's verdicts)"""
     ms, ks, sg = [], [], []
     for i in range(n):
         d = rnd.randrange(1, N).to_bytes(32, "big")
@@ -150,8 +149,13 @@ def test_random_schnorr_vs_oracle(eng, orc, n):
             k = k[:j] + bytes([k[j] ^ (1 << rnd.randrange(8))]) + k[j + 1:]
         ms.append(m); ks.append(k); sg.append(s)
     ms, ks, sg = _rows(ms, 32), _rows(ks, 32), _rows(sg, 64)
+    return ms, ks, sg, orc.schnorr_verify_batch(ms, ks, sg, 4).astype(bool)
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 700, 3000])
+def test_random_schnorr_vs_oracle(eng, orc, n):
+    ms, ks, sg, exp = _random_schnorr(orc, random.Random(2000 + n), n)
     got = eng.verify_schnorr(ms, ks, sg)
-    exp = orc.schnorr_verify_batch(ms, ks, sg, 4).astype(bool)
     assert np.array_equal(got, exp), np.nonzero(got != exp)[0][:10]
 
 
@@ -985,6 +989,55 @@ def test_streaming_zero_copy_reserve_mixed_with_copies(eng, orc):
         assert np.array_equal(eng.wait(), outstanding.pop(0))
     with pytest.raises(Exception):
         eng.queue_reserve(4, 40)                                 # not a key length
+
+
+def test_streaming_rows_queued_in_place(eng, orc):
+    """lamd_queue_*_batch_inplace(): rows that stay in the caller's memory (registered or not) and cross the bus from there, mixed inside one flush
+    with copied rows before, between and after them (tickets keep counting), three kinds, small batches (copied: the latency kernel's) and large
+    ones, several flushes in flight -- verdicts equal the oracle's"""
+    rnd = random.Random(4242)
+    outstanding, keep = [], []
+    for b in range(5):
+        n_copy, n_in1, n_mid, n_in2 = rnd.choice((1, 300)), rnd.choice((4097, 9000)), rnd.choice((0, 77)), rnd.choice((5000, 4100))
+        n = n_copy + n_in1 + n_mid + n_in2
+        hs, sg, pk = _random_ecdsa(orc, rnd, n, 33)
+        sg = sg.copy(); sg[::5, 40] ^= 0x04
+        e33 = orc.ecdsa_verify_batch(hs, sg, pk, 33, 4).astype(bool)
+        ns = rnd.choice((4500, 6000))
+        ms, xs, ss, es = _random_schnorr(orc, rnd, ns)
+        n65 = rnd.choice((10, 4200))
+        hs65, sg65, pk65 = _random_ecdsa(orc, rnd, n65, 65)
+        e65 = orc.ecdsa_verify_batch(hs65, sg65, pk65, 65, 4).astype(bool)
+        o1, o2, o3 = n_copy, n_copy + n_in1, n_copy + n_in1 + n_mid
+        part = lambda lo, hi: [np.ascontiguousarray(x[lo:hi]) for x in (hs, sg, pk)]
+        p1, p2 = part(o1, o2), part(o3, n)
+        sch = [np.ascontiguousarray(x) for x in (ms, xs, ss)]
+        p65 = [np.ascontiguousarray(x) for x in (hs65, sg65, pk65)]
+        keep.append((p1, p2, sch, p65))                              # alive and unchanged until collected
+        if b % 2 == 0:
+            assert all(eng.host_register(x) for x in p1 + sch), "hipHostRegister refused plain host memory"
+        t0 = eng.queue_ecdsa_batch(hs[:o1], sg[:o1], pk[:o1])
+        t1 = eng.queue_ecdsa_batch_inplace(*p1)
+        if n_mid:
+            eng.queue_ecdsa_batch(hs[o2:o3], sg[o2:o3], pk[o2:o3])
+        t2 = eng.queue_ecdsa_batch_inplace(*p2)
+        t3 = eng.queue_schnorr_batch_inplace(*sch)
+        t4 = eng.queue_ecdsa_batch_inplace(*p65) if b % 2 else eng.queue_ecdsa_batch(*p65)
+        assert (t0, t1, t2, t3, t4) == (0, o1, o3, n, n + ns)
+        eng.flush()
+        outstanding.append((np.concatenate([e33, es, e65]), b))
+        if len(outstanding) == 3:
+            exp, bb = outstanding.pop(0)
+            assert np.array_equal(eng.wait(), exp), bb
+            if bb % 2 == 0:
+                assert all(eng.host_unregister(x) for x in keep[bb][0] + keep[bb][2])
+    while outstanding:
+        exp, bb = outstanding.pop(0)
+        assert np.array_equal(eng.wait(), exp), bb
+        if bb % 2 == 0:
+            assert all(eng.host_unregister(x) for x in keep[bb][0] + keep[bb][2])
+    with pytest.raises(ValueError):
+        eng.queue_ecdsa_batch_inplace(hs[:, :31], sg, pk)
 
 
 def test_key_table_cache_warm_cold_and_bounded(orc):

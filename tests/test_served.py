@@ -19,7 +19,8 @@ PER = 484
 
 class Stats(ctypes.Structure):
     _fields_ = [(k, ctypes.c_uint64) for k in ("requests", "engine_calls", "merged_requests", "merged_rows", "largest_merge_requests", "clients_now", "clients_total",
-                                               "flushes", "flush_rows", "engine_flushes", "largest_engine_flush_requests", "devices")] + [("rows_by_device", ctypes.c_uint64 * 8)]
+                                               "flushes", "flush_rows", "engine_flushes", "largest_engine_flush_requests", "devices")] + [("rows_by_device", ctypes.c_uint64 * 8)] + \
+               [("flush_rows_in_place", ctypes.c_uint64), ("pinned_blocks_now", ctypes.c_uint64)]
 
 
 class TxTemplate(ctypes.Structure):
@@ -398,6 +399,9 @@ def test_streaming_flushes_keep_their_order_and_their_rows(stub):
         assert L.lamd_client_server_stats(ctx, ctypes.byref(st2)) == 0
         assert sum(1 for i in range(3) if st2.rows_by_device[i] > st1.rows_by_device[i]) >= 2
         assert st2.flushes == 8 + 1 + 1 + 1 + 2 + 1 + 12 + 30 and st2.engine_flushes <= st2.flushes and st2.flush_rows >= big
+        # every flush block was pinned when it was attached and its rows were queued in place (the stub computes their verdicts from the block when the
+        # flush is collected, and refuses in-place rows outside registered memory); the poisoned flush's rows never got that far
+        assert st2.pinned_blocks_now >= 1 and 0 < st2.flush_rows - st2.flush_rows_in_place <= 64
         L.lamd_shutdown(ctx)
     finally:
         out = _stop(p)
@@ -428,10 +432,15 @@ print("bad", bad)
 """
 
 
-def test_streams_of_eight_client_processes_share_the_engine_flushes(stub):
+@pytest.mark.parametrize("mode", ["in_place", "copy_flushes", "runtime_refuses_to_pin"])
+def test_streams_of_eight_client_processes_share_the_engine_flushes(stub, mode, monkeypatch):
+    """... with the flush rows queued in place from the clients' pinned blocks (the default), copied (--copy-flushes), and copied because the runtime
+    refuses to pin a block (the fallback): the same verdicts"""
     so, d = stub
-    sock = os.path.join(d, "t.sock")
-    p = _start(sock, so, ["--devices", "0,1"])
+    sock = os.path.join(d, "t_%s.sock" % mode)
+    if mode == "runtime_refuses_to_pin":
+        monkeypatch.setenv("STUB_REFUSE_REGISTER", "1")
+    p = _start(sock, so, ["--devices", "0,1"] + (["--copy-flushes"] if mode == "copy_flushes" else []))
     try:
         procs = [subprocess.Popen([sys.executable, "-c", STREAM_CLIENT_SCRIPT, ROOT, sock, str(300 + i), "60"], stdout=subprocess.PIPE, text=True) for i in range(8)]
         outs = [q.communicate(timeout=180)[0] for q in procs]
@@ -440,10 +449,15 @@ def test_streams_of_eight_client_processes_share_the_engine_flushes(stub):
         rc, ctx = _connect(L, sock)
         assert rc == 0
         st = Stats()
-        assert L.lamd_client_server_stats(ctx, ctypes.byref(st)) == 0
+        for _ in range(100):      # the server lets go of a client's blocks when it sees the connection close: a moment after the process has gone
+            assert L.lamd_client_server_stats(ctx, ctypes.byref(st)) == 0
+            if st.pinned_blocks_now == 0 and st.clients_now == 1:
+                break
+            time.sleep(0.05)
         L.lamd_shutdown(ctx)
         assert st.flushes == 8 * 60 and st.engine_flushes <= st.flushes and st.rows_by_device[0] > 0 and st.rows_by_device[1] > 0
         assert st.rows_by_device[0] + st.rows_by_device[1] == st.flush_rows
+        assert st.flush_rows_in_place == (st.flush_rows if mode == "in_place" else 0) and st.pinned_blocks_now == 0     # the clients are gone: nothing stays pinned
     finally:
         _stop(p)
 
@@ -671,8 +685,8 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
     """VERDICT r05 "next" 8: BASELINE configs[4] as channelds see it -- 8 client processes, each STREAMING its channels' commitments (flushes kept in
     flight: lamd_queue_*_batch / lamd_flush / lamd_wait of the client library) through ONE lamd_served.  Every verdict equals construction (= the
     in-process engine's, checked on the same rows), and the rate of the whole job is compared with the same job streamed by one in-process
-    producer (the ratio lands in gpurun_out/served_stream.json: 0.77 on the round's box, profiles/r06_served_stream.txt; asserted >= 0.4 -- the
-    box's host cores decide the rest)."""
+    producer (the ratio lands in gpurun_out/served_stream.json: 0.85-0.88 with the flush rows queued in place from the clients' pinned blocks, 0.67-0.69
+    with --copy-flushes, profiles/r06_served_stream.txt; asserted >= 0.4 -- the box's host cores decide the rest)."""
     import json
     import torch
     from lightning_amd import Engine, workload
@@ -683,7 +697,7 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
         per = st["per"]
         assert per == PER
         # in-process: the same flushes (64 commitments each), the two kinds interleaved, DEPTH in flight
-        def inproc():
+        def inproc(inplace=False):
             jobs = []
             for kind in ("ecdsa", "schnorr"):
                 wl = st[kind]
@@ -694,7 +708,10 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
             t0 = time.time()
             for _, kind, o, z in jobs:
                 wl = st[kind]
-                (eng.queue_ecdsa_batch if kind == "ecdsa" else eng.queue_schnorr_batch)(wl.cols[0][o:z], wl.cols[1][o:z], wl.cols[2][o:z])
+                if inplace:
+                    (eng.queue_ecdsa_batch_inplace if kind == "ecdsa" else eng.queue_schnorr_batch_inplace)(wl.cols[0][o:z], wl.cols[1][o:z], wl.cols[2][o:z])
+                else:
+                    (eng.queue_ecdsa_batch if kind == "ecdsa" else eng.queue_schnorr_batch)(wl.cols[0][o:z], wl.cols[1][o:z], wl.cols[2][o:z])
                 eng.flush()
                 pend.append(wl.expect[o:z])
                 if len(pend) == DEPTH:
@@ -705,6 +722,14 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
         inproc()
         t_in, bad_in = min(inproc() for _ in range(3))
         assert bad_in == 0
+        # the same producer with its rows queued IN PLACE (the columns pinned once: lamd_host_register): no host copy at all
+        cols = [c for kind in ("ecdsa", "schnorr") for c in st[kind].cols]
+        pinned = all(eng.host_register(c) for c in cols)
+        inproc(True)
+        t_in_place, bad_in_place = min(inproc(True) for _ in range(3))
+        assert bad_in_place == 0
+        if pinned:
+            assert all(eng.host_unregister(c) for c in cols)
         nv = st["ecdsa"].n + st["schnorr"].n
     finally:
         eng.close()
@@ -739,9 +764,10 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
         stt = Stats()
         assert L.lamd_client_server_stats(ctx, ctypes.byref(stt)) == 0
         L.lamd_shutdown(ctx)
-        rec = {"verifies": nv, "clients": W, "commitments_per_flush": CPF, "flushes_in_flight_per_client": DEPTH, "in_process_s": t_in, "served_s": t_served,
+        rec = {"verifies": nv, "clients": W, "commitments_per_flush": CPF, "flushes_in_flight_per_client": DEPTH, "in_process_s": t_in, "served_s": t_served, "in_process_in_place_s": t_in_place, "in_process_columns_pinned": bool(pinned),
                "in_process_verifies_per_s": nv / t_in, "served_verifies_per_s": nv / t_served, "served_over_in_process": t_in / t_served,
-               "client_flushes": int(stt.flushes), "engine_flushes": int(stt.engine_flushes), "largest_engine_flush_requests": int(stt.largest_engine_flush_requests)}
+               "client_flushes": int(stt.flushes), "engine_flushes": int(stt.engine_flushes), "largest_engine_flush_requests": int(stt.largest_engine_flush_requests),
+               "flush_rows": int(stt.flush_rows), "flush_rows_in_place": int(stt.flush_rows_in_place), "server_args": os.environ.get("LAMD_SERVED_TEST_ARGS", "")}
         print("served streaming:", rec)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "served_stream.json"), "w"), indent=1)
