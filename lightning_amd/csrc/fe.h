@@ -285,6 +285,9 @@ LAMD_HD void fe_mac_k(u64 &acc, u32 a, u32 k) {
 
 // the asm statements' operand lists (tools/gen_fe_asm.py: operand map) and what follows them
 // (the latency schedule, fe_asm_ilp.inc, brings eight more pinned accumulators: LAMD_FE_ASM_EXTRA_DECL / _OUT)
+#if !defined(LAMD_FE_ASM_CLOBBER)   // (a generated schedule that parks the multiply-adds' unused carry-out in an SGPR pair names the pair here)
+#define LAMD_FE_ASM_CLOBBER "vcc"
+#endif
 #if !defined(LAMD_FE_ASM_EXTRA_DECL)
 #define LAMD_FE_ASM_EXTRA_DECL
 #define LAMD_FE_ASM_EXTRA_OUT
@@ -330,7 +333,7 @@ LAMD_HD fe fe_mul(const fe &a, const fe &b) {
 #if defined(LAMD_FE_ASM_BLOCK)
   // the whole multiplication as ONE asm statement (fe_asm.inc): no compiler-inserted s_nop between the dependent multiply-adds
   LAMD_FE_ASM_DECL
-  asm(LAMD_FE_MUL_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K : "vcc");
+  asm(LAMD_FE_MUL_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) fe_mul_col<ch>(a, b, k, acc)
@@ -347,7 +350,7 @@ LAMD_HD fe fe_sqr(const fe &a) {
   for (int i = 0; i < 9; i++) d.n[i] = a.n[i] << 1;
 #if defined(LAMD_FE_ASM_BLOCK)
   LAMD_FE_ASM_DECL
-  asm(LAMD_FE_SQR_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), LAMD_FE_ASM_K : "vcc");
+  asm(LAMD_FE_SQR_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), LAMD_FE_ASM_K : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) fe_sqr_col<ch>(a, d.n, k, acc)
@@ -367,7 +370,7 @@ LAMD_HD fe fe_mul_add(const fe &a, const fe &b, const fe &ad) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) <= 7 && FE_MAG(ad) <= 7);
 #if defined(LAMD_FE_ASM_BLOCK)
   LAMD_FE_ASM_DECL
-  asm(LAMD_FE_MULADD_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(ad) : "vcc");
+  asm(LAMD_FE_MULADD_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(ad) : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) do { fe_mul_col<ch>(a, b, k, acc); if ((k) < 9) acc += ad.n[(k) < 9 ? (k) : 0]; } while (0)
@@ -383,7 +386,7 @@ LAMD_HD fe fe_sqr_add(const fe &a, const fe &ad) {
   for (int i = 0; i < 9; i++) d.n[i] = a.n[i] << 1;
 #if defined(LAMD_FE_ASM_BLOCK)
   LAMD_FE_ASM_DECL
-  asm(LAMD_FE_SQRADD_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(ad) : "vcc");
+  asm(LAMD_FE_SQRADD_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(d), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(ad) : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) do { fe_sqr_col<ch>(a, d.n, k, acc); if ((k) < 9) acc += ad.n[(k) < 9 ? (k) : 0]; } while (0)
@@ -396,7 +399,7 @@ LAMD_HD fe fe_mul2(const fe &a, const fe &b, const fe &c, const fe &d) {
   LAMD_ASSERT(FE_MAG(a) * FE_MAG(b) + FE_MAG(c) * FE_MAG(d) <= 7);
 #if defined(LAMD_FE_ASM_BLOCK)
   LAMD_FE_ASM_DECL
-  asm(LAMD_FE_MUL2_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(c), LAMD_FE_ASM_IO9(d) : "vcc");
+  asm(LAMD_FE_MUL2_ASM : LAMD_FE_ASM_OUT : LAMD_FE_ASM_IO9(a), LAMD_FE_ASM_IO9(b), LAMD_FE_ASM_K, LAMD_FE_ASM_IO9(c), LAMD_FE_ASM_IO9(d) : LAMD_FE_ASM_CLOBBER);
   LAMD_FE_ASM_DONE
 #else
 #define LAMD_P(k, acc, ch) do { fe_mul_col<ch>(a, b, k, acc); fe_mul_col<ch>(c, d, k, acc); } while (0)

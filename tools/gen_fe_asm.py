@@ -28,6 +28,11 @@ usage: tools/gen_fe_asm.py > lightning_amd/csrc/fe_asm.inc;  tools/gen_fe_asm.py
 import sys
 
 ILP = "--ilp" in sys.argv
+# --signed: the pure products (limb x limb) as v_mad_i64_i32 -- the same 64-bit result for factors below 2^31 (the additions wrap mod 2^64 either way) and
+# ~6 % cheaper to issue (profiles/r02_fe_bench_variants.txt); the folds whose factor is a raw 32-bit accumulator half, and the addend's "times 1", stay
+# unsigned.  Contract: every LIMB factor below 2^31 -- magnitude <= 3 for a multiplication's operands, <= 1 for a squaring's (its doubled limbs).
+SIGNED = "--signed" in sys.argv
+SCARRY = "--sgpr-carry" in sys.argv      # the (unused) carry-out into s[20:21] instead of vcc
 OFF = 8 if ILP else 0                # the latency schedule has eight more (pinned) outputs in front of the inputs
 HI, LO = 20, 22                      # v[20:21], v[22:23]
 LK = lambda k: 24 + 2 * k            # v[24:25] .. v[38:39]: L0..L7 (latency schedule)
@@ -45,8 +50,8 @@ hil, hih, lol, loh = "v%d" % HI, "v%d" % (HI + 1), "v%d" % LO, "v%d" % (LO + 1)
 EXTRA = {"prod2": False, "addend": False}   # set per emitted macro
 
 
-def mad(acc, x, y, addend=None):
-    return "v_mad_u64_u32 %s, vcc, %s, %s, %s" % (acc, x, y, acc if addend is None else addend)
+def mad(acc, x, y, addend=None, limbs=False):
+    return "%s %s, %s, %s, %s, %s" % ("v_mad_i64_i32" if SIGNED and limbs else "v_mad_u64_u32", acc, "s[20:21]" if SCARRY else "vcc", x, y, acc if addend is None else addend)
 
 
 def column(acc, k, square, first):
@@ -59,12 +64,12 @@ def column(acc, k, square, first):
             x, y = (A(i), A(j)) if i == j else (B(i), A(j))      # B = doubled limbs
         else:
             x, y = A(i), B(j)
-        out.append(mad(acc, x, y, "0" if first and not out else None))
+        out.append(mad(acc, x, y, "0" if first and not out else None, limbs=True))
     if EXTRA["prod2"]:      # a second full product c*d accumulated into the same columns: one reduction for a*b + c*d
         for i in range(9):
             j = k - i
             if 0 <= j <= 8:
-                out.append(mad(acc, C2(i), D2(j)))
+                out.append(mad(acc, C2(i), D2(j), limbs=True))
     if EXTRA["addend"] and k <= 8:   # + e: limb k of a lazy field element joins column k (times the inline constant 1)
         out.append(mad(acc, C2(k), "1"))
     return out
@@ -166,6 +171,8 @@ def emit(name, square, prod2=False, addend=False):
 print("// GENERATED by tools/gen_fe_asm.py -- do not edit.  See that file for the operand map.")
 print("#define LAMD_FE_ASM_HI \"{v[%d:%d]}\"" % (HI, HI + 1))
 print("#define LAMD_FE_ASM_LO \"{v[%d:%d]}\"" % (LO, LO + 1))
+if SCARRY:
+    print("#define LAMD_FE_ASM_CLOBBER \"vcc\", \"s20\", \"s21\"")
 if ILP:
     print("// the latency schedule's own accumulators: eight more pinned outputs (fe.h appends them to LAMD_FE_ASM_DECL / LAMD_FE_ASM_OUT)")
     print("#define LAMD_FE_ASM_EXTRA_DECL u64 " + ", ".join("l%d" % k for k in range(8)) + ";")
