@@ -219,11 +219,25 @@ class Clock:
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------
-def stream_shard(eng, st, bounds, k, grp, depth, first_grp=0):
+def pin_storm(eng, st):
+    """the storm's host columns pinned once, outside every clock (lamd_host_register) -- the state a sidecar's shared blocks are in: their rows are
+    then queued IN PLACE (no staging copy on the host).  -> True when the runtime pinned every column"""
+    return all(eng.host_register(c) for kind in ("ecdsa", "schnorr") if kind in st for c in st[kind].cols)
+
+
+def unpin_storm(eng, st):
+    for kind in ("ecdsa", "schnorr"):
+        if kind in st:
+            for c in st[kind].cols:
+                eng.host_unregister(c)
+
+
+def stream_shard(eng, st, bounds, k, grp, depth, first_grp=0, inplace=False):
     """configs[4] for shard k: the commitments [bounds[kind][k], bounds[kind][k+1]) of BOTH kinds through the streaming queue as ONE pipeline -- flushes
     of `grp` rows, the two kinds taking turns in proportion to their length, up to `depth` flushes in flight -- from host memory to verdicts in host
     memory.  (Until round 5 the ECDSA rows were streamed and drained before the first BIP-340 flush went out: two pipeline fills and two drains per
-    shard, 2.6 ms of a 5 ms 1/8 shard.)  first_grp > 0: the first flush of each kind is that many rows (the device starts sooner).
+    shard, 2.6 ms of a 5 ms 1/8 shard.)  first_grp > 0: the first flush of each kind is that many rows (the device starts sooner).  inplace: the rows
+    are queued where they are (lamd_queue_*_batch_inplace; the columns pinned by pin_storm) instead of being copied into the staging set.
     -> {kind: uint8 verdicts of the shard}"""
     import numpy as np
     jobs = []
@@ -249,9 +263,9 @@ def stream_shard(eng, st, bounds, k, grp, depth, first_grp=0):
     for _, kind, o, e in jobs:
         wl = st[kind]
         if kind == "ecdsa":
-            eng.queue_ecdsa_batch(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
+            (eng.queue_ecdsa_batch_inplace if inplace else eng.queue_ecdsa_batch)(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
         else:
-            eng.queue_schnorr_batch(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
+            (eng.queue_schnorr_batch_inplace if inplace else eng.queue_schnorr_batch)(wl.cols[0][o:e], wl.cols[1][o:e], wl.cols[2][o:e])
         eng.flush()
         pend.append((kind, o, e))
         if len(pend) == depth:
@@ -518,26 +532,41 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
     per, grp = st["per"], 256 * st["per"]
     depth = min(8, eng.info()["queue_sets"] - 1)
     first = storm_first_flush(per)
-    res5, bad5 = {}, 0
-    for W in (1, 2, 4, 8):
-        bb = {kind: sharding.shard_bounds(st[kind].n, W, [per] * (st[kind].n // per)) for kind in ("ecdsa", "schnorr")}
-        shard_ms = []
-        for k in range(W):
-            keep = {}
+    pinned = pin_storm(eng, st)
 
-            def one():
-                keep.update(stream_shard(eng, st, bb, k, grp, depth, first))
-                for kind in ("ecdsa", "schnorr"):
-                    gather(torch.from_numpy(keep[kind]).to(device))
-            shard_ms.append(best(one, 3 if W < 4 else 5) * 1e3)      # short shards: more repetitions (a 5 ms shard that meets one hiccup reads 10 ms)
-            for kind, got in keep.items():
-                bad5 += int((got.astype(bool) != st[kind].expect[int(bb[kind][k]):int(bb[kind][k + 1])]).sum())
-        res5[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms), "shard_commitments": [int((bb["ecdsa"][k + 1] - bb["ecdsa"][k] + bb["schnorr"][k + 1] - bb["schnorr"][k]) // per) for k in range(W)]}
-    for W in ("2", "4", "8"):
-        res5[W]["predicted_speedup"] = res5["1"]["slowest_ms"] / res5[W]["slowest_ms"]
+    def sweep5(inplace, Ws=(1, 2, 4, 8)):
+        res5, bad5 = {}, 0
+        for W in Ws:
+            bb = {kind: sharding.shard_bounds(st[kind].n, W, [per] * (st[kind].n // per)) for kind in ("ecdsa", "schnorr")}
+            shard_ms = []
+            for k in range(W):
+                keep = {}
+
+                def one():
+                    keep.update(stream_shard(eng, st, bb, k, grp, depth, first, inplace=inplace))
+                    for kind in ("ecdsa", "schnorr"):
+                        gather(torch.from_numpy(keep[kind]).to(device))
+                shard_ms.append(best(one, 3 if W < 4 else 5) * 1e3)      # short shards: more repetitions (a 5 ms shard that meets one hiccup reads 10 ms)
+                for kind, got in keep.items():
+                    bad5 += int((got.astype(bool) != st[kind].expect[int(bb[kind][k]):int(bb[kind][k + 1])]).sum())
+            res5[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms), "shard_commitments": [int((bb["ecdsa"][k + 1] - bb["ecdsa"][k] + bb["schnorr"][k + 1] - bb["schnorr"][k]) // per) for k in range(W)]}
+        for W in res5:
+            if W != "1":
+                res5[W]["predicted_speedup"] = res5["1"]["slowest_ms"] / res5[W]["slowest_ms"]
+        return res5, bad5
     nv = st["ecdsa"].n + st["schnorr"].n
+    # the producer copies its rows from pageable host memory into the engine's pinned staging set (lamd_queue_*_batch); beside it, at W = 1 and 8, the rows
+    # where a sidecar holds them -- pinned host memory, queued in place (no host copy; the form lamd_served streams its clients' blocks with)
+    res5, bad5 = sweep5(False)
     out["cfg5_commit_storm_streaming"] = dict(res5, verifies=nv, mismatches=bad5, predicted_speedup_8=res5["8"]["predicted_speedup"],
-                                              verifies_per_s_predicted_8=nv / (res5["8"]["slowest_ms"] * 1e-3), first_flush_rows=first)
+                                              verifies_per_s_predicted_8=nv / (res5["8"]["slowest_ms"] * 1e-3), first_flush_rows=first,
+                                              producer="rows copied from pageable host memory into the pinned staging set (lamd_queue_*_batch)")
+    if pinned:
+        resi, badi = sweep5(True, (1, 8))
+        bad5 += badi
+        out["cfg5_commit_storm_streaming"]["mismatches"] = bad5
+        out["cfg5_commit_storm_streaming"]["in_place_producer"] = {W: {"slowest_ms": resi[W]["slowest_ms"], "predicted_speedup": resi[W].get("predicted_speedup")} for W in resi}
+        unpin_storm(eng, st)
     out["gather_alone_ms"] = t_gather * 1e3
     out["gather"] = "one-rank RCCL all-gather" if dist.is_initialized() else "device copy of the padded verdict bytes (no communicator in a --gpus 1 run)"
     out["note"] = ("one GPU plays every rank of W = 1, 2, 4, 8 in turn: shard k of W as sharding.run_sharded cuts it (message / commitment boundaries; gossip "

@@ -3988,25 +3988,44 @@ extern "C" int lamd_flush(lamd_ctx *ctx) {
     const bool split = q.n <= L->chunk;
     if (!q.foreign.empty()) {
       // rows queued in place: every run of rows -- the caller's buffers for the in-place ones, the staging set for what lies between them -- goes down
-      // the copy stream into its rows of the device twin, three copies per run, ONE event behind the last (as the single-event form below)
+      // the copy stream into its rows of the device twin, column by column in the order and behind the events of the staged form below (keys first:
+      // de-duplication and table building start on them)
       hipStream_t &csr = ctx->copy_streams[ctx->copy_turn++ % (unsigned)ctx->n_copy_streams];
       if (!csr) HIPCHK(ctx, hipStreamCreateWithFlags(&csr, hipStreamNonBlocking));
       hipStream_t cs = csr;
-      auto run = [&](size_t row0, size_t cnt, const u8 *a, const u8 *b, const u8 *c) -> hipError_t {
-        hipError_t e = hipMemcpyAsync(qd_c + row0 * kb, c, cnt * kb, hipMemcpyHostToDevice, cs);
-        if (e == hipSuccess) e = hipMemcpyAsync(qd_b + row0 * 64, b, cnt * 64, hipMemcpyHostToDevice, cs);
-        if (e == hipSuccess) e = hipMemcpyAsync(qd_a + row0 * 32, a, cnt * 32, hipMemcpyHostToDevice, cs);
+      auto column = [&](int col) -> hipError_t {   // 0 keys, 1 signatures, 2 hashes
+        const size_t w = col == 0 ? kb : col == 1 ? 64 : 32;
+        u8 *const dst = col == 0 ? qd_c : col == 1 ? qd_b : qd_a;
+        const u8 *const own = col == 0 ? q.h_c : col == 1 ? q.h_b : q.h_a;
+        size_t at = 0;
+        hipError_t e = hipSuccess;
+        for (const auto &f : q.foreign) {
+          if (f.row0 > at && e == hipSuccess) e = hipMemcpyAsync(dst + at * w, own + at * w, (f.row0 - at) * w, hipMemcpyHostToDevice, cs);
+          if (e == hipSuccess) e = hipMemcpyAsync(dst + f.row0 * w, col == 0 ? f.c : col == 1 ? f.b : f.a, f.count * w, hipMemcpyHostToDevice, cs);
+          at = f.row0 + f.count;
+        }
+        if (at < q.n && e == hipSuccess) e = hipMemcpyAsync(dst + at * w, own + at * w, (q.n - at) * w, hipMemcpyHostToDevice, cs);
         return e;
       };
-      size_t at = 0;
-      for (const auto &f : q.foreign) {
-        if (f.row0 > at) HIPCHK(ctx, run(at, f.row0 - at, q.h_a + 32 * at, q.h_b + 64 * at, q.h_c + kb * at));
-        HIPCHK(ctx, run(f.row0, f.count, f.a, f.b, f.c));
-        at = f.row0 + f.count;
+      const int events = ctx->copy_events ? ctx->copy_events : (ctx->q_inflight >= 2 ? 1 : 3);
+      HIPCHK(ctx, column(0));
+      if (events > 1) {
+        HIPCHK(ctx, hipEventRecord(q.ev_keys, cs));
+        HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_keys, 0));
       }
-      if (at < q.n) HIPCHK(ctx, run(at, q.n - at, q.h_a + 32 * at, q.h_b + 64 * at, q.h_c + kb * at));
+      HIPCHK(ctx, column(1));
+      if (events >= 3) {
+        HIPCHK(ctx, hipEventRecord(q.ev_sigs, cs));
+        L->sigs_pending = true;
+        L->ev_sigs_wait = q.ev_sigs;
+      }
+      HIPCHK(ctx, column(2));
       HIPCHK(ctx, hipEventRecord(q.ev_all, cs));
-      HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_all, 0));
+      if (events == 1) HIPCHK(ctx, hipStreamWaitEvent(L->stream, q.ev_all, 0));
+      if (events == 2) {
+        L->sigs_pending = true;
+        L->ev_sigs_wait = q.ev_all;
+      }
       HIPCHK(ctx, hipStreamWaitEvent(L->stream2, q.ev_all, 0));
     } else if (split && ctx->use_copy_stream) {
       // Round 3: the copies of EVERY flush go down one stream of their own, in flush order, behind nothing but each other.  On the

@@ -95,7 +95,7 @@ class StubEngine:
 
     def __init__(self, device=0):
         self.device, self.auto_order = device, True
-        self.calls, self.marks, self.waits = [], [], []
+        self.calls, self.marks, self.waits, self.pins = [], [], [], []
         self._ms = [[0.0, 0], [0.0, 0]]
         self._last = {0: (0, 0), 1: (0, 0)}
         self._queued, self._flushed, self._reserved = [], [], None
@@ -137,6 +137,17 @@ class StubEngine:
 
     def queue_schnorr_batch(self, m, k, s):
         self._queued.append(verdict_rows(_t(m), _t(k), _t(s)).numpy().astype(bool))
+
+    # (host memory is the stub's device: "pinning" always succeeds and in-place rows are read when they are queued)
+    def host_register(self, arr):
+        self.pins.append(arr.nbytes)
+        return True
+
+    def host_unregister(self, arr):
+        return True
+
+    queue_ecdsa_batch_inplace = queue_ecdsa_batch
+    queue_schnorr_batch_inplace = queue_schnorr_batch
 
     def queue_reserve(self, n, keylen):
         key = (self._next_set % self.SETS, keylen)

@@ -685,7 +685,7 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
     """VERDICT r05 "next" 8: BASELINE configs[4] as channelds see it -- 8 client processes, each STREAMING its channels' commitments (flushes kept in
     flight: lamd_queue_*_batch / lamd_flush / lamd_wait of the client library) through ONE lamd_served.  Every verdict equals construction (= the
     in-process engine's, checked on the same rows), and the rate of the whole job is compared with the same job streamed by one in-process
-    producer (the ratio lands in gpurun_out/served_stream.json: 0.85-0.88 with the flush rows queued in place from the clients' pinned blocks, 0.67-0.69
+    producer (the ratio lands in gpurun_out/served_stream.json: median 0.75 (0.54-1.01 over ten runs) with the flush rows queued in place from the clients' pinned blocks, 0.63
     with --copy-flushes, profiles/r06_served_stream.txt; asserted >= 0.4 -- the box's host cores decide the rest)."""
     import json
     import torch
