@@ -283,8 +283,9 @@ int lamd_queue_reserve(lamd_ctx *ctx, size_t n, size_t keylen, uint8_t **hash32,
 /* In-place form for a host that ALREADY holds the rows in pinned memory (lamd_served: its clients' shared blocks): the n triples (keys packed, publen
  * / 32 bytes each) get tickets like the batch forms, but their bytes are not copied -- they cross the bus from the caller's buffers when the set is
  * flushed.  The buffers must stay unchanged until the flush that carries the rows has been collected (lamd_poll / lamd_wait).  Batches of <= 4 096
- * rows are copied as by lamd_queue_*_batch (the latency kernel reads the staging rows themselves).  lamd_host_register() pins a range for every
- * device (hipHostRegister, portable) so that those transfers are DMA; unregistered memory still works, through the runtime's staging buffers.
+ * rows (the latency kernel reads the staging rows themselves) and rows in memory that is NOT pinned end to end are copied as by lamd_queue_*_batch.
+ * lamd_host_register() pins a range for every device (hipHostRegister, portable): register whole, page-aligned blocks, once, and keep them
+ * registered while rows of theirs are queued.
  * Both may be called from any thread while another drives the context.  (Replaces nothing in the reference: the producer side of SURVEY.md 8(f)'s
  * sidecar, channeld/channeld.c:7063-7121 being one process per channel.) */
 int lamd_queue_ecdsa_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *hash32, const uint8_t *sig64, const uint8_t *pubkey, size_t publen);

@@ -3869,8 +3869,8 @@ extern "C" int lamd_queue_schnorr_batch(lamd_ctx *ctx, size_t n, const uint8_t *
 // The rows stay where they are: n triples in the caller's memory (keys packed, publen bytes each) get a row range in the open staging set and cross
 // the bus FROM THE CALLER'S BUFFERS when the set is flushed -- the form for a host that already holds its callers' rows in pinned memory (lamd_served:
 // the clients' shared blocks, registered with lamd_host_register()).  The buffers must not change until the flush that carries the rows has been
-// collected (lamd_poll / lamd_wait).  Batches the latency kernel would take (<= 4 096 rows) are copied like lamd_queue_*_batch(): that kernel reads the
-// staging rows themselves.
+// collected (lamd_poll / lamd_wait).  Batches the latency kernel would take (<= 4 096 rows), and rows in memory the runtime does not hold pinned,
+// are copied like lamd_queue_*_batch().
 static int queue_push_inplace(lamd_ctx *ctx, int kind, size_t n, const u8 *a, const u8 *sig, const u8 *key) {
   if (!ctx) return LAMD_ERR_ARG;
   if (!a || !sig || !key) {
@@ -3878,6 +3878,20 @@ static int queue_push_inplace(lamd_ctx *ctx, int kind, size_t n, const u8 *a, co
     return LAMD_ERR_ARG;
   }
   if (n <= SMALL_MAX || !ctx->use_copy_stream) return queue_push(ctx, kind, n, a, sig, key, Q_KEYBYTES[kind]);
+  // Only memory the runtime holds pinned stays in place.  An asynchronous copy from PAGEABLE memory makes the runtime pin the pages itself for the
+  // length of the transfer, and such a transient pin next to (in one page with) a registered range left the runtime unable to finish a later
+  // pageable copy (tests: a process hung in an unrelated device-to-host copy, round 6) -- so rows in memory that is not registered end to end are
+  // copied into the staging set like any others.
+  const size_t w[3] = {32, 64, Q_KEYBYTES[kind]};
+  const u8 *col[3] = {a, sig, key};
+  for (int c = 0; c < 3; c++)
+    for (const u8 *p : {col[c], col[c] + w[c] * n - 1}) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return queue_push(ctx, kind, n, a, sig, key, Q_KEYBYTES[kind]);
+      }
+    }
   u8 *da, *db, *dc;
   const int first = queue_take(ctx, kind, n, &da, &db, &dc);
   if (first < 0) return first;
@@ -3897,7 +3911,7 @@ extern "C" int lamd_queue_schnorr_batch_inplace(lamd_ctx *ctx, size_t n, const u
 }
 // Pins a range of the caller's memory for every device (hipHostRegisterPortable), so that rows queued in place leave it by DMA.  Callable from any
 // thread, also while another thread drives the context: nothing of the context is touched but its device number.  < 0: LAMD_ERR_HIP (the range stays
-// usable -- unpinned memory crosses the bus through the runtime's own staging buffers, slowly and synchronously).
+// usable: rows queued "in place" from memory that is not pinned are copied into the staging set).  Register whole, page-aligned blocks.
 extern "C" int lamd_host_register(lamd_ctx *ctx, void *p, size_t bytes) {
   if (!ctx || !p || !bytes) return LAMD_ERR_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess || hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {

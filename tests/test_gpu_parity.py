@@ -991,6 +991,15 @@ def test_streaming_zero_copy_reserve_mixed_with_copies(eng, orc):
         eng.queue_reserve(4, 40)                                 # not a key length
 
 
+def _page_block(x):
+    """a copy of x in anonymous pages of its own (page-aligned, whole pages): what a host registers"""
+    import mmap
+    m = mmap.mmap(-1, max(mmap.PAGESIZE, (x.nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE))
+    a = np.frombuffer(m, dtype=np.uint8, count=x.nbytes).reshape(x.shape)
+    a[:] = x
+    return a
+
+
 def test_streaming_rows_queued_in_place(eng, orc):
     """lamd_queue_*_batch_inplace(): rows that stay in the caller's memory (registered or not) and cross the bus from there, mixed inside one flush
     with copied rows before, between and after them (tickets keep counting), three kinds, small batches (copied: the latency kernel's) and large
@@ -1009,13 +1018,16 @@ def test_streaming_rows_queued_in_place(eng, orc):
         hs65, sg65, pk65 = _random_ecdsa(orc, rnd, n65, 65)
         e65 = orc.ecdsa_verify_batch(hs65, sg65, pk65, 65, 4).astype(bool)
         o1, o2, o3 = n_copy, n_copy + n_in1, n_copy + n_in1 + n_mid
-        part = lambda lo, hi: [np.ascontiguousarray(x[lo:hi]) for x in (hs, sg, pk)]
-        p1, p2 = part(o1, o2), part(o3, n)
-        sch = [np.ascontiguousarray(x) for x in (ms, xs, ss)]
+        # even batches: p1 and the BIP-340 rows live in blocks of whole pages of their own, registered (they stay in place); everything else -- p2, the
+        # 65-byte-key rows, all of the odd batches -- is plain pageable memory (views of larger arrays): the engine copies such rows
+        own = (lambda x: _page_block(x)) if b % 2 == 0 else np.ascontiguousarray
+        part = lambda lo, hi, f: [f(x[lo:hi]) for x in (hs, sg, pk)]
+        p1, p2 = part(o1, o2, own), part(o3, n, np.ascontiguousarray)
+        sch = [own(x) for x in (ms, xs, ss)]
         p65 = [np.ascontiguousarray(x) for x in (hs65, sg65, pk65)]
         keep.append((p1, p2, sch, p65))                              # alive and unchanged until collected
         if b % 2 == 0:
-            assert all(eng.host_register(x) for x in p1 + sch), "hipHostRegister refused plain host memory"
+            assert all(eng.host_register(x) for x in p1 + sch), "hipHostRegister refused whole pages of host memory"
         t0 = eng.queue_ecdsa_batch(hs[:o1], sg[:o1], pk[:o1])
         t1 = eng.queue_ecdsa_batch_inplace(*p1)
         if n_mid:

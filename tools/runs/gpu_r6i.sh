@@ -7,4 +7,4 @@ S=$(date +%s); timeout 1700 python -m pytest tests -m gpu -q -x 2>&1 | grep -E "
 cp gpurun_out/served_stream.json gpurun_out/r6i/ 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee gpurun_out/r6i/smoke.txt
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r6i/bench20.json 2> gpurun_out/r6i/bench20.err; cp bench_details.json gpurun_out/r6i/details20.json
-grep real gpurun_out/r6i/bench20.err; wc -c gpurun_out/r6i/bench20.json; cat gpurun_out/r6i/bench20.json
+grep ^real gpurun_out/r6i/bench20.err; wc -c gpurun_out/r6i/bench20.json; cat gpurun_out/r6i/bench20.json
