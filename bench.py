@@ -1048,7 +1048,7 @@ def main():
         # gfx950 counts memory-side read requests at 64 B each; for this kernel's access pattern (49 random table entries of 64-96 B per row) the
         # counter is calibrated on a gather of known size (tools/microbench.hip `gather`; factor and source in pmc_latest.json)
         traffic = traffic_raw = traffic_src = fetch_factor = None
-        valu_issue = None
+        valu_issue = tables = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_ecmult_ecdsa_1M"]
             if n == 1_000_000:
@@ -1077,6 +1077,28 @@ def main():
                                       "share_ecmult": sum(v for k, v in sv.items() if k.startswith("k_ecmult_keyed<false")) / tot,
                                       "share_key_tables": tab / tot,
                                       "note": "all kernels of a step: VALU wave-instructions x 4 cycles / (1024 SIMDs x clock x step time)"}
+                # the key-table kernels priced like the dominant one (VERDICT r05 "next" 3): instructions per key, lanes, issue fraction of the isolated stage
+                keys_step = sum(int(v[1]) for v in keyed.values()) if keyed else 0
+                if keys_step and isolated.get("ecdsa") and isolated.get("schnorr"):
+                    wb = sum(v for k, v in sv.items() if k.startswith("k_keys_bases"))
+                    wf = sum(v for k, v in sv.items() if k.startswith("k_kc_"))
+                    iso_tab_ms = float(np.mean(np.array(isolated["ecdsa"]), axis=0)[1] + np.mean(np.array(isolated["schnorr"]), axis=0)[1])
+                    kclk = (pm.get("shader_clock_GHz") or clk / 1e9) * 1e9
+                    tables = {"kernels": "k_keys_bases_both (key parse + the 114-doubling chain, one lane per key) + k_kc_finish_both (Gray-code chains of mixed additions, Z products, "
+                                         "rescale: four lanes per 7-tooth key)",
+                              "distinct_keys_per_step": keys_step,
+                              "valu_wave_instr_per_step": {"bases": wb, "finish": wf},
+                              "valu_lane_instr_per_key": {"bases": wb * 64 / keys_step, "finish": wf * 64 / keys_step, "both": (wb + wf) * 64 / keys_step},
+                              "valu_lane_instr_per_verify_at_this_reuse": (wb + wf) * 64 / (2.0 * n),
+                              "lanes_per_step": {"bases": keys_step, "finish": 4 * keys_step}, "lane_slots_of_the_chip_at_4_waves_per_simd": simds * 4 * 64,
+                              "waves_per_call_over_simds": {"bases": keys_step / 2 / 64 / simds, "finish": 4 * keys_step / 2 / 64 / simds},
+                              "isolated_stage_ms_per_step": iso_tab_ms,
+                              "issue_frac_isolated": (wb + wf) * 4 / simds / kclk / (iso_tab_ms * 1e-3),
+                              "share_of_step_valu": tab / tot,
+                              "note": "counts from the PMC passes of the cold loop; isolated_stage_ms = the keys_and_tables brackets of one ECDSA and one BIP-340 call alone on the chip "
+                                      "(they hold the de-duplication's tail too); issue_frac_isolated = instructions x 4 cycles / (SIMDs x kernel clock x that time): "
+                                      "alone, the stage is latency-bound (waves_per_call_over_simds: about 1.2 and 4.8 waves per SIMD, one dependent chain each) -- inside the loop its instructions fill "
+                                      "the slots ecmult leaves (valu_issue.step)"}
         except Exception:
             pass
         iso_ms = iso_launch[0] or float(np.mean(np.array(isolated["ecdsa"]), axis=0)[2])
@@ -1143,6 +1165,7 @@ def main():
                 "valu_issue_frac": valu_issue["frac"] if valu_issue else None,
                 "valu_issue_frac_step": valu_issue["step"]["frac"] if valu_issue and "step" in valu_issue else None,
                 "valu_share_key_tables": valu_issue["step"]["share_key_tables"] if valu_issue and "step" in valu_issue else None,
+                "tables": tables,
                 # SURVEY 8(d)'s implementation-independent yardstick (1.32e5 mul32 for a generic ECDSA verification) over the same time: NOT a
                 # utilisation figure (the combs execute 2.2x fewer multiplies than the yardstick's generic algorithm)
                 "survey_yardstick": {"mul32_per_verify": W_ECDSA65, "yardstick_Tmul32_per_s_in_loop": W_ECDSA65 * n / t_ecmult / 1e12,
