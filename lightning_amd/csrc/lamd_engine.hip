@@ -773,8 +773,20 @@ __global__ void __launch_bounds__(256) k_cache_publish(const u32 *__restrict__ p
     slot = (slot + 1u) & mask;
   }
 }
+// The cold rows -- rows under a key that gets no table -- are known as soon as the keys are classified, long before the tables exist: their list is
+// made here, right behind k_dedupe_classify, and the ladder (key parse + 128 doublings per row, the longest chain of a call) starts on the side
+// stream while the main stream still builds the tables.  (Round 6: until then k_partition made this list too, AFTER the table kernels -- a gossip
+// shard's ladder started 0.7 ms into a 3 ms call for no reason: profiles/r06_shard_timeline_cold.txt.)  k_partition<.., true> then leaves them alone.
+__global__ void __launch_bounds__(256) k_partition_cold(size_t n, const u32 *__restrict__ rep, const u32 *__restrict__ newent, u32 *__restrict__ plan,
+                                                        u32 *__restrict__ listcold) {
+  LAMD_PRIO(1);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool cold = i < n && rep[i] != ENT_NONE && newent[rep[i]] == ENT_NONE;
+  const u32 pos = wave_alloc(&plan[P_COLD], cold);
+  if (cold) listcold[pos] = (u32)i;
+}
 // rows the cache did not know: those whose key just got a table join the row list of its shape, the rest take the ladder
-template <bool BYROW>
+template <bool BYROW, bool COLD_LISTED = false>
 __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ row_ent, const u32 *__restrict__ rep, const u32 *__restrict__ uid,
                                                    const u32 *__restrict__ newent, const cache_ent *__restrict__ ents, u32 *__restrict__ plan,
                                                    u32 *__restrict__ list7, u32 *__restrict__ list10, u32 *__restrict__ listcold,
@@ -797,7 +809,7 @@ __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ r
     T = 254;
   }
   u32 *const ctr[4] = {&plan[P_L7], &plan[P_L10], &plan[P_COLD], &plan[P_EARLY]};
-  const bool pr[4] = {miss && T == 7u, miss && T == 10u, miss && T == 255u, dead};
+  const bool pr[4] = {miss && T == 7u, miss && T == 10u, !COLD_LISTED && miss && T == 255u, dead};
   u32 pos[4];
   block_alloc4(ctr, pr, pos);
   const u32 p7 = pos[0], p10 = pos[1], pc = pos[2];
@@ -807,7 +819,7 @@ __global__ void __launch_bounds__(256) k_partition(size_t n, u32 *__restrict__ r
   else if (T == 0u) {
     out[i] = 0;
     if (keyok_row) keyok_row[i] = 0;
-  } else listcold[pc] = (u32)i;
+  } else if (!COLD_LISTED) listcold[pc] = (u32)i;
 }
 // key tables, four stages (verify_core.h "Building one key's table"): bases and prefix run one thread per key, the
 // chains and the rescale one thread per (key, 16-entry chain) so that a few hundred keys still fill the chip.
@@ -1556,6 +1568,7 @@ struct lamd_ctx {
   bool use_d2h_stream = false;
   int keyed_mode = -1;           // -1 auto, 0 never, 1 whenever keys repeat at all (LAMD_KEYED)
   size_t keyed_min_rows = 8192;  // below this a batch is latency-bound: per-signature ladder
+  bool early_cold = true;         // LAMD_EARLY_COLD=0: the cold rows' list is made by k_partition, after the table kernels (rounds 1-5)
   bool fused_front = true;        // LAMD_FUSED_FRONT=0: the front end of a keyed call as the 19 launches + 5 fills of round 2 (see k_call_init)
   bool kc_tree = false;           // LAMD_KC_TREE=1: key tables by the affine tree builder (k_kc_tree_both) instead of the Gray-code chains (k_kc_finish_both); read on the root context
   bool small_fused = true;        // LAMD_SMALL_FUSED=0: small batches take the partitioning path even with a cache
@@ -1806,6 +1819,7 @@ static int make_lanes(lamd_ctx *root, int count) {
     L->keyed_min_rows = root->keyed_min_rows;
     L->small_fused = root->small_fused;
     L->fused_front = root->fused_front;
+    L->early_cold = root->early_cold;
     L->keyed_min_uses = root->keyed_min_uses;
     L->keyed_dense_uses = root->keyed_dense_uses;
     L->keyed_teeth = root->keyed_teeth;
@@ -1857,6 +1871,7 @@ extern "C" int lamd_init(lamd_ctx **out, int device) {
   if (const char *w = getenv("LAMD_SPIN_US")) ctx->spin_us = (unsigned)atoi(w);
   if (const char *w = getenv("LAMD_PRIO")) ctx->prio_mask = (u32)atoi(w);
   if (const char *w = getenv("LAMD_FUSED_FRONT")) ctx->fused_front = atoi(w) != 0;
+  if (const char *w = getenv("LAMD_EARLY_COLD")) ctx->early_cold = atoi(w) != 0;
   if (const char *w = getenv("LAMD_KC_TREE")) ctx->kc_tree = atoi(w) != 0;
   if (const char *w = getenv("LAMD_PREP_BATCH")) ctx->prep_batch = atoi(w) < 1 ? 1 : (size_t)atoi(w);
   if (const char *w = getenv("LAMD_PREP_MIN_THREADS")) ctx->prep_min_threads = atol(w) < 0 ? 0 : (size_t)atol(w);
@@ -2516,6 +2531,7 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
       lf.n = (u32)nf;
     }
   }
+  bool cold_started = false;
   if (ctx->fused_front) {
     // six launches (see k_call_init)
     {
@@ -2536,6 +2552,19 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
                        (u32 *)ctx->hk7_row.p, (u32 *)ctx->hk7_ent.p, (u32 *)ctx->hk7_slot.p, (u32 *)ctx->hk10_row.p, (u32 *)ctx->hk10_ent.p,
                        (u32 *)ctx->hk10_slot.p, lf);
     if (time_it) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->early_cold) {
+      // the cold rows' list, and their ladder on the side stream, before the tables are built (k_partition_cold)
+      hipLaunchKernelGGL(k_partition_cold, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, (const u32 *)ctx->kd_rep.p, (const u32 *)ctx->kd_newent.p, plan, listcold);
+      HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+      hipStream_t main = ctx->stream;
+      ctx->stream = ctx->stream3;
+      rc = launch_direct(ctx, mode, n, (const u32 *)listcold, (const u32 *)(plan + P_COLD), recs, d_sig, d_key, keylen, keystride, fin, keyok_out, d_ok, false, plan);
+      ctx->stream = main;
+      if (rc != LAMD_OK) return rc;
+      HIPCHK(ctx, hipEventRecord(ctx->ev_cold, ctx->stream3));
+      cold_started = true;
+    }
     const bool on7 = thr7 != 0xFFFFFFFFu, on10 = thr10 != 0xFFFFFFFFu;
     if (on7 || on10) {
       const kc_shape_args A7 = {(u32)(on7 ? hk7_cap : 0), (const u32 *)ctx->hk7_row.p, (const u32 *)ctx->hk7_ent.p, (const u32 *)ctx->hk7_slot.p,
@@ -2561,7 +2590,8 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
       root->pub_pending[ctx->lane_id] = true;
     }
     if (ctx->sigs_pending) { HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_sigs_wait, 0)); ctx->sigs_pending = false; }
-    hipLaunchKernelGGL((k_partition<true>), dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)nullptr,
+    auto part = cold_started ? k_partition<true, true> : k_partition<true, false>;
+    hipLaunchKernelGGL(part, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, n, row_ent, (const u32 *)ctx->kd_rep.p, (const u32 *)nullptr,
                        (const u32 *)ctx->kd_newent.p, ents, plan, list7, list10, listcold, keyok_out, d_ok, d_sig, mode);
   } else {
     HIPCHK(ctx, hipMemsetAsync(plan, 0, P_WORDS * 4, ctx->stream));
@@ -2618,9 +2648,9 @@ static int run_chunk(lamd_ctx *ctx, int mode, size_t n, const u8 *d_a, const u8 
   }
   // cold rows (keys seen too rarely for a table) take the per-signature ladder on a third stream: usually few rows, i.e.
   // a latency-bound launch that should hide behind the table-driven kernels instead of serialising with them
-  HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
-  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
-  {
+  if (!cold_started) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));  // row lists are complete
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
     hipStream_t main = ctx->stream;
     ctx->stream = ctx->stream3;
     rc = launch_direct(ctx, mode, n, (const u32 *)listcold, (const u32 *)(plan + P_COLD), recs, d_sig, d_key, keylen, keystride, fin, keyok_out,

@@ -58,6 +58,32 @@ if mode == "gossip":
     marker(3)
     print("whole job: host wall ms", " ".join("%.3f" % whole() for _ in range(2)))
     marker(4)
+elif mode == "gossip8":
+    # one 1/8 shard of configs[3] cut PER MESSAGE KIND (sharding.segment_bounds, as bench.py and lamd_multi cut it): range 0 of the announcements and
+    # range 0 of the updates as two asynchronous calls, one synchronise.  marker 10 | the shard x R | marker 11
+    eng = Engine(0)
+    g = workload.make_gossip(eng, 500_000, 2_000_000, n_nodes=15000, device=dev)
+    sb = sharding.segment_bounds([0, g.n_cann, g.n], 8, sharding.gossip_weights(g.msgs, g.off))
+    calls = []
+    for s_ in range(2):
+        lo, hi = int(sb[s_, 0]), int(sb[s_, 1])
+        rb = (g.d_rowbase[lo:hi + 1] - g.d_rowbase[lo]).contiguous()
+        calls.append((lo, hi, rb, int(g.rowbase[hi] - g.rowbase[lo]), torch.zeros(hi - lo, dtype=torch.int8, device=dev)))
+    torch.cuda.synchronize()
+
+    def one():
+        t = time.perf_counter()
+        for lo, hi, rb, rows, d_v in calls:
+            eng.sigcheck_gossip_device(hi - lo, g.d_msgs, g.d_off[lo:hi + 1], g.d_ids[lo:hi], rb, rows, d_v)
+        eng.synchronize()
+        return (time.perf_counter() - t) * 1e3
+    for _ in range(eng.info()["lanes"] + 2):
+        one()
+    marker(10)
+    ts = [one() for _ in range(R)]
+    marker(11)
+    bad = sum(int((d_v.cpu().numpy() != g.expect[lo:hi]).sum()) for lo, hi, rb, rows, d_v in calls)
+    print("per-kind 1/8 shard: %s messages, host wall ms %s, mismatches %d" % ([hi - lo for lo, hi, *_ in calls], " ".join("%.3f" % t for t in ts), bad))
 elif mode == "storm":
     # one 1/8 shard of BASELINE configs[4] (1 250 commitments: 937 ECDSA + 313 BIP-340) through the streaming queue as bench.py's strong-scaling sweep
     # runs it; marker 8 | the shard x R (host wall printed per repetition, with the host time spent inside queue_*_batch / flush / wait) | marker 9
