@@ -345,11 +345,22 @@ def sharded_configs(plat, eng, rank, world, tstream, div=1):
     wait = lambda: eng.stream_wait_results(tstream)     # the collective (torch's stream) starts when the verdicts exist: device-side edge
     empty = torch.empty(0, dtype=torch.int8, device=device)
     reps = 2 + eng.info()["lanes"]
-    # (two asynchronous range calls per rank, not ONE spans call over both ranges -- lamd_sigcheck_gossip_spans_device, sharding's `verify_ranges`: measured on
-    # one GPU playing every rank, the two calls overlap one's front end with the other's ecmult and are as fast at W = 8 and 8 % faster at W = 4:
-    # profiles/r06_strong_scaling.txt)
-    ts, (full, _) = timed(lambda: sharding.run_sharded_segments(g.n, seg, rank, world, gossip_range, gw, wait, empty), reps)
+    # ONE spans call over the rank's ranges (lamd_sigcheck_gossip_spans_device, sharding's `verify_ranges`): one front end per rank, and -- since the cold
+    # rows' ladder starts right behind the key classification -- the announcements' ladder runs under the updates' table kernels inside the one call.
+    # Measured on one GPU playing every rank (profiles/r06_strong_scaling.txt, sessions aa-ad): 3.3 against 3.4-3.8 ms for two asynchronous range calls
+    # at W = 8, 18.2 against 19.0 ms at W = 1 (6.0 against 5.8 at W = 4).  The two-call form is timed beside it.
+    mine = [(int(sb[s, rank]), int(sb[s, rank + 1])) for s in range(sb.shape[0]) if sb[s, rank + 1] > sb[s, rank]]
+    sp = gossip_spans(g, mine, device) if mine else None
+    plat.synchronize()
+
+    def gossip_ranges(ranges):
+        assert ranges == mine
+        eng.sigcheck_gossip_spans_device(sp[0], g.d_msgs, sp[1], sp[2], sp[3], sp[4], sp[5], sp[6])
+        return sp[6]
+    ts, (full, _) = timed(lambda: sharding.run_sharded_segments(g.n, seg, rank, world, gossip_range, gw, wait, empty, verify_ranges=gossip_ranges), reps)
     bad = int((full.cpu().numpy() != g.expect).sum())
+    ts2, (full2, _) = timed(lambda: sharding.run_sharded_segments(g.n, seg, rank, world, gossip_range, gw, wait, empty), reps)
+    bad += int((full2.cpu().numpy() != g.expect).sum())
 
     def one_cut(a, z):
         v = gossip_range(a, z)
@@ -357,7 +368,8 @@ def sharded_configs(plat, eng, rank, world, tstream, div=1):
         return v
     ts1, (full1, _) = timed(lambda: sharding.run_sharded(g.n, rank, world, one_cut, None, gw), reps)
     bad += int((full1.cpu().numpy() != g.expect).sum())
-    out["cfg4_gossip_replay_sharded"] = {"messages": g.n, "verifies": g.rows, "ranks": world, "split": "per message kind (announcements | updates), range r of each per rank: two asynchronous calls",
+    out["cfg4_gossip_replay_sharded"] = {"messages": g.n, "verifies": g.rows, "ranks": world, "split": "per message kind (announcements | updates), range r of each per rank: ONE spans call",
+                                         "two_calls_ms": min(ts2[-2:]) * 1e3, "two_calls_verifies_per_s": g.rows / min(ts2[-2:]),
                                          "shard_messages": [[int(sb[s, k + 1] - sb[s, k]) for k in range(world)] for s in range(sb.shape[0])],
                                          "verifies_per_s": g.rows / min(ts[-2:]), "messages_per_s": g.n / min(ts[-2:]), "ms": min(ts[-2:]) * 1e3,
                                          "one_cut_ms": min(ts1[-2:]) * 1e3, "one_cut_verifies_per_s": g.rows / min(ts1[-2:]),
@@ -483,9 +495,9 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
                 dst.append(best(one, 5 if W > 1 else 6) * 1e3)
                 for lo, hi, rb, rows, d_v in prep:
                     bad3 += int((d_v.cpu().numpy() != g.expect[lo:hi]).sum())
-        res3[str(W)] = {"shard_ms": shard_ms, "slowest_ms": max(shard_ms),
+        res3[str(W)] = {"shard_ms": spans_ms, "slowest_ms": max(spans_ms),
                         "shard_messages": [[int(sb[s, k + 1] - sb[s, k]) for k in range(W)] for s in range(sb.shape[0])]}
-        res3[str(W)]["one_spans_call_shard_ms"] = spans_ms
+        res3[str(W)]["two_calls_shard_ms"] = shard_ms
         if os.environ.get("LAMD_BENCH_BY_KEY", "0") == "1" and not plat.is_stub:
             # experiment (profiles/r06_strong_scaling.txt): shard k = every message whose SIGNER KEY hashes to k -- the node id of a channel_update, node_id_1 of a
             # channel_announcement (synthetic layout: feature length 0, the key at byte 300) -- as ONE spans call: a rank builds the tables of ITS node keys only
@@ -517,13 +529,13 @@ def strong_scaling_sweep(plat, eng, tstream, div=1):
                 bad3 += int((sp[6].cpu().numpy() != g.expect[sel]).sum())
             res3[str(W)]["by_signer_key_shard_ms"] = by_key_ms
         res3_one[str(W)] = {"shard_ms": one_cut_ms, "slowest_ms": max(one_cut_ms), "shard_messages": [int(b1[k + 1] - b1[k]) for k in range(W)]}
-    t1 = min(res3["1"]["slowest_ms"], res3_one["1"]["slowest_ms"])      # T(1): the better way to run the whole job on one GPU
+    t1 = min(res3["1"]["slowest_ms"], res3_one["1"]["slowest_ms"], max(res3["1"]["two_calls_shard_ms"]))      # T(1): the best way to run the whole job on one GPU
     for W in ("2", "4", "8"):
         res3[W]["predicted_speedup"] = t1 / res3[W]["slowest_ms"]
         res3_one[W]["predicted_speedup"] = t1 / res3_one[W]["slowest_ms"]
     out["cfg4_gossip_replay"] = dict(res3, verifies=g.rows, messages=g.n, mismatches=bad3, predicted_speedup_8=res3["8"]["predicted_speedup"],
                                      verifies_per_s_predicted_8=g.rows / (res3["8"]["slowest_ms"] * 1e-3), t1_ms=t1,
-                                     split="per message kind: shard k = range k of the announcements + range k of the updates, two asynchronous range calls (one_spans_call_shard_ms: as ONE spans call)",
+                                     split="per message kind: shard k = range k of the announcements + range k of the updates as ONE spans call (two_calls_shard_ms: as two asynchronous range calls)",
                                      one_cut=dict(res3_one, predicted_speedup_8=res3_one["8"]["predicted_speedup"],
                                                   note="one cut over the whole job, balanced by cost (rounds 1-5): the slowest shard is a kind's worst case"))
     del g

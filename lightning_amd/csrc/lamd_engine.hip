@@ -30,8 +30,11 @@ constexpr int MAX_LANES = 8;
 // from LAMD_PRIO (default: see lamd_init): 1 front end (init / lookup / dedupe / classify / partition), 2 cold-row ladder + its key parse,
 // 4 scalar preparation, 8 key-table building, 16 BIP-340 parity stage.
 __device__ u32 g_prio;
+// Default 13 = front end + scalar preparation + key tables (round 6, profiles/r06_strong_scaling.txt session ac: a 1/8 gossip shard 3.48 against 3.65 ms --
+// the 30 waves of 1 875 node keys' doubling chains no longer wait their turn behind three ladder waves per SIMD -- and the headline loop +0.5 %; rounds 4-5
+// ran with 0: there the mask cost the chained loop 1-9 %, before the front end was fused).
 #ifndef LAMD_PRIO_DEFAULT
-#define LAMD_PRIO_DEFAULT 0
+#define LAMD_PRIO_DEFAULT 13
 #endif
 #define LAMD_PRIO(bit)                                     \
   do {                                                     \
