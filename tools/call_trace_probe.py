@@ -104,16 +104,21 @@ elif mode == "storm":
             return r
         return w
     eng.queue_ecdsa_batch, eng.queue_schnorr_batch = timed("queue", real[0]), timed("queue", real[1])
+    eng.queue_ecdsa_batch_inplace, eng.queue_schnorr_batch_inplace = timed("queue", eng.queue_ecdsa_batch_inplace), timed("queue", eng.queue_schnorr_batch_inplace)
     eng.flush, eng.wait = timed("flush", real[2]), timed("wait", real[3])
     depth = min(8, eng.info()["queue_sets"] - 1)
+    INPLACE = os.environ.get("PROBE_INPLACE", "0") == "1" and bench.pin_storm(eng, st)     # rows queued where they are (pinned columns)
+    GRP = int(os.environ.get("PROBE_GROUP", "256"))
+    _ss = bench.stream_shard
+    bench.stream_shard = lambda e, s_, b_, k, g_, d, f=0: _ss(e, s_, b_, k, GRP * per, d, f, inplace=INPLACE)
     for _ in range(3):
-        bench.stream_shard(eng, st, bb, 0, 256 * per, depth)
+        bench.stream_shard(eng, st, bb, 0, 256 * per, depth, bench.storm_first_flush(per))
     marker(8)
     for r in range(R):
         for k in tq:
             tq[k] = 0.0
         t = time.perf_counter()
-        got = bench.stream_shard(eng, st, bb, 0, 256 * per, depth)
+        got = bench.stream_shard(eng, st, bb, 0, 256 * per, depth, bench.storm_first_flush(per))
         dt = time.perf_counter() - t
         bad = sum(int((got[kind].astype(bool) != st[kind].expect[int(bb[kind][0]):int(bb[kind][1])]).sum()) for kind in got)
         print("storm shard 0 of 8: %.3f ms host wall (queue_*_batch %.3f, flush %.3f, wait %.3f ms), mismatches %d" % (dt * 1e3, tq["queue"] * 1e3, tq["flush"] * 1e3, tq["wait"] * 1e3, bad))
