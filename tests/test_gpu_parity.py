@@ -653,7 +653,9 @@ def test_single_lane_mode_matches(orc):
                                  {"LAMD_COPY_EVENTS": "3", "LAMD_COPY_ONE": "0"}, {"LAMD_COPY_EVENTS": "1", "LAMD_COPY_ONE": "0"}, {"LAMD_COPY_EVENTS": "2"},
                                  {"LAMD_COPY_STREAMS": "2"}, {"LAMD_COPY_EVENTS": "1", "LAMD_COPY_ONE": "1", "LAMD_COPY_STREAMS": "3"},
                                  # ... and calls cut into chunks that alternate between a lane and its peer (lamd_set_chunk_rows does the same at run time)
-                                 {"LAMD_CHUNK_ROWS": "20000"}])
+                                 {"LAMD_CHUNK_ROWS": "20000"},
+                                 # round 6: the cold rows listed by k_partition again (after the table kernels), no wave priorities, every priority, the ladder on its own stream beside the early list
+                                 {"LAMD_EARLY_COLD": "0"}, {"LAMD_PRIO": "0"}, {"LAMD_PRIO": "31"}, {"LAMD_EARLY_COLD": "0", "LAMD_PRIO": "0", "LAMD_CACHE": "0"}, {"LAMD_MERGE_SIDE": "0", "LAMD_CACHE": "0"}])
 def test_scheduling_variants_give_the_same_verdicts(orc, env):
     """the round-2 front end (19 launches), the ladder on a stream of its own, chained ecmult launches, flush copies on the lane's prep
     stream, row lists in arrival order instead of grouped by key, the pairs-first ecmult kernel (k_ecmult_keyed_pairs: both comb shapes
