@@ -71,10 +71,20 @@ elif mode == "gossip8":
         calls.append((lo, hi, rb, int(g.rowbase[hi] - g.rowbase[lo]), torch.zeros(hi - lo, dtype=torch.int8, device=dev)))
     torch.cuda.synchronize()
 
+    SPANS = os.environ.get("PROBE_SPANS", "0") == "1"      # ... or as ONE spans call over both ranges (the form bench.py runs)
+    if SPANS:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        sp = bench.gossip_spans(g, [(lo, hi) for lo, hi, *_ in calls], dev)
+        torch.cuda.synchronize()
+
     def one():
         t = time.perf_counter()
-        for lo, hi, rb, rows, d_v in calls:
-            eng.sigcheck_gossip_device(hi - lo, g.d_msgs, g.d_off[lo:hi + 1], g.d_ids[lo:hi], rb, rows, d_v)
+        if SPANS:
+            eng.sigcheck_gossip_spans_device(sp[0], g.d_msgs, sp[1], sp[2], sp[3], sp[4], sp[5], sp[6])
+        else:
+            for lo, hi, rb, rows, d_v in calls:
+                eng.sigcheck_gossip_device(hi - lo, g.d_msgs, g.d_off[lo:hi + 1], g.d_ids[lo:hi], rb, rows, d_v)
         eng.synchronize()
         return (time.perf_counter() - t) * 1e3
     for _ in range(eng.info()["lanes"] + 2):
@@ -82,7 +92,8 @@ elif mode == "gossip8":
     marker(10)
     ts = [one() for _ in range(R)]
     marker(11)
-    bad = sum(int((d_v.cpu().numpy() != g.expect[lo:hi]).sum()) for lo, hi, rb, rows, d_v in calls)
+    bad = int((sp[6].cpu().numpy() != np.concatenate([g.expect[lo:hi] for lo, hi, *_ in calls])).sum()) if SPANS else \
+        sum(int((d_v.cpu().numpy() != g.expect[lo:hi]).sum()) for lo, hi, rb, rows, d_v in calls)
     print("per-kind 1/8 shard: %s messages, host wall ms %s, mismatches %d" % ([hi - lo for lo, hi, *_ in calls], " ".join("%.3f" % t for t in ts), bad))
 elif mode == "storm":
     # one 1/8 shard of BASELINE configs[4] (1 250 commitments: 937 ECDSA + 313 BIP-340) through the streaming queue as bench.py's strong-scaling sweep
