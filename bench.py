@@ -167,6 +167,35 @@ def write_outputs(details, json_fd, details_path=None):
 
 # ------------------------------------------------------------------------------------------------------------------------------------
 # the machine under the bench: an MI355X through PyTorch-ROCm -- or, for the CPU tests of the multi-rank path, a stand-in module
+def bind_to_gpu_numa_node(torch, local_rank):
+    """The host side of a rank -- the producer that fills the staging sets, the threads the engine starts -- on the CPUs of the NUMA node its GPU hangs on,
+    BEFORE anything is allocated (first touch decides where the workload's host arrays live).  On the two-socket hosts of the pool a process that floats
+    over both sockets got its rows on the far node in about one run of three: the whole-job stream of configs[4] then read 30-33 ms instead of 23-24
+    (profiles/r06_strong_scaling.txt, session ac) and host -> host 0.91 x instead of 0.98 x of the resident rate.  What every RCCL launcher does per rank;
+    LAMD_BENCH_NUMA=0 leaves the affinity alone.  -> {"gpu_node", "cpus", "bound"} for the details file"""
+    info = {"gpu_node": None, "cpus": None, "bound": False}
+    if os.environ.get("LAMD_BENCH_NUMA", "1") == "0":
+        return info
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        info["gpu_node"] = node
+        if node < 0:
+            return info
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) >= 8:           # (a cpuset that leaves the rank fewer CPUs on that node than the baseline's threads: stay where we are)
+            os.sched_setaffinity(0, cpus)
+            info["cpus"], info["bound"] = len(cpus), True
+    except Exception as e:           # no sysfs, no such attribute: the run goes on unbound
+        info["error"] = str(e)[:80]
+    return info
+
+
 class GpuPlatform:
     backend, is_stub = "nccl", False
 
@@ -175,6 +204,7 @@ class GpuPlatform:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: lightning_amd has no CPU fallback")
         torch.cuda.set_device(local_rank)
+        self.numa = bind_to_gpu_numa_node(torch, local_rank)
         from lightning_amd import Engine, workload
         self.torch, self.Engine, self.workload = torch, Engine, workload
         self.device = "cuda:%d" % local_rank
@@ -1238,6 +1268,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["phase_seconds"] = dict(clock.t, total=time.perf_counter() - t_start)
+        out["host_numa"] = getattr(plat, "numa", None)
         write_outputs(out, json_fd, args.details)
         if eng_warm is not None:
             eng_warm.close()
