@@ -292,6 +292,8 @@ int lamd_queue_ecdsa_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *hash3
 int lamd_queue_schnorr_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *msg32, const uint8_t *xonly32, const uint8_t *sig64);
 int lamd_host_register(lamd_ctx *ctx, void *p, size_t bytes);
 int lamd_host_unregister(lamd_ctx *ctx, void *p);
+/* The NUMA node device `device` hangs on (sysfs), -1 when unknown: run the producer threads and allocate the buffers that feed a device there. */
+int lamd_device_numa_node(int device);
 int lamd_flush(lamd_ctx *ctx);
 /* 1 = finished (ok[0..*n) filled, tickets in submission order), 0 = still running, < 0 error */
 int lamd_poll(lamd_ctx *ctx, uint8_t *ok, size_t cap, size_t *n);

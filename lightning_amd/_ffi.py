@@ -84,6 +84,7 @@ SYMBOLS = {
     "lamd_queue_schnorr_batch_inplace": (ctypes.c_int, [ctypes.c_void_p, c_sz, c_u8p, c_u8p, c_u8p]),
     "lamd_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, c_sz]),
     "lamd_host_unregister": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "lamd_device_numa_node": (ctypes.c_int, [ctypes.c_int]),
     "lamd_results_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_results_mark_last": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "lamd_stream_wait_mark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

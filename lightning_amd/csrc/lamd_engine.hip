@@ -3953,6 +3953,23 @@ extern "C" int lamd_host_register(lamd_ctx *ctx, void *p, size_t bytes) {
   }
   return LAMD_OK;
 }
+// The NUMA node a device hangs on (/sys/bus/pci/devices/<domain:bus:device.function>/numa_node), -1 when the platform does not say: where a host puts the
+// threads and buffers that feed that device (lamd_served binds each device's engine thread there; bench.py binds itself).  No context needed.
+extern "C" int lamd_device_numa_node(int device) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (char *c = bdf; *c; c++) *c = (char)tolower((unsigned char)*c);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+  FILE *f = fopen(path.c_str(), "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
 extern "C" int lamd_host_unregister(lamd_ctx *ctx, void *p) {
   if (!ctx || !p) return LAMD_ERR_ARG;
   if (hipSetDevice(ctx->device) != hipSuccess || hipHostUnregister(p) != hipSuccess) {

@@ -2,7 +2,7 @@
 // Protocol and rationale: include/lightning_amd_served.h.  SURVEY.md section 7 "Process model": one channeld per channel
 // (channeld/channeld.c:7019-7129), gossipd, lightningd and plugins are separate single-threaded processes that verify inline.
 //
-//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US] [--copy-flushes]
+//   lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US] [--copy-flushes] [--no-numa]
 //
 // Threads: an acceptor; one reader per connection (blocks in recv, turns a request into a job; a synchronous job it waits for and answers, a
 // flush it hands over and goes on reading); ONE engine thread PER DEVICE, the only caller of that device's context (a context is not
@@ -18,6 +18,7 @@
 // verification code, and tests bind a stub library to run the queueing / merging / scattering on a machine without a GPU.
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -63,6 +64,7 @@ struct engine_api {
   decltype(&lamd_queue_schnorr_batch_inplace) queue_schnorr_inplace = nullptr;
   decltype(&lamd_host_register) host_register = nullptr;
   decltype(&lamd_host_unregister) host_unregister = nullptr;
+  decltype(&lamd_device_numa_node) numa_node = nullptr;   // optional
   decltype(&lamd_flush) flush = nullptr;
   decltype(&lamd_poll) poll = nullptr;
   decltype(&lamd_wait) wait = nullptr;
@@ -115,6 +117,8 @@ struct device {
   std::deque<flight> inflight;
   std::vector<uint8_t> okbuf;
   std::thread th;
+  int numa = -1;          // the NUMA node the device hangs on (-1: unknown / --no-numa): its engine thread and its context's buffers live there
+  cpu_set_t cpus;         // ... that node's CPUs
 };
 
 engine_api E;
@@ -137,6 +141,32 @@ unsigned g_linger_us = 0;
 // engine's staging set first: the copy -- 161 bytes per row, by the one engine thread of the device and its copy helpers -- was a third of the
 // service's time per streamed row (profiles/r06_served_stream.txt).  --copy-flushes switches it off (the A/B, and for a runtime that cannot pin).
 bool g_inplace = true;
+// Every device's engine thread -- and the thread that creates its context, while it does -- runs on the CPUs of the NUMA node the device hangs on: the
+// context's pinned staging sets are first touched there and the launches come from the near socket.  --no-numa leaves the threads where the scheduler puts them.
+bool g_numa = true;
+bool node_cpus(int node, cpu_set_t *out) {
+  char path[96];
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE *f = fopen(path, "r");
+  if (!f) return false;
+  CPU_ZERO(out);
+  int a, b, n = 0;
+  for (;;) {
+    if (fscanf(f, "%d", &a) != 1) break;
+    b = a;
+    int c = fgetc(f);
+    if (c == '-') {
+      if (fscanf(f, "%d", &b) != 1) break;
+      c = fgetc(f);
+    }
+    for (int i = a; i <= b && i < CPU_SETSIZE; i++, n++) CPU_SET(i, out);
+    if (c != ',') break;
+  }
+  fclose(f);
+  cpu_set_t mine;
+  if (sched_getaffinity(0, sizeof mine, &mine) == 0) CPU_AND(out, out, &mine);   // never outside what the process may use
+  return n > 0 && CPU_COUNT(out) > 0;
+}
 const size_t ENGINE_FLUSHES_IN_FLIGHT = 8;
 
 const uint8_t *sec(const job *j, int i) { return j->c->shm[j->slot].p + j->off[i]; }
@@ -584,6 +614,7 @@ void run_round(std::vector<job *> &round) {
 
 void engine_loop(device *dev) {
   D = dev;
+  if (dev->numa >= 0) sched_setaffinity(0, sizeof dev->cpus, &dev->cpus);
   for (;;) {
     std::vector<job *> round, sync, fl;
     {
@@ -772,8 +803,9 @@ int main(int argc, char **argv) {
     else if (a == "--max-flush-rows") g_max_flush_rows = (size_t)atoll(val());
     else if (a == "--linger-us") g_linger_us = (unsigned)atoi(val());
     else if (a == "--copy-flushes") g_inplace = false;
+    else if (a == "--no-numa") g_numa = false;
     else {
-      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US] [--copy-flushes]\n");
+      fprintf(stderr, "usage: lamd_served [--socket PATH] [--device N | --devices A,B,..] [--engine LIB] [--max-merge ROWS] [--max-flush-rows ROWS] [--linger-us US] [--copy-flushes] [--no-numa]\n");
       return 2;
     }
   }
@@ -803,11 +835,22 @@ int main(int argc, char **argv) {
   *(void **)&E.queue_schnorr_inplace = dlsym(E.lib, "lamd_queue_schnorr_batch_inplace");
   *(void **)&E.host_register = dlsym(E.lib, "lamd_host_register");
   *(void **)&E.host_unregister = dlsym(E.lib, "lamd_host_unregister");
+  *(void **)&E.numa_node = dlsym(E.lib, "lamd_device_numa_node");
   memset(&g_stats, 0, sizeof g_stats);
   for (size_t k = 0; k < devices.size(); k++) {
     device *dev = new device;
     dev->id = (int)k;
+    cpu_set_t before;
+    const bool have_before = sched_getaffinity(0, sizeof before, &before) == 0;
+    if (g_numa && E.numa_node) {
+      const int node = E.numa_node(devices[k]);
+      if (node >= 0 && node_cpus(node, &dev->cpus)) {
+        dev->numa = node;
+        sched_setaffinity(0, sizeof dev->cpus, &dev->cpus);   // the context's host buffers are allocated (and first touched) by this thread
+      }
+    }
     const int rc = E.init(&dev->ctx, devices[k]);
+    if (have_before) sched_setaffinity(0, sizeof before, &before);
     if (rc != LAMD_OK) {
       fprintf(stderr, "lamd_served: lamd_init(device %d) failed (%d): %s\n", devices[k], rc, dev->ctx ? E.last_error(dev->ctx) : "no device");
       if (dev->ctx) E.shutdown(dev->ctx);
@@ -846,7 +889,10 @@ int main(int argc, char **argv) {
   for (device *d : g_dev) d->th = std::thread(engine_loop, d);
   std::string devs;
   for (size_t k = 0; k < devices.size(); k++) devs += (k ? "," : "") + std::to_string(devices[k]);
-  printf("lamd_served: ready on %s (device %s, engine %s)\n", sock.c_str(), devs.c_str(), engine.c_str());
+  std::string numa_note;
+  for (size_t k = 0; k < g_dev.size(); k++)
+    if (g_dev[k]->numa >= 0) numa_note += (numa_note.empty() ? "; " : ", ") + std::string("device ") + std::to_string(devices[k]) + " on NUMA node " + std::to_string(g_dev[k]->numa);
+  printf("lamd_served: ready on %s (device %s, engine %s%s)\n", sock.c_str(), devs.c_str(), engine.c_str(), numa_note.c_str());
   fflush(stdout);
   std::vector<std::thread> readers;
   while (!g_quit.load()) {

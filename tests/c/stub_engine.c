@@ -200,6 +200,7 @@ int lamd_queue_ecdsa_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *h, co
 int lamd_queue_schnorr_batch_inplace(lamd_ctx *ctx, size_t n, const uint8_t *m, const uint8_t *x, const uint8_t *s) {
 	return push_late(ctx, n, m, x, s, 32, 32, 64, 0);
 }
+int lamd_device_numa_node(int device) { return device == 2 ? -1 : 0; }   /* (device 2: a platform that does not say) */
 int lamd_flush(lamd_ctx *ctx) {
 	if (!g_open.n) return LAMD_OK;
 	if (g_count == STUB_SETS) { strcpy(ctx->err, "stub: too many flushes outstanding"); return LAMD_ERR_STATE; }

@@ -68,6 +68,7 @@ def _start(sock, engine=None, extra=()):
     if "ready" not in line:
         p.kill()
         raise RuntimeError("lamd_served did not start: %r %r" % (line, p.stderr.read()))
+    p.ready_line = line
     return p
 
 
@@ -321,6 +322,12 @@ def test_streaming_flushes_keep_their_order_and_their_rows(stub):
     so, d = stub
     sock = os.path.join(d, "s.sock")
     p = _start(sock, so, ["--devices", "0,1,2"])
+    # every device's engine thread lives on the NUMA node its device hangs on, where the engine library knows it (the stub: node 0 for devices 0 and 1,
+    # unknown for device 2); --no-numa leaves the threads alone
+    assert "device 0 on NUMA node 0, device 1 on NUMA node 0" in p.ready_line and "device 2 on NUMA" not in p.ready_line, p.ready_line
+    q = _start(sock + ".nn", so, ["--devices", "0,1", "--no-numa"])
+    assert "NUMA" not in q.ready_line
+    _stop(q)
     try:
         L = _client()
         rc, ctx = _connect(L, sock)
@@ -685,8 +692,8 @@ def test_eight_client_processes_stream_their_commitments_through_the_service(tmp
     """VERDICT r05 "next" 8: BASELINE configs[4] as channelds see it -- 8 client processes, each STREAMING its channels' commitments (flushes kept in
     flight: lamd_queue_*_batch / lamd_flush / lamd_wait of the client library) through ONE lamd_served.  Every verdict equals construction (= the
     in-process engine's, checked on the same rows), and the rate of the whole job is compared with the same job streamed by one in-process
-    producer (the ratio lands in gpurun_out/served_stream.json: median 0.75 (0.54-1.01 over ten runs) with the flush rows queued in place from the clients' pinned blocks, 0.63
-    with --copy-flushes, profiles/r06_served_stream.txt; asserted >= 0.4 -- the box's host cores decide the rest)."""
+    producer (the ratio lands in gpurun_out/served_stream.json: median 0.84 with the flush rows queued in place from the clients' pinned blocks and the engine threads on their GPU's NUMA node (0.74 with
+    --no-numa, 0.63 with --copy-flushes), profiles/r06_served_stream.txt; asserted >= 0.4 -- the box's host cores decide the rest)."""
     import json
     import torch
     from lightning_amd import Engine, workload
