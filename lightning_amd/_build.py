@@ -28,7 +28,7 @@ EXTRA = os.environ.get("LAMD_BUILD_FLAGS", "").split()
 ENGINE_TUS = [
     ("lamd_engine.hip", _H("verify_core.h", "group.h", "fe.h", "fe_asm.inc", "fuzz.h", "scalar.h", "sha256.h", "lamd_common.h", "bolt12.h") +
      _I("lightning_amd.h", "lightning_amd_debug.h"), HIPFLAGS + EXTRA),
-    ("lamd_multi.cpp", _I("lightning_amd.h", "lightning_amd_debug.h"), ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall"]),
+    ("lamd_multi.cpp", _H("numa_cpus.h") + _I("lightning_amd.h", "lightning_amd_debug.h"), ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall"]),
 ]
 SOURCES = sorted({os.path.join(CSRC, tu[0]) for tu in ENGINE_TUS} | {h for tu in ENGINE_TUS for h in tu[1]})
 
@@ -106,7 +106,7 @@ def build_testgen(force=False):
 SERVED = os.path.join(PKG, "lamd_served")
 CLIENT = os.path.join(PKG, "liblightning_amd_client.so")
 SHIM_CLIENT = os.path.join(PKG, "liblightning_amd_cln_client.so")
-SERVED_SOURCES = _H("lamd_served.cpp", "served_common.h") + _I("lightning_amd_served.h", "lightning_amd.h")
+SERVED_SOURCES = _H("lamd_served.cpp", "served_common.h", "numa_cpus.h") + _I("lightning_amd_served.h", "lightning_amd.h")
 CLIENT_SOURCES = _H("lamd_client.cpp", "served_common.h") + _I("lightning_amd_served.h", "lightning_amd.h")
 
 

@@ -26,6 +26,7 @@
 
 #include "../../include/lightning_amd.h"
 #include "../../include/lightning_amd_debug.h"
+#include "numa_cpus.h"
 
 namespace {
 
@@ -344,7 +345,24 @@ extern "C" int lamd_multi_init_backend(lamd_multi **out, const int *devices, int
   m->buf.assign(n_devices, devbufs());
   if (const char *e = getenv("LAMD_MULTI_CHUNK")) m->chunk_rows = (size_t)atoll(e) < 64 ? 64 : (size_t)atoll(e);
   int rc = LAMD_OK;
-  for (int i = 0; i < n_devices && rc == LAMD_OK; i++) rc = m->be.dev_open(m->be.user, m->devices[i], &m->handle[i]);
+  // With the real engine behind it, device i's context is created and its worker thread runs on the CPUs of the NUMA node the device hangs on
+  // (lamd_device_numa_node; LAMD_MULTI_NUMA=0 leaves the threads where the scheduler puts them): the worker copies the caller's rows to its device.
+  std::vector<int> node(n_devices, -1);
+  std::vector<cpu_set_t> cpus(n_devices);
+  const bool numa = m->be.user == &m->eng && !(getenv("LAMD_MULTI_NUMA") && atoi(getenv("LAMD_MULTI_NUMA")) == 0);
+  cpu_set_t before;
+  const bool have_before = sched_getaffinity(0, sizeof before, &before) == 0;
+  for (int i = 0; i < n_devices && rc == LAMD_OK; i++) {
+    if (numa) {
+      const int nd = lamd_device_numa_node(m->devices[i]);
+      if (nd >= 0 && lamd_node_cpus(nd, &cpus[i])) {
+        node[i] = nd;
+        sched_setaffinity(0, sizeof cpus[i], &cpus[i]);
+      }
+    }
+    rc = m->be.dev_open(m->be.user, m->devices[i], &m->handle[i]);
+    if (numa && have_before) sched_setaffinity(0, sizeof before, &before);
+  }
   if (rc == LAMD_OK) rc = m->be.gather_open(m->be.user, m->handle.data(), n_devices);
   if (rc != LAMD_OK) {
     *out = m;  // so that lamd_multi_last_error() can say why; the caller still calls lamd_multi_shutdown()
@@ -353,7 +371,12 @@ extern "C" int lamd_multi_init_backend(lamd_multi **out, const int *devices, int
   }
   for (int i = 0; i < n_devices; i++) {
     worker *wk = new worker;
-    wk->th = std::thread([wk] { wk->loop(); });
+    const bool bind = node[i] >= 0;
+    const cpu_set_t where = cpus[i];
+    wk->th = std::thread([wk, bind, where] {
+      if (bind) sched_setaffinity(0, sizeof where, &where);
+      wk->loop();
+    });
     m->w.push_back(wk);
   }
   *out = m;

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/lightning_amd.h"
+#include "numa_cpus.h"
 #include "served_common.h"
 
 using namespace lamd_srv;
@@ -144,29 +145,6 @@ bool g_inplace = true;
 // Every device's engine thread -- and the thread that creates its context, while it does -- runs on the CPUs of the NUMA node the device hangs on: the
 // context's pinned staging sets are first touched there and the launches come from the near socket.  --no-numa leaves the threads where the scheduler puts them.
 bool g_numa = true;
-bool node_cpus(int node, cpu_set_t *out) {
-  char path[96];
-  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-  FILE *f = fopen(path, "r");
-  if (!f) return false;
-  CPU_ZERO(out);
-  int a, b, n = 0;
-  for (;;) {
-    if (fscanf(f, "%d", &a) != 1) break;
-    b = a;
-    int c = fgetc(f);
-    if (c == '-') {
-      if (fscanf(f, "%d", &b) != 1) break;
-      c = fgetc(f);
-    }
-    for (int i = a; i <= b && i < CPU_SETSIZE; i++, n++) CPU_SET(i, out);
-    if (c != ',') break;
-  }
-  fclose(f);
-  cpu_set_t mine;
-  if (sched_getaffinity(0, sizeof mine, &mine) == 0) CPU_AND(out, out, &mine);   // never outside what the process may use
-  return n > 0 && CPU_COUNT(out) > 0;
-}
 const size_t ENGINE_FLUSHES_IN_FLIGHT = 8;
 
 const uint8_t *sec(const job *j, int i) { return j->c->shm[j->slot].p + j->off[i]; }
@@ -844,7 +822,7 @@ int main(int argc, char **argv) {
     const bool have_before = sched_getaffinity(0, sizeof before, &before) == 0;
     if (g_numa && E.numa_node) {
       const int node = E.numa_node(devices[k]);
-      if (node >= 0 && node_cpus(node, &dev->cpus)) {
+      if (node >= 0 && lamd_node_cpus(node, &dev->cpus)) {
         dev->numa = node;
         sched_setaffinity(0, sizeof dev->cpus, &dev->cpus);   // the context's host buffers are allocated (and first touched) by this thread
       }
